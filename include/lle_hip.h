@@ -1,0 +1,210 @@
+/*
+ * lle_hip.h -- C ABI of lle_amd: a batched, MI355X-native replacement for the `World.step()` hot path of
+ * yamoling/lle (reset / step / available_actions / get_state / set_state / layered observation).
+ *
+ * The reference's boundary for this path is the PyO3 class `lle.world.World`
+ * (src/bindings/world/pyworld.rs:42-76) over the Rust `lle::World` (src/core/world.rs:21-44).  This header is what
+ * a host in any language (the Python package in lle_amd/, a Rust `extern "C"` block, cgo ...) binds instead:
+ * plain pointers and sizes, no torch types.  Each entry point cites the reference interface it replaces.
+ *
+ * Threading: a batch handle is NOT thread-safe (the reference serialises through a Mutex, pyworld.rs:69-82);
+ * distinct handles are independent.  All device work of a call is enqueued on the `stream` argument
+ * (a hipStream_t passed as void*; NULL = the default stream) and is asynchronous unless stated otherwise.
+ *
+ * Value codes (identical to the reference):
+ *   actions  NORTH=0 SOUTH=1 EAST=2 WEST=3 STAY=4            (src/bindings/world/pyaction.rs:13-25)
+ *   events   AGENT_EXIT=0 GEM_COLLECTED=1 AGENT_DIED=2        (src/bindings/world/pyevent.rs:9-16)
+ *   direction NORTH=0 EAST=1 SOUTH=2 WEST=3                   (src/core/tiles/direction.rs:8-18)
+ *   positions are (i, j) = (row, column)                       (src/bindings/world/pyposition.rs:3-9)
+ */
+#ifndef LLE_HIP_H
+#define LLE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LLE_ABI_VERSION 1
+
+/* static limits of this implementation (maps beyond them are rejected at parse/compile time) */
+#define LLE_MAX_AGENTS 16
+#define LLE_MAX_SOURCES 32
+#define LLE_MAX_GEMS 32
+#define LLE_MAX_BEAM_LEN 32
+#define LLE_MAX_DIM 255
+
+typedef struct lle_map lle_map;     /* a parsed + compiled map (host object; no GPU needed) */
+typedef struct lle_batch lle_batch; /* n_envs lock-stepped worlds of one map, resident on one GPU */
+
+/* ---- status codes of the C functions (whole-call errors) */
+enum {
+    LLE_OK = 0,
+    LLE_ERR_NULL = -1,        /* NULL handle / pointer */
+    LLE_ERR_ARG = -2,         /* bad argument (arity, range) */
+    LLE_ERR_HIP = -3,         /* a HIP runtime call failed; see lle_last_error() */
+    LLE_ERR_UNSUPPORTED = -4, /* map exceeds a static limit of the kernels (LDS footprint, layers ...) */
+    LLE_ERR_NO_DEVICE = -5,   /* no HIP device: the product has NO CPU fallback */
+    LLE_ERR_ARENA = -6        /* caller-provided arena too small or misaligned */
+};
+
+/* ---- parse errors: the v1-map subset of `ParseError` (src/core/parsing/errors.rs:5-74) */
+enum {
+    LLE_PARSE_OK = 0,
+    LLE_PARSE_EMPTY_WORLD = 1,
+    LLE_PARSE_NO_AGENTS = 2,
+    LLE_PARSE_INVALID_TILE = 3,
+    LLE_PARSE_NOT_ENOUGH_EXIT_TILES = 4,
+    LLE_PARSE_DUPLICATE_START_TILE = 5,
+    LLE_PARSE_INCONSISTENT_DIMENSIONS = 6,
+    LLE_PARSE_INVALID_AGENT_ID = 7,
+    LLE_PARSE_INVALID_DIRECTION = 8,
+    LLE_PARSE_AGENT_WITHOUT_START = 9,
+    LLE_PARSE_NOT_ENOUGH_START_TILES = 10,
+    LLE_PARSE_TOML_UNSUPPORTED = 11, /* TOML (v2) maps are outside the hot-path scope */
+    LLE_PARSE_INVALID_LEVEL = 12,
+    LLE_PARSE_LIMIT = 13             /* valid map, but beyond LLE_MAX_* */
+};
+
+/* ---- per-environment result codes (buffer LLE_BUF_ERR), the batched form of `RuntimeWorldError`
+ * (src/core/errors.rs:6-45).  An env with a non-zero code after `step` is left untouched and emits no
+ * event, like the reference (src/core/world.rs:436-453). */
+enum {
+    LLE_ENV_OK = 0,
+    /* 1..LLE_MAX_AGENTS: InvalidAction by agent (code - 1), lowest offending agent id */
+    LLE_ENV_INVALID_WORLD_STATE = 0x40,
+    LLE_ENV_OUT_OF_WORLD_POSITION = 0x41,
+    LLE_ENV_INVALID_AGENT_POSITION = 0x42
+};
+
+/* ================================================================== maps (host only)
+ * replaces World::try_from(&str) / World::get_level (src/core/world.rs:599-643; pyworld.rs:147-200) */
+
+/* Parse a v1 text map.  Returns NULL and sets *parse_error (LLE_PARSE_*) on failure. */
+lle_map* lle_map_parse(const char* text, size_t len, int* parse_error);
+/* One of the six built-in levels, 1..6 (src/core/levels.rs:1-8). */
+lle_map* lle_map_level(int level, int* parse_error);
+void lle_map_free(lle_map* map);
+
+typedef struct lle_map_info {
+    int32_t height, width, n_agents, n_gems, n_sources;
+    int32_t n_layers;        /* C = 2A + 4 (python/lle/observations.py:204-211) */
+    int32_t n_exits, n_walls, n_voids, n_laser_tiles;
+    int32_t obs_bytes;       /* C*H*W int8 */
+    int32_t obs_stride;      /* obs_bytes rounded up to 16 (per-env pitch of LLE_BUF_OBS) */
+    int32_t max_beam_len, max_cell_layers;
+    int32_t obs_supported;   /* 0 if a laser colour addresses a layer >= C (IndexError in the reference) */
+    int32_t table_bytes;     /* size of the device table blob */
+} lle_map_info;
+int lle_map_get_info(const lle_map* map, lle_map_info* out);
+
+/* position lists (World properties start_pos/exit_pos/wall_pos/void_pos/gems positions, pyworld.rs:46-56,394-399) */
+enum { LLE_POS_START = 0, LLE_POS_EXIT = 1, LLE_POS_WALL = 2, LLE_POS_VOID = 3, LLE_POS_GEM = 4 };
+/* Writes up to `cap` (i, j) pairs; returns the total count (or a negative status). */
+int lle_map_positions(const lle_map* map, int which, int32_t* out_ij, int cap);
+
+/* laser sources in laser_id order (World.laser_sources, pyworld.rs:351-362) */
+typedef struct lle_source_info { int32_t i, j, direction, agent_id, enabled, length, laser_id; } lle_source_info;
+int lle_map_sources(const lle_map* map, lle_source_info* out, int cap);
+/* LaserSource.enable/disable/set_agent_id (src/core/tiles/laser_source.rs:37-47).  -1 = leave unchanged.
+ * Only changes the host object: call lle_batch_update_sources() to push it to a live batch. */
+int lle_map_set_source(lle_map* map, int laser_id, int enabled, int agent_id);
+
+/* static description of World.lasers (src/core/world.rs:159-172): per laser position the outer layer and, if
+ * nested, the second one; `offset` indexes the beam mask of `laser_id`. */
+typedef struct lle_laser_tile { int32_t i, j, laser_id, offset, layer; } lle_laser_tile;
+int lle_map_laser_tiles(const lle_map* map, lle_laser_tile* out, int cap);
+
+/* World.world_string (pyworld.rs:212-218): v1 text with the current source colours.  Returns needed size. */
+size_t lle_map_world_string(const lle_map* map, char* buf, size_t cap);
+
+/* ================================================================== batches (device) */
+
+enum {
+    LLE_BUF_POS = 0,   /* u8  [n][A][2]   (i, j) of every agent               World.agents_positions */
+    LLE_BUF_BITS,      /* u64 [n]         alive bits 0-15 | arrived 16-31 | occupant 32-47 */
+    LLE_BUF_GEMS,      /* u32 [n]         bit g = gem g collected (parse order; World.gems) */
+    LLE_BUF_BEAMS,     /* u32 [n][L]      bit k = beam of source l is on at offset k (LaserBeam, laser.rs:15-21) */
+    LLE_BUF_AVAIL,     /* u8  [n][A]      bit a = Action a available (World.available_actions) */
+    LLE_BUF_ACTIONS,   /* u8  [n][A]      joint action taken by the last step (input, or sampled output) */
+    LLE_BUF_ERR,       /* u8  [n]         LLE_ENV_* of the last step / set_state */
+    LLE_BUF_EVCOUNT,   /* u8  [n]         number of events of the last step (bit 7: env was auto-reset first) */
+    LLE_BUF_EVENTS,    /* u8  [n][2A]     entry = type << 4 | agent, in the reference's order */
+    LLE_BUF_DONE,      /* u8  [n]         1 if any agent is dead or all have arrived (LLE.compute_done, env.py:253-254) */
+    LLE_BUF_OBS,       /* i8  [n][obs_stride]  first C*H*W bytes = layered observation (C,H,W) */
+    LLE_BUF_STATS,     /* i64 [n_blocks][8] per-block partial counters (see lle_batch_stats) */
+    LLE_BUF_REQ_POS,   /* u8  [n][A][2]   set_state request */
+    LLE_BUF_REQ_GEMS,  /* u32 [n] */
+    LLE_BUF_REQ_ALIVE, /* u16 [n] */
+    LLE_BUF_COUNT
+};
+
+typedef struct lle_buffer_desc {
+    void* ptr;            /* device pointer */
+    int64_t arena_offset; /* byte offset inside the arena */
+    int64_t bytes;
+    int32_t elem_bytes;
+    int32_t ndim;
+    int64_t shape[3];
+    int64_t stride[3];    /* in elements */
+} lle_buffer_desc;
+
+/* Bytes of device memory a batch needs (so a host can allocate the arena itself, 256-B aligned). */
+int64_t lle_batch_arena_bytes(const lle_map* map, int64_t n_envs);
+
+/* Create n_envs worlds of `map` on HIP device `device_id` and reset them (World::new calls reset, world.rs:82).
+ * arena: caller-owned device memory of >= lle_batch_arena_bytes() bytes, or NULL to let the handle hipMalloc it.
+ * Returns NULL on failure (see lle_last_status()/lle_last_error()).  There is no CPU fallback. */
+lle_batch* lle_batch_create(const lle_map* map, int64_t n_envs, int device_id, void* arena, int64_t arena_bytes,
+                            void* stream);
+void lle_batch_free(lle_batch* b);
+
+int lle_batch_get_buffer(const lle_batch* b, int which, lle_buffer_desc* out);
+int64_t lle_batch_n_envs(const lle_batch* b);
+
+/* World.reset (src/core/world.rs:411-432) for every env, or for envs whose byte in env_mask (device, u8[n]) != 0. */
+int lle_batch_reset(lle_batch* b, const uint8_t* env_mask_dev, void* stream);
+
+/* World.step (src/core/world.rs:435-475) + Layered.observe (python/lle/observations.py:254-266) for every env. */
+enum {
+    LLE_STEP_SAMPLE_ACTIONS = 1, /* ignore `actions`: draw uniformly from each agent's available actions with the
+                                    counter-based sampler of DESIGN.md (seed, env, t, agent); writes LLE_BUF_ACTIONS */
+    LLE_STEP_AUTO_RESET = 2,     /* reset an env at the start of the step when LLE_BUF_DONE says it is over */
+    LLE_STEP_NO_OBS = 4          /* skip the observation write */
+};
+/* actions_dev: device u8 [n][A], or NULL to use LLE_BUF_ACTIONS as already filled by the host. */
+int lle_batch_step(lle_batch* b, const uint8_t* actions_dev, uint32_t flags, uint64_t seed, uint64_t t,
+                   int64_t env_offset, void* stream);
+
+/* World.set_state (src/core/world.rs:515-597) with the reference's semantics (incl. its lossy re-derivation of
+ * beams and its rollback rules) from LLE_BUF_REQ_*; per-env result in LLE_BUF_ERR, events in LLE_BUF_EVENTS. */
+int lle_batch_set_state(lle_batch* b, void* stream);
+
+/* Push the map's current source colours / enabled flags to the device tables and apply
+ * LaserBeam::enable/disable (laser.rs:69-77) to the beam masks of every env; rewrites the observation. */
+int lle_batch_update_sources(lle_batch* b, const lle_map* map, void* stream);
+
+/* Rebuild LLE_BUF_OBS from the current state. */
+int lle_batch_observe(lle_batch* b, void* stream);
+
+/* Sum the per-block counters (synchronises `stream`):
+ * out[0] env_steps, [1] agent_steps, [2] gems, [3] exits, [4] deaths, [5] invalid, [6] auto_resets, [7] reward_sum */
+int lle_batch_stats(lle_batch* b, int64_t out[8], int reset_counters, void* stream);
+
+/* The sampler used by LLE_STEP_SAMPLE_ACTIONS (host copy, for harnesses). */
+uint64_t lle_action_hash(uint64_t seed, uint64_t env, uint64_t t, uint64_t agent);
+
+int lle_abi_version(void);
+int lle_last_status(void);
+const char* lle_last_error(void);
+/* Name + dynamic-LDS bytes + envs-per-wave of the step kernel a batch launches (for profiling reports). */
+int lle_batch_kernel_info(const lle_batch* b, char* name_buf, size_t cap, int32_t* lds_bytes, int32_t* envs_per_wave);
+/* Tuning knob: environments per wavefront in the step kernel (power of two, 1..64). */
+int lle_batch_set_envs_per_wave(lle_batch* b, int envs_per_wave);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LLE_HIP_H */

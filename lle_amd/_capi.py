@@ -1,0 +1,195 @@
+"""ctypes binding of liblle_hip.so (the C ABI of include/lle_hip.h).
+
+This is the binding a reference maintainer would write in place of the PyO3 glue of
+src/bindings/world/pyworld.rs: plain pointers and sizes.  The library is built in-tree by
+`lle_amd.build.build_native()` (hipcc, gfx950).  There is no fallback: if the library is missing the import
+of anything that needs it raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblle_hip.so")
+
+# enum lle_hip.h
+(LLE_BUF_POS, LLE_BUF_BITS, LLE_BUF_GEMS, LLE_BUF_BEAMS, LLE_BUF_AVAIL, LLE_BUF_ACTIONS, LLE_BUF_ERR, LLE_BUF_EVCOUNT,
+ LLE_BUF_EVENTS, LLE_BUF_DONE, LLE_BUF_OBS, LLE_BUF_STATS, LLE_BUF_REQ_POS, LLE_BUF_REQ_GEMS, LLE_BUF_REQ_ALIVE,
+ LLE_BUF_COUNT) = range(16)
+BUFFER_NAMES = ["pos", "bits", "gems", "beams", "avail", "actions", "err", "evcount", "events", "done", "obs", "stats",
+                "req_pos", "req_gems", "req_alive"]
+LLE_POS_START, LLE_POS_EXIT, LLE_POS_WALL, LLE_POS_VOID, LLE_POS_GEM = range(5)
+LLE_STEP_SAMPLE_ACTIONS, LLE_STEP_AUTO_RESET, LLE_STEP_NO_OBS = 1, 2, 4
+LLE_ENV_INVALID_WORLD_STATE, LLE_ENV_OUT_OF_WORLD_POSITION, LLE_ENV_INVALID_AGENT_POSITION = 0x40, 0x41, 0x42
+LLE_ERR_NO_DEVICE = -5
+
+PARSE_ERROR_NAMES = {
+    1: "EmptyWorld", 2: "NoAgents", 3: "InvalidTile", 4: "NotEnoughExitTiles", 5: "DuplicateStartTile",
+    6: "InconsistentDimensions", 7: "InvalidAgentId", 8: "InvalidDirection", 9: "AgentWithoutStart",
+    10: "NotEnoughStartTiles", 11: "TomlUnsupported", 12: "InvalidLevel", 13: "Limit",
+}
+
+EXPORTS = [
+    "lle_abi_version", "lle_last_status", "lle_last_error", "lle_action_hash",
+    "lle_map_parse", "lle_map_level", "lle_map_free", "lle_map_get_info", "lle_map_positions", "lle_map_sources",
+    "lle_map_set_source", "lle_map_laser_tiles", "lle_map_world_string",
+    "lle_batch_arena_bytes", "lle_batch_create", "lle_batch_free", "lle_batch_get_buffer", "lle_batch_n_envs",
+    "lle_batch_reset", "lle_batch_step", "lle_batch_set_state", "lle_batch_update_sources", "lle_batch_observe",
+    "lle_batch_stats", "lle_batch_kernel_info", "lle_batch_set_envs_per_wave",
+]
+
+
+class MapInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "height", "width", "n_agents", "n_gems", "n_sources", "n_layers", "n_exits", "n_walls", "n_voids",
+        "n_laser_tiles", "obs_bytes", "obs_stride", "max_beam_len", "max_cell_layers", "obs_supported", "table_bytes")]
+
+
+class SourceInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("i", "j", "direction", "agent_id", "enabled", "length", "laser_id")]
+
+
+class LaserTile(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("i", "j", "laser_id", "offset", "layer")]
+
+
+class BufferDesc(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("arena_offset", C.c_int64), ("bytes", C.c_int64), ("elem_bytes", C.c_int32),
+                ("ndim", C.c_int32), ("shape", C.c_int64 * 3), ("stride", C.c_int64 * 3)]
+
+
+_lib = None
+
+
+def lib():
+    """Load liblle_hip.so.  torch is imported first when available so that the HIP runtime torch bundles
+    (same SONAME, libamdhip64.so.7) is the single runtime instance of the process."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  lle_amd has no fallback implementation.")
+    try:
+        import torch  # noqa: F401  (loads torch's libamdhip64 first)
+    except Exception:  # pragma: no cover - torch is plumbing, the map functions work without it
+        pass
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, u64, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_uint32
+    L.lle_abi_version.restype = i32
+    L.lle_last_status.restype = i32
+    L.lle_last_error.restype = C.c_char_p
+    L.lle_action_hash.restype = u64
+    L.lle_action_hash.argtypes = [u64, u64, u64, u64]
+    L.lle_map_parse.restype = vp
+    L.lle_map_parse.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
+    L.lle_map_level.restype = vp
+    L.lle_map_level.argtypes = [i32, C.POINTER(C.c_int)]
+    L.lle_map_free.argtypes = [vp]
+    L.lle_map_get_info.restype = i32
+    L.lle_map_get_info.argtypes = [vp, C.POINTER(MapInfo)]
+    L.lle_map_positions.restype = i32
+    L.lle_map_positions.argtypes = [vp, i32, C.POINTER(C.c_int32), i32]
+    L.lle_map_sources.restype = i32
+    L.lle_map_sources.argtypes = [vp, C.POINTER(SourceInfo), i32]
+    L.lle_map_set_source.restype = i32
+    L.lle_map_set_source.argtypes = [vp, i32, i32, i32]
+    L.lle_map_laser_tiles.restype = i32
+    L.lle_map_laser_tiles.argtypes = [vp, C.POINTER(LaserTile), i32]
+    L.lle_map_world_string.restype = C.c_size_t
+    L.lle_map_world_string.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.lle_batch_arena_bytes.restype = i64
+    L.lle_batch_arena_bytes.argtypes = [vp, i64]
+    L.lle_batch_create.restype = vp
+    L.lle_batch_create.argtypes = [vp, i64, i32, vp, i64, vp]
+    L.lle_batch_free.argtypes = [vp]
+    L.lle_batch_get_buffer.restype = i32
+    L.lle_batch_get_buffer.argtypes = [vp, i32, C.POINTER(BufferDesc)]
+    L.lle_batch_n_envs.restype = i64
+    L.lle_batch_n_envs.argtypes = [vp]
+    L.lle_batch_reset.restype = i32
+    L.lle_batch_reset.argtypes = [vp, vp, vp]
+    L.lle_batch_step.restype = i32
+    L.lle_batch_step.argtypes = [vp, vp, u32, u64, u64, i64, vp]
+    L.lle_batch_set_state.restype = i32
+    L.lle_batch_set_state.argtypes = [vp, vp]
+    L.lle_batch_update_sources.restype = i32
+    L.lle_batch_update_sources.argtypes = [vp, vp, vp]
+    L.lle_batch_observe.restype = i32
+    L.lle_batch_observe.argtypes = [vp, vp]
+    L.lle_batch_stats.restype = i32
+    L.lle_batch_stats.argtypes = [vp, C.POINTER(C.c_int64), i32, vp]
+    L.lle_batch_kernel_info.restype = i32
+    L.lle_batch_kernel_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.lle_batch_set_envs_per_wave.restype = i32
+    L.lle_batch_set_envs_per_wave.argtypes = [vp, i32]
+    _lib = L
+    return L
+
+
+class MapParseError(ValueError):
+    """A map could not be parsed/compiled; `.kind` is the reference's ParseError variant name."""
+
+    def __init__(self, code):
+        self.code = code
+        self.kind = PARSE_ERROR_NAMES.get(code, f"ParseError{code}")
+        super().__init__(self.kind)
+
+
+class Map:
+    """Host-side compiled map (lle_map*).  Needs no GPU."""
+
+    def __init__(self, text=None, level=None):
+        L = lib()
+        err = C.c_int(0)
+        if level is not None:
+            self.h = L.lle_map_level(int(level), C.byref(err))
+        else:
+            data = text.encode()
+            self.h = L.lle_map_parse(data, len(data), C.byref(err))
+        if not self.h:
+            raise MapParseError(err.value)
+        self.refresh()
+
+    def refresh(self):
+        info = MapInfo()
+        lib().lle_map_get_info(self.h, C.byref(info))
+        self.info = info
+        for name, _ in MapInfo._fields_:
+            setattr(self, name, int(getattr(info, name)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().lle_map_free(self.h)
+            self.h = None
+
+    def positions(self, which):
+        n = lib().lle_map_positions(self.h, which, None, 0)
+        buf = (C.c_int32 * max(2 * n, 1))()
+        lib().lle_map_positions(self.h, which, buf, n)
+        return [(int(buf[2 * k]), int(buf[2 * k + 1])) for k in range(n)]
+
+    def sources(self):
+        n = lib().lle_map_sources(self.h, None, 0)
+        arr = (SourceInfo * max(n, 1))()
+        lib().lle_map_sources(self.h, arr, n)
+        return [arr[k] for k in range(n)]
+
+    def laser_tiles(self):
+        n = lib().lle_map_laser_tiles(self.h, None, 0)
+        arr = (LaserTile * max(n, 1))()
+        lib().lle_map_laser_tiles(self.h, arr, n)
+        return [arr[k] for k in range(n)]
+
+    def set_source(self, laser_id, enabled=None, agent_id=None):
+        rc = lib().lle_map_set_source(self.h, laser_id, -1 if enabled is None else int(bool(enabled)),
+                                      -1 if agent_id is None else int(agent_id))
+        if rc != 0:
+            raise ValueError(lib().lle_last_error().decode())
+        self.refresh()
+
+    def world_string(self):
+        n = lib().lle_map_world_string(self.h, None, 0)
+        buf = C.create_string_buffer(n)
+        lib().lle_map_world_string(self.h, buf, n)
+        return buf.value.decode()

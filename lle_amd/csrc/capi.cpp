@@ -1,0 +1,392 @@
+// capi.cpp -- the extern "C" boundary declared in include/lle_hip.h.
+//
+// Host side of the batched World: owns the device arena (or adopts a caller-provided one), uploads the
+// compiled map tables and launches the kernels of kernels.hip.  There is no CPU execution path: every
+// dynamic entry point needs a HIP device and fails loudly without one.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/lle_hip.h"
+#include "kernels.h"
+#include "map_compile.hpp"
+#include "step_logic.hpp"
+
+using namespace lle;
+
+struct lle_map { Map m; };
+
+namespace {
+thread_local std::string g_error;
+thread_local int g_status = LLE_OK;
+
+int fail(int status, const std::string& msg) {
+    g_status = status;
+    g_error = msg;
+    return status;
+}
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return fail(LLE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr int64_t ALIGN = 256;
+int64_t align_up(int64_t x) { return (x + ALIGN - 1) / ALIGN * ALIGN; }
+
+struct Layout {
+    int64_t off[LLE_BUF_COUNT];
+    int64_t bytes[LLE_BUF_COUNT];
+    int64_t off_tables;
+    int64_t total;
+    int64_t n_stat_blocks;
+};
+
+Layout make_layout(const MapHeader& h, int64_t n) {
+    Layout l{};
+    const int64_t A = h.A, L = h.L;
+    const int64_t n_pad = (n + 63) / 64 * 64;
+    l.n_stat_blocks = (n + MIN_ENVS_PER_WAVE - 1) / MIN_ENVS_PER_WAVE;
+    int64_t sz[LLE_BUF_COUNT];
+    sz[LLE_BUF_POS] = n_pad * A * 2;
+    sz[LLE_BUF_BITS] = n_pad * 8;
+    sz[LLE_BUF_GEMS] = n_pad * 4;
+    sz[LLE_BUF_BEAMS] = n_pad * (L > 0 ? L : 1) * 4;
+    sz[LLE_BUF_AVAIL] = n_pad * A;
+    sz[LLE_BUF_ACTIONS] = n_pad * A;
+    sz[LLE_BUF_ERR] = n_pad;
+    sz[LLE_BUF_EVCOUNT] = n_pad;
+    sz[LLE_BUF_EVENTS] = n_pad * 2 * A;
+    sz[LLE_BUF_DONE] = n_pad;
+    sz[LLE_BUF_OBS] = n * (int64_t)h.obs_stride;
+    sz[LLE_BUF_STATS] = l.n_stat_blocks * 8 * 8;
+    sz[LLE_BUF_REQ_POS] = n_pad * A * 2;
+    sz[LLE_BUF_REQ_GEMS] = n_pad * 4;
+    sz[LLE_BUF_REQ_ALIVE] = n_pad * 2;
+    int64_t off = 0;
+    l.off_tables = off;
+    off = align_up(off + h.blob_bytes);
+    for (int k = 0; k < LLE_BUF_COUNT; k++) {
+        l.off[k] = off;
+        l.bytes[k] = sz[k];
+        off = align_up(off + sz[k]);
+    }
+    l.total = off;
+    return l;
+}
+}  // namespace
+
+struct lle_batch {
+    MapHeader hdr;
+    int64_t n_envs;
+    int device;
+    uint8_t* arena;
+    bool owns_arena;
+    Layout layout;
+    BatchPtrs ptrs;
+    uint32_t envs_per_wave;
+};
+
+extern "C" {
+
+int lle_abi_version(void) { return LLE_ABI_VERSION; }
+int lle_last_status(void) { return g_status; }
+const char* lle_last_error(void) { return g_error.c_str(); }
+
+uint64_t lle_action_hash(uint64_t seed, uint64_t env, uint64_t t, uint64_t agent) {
+    return action_hash_agent(action_hash_env(seed, env, t), agent);
+}
+
+// ------------------------------------------------------------------------------------------------ maps
+lle_map* lle_map_parse(const char* text, size_t len, int* parse_error) {
+    if (!text) { if (parse_error) *parse_error = LLE_PARSE_EMPTY_WORLD; fail(LLE_ERR_NULL, "text is NULL"); return nullptr; }
+    lle_map* m = new (std::nothrow) lle_map();
+    if (!m) return nullptr;
+    int rc = parse_map(text, len, m->m);
+    if (parse_error) *parse_error = rc;
+    if (rc != LLE_PARSE_OK) { delete m; fail(LLE_ERR_ARG, "map parse error " + std::to_string(rc)); return nullptr; }
+    g_status = LLE_OK;
+    return m;
+}
+
+lle_map* lle_map_level(int level, int* parse_error) {
+    if (level < 1 || level > 6) { if (parse_error) *parse_error = LLE_PARSE_INVALID_LEVEL; fail(LLE_ERR_ARG, "level must be 1..6"); return nullptr; }
+    return lle_map_parse(LEVEL_TEXT[level - 1], std::strlen(LEVEL_TEXT[level - 1]), parse_error);
+}
+
+void lle_map_free(lle_map* map) { delete map; }
+
+int lle_map_get_info(const lle_map* map, lle_map_info* out) {
+    if (!map || !out) return fail(LLE_ERR_NULL, "NULL argument");
+    const Map& m = map->m;
+    out->height = m.H; out->width = m.W; out->n_agents = m.n_agents(); out->n_gems = (int)m.gems.size();
+    out->n_sources = (int)m.sources.size(); out->n_layers = m.n_layers();
+    out->n_exits = (int)m.exits.size(); out->n_walls = (int)m.walls.size(); out->n_voids = (int)m.voids.size();
+    out->n_laser_tiles = m.n_laser_tiles();
+    out->obs_bytes = (int)m.header.obs_bytes; out->obs_stride = (int)m.header.obs_stride;
+    int mb = 0;
+    for (auto& s : m.sources) mb = std::max(mb, (int)s.beam.size());
+    out->max_beam_len = mb; out->max_cell_layers = (int)m.header.max_layers;
+    out->obs_supported = (int)m.header.obs_supported; out->table_bytes = (int)m.header.blob_bytes;
+    return LLE_OK;
+}
+
+int lle_map_positions(const lle_map* map, int which, int32_t* out_ij, int cap) {
+    if (!map) return fail(LLE_ERR_NULL, "NULL map");
+    const Map& m = map->m;
+    std::vector<Pos> tmp;
+    const std::vector<Pos>* v = nullptr;
+    switch (which) {
+        case LLE_POS_START: for (auto& s : m.starts) tmp.push_back(s[0]); v = &tmp; break;
+        case LLE_POS_EXIT: v = &m.exits; break;
+        case LLE_POS_WALL: v = &m.walls; break;
+        case LLE_POS_VOID: v = &m.voids; break;
+        case LLE_POS_GEM: v = &m.gems; break;
+        default: return fail(LLE_ERR_ARG, "unknown position list");
+    }
+    for (int k = 0; k < (int)v->size() && k < cap && out_ij; k++) { out_ij[2 * k] = (*v)[k].i; out_ij[2 * k + 1] = (*v)[k].j; }
+    return (int)v->size();
+}
+
+int lle_map_sources(const lle_map* map, lle_source_info* out, int cap) {
+    if (!map) return fail(LLE_ERR_NULL, "NULL map");
+    const Map& m = map->m;
+    for (int k = 0; k < (int)m.sources.size() && k < cap && out; k++) {
+        const Source& s = m.sources[k];
+        out[k] = lle_source_info{s.pos.i, s.pos.j, s.direction, s.agent_id, s.enabled ? 1 : 0, (int)s.beam.size(), s.laser_id};
+    }
+    return (int)m.sources.size();
+}
+
+int lle_map_set_source(lle_map* map, int laser_id, int enabled, int agent_id) {
+    if (!map) return fail(LLE_ERR_NULL, "NULL map");
+    Map& m = map->m;
+    if (laser_id < 0 || laser_id >= (int)m.sources.size()) return fail(LLE_ERR_ARG, "laser_id out of range");
+    if (enabled >= 0) m.sources[laser_id].enabled = enabled != 0;
+    if (agent_id >= 0) m.sources[laser_id].agent_id = agent_id;
+    m.compile();
+    return LLE_OK;
+}
+
+int lle_map_laser_tiles(const lle_map* map, lle_laser_tile* out, int cap) {
+    if (!map) return fail(LLE_ERR_NULL, "NULL map");
+    const Map& m = map->m;
+    int n = 0;
+    for (int c = 0; c < m.H * m.W; c++) {
+        const auto& layers = m.cell_layers[c];
+        for (int k = 0; k < (int)layers.size() && k < 2; k++) {
+            if (out && n < cap) out[n] = lle_laser_tile{c / m.W, c % m.W, layers[k].laser_id, layers[k].offset, k};
+            n++;
+        }
+    }
+    return n;
+}
+
+size_t lle_map_world_string(const lle_map* map, char* buf, size_t cap) {
+    if (!map) return 0;
+    std::string s = map->m.world_string();
+    if (buf && cap > 0) {
+        size_t n = std::min(cap - 1, s.size());
+        std::memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    }
+    return s.size() + 1;
+}
+
+// ------------------------------------------------------------------------------------------------ batches
+int64_t lle_batch_arena_bytes(const lle_map* map, int64_t n_envs) {
+    if (!map || n_envs <= 0) return fail(LLE_ERR_ARG, "bad arguments");
+    return make_layout(map->m.header, n_envs).total;
+}
+
+static void bind_ptrs(lle_batch* b) {
+    uint8_t* base = b->arena;
+    const Layout& l = b->layout;
+    BatchPtrs& p = b->ptrs;
+    p.tables = base + l.off_tables;
+    p.pos = reinterpret_cast<uint16_t*>(base + l.off[LLE_BUF_POS]);
+    p.bits = reinterpret_cast<uint64_t*>(base + l.off[LLE_BUF_BITS]);
+    p.gems = reinterpret_cast<uint32_t*>(base + l.off[LLE_BUF_GEMS]);
+    p.beams = reinterpret_cast<uint32_t*>(base + l.off[LLE_BUF_BEAMS]);
+    p.avail = base + l.off[LLE_BUF_AVAIL];
+    p.actions = base + l.off[LLE_BUF_ACTIONS];
+    p.err = base + l.off[LLE_BUF_ERR];
+    p.evcount = base + l.off[LLE_BUF_EVCOUNT];
+    p.events = base + l.off[LLE_BUF_EVENTS];
+    p.done = base + l.off[LLE_BUF_DONE];
+    p.obs = reinterpret_cast<int8_t*>(base + l.off[LLE_BUF_OBS]);
+    p.stats = reinterpret_cast<int64_t*>(base + l.off[LLE_BUF_STATS]);
+    p.req_pos = reinterpret_cast<const uint16_t*>(base + l.off[LLE_BUF_REQ_POS]);
+    p.req_gems = reinterpret_cast<const uint32_t*>(base + l.off[LLE_BUF_REQ_GEMS]);
+    p.req_alive = reinterpret_cast<const uint16_t*>(base + l.off[LLE_BUF_REQ_ALIVE]);
+    p.n_envs = b->n_envs;
+}
+
+static int launch(lle_batch* b, int mode, LaunchArgs K, void* stream) {
+    K.envs_per_wave = b->envs_per_wave;
+    HIP_TRY(launch_world_kernel(mode, b->hdr, b->ptrs, K, (hipStream_t)stream));
+    g_status = LLE_OK;
+    return LLE_OK;
+}
+
+static int create_impl(lle_batch* b, const lle_map* map, void* arena, int64_t arena_bytes, void* stream) {
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return fail(LLE_ERR_NO_DEVICE, "no HIP device: lle_amd has no CPU execution path");
+    if (b->device < 0 || b->device >= n_dev) return fail(LLE_ERR_ARG, "device_id out of range");
+    HIP_TRY(hipSetDevice(b->device));
+    const uint32_t lds = kernel_lds_bytes(b->hdr);
+    if (lds > 64 * 1024) return fail(LLE_ERR_UNSUPPORTED, "map tables need " + std::to_string(lds) + " B of LDS per wave (> 64 KiB)");
+    b->layout = make_layout(b->hdr, b->n_envs);
+    if (arena) {
+        if (arena_bytes < b->layout.total || (reinterpret_cast<uintptr_t>(arena) % ALIGN) != 0)
+            return fail(LLE_ERR_ARENA, "arena too small or not 256-byte aligned");
+        b->arena = static_cast<uint8_t*>(arena);
+        b->owns_arena = false;
+    } else {
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, (size_t)b->layout.total));
+        b->arena = static_cast<uint8_t*>(p);
+        b->owns_arena = true;
+    }
+    bind_ptrs(b);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(b->arena, 0, (size_t)b->layout.off[LLE_BUF_OBS], st));
+    HIP_TRY(hipMemsetAsync(b->arena + b->layout.off[LLE_BUF_STATS], 0,
+                           (size_t)(b->layout.total - b->layout.off[LLE_BUF_STATS]), st));
+    HIP_TRY(hipMemcpyAsync(b->arena + b->layout.off_tables, map->m.blob.data(), map->m.blob.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));  // the blob is a host vector: make the copy complete before returning
+    LaunchArgs K{};
+    return launch(b, KMODE_RESET, K, stream);
+}
+
+lle_batch* lle_batch_create(const lle_map* map, int64_t n_envs, int device_id, void* arena, int64_t arena_bytes, void* stream) {
+    if (!map) { fail(LLE_ERR_NULL, "NULL map"); return nullptr; }
+    if (n_envs <= 0) { fail(LLE_ERR_ARG, "n_envs must be positive"); return nullptr; }
+    lle_batch* b = new (std::nothrow) lle_batch();
+    if (!b) return nullptr;
+    b->hdr = map->m.header;
+    b->n_envs = n_envs;
+    b->device = device_id;
+    b->arena = nullptr;
+    b->owns_arena = false;
+    b->envs_per_wave = 64;
+    if (create_impl(b, map, arena, arena_bytes, stream) != LLE_OK) {
+        if (b->owns_arena && b->arena) (void)hipFree(b->arena);
+        delete b;
+        return nullptr;
+    }
+    return b;
+}
+
+void lle_batch_free(lle_batch* b) {
+    if (!b) return;
+    if (b->owns_arena && b->arena) (void)hipFree(b->arena);
+    delete b;
+}
+
+int64_t lle_batch_n_envs(const lle_batch* b) { return b ? b->n_envs : 0; }
+
+int lle_batch_get_buffer(const lle_batch* b, int which, lle_buffer_desc* out) {
+    if (!b || !out) return fail(LLE_ERR_NULL, "NULL argument");
+    if (which < 0 || which >= LLE_BUF_COUNT) return fail(LLE_ERR_ARG, "unknown buffer");
+    const int64_t n = b->n_envs, A = b->hdr.A, L = b->hdr.L;
+    lle_buffer_desc d{};
+    d.ptr = b->arena + b->layout.off[which];
+    d.arena_offset = b->layout.off[which];
+    d.bytes = b->layout.bytes[which];
+    auto set = [&](int elem, int ndim, int64_t s0, int64_t s1, int64_t s2, int64_t t0, int64_t t1, int64_t t2) {
+        d.elem_bytes = elem; d.ndim = ndim;
+        d.shape[0] = s0; d.shape[1] = s1; d.shape[2] = s2;
+        d.stride[0] = t0; d.stride[1] = t1; d.stride[2] = t2;
+    };
+    switch (which) {
+        case LLE_BUF_POS: case LLE_BUF_REQ_POS: set(1, 3, n, A, 2, 2 * A, 2, 1); break;
+        case LLE_BUF_BITS: set(8, 1, n, 1, 1, 1, 1, 1); break;
+        case LLE_BUF_GEMS: case LLE_BUF_REQ_GEMS: set(4, 1, n, 1, 1, 1, 1, 1); break;
+        case LLE_BUF_BEAMS: set(4, 2, n, L, 1, L, 1, 1); break;
+        case LLE_BUF_AVAIL: case LLE_BUF_ACTIONS: set(1, 2, n, A, 1, A, 1, 1); break;
+        case LLE_BUF_ERR: case LLE_BUF_EVCOUNT: case LLE_BUF_DONE: set(1, 1, n, 1, 1, 1, 1, 1); break;
+        case LLE_BUF_EVENTS: set(1, 2, n, 2 * A, 1, 2 * A, 1, 1); break;
+        case LLE_BUF_OBS: set(1, 2, n, b->hdr.obs_bytes, 1, b->hdr.obs_stride, 1, 1); break;
+        case LLE_BUF_STATS: set(8, 2, b->layout.n_stat_blocks, 8, 1, 8, 1, 1); break;
+        case LLE_BUF_REQ_ALIVE: set(2, 1, n, 1, 1, 1, 1, 1); break;
+    }
+    *out = d;
+    return LLE_OK;
+}
+
+int lle_batch_reset(lle_batch* b, const uint8_t* env_mask_dev, void* stream) {
+    if (!b) return fail(LLE_ERR_NULL, "NULL batch");
+    LaunchArgs K{};
+    K.env_mask = env_mask_dev;
+    return launch(b, KMODE_RESET, K, stream);
+}
+
+int lle_batch_step(lle_batch* b, const uint8_t* actions_dev, uint32_t flags, uint64_t seed, uint64_t t, int64_t env_offset,
+                   void* stream) {
+    if (!b) return fail(LLE_ERR_NULL, "NULL batch");
+    LaunchArgs K{};
+    K.flags = flags; K.seed = seed; K.t = t; K.env_offset = env_offset; K.actions_in = actions_dev;
+    return launch(b, KMODE_STEP, K, stream);
+}
+
+int lle_batch_set_state(lle_batch* b, void* stream) {
+    if (!b) return fail(LLE_ERR_NULL, "NULL batch");
+    LaunchArgs K{};
+    return launch(b, KMODE_SET_STATE, K, stream);
+}
+
+int lle_batch_observe(lle_batch* b, void* stream) {
+    if (!b) return fail(LLE_ERR_NULL, "NULL batch");
+    LaunchArgs K{};
+    return launch(b, KMODE_OBSERVE, K, stream);
+}
+
+int lle_batch_update_sources(lle_batch* b, const lle_map* map, void* stream) {
+    if (!b || !map) return fail(LLE_ERR_NULL, "NULL argument");
+    const MapHeader& nh = map->m.header;
+    if (nh.H != b->hdr.H || nh.W != b->hdr.W || nh.A != b->hdr.A || nh.L != b->hdr.L || nh.blob_bytes != b->hdr.blob_bytes)
+        return fail(LLE_ERR_ARG, "map does not match the batch");
+    HIP_TRY(hipSetDevice(b->device));
+    LaunchArgs K{};
+    K.old_enabled = b->hdr.enabled_mask;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(b->arena + b->layout.off_tables, map->m.blob.data(), map->m.blob.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    b->hdr = nh;
+    return launch(b, KMODE_SOURCES, K, stream);
+}
+
+int lle_batch_stats(lle_batch* b, int64_t out[8], int reset_counters, void* stream) {
+    if (!b || !out) return fail(LLE_ERR_NULL, "NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<int64_t> host((size_t)b->layout.n_stat_blocks * 8);
+    HIP_TRY(hipMemcpyAsync(host.data(), b->ptrs.stats, host.size() * 8, hipMemcpyDeviceToHost, st));
+    if (reset_counters) HIP_TRY(hipMemsetAsync(b->ptrs.stats, 0, host.size() * 8, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int k = 0; k < 8; k++) out[k] = 0;
+    for (size_t i = 0; i < host.size(); i++) out[i & 7] += host[i];
+    return LLE_OK;
+}
+
+int lle_batch_kernel_info(const lle_batch* b, char* name_buf, size_t cap, int32_t* lds_bytes, int32_t* envs_per_wave) {
+    if (!b) return fail(LLE_ERR_NULL, "NULL batch");
+    if (name_buf && cap) std::snprintf(name_buf, cap, "%s", kernel_variant_name(kernel_variant((int)b->hdr.A, (int)b->hdr.L)));
+    if (lds_bytes) *lds_bytes = (int32_t)kernel_lds_bytes(b->hdr);
+    if (envs_per_wave) *envs_per_wave = (int32_t)b->envs_per_wave;
+    return LLE_OK;
+}
+
+int lle_batch_set_envs_per_wave(lle_batch* b, int epw) {
+    if (!b) return fail(LLE_ERR_NULL, "NULL batch");
+    if (epw < (int)MIN_ENVS_PER_WAVE || epw > 64 || (epw & (epw - 1))) return fail(LLE_ERR_ARG, "envs_per_wave must be 8, 16, 32 or 64");
+    b->envs_per_wave = (uint32_t)epw;
+    return LLE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,17 @@
+// kernels.h -- host-visible launch interface of kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "tables.h"
+
+namespace lle {
+
+enum { KMODE_STEP = 0, KMODE_RESET = 1, KMODE_SET_STATE = 2, KMODE_OBSERVE = 3, KMODE_SOURCES = 4 };
+constexpr uint32_t MIN_ENVS_PER_WAVE = 8;
+
+int kernel_variant(int A, int L);
+const char* kernel_variant_name(int variant);
+uint32_t kernel_lds_bytes(const MapHeader& h);
+hipError_t launch_world_kernel(int mode, const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K, hipStream_t stream);
+
+}  // namespace lle

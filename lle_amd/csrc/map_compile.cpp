@@ -1,0 +1,390 @@
+// map_compile.cpp -- see map_compile.hpp.
+#include "map_compile.hpp"
+
+#include <algorithm>
+#include <cctype>
+#include <cstring>
+#include <map>
+
+#include "../../include/lle_hip.h"
+
+namespace lle {
+
+// The six built-in levels (data of the reference's resources/levels/lvl1..6, whitespace-normalised;
+// src/core/levels.rs:1-8).  All are 12 rows x 13 columns.
+const char* const LEVEL_TEXT[6] = {
+    // level 1
+    ". . . . . . . S0 . . . . .\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . . . . G . .\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . X . . . . .\n"
+    ". . . . . . . . . . . . .\n",
+    // level 2
+    ". . . . . . S1 S0 . . . . .\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . . . . G . .\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . X X . . . . .\n"
+    ". . . . . . . . . . . . .\n",
+    // level 3
+    ". . . . . . . S0 S1 . . . .\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . . . . . . .\n"
+    "L0E . . . . . . . . . . . .\n"
+    ". . . . . . . . . . G . .\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . X X . . . .\n"
+    ". . . . . . . . . . . . .\n",
+    // level 4
+    ". . . . . . . S0 S1 . . . .\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . . . . . . .\n"
+    "L0E . . . . . . . . . . . .\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . . . . . . L1W\n"
+    ". . . . . . . . . . G . .\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . X X . . . .\n"
+    ". . . . . . . . . . . . .\n",
+    // level 5
+    "G . L2S . S0 S1 S2 S3 . . . . .\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . . . . . . .\n"
+    "@ @ . . . . . . . . . . .\n"
+    ". . . . . . . @ @ @ @ @ @\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . . . . . . L1W\n"
+    ". . . . . . . @ G . . . .\n"
+    ". G . . . . . @ @ @ @ @ @\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . . . X X . .\n"
+    ". . . . G . . . . X X . G\n",
+    // level 6
+    "G L2S . . S0 S1 S2 S3 . . . . .\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . . . . . . .\n"
+    "@ @ . . . . . . . . . . .\n"
+    "L0E . . . . . . @ @ @ @ @ @\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . . . . . . . . . L1W\n"
+    ". . . . . . . @ . G . . .\n"
+    ". . . . . . . @ @ @ @ @ @\n"
+    ". . . . . . . . . . . . .\n"
+    ". . . . G . . . . . X X .\n"
+    ". . . . . . . . . . X X G\n",
+};
+
+namespace {
+
+const int DIR_DELTA[4][2] = {{-1, 0}, {0, 1}, {1, 0}, {0, -1}};  // N E S W (direction.rs:20-27)
+
+// Rust `str::parse::<usize>()`
+bool parse_usize(const std::string& s, int& out) {
+    size_t k = 0;
+    if (k < s.size() && s[k] == '+') k++;
+    if (k >= s.size()) return false;
+    long v = 0;
+    for (; k < s.size(); k++) {
+        if (!std::isdigit((unsigned char)s[k])) return false;
+        v = v * 10 + (s[k] - '0');
+        if (v > 100000) return false;
+    }
+    out = (int)v;
+    return true;
+}
+
+std::vector<std::string> split_ws(const std::string& line) {
+    std::vector<std::string> out;
+    size_t k = 0;
+    while (k < line.size()) {
+        while (k < line.size() && std::isspace((unsigned char)line[k])) k++;
+        size_t s = k;
+        while (k < line.size() && !std::isspace((unsigned char)line[k])) k++;
+        if (k > s) out.push_back(line.substr(s, k - s));
+    }
+    return out;
+}
+
+}  // namespace
+
+int parse_map(const char* text, size_t len, Map& m) {
+    std::string all(text, len);
+    if (all.find('=') != std::string::npos) return LLE_PARSE_TOML_UNSUPPORTED;
+
+    // ---- tokenise (parser_v1.rs:132-175)
+    struct RawSource { Pos pos; int dir; int agent; };
+    std::vector<RawSource> raw_sources;
+    int height = 0, width = -1;
+    size_t p = 0;
+    while (p <= all.size()) {
+        size_t e = all.find('\n', p);
+        if (e == std::string::npos) e = all.size();
+        std::vector<std::string> toks = split_ws(all.substr(p, e - p));
+        p = e + 1;
+        if (toks.empty()) continue;
+        for (int col = 0; col < (int)toks.size(); col++) {
+            const std::string& t = toks[col];
+            Pos pos{height, col};
+            switch (std::toupper((unsigned char)t[0])) {
+                case '.': break;
+                case 'G': m.gems.push_back(pos); break;
+                case '@': m.walls.push_back(pos); break;
+                case 'X': m.exits.push_back(pos); break;
+                case 'V': m.voids.push_back(pos); break;
+                case 'S': {
+                    int id;
+                    if (!parse_usize(t.substr(1), id)) return LLE_PARSE_INVALID_AGENT_ID;
+                    if (id >= 4096) return LLE_PARSE_LIMIT;
+                    if ((int)m.starts.size() <= id) m.starts.resize(id + 1);
+                    if (!m.starts[id].empty()) return LLE_PARSE_DUPLICATE_START_TILE;
+                    m.starts[id].push_back(pos);
+                    break;
+                }
+                case 'L': {
+                    int dir;
+                    switch (std::tolower((unsigned char)t.back())) {
+                        case 'n': dir = 0; break;
+                        case 'e': dir = 1; break;
+                        case 's': dir = 2; break;
+                        case 'w': dir = 3; break;
+                        default: return LLE_PARSE_INVALID_DIRECTION;  // the reference panics (laser_config.rs:22)
+                    }
+                    int agent;
+                    if (t.size() < 2 || !parse_usize(t.substr(1, t.size() - 2), agent)) return LLE_PARSE_INVALID_AGENT_ID;
+                    raw_sources.push_back({pos, dir, agent});
+                    m.walls.push_back(pos);
+                    break;
+                }
+                default: return LLE_PARSE_INVALID_TILE;
+            }
+        }
+        if (width < 0) width = (int)toks.size();
+        else if (width != (int)toks.size()) return LLE_PARSE_INCONSISTENT_DIMENSIONS;
+        height++;
+    }
+    if (height == 0) return LLE_PARSE_EMPTY_WORLD;
+    m.H = height;
+    m.W = width;
+
+    // ---- pre_validate (world_config.rs:124-147)
+    if (m.starts.empty()) return LLE_PARSE_NO_AGENTS;
+    if (m.exits.size() < m.starts.size()) return LLE_PARSE_NOT_ENOUGH_EXIT_TILES;
+
+    // ---- make_grid (world_config.rs:176-199): later writes win: gems, exits, voids, walls
+    const int HW = m.H * m.W;
+    m.kind.assign(HW, K_FLOOR);
+    for (auto& q : m.gems) m.kind[q.i * m.W + q.j] = K_GEM;
+    for (auto& q : m.exits) m.kind[q.i * m.W + q.j] = K_EXIT;
+    for (auto& q : m.voids) m.kind[q.i * m.W + q.j] = K_VOID;
+    for (auto& q : m.walls) m.kind[q.i * m.W + q.j] = K_WALL;
+    m.gem_index.assign(HW, -1);
+    for (size_t g = 0; g < m.gems.size(); g++) m.gem_index[m.gems[g].i * m.W + m.gems[g].j] = (int)g;
+
+    // ---- laser_setup (world_config.rs:203-250).  Sources in parse order; each beam stops at the first
+    // non-walkable tile (Wall or an already placed LaserSource; later sources are still Walls at this point).
+    m.cell_layers.assign(HW, {});
+    for (size_t s = 0; s < raw_sources.size(); s++) {
+        const RawSource& rs = raw_sources[s];
+        Source src;
+        src.pos = rs.pos; src.direction = rs.dir; src.agent_id = rs.agent; src.enabled = true; src.laser_id = (int)s;
+        int i = rs.pos.i + DIR_DELTA[rs.dir][0], j = rs.pos.j + DIR_DELTA[rs.dir][1];
+        while (i >= 0 && j >= 0 && i < m.H && j < m.W) {
+            uint8_t k = m.kind[i * m.W + j];
+            if (k == K_WALL || k == K_SOURCE) break;
+            src.beam.push_back({i, j});
+            i += DIR_DELTA[rs.dir][0];
+            j += DIR_DELTA[rs.dir][1];
+        }
+        bool is_blocked = false;
+        for (size_t k = 0; k < src.beam.size(); k++) {
+            const Pos bp = src.beam[k];
+            if (src.agent_id < (int)m.starts.size() && m.starts[src.agent_id].size() == 1 && m.starts[src.agent_id][0] == bp)
+                is_blocked = true;
+            // the new Laser wraps whatever is there: it becomes the OUTERMOST layer
+            auto& layers = m.cell_layers[bp.i * m.W + bp.j];
+            layers.insert(layers.begin(), CellLayer{(int)s, (int)k});
+            if (!is_blocked) {
+                for (size_t a = 0; a < m.starts.size(); a++) {
+                    if ((int)a == src.agent_id) continue;
+                    auto& st = m.starts[a];
+                    st.erase(std::remove(st.begin(), st.end(), bp), st.end());
+                }
+            }
+        }
+        m.kind[rs.pos.i * m.W + rs.pos.j] = K_SOURCE;
+        m.sources.push_back(std::move(src));
+    }
+
+    // ---- post_validate (world_config.rs:149-168)
+    size_t total = 0;
+    for (auto& st : m.starts) {
+        if (st.empty()) return LLE_PARSE_AGENT_WITHOUT_START;
+        total += st.size();
+    }
+    if (total < m.starts.size()) return LLE_PARSE_NOT_ENOUGH_START_TILES;
+
+    // ---- static limits of the kernels
+    if (m.H > LLE_MAX_DIM || m.W > LLE_MAX_DIM || m.n_agents() > LLE_MAX_AGENTS || (int)m.gems.size() > LLE_MAX_GEMS ||
+        (int)m.sources.size() > LLE_MAX_SOURCES)
+        return LLE_PARSE_LIMIT;
+    for (auto& s : m.sources)
+        if ((int)s.beam.size() > LLE_MAX_BEAM_LEN) return LLE_PARSE_LIMIT;
+    for (auto& l : m.cell_layers)
+        if ((int)l.size() > MAX_CELL_LAYERS) return LLE_PARSE_LIMIT;  // impossible: one beam per travel direction
+    if ((int64_t)m.n_layers() * HW >= (1 << 20)) return LLE_PARSE_LIMIT;
+
+    m.compile();
+    return LLE_PARSE_OK;
+}
+
+int Map::n_laser_tiles() const {
+    int n = 0;
+    for (auto& l : cell_layers) n += (int)std::min<size_t>(l.size(), 2);
+    return n;
+}
+
+void Map::compile() {
+    const int A = n_agents(), G = (int)gems.size(), L = (int)sources.size(), C = n_layers(), HW = H * W;
+    MapHeader h{};
+    h.magic = MAP_MAGIC;
+    h.H = H; h.W = W; h.A = A; h.G = G; h.L = L; h.C = C; h.HW = HW;
+    h.obs_bytes = (uint32_t)(C * HW);
+    h.obs_stride = (h.obs_bytes + 15u) & ~15u;
+    h.n_chunks = h.obs_stride / 16;
+    h.obs_supported = 1;
+    for (int a = 0; a < A; a++) h.start[a] = (uint16_t)(starts[a][0].i | (starts[a][0].j << 8));
+    for (int g = 0; g < G; g++) {
+        h.gem_cell[g] = (uint16_t)(gems[g].i | (gems[g].j << 8));
+        if (cell_layers[gems[g].i * W + gems[g].j].empty()) h.direct_gems |= 1u << g;
+    }
+    for (int s = 0; s < L; s++) {
+        const Source& src = sources[s];
+        h.beam_len[s] = (uint8_t)src.beam.size();
+        h.beam_full[s] = src.beam.size() >= 32 ? 0xFFFFFFFFu : ((1u << src.beam.size()) - 1u);
+        h.beam_colour[s] = (uint8_t)std::min(src.agent_id, (int)NO_COLOUR);
+        if (src.enabled) h.enabled_mask |= 1u << s;
+    }
+
+    // ---- cell tables
+    std::vector<uint64_t> cell_lay(HW, 0);
+    std::vector<uint32_t> cell_meta(HW, 0);
+    static const int ACT_DELTA[4][2] = {{-1, 0}, {1, 0}, {0, 1}, {0, -1}};  // N S E W (action.rs:18-26)
+    for (int i = 0; i < H; i++)
+        for (int j = 0; j < W; j++) {
+            const int c = i * W + j;
+            const auto& layers = cell_layers[c];
+            h.max_layers = std::max<uint32_t>(h.max_layers, (uint32_t)layers.size());
+            uint64_t lay = 0;
+            for (size_t k = 0; k < layers.size(); k++) {
+                const Source& src = sources[layers[k].laser_id];
+                uint32_t colour = (uint32_t)std::min(src.agent_id, (int)NO_COLOUR);
+                if ((int)colour >= A) colour = NO_COLOUR;
+                lay |= (uint64_t)lay_pack((uint32_t)layers[k].laser_id, (uint32_t)layers[k].offset, colour) << (16 * k);
+            }
+            cell_lay[c] = lay;
+            uint32_t walk = 0;
+            for (int d = 0; d < 4; d++) {
+                int ni = i + ACT_DELTA[d][0], nj = j + ACT_DELTA[d][1];
+                if (ni < 0 || nj < 0 || ni >= H || nj >= W) continue;
+                uint8_t k = kind[ni * W + nj];
+                if (k != K_WALL && k != K_SOURCE) walk |= 1u << d;
+            }
+            uint32_t gi = gem_index[c] >= 0 ? (uint32_t)gem_index[c] : 31u;
+            cell_meta[c] = kind[c] | (gi << 3) | (walk << 8) | ((uint32_t)layers.size() << 12);
+        }
+
+    // ---- static observation (observations.py:216-237): WALL, VOID, EXIT, then -1 at each source on its colour layer
+    const int LASER_0 = A, WALL = 2 * A, VOID = WALL + 1, GEM = VOID + 1, EXIT = GEM + 1;
+    std::vector<int8_t> tmpl(h.obs_stride, 0);
+    auto at = [&](int layer, Pos q) -> int8_t& { return tmpl[(size_t)layer * HW + q.i * W + q.j]; };
+    for (auto& q : walls) at(WALL, q) = 1;
+    for (auto& q : voids) at(VOID, q) = 1;
+    for (auto& q : exits) at(EXIT, q) = 1;
+    for (auto& s : sources) {
+        if (LASER_0 + s.agent_id >= C) { h.obs_supported = 0; continue; }
+        at(LASER_0 + s.agent_id, s.pos) = -1;
+    }
+
+    // ---- dynamic observation bytes (observations.py:254-263): laser tiles that World.lasers() exposes
+    // (outer layer + the one directly below, world.rs:159-172), then uncollected gems
+    struct Dyn { int n_refs = 0; uint32_t ref[2] = {0, 0}; uint32_t gem = NO_GEM; };
+    std::map<uint32_t, Dyn> dyn;
+    for (int c = 0; c < HW; c++) {
+        const auto& layers = cell_layers[c];
+        for (size_t k = 0; k < layers.size() && k < 2; k++) {
+            const Source& src = sources[layers[k].laser_id];
+            if (LASER_0 + src.agent_id >= C) { h.obs_supported = 0; continue; }
+            uint32_t idx = (uint32_t)((LASER_0 + src.agent_id) * HW + c);
+            Dyn& d = dyn[idx];
+            d.ref[d.n_refs++] = (uint32_t)layers[k].laser_id | ((uint32_t)layers[k].offset << 5);
+        }
+    }
+    for (int g = 0; g < G; g++) dyn[(uint32_t)(GEM * HW + gems[g].i * W + gems[g].j)].gem = (uint32_t)g;
+    std::vector<uint64_t> dyn_tab;
+    for (auto& kv : dyn) {
+        const Dyn& d = kv.second;
+        uint64_t e = kv.first | ((uint64_t)(uint8_t)tmpl[kv.first] << 20) | ((uint64_t)d.n_refs << 28) |
+                     ((uint64_t)d.ref[0] << 30) | ((uint64_t)d.ref[1] << 40) | ((uint64_t)d.gem << 50);
+        dyn_tab.push_back(e);
+    }
+    h.D = (uint32_t)dyn_tab.size();
+
+    // ---- assemble blob
+    auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    size_t off = sizeof(MapHeader);
+    h.off_cell_lay = (uint32_t)off; off = align16(off + cell_lay.size() * 8);
+    h.off_cell_meta = (uint32_t)off; off = align16(off + cell_meta.size() * 4);
+    h.off_dyn = (uint32_t)off; off = align16(off + dyn_tab.size() * 8);
+    h.off_template = (uint32_t)off; off = align16(off + tmpl.size());
+    h.blob_bytes = (uint32_t)off;
+    h.lds_table_bytes = h.blob_bytes - h.off_cell_lay;
+    blob.assign(off, 0);
+    std::memcpy(blob.data() + h.off_cell_lay, cell_lay.data(), cell_lay.size() * 8);
+    std::memcpy(blob.data() + h.off_cell_meta, cell_meta.data(), cell_meta.size() * 4);
+    if (!dyn_tab.empty()) std::memcpy(blob.data() + h.off_dyn, dyn_tab.data(), dyn_tab.size() * 8);
+    std::memcpy(blob.data() + h.off_template, tmpl.data(), tmpl.size());
+    std::memcpy(blob.data(), &h, sizeof h);
+    header = h;
+}
+
+std::string Map::world_string() const {
+    // parser_v1.rs:100-130
+    std::vector<std::vector<std::string>> res(H, std::vector<std::string>(W, " . "));
+    for (size_t a = 0; a < starts.size(); a++) res[starts[a][0].i][starts[a][0].j] = "S" + std::to_string(a) + " ";
+    for (auto& q : gems) res[q.i][q.j] = " G ";
+    for (auto& q : walls) res[q.i][q.j] = " @ ";
+    for (auto& q : exits) res[q.i][q.j] = " X ";
+    for (auto& q : voids) res[q.i][q.j] = " V ";
+    static const char* DIRS = "NESW";
+    for (auto& s : sources) res[s.pos.i][s.pos.j] = "L" + std::to_string(s.agent_id) + DIRS[s.direction];
+    std::string out;
+    for (int i = 0; i < H; i++) {
+        if (i) out += "\n";
+        for (int j = 0; j < W; j++) {
+            if (j) out += " ";
+            out += res[i][j];
+        }
+    }
+    return out;
+}
+
+}  // namespace lle

@@ -1,0 +1,58 @@
+// map_compile.hpp -- host-side map compiler: v1 text -> static tables for the HIP kernels.
+//
+// Replaces, for the hot path, the reference's build-time pipeline
+//   parser_v1::parse (src/core/parsing/parser_v1.rs:132-175)
+//   -> WorldConfig::into_world (src/core/parsing/world_config.rs:107-122): pre_validate, make_grid (:176-199),
+//      laser_setup (:203-250, beam tracing + start pruning), post_validate.
+// Instead of a grid of boxed tiles it emits flat tables (tables.h).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "tables.h"
+
+namespace lle {
+
+struct Pos {
+    int i, j;
+    bool operator==(const Pos& o) const { return i == o.i && j == o.j; }
+};
+
+struct Source {
+    Pos pos;
+    int direction;  // N=0 E=1 S=2 W=3
+    int agent_id;   // colour (mutable: LaserSource.set_agent_id)
+    bool enabled;
+    int laser_id;
+    std::vector<Pos> beam;  // cells in offset order
+};
+
+struct CellLayer { int laser_id, offset; };
+
+struct Map {
+    int H = 0, W = 0;
+    std::vector<Pos> gems, exits, voids, walls;       // parse order (walls include sources, parser_v1.rs:22-25)
+    std::vector<std::vector<Pos>> starts;             // per agent, after start pruning
+    std::vector<Source> sources;                      // laser_id order
+    std::vector<std::vector<CellLayer>> cell_layers;  // [HW], outermost first
+    std::vector<uint8_t> kind;                        // [HW] CellKind of the innermost tile
+    std::vector<int> gem_index;                       // [HW] or -1
+
+    int n_agents() const { return (int)starts.size(); }
+    int n_layers() const { return 2 * n_agents() + 4; }
+    int n_laser_tiles() const;
+
+    // compiled form
+    MapHeader header{};
+    std::vector<uint8_t> blob;  // header + sections
+    void compile();             // (re)builds header + blob from the fields above
+
+    std::string world_string() const;  // parser_v1.rs:100-130 to_v1_string
+};
+
+// Returns LLE_PARSE_* (0 = ok).
+int parse_map(const char* text, size_t len, Map& out);
+extern const char* const LEVEL_TEXT[6];
+
+}  // namespace lle

@@ -1,0 +1,400 @@
+// step_logic.hpp -- per-environment state machine of the batched World (one lane = one environment).
+//
+// Bitmask restatement of the reference's sequential tile-object semantics:
+//   World::step               src/core/world.rs:435-475
+//   solve_vertex_conflicts    src/core/world.rs:365-378 + src/utils/mod.rs:18-36
+//   move_agents               src/core/world.rs:477-505  (leave* -> pre_enter* -> enter*, each in agent order)
+//   Tile/Laser/Gem/Void       src/core/tiles/{tile.rs:20-99, laser.rs:157-202, gem.rs:26-35, void.rs:13-22}
+//   compute_available_actions src/core/world.rs:343-363
+//   World::reset              src/core/world.rs:411-432
+//   World::set_state          src/core/world.rs:515-597
+//
+// Representation: a beam (`LaserBeam{Vec<bool>}`) is a u32 mask, bit k = on at offset k; the occupant slot of a
+// cell is one "occupant" bit per agent (agents never share a cell, so the slot of a cell is the agent standing
+// on it with that bit set); gems are one collected-bit each.  A cell's stack of `Laser` wrappers is the static
+// `cell_lay` entry (tables.h), outermost layer first.
+//
+// Everything is written against register arrays with compile-time indices (AM = max agents, LM = max sources of
+// this instantiation): runtime-indexed private arrays would go to scratch memory on gfx950.
+#pragma once
+#include <stdint.h>
+
+#include "tables.h"
+
+#if defined(__HIPCC__)
+#define LLE_HD __host__ __device__ __forceinline__
+#else
+#define LLE_HD inline
+#endif
+
+namespace lle {
+
+// splitmix64 finaliser
+LLE_HD uint64_t mix64(uint64_t x) {
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL;
+    x ^= x >> 27; x *= 0x94D049BB133111EBULL;
+    x ^= x >> 31;
+    return x;
+}
+// Counter-based action sampler (DESIGN.md "Action stream"): stateless in (seed, env, t, agent).
+LLE_HD uint64_t action_hash_env(uint64_t seed, uint64_t env, uint64_t t) {
+    uint64_t x = seed + 0x9E3779B97F4A7C15ULL * (env + 1);
+    x ^= 0xD1B54A32D192ED03ULL * (t + 1);
+    return mix64(x);
+}
+LLE_HD uint64_t action_hash_agent(uint64_t env_hash, uint64_t agent) {
+    return mix64(env_hash ^ (0x8CB92BA72F3D8DD7ULL * (agent + 1)));
+}
+// k-th set bit of the 5-bit availability mask in enum order N,S,E,W,STAY, k uniform in [0, popcount)
+LLE_HD uint32_t sample_action(uint32_t mask, uint64_t h) {
+    mask &= 31u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t n = (uint32_t)__popc(mask);
+#else
+    uint32_t n = (uint32_t)__builtin_popcount(mask);
+#endif
+    uint32_t k = (uint32_t)(h >> 33) % n;
+    uint32_t act = 4;
+#pragma unroll
+    for (int b = 4; b >= 0; b--) {
+        // position of the k-th set bit: count set bits below b
+        uint32_t below = mask & ((1u << b) - 1u);
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint32_t r = (uint32_t)__popc(below);
+#else
+        uint32_t r = (uint32_t)__builtin_popcount(below);
+#endif
+        if (((mask >> b) & 1u) && r == k) act = (uint32_t)b;
+    }
+    return act;
+}
+
+// Static tables as seen by the logic (pointers may be LDS or global).
+struct MapView {
+    const uint64_t* cell_lay;
+    const uint32_t* cell_meta;
+    const MapHeader* hdr;  // uniform fields
+    int W, A, L, G;
+    uint32_t enabled;      // bit b: source b enabled
+    uint32_t max_layers;
+};
+
+template <int AM, int LM>
+struct Env {
+    uint32_t pos[AM];  // i | j << 8
+    uint32_t alive, arrived, occ;  // bit per agent
+    uint32_t gems;                 // bit per gem: collected
+    uint32_t beams[LM];
+};
+
+template <int AM>
+struct Events {
+    static constexpr int NW = (2 * AM + 7) / 8;
+    uint64_t w[NW];
+    uint32_t n;
+    LLE_HD void clear() {
+#pragma unroll
+        for (int k = 0; k < NW; k++) w[k] = 0;
+        n = 0;
+    }
+    LLE_HD void push(uint32_t type, uint32_t agent) {
+        const uint64_t byte = (uint64_t)((type << 4) | agent);
+        const uint32_t word = n >> 3, sh = (n & 7u) * 8u;
+#pragma unroll
+        for (int k = 0; k < NW; k++) w[k] |= (word == (uint32_t)k) ? (byte << sh) : 0ull;
+        n++;
+    }
+};
+
+LLE_HD uint32_t cell_of(uint32_t p, int W) { return (p & 0xFFu) * (uint32_t)W + (p >> 8); }
+
+template <int LM>
+LLE_HD uint32_t beam_get(const uint32_t (&b)[LM], uint32_t idx) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < LM; k++) r = (idx == (uint32_t)k) ? b[k] : r;
+    return r;
+}
+template <int LM>
+LLE_HD void beam_set(uint32_t (&b)[LM], uint32_t idx, uint32_t v) {
+#pragma unroll
+    for (int k = 0; k < LM; k++) b[k] = (idx == (uint32_t)k) ? v : b[k];
+}
+
+// Tile::leave on a laser stack (laser.rs:199-202 -> :157-162 -> :50-55): every layer whose bit is off is
+// re-lit from its offset to the end, unless the source is disabled.
+template <int LM>
+LLE_HD void lasers_leave(uint32_t (&beams)[LM], uint64_t lay, const MapView& mv) {
+    for (uint32_t k = 0; k < mv.max_layers; k++) {
+        const uint32_t e = (uint32_t)(lay >> (16 * k)) & 0xFFFFu;
+        if (!(e & LAY_VALID)) break;
+        const uint32_t b = (e >> 1) & 31u, off = (e >> 6) & 31u;
+        uint32_t m = beam_get<LM>(beams, b);
+        if (!((m >> off) & 1u) && ((mv.enabled >> b) & 1u)) {
+            m |= (0xFFFFFFFFu << off);  // bits beyond the beam length are trimmed by canonicalise()
+            beam_set<LM>(beams, b, m);
+        }
+    }
+}
+
+// Tile::pre_enter on a laser stack (laser.rs:173-182): an ALIVE agent of the beam's colour switches the beam
+// off from its offset on.  (Order over layers is irrelevant: each layer is a different beam.)
+template <int LM>
+LLE_HD void lasers_pre_enter(uint32_t (&beams)[LM], uint64_t lay, uint32_t agent, bool alive, const MapView& mv) {
+    if (!alive) return;
+    for (uint32_t k = 0; k < mv.max_layers; k++) {
+        const uint32_t e = (uint32_t)(lay >> (16 * k)) & 0xFFFFu;
+        if (!(e & LAY_VALID)) break;
+        const uint32_t b = (e >> 1) & 31u, off = (e >> 6) & 31u, colour = e >> 11;
+        if (colour == agent && ((mv.enabled >> b) & 1u)) {
+            uint32_t m = beam_get<LM>(beams, b);
+            m &= (1u << off) - 1u;
+            beam_set<LM>(beams, b, m);
+        }
+    }
+}
+
+// Laser::enter (laser.rs:184-197): the first layer (outermost first) that is on and of another colour stops the
+// agent; whether one exists does not depend on the order.
+template <int LM>
+LLE_HD bool lasers_block(const uint32_t (&beams)[LM], uint64_t lay, uint32_t agent, const MapView& mv) {
+    bool blocked = false;
+    for (uint32_t k = 0; k < mv.max_layers; k++) {
+        const uint32_t e = (uint32_t)(lay >> (16 * k)) & 0xFFFFu;
+        if (!(e & LAY_VALID)) break;
+        const uint32_t b = (e >> 1) & 31u, off = (e >> 6) & 31u, colour = e >> 11;
+        const uint32_t m = beam_get<LM>(beams, b);
+        blocked |= ((m >> off) & 1u) && (colour != agent);
+    }
+    return blocked;
+}
+
+// Tile::enter for agent a at its cell (tile.rs:29-50).  Returns true if the agent died in this call.
+template <int AM, int LM, bool EMIT>
+LLE_HD bool enter_agent(Env<AM, LM>& s, uint32_t a, uint32_t cell, const MapView& mv, Events<AM>& ev) {
+    const uint32_t bit = 1u << a;
+    const bool is_alive = (s.alive & bit) != 0;
+    if (lasers_block<LM>(s.beams, mv.cell_lay[cell], a, mv)) {
+        if (is_alive) {
+            s.alive &= ~bit;
+            if (EMIT) ev.push(EV_DIED, a);
+            return true;
+        }
+        return false;  // a corpse in a lit beam: nothing happens, the wrapped tile is not entered
+    }
+    const uint32_t meta = mv.cell_meta[cell];
+    const uint32_t kind = meta & 7u;
+    s.occ |= bit;  // Floor / Exit / Gem / Void all take the agent as occupant
+    if (kind == K_EXIT) {
+        if (!(s.arrived & bit)) {
+            s.arrived |= bit;
+            if (EMIT) ev.push(EV_EXIT, a);
+        }
+    } else if (kind == K_GEM) {
+        const uint32_t g = 1u << ((meta >> 3) & 31u);
+        if (!(s.gems & g)) {
+            s.gems |= g;
+            if (EMIT) ev.push(EV_GEM, a);
+        }
+    } else if (kind == K_VOID) {
+        if (is_alive) {
+            s.alive &= ~bit;
+            if (EMIT) ev.push(EV_DIED, a);
+            return true;
+        }
+    }
+    return false;
+}
+
+// One call of World::move_agents (world.rs:477-505).  old_pos: where alive agents leave from.
+template <int AM, int LM>
+LLE_HD bool move_agents(Env<AM, LM>& s, const uint32_t (&old_pos)[AM], const uint32_t (&new_pos)[AM], const MapView& mv,
+                        Events<AM>& ev) {
+#pragma unroll
+    for (int a = 0; a < AM; a++) {
+        if (a < mv.A && ((s.alive >> a) & 1u)) {
+            s.occ &= ~(1u << a);
+            lasers_leave<LM>(s.beams, mv.cell_lay[cell_of(old_pos[a], mv.W)], mv);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < AM; a++) {
+        if (a < mv.A) lasers_pre_enter<LM>(s.beams, mv.cell_lay[cell_of(new_pos[a], mv.W)], (uint32_t)a, (s.alive >> a) & 1u, mv);
+    }
+    bool died = false;
+#pragma unroll
+    for (int a = 0; a < AM; a++) {
+        if (a < mv.A) died |= enter_agent<AM, LM, true>(s, (uint32_t)a, cell_of(new_pos[a], mv.W), mv, ev);
+    }
+    return died;
+}
+
+// bits beyond each beam's length back to 0 (keeps the stored masks canonical)
+template <int AM, int LM>
+LLE_HD void canonicalise(Env<AM, LM>& s, const MapView& mv) {
+#pragma unroll
+    for (int b = 0; b < LM; b++)
+        if (b < mv.L) s.beams[b] &= mv.hdr->beam_full[b];
+}
+
+// compute_available_actions (world.rs:343-363) as 5-bit masks (bit = Action value).
+template <int AM, int LM>
+LLE_HD void compute_avail(const Env<AM, LM>& s, const MapView& mv, uint32_t (&avail)[AM]) {
+#pragma unroll
+    for (int a = 0; a < AM; a++) {
+        if (a >= mv.A) { avail[a] = 0; continue; }
+        uint32_t m = 16u;  // Stay
+        if (((s.alive >> a) & 1u) && !((s.arrived >> a) & 1u)) {
+            uint32_t walk = (mv.cell_meta[cell_of(s.pos[a], mv.W)] >> 8) & 15u;
+            uint32_t blocked = 0;
+#pragma unroll
+            for (int o = 0; o < AM; o++) {
+                if (o < mv.A && o != a && ((s.occ >> o) & 1u)) {
+                    const int d = (int)s.pos[o] - (int)s.pos[a];
+                    blocked |= (d == -1) ? 1u : 0u;    // North: i - 1
+                    blocked |= (d == 1) ? 2u : 0u;     // South: i + 1
+                    blocked |= (d == 256) ? 4u : 0u;   // East:  j + 1
+                    blocked |= (d == -256) ? 8u : 0u;  // West:  j - 1
+                }
+            }
+            m |= walk & ~blocked;
+        }
+        avail[a] = m;
+    }
+}
+
+LLE_HD uint32_t apply_action(uint32_t p, uint32_t act) {
+    // action.rs:18-26 deltas on the packed i | j << 8 form
+    const int d = (act == 0) ? -1 : (act == 1) ? 1 : (act == 2) ? 256 : (act == 3) ? -256 : 0;
+    return (uint32_t)((int)p + d);
+}
+
+// World::step after the availability check.  Returns the number of move_agents passes.
+template <int AM, int LM>
+LLE_HD void step_env(Env<AM, LM>& s, const uint32_t (&actions)[AM], const MapView& mv, Events<AM>& ev) {
+    uint32_t np[AM];
+#pragma unroll
+    for (int a = 0; a < AM; a++) np[a] = (a < mv.A) ? apply_action(s.pos[a], actions[a]) : 0xFFFF0000u + (uint32_t)a;
+    // solve_vertex_conflicts: every agent whose target is shared goes back to its current cell, until stable
+    bool conflict = true;
+    while (conflict) {
+        conflict = false;
+        uint32_t dup = 0;
+#pragma unroll
+        for (int i = 0; i < AM; i++)
+#pragma unroll
+            for (int j = i + 1; j < AM; j++)
+                if (j < mv.A && np[i] == np[j]) dup |= (1u << i) | (1u << j);
+#pragma unroll
+        for (int i = 0; i < AM; i++)
+            if ((dup >> i) & 1u) { np[i] = s.pos[i]; conflict = true; }
+    }
+    bool died = move_agents<AM, LM>(s, s.pos, np, mv, ev);
+#pragma unroll
+    for (int a = 0; a < AM; a++) s.pos[a] = np[a];
+    while (died) died = move_agents<AM, LM>(s, np, np, mv, ev);
+    canonicalise<AM, LM>(s, mv);
+}
+
+// Tile::reset over the whole grid (tile.rs:75-84): occupants cleared, gems uncollected, every enabled beam fully
+// on (a disabled beam stays dark: laser.rs:50-53).
+template <int AM, int LM>
+LLE_HD void reset_tiles(Env<AM, LM>& s, const MapView& mv) {
+    s.occ = 0;
+    s.gems = 0;
+#pragma unroll
+    for (int b = 0; b < LM; b++) s.beams[b] = (b < mv.L && ((mv.enabled >> b) & 1u)) ? mv.hdr->beam_full[b] : 0u;
+}
+
+// World::reset (world.rs:411-432); events of the initial enter are dropped.
+template <int AM, int LM>
+LLE_HD void reset_env(Env<AM, LM>& s, const MapView& mv) {
+    reset_tiles<AM, LM>(s, mv);
+    s.alive = (mv.A >= 32) ? 0xFFFFFFFFu : ((1u << mv.A) - 1u);
+    s.arrived = 0;
+#pragma unroll
+    for (int a = 0; a < AM; a++) s.pos[a] = (a < mv.A) ? (uint32_t)mv.hdr->start[a] : 0xFFFF0000u + (uint32_t)a;
+#pragma unroll
+    for (int a = 0; a < AM; a++)
+        if (a < mv.A) lasers_pre_enter<LM>(s.beams, mv.cell_lay[cell_of(s.pos[a], mv.W)], (uint32_t)a, true, mv);
+    Events<AM> ev;
+    ev.clear();
+#pragma unroll
+    for (int a = 0; a < AM; a++)
+        if (a < mv.A) enter_agent<AM, LM, false>(s, (uint32_t)a, cell_of(s.pos[a], mv.W), mv, ev);
+    canonicalise<AM, LM>(s, mv);
+}
+
+// reset tiles, collect the requested direct gems, pre_enter with the agents' CURRENT alive flags, then
+// agent.reset() + enter (+ die if requested dead) per agent: world.rs:543-586.  Returns whether the resulting
+// get_state() equals the target (world.rs:588-589).
+template <int AM, int LM, bool EMIT>
+LLE_HD bool apply_state(Env<AM, LM>& s, const uint32_t (&tpos)[AM], uint32_t tgems, uint32_t talive, const MapView& mv,
+                        Events<AM>& ev) {
+    reset_tiles<AM, LM>(s, mv);
+    s.gems = tgems & mv.hdr->direct_gems;  // only direct Tile::Gem are collected up-front (world.rs:550-554)
+#pragma unroll
+    for (int a = 0; a < AM; a++)
+        if (a < mv.A) lasers_pre_enter<LM>(s.beams, mv.cell_lay[cell_of(tpos[a], mv.W)], (uint32_t)a, (s.alive >> a) & 1u, mv);
+#pragma unroll
+    for (int a = 0; a < AM; a++)
+        if (a < mv.A) s.pos[a] = tpos[a];
+#pragma unroll
+    for (int a = 0; a < AM; a++) {
+        if (a < mv.A) {
+            const uint32_t bit = 1u << a;
+            s.alive |= bit;      // agent.reset()
+            s.arrived &= ~bit;
+            enter_agent<AM, LM, EMIT>(s, (uint32_t)a, cell_of(tpos[a], mv.W), mv, ev);
+            if (!((talive >> a) & 1u)) s.alive &= ~bit;
+        }
+    }
+    canonicalise<AM, LM>(s, mv);
+    return s.gems == tgems && s.alive == talive;
+}
+
+// World::set_state (world.rs:515-597) for one request.  Returns ENV_OK, ENV_INVALID_WORLD_STATE (duplicate
+// positions: nothing touched; or final mismatch: NO rollback, like the reference), ENV_OUT_OF_WORLD_POSITION
+// (nothing touched) or ENV_INVALID_AGENT_POSITION (after the reference's rollback through set_state(current)).
+// `avail_dirty`: whether compute_available_actions ran in the reference.
+template <int AM, int LM>
+LLE_HD uint8_t set_state_env(Env<AM, LM>& s, const uint32_t (&req_pos)[AM], uint32_t req_gems, uint32_t req_alive,
+                             const MapView& mv, Events<AM>& ev, bool& avail_dirty) {
+    avail_dirty = false;
+    const uint32_t amask = (1u << mv.A) - 1u, gmask = (mv.G >= 32) ? 0xFFFFFFFFu : ((1u << mv.G) - 1u);
+    req_alive &= amask;
+    req_gems &= gmask;
+    bool dup = false, oob = false, unwalkable = false;
+#pragma unroll
+    for (int i = 0; i < AM; i++) {
+        if (i >= mv.A) continue;
+#pragma unroll
+        for (int j = i + 1; j < AM; j++)
+            if (j < mv.A && req_pos[i] == req_pos[j]) dup = true;
+        if ((req_pos[i] & 0xFFu) >= mv.hdr->H || (req_pos[i] >> 8) >= mv.hdr->W) oob = true;
+    }
+    if (dup) return ENV_INVALID_WORLD_STATE;
+    if (oob) return ENV_OUT_OF_WORLD_POSITION;
+#pragma unroll
+    for (int a = 0; a < AM; a++) {
+        if (a >= mv.A) continue;
+        const uint32_t kind = mv.cell_meta[cell_of(req_pos[a], mv.W)] & 7u;
+        if (kind == K_WALL || kind == K_SOURCE) unwalkable = true;
+    }
+    if (unwalkable) {
+        // pre_enter failed -> self.set_state(&current_state).unwrap() -> Err(InvalidAgentPosition)
+        uint32_t cur_pos[AM];
+#pragma unroll
+        for (int a = 0; a < AM; a++) cur_pos[a] = s.pos[a];
+        Events<AM> dropped;
+        dropped.clear();
+        apply_state<AM, LM, false>(s, cur_pos, s.gems, s.alive, mv, dropped);
+        avail_dirty = true;
+        return ENV_INVALID_AGENT_POSITION;
+    }
+    if (!apply_state<AM, LM, true>(s, req_pos, req_gems, req_alive, mv, ev)) return ENV_INVALID_WORLD_STATE;
+    avail_dirty = true;
+    return ENV_OK;
+}
+
+}  // namespace lle

@@ -1,0 +1,112 @@
+// tables.h -- static map tables shared by the host map compiler and the HIP kernels.
+//
+// One map compiles to a flat "blob": a MapHeader followed by 16-byte aligned sections.  The kernel copies the
+// sections into LDS verbatim (same offsets), so the host compiler alone defines the layout.
+//
+//   cell_lay [HW] u64 : up to 4 laser layers of the cell, OUTERMOST first (a later source wraps an earlier one,
+//                       reference src/core/parsing/world_config.rs:223-247), 16 bits each:
+//                         bit 0 valid | bits 1-5 beam (laser_id) | bits 6-10 offset | bits 11-15 colour
+//                       colour 31 = "no agent has this colour" (reference colours >= n_agents are legal, Q5)
+//   cell_meta[HW] u32 : bits 0-2 kind | bits 3-7 gem index | bits 8-11 static walk mask (bit = Action N,S,E,W:
+//                       neighbour in bounds and not Wall/LaserSource, reference world.rs:351-356, tile.rs:63-73)
+//                       | bits 12-14 number of layers
+//   dyn      [D]  u64 : the observation bytes that depend on dynamic state other than agent positions:
+//                         bits 0-19 byte index in the (C,H,W) int8 observation | bits 20-27 base value (int8)
+//                         bits 28-29 number of laser refs (0-2) | bits 30-39 ref0 (beam:5, offset:5)
+//                         bits 40-49 ref1 | bits 50-55 gem index (63 = none)
+//                       value = base; any ref on -> 1; gem present and not collected -> 1
+//                       (write order of reference python/lle/observations.py:216-266)
+//   template [obs_stride] i8 : static observation (walls, voids, exits, -1 at sources), dyn bytes at their base
+#pragma once
+#include <stdint.h>
+
+namespace lle {
+
+enum CellKind : uint32_t { K_FLOOR = 0, K_WALL = 1, K_VOID = 2, K_EXIT = 3, K_GEM = 4, K_SOURCE = 5 };
+
+constexpr int MAX_AGENTS = 16;
+constexpr int MAX_SOURCES = 32;
+constexpr int MAX_GEMS = 32;
+constexpr int MAX_BEAM_LEN = 32;
+constexpr int MAX_CELL_LAYERS = 4;
+constexpr uint32_t NO_GEM = 63;
+constexpr uint32_t NO_COLOUR = 31;
+
+struct MapHeader {
+    uint32_t magic;          // 'LLE1'
+    uint32_t H, W, A, G, L, C;
+    uint32_t HW;
+    uint32_t obs_bytes;      // C*HW
+    uint32_t obs_stride;     // obs_bytes rounded up to 16
+    uint32_t n_chunks;       // obs_stride / 16
+    uint32_t D;              // number of dyn entries
+    uint32_t max_layers;     // max laser layers on any cell
+    uint32_t enabled_mask;   // bit b: source b enabled
+    uint32_t blob_bytes;     // header + sections
+    uint32_t off_cell_lay, off_cell_meta, off_dyn, off_template;  // byte offsets from blob start
+    uint32_t lds_table_bytes;  // bytes [off_cell_lay, blob_bytes) copied to LDS
+    uint32_t obs_supported;
+    uint32_t direct_gems;    // bit g: gem g is a direct Tile::Gem (no laser layer on its cell)
+    uint32_t pad0, pad1;
+    uint16_t start[MAX_AGENTS];        // start cell of each agent, i | j << 8
+    uint32_t beam_full[MAX_SOURCES];   // (1 << len) - 1
+    uint8_t beam_len[MAX_SOURCES];
+    uint8_t beam_colour[MAX_SOURCES];  // min(colour, 31)
+    uint16_t gem_cell[MAX_GEMS];       // cell of each gem, i | j << 8
+};
+static_assert(sizeof(MapHeader) % 16 == 0, "sections must stay 16-byte aligned");
+
+constexpr uint32_t MAP_MAGIC = 0x31454C4Cu;
+
+// ---- cell_lay entry helpers
+constexpr uint32_t LAY_VALID = 1u;
+inline constexpr uint32_t lay_pack(uint32_t beam, uint32_t off, uint32_t colour) {
+    return LAY_VALID | (beam << 1) | (off << 6) | (colour << 11);
+}
+
+// ---- per-env error codes (mirror include/lle_hip.h)
+constexpr uint8_t ENV_OK = 0;
+constexpr uint8_t ENV_INVALID_WORLD_STATE = 0x40;
+constexpr uint8_t ENV_OUT_OF_WORLD_POSITION = 0x41;
+constexpr uint8_t ENV_INVALID_AGENT_POSITION = 0x42;
+
+// ---- step flags (mirror include/lle_hip.h)
+constexpr uint32_t STEP_SAMPLE_ACTIONS = 1, STEP_AUTO_RESET = 2, STEP_NO_OBS = 4;
+
+// ---- event codes
+constexpr uint32_t EV_EXIT = 0, EV_GEM = 1, EV_DIED = 2;
+
+// Per-launch arguments.
+struct LaunchArgs {
+    uint32_t flags;            // STEP_*
+    uint32_t envs_per_wave;    // 1..64, power of two
+    uint64_t seed, t;
+    int64_t env_offset;        // global id of env 0 (multi-GPU shards sample as one big batch)
+    const uint8_t* env_mask;   // reset: optional u8[n]
+    const uint8_t* actions_in; // step: optional u8[n][A]
+    uint32_t old_enabled;      // update_sources: enabled mask before the update
+    uint32_t pad;
+};
+
+// Device pointers of one batch (kernel argument, passed by value).
+struct BatchPtrs {
+    const uint8_t* tables;   // device blob (MapHeader + sections)
+    uint16_t* pos;           // [n][A]   i | j << 8
+    uint64_t* bits;          // [n]
+    uint32_t* gems;          // [n]
+    uint32_t* beams;         // [n][L]
+    uint8_t* avail;          // [n][A]
+    uint8_t* actions;        // [n][A]
+    uint8_t* err;            // [n]
+    uint8_t* evcount;        // [n]
+    uint8_t* events;         // [n][2A]
+    uint8_t* done;           // [n]
+    int8_t* obs;             // [n][obs_stride]
+    int64_t* stats;          // [n_blocks][8]
+    const uint16_t* req_pos; // [n][A]
+    const uint32_t* req_gems;
+    const uint16_t* req_alive;
+    int64_t n_envs;
+};
+
+}  // namespace lle

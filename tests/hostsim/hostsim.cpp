@@ -1,0 +1,214 @@
+// hostsim.cpp -- TEST-ONLY host build of the device state machine (lle_amd/csrc/step_logic.hpp) and of the
+// table-driven observation patching, so that the logic and the map tables can be diffed against the oracle on a
+// machine without a GPU.  It is compiled by tests/hostsim/__init__.py with g++, lives under tests/, and is never
+// loaded by the lle_amd package: the product has no CPU execution path.
+//
+// It mirrors phase 1 / phase 2 of world_kernel (kernels.hip) one environment at a time, on buffers with exactly the
+// device layout (include/lle_hip.h LLE_BUF_*).
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/lle_hip.h"
+#include "../../lle_amd/csrc/map_compile.hpp"
+#include "../../lle_amd/csrc/step_logic.hpp"
+
+using namespace lle;
+
+struct hs_batch {
+    Map map;
+    int64_t n;
+    std::vector<uint16_t> pos, req_pos, req_alive;
+    std::vector<uint64_t> bits;
+    std::vector<uint32_t> gems, beams, req_gems;
+    std::vector<uint8_t> avail, actions, err, evcount, events, done;
+    std::vector<int8_t> obs;
+    int64_t stats[8];
+};
+
+enum { M_STEP = 0, M_RESET = 1, M_SET_STATE = 2, M_OBSERVE = 3, M_SOURCES = 4 };
+
+template <int AM, int LM>
+static void run(hs_batch* b, int mode, uint32_t flags, uint64_t seed, uint64_t t, int64_t env_offset,
+                const uint8_t* actions_in, const uint8_t* env_mask, uint32_t old_enabled) {
+    const MapHeader* hdr = &b->map.header;
+    const uint8_t* blob = b->map.blob.data();
+    const int A = (int)hdr->A, L = (int)hdr->L;
+    MapView mv;
+    mv.cell_lay = reinterpret_cast<const uint64_t*>(blob + hdr->off_cell_lay);
+    mv.cell_meta = reinterpret_cast<const uint32_t*>(blob + hdr->off_cell_meta);
+    mv.hdr = hdr; mv.W = (int)hdr->W; mv.A = A; mv.L = L; mv.G = (int)hdr->G;
+    mv.enabled = hdr->enabled_mask; mv.max_layers = hdr->max_layers;
+    const uint64_t* dyn = reinterpret_cast<const uint64_t*>(blob + hdr->off_dyn);
+    std::vector<int8_t> tmpl(blob + hdr->off_template, blob + hdr->off_template + hdr->obs_stride);
+    const uint32_t amask = (1u << A) - 1u;
+
+    for (int64_t env = 0; env < b->n; env++) {
+        Env<AM, LM> s;
+        for (int a = 0; a < AM; a++) s.pos[a] = (a < A) ? (uint32_t)b->pos[env * A + a] : 0xFFFF0000u + (uint32_t)a;
+        const uint64_t bits = b->bits[env];
+        s.alive = (uint32_t)bits & 0xFFFFu; s.arrived = (uint32_t)(bits >> 16) & 0xFFFFu; s.occ = (uint32_t)(bits >> 32) & 0xFFFFu;
+        s.gems = b->gems[env];
+        for (int k = 0; k < LM; k++) s.beams[k] = (k < L) ? b->beams[env * L + k] : 0u;
+        bool store_state = true, store_avail = false, touched = true;
+        uint32_t avail[AM];
+        Events<AM> ev;
+        ev.clear();
+        uint32_t err = 0, was_reset = 0;
+        if (mode == M_STEP) {
+            for (int a = 0; a < AM; a++) avail[a] = (a < A) ? (uint32_t)b->avail[env * A + a] : 0u;
+            if ((flags & STEP_AUTO_RESET) && (s.alive != amask || s.arrived == amask)) {
+                reset_env<AM, LM>(s, mv);
+                compute_avail<AM, LM>(s, mv, avail);
+                was_reset = 1;
+            }
+            uint32_t act[AM];
+            if (flags & STEP_SAMPLE_ACTIONS) {
+                const uint64_t he = action_hash_env(seed, (uint64_t)(env_offset + env), t);
+                for (int a = 0; a < AM; a++) act[a] = (a < A) ? sample_action(avail[a], action_hash_agent(he, (uint64_t)a)) : 4u;
+            } else {
+                const uint8_t* src = actions_in ? actions_in : b->actions.data();
+                for (int a = 0; a < AM; a++) act[a] = (a < A) ? (uint32_t)src[env * A + a] : 4u;
+            }
+            for (int a = 0; a < A; a++) b->actions[env * A + a] = (uint8_t)act[a];
+            for (int a = AM - 1; a >= 0; a--)
+                if (a < A && (act[a] > 4u || !((avail[a] >> act[a]) & 1u))) err = (uint32_t)a + 1u;
+            if (err == 0) {
+                step_env<AM, LM>(s, act, mv, ev);
+                compute_avail<AM, LM>(s, mv, avail);
+                store_avail = true;
+            } else {
+                store_state = was_reset != 0;
+                store_avail = was_reset != 0;
+            }
+        } else if (mode == M_RESET) {
+            if (!env_mask || env_mask[env]) {
+                reset_env<AM, LM>(s, mv);
+                compute_avail<AM, LM>(s, mv, avail);
+                store_avail = true;
+            } else {
+                store_state = false;
+                touched = false;
+            }
+        } else if (mode == M_SET_STATE) {
+            uint32_t rp[AM];
+            for (int a = 0; a < AM; a++) rp[a] = (a < A) ? (uint32_t)b->req_pos[env * A + a] : 0xFFFF0000u + (uint32_t)a;
+            bool dirty = false;
+            err = set_state_env<AM, LM>(s, rp, b->req_gems[env], (uint32_t)b->req_alive[env], mv, ev, dirty);
+            if (err != 0) ev.clear();
+            if (dirty) { compute_avail<AM, LM>(s, mv, avail); store_avail = true; }
+        } else if (mode == M_SOURCES) {
+            for (int k = 0; k < LM; k++) {
+                if (k < L) {
+                    const bool was = (old_enabled >> k) & 1u, now = (mv.enabled >> k) & 1u;
+                    if (was && !now) s.beams[k] = 0u;
+                    if (!was && now) s.beams[k] = hdr->beam_full[k];
+                }
+            }
+        } else {
+            store_state = false;
+        }
+        if (store_state) {
+            for (int a = 0; a < A; a++) b->pos[env * A + a] = (uint16_t)s.pos[a];
+            b->bits[env] = (uint64_t)s.alive | ((uint64_t)s.arrived << 16) | ((uint64_t)s.occ << 32);
+            b->gems[env] = s.gems;
+            for (int k = 0; k < L; k++) b->beams[env * L + k] = s.beams[k];
+        }
+        if (store_avail) for (int a = 0; a < A; a++) b->avail[env * A + a] = (uint8_t)avail[a];
+        if ((mode == M_STEP || mode == M_RESET || mode == M_SET_STATE) && touched) {
+            b->err[env] = (uint8_t)err;
+            b->evcount[env] = (uint8_t)(ev.n | (was_reset << 7));
+            for (int k = 0; k < 2 * A; k++) b->events[env * 2 * A + k] = (uint8_t)(ev.w[k >> 3] >> ((k & 7) * 8));
+            b->done[env] = (s.alive != amask || s.arrived == amask) ? 1 : 0;
+        }
+        if (mode == M_STEP) {
+            int64_t n_gem = 0, n_exit = 0, n_died = 0;
+            for (uint32_t k = 0; k < ev.n; k++) {
+                const uint32_t ty = ((uint32_t)(ev.w[k >> 3] >> ((k & 7) * 8)) >> 4) & 3u;
+                n_gem += ty == EV_GEM; n_exit += ty == EV_EXIT; n_died += ty == EV_DIED;
+            }
+            const int64_t bonus = (err == 0 && s.arrived == amask) ? 1 : 0;
+            b->stats[0] += 1; b->stats[1] += A; b->stats[2] += n_gem; b->stats[3] += n_exit; b->stats[4] += n_died;
+            b->stats[5] += err != 0; b->stats[6] += was_reset; b->stats[7] += n_gem + n_exit - n_died + bonus;
+        }
+        // phase 2
+        if ((mode == M_STEP && (flags & STEP_NO_OBS)) || !hdr->obs_supported) continue;
+        for (uint32_t d = 0; d < hdr->D; d++) {
+            const uint64_t e = dyn[d];
+            const uint32_t idx = (uint32_t)e & 0xFFFFFu;
+            int32_t v = (int8_t)(uint8_t)(e >> 20);
+            const uint32_t n_refs = (uint32_t)(e >> 28) & 3u;
+            const uint32_t r0 = (uint32_t)(e >> 30) & 0x3FFu, r1 = (uint32_t)(e >> 40) & 0x3FFu;
+            const uint32_t gem = (uint32_t)(e >> 50) & 63u;
+            if (n_refs >= 1 && ((s.beams[r0 & 31u] >> (r0 >> 5)) & 1u)) v = 1;
+            if (n_refs >= 2 && ((s.beams[r1 & 31u] >> (r1 >> 5)) & 1u)) v = 1;
+            if (gem != NO_GEM && !((s.gems >> gem) & 1u)) v = 1;
+            tmpl[idx] = (int8_t)v;
+        }
+        for (int a = 0; a < A; a++) tmpl[(uint32_t)a * hdr->HW + cell_of(s.pos[a], mv.W)] = 1;
+        std::memcpy(b->obs.data() + (size_t)env * hdr->obs_stride, tmpl.data(), hdr->obs_stride);
+        for (int a = 0; a < A; a++) tmpl[(uint32_t)a * hdr->HW + cell_of(s.pos[a], mv.W)] = 0;
+    }
+}
+
+static void dispatch(hs_batch* b, int mode, uint32_t flags, uint64_t seed, uint64_t t, int64_t env_offset,
+                     const uint8_t* actions_in, const uint8_t* env_mask, uint32_t old_enabled) {
+    const int A = (int)b->map.header.A, L = (int)b->map.header.L;
+    if (A <= 4 && L <= 4) run<4, 4>(b, mode, flags, seed, t, env_offset, actions_in, env_mask, old_enabled);
+    else if (A <= 8 && L <= 8) run<8, 8>(b, mode, flags, seed, t, env_offset, actions_in, env_mask, old_enabled);
+    else if (A <= 16 && L <= 16) run<16, 16>(b, mode, flags, seed, t, env_offset, actions_in, env_mask, old_enabled);
+    else run<16, 32>(b, mode, flags, seed, t, env_offset, actions_in, env_mask, old_enabled);
+}
+
+extern "C" {
+hs_batch* hs_create(const char* text, int64_t n, int* parse_error) {
+    hs_batch* b = new hs_batch();
+    int rc = parse_map(text, std::strlen(text), b->map);
+    if (parse_error) *parse_error = rc;
+    if (rc != 0) { delete b; return nullptr; }
+    const MapHeader& h = b->map.header;
+    b->n = n;
+    const size_t A = h.A, L = h.L ? h.L : 1;
+    b->pos.assign(n * A, 0); b->req_pos.assign(n * A, 0); b->req_alive.assign(n, 0);
+    b->bits.assign(n, 0); b->gems.assign(n, 0); b->beams.assign(n * L, 0); b->req_gems.assign(n, 0);
+    b->avail.assign(n * A, 0); b->actions.assign(n * A, 0); b->err.assign(n, 0); b->evcount.assign(n, 0);
+    b->events.assign(n * 2 * A, 0); b->done.assign(n, 0); b->obs.assign((size_t)n * h.obs_stride, 0);
+    std::memset(b->stats, 0, sizeof b->stats);
+    dispatch(b, M_RESET, 0, 0, 0, 0, nullptr, nullptr, 0);
+    return b;
+}
+void hs_free(hs_batch* b) { delete b; }
+void hs_reset(hs_batch* b, const uint8_t* mask) { dispatch(b, M_RESET, 0, 0, 0, 0, nullptr, mask, 0); }
+void hs_step(hs_batch* b, const uint8_t* actions, uint32_t flags, uint64_t seed, uint64_t t, int64_t env_offset) {
+    dispatch(b, M_STEP, flags, seed, t, env_offset, actions, nullptr, 0);
+}
+void hs_set_state(hs_batch* b) { dispatch(b, M_SET_STATE, 0, 0, 0, 0, nullptr, nullptr, 0); }
+void hs_observe(hs_batch* b) { dispatch(b, M_OBSERVE, 0, 0, 0, 0, nullptr, nullptr, 0); }
+void hs_set_source(hs_batch* b, int laser_id, int enabled, int agent_id) {
+    const uint32_t old = b->map.header.enabled_mask;
+    if (enabled >= 0) b->map.sources[laser_id].enabled = enabled != 0;
+    if (agent_id >= 0) b->map.sources[laser_id].agent_id = agent_id;
+    b->map.compile();
+    dispatch(b, M_SOURCES, 0, 0, 0, 0, nullptr, nullptr, old);
+}
+void* hs_buffer(hs_batch* b, int which) {
+    switch (which) {
+        case LLE_BUF_POS: return b->pos.data();
+        case LLE_BUF_BITS: return b->bits.data();
+        case LLE_BUF_GEMS: return b->gems.data();
+        case LLE_BUF_BEAMS: return b->beams.data();
+        case LLE_BUF_AVAIL: return b->avail.data();
+        case LLE_BUF_ACTIONS: return b->actions.data();
+        case LLE_BUF_ERR: return b->err.data();
+        case LLE_BUF_EVCOUNT: return b->evcount.data();
+        case LLE_BUF_EVENTS: return b->events.data();
+        case LLE_BUF_DONE: return b->done.data();
+        case LLE_BUF_OBS: return b->obs.data();
+        case LLE_BUF_STATS: return b->stats;
+        case LLE_BUF_REQ_POS: return b->req_pos.data();
+        case LLE_BUF_REQ_GEMS: return b->req_gems.data();
+        case LLE_BUF_REQ_ALIVE: return b->req_alive.data();
+    }
+    return nullptr;
+}
+}

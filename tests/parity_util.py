@@ -1,0 +1,95 @@
+"""Bit-exact comparison of an engine's packed buffers (device layout, as numpy) with the oracle's canonical dump."""
+import numpy as np
+
+
+def unpack_engine(bufs, A, G, L, beam_stride, C, H, W):
+    """bufs: dict name -> numpy array in the LLE_BUF_* layout.  Returns the oracle's canonical layout."""
+    n = bufs["bits"].shape[0]
+    bits = bufs["bits"].astype(np.uint64)
+    ar = np.arange(A, dtype=np.uint64)
+    out = {
+        "pos": bufs["pos"].reshape(n, A, 2).astype(np.uint8),
+        "alive": ((bits[:, None] >> ar) & 1).astype(np.uint8),
+        "arrived": ((bits[:, None] >> (ar + 16)) & 1).astype(np.uint8),
+        "occupant": ((bits[:, None] >> (ar + 32)) & 1).astype(np.uint8),
+        "gems": ((bufs["gems"].astype(np.uint64)[:, None] >> np.arange(G, dtype=np.uint64)) & 1).astype(np.uint8),
+        "avail": bufs["avail"].reshape(n, A).astype(np.uint8),
+    }
+    if L:
+        bm = bufs["beams"].reshape(n, -1)[:, :L].astype(np.uint64)
+        out["beams"] = ((bm[:, :, None] >> np.arange(beam_stride, dtype=np.uint64)) & 1).astype(np.uint8)
+    else:
+        out["beams"] = np.zeros((n, 0, beam_stride), np.uint8)
+    if "obs" in bufs and bufs["obs"] is not None:
+        out["obs"] = bufs["obs"].reshape(n, -1)[:, : C * H * W].reshape(n, C, H, W)
+    ev = bufs["events"].reshape(n, 2 * A)
+    out["events"] = np.stack([ev >> 4, ev & 15], axis=-1).astype(np.uint8)
+    out["ev_count"] = bufs["evcount"].astype(np.uint8)
+    out["err"] = bufs["err"].astype(np.int32)
+    out["actions"] = bufs["actions"].reshape(n, A).astype(np.uint8)
+    return out
+
+
+def assert_state_equal(eng, dump, where=""):
+    for key in ("pos", "alive", "arrived", "occupant", "gems", "beams", "avail"):
+        a, b = eng[key], dump[key]
+        if not np.array_equal(a, b):
+            bad = np.argwhere(a.reshape(a.shape[0], -1) != b.reshape(b.shape[0], -1))
+            e = int(bad[0][0])
+            raise AssertionError(f"{where}: '{key}' differs in {len(set(bad[:, 0]))} envs; first env {e}: engine={a[e].tolist()} oracle={b[e].tolist()}")
+
+
+def assert_step_equal(eng, ostep, where="", check_obs=True):
+    """ostep: dict returned by OracleBatch.step()."""
+    n, cap = eng["events"].shape[0], eng["events"].shape[1]
+    for key in ("actions", "err", "ev_count"):
+        if not np.array_equal(eng[key], ostep[key]):
+            bad = np.argwhere(eng[key].reshape(n, -1) != ostep[key].reshape(n, -1))
+            e = int(bad[0][0])
+            raise AssertionError(f"{where}: '{key}' differs; first env {e}: engine={eng[key][e].tolist()} oracle={ostep[key][e].tolist()}")
+    cnt = (ostep["ev_count"] & 0x7F).astype(np.int64)
+    valid = np.arange(cap)[None, :] < cnt[:, None]
+    ea = np.where(valid[:, :, None], eng["events"], 0)
+    eb = np.where(valid[:, :, None], ostep["events"], 0)
+    if not np.array_equal(ea, eb):
+        e = int(np.argwhere((ea != eb).reshape(n, -1))[0][0])
+        raise AssertionError(f"{where}: events differ; first env {e}: engine={ea[e].tolist()} oracle={eb[e].tolist()}")
+    if check_obs and "obs" in eng and "obs" in ostep:
+        if not np.array_equal(eng["obs"], ostep["obs"]):
+            bad = np.argwhere((eng["obs"] != ostep["obs"]).reshape(n, -1))
+            e = int(bad[0][0])
+            idx = np.argwhere(eng["obs"][e] != ostep["obs"][e])
+            raise AssertionError(f"{where}: obs differs in {len(set(bad[:, 0]))} envs; first env {e} at (c,i,j)={idx[:5].tolist()} "
+                                 f"engine={[int(eng['obs'][e][tuple(q)]) for q in idx[:5]]} oracle={[int(ostep['obs'][e][tuple(q)]) for q in idx[:5]]}")
+
+
+# maps used by the differential tests beyond the six levels: crossings (nested lasers), voids, gems and exits under
+# beams, same-colour nesting, colours without agent, disabled-looking corners
+EXTRA_MAPS = {
+    "q1": "S0 . G X\n. . L2W X\n. S1 . X\n. L1N . S2",
+    "nested": (
+        "S0 . G . L1S . X\n"
+        "L0E . . G . . .\n"
+        ". S1 . . . V .\n"
+        "L2E . G . . . X\n"
+        ". . S2 . . . X\n"
+        ". . . . L0N . ."
+    ),
+    "voids_gems": (
+        "S0 G V . X\n"
+        ". V G . X\n"
+        "S1 . . G V\n"
+        "L0E . . . .\n"
+        ". G . V ."
+    ),
+    "exit_under_beam": "L1E . X X\nS0 . . .\nS1 . . G\nL0E G . .",
+    # laser colours >= n_agents are legal (Q5): with A=1 their layers alias WALL (1), VOID (2) and GEM (3)
+    "colour_alias": "S0 . . .\n. G X .\nL3E . . .\n. . . L2W\nL1E . G .",
+    "three_beams": (
+        ". . L0S . . X\n"
+        "L1E . . . . X\n"
+        ". . . . L2W X\n"
+        "S0 S1 G S2 . ."
+    ),
+    "corridor": "S0 S1 S2 S3 . . G X X X X",
+}
