@@ -1,0 +1,164 @@
+"""bench.py -- env-steps/s of the batched World.step() hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch: on-device action sampling (uniform over available actions),
+auto-reset of finished envs, World.step, event / availability emission and the int8 layered observation, for
+65 536 level-6 environments per GPU (BASELINE.json configs[2], the configuration the metric is quoted on).
+All inputs are resident in HBM before the timed region.  Envs shard over GPUs with no data-path collective
+(weak scaling); the only collective is one RCCL all-reduce of the rollout counters after the timed region.
+
+Prints ONE JSON line (rank 0).  value = agent-steps/s over the whole job (agents x envs x steps / s);
+env-steps/s is reported next to it.  roofline / cpu_baseline objects: see DESIGN.md section "Measurement".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ENVS_PER_GPU = 65536
+LEVEL = 6
+SEED = 1234
+# algorithmic bytes per env-step of level 6
+#   obs C*H*W = 12*12*13 = 1872, state r/w 2*24 = 48, actions 4, avail 4, events 1 + 2*4 = 9
+ALGO_BYTES_PER_ENV_STEP = 1937
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(level_text, seconds_target=12.0):
+    """The CPU oracle (C restatement of the reference algorithm, kind "port") on a bounded sample of the same workload."""
+    import numpy as np
+
+    from oracle import oracle
+
+    threads = min(os.cpu_count() or 1, 64)
+    n = 4096
+    ob = oracle.OracleBatch(level_text, n)
+    obs = np.zeros((n, ob.C * ob.H * ob.W), np.int8)
+    ob.rollout(5, SEED, threads, obs)  # warm-up
+    t0 = time.perf_counter()
+    ob.rollout(20, SEED, threads, obs)
+    rate = n * 20 / (time.perf_counter() - t0)
+    steps = max(20, min(2000, int(seconds_target * rate / n)))
+    t0 = time.perf_counter()
+    ob.rollout(steps, SEED, threads, obs)
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    ob.rollout(max(steps // 8, 5), SEED, 1, obs)
+    dt1 = time.perf_counter() - t1
+    return {
+        "value": ob.A * n * steps / dt, "unit": "agent-steps/s", "cores": threads, "kind": "port",
+        "env_steps_per_s": n * steps / dt,
+        "single_thread_env_steps_per_s": n * max(steps // 8, 5) / dt1,
+        "sample": f"level {LEVEL}, {n} envs x {steps} steps, sampled actions + auto-reset + int8 layered obs, "
+                  f"C restatement of the Rust reference algorithm (oracle/lle_oracle.c), {threads} threads",
+    }
+
+
+def load_traffic():
+    """HBM bytes per launch from the committed PMC profile of this same command (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get("hbm_bytes_per_launch")
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--envs-per-wave", type=int, default=0, help="0 = library default")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from lle_amd import BatchedWorld
+    from lle_amd.distributed import allreduce_max, allreduce_stats, shard_offset
+    from oracle.levels import LEVELS  # map text only (data)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU execution path)"
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    n = args.envs_per_gpu
+    text = LEVELS[LEVEL]
+    bw = BatchedWorld(text, n, device=dev, envs_per_wave=args.envs_per_wave or None)
+    offset = shard_offset(n, rank)
+
+    def run(k, t0):
+        for t in range(t0, t0 + k):
+            bw.step(sample=True, auto_reset=True, seed=SEED, t=t, env_offset=offset)
+
+    run(args.warmup, 0)
+    torch.cuda.synchronize(dev)
+    bw.stats(reset=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t_start = time.perf_counter()
+    ev0.record()
+    run(args.steps, args.warmup)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # average launch-to-launch duration on the launch stream
+
+    elapsed = allreduce_max(elapsed, dev) if world > 1 else elapsed
+    stats = bw.stats()
+    stats = allreduce_stats(stats, dev) if world > 1 else stats
+
+    if rank == 0:
+        A = bw.map.n_agents
+        total_envs = n * world
+        env_steps_s = total_envs * args.steps / elapsed
+        achieved = ALGO_BYTES_PER_ENV_STEP * n / (kernel_ms * 1e-3) / 1e9
+        info = bw.kernel_info()
+        out = {
+            "metric": "env-steps/s (agents x envs x steps/s), level-6 batch 65536",
+            "value": A * env_steps_s, "unit": "agent-steps/s",
+            "env_steps_per_s": env_steps_s,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"World.level({LEVEL}) 4 agents 12x13, {n} envs/GPU, sampled actions + auto-reset + "
+                                   "int8 layered obs (C=12)", "envs_per_gpu": n, "global_batch": total_envs,
+                       "parallelism": f"env-shard x{world}", "kernel": info["kernel"], "envs_per_wave": info["envs_per_wave"],
+                       "lds_bytes_per_wave": info["lds_bytes"]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(),
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n, "kernel_ms": kernel_ms},
+            "rollout_stats": stats,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(text)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,1 +1,25 @@
-"""lle_amd -- batched, MI355X-native World.step() for the Laser Learning Environment (drop-in for yamoling/lle's hot path)."""
+"""lle_amd -- batched, MI355X-native `World.step()` for the Laser Learning Environment.
+
+Drop-in for the hot path of yamoling/lle: `World` (single environment, reference API) and `BatchedWorld`
+(tens of thousands of lock-stepped environments per kernel launch, torch tensors over device buffers).
+The compute path is hand-written HIP for gfx950 behind the C ABI of include/lle_hip.h; there is no CPU fallback.
+"""
+from ._capi import Map, MapParseError
+from .world import (Action, Agent, Direction, EventType, Gem, InvalidActionError, InvalidLevelError, InvalidWorldStateError,
+                    Laser, LaserSource, ParsingError, World, WorldEvent, WorldState)
+
+
+def __getattr__(name):
+    # BatchedWorld imports torch; keep `import lle_amd` light for parse-only users
+    if name == "BatchedWorld":
+        from .batched import BatchedWorld
+        return BatchedWorld
+    if name in ("Layered", "LayeredPadded"):
+        from . import observations
+        return getattr(observations, name)
+    raise AttributeError(name)
+
+
+__all__ = ["Action", "Agent", "BatchedWorld", "Direction", "EventType", "Gem", "InvalidActionError", "InvalidLevelError",
+           "InvalidWorldStateError", "Laser", "LaserSource", "Layered", "LayeredPadded", "Map", "MapParseError",
+           "ParsingError", "World", "WorldEvent", "WorldState"]

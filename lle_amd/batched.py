@@ -1,0 +1,220 @@
+"""BatchedWorld: n lock-stepped worlds of one map resident on one MI355X, exposed as torch tensors.
+
+The device work (reset / step / set_state / layered observation) is done by the HIP kernels behind the C ABI
+of include/lle_hip.h; torch only provides the device arena, the stream and (for multi-GPU) torch.distributed.
+Every tensor below is a zero-copy view into the batch's arena and is overwritten by the next call.
+"""
+import ctypes as C
+
+import torch
+
+from . import _capi
+from ._capi import (LLE_BUF_COUNT, BUFFER_NAMES, LLE_STEP_AUTO_RESET, LLE_STEP_NO_OBS, LLE_STEP_SAMPLE_ACTIONS, BufferDesc, Map)
+
+_TORCH_DTYPES = {
+    "pos": torch.uint8, "bits": torch.int64, "gems": torch.int32, "beams": torch.int32, "avail": torch.uint8,
+    "actions": torch.uint8, "err": torch.uint8, "evcount": torch.uint8, "events": torch.uint8, "done": torch.uint8,
+    "obs": torch.int8, "stats": torch.int64, "req_pos": torch.uint8, "req_gems": torch.int32, "req_alive": torch.int16,
+}
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("lle_amd: no HIP device is visible. The batched World runs only on the GPU "
+                           "(there is no CPU fallback); build and run on an MI355X box.")
+
+
+class BatchedWorld:
+    """n_envs independent `World`s of one map stepped by one kernel launch.
+
+    Attributes (torch tensors on `device`, views into one arena):
+      pos [n,A,2] u8 (i,j) - bits [n] i64 (alive 0-15 | arrived 16-31 | occupant 32-47) - gems [n] i32 (bit g collected)
+      beams [n,L] i32 (bit k = on at offset k) - avail [n,A] u8 (bit a = Action a) - actions [n,A] u8
+      err [n] u8 - evcount [n] u8 - events [n,2A] u8 (type<<4|agent) - done [n] u8 - obs [n,C,H,W] i8
+    """
+
+    def __init__(self, map_or_text, n_envs, device=None, envs_per_wave=None):
+        _require_gpu()
+        self.map = map_or_text if isinstance(map_or_text, Map) else Map(map_or_text)
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        self.n_envs = int(n_envs)
+        L = _capi.lib()
+        nbytes = L.lle_batch_arena_bytes(self.map.h, self.n_envs)
+        if nbytes <= 0:
+            raise RuntimeError(L.lle_last_error().decode())
+        with torch.cuda.device(self.device):
+            self.arena = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+            skew = (-self.arena.data_ptr()) % 256
+            self._base = self.arena[skew:skew + nbytes]
+            self.h = L.lle_batch_create(self.map.h, self.n_envs, self.device.index or 0, self._base.data_ptr(), nbytes,
+                                        self._stream())
+        if not self.h:
+            raise RuntimeError(f"lle_batch_create failed: {L.lle_last_error().decode()}")
+        if envs_per_wave is not None:
+            self.set_envs_per_wave(envs_per_wave)
+        self._bind()
+        self.t = 0
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"lle_amd C ABI call failed ({rc}): {_capi.lib().lle_last_error().decode()}")
+
+    def _bind(self):
+        L = _capi.lib()
+        m = self.map
+        self._desc = {}
+        for which in range(LLE_BUF_COUNT):
+            d = BufferDesc()
+            self._check(L.lle_batch_get_buffer(self.h, which, C.byref(d)))
+            name = BUFFER_NAMES[which]
+            dt = _TORCH_DTYPES[name]
+            self._desc[name] = (int(d.arena_offset), int(d.bytes), [int(d.shape[k]) for k in range(d.ndim)], int(d.elem_bytes))
+            raw = self._base[d.arena_offset:d.arena_offset + d.bytes]
+            if name == "obs":
+                t = raw.view(torch.int8)[: self.n_envs * m.obs_stride].view(self.n_envs, m.obs_stride)
+                self.obs_rows = t
+                t = t[:, : m.obs_bytes].unflatten(1, (m.n_layers, m.height, m.width))
+            else:
+                shape = [int(d.shape[k]) for k in range(d.ndim)]
+                count = 1
+                for s in shape:
+                    count *= s
+                t = raw[: count * d.elem_bytes].view(dt).view(shape)
+            setattr(self, name, t)
+
+    def __del__(self):
+        h = getattr(self, "h", None)
+        if h:
+            _capi.lib().lle_batch_free(h)
+            self.h = None
+
+    def set_envs_per_wave(self, epw):
+        self._check(_capi.lib().lle_batch_set_envs_per_wave(self.h, int(epw)))
+
+    def kernel_info(self):
+        name = C.create_string_buffer(64)
+        lds, epw = C.c_int32(0), C.c_int32(0)
+        _capi.lib().lle_batch_kernel_info(self.h, name, 64, C.byref(lds), C.byref(epw))
+        return {"kernel": name.value.decode(), "lds_bytes": lds.value, "envs_per_wave": epw.value}
+
+    # ------------------------------------------------------------------ World API, batched
+    @property
+    def n_agents(self):
+        return self.map.n_agents
+
+    def reset(self, env_mask=None):
+        """World.reset for every env (or those with env_mask != 0)."""
+        mp = None
+        if env_mask is not None:
+            env_mask = env_mask.to(self.device, torch.uint8).contiguous()
+            mp = env_mask.data_ptr()
+        self._check(_capi.lib().lle_batch_reset(self.h, mp, self._stream()))
+        self.t = 0
+
+    def step(self, actions=None, sample=False, auto_reset=False, seed=0, t=None, env_offset=0, write_obs=True):
+        """World.step + Layered.observe for every env.
+
+        actions: uint8 tensor [n, A] on the device (Action values), or None with sample=True to draw uniformly from the
+        available actions with the counter-based sampler (seed, env_offset + env, t, agent)."""
+        flags = 0
+        ap = None
+        if sample:
+            flags |= LLE_STEP_SAMPLE_ACTIONS
+        else:
+            if actions is None:
+                raise ValueError("actions is required unless sample=True")
+            if actions.dtype != torch.uint8 or not actions.is_contiguous() or actions.device != self.device:
+                actions = actions.to(self.device, torch.uint8).contiguous()
+            if tuple(actions.shape) != (self.n_envs, self.map.n_agents):
+                raise ValueError(f"Invalid number of actions: given {tuple(actions.shape)}, expected {(self.n_envs, self.map.n_agents)}")
+            ap = actions.data_ptr()
+        if auto_reset:
+            flags |= LLE_STEP_AUTO_RESET
+        if not write_obs:
+            flags |= LLE_STEP_NO_OBS
+        if t is None:
+            t = self.t
+        self._check(_capi.lib().lle_batch_step(self.h, ap, flags, int(seed), int(t), int(env_offset), self._stream()))
+        self.t = t + 1
+
+    def set_state(self, positions, gems_collected, agents_alive):
+        """World.set_state for every env.  positions u8 [n,A,2]; gems_collected bool [n,G]; agents_alive bool [n,A].
+        Per-env result in `err` (0, or LLE_ENV_*), events in `events`/`evcount`."""
+        G, A = self.map.n_gems, self.map.n_agents
+        self.req_pos.copy_(positions.to(self.device, torch.uint8).view(self.n_envs, A, 2))
+        gw = (1 << torch.arange(G, device=self.device, dtype=torch.int64))
+        self.req_gems.copy_((gems_collected.to(self.device, torch.int64).view(self.n_envs, G) * gw).sum(1).to(torch.int32))
+        aw = (1 << torch.arange(A, device=self.device, dtype=torch.int64))
+        self.req_alive.copy_((agents_alive.to(self.device, torch.int64).view(self.n_envs, A) * aw).sum(1).to(torch.int16))
+        self._check(_capi.lib().lle_batch_set_state(self.h, self._stream()))
+
+    def update_sources(self):
+        """Push self.map's current source colours / enabled flags to the device (LaserSource.enable/disable/set_colour)."""
+        self._check(_capi.lib().lle_batch_update_sources(self.h, self.map.h, self._stream()))
+
+    def observe(self):
+        self._check(_capi.lib().lle_batch_observe(self.h, self._stream()))
+        return self.obs
+
+    def stats(self, reset=False):
+        out = (C.c_int64 * 8)()
+        self._check(_capi.lib().lle_batch_stats(self.h, out, int(reset), self._stream()))
+        keys = ["env_steps", "agent_steps", "gems", "exits", "deaths", "invalid", "auto_resets", "reward_sum"]
+        return {k: int(out[i]) for i, k in enumerate(keys)}
+
+    # decoded views (small torch ops, for convenience)
+    def agents_alive(self):
+        return ((self.bits.unsqueeze(1) >> torch.arange(self.map.n_agents, device=self.device)) & 1).bool()
+
+    def agents_arrived(self):
+        return ((self.bits.unsqueeze(1) >> (16 + torch.arange(self.map.n_agents, device=self.device))) & 1).bool()
+
+    def gems_collected(self):
+        return ((self.gems.to(torch.int64).unsqueeze(1) >> torch.arange(self.map.n_gems, device=self.device)) & 1).bool()
+
+    def available_actions(self):
+        """bool [n, A, 5], the layout of LLE.available_actions (python/lle/env/env.py:146-152)."""
+        return ((self.avail.to(torch.int64).unsqueeze(2) >> torch.arange(5, device=self.device)) & 1).bool()
+
+    def observation(self):
+        """(n, A, C, H, W) view of the layered observation: the reference tiles one (C,H,W) slice A times
+        (python/lle/observations.py:266); here it is a broadcast view, not a copy."""
+        return self.obs.unsqueeze(1).expand(-1, self.map.n_agents, -1, -1, -1)
+
+    def host_small_state(self):
+        """One device->host copy of everything except the observation, as numpy arrays in the LLE_BUF_* layout."""
+        import numpy as np
+        lo, hi = self._desc["pos"][0], self._desc["obs"][0]
+        host = self._base[lo:hi].cpu().numpy()
+        np_dt = {"pos": np.uint8, "bits": np.uint64, "gems": np.uint32, "beams": np.uint32, "avail": np.uint8,
+                 "actions": np.uint8, "err": np.uint8, "evcount": np.uint8, "events": np.uint8, "done": np.uint8}
+        out = {}
+        for name, dt in np_dt.items():
+            off, _nbytes, shape, elem = self._desc[name]
+            count = 1
+            for v in shape:
+                count *= v
+            out[name] = host[off - lo: off - lo + count * elem].view(dt).reshape(shape)
+        return out
+
+    def host_buffers(self, names=("pos", "bits", "gems", "beams", "avail", "actions", "err", "evcount", "events", "done", "obs")):
+        """numpy copies in the LLE_BUF_* layout (synchronises)."""
+        torch.cuda.synchronize(self.device)
+        out = {}
+        for nme in names:
+            t = self.obs_rows if nme == "obs" else getattr(self, nme)
+            out[nme] = t.cpu().numpy()
+        import numpy as np
+        if "bits" in out:
+            out["bits"] = out["bits"].view(np.uint64)
+        if "gems" in out:
+            out["gems"] = out["gems"].view(np.uint32)
+        if "beams" in out:
+            out["beams"] = out["beams"].view(np.uint32)
+        return out

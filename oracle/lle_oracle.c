@@ -787,16 +787,18 @@ int ow_layered_obs(ow_world* w, int8_t* obs) {
         if (LASER_0 + b->agent_id >= C) return -1;
         OBS(LASER_0 + b->agent_id, b->source.i, b->source.j) = -1;
     }
-    int n = ow_lasers(w, NULL, 0);
-    int32_t* rows = (int32_t*)malloc(sizeof(int32_t) * 6 * (size_t)(n + 1));
-    ow_lasers(w, rows, n);
-    for (int k = 0; k < n; k++) {
-        if (rows[6 * k + 4]) {
-            if (LASER_0 + rows[6 * k + 3] >= C) { free(rows); return -1; }
-            OBS(LASER_0 + rows[6 * k + 3], rows[6 * k + 0], rows[6 * k + 1]) = 1;
+    /* for laser in world.lasers: outer Laser and, if it directly wraps another Laser, that one (world.rs:159-172) */
+    for (int k = 0; k < w->n_lasers_pos; k++) {
+        pos_t p = w->lasers_positions[k];
+        tile_t* t = at(w, p.i, p.j);
+        tile_t* layers[2] = { t, (t->wrapped->kind == T_LASER) ? t->wrapped : NULL };
+        for (int q = 0; q < 2; q++) {
+            tile_t* l = layers[q];
+            if (!l || !laser_is_on(l)) continue;
+            if (LASER_0 + l->beam->agent_id >= C) return -1;
+            OBS(LASER_0 + l->beam->agent_id, p.i, p.j) = 1;
         }
     }
-    free(rows);
     for (int g = 0; g < w->n_gems; g++)
         if (!gem_at(w, w->gems_positions[g])->collected) OBS(GEM, w->gems_positions[g].i, w->gems_positions[g].j) = 1;
     for (int a = 0; a < A; a++) OBS(a, w->agents_positions[a].i, w->agents_positions[a].j) = 1;
@@ -923,8 +925,10 @@ void ow_batch_dump(ow_batch* b, int64_t e0, int64_t e1, int beam_stride,
 typedef struct { ow_batch* b; int64_t e0, e1; int steps; uint64_t seed; int8_t* obs; int64_t stats[8]; } rollout_job;
 static void* rollout_thread(void* arg) {
     rollout_job* j = (rollout_job*)arg;
+    int64_t stats[8] = {0};  /* thread-local: the job structs of neighbouring threads share cache lines */
     for (int t = 0; t < j->steps; t++)
-        ow_batch_step_range(j->b, j->e0, j->e1, NULL, 1, j->seed, (uint64_t)t, 0, NULL, NULL, NULL, NULL, j->obs, j->stats);
+        ow_batch_step_range(j->b, j->e0, j->e1, NULL, 1, j->seed, (uint64_t)t, 0, NULL, NULL, NULL, NULL, j->obs, stats);
+    for (int q = 0; q < 8; q++) j->stats[q] = stats[q];
     return NULL;
 }
 void ow_batch_rollout(ow_batch* b, int steps, uint64_t seed, int n_threads, int8_t* obs, int64_t* stats_out) {

@@ -1,0 +1,129 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every symbol include/lle_hip.h declares;
+the host-only map functions agree with the oracle's parser; the facade's value types behave like the reference's."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle.levels import LEVELS
+from tests.parity_util import EXTRA_MAPS
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from lle_amd import _capi
+
+    header = open(os.path.join(ROOT, "include", "lle_hip.h")).read()
+    declared = set(re.findall(r"\b(lle_[a-z_0-9]+)\s*\(", header))
+    assert declared, "no declarations found"
+    L = _capi.lib()
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, f"liblle_hip.so lacks {missing}"
+    assert declared == set(_capi.EXPORTS)
+    assert L.lle_abi_version() == 1
+
+
+def test_no_device_fails_loudly():
+    import torch
+
+    from lle_amd import BatchedWorld, World
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        BatchedWorld(LEVELS[1], 4)
+    w = World("S0 . X")  # parsing needs no GPU ...
+    assert w.exit_pos == [(0, 2)]
+    with pytest.raises(RuntimeError, match="no HIP device"):  # ... the dynamics do, and say so
+        w.reset()
+
+
+@pytest.mark.parametrize("name", [f"level{k}" for k in range(1, 7)] + list(EXTRA_MAPS))
+def test_map_compiler_matches_oracle_parser(oracle_mod, name):
+    from lle_amd import _capi
+
+    text = LEVELS[int(name[5:])] if name.startswith("level") else EXTRA_MAPS[name]
+    m = _capi.Map(text)
+    o = oracle_mod.OracleWorld(text)
+    assert (m.height, m.width, m.n_agents, m.n_gems, m.n_sources) == (o.height, o.width, o.n_agents, o.n_gems, o.n_sources)
+    assert m.positions(_capi.LLE_POS_START) == o.start_pos
+    assert m.positions(_capi.LLE_POS_EXIT) == o.exit_pos
+    assert m.positions(_capi.LLE_POS_WALL) == o.wall_pos
+    assert m.positions(_capi.LLE_POS_VOID) == o.void_pos
+    assert m.positions(_capi.LLE_POS_GEM) == o.gem_pos
+    assert [(s.i, s.j, s.direction, s.agent_id, s.enabled, s.length) for s in m.sources()] == o.sources()
+    assert sorted((t.i, t.j, t.laser_id) for t in m.laser_tiles()) == sorted((l[0], l[1], l[2]) for l in o.lasers())
+    assert m.n_layers == 2 * o.n_agents + 4 and m.obs_bytes == m.n_layers * o.height * o.width
+
+
+def test_level_maps_are_12x13():
+    from lle_amd import _capi
+
+    for lvl in range(1, 7):
+        m = _capi.Map(level=lvl)
+        assert (m.height, m.width) == (12, 13)
+    m6 = _capi.Map(level=6)
+    assert (m6.n_agents, m6.n_gems, m6.n_sources, m6.obs_bytes) == (4, 4, 3, 1872)
+    assert sorted(s.length for s in m6.sources()) == [2, 6, 12]
+    with pytest.raises(_capi.MapParseError) as e:
+        _capi.Map(level=7)
+    assert e.value.kind == "InvalidLevel"
+
+
+def test_world_string_roundtrip():
+    from lle_amd import World
+
+    # tests/world_integration_tests.rs:467-479
+    w = World("S0  L0S  X ")
+    assert w.world_string == "S0  L0S  X "
+    w._map.set_source(0, agent_id=1)
+    assert w.world_string == "S0  L1S  X "
+
+
+def test_parse_errors_are_parsing_errors():
+    from lle_amd import InvalidLevelError, ParsingError, World
+
+    for text in ("", "X G", "S0 S0 X X", "S1 S0 X", "X S0 .\n . ."):
+        with pytest.raises(ParsingError):
+            World(text)
+    with pytest.raises(InvalidLevelError):
+        World.level(9)
+    with pytest.raises(FileNotFoundError):
+        World.from_file("/nonexistent/level")
+    assert World.from_file("lvl3").n_agents == 2 and World.from_file("level6").n_agents == 4
+
+
+def test_action_value_type():
+    from lle_amd import Action
+
+    # python/tests/test_actions.py:58-85 (binding's (dx,dy) convention) and src/action.rs:18-26
+    assert [a.value for a in Action.variants()] == [0, 1, 2, 3, 4] and Action.cardinality() == 5
+    assert Action.NORTH.delta == (-1, 0) and Action.SOUTH.delta == (1, 0) and Action.EAST.delta == (0, 1)
+    assert Action.WEST.delta == (0, -1) and Action.STAY.delta == (0, 0)
+    assert Action.from_delta(-1, 0) == Action.WEST and Action.from_delta(0, -1) == Action.NORTH
+    assert Action.from_delta(1, 0) == Action.EAST and Action.from_delta(0, 1) == Action.SOUTH
+    assert Action.NORTH.opposite() == Action.SOUTH and Action.STAY.opposite() == Action.STAY
+    assert Action(2) == Action.EAST
+    with pytest.raises(ValueError):
+        Action(5)
+    with pytest.raises(ValueError):
+        Action.from_delta(1, 1)
+
+
+def test_world_state_value_type():
+    from lle_amd import WorldState
+
+    # python/tests/test_world.py:651-664
+    s = WorldState([(0, 0)], [False])
+    assert list(s.as_array()) == [0.0, 0.0, 0.0, 1.0]
+    assert WorldState.from_array([0.0, 0.0, 0.0, 1.0], 1, 1) == s
+    s = WorldState([(25, 17), (10, 30)], [True, False], agents_alive=[True, False])
+    expected = [25.0, 17.0, 10.0, 30.0, 1.0, 0.0, 1.0, 0.0]
+    assert list(s.as_array()) == expected and s.as_array().dtype == np.float32
+    assert WorldState.from_array(expected, 2, 2) == s
+    # python/tests/test_world.py:395-407
+    assert WorldState([(0, 0)], [False], [True]) != WorldState([(0, 0)], [False], [False])
+    assert hash(WorldState([(0, 0)], [False])) == hash(WorldState([(0, 0)], [False], [True]))
+    assert all(WorldState([(0, 0)], [False]).agents_alive)

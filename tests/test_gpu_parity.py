@@ -1,0 +1,228 @@
+"""Parity proper: BatchedWorld (C ABI -> HIP kernels) vs the CPU oracle on identical action streams, bit-exact for
+state, events (order included), availability masks and the int8 layered observation."""
+import numpy as np
+import pytest
+
+from oracle.levels import LEVELS
+from tests.parity_util import EXTRA_MAPS, assert_state_equal, assert_step_equal, unpack_engine
+
+pytestmark = pytest.mark.gpu
+
+MAPS = {f"level{k}": v for k, v in LEVELS.items()}
+MAPS.update(EXTRA_MAPS)
+
+
+def dims_of(ob):
+    return (ob.A, ob.G, ob.Ls, ob.beam_stride, ob.C, ob.H, ob.W)
+
+
+def check(bw, ob, ostep, where):
+    eng = unpack_engine(bw.host_buffers(), *dims_of(ob))
+    if ostep is not None:
+        assert_step_equal(eng, ostep, where)
+    assert_state_equal(eng, ob.dump(), where)
+
+
+@pytest.mark.parametrize("name", list(MAPS))
+@pytest.mark.parametrize("auto_reset", [False, True])
+def test_random_rollout(oracle_mod, name, auto_reset):
+    from lle_amd import BatchedWorld
+
+    text = MAPS[name]
+    n, steps = 1000, 50  # not a multiple of 64: exercises the ragged last wave
+    ob = oracle_mod.OracleBatch(text, n)
+    bw = BatchedWorld(text, n)
+    check(bw, ob, None, f"{name} after reset")
+    for t in range(steps):
+        bw.step(sample=True, auto_reset=auto_reset, seed=1234, t=t, env_offset=3)
+        ostep = ob.step(None, auto_reset=auto_reset, seed=1234, t=t, env_offset=3)
+        check(bw, ob, ostep, f"{name} t={t}")
+
+
+@pytest.mark.parametrize("epw", [8, 16, 32, 64])
+def test_envs_per_wave_variants(oracle_mod, epw):
+    from lle_amd import BatchedWorld
+
+    n = 777
+    ob = oracle_mod.OracleBatch(LEVELS[6], n)
+    bw = BatchedWorld(LEVELS[6], n, envs_per_wave=epw)
+    for t in range(20):
+        bw.step(sample=True, auto_reset=True, seed=5, t=t)
+        check(bw, ob, ob.step(None, auto_reset=True, seed=5, t=t), f"epw={epw} t={t}")
+
+
+def test_config2_level1_batch4096(oracle_mod):
+    """BASELINE.json configs[1]: level 1, batch 4096, bit-exact."""
+    from lle_amd import BatchedWorld
+
+    n = 4096
+    ob = oracle_mod.OracleBatch(LEVELS[1], n)
+    bw = BatchedWorld(LEVELS[1], n)
+    for t in range(100):
+        bw.step(sample=True, auto_reset=True, seed=1234, t=t)
+        check(bw, ob, ob.step(None, auto_reset=True, seed=1234, t=t), f"t={t}")
+
+
+def test_config3_level6_batch65536(oracle_mod):
+    """BASELINE.json configs[2] at full size: level 6, batch 65536 + layered obs, bit-exact for 12 steps."""
+    from lle_amd import BatchedWorld
+
+    n = 65536
+    ob = oracle_mod.OracleBatch(LEVELS[6], n)
+    bw = BatchedWorld(LEVELS[6], n)
+    for t in range(12):
+        bw.step(sample=True, auto_reset=True, seed=1234, t=t)
+        check(bw, ob, ob.step(None, auto_reset=True, seed=1234, t=t), f"t={t}")
+
+
+def test_explicit_and_invalid_actions(oracle_mod):
+    import torch
+
+    from lle_amd import BatchedWorld
+
+    n = 512
+    ob = oracle_mod.OracleBatch(LEVELS[6], n)
+    bw = BatchedWorld(LEVELS[6], n)
+    rng = np.random.default_rng(0)
+    for t in range(40):
+        actions = rng.integers(0, 6, size=(n, ob.A), dtype=np.uint8)  # unavailable and out-of-range (5) included
+        bw.step(torch.from_numpy(actions).cuda())
+        check(bw, ob, ob.step(actions), f"t={t}")
+
+
+def test_masked_reset(oracle_mod):
+    import torch
+
+    from lle_amd import BatchedWorld
+
+    n = 300
+    ob = oracle_mod.OracleBatch(LEVELS[5], n)
+    bw = BatchedWorld(LEVELS[5], n)
+    for t in range(15):
+        bw.step(sample=True, seed=9, t=t)
+        ob.step(None, seed=9, t=t)
+    mask = (np.arange(n) % 3 == 0)
+    bw.reset(torch.from_numpy(mask.astype(np.uint8)).cuda())
+    for e in np.nonzero(mask)[0]:
+        ob.world(int(e)).reset()
+    check(bw, ob, None, "after masked reset")
+
+
+def test_batched_set_state(oracle_mod):
+    """World.set_state semantics (lossy, with the reference's rollback rules) on random requests."""
+    import torch
+
+    from lle_amd import BatchedWorld
+
+    text = EXTRA_MAPS["nested"]
+    n = 600
+    ob = oracle_mod.OracleBatch(text, n)
+    bw = BatchedWorld(text, n)
+    rng = np.random.default_rng(1)
+    for rnd in range(6):
+        for t in range(5):
+            bw.step(sample=True, seed=rnd, t=t)
+            ob.step(None, seed=rnd, t=t)
+        pos = np.stack([rng.integers(0, ob.H + (rnd == 5), size=(n, ob.A)), rng.integers(0, ob.W, size=(n, ob.A))], axis=-1).astype(np.uint8)
+        gems = rng.integers(0, 2, size=(n, ob.G)).astype(bool)
+        alive = rng.integers(0, 4, size=(n, ob.A)) > 0
+        bw.set_state(torch.from_numpy(pos).cuda(), torch.from_numpy(gems).cuda(), torch.from_numpy(alive).cuda())
+        host = bw.host_buffers()
+        codes = {0: 0, -4: 0x40, -5: 0x41, -6: 0x42}
+        for e in range(n):
+            w = ob.world(e)
+            try:
+                ev = w.set_state([tuple(int(v) for v in p) for p in pos[e]], list(gems[e]), list(alive[e]))
+                rc = 0
+            except oracle_mod.OracleError as ex:
+                rc = {"InvalidWorldState": 0x40, "OutOfWorldPosition": 0x41, "InvalidAgentPosition": 0x42}[ex.kind]
+                ev = []
+            assert int(host["err"][e]) == rc, (e, int(host["err"][e]), rc)
+            cnt = int(host["evcount"][e]) & 0x7F
+            got = [(int(b) >> 4, int(b) & 15) for b in host["events"][e][:cnt]]
+            assert got == ev, (e, got, ev)
+        check(bw, ob, None, f"set_state round {rnd}")
+        bw.observe()
+        eng = unpack_engine(bw.host_buffers(), *dims_of(ob))
+        obs = np.stack([ob.world(e).obs() for e in range(n)])
+        assert np.array_equal(eng["obs"], obs)
+
+
+def test_update_sources(oracle_mod):
+    from lle_amd import BatchedWorld
+
+    text = EXTRA_MAPS["three_beams"]
+    n = 200
+    ob = oracle_mod.OracleBatch(text, n)
+    bw = BatchedWorld(text, n)
+    for t in range(6):
+        bw.step(sample=True, seed=2, t=t)
+        ob.step(None, seed=2, t=t)
+    for (lid, en, col) in [(0, False, None), (1, None, 0), (0, True, None), (2, False, 2)]:
+        bw.map.set_source(lid, enabled=en, agent_id=col)
+        bw.update_sources()
+        for e in range(n):
+            ob.world(e).set_source(lid, enabled=en, colour=col)
+        check(bw, ob, None, f"after set_source {lid}")
+        eng = unpack_engine(bw.host_buffers(), *dims_of(ob))
+        obs = np.stack([ob.world(e).obs() for e in range(n)])
+        assert np.array_equal(eng["obs"], obs)
+        for t in range(4):
+            bw.step(sample=True, seed=3 + lid, t=t)
+            check(bw, ob, ob.step(None, seed=3 + lid, t=t), f"steps after set_source {lid}")
+
+
+def test_full_size_properties():
+    """Size-independent properties at BASELINE's full batch (65536): determinism, shard invariance (env_offset),
+    observation consistent with the state it was built from, counters equal to the events emitted."""
+    import torch
+
+    from lle_amd import BatchedWorld
+
+    n = 65536
+    a = BatchedWorld(LEVELS[6], n)
+    lo = BatchedWorld(LEVELS[6], n // 2)
+    hi = BatchedWorld(LEVELS[6], n // 2)
+    ev_total = torch.zeros(3, dtype=torch.int64, device="cuda")
+    for t in range(30):
+        a.step(sample=True, auto_reset=True, seed=77, t=t)
+        lo.step(sample=True, auto_reset=True, seed=77, t=t, env_offset=0)
+        hi.step(sample=True, auto_reset=True, seed=77, t=t, env_offset=n // 2)
+        cnt = (a.evcount & 0x7F).to(torch.int64)
+        valid = torch.arange(a.events.shape[1], device="cuda")[None, :] < cnt[:, None]
+        ty = (a.events >> 4).to(torch.int64)
+        for k in range(3):
+            ev_total[k] += ((ty == k) & valid).sum()
+    for name in ("pos", "bits", "gems", "beams", "avail", "events", "evcount", "obs"):
+        whole = getattr(a, name)
+        parts = torch.cat([getattr(lo, name), getattr(hi, name)], 0)
+        assert torch.equal(whole, parts), name
+    # observation vs state: agent layers hold exactly one 1 at the agent's cell
+    A, H, W = a.map.n_agents, a.map.height, a.map.width
+    pos = a.pos.to(torch.int64)
+    cell = pos[..., 0] * W + pos[..., 1]
+    agent_layers = a.obs[:, :A].reshape(n, A, H * W)
+    assert torch.equal(agent_layers.sum(-1).to(torch.int64), torch.ones(n, A, dtype=torch.int64, device="cuda"))
+    assert torch.all(agent_layers.gather(2, cell.unsqueeze(-1)) == 1)
+    st = a.stats()
+    assert st["env_steps"] == 30 * n and st["agent_steps"] == 30 * n * A
+    assert (st["exits"], st["gems"], st["deaths"]) == tuple(int(v) for v in ev_total.tolist())
+
+
+def test_world_facade_pickle_and_deepcopy():
+    import copy
+    import pickle
+    import random
+
+    from lle_amd import World
+
+    random.seed(0)
+    for lvl in range(1, 7):  # python/tests/test_serialization.py:19-38
+        world = World.level(lvl)
+        world.reset()
+        for _ in range(10):
+            world.step([random.choice(a) for a in world.available_actions()])
+            clone = pickle.loads(pickle.dumps(world))
+            assert clone.get_state() == world.get_state()
+            assert clone.wall_pos == world.wall_pos and clone.exit_pos == world.exit_pos
+        assert copy.deepcopy(world).get_state() == world.get_state()
