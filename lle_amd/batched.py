@@ -86,7 +86,7 @@ class BatchedWorld:
                 for s in shape:
                     count *= s
                 t = raw[: count * d.elem_bytes].view(dt).view(shape)
-            setattr(self, name, t)
+            setattr(self, "stats_blocks" if name == "stats" else name, t)
 
     def __del__(self):
         h = getattr(self, "h", None)

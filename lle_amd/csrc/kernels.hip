@@ -109,8 +109,15 @@ __global__ void __launch_bounds__(64) world_kernel(BatchPtrs P, LaunchArgs K) {
             }
             // availability check: lowest offending agent (world.rs:444-453), before any mutation
 #pragma unroll
-            for (int a = AM - 1; a >= 0; a--)
-                if (a < A && (act[a] > 4u || !((avail[a] >> act[a]) & 1u))) err = (uint32_t)a + 1u;
+            for (int a = AM - 1; a >= 0; a--) {
+                if (a < A) {
+                    // `avail` is the cached list of the reference (world.rs:444-453).  It can only disagree with the
+                    // static walk mask after a failed set_state left it stale (world.rs:588-594 returns before
+                    // recomputing it); the reference would then index out of the grid and panic, we refuse the action.
+                    const uint32_t walk = ((mv.cell_meta[cell_of(s.pos[a], mv.W)] >> 8) & 15u) | 16u;
+                    if (act[a] > 4u || !((avail[a] >> act[a]) & 1u) || !((walk >> act[a]) & 1u)) err = (uint32_t)a + 1u;
+                }
+            }
             if (err == 0) {
                 step_env<AM, LM>(s, act, mv, ev);
                 compute_avail<AM, LM>(s, mv, avail);

@@ -388,8 +388,9 @@ LLE_HD uint8_t set_state_env(Env<AM, LM>& s, const uint32_t (&req_pos)[AM], uint
         for (int a = 0; a < AM; a++) cur_pos[a] = s.pos[a];
         Events<AM> dropped;
         dropped.clear();
-        apply_state<AM, LM, false>(s, cur_pos, s.gems, s.alive, mv, dropped);
-        avail_dirty = true;
+        // the reference `.unwrap()`s this inner call: if the snapshot cannot be restored (a collected gem under a
+        // beam) it panics before compute_available_actions; otherwise the availability lists were recomputed
+        avail_dirty = apply_state<AM, LM, false>(s, cur_pos, s.gems, s.alive, mv, dropped);
         return ENV_INVALID_AGENT_POSITION;
     }
     if (!apply_state<AM, LM, true>(s, req_pos, req_gems, req_alive, mv, ev)) return ENV_INVALID_WORLD_STATE;

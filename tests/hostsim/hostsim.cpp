@@ -71,8 +71,15 @@ static void run(hs_batch* b, int mode, uint32_t flags, uint64_t seed, uint64_t t
                 for (int a = 0; a < AM; a++) act[a] = (a < A) ? (uint32_t)src[env * A + a] : 4u;
             }
             for (int a = 0; a < A; a++) b->actions[env * A + a] = (uint8_t)act[a];
-            for (int a = AM - 1; a >= 0; a--)
-                if (a < A && (act[a] > 4u || !((avail[a] >> act[a]) & 1u))) err = (uint32_t)a + 1u;
+            for (int a = AM - 1; a >= 0; a--) {
+                if (a < A) {
+                    // `avail` is the cached list of the reference (world.rs:444-453).  It can only disagree with the
+                    // static walk mask after a failed set_state left it stale (world.rs:588-594 returns before
+                    // recomputing it); the reference would then index out of the grid and panic, we refuse the action.
+                    const uint32_t walk = ((mv.cell_meta[cell_of(s.pos[a], mv.W)] >> 8) & 15u) | 16u;
+                    if (act[a] > 4u || !((avail[a] >> act[a]) & 1u) || !((walk >> act[a]) & 1u)) err = (uint32_t)a + 1u;
+                }
+            }
             if (err == 0) {
                 step_env<AM, LM>(s, act, mv, ev);
                 compute_avail<AM, LM>(s, mv, avail);

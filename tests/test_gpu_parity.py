@@ -146,6 +146,12 @@ def test_batched_set_state(oracle_mod):
         eng = unpack_engine(bw.host_buffers(), *dims_of(ob))
         obs = np.stack([ob.world(e).obs() for e in range(n)])
         assert np.array_equal(eng["obs"], obs)
+        # a set_state that failed with InvalidWorldState leaves the reference with stale availability lists (its next
+        # step may index out of the grid and panic): such worlds are reset before the rollout goes on
+        poisoned = host["err"] == 0x40
+        bw.reset(torch.from_numpy(poisoned.astype(np.uint8)).cuda())
+        for e in np.nonzero(poisoned)[0]:
+            ob.world(int(e)).reset()
 
 
 def test_update_sources(oracle_mod):

@@ -60,3 +60,43 @@ def test_sampler_matches_oracle(oracle_mod):
 
     for seed, env, t, agent in [(0, 0, 0, 0), (1234, 65535, 99, 3), (2**63, 2**40, 2**33, 15)]:
         assert _capi.lib().lle_action_hash(seed, env, t, agent) == oracle_mod.action_hash(seed, env, t, agent)
+
+
+def test_set_state_random_requests(oracle_mod):
+    """World.set_state (lossy re-derivation + rollback rules) on random, often invalid, requests."""
+    from lle_amd import _decode
+    from tests import hostsim
+    from tests.parity_util import EXTRA_MAPS
+
+    text = EXTRA_MAPS["nested"]
+    n = 300
+    ob = oracle_mod.OracleBatch(text, n)
+    sb = hostsim.SimBatch(text, n)
+    dims = (ob.A, ob.G, ob.Ls, ob.beam_stride, ob.C, ob.H, ob.W)
+    rng = np.random.default_rng(1)
+    codes = {"InvalidWorldState": 0x40, "OutOfWorldPosition": 0x41, "InvalidAgentPosition": 0x42}
+    for rnd in range(8):
+        for t in range(5):
+            sb.step(None, flags=1, seed=rnd, t=t)
+            ob.step(None, seed=rnd, t=t)
+        pos = np.stack([rng.integers(0, ob.H + (rnd >= 6), size=(n, ob.A)), rng.integers(0, ob.W, size=(n, ob.A))], axis=-1).astype(np.uint8)
+        gems = rng.integers(0, 2, size=(n, ob.G)).astype(bool)
+        alive = rng.integers(0, 4, size=(n, ob.A)) > 0
+        sb.buf("req_pos")[:] = pos
+        sb.buf("req_gems")[:] = [_decode.pack_bits(g) for g in gems]
+        sb.buf("req_alive")[:] = [_decode.pack_bits(a) for a in alive]
+        sb.set_state()
+        for e in range(n):
+            try:
+                ev, rc = ob.world(e).set_state([tuple(int(v) for v in p) for p in pos[e]], list(gems[e]), list(alive[e])), 0
+            except oracle_mod.OracleError as ex:
+                ev, rc = [], codes[ex.kind]
+            assert int(sb.buf("err")[e]) == rc, (e, int(sb.buf("err")[e]), rc)
+            assert _decode.events_list(sb.buf("evcount")[e], sb.buf("events")[e]) == ev
+        assert_state_equal(unpack_engine(sim_bufs(sb), *dims), ob.dump(), f"set_state round {rnd}")
+        # a set_state that failed with InvalidWorldState leaves the reference with stale availability lists (its next
+        # step may index out of the grid and panic): such worlds are reset before the rollout goes on
+        poisoned = (sb.buf("err") == 0x40).astype(np.uint8)
+        sb.L.hs_reset(sb.h, poisoned.ctypes.data)
+        for e in np.nonzero(poisoned)[0]:
+            ob.world(int(e)).reset()
