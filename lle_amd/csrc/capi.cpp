@@ -69,7 +69,7 @@ Layout make_layout(const MapHeader& h, int64_t n) {
     sz[LLE_BUF_REQ_ALIVE] = n_pad * 2;
     int64_t off = 0;
     l.off_tables = off;
-    off = align_up(off + h.blob_bytes);
+    off = align_up(off + h.blob_capacity);
     for (int k = 0; k < LLE_BUF_COUNT; k++) {
         l.off[k] = off;
         l.bytes[k] = sz[k];
@@ -239,7 +239,9 @@ static int create_impl(lle_batch* b, const lle_map* map, void* arena, int64_t ar
         return fail(LLE_ERR_NO_DEVICE, "no HIP device: lle_amd has no CPU execution path");
     if (b->device < 0 || b->device >= n_dev) return fail(LLE_ERR_ARG, "device_id out of range");
     HIP_TRY(hipSetDevice(b->device));
-    const uint32_t lds = kernel_lds_bytes(b->hdr);
+    MapHeader worst = b->hdr;
+    worst.lds_table_bytes += worst.blob_capacity - worst.blob_bytes;
+    const uint32_t lds = kernel_lds_bytes(worst);
     if (lds > 64 * 1024) return fail(LLE_ERR_UNSUPPORTED, "map tables need " + std::to_string(lds) + " B of LDS per wave (> 64 KiB)");
     b->layout = make_layout(b->hdr, b->n_envs);
     if (arena) {
@@ -274,7 +276,9 @@ lle_batch* lle_batch_create(const lle_map* map, int64_t n_envs, int device_id, v
     b->device = device_id;
     b->arena = nullptr;
     b->owns_arena = false;
-    b->envs_per_wave = 64;
+    // enough waves to cover the 256 CUs several times over, at most 32 envs per wave (measured best on level 6)
+    b->envs_per_wave = 32;
+    while (b->envs_per_wave > MIN_ENVS_PER_WAVE && n_envs / b->envs_per_wave < 2048) b->envs_per_wave /= 2;
     if (create_impl(b, map, arena, arena_bytes, stream) != LLE_OK) {
         if (b->owns_arena && b->arena) (void)hipFree(b->arena);
         delete b;
@@ -350,7 +354,8 @@ int lle_batch_observe(lle_batch* b, void* stream) {
 int lle_batch_update_sources(lle_batch* b, const lle_map* map, void* stream) {
     if (!b || !map) return fail(LLE_ERR_NULL, "NULL argument");
     const MapHeader& nh = map->m.header;
-    if (nh.H != b->hdr.H || nh.W != b->hdr.W || nh.A != b->hdr.A || nh.L != b->hdr.L || nh.blob_bytes != b->hdr.blob_bytes)
+    if (nh.H != b->hdr.H || nh.W != b->hdr.W || nh.A != b->hdr.A || nh.L != b->hdr.L || nh.G != b->hdr.G ||
+        nh.blob_capacity != b->hdr.blob_capacity || nh.blob_bytes > nh.blob_capacity)
         return fail(LLE_ERR_ARG, "map does not match the batch");
     HIP_TRY(hipSetDevice(b->device));
     LaunchArgs K{};

@@ -356,6 +356,8 @@ void Map::compile() {
     h.off_dyn = (uint32_t)off; off = align16(off + dyn_tab.size() * 8);
     h.off_template = (uint32_t)off; off = align16(off + tmpl.size());
     h.blob_bytes = (uint32_t)off;
+    // recolouring can split merged dyn entries: at most one per exposed laser tile plus one per gem
+    h.blob_capacity = (uint32_t)align16(off + ((size_t)n_laser_tiles() + (size_t)G - dyn_tab.size()) * 8);
     h.lds_table_bytes = h.blob_bytes - h.off_cell_lay;
     blob.assign(off, 0);
     std::memcpy(blob.data() + h.off_cell_lay, cell_lay.data(), cell_lay.size() * 8);

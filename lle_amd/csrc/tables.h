@@ -47,7 +47,8 @@ struct MapHeader {
     uint32_t lds_table_bytes;  // bytes [off_cell_lay, blob_bytes) copied to LDS
     uint32_t obs_supported;
     uint32_t direct_gems;    // bit g: gem g is a direct Tile::Gem (no laser layer on its cell)
-    uint32_t pad0, pad1;
+    uint32_t blob_capacity;  // blob_bytes with the largest possible dyn table (any recolouring of the sources fits)
+    uint32_t pad1;
     uint16_t start[MAX_AGENTS];        // start cell of each agent, i | j << 8
     uint32_t beam_full[MAX_SOURCES];   // (1 << len) - 1
     uint8_t beam_len[MAX_SOURCES];
