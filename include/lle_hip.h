@@ -193,7 +193,8 @@ int lle_batch_observe(lle_batch* b, void* stream);
  * out[0] env_steps, [1] agent_steps, [2] gems, [3] exits, [4] deaths, [5] invalid, [6] auto_resets, [7] reward_sum */
 int lle_batch_stats(lle_batch* b, int64_t out[8], int reset_counters, void* stream);
 
-/* The sampler used by LLE_STEP_SAMPLE_ACTIONS (host copy, for harnesses). */
+/* The sampler used by LLE_STEP_SAMPLE_ACTIONS (host copy, for harnesses): the 16-bit field f of (seed, env, t, agent);
+ * the action taken is the k-th available one in enum order with k = (f * popcount(avail)) >> 16.  See DESIGN.md. */
 uint64_t lle_action_hash(uint64_t seed, uint64_t env, uint64_t t, uint64_t agent);
 
 int lle_abi_version(void);
@@ -201,7 +202,7 @@ int lle_last_status(void);
 const char* lle_last_error(void);
 /* Name + dynamic-LDS bytes + envs-per-wave of the step kernel a batch launches (for profiling reports). */
 int lle_batch_kernel_info(const lle_batch* b, char* name_buf, size_t cap, int32_t* lds_bytes, int32_t* envs_per_wave);
-/* Tuning knob: environments per wavefront in the step kernel (power of two, 1..64). */
+/* Tuning knob: environments per wavefront in the step kernel (8, 16, 32 or 64). */
 int lle_batch_set_envs_per_wave(lle_batch* b, int envs_per_wave);
 
 #ifdef __cplusplus

@@ -5,6 +5,7 @@
 // dynamic entry point needs a HIP device and fails loudly without one.
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -42,6 +43,7 @@ struct Layout {
     int64_t off[LLE_BUF_COUNT];
     int64_t bytes[LLE_BUF_COUNT];
     int64_t off_tables;
+    int64_t off_init;
     int64_t total;
     int64_t n_stat_blocks;
 };
@@ -49,7 +51,7 @@ struct Layout {
 Layout make_layout(const MapHeader& h, int64_t n) {
     Layout l{};
     const int64_t A = h.A, L = h.L;
-    const int64_t n_pad = (n + 63) / 64 * 64;
+    const int64_t n_pad = (n + 1 + 63) / 64 * 64;  // + one hidden env (slot n) used to compute the reset state on the device
     l.n_stat_blocks = (n + MIN_ENVS_PER_WAVE - 1) / MIN_ENVS_PER_WAVE;
     int64_t sz[LLE_BUF_COUNT];
     sz[LLE_BUF_POS] = n_pad * A * 2;
@@ -70,6 +72,8 @@ Layout make_layout(const MapHeader& h, int64_t n) {
     int64_t off = 0;
     l.off_tables = off;
     off = align_up(off + h.blob_capacity);
+    l.off_init = off;
+    off = align_up(off + (int64_t)sizeof(InitRecord));
     for (int k = 0; k < LLE_BUF_COUNT; k++) {
         l.off[k] = off;
         l.bytes[k] = sz[k];
@@ -98,7 +102,7 @@ int lle_last_status(void) { return g_status; }
 const char* lle_last_error(void) { return g_error.c_str(); }
 
 uint64_t lle_action_hash(uint64_t seed, uint64_t env, uint64_t t, uint64_t agent) {
-    return action_hash_agent(action_hash_env(seed, env, t), agent);
+    return action_field(action_hash_group(action_hash_env(seed, env, t), agent >> 2), (uint32_t)agent);
 }
 
 // ------------------------------------------------------------------------------------------------ maps
@@ -208,6 +212,7 @@ static void bind_ptrs(lle_batch* b) {
     const Layout& l = b->layout;
     BatchPtrs& p = b->ptrs;
     p.tables = base + l.off_tables;
+    p.init = reinterpret_cast<const InitRecord*>(base + l.off_init);
     p.pos = reinterpret_cast<uint16_t*>(base + l.off[LLE_BUF_POS]);
     p.bits = reinterpret_cast<uint64_t*>(base + l.off[LLE_BUF_BITS]);
     p.gems = reinterpret_cast<uint32_t*>(base + l.off[LLE_BUF_GEMS]);
@@ -228,8 +233,31 @@ static void bind_ptrs(lle_batch* b) {
 
 static int launch(lle_batch* b, int mode, LaunchArgs K, void* stream) {
     K.envs_per_wave = b->envs_per_wave;
+    K.env_base = 0;
+    K.env_limit = b->n_envs;
     HIP_TRY(launch_world_kernel(mode, b->hdr, b->ptrs, K, (hipStream_t)stream));
     g_status = LLE_OK;
+    return LLE_OK;
+}
+
+// World::reset is deterministic for v1 maps, so its result is the same for every env: run it once on the hidden env
+// (slot n_envs) with the current tables and keep the result as the InitRecord the auto-reset path copies from.
+static int refresh_init_record(lle_batch* b, void* stream) {
+    LaunchArgs K{};
+    K.envs_per_wave = MIN_ENVS_PER_WAVE;
+    K.env_base = b->n_envs;
+    K.env_limit = b->n_envs + 1;
+    K.flags = STEP_NO_OBS;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(launch_world_kernel(KMODE_RESET, b->hdr, b->ptrs, K, st));
+    uint8_t* rec = b->arena + b->layout.off_init;
+    const int64_t n = b->n_envs, A = b->hdr.A, L = b->hdr.L;
+    HIP_TRY(hipMemcpyAsync(rec + offsetof(InitRecord, pos), b->ptrs.pos + n * A, (size_t)A * 2, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(rec + offsetof(InitRecord, bits), b->ptrs.bits + n, 8, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(rec + offsetof(InitRecord, gems), b->ptrs.gems + n, 4, hipMemcpyDeviceToDevice, st));
+    if (L > 0)
+        HIP_TRY(hipMemcpyAsync(rec + offsetof(InitRecord, beams), b->ptrs.beams + n * L, (size_t)L * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(rec + offsetof(InitRecord, avail), b->ptrs.avail + n * A, (size_t)A, hipMemcpyDeviceToDevice, st));
     return LLE_OK;
 }
 
@@ -262,6 +290,8 @@ static int create_impl(lle_batch* b, const lle_map* map, void* arena, int64_t ar
                            (size_t)(b->layout.total - b->layout.off[LLE_BUF_STATS]), st));
     HIP_TRY(hipMemcpyAsync(b->arena + b->layout.off_tables, map->m.blob.data(), map->m.blob.size(), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));  // the blob is a host vector: make the copy complete before returning
+    int rc = refresh_init_record(b, stream);
+    if (rc != LLE_OK) return rc;
     LaunchArgs K{};
     return launch(b, KMODE_RESET, K, stream);
 }
@@ -364,6 +394,8 @@ int lle_batch_update_sources(lle_batch* b, const lle_map* map, void* stream) {
     HIP_TRY(hipMemcpyAsync(b->arena + b->layout.off_tables, map->m.blob.data(), map->m.blob.size(), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
     b->hdr = nh;
+    int rc = refresh_init_record(b, stream);
+    if (rc != LLE_OK) return rc;
     return launch(b, KMODE_SOURCES, K, stream);
 }
 

@@ -20,6 +20,16 @@ namespace lle {
 
 enum Mode : int { MODE_STEP = 0, MODE_RESET = 1, MODE_SET_STATE = 2, MODE_OBSERVE = 3, MODE_SOURCES = 4 };
 
+// The workgroup IS one wavefront, and a wave's LDS operations execute in issue order, so lanes of the wave may hand
+// data to each other through LDS without `s_barrier` and without the `s_waitcnt vmcnt(0)` that `__syncthreads()`
+// emits (which would stall every environment of phase 2 on the completion of the previous environment's global
+// stores).  wave_sync() only pins the compiler's ordering.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
@@ -30,16 +40,74 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
     return v;
 }
 
+// ---- per-env record I/O.  When the map has exactly AM agents the record of an env is a whole number of dwords and
+// moves as dwords (the compiler merges neighbours into dwordx2/x4); otherwise element by element.
+template <int AM>
+__device__ __forceinline__ void load_u16s(const uint16_t* __restrict__ base, int64_t env, int A, uint32_t (&out)[AM], uint32_t fill) {
+    if (A == AM && AM % 2 == 0) {
+        const uint32_t* __restrict__ w = reinterpret_cast<const uint32_t*>(base) + env * (AM / 2);
+#pragma unroll
+        for (int k = 0; k < AM / 2; k++) { const uint32_t v = w[k]; out[2 * k] = v & 0xFFFFu; out[2 * k + 1] = v >> 16; }
+    } else {
+#pragma unroll
+        for (int a = 0; a < AM; a++) out[a] = (a < A) ? (uint32_t)base[env * A + a] : fill + (uint32_t)a;
+    }
+}
+template <int AM>
+__device__ __forceinline__ void store_u16s(uint16_t* __restrict__ base, int64_t env, int A, const uint32_t (&v)[AM]) {
+    if (A == AM && AM % 2 == 0) {
+        uint32_t* __restrict__ w = reinterpret_cast<uint32_t*>(base) + env * (AM / 2);
+#pragma unroll
+        for (int k = 0; k < AM / 2; k++) w[k] = (v[2 * k] & 0xFFFFu) | (v[2 * k + 1] << 16);
+    } else {
+#pragma unroll
+        for (int a = 0; a < AM; a++)
+            if (a < A) base[env * A + a] = (uint16_t)v[a];
+    }
+}
+template <int AM>
+__device__ __forceinline__ void load_u8s(const uint8_t* __restrict__ base, int64_t env, int A, uint32_t (&out)[AM], uint32_t fill) {
+    if (A == AM && AM % 4 == 0) {
+        const uint32_t* __restrict__ w = reinterpret_cast<const uint32_t*>(base) + env * (AM / 4);
+#pragma unroll
+        for (int k = 0; k < AM / 4; k++) {
+            const uint32_t v = w[k];
+#pragma unroll
+            for (int q = 0; q < 4; q++) out[4 * k + q] = (v >> (8 * q)) & 0xFFu;
+        }
+    } else {
+#pragma unroll
+        for (int a = 0; a < AM; a++) out[a] = (a < A) ? (uint32_t)base[env * A + a] : fill;
+    }
+}
+template <int AM>
+__device__ __forceinline__ void store_u8s(uint8_t* __restrict__ base, int64_t env, int A, const uint32_t (&v)[AM]) {
+    if (A == AM && AM % 4 == 0) {
+        uint32_t* __restrict__ w = reinterpret_cast<uint32_t*>(base) + env * (AM / 4);
+#pragma unroll
+        for (int k = 0; k < AM / 4; k++)
+            w[k] = (v[4 * k] & 0xFFu) | ((v[4 * k + 1] & 0xFFu) << 8) | ((v[4 * k + 2] & 0xFFu) << 16) | (v[4 * k + 3] << 24);
+    } else {
+#pragma unroll
+        for (int a = 0; a < AM; a++)
+            if (a < A) base[env * A + a] = (uint8_t)v[a];
+    }
+}
+
 template <int AM, int LM, int MODE>
-__global__ void __launch_bounds__(64) world_kernel(BatchPtrs P, LaunchArgs K) {
+__global__ void __launch_bounds__(64) world_kernel(BatchPtrs P, LaunchArgs K, MapHeader H) {
+    // H travels in the kernel-argument segment: the uniform map constants are there before the first instruction,
+    // instead of behind a dependent scalar load from the table blob.
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const MapHeader* __restrict__ hdr = reinterpret_cast<const MapHeader*>(P.tables);
+    const MapHeader* __restrict__ hdr = &H;
     const uint32_t lane = threadIdx.x;
     const int A = (int)hdr->A, L = (int)hdr->L;
     const uint32_t epw = K.envs_per_wave;
-    const int64_t env0 = (int64_t)blockIdx.x * epw;
+    const int64_t env0 = K.env_base + (int64_t)blockIdx.x * epw;
     const int64_t env = env0 + lane;
-    const bool active = lane < epw && env < P.n_envs;
+    const bool active = lane < epw && env < K.env_limit;
+    const bool write_obs = hdr->obs_supported && !(K.flags & STEP_NO_OBS);
+    const int64_t n_here = (K.env_limit - env0) < (int64_t)epw ? (K.env_limit - env0) : (int64_t)epw;
 
     // ---- static tables -> LDS (the wave's private copy; section offsets are those of the blob)
     const uint32_t tab_bytes = hdr->lds_table_bytes, tab_off = hdr->off_cell_lay;
@@ -53,8 +121,9 @@ __global__ void __launch_bounds__(64) world_kernel(BatchPtrs P, LaunchArgs K) {
     const uint64_t* dyn = reinterpret_cast<const uint64_t*>(lds + (hdr->off_dyn - tab_off));
     int8_t* tmpl = reinterpret_cast<int8_t*>(lds + (hdr->off_template - tab_off));
     uint32_t* scratch = reinterpret_cast<uint32_t*>(lds + tab_bytes);
-    const uint32_t scr_stride = (uint32_t)(L + A + 1) | 1u;  // odd: lanes spread over banks
-    __syncthreads();
+    const uint32_t scr_stride = (uint32_t)(L + A + 2) | 1u;  // odd: lanes spread over banks
+    const uint64_t obs_stride = hdr->obs_stride;
+    wave_sync();
 
     MapView mv;
     mv.cell_lay = cell_lay; mv.cell_meta = cell_meta; mv.hdr = hdr;
@@ -63,49 +132,61 @@ __global__ void __launch_bounds__(64) world_kernel(BatchPtrs P, LaunchArgs K) {
     const uint32_t amask = (1u << A) - 1u;
     uint64_t stat1 = 0, stat2 = 0;  // packed per-env counters, summed over the wave below
 
+    // the env's packed state
+    Env<AM, LM> s;
+    uint32_t avail[AM];
     if (active) {
-        Env<AM, LM> s;
-#pragma unroll
-        for (int a = 0; a < AM; a++) s.pos[a] = (a < A) ? (uint32_t)P.pos[env * A + a] : 0xFFFF0000u + (uint32_t)a;
-        {
-            const uint64_t bits = P.bits[env];
-            s.alive = (uint32_t)bits & 0xFFFFu; s.arrived = (uint32_t)(bits >> 16) & 0xFFFFu; s.occ = (uint32_t)(bits >> 32) & 0xFFFFu;
-        }
+        load_u16s<AM>(P.pos, env, A, s.pos, 0xFFFF0000u);
+        const uint64_t bits = P.bits[env];
+        s.alive = (uint32_t)bits & 0xFFFFu; s.arrived = (uint32_t)(bits >> 16) & 0xFFFFu; s.occ = (uint32_t)(bits >> 32) & 0xFFFFu;
         s.gems = P.gems[env];
 #pragma unroll
         for (int b = 0; b < LM; b++) s.beams[b] = (b < L) ? P.beams[env * L + b] : 0u;
+        if (MODE == MODE_STEP) load_u8s<AM>(P.avail, env, A, avail, 0u);
+    }
 
+    if (active) {
         bool store_state = true, store_avail = false, touched = true;
-        uint32_t avail[AM];
         Events<AM> ev;
         ev.clear();
         uint32_t err = 0, was_reset = 0;
 
         if (MODE == MODE_STEP) {
+            if (K.flags & STEP_AUTO_RESET) {
+                // a finished env restarts from the reset state: identical for every env of the map, computed once on
+                // the device into P.init (uniform scalar loads + selects instead of re-running World::reset per lane)
+                const bool over = s.alive != amask || s.arrived == amask;
+                const InitRecord* __restrict__ in0 = P.init;
+                const uint64_t ib = in0->bits;
 #pragma unroll
-            for (int a = 0; a < AM; a++) avail[a] = (a < A) ? (uint32_t)P.avail[env * A + a] : 0u;
-            if ((K.flags & STEP_AUTO_RESET) && (s.alive != amask || s.arrived == amask)) {
-                reset_env<AM, LM>(s, mv);
-                compute_avail<AM, LM>(s, mv, avail);
-                was_reset = 1;
+                for (int a = 0; a < AM; a++) {
+                    if (a < A) {
+                        s.pos[a] = over ? (uint32_t)in0->pos[a] : s.pos[a];
+                        avail[a] = over ? (uint32_t)in0->avail[a] : avail[a];
+                    }
+                }
+                s.alive = over ? ((uint32_t)ib & 0xFFFFu) : s.alive;
+                s.arrived = over ? ((uint32_t)(ib >> 16) & 0xFFFFu) : s.arrived;
+                s.occ = over ? ((uint32_t)(ib >> 32) & 0xFFFFu) : s.occ;
+                s.gems = over ? in0->gems : s.gems;
+#pragma unroll
+                for (int b = 0; b < LM; b++)
+                    if (b < L) s.beams[b] = over ? in0->beams[b] : s.beams[b];
+                was_reset = over ? 1u : 0u;
             }
             uint32_t act[AM];
             if (K.flags & STEP_SAMPLE_ACTIONS) {
                 const uint64_t he = action_hash_env(K.seed, (uint64_t)(K.env_offset + env), K.t);
+                uint64_t hg = 0;
 #pragma unroll
-                for (int a = 0; a < AM; a++) act[a] = (a < A) ? sample_action(avail[a], action_hash_agent(he, (uint64_t)a)) : 4u;
-#pragma unroll
-                for (int a = 0; a < AM; a++)
-                    if (a < A) P.actions[env * A + a] = (uint8_t)act[a];
-            } else {
-                const uint8_t* __restrict__ src = K.actions_in ? K.actions_in : P.actions;
-#pragma unroll
-                for (int a = 0; a < AM; a++) act[a] = (a < A) ? (uint32_t)src[env * A + a] : 4u;
-                if (K.actions_in) {
-#pragma unroll
-                    for (int a = 0; a < AM; a++)
-                        if (a < A) P.actions[env * A + a] = (uint8_t)act[a];
+                for (int a = 0; a < AM; a++) {
+                    if ((a & 3) == 0 && a < A) hg = action_hash_group(he, (uint64_t)(a >> 2));
+                    act[a] = (a < A) ? sample_action(avail[a], action_field(hg, (uint32_t)a)) : 4u;
                 }
+                store_u8s<AM>(P.actions, env, A, act);
+            } else {
+                load_u8s<AM>(K.actions_in ? K.actions_in : P.actions, env, A, act, 4u);
+                if (K.actions_in) store_u8s<AM>(P.actions, env, A, act);
             }
             // availability check: lowest offending agent (world.rs:444-453), before any mutation
 #pragma unroll
@@ -115,7 +196,8 @@ __global__ void __launch_bounds__(64) world_kernel(BatchPtrs P, LaunchArgs K) {
                     // static walk mask after a failed set_state left it stale (world.rs:588-594 returns before
                     // recomputing it); the reference would then index out of the grid and panic, we refuse the action.
                     const uint32_t walk = ((mv.cell_meta[cell_of(s.pos[a], mv.W)] >> 8) & 15u) | 16u;
-                    if (act[a] > 4u || !((avail[a] >> act[a]) & 1u) || !((walk >> act[a]) & 1u)) err = (uint32_t)a + 1u;
+                    const bool bad = act[a] > 4u || !(((avail[a] & walk) >> (act[a] & 7u)) & 1u);
+                    err = bad ? (uint32_t)a + 1u : err;
                 }
             }
             if (err == 0) {
@@ -137,8 +219,7 @@ __global__ void __launch_bounds__(64) world_kernel(BatchPtrs P, LaunchArgs K) {
             }
         } else if (MODE == MODE_SET_STATE) {
             uint32_t rp[AM];
-#pragma unroll
-            for (int a = 0; a < AM; a++) rp[a] = (a < A) ? (uint32_t)P.req_pos[env * A + a] : 0xFFFF0000u + (uint32_t)a;
+            load_u16s<AM>(P.req_pos, env, A, rp, 0xFFFF0000u);
             bool dirty = false;
             err = set_state_env<AM, LM>(s, rp, P.req_gems[env], (uint32_t)P.req_alive[env], mv, ev, dirty);
             if (err != 0) ev.clear();
@@ -158,55 +239,56 @@ __global__ void __launch_bounds__(64) world_kernel(BatchPtrs P, LaunchArgs K) {
         }
 
         if (store_state) {
-#pragma unroll
-            for (int a = 0; a < AM; a++)
-                if (a < A) P.pos[env * A + a] = (uint16_t)s.pos[a];
+            store_u16s<AM>(P.pos, env, A, s.pos);
             P.bits[env] = (uint64_t)s.alive | ((uint64_t)s.arrived << 16) | ((uint64_t)s.occ << 32);
             P.gems[env] = s.gems;
 #pragma unroll
             for (int b = 0; b < LM; b++)
                 if (b < L) P.beams[env * L + b] = s.beams[b];
         }
-        if (store_avail) {
-#pragma unroll
-            for (int a = 0; a < AM; a++)
-                if (a < A) P.avail[env * A + a] = (uint8_t)avail[a];
-        }
+        if (store_avail) store_u8s<AM>(P.avail, env, A, avail);
         if ((MODE == MODE_STEP || MODE == MODE_RESET || MODE == MODE_SET_STATE) && touched) {
             P.err[env] = (uint8_t)err;
             P.evcount[env] = (uint8_t)(ev.n | (was_reset << 7));
+            if (A == AM && AM % 4 == 0) {
+                uint32_t* __restrict__ w = reinterpret_cast<uint32_t*>(P.events) + env * (AM / 2);
 #pragma unroll
-            for (int k = 0; k < 2 * AM; k++)
-                if (k < 2 * A) P.events[env * 2 * A + k] = (uint8_t)(ev.w[k >> 3] >> ((k & 7) * 8));
+                for (int k = 0; k < AM / 2; k++) w[k] = (uint32_t)(ev.w[k >> 1] >> ((k & 1) * 32));
+            } else {
+#pragma unroll
+                for (int k = 0; k < 2 * AM; k++)
+                    if (k < 2 * A) P.events[env * 2 * A + k] = (uint8_t)(ev.w[k >> 3] >> ((k & 7) * 8));
+            }
             P.done[env] = (s.alive != amask || s.arrived == amask) ? 1 : 0;
         }
 
-        // hand the dynamic state to phase 2
+        // hand the dynamic state to phase 2: [0 | beam masks | ~gem bits | byte index of each agent in the observation]
         uint32_t* sc = scratch + lane * scr_stride;
+        sc[0] = 0u;
 #pragma unroll
         for (int b = 0; b < LM; b++)
-            if (b < L) sc[b] = s.beams[b];
-        sc[L] = s.gems;
+            if (b < L) sc[1 + b] = s.beams[b];
+        sc[L + 1] = ~s.gems;
 #pragma unroll
         for (int a = 0; a < AM; a++)
-            if (a < A) sc[L + 1 + a] = (uint32_t)a * hdr->HW + cell_of(s.pos[a], mv.W);
+            if (a < A) sc[L + 2 + a] = (uint32_t)a * hdr->HW + cell_of(s.pos[a], mv.W);
 
         if (MODE == MODE_STEP) {
-            uint32_t n_gem = 0, n_exit = 0, n_died = 0;
+            // event bytes are type << 4 | agent: DIED sets bit 5, GEM bit 4, EXIT neither
+            uint32_t n_died = 0, n_gem = 0;
 #pragma unroll
-            for (int k = 0; k < 2 * AM; k++) {
-                if ((uint32_t)k < ev.n) {
-                    const uint32_t ty = ((uint32_t)(ev.w[k >> 3] >> ((k & 7) * 8)) >> 4) & 3u;
-                    n_gem += ty == EV_GEM; n_exit += ty == EV_EXIT; n_died += ty == EV_DIED;
-                }
+            for (int k = 0; k < Events<AM>::NW; k++) {
+                n_died += (uint32_t)__popcll(ev.w[k] & 0x2020202020202020ull);
+                n_gem += (uint32_t)__popcll(ev.w[k] & 0x1010101010101010ull);
             }
+            const uint32_t n_exit = ev.n - n_died - n_gem;
             const uint32_t bonus = (err == 0 && s.arrived == amask) ? 1u : 0u;
             stat1 = (uint64_t)n_gem | ((uint64_t)n_exit << 12) | ((uint64_t)n_died << 24) |
                     ((uint64_t)(err != 0) << 36) | ((uint64_t)was_reset << 48);
             stat2 = 1ull | ((uint64_t)bonus << 12);
         }
     }
-    __syncthreads();
+    wave_sync();
 
     if (MODE == MODE_STEP) {
         // per-wave partial counters; the slot of this wave is private, so no atomics
@@ -223,54 +305,71 @@ __global__ void __launch_bounds__(64) world_kernel(BatchPtrs P, LaunchArgs K) {
     }
 
     // ---- phase 2: layered observation, one environment of the wave at a time
-    if (MODE == MODE_STEP && (K.flags & STEP_NO_OBS)) return;
-    if (!hdr->obs_supported) return;
+    if (!write_obs || n_here <= 0) return;
     const uint32_t D = hdr->D, n_chunks = hdr->n_chunks;
-    const uint64_t obs_stride = hdr->obs_stride;
-    const int64_t n_here = (P.n_envs - env0) < (int64_t)epw ? (P.n_envs - env0) : (int64_t)epw;
+    // Each lane serves the same dyn entry for every environment: decode it once.
+    // A laser / gem reference becomes (dword of the hand-over record, bit); an absent one points at the record's
+    // zero word, so the per-environment evaluation is branch-free.
+    const bool has_d0 = lane < D;
+    const uint64_t e0 = has_d0 ? dyn[lane] : 0ull;
+    const uint32_t d0_idx = (uint32_t)e0 & 0xFFFFFu;
+    const int32_t d0_base = (int8_t)(uint8_t)(e0 >> 20);
+    const uint32_t d0_refs = (uint32_t)(e0 >> 28) & 3u, d0_gem = (uint32_t)(e0 >> 50) & 63u;
+    const uint32_t d0_r0 = (uint32_t)(e0 >> 30) & 0x3FFu, d0_r1 = (uint32_t)(e0 >> 40) & 0x3FFu;
+    const uint32_t d0_w0 = d0_refs >= 1 ? 1u + (d0_r0 & 31u) : 0u, d0_s0 = d0_refs >= 1 ? d0_r0 >> 5 : 0u;
+    const uint32_t d0_w1 = d0_refs >= 2 ? 1u + (d0_r1 & 31u) : 0u, d0_s1 = d0_refs >= 2 ? d0_r1 >> 5 : 0u;
+    const uint32_t d0_wg = d0_gem != NO_GEM ? (uint32_t)L + 1u : 0u, d0_sg = d0_gem != NO_GEM ? (d0_gem & 31u) : 0u;
+    const bool is_agent_lane = (int)lane < A;
+    const uint4* srcv = reinterpret_cast<const uint4*>(tmpl);
+
     for (int64_t k = 0; k < n_here; k++) {
         const uint32_t* sc = scratch + (uint32_t)k * scr_stride;
         // (a) bytes that depend on beams / gems
-        for (uint32_t d = lane; d < D; d += 64) {
+        {
+            const uint32_t lit = ((sc[d0_w0] >> d0_s0) | (sc[d0_w1] >> d0_s1) | (sc[d0_wg] >> d0_sg)) & 1u;
+            if (has_d0) tmpl[d0_idx] = (int8_t)(lit ? 1 : d0_base);
+        }
+        for (uint32_t d = lane + 64u; d < D; d += 64) {  // maps with more than 64 dynamic bytes
             const uint64_t e = dyn[d];
-            const uint32_t idx = (uint32_t)e & 0xFFFFFu;
-            int32_t v = (int8_t)(uint8_t)(e >> 20);
-            const uint32_t n_refs = (uint32_t)(e >> 28) & 3u;
+            const uint32_t refs = (uint32_t)(e >> 28) & 3u, gem = (uint32_t)(e >> 50) & 63u;
             const uint32_t r0 = (uint32_t)(e >> 30) & 0x3FFu, r1 = (uint32_t)(e >> 40) & 0x3FFu;
-            const uint32_t gem = (uint32_t)(e >> 50) & 63u;
-            if (n_refs >= 1 && ((sc[r0 & 31u] >> (r0 >> 5)) & 1u)) v = 1;
-            if (n_refs >= 2 && ((sc[r1 & 31u] >> (r1 >> 5)) & 1u)) v = 1;
-            if (gem != NO_GEM && !((sc[L] >> gem) & 1u)) v = 1;
-            tmpl[idx] = (int8_t)v;
+            const uint32_t w0 = refs >= 1 ? 1u + (r0 & 31u) : 0u, w1 = refs >= 2 ? 1u + (r1 & 31u) : 0u;
+            const uint32_t wg = gem != NO_GEM ? (uint32_t)L + 1u : 0u;
+            const uint32_t lit = ((sc[w0] >> (refs >= 1 ? r0 >> 5 : 0u)) | (sc[w1] >> (refs >= 2 ? r1 >> 5 : 0u)) |
+                                  (sc[wg] >> (gem != NO_GEM ? (gem & 31u) : 0u))) & 1u;
+            tmpl[(uint32_t)e & 0xFFFFFu] = (int8_t)(lit ? 1 : (int32_t)(int8_t)(uint8_t)(e >> 20));
         }
         // (b) agents (dead ones included, observations.py:264-265)
-        uint32_t agent_idx = 0;
-        if ((int)lane < A) {
-            agent_idx = sc[L + 1 + lane];
-            tmpl[agent_idx] = 1;
-        }
-        __syncthreads();
-        // (c) stream the patched copy: 16 B per lane, 1 KiB contiguous per wave instruction
+        const uint32_t agent_idx = is_agent_lane ? sc[L + 2 + lane] : 0u;
+        if (is_agent_lane) tmpl[agent_idx] = 1;
+        wave_sync();
+        // (c) stream the patched copy as one contiguous row: 16 B per lane, 1 KiB per wave instruction
         uint4* __restrict__ dst = reinterpret_cast<uint4*>(P.obs + (uint64_t)(env0 + k) * obs_stride);
-        const uint4* srcv = reinterpret_cast<const uint4*>(tmpl);
-        for (uint32_t c = lane; c < n_chunks; c += 64) dst[c] = srcv[c];
-        __syncthreads();
-        // (d) agents off again (their layers are all-zero in the static copy)
-        if ((int)lane < A) tmpl[agent_idx] = 0;
+        {
+            const uint32_t c0 = lane, c1 = lane + 64u;
+            const uint4 v0 = srcv[c0 < n_chunks ? c0 : 0u], v1 = srcv[c1 < n_chunks ? c1 : 0u];
+            if (c0 < n_chunks) dst[c0] = v0;
+            if (c1 < n_chunks) dst[c1] = v1;
+        }
+        for (uint32_t c = lane + 128u; c < n_chunks; c += 64) dst[c] = srcv[c];  // rows longer than 2 KiB
+        wave_sync();
+        // (d) agents off again (their layers are all-zero in the static copy); LDS is in order, so this lands after
+        // the reads above and before the next environment's patches
+        if (is_agent_lane) tmpl[agent_idx] = 0;
     }
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
 template <int AM, int LM>
-static hipError_t launch_mode(int mode, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_blocks, uint32_t lds_bytes,
-                              hipStream_t stream) {
+static hipError_t launch_mode(int mode, const BatchPtrs& P, const LaunchArgs& K, const MapHeader& H, uint32_t n_blocks,
+                              uint32_t lds_bytes, hipStream_t stream) {
     dim3 grid(n_blocks), block(64);
     switch (mode) {
-        case MODE_STEP: hipLaunchKernelGGL((world_kernel<AM, LM, MODE_STEP>), grid, block, lds_bytes, stream, P, K); break;
-        case MODE_RESET: hipLaunchKernelGGL((world_kernel<AM, LM, MODE_RESET>), grid, block, lds_bytes, stream, P, K); break;
-        case MODE_SET_STATE: hipLaunchKernelGGL((world_kernel<AM, LM, MODE_SET_STATE>), grid, block, lds_bytes, stream, P, K); break;
-        case MODE_OBSERVE: hipLaunchKernelGGL((world_kernel<AM, LM, MODE_OBSERVE>), grid, block, lds_bytes, stream, P, K); break;
-        case MODE_SOURCES: hipLaunchKernelGGL((world_kernel<AM, LM, MODE_SOURCES>), grid, block, lds_bytes, stream, P, K); break;
+        case MODE_STEP: hipLaunchKernelGGL((world_kernel<AM, LM, MODE_STEP>), grid, block, lds_bytes, stream, P, K, H); break;
+        case MODE_RESET: hipLaunchKernelGGL((world_kernel<AM, LM, MODE_RESET>), grid, block, lds_bytes, stream, P, K, H); break;
+        case MODE_SET_STATE: hipLaunchKernelGGL((world_kernel<AM, LM, MODE_SET_STATE>), grid, block, lds_bytes, stream, P, K, H); break;
+        case MODE_OBSERVE: hipLaunchKernelGGL((world_kernel<AM, LM, MODE_OBSERVE>), grid, block, lds_bytes, stream, P, K, H); break;
+        case MODE_SOURCES: hipLaunchKernelGGL((world_kernel<AM, LM, MODE_SOURCES>), grid, block, lds_bytes, stream, P, K, H); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -289,19 +388,19 @@ const char* kernel_variant_name(int variant) {
 }
 
 uint32_t kernel_lds_bytes(const MapHeader& h) {
-    const uint32_t scr_stride = (h.L + h.A + 1) | 1u;
+    const uint32_t scr_stride = (h.L + h.A + 2) | 1u;
     return h.lds_table_bytes + 64 * scr_stride * 4 + 64;
 }
 
 hipError_t launch_world_kernel(int mode, const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K, hipStream_t stream) {
     const uint32_t epw = K.envs_per_wave;
-    const uint32_t n_blocks = (uint32_t)((P.n_envs + epw - 1) / epw);
+    const uint32_t n_blocks = (uint32_t)((K.env_limit - K.env_base + epw - 1) / epw);
     const uint32_t lds = kernel_lds_bytes(h);
     switch (kernel_variant((int)h.A, (int)h.L)) {
-        case 0: return launch_mode<4, 4>(mode, P, K, n_blocks, lds, stream);
-        case 1: return launch_mode<8, 8>(mode, P, K, n_blocks, lds, stream);
-        case 2: return launch_mode<16, 16>(mode, P, K, n_blocks, lds, stream);
-        default: return launch_mode<16, 32>(mode, P, K, n_blocks, lds, stream);
+        case 0: return launch_mode<4, 4>(mode, P, K, h, n_blocks, lds, stream);
+        case 1: return launch_mode<8, 8>(mode, P, K, h, n_blocks, lds, stream);
+        case 2: return launch_mode<16, 16>(mode, P, K, h, n_blocks, lds, stream);
+        default: return launch_mode<16, 32>(mode, P, K, h, n_blocks, lds, stream);
     }
 }
 

@@ -250,7 +250,7 @@ int parse_map(const char* text, size_t len, Map& m) {
         if ((int)s.beam.size() > LLE_MAX_BEAM_LEN) return LLE_PARSE_LIMIT;
     for (auto& l : m.cell_layers)
         if ((int)l.size() > MAX_CELL_LAYERS) return LLE_PARSE_LIMIT;  // impossible: one beam per travel direction
-    if ((int64_t)m.n_layers() * HW >= (1 << 20)) return LLE_PARSE_LIMIT;
+    if ((int64_t)m.n_layers() * HW >= (1 << 20)) return LLE_PARSE_LIMIT;  // 16-bit chunk ids, 20-bit byte indices
 
     m.compile();
     return LLE_PARSE_OK;

@@ -37,34 +37,34 @@ LLE_HD uint64_t mix64(uint64_t x) {
     return x;
 }
 // Counter-based action sampler (DESIGN.md "Action stream"): stateless in (seed, env, t, agent).
+// One 64-bit hash serves a group of four agents, 16 bits each; the action is the k-th available one with
+// k = (field16 * popcount(mask)) >> 16, i.e. uniform up to a 2^-16 bias.
 LLE_HD uint64_t action_hash_env(uint64_t seed, uint64_t env, uint64_t t) {
     uint64_t x = seed + 0x9E3779B97F4A7C15ULL * (env + 1);
     x ^= 0xD1B54A32D192ED03ULL * (t + 1);
     return mix64(x);
 }
-LLE_HD uint64_t action_hash_agent(uint64_t env_hash, uint64_t agent) {
-    return mix64(env_hash ^ (0x8CB92BA72F3D8DD7ULL * (agent + 1)));
+LLE_HD uint64_t action_hash_group(uint64_t env_hash, uint64_t group) {
+    return mix64(env_hash + 0x8CB92BA72F3D8DD7ULL * (group + 1));
 }
-// k-th set bit of the 5-bit availability mask in enum order N,S,E,W,STAY, k uniform in [0, popcount)
-LLE_HD uint32_t sample_action(uint32_t mask, uint64_t h) {
-    mask &= 31u;
+LLE_HD uint32_t action_field(uint64_t group_hash, uint32_t agent) { return (uint32_t)(group_hash >> (16u * (agent & 3u))) & 0xFFFFu; }
+
+LLE_HD uint32_t popc5(uint32_t m) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t n = (uint32_t)__popc(mask);
+    return (uint32_t)__popc(m);
 #else
-    uint32_t n = (uint32_t)__builtin_popcount(mask);
+    return (uint32_t)__builtin_popcount(m);
 #endif
-    uint32_t k = (uint32_t)(h >> 33) % n;
+}
+// k-th set bit of the 5-bit availability mask in enum order N,S,E,W,STAY
+LLE_HD uint32_t sample_action(uint32_t mask, uint32_t field16) {
+    mask &= 31u;
+    const uint32_t k = (field16 * popc5(mask)) >> 16;
     uint32_t act = 4;
 #pragma unroll
     for (int b = 4; b >= 0; b--) {
-        // position of the k-th set bit: count set bits below b
-        uint32_t below = mask & ((1u << b) - 1u);
-#if defined(__HIP_DEVICE_COMPILE__)
-        uint32_t r = (uint32_t)__popc(below);
-#else
-        uint32_t r = (uint32_t)__builtin_popcount(below);
-#endif
-        if (((mask >> b) & 1u) && r == k) act = (uint32_t)b;
+        const uint32_t below = popc5(mask & ((1u << b) - 1u));
+        act = (((mask >> b) & 1u) && below == k) ? (uint32_t)b : act;
     }
     return act;
 }
@@ -87,6 +87,9 @@ struct Env {
     uint32_t beams[LM];
 };
 
+// Ordered event list of one step, one byte per event (type << 4 | agent), packed little-endian into 64-bit words.
+// Everything below is written predicated (selects instead of branches): the lanes of a wave are different
+// environments, so a data-dependent `if` costs an exec-mask round trip for every lane.
 template <int AM>
 struct Events {
     static constexpr int NW = (2 * AM + 7) / 8;
@@ -97,12 +100,12 @@ struct Events {
         for (int k = 0; k < NW; k++) w[k] = 0;
         n = 0;
     }
-    LLE_HD void push(uint32_t type, uint32_t agent) {
-        const uint64_t byte = (uint64_t)((type << 4) | agent);
+    LLE_HD void push_if(bool c, uint32_t type, uint32_t agent) {
+        const uint64_t byte = c ? (uint64_t)((type << 4) | agent) : 0ull;
         const uint32_t word = n >> 3, sh = (n & 7u) * 8u;
 #pragma unroll
-        for (int k = 0; k < NW; k++) w[k] |= (word == (uint32_t)k) ? (byte << sh) : 0ull;
-        n++;
+        for (int k = 0; k < NW; k++) w[k] |= (NW == 1 || word == (uint32_t)k) ? (byte << sh) : 0ull;
+        n += c ? 1u : 0u;
     }
 };
 
@@ -116,24 +119,21 @@ LLE_HD uint32_t beam_get(const uint32_t (&b)[LM], uint32_t idx) {
     return r;
 }
 template <int LM>
-LLE_HD void beam_set(uint32_t (&b)[LM], uint32_t idx, uint32_t v) {
+LLE_HD void beam_set_if(uint32_t (&b)[LM], uint32_t idx, bool c, uint32_t v) {
 #pragma unroll
-    for (int k = 0; k < LM; k++) b[k] = (idx == (uint32_t)k) ? v : b[k];
+    for (int k = 0; k < LM; k++) b[k] = (c && idx == (uint32_t)k) ? v : b[k];
 }
 
 // Tile::leave on a laser stack (laser.rs:199-202 -> :157-162 -> :50-55): every layer whose bit is off is
-// re-lit from its offset to the end, unless the source is disabled.
+// re-lit from its offset to the end, unless the source is disabled.  `doit`: the agent is alive (world.rs:483).
 template <int LM>
-LLE_HD void lasers_leave(uint32_t (&beams)[LM], uint64_t lay, const MapView& mv) {
-    for (uint32_t k = 0; k < mv.max_layers; k++) {
+LLE_HD void lasers_leave(uint32_t (&beams)[LM], uint64_t lay, bool doit, const MapView& mv) {
+    for (uint32_t k = 0; k < mv.max_layers; k++) {  // uniform trip count; absent layers are predicated off
         const uint32_t e = (uint32_t)(lay >> (16 * k)) & 0xFFFFu;
-        if (!(e & LAY_VALID)) break;
         const uint32_t b = (e >> 1) & 31u, off = (e >> 6) & 31u;
-        uint32_t m = beam_get<LM>(beams, b);
-        if (!((m >> off) & 1u) && ((mv.enabled >> b) & 1u)) {
-            m |= (0xFFFFFFFFu << off);  // bits beyond the beam length are trimmed by canonicalise()
-            beam_set<LM>(beams, b, m);
-        }
+        const uint32_t m = beam_get<LM>(beams, b);
+        const bool c = doit && (e & LAY_VALID) && !((m >> off) & 1u) && ((mv.enabled >> b) & 1u);
+        beam_set_if<LM>(beams, b, c, m | (0xFFFFFFFFu << off));  // bits beyond the length are trimmed by canonicalise()
     }
 }
 
@@ -141,16 +141,12 @@ LLE_HD void lasers_leave(uint32_t (&beams)[LM], uint64_t lay, const MapView& mv)
 // off from its offset on.  (Order over layers is irrelevant: each layer is a different beam.)
 template <int LM>
 LLE_HD void lasers_pre_enter(uint32_t (&beams)[LM], uint64_t lay, uint32_t agent, bool alive, const MapView& mv) {
-    if (!alive) return;
     for (uint32_t k = 0; k < mv.max_layers; k++) {
         const uint32_t e = (uint32_t)(lay >> (16 * k)) & 0xFFFFu;
-        if (!(e & LAY_VALID)) break;
         const uint32_t b = (e >> 1) & 31u, off = (e >> 6) & 31u, colour = e >> 11;
-        if (colour == agent && ((mv.enabled >> b) & 1u)) {
-            uint32_t m = beam_get<LM>(beams, b);
-            m &= (1u << off) - 1u;
-            beam_set<LM>(beams, b, m);
-        }
+        const bool c = alive && (e & LAY_VALID) && colour == agent && ((mv.enabled >> b) & 1u);
+        const uint32_t m = beam_get<LM>(beams, b);
+        beam_set_if<LM>(beams, b, c, m & ((1u << off) - 1u));
     }
 }
 
@@ -161,71 +157,53 @@ LLE_HD bool lasers_block(const uint32_t (&beams)[LM], uint64_t lay, uint32_t age
     bool blocked = false;
     for (uint32_t k = 0; k < mv.max_layers; k++) {
         const uint32_t e = (uint32_t)(lay >> (16 * k)) & 0xFFFFu;
-        if (!(e & LAY_VALID)) break;
         const uint32_t b = (e >> 1) & 31u, off = (e >> 6) & 31u, colour = e >> 11;
         const uint32_t m = beam_get<LM>(beams, b);
-        blocked |= ((m >> off) & 1u) && (colour != agent);
+        blocked |= (e & LAY_VALID) && ((m >> off) & 1u) && (colour != agent);
     }
     return blocked;
 }
 
 // Tile::enter for agent a at its cell (tile.rs:29-50).  Returns true if the agent died in this call.
+//   blocked by a lit beam of another colour: alive -> dies (AgentDied), dead -> nothing; the wrapped tile is NOT entered.
+//   otherwise the innermost tile takes the agent as occupant; Exit: arrive once (AgentExit, no alive check);
+//   Gem: collect once (GemCollected, no alive check); Void: dies if alive (AgentDied).
 template <int AM, int LM, bool EMIT>
 LLE_HD bool enter_agent(Env<AM, LM>& s, uint32_t a, uint32_t cell, const MapView& mv, Events<AM>& ev) {
     const uint32_t bit = 1u << a;
     const bool is_alive = (s.alive & bit) != 0;
-    if (lasers_block<LM>(s.beams, mv.cell_lay[cell], a, mv)) {
-        if (is_alive) {
-            s.alive &= ~bit;
-            if (EMIT) ev.push(EV_DIED, a);
-            return true;
-        }
-        return false;  // a corpse in a lit beam: nothing happens, the wrapped tile is not entered
-    }
+    const bool blocked = lasers_block<LM>(s.beams, mv.cell_lay[cell], a, mv);
     const uint32_t meta = mv.cell_meta[cell];
     const uint32_t kind = meta & 7u;
-    s.occ |= bit;  // Floor / Exit / Gem / Void all take the agent as occupant
-    if (kind == K_EXIT) {
-        if (!(s.arrived & bit)) {
-            s.arrived |= bit;
-            if (EMIT) ev.push(EV_EXIT, a);
-        }
-    } else if (kind == K_GEM) {
-        const uint32_t g = 1u << ((meta >> 3) & 31u);
-        if (!(s.gems & g)) {
-            s.gems |= g;
-            if (EMIT) ev.push(EV_GEM, a);
-        }
-    } else if (kind == K_VOID) {
-        if (is_alive) {
-            s.alive &= ~bit;
-            if (EMIT) ev.push(EV_DIED, a);
-            return true;
-        }
-    }
-    return false;
+    const uint32_t gbit = 1u << ((meta >> 3) & 31u);
+    const bool inner = !blocked;
+    const bool ev_exit = inner && kind == K_EXIT && !(s.arrived & bit);
+    const bool ev_gem = inner && kind == K_GEM && !(s.gems & gbit);
+    const bool died = is_alive && (blocked || kind == K_VOID);
+    s.occ |= inner ? bit : 0u;
+    s.arrived |= ev_exit ? bit : 0u;
+    s.gems |= ev_gem ? gbit : 0u;
+    s.alive &= died ? ~bit : 0xFFFFFFFFu;
+    if (EMIT) ev.push_if(died || ev_exit || ev_gem, died ? EV_DIED : (ev_gem ? EV_GEM : EV_EXIT), a);
+    return died;
 }
 
 // One call of World::move_agents (world.rs:477-505).  old_pos: where alive agents leave from.
 template <int AM, int LM>
 LLE_HD bool move_agents(Env<AM, LM>& s, const uint32_t (&old_pos)[AM], const uint32_t (&new_pos)[AM], const MapView& mv,
                         Events<AM>& ev) {
+    const uint32_t alive0 = s.alive;  // leave and pre_enter both see the flags of before this pass's enter loop
+    s.occ &= ~alive0;                 // Tile::leave: `slot.take()` for every alive agent
 #pragma unroll
-    for (int a = 0; a < AM; a++) {
-        if (a < mv.A && ((s.alive >> a) & 1u)) {
-            s.occ &= ~(1u << a);
-            lasers_leave<LM>(s.beams, mv.cell_lay[cell_of(old_pos[a], mv.W)], mv);
-        }
-    }
+    for (int a = 0; a < AM; a++)
+        if (a < mv.A) lasers_leave<LM>(s.beams, mv.cell_lay[cell_of(old_pos[a], mv.W)], (alive0 >> a) & 1u, mv);
 #pragma unroll
-    for (int a = 0; a < AM; a++) {
-        if (a < mv.A) lasers_pre_enter<LM>(s.beams, mv.cell_lay[cell_of(new_pos[a], mv.W)], (uint32_t)a, (s.alive >> a) & 1u, mv);
-    }
+    for (int a = 0; a < AM; a++)
+        if (a < mv.A) lasers_pre_enter<LM>(s.beams, mv.cell_lay[cell_of(new_pos[a], mv.W)], (uint32_t)a, (alive0 >> a) & 1u, mv);
     bool died = false;
 #pragma unroll
-    for (int a = 0; a < AM; a++) {
+    for (int a = 0; a < AM; a++)
         if (a < mv.A) died |= enter_agent<AM, LM, true>(s, (uint32_t)a, cell_of(new_pos[a], mv.W), mv, ev);
-    }
     return died;
 }
 
@@ -243,23 +221,21 @@ LLE_HD void compute_avail(const Env<AM, LM>& s, const MapView& mv, uint32_t (&av
 #pragma unroll
     for (int a = 0; a < AM; a++) {
         if (a >= mv.A) { avail[a] = 0; continue; }
-        uint32_t m = 16u;  // Stay
-        if (((s.alive >> a) & 1u) && !((s.arrived >> a) & 1u)) {
-            uint32_t walk = (mv.cell_meta[cell_of(s.pos[a], mv.W)] >> 8) & 15u;
-            uint32_t blocked = 0;
+        const bool can_move = ((s.alive >> a) & 1u) && !((s.arrived >> a) & 1u);
+        const uint32_t walk = (mv.cell_meta[cell_of(s.pos[a], mv.W)] >> 8) & 15u;
+        uint32_t blocked = 0;
 #pragma unroll
-            for (int o = 0; o < AM; o++) {
-                if (o < mv.A && o != a && ((s.occ >> o) & 1u)) {
-                    const int d = (int)s.pos[o] - (int)s.pos[a];
-                    blocked |= (d == -1) ? 1u : 0u;    // North: i - 1
-                    blocked |= (d == 1) ? 2u : 0u;     // South: i + 1
-                    blocked |= (d == 256) ? 4u : 0u;   // East:  j + 1
-                    blocked |= (d == -256) ? 8u : 0u;  // West:  j - 1
-                }
+        for (int o = 0; o < AM; o++) {
+            if (o < mv.A && o != a) {
+                const int d = (int)s.pos[o] - (int)s.pos[a];
+                uint32_t hit = (d == -1) ? 1u : 0u;   // North: i - 1
+                hit |= (d == 1) ? 2u : 0u;            // South: i + 1
+                hit |= (d == 256) ? 4u : 0u;          // East:  j + 1
+                hit |= (d == -256) ? 8u : 0u;         // West:  j - 1
+                blocked |= ((s.occ >> o) & 1u) ? hit : 0u;  // only an occupant blocks (tile.rs:86-99)
             }
-            m |= walk & ~blocked;
         }
-        avail[a] = m;
+        avail[a] = 16u | (can_move ? (walk & ~blocked) : 0u);  // Stay is always available
     }
 }
 
@@ -284,10 +260,10 @@ LLE_HD void step_env(Env<AM, LM>& s, const uint32_t (&actions)[AM], const MapVie
         for (int i = 0; i < AM; i++)
 #pragma unroll
             for (int j = i + 1; j < AM; j++)
-                if (j < mv.A && np[i] == np[j]) dup |= (1u << i) | (1u << j);
+                dup |= (j < mv.A && np[i] == np[j]) ? ((1u << i) | (1u << j)) : 0u;
 #pragma unroll
-        for (int i = 0; i < AM; i++)
-            if ((dup >> i) & 1u) { np[i] = s.pos[i]; conflict = true; }
+        for (int i = 0; i < AM; i++) np[i] = ((dup >> i) & 1u) ? s.pos[i] : np[i];
+        conflict = dup != 0;
     }
     bool died = move_agents<AM, LM>(s, s.pos, np, mv, ev);
 #pragma unroll

@@ -83,14 +83,27 @@ struct LaunchArgs {
     uint32_t envs_per_wave;    // 1..64, power of two
     uint64_t seed, t;
     int64_t env_offset;        // global id of env 0 (multi-GPU shards sample as one big batch)
+    int64_t env_base;          // first environment of this launch (block b handles env_base + b * envs_per_wave ...)
+    int64_t env_limit;         // one past the last environment of this launch
     const uint8_t* env_mask;   // reset: optional u8[n]
     const uint8_t* actions_in; // step: optional u8[n][A]
     uint32_t old_enabled;      // update_sources: enabled mask before the update
     uint32_t pad;
 };
 
+// State of a freshly reset environment (identical for every env of a map: v1 maps have one start per agent).
+// Filled on the device by resetting a hidden environment; read by the auto-reset path of the step kernel.
+struct InitRecord {
+    uint16_t pos[MAX_AGENTS];
+    uint64_t bits;
+    uint32_t gems;
+    uint32_t beams[MAX_SOURCES];
+    uint8_t avail[MAX_AGENTS];
+};
+
 // Device pointers of one batch (kernel argument, passed by value).
 struct BatchPtrs {
+    const InitRecord* init;  // reset state (see InitRecord)
     const uint8_t* tables;   // device blob (MapHeader + sections)
     uint16_t* pos;           // [n][A]   i | j << 8
     uint64_t* bits;          // [n]

@@ -817,17 +817,18 @@ static uint64_t mix64(uint64_t x) { /* splitmix64 finaliser */
     x ^= x >> 31;
     return x;
 }
+/* 16-bit field of (seed, env, t, agent): one 64-bit hash serves four agents (DESIGN.md "Action stream") */
 uint64_t ow_action_hash(uint64_t seed, uint64_t env, uint64_t t, uint64_t agent) {
     uint64_t x = seed + 0x9E3779B97F4A7C15ULL * (env + 1);
     x ^= 0xD1B54A32D192ED03ULL * (t + 1);
     x = mix64(x);
-    x ^= 0x8CB92BA72F3D8DD7ULL * (agent + 1);
-    return mix64(x);
+    x = mix64(x + 0x8CB92BA72F3D8DD7ULL * ((agent >> 2) + 1));
+    return (x >> (16 * (agent & 3))) & 0xFFFF;
 }
-/* uniform over the set bits of the 5-bit availability mask, k-th set bit in enum order N,S,E,W,STAY */
+/* uniform (up to 2^-16) over the set bits of the 5-bit availability mask: k-th set bit in enum order N,S,E,W,STAY */
 int ow_sample_action(uint8_t mask, uint64_t seed, uint64_t env, uint64_t t, uint64_t agent) {
-    int n = __builtin_popcount(mask & 31u);
-    uint32_t k = (uint32_t)(ow_action_hash(seed, env, t, agent) >> 33) % (uint32_t)n;
+    uint32_t n = (uint32_t)__builtin_popcount(mask & 31u);
+    uint32_t k = ((uint32_t)ow_action_hash(seed, env, t, agent) * n) >> 16;
     for (int b = 0; b < 5; b++) if (mask & (1u << b)) { if (k == 0) return b; k--; }
     return ACT_STAY;
 }

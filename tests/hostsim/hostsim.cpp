@@ -65,7 +65,11 @@ static void run(hs_batch* b, int mode, uint32_t flags, uint64_t seed, uint64_t t
             uint32_t act[AM];
             if (flags & STEP_SAMPLE_ACTIONS) {
                 const uint64_t he = action_hash_env(seed, (uint64_t)(env_offset + env), t);
-                for (int a = 0; a < AM; a++) act[a] = (a < A) ? sample_action(avail[a], action_hash_agent(he, (uint64_t)a)) : 4u;
+                uint64_t hg = 0;
+                for (int a = 0; a < AM; a++) {
+                    if ((a & 3) == 0 && a < A) hg = action_hash_group(he, (uint64_t)(a >> 2));
+                    act[a] = (a < A) ? sample_action(avail[a], action_field(hg, (uint32_t)a)) : 4u;
+                }
             } else {
                 const uint8_t* src = actions_in ? actions_in : b->actions.data();
                 for (int a = 0; a < AM; a++) act[a] = (a < A) ? (uint32_t)src[env * A + a] : 4u;
