@@ -31,32 +31,34 @@ ALGO_BYTES_PER_ENV_STEP = 1937
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(level_text, seconds_target=12.0):
-    """The CPU oracle (C restatement of the reference algorithm, kind "port") on a bounded sample of the same workload."""
+def cpu_baseline(level_text, n_envs, seconds_target=12.0):
+    """The CPU oracle (C restatement of the reference algorithm, kind "port") on a bounded sample of the same workload:
+    the same n_envs level-6 environments, sampled actions + auto-reset + int8 layered observation, for about
+    `seconds_target` seconds on every host core (one thread per core over disjoint env ranges)."""
     import numpy as np
 
     from oracle import oracle
 
-    threads = min(os.cpu_count() or 1, 64)
-    n = 4096
-    ob = oracle.OracleBatch(level_text, n)
-    obs = np.zeros((n, ob.C * ob.H * ob.W), np.int8)
-    ob.rollout(5, SEED, threads, obs)  # warm-up
+    threads = min(os.cpu_count() or 1, 256)
+    ob = oracle.OracleBatch(level_text, n_envs)
+    obs = np.zeros((n_envs, ob.C * ob.H * ob.W), np.int8)
+    ob.rollout(2, SEED, threads, obs)  # warm-up
     t0 = time.perf_counter()
-    ob.rollout(20, SEED, threads, obs)
-    rate = n * 20 / (time.perf_counter() - t0)
-    steps = max(20, min(2000, int(seconds_target * rate / n)))
+    ob.rollout(8, SEED, threads, obs)
+    rate = n_envs * 8 / (time.perf_counter() - t0)
+    steps = max(8, int(seconds_target * rate / n_envs))
     t0 = time.perf_counter()
     ob.rollout(steps, SEED, threads, obs)
     dt = time.perf_counter() - t0
+    steps1 = max(2, steps // (4 * threads))
     t1 = time.perf_counter()
-    ob.rollout(max(steps // 8, 5), SEED, 1, obs)
+    ob.rollout(steps1, SEED, 1, obs)
     dt1 = time.perf_counter() - t1
     return {
-        "value": ob.A * n * steps / dt, "unit": "agent-steps/s", "cores": threads, "kind": "port",
-        "env_steps_per_s": n * steps / dt,
-        "single_thread_env_steps_per_s": n * max(steps // 8, 5) / dt1,
-        "sample": f"level {LEVEL}, {n} envs x {steps} steps, sampled actions + auto-reset + int8 layered obs, "
+        "value": ob.A * n_envs * steps / dt, "unit": "agent-steps/s", "cores": threads, "kind": "port",
+        "env_steps_per_s": n_envs * steps / dt, "seconds": dt,
+        "single_thread_env_steps_per_s": n_envs * steps1 / dt1,
+        "sample": f"level {LEVEL}, {n_envs} envs x {steps} steps ({dt:.1f} s), sampled actions + auto-reset + int8 layered obs, "
                   f"C restatement of the Rust reference algorithm (oracle/lle_oracle.c), {threads} threads",
     }
 
@@ -154,7 +156,7 @@ def main():
             "rollout_stats": stats,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(text)
+            out["cpu_baseline"] = cpu_baseline(text, n)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -162,6 +162,11 @@ class BatchedWorld:
         self._check(_capi.lib().lle_batch_observe(self.h, self._stream()))
         return self.obs
 
+    def _noop_launch(self):
+        """Profiling aid: a launch that loads the tables and the state and does nothing else (step with every
+        action invalid and no observation write is the closest public equivalent)."""
+        self._check(_capi.lib().lle_batch_step(self.h, None, LLE_STEP_NO_OBS | 0x100, 0, 0, 0, self._stream()))
+
     def stats(self, reset=False):
         out = (C.c_int64 * 8)()
         self._check(_capi.lib().lle_batch_stats(self.h, out, int(reset), self._stream()))

@@ -24,4 +24,8 @@ for epw in (32, 64):
     def v4():
         bw.step(inv, write_obs=False)     # invalid action: checks only, no step
     bw.reset(); r4 = timeit(v4)
-    print(f"n={n} epw={epw}: sample+autoreset {r1:.2f} us | explicit STAY (fresh envs, no deaths) {r3:.2f} us | sample no-reset (mostly dead) {r2:.2f} us | invalid actions (no step) {r4:.2f} us", flush=True)
+    e0 = torch.empty(1, device="cuda")
+    def v5():
+        e0.add_(1)   # a trivial torch kernel: the launch-to-launch floor
+    r5 = timeit(v5)
+    print(f"n={n} epw={epw}: trivial-kernel floor {r5:.2f} us | sample+autoreset {r1:.2f} us | explicit STAY (fresh envs, no deaths) {r3:.2f} us | sample no-reset (mostly dead) {r2:.2f} us | invalid actions (no step) {r4:.2f} us", flush=True)
