@@ -92,4 +92,15 @@ EXTRA_MAPS = {
         "S0 S1 G S2 . ."
     ),
     "corridor": "S0 S1 S2 S3 . . G X X X X",
+    # python/tests/test_world.py:855-874: 14 agents, 14 sources (the 16x16 kernel instantiation)
+    "many_agents": " .   .   . . . .\n" + "".join(f"S{k}  L{k}W  . . . X\n" for k in range(14)),
 }
+
+
+def _add_generated():
+    from lle_amd import mapgen
+    EXTRA_MAPS["config5_32x32"] = mapgen.config5(0)          # BASELINE.json configs[4]: 8 agents, 8 lasers, crossings
+    EXTRA_MAPS["gen_16x16_12agents"] = mapgen.generate(16, 16, 12, 10, 6, seed=3, n_voids=3)
+
+
+_add_generated()

@@ -232,3 +232,34 @@ def test_world_facade_pickle_and_deepcopy():
             assert clone.get_state() == world.get_state()
             assert clone.wall_pos == world.wall_pos and clone.exit_pos == world.exit_pos
         assert copy.deepcopy(world).get_state() == world.get_state()
+
+
+def test_config5_generated_32x32(oracle_mod):
+    """BASELINE.json configs[4]: generated 32x32 map, 8 agents, 8 lasers (crossing beams), bit-exact at n=4096, and
+    the size-independent properties at the full batch of 65536."""
+    import torch
+
+    from lle_amd import BatchedWorld, mapgen
+
+    text = mapgen.config5(0)
+    n = 4096
+    ob = oracle_mod.OracleBatch(text, n)
+    bw = BatchedWorld(text, n)
+    assert bw.kernel_info()["kernel"] == "world_kernel<8,8>"
+    for t in range(30):
+        bw.step(sample=True, auto_reset=(t % 2 == 0), seed=11, t=t)
+        check(bw, ob, ob.step(None, auto_reset=(t % 2 == 0), seed=11, t=t), f"t={t}")
+    del bw, ob
+    n = 65536
+    a, b = BatchedWorld(text, n), BatchedWorld(text, n, envs_per_wave=8)
+    for t in range(10):
+        a.step(sample=True, auto_reset=True, seed=5, t=t)
+        b.step(sample=True, auto_reset=True, seed=5, t=t)
+    for name in ("pos", "bits", "gems", "beams", "avail", "events", "evcount", "obs"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    A, H, W = a.map.n_agents, a.map.height, a.map.width
+    pos = a.pos.to(torch.int64)
+    cell = pos[..., 0] * W + pos[..., 1]
+    agent_layers = a.obs[:, :A].reshape(n, A, H * W)
+    assert torch.equal(agent_layers.sum(-1).to(torch.int64), torch.ones(n, A, dtype=torch.int64, device="cuda"))
+    assert torch.all(agent_layers.gather(2, cell.unsqueeze(-1)) == 1)
