@@ -141,6 +141,9 @@ enum {
     LLE_BUF_COUNT
 };
 
+/* The per-agent buffers (POS, AVAIL, ACTIONS, EVENTS, REQ_POS) are laid out with an env pitch of 4, 8 or 16 agents
+ * (the smallest that holds the map's A), so that a record is a whole number of dwords: always address them through
+ * `stride` below. */
 typedef struct lle_buffer_desc {
     void* ptr;            /* device pointer */
     int64_t arena_offset; /* byte offset inside the arena */
@@ -202,6 +205,10 @@ int lle_last_status(void);
 const char* lle_last_error(void);
 /* Name + dynamic-LDS bytes + envs-per-wave of the step kernel a batch launches (for profiling reports). */
 int lle_batch_kernel_info(const lle_batch* b, char* name_buf, size_t cap, int32_t* lds_bytes, int32_t* envs_per_wave);
+/* Profiling aid: one step (flags as lle_batch_step) that also writes, per wavefront, eight s_memrealtime stamps
+ * (10 ns ticks: entry, tables in LDS, state requested, logic done, state stored, observation stores issued, drained)
+ * to stamps_dev [n_waves][8] u64. */
+int lle_batch_step_stamped(lle_batch* b, uint32_t flags, uint64_t seed, uint64_t t, uint64_t* stamps_dev, void* stream);
 /* Tuning knob: environments per wavefront in the step kernel (8, 16, 32 or 64). */
 int lle_batch_set_envs_per_wave(lle_batch* b, int envs_per_wave);
 

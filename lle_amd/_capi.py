@@ -34,7 +34,7 @@ EXPORTS = [
     "lle_map_set_source", "lle_map_laser_tiles", "lle_map_world_string",
     "lle_batch_arena_bytes", "lle_batch_create", "lle_batch_free", "lle_batch_get_buffer", "lle_batch_n_envs",
     "lle_batch_reset", "lle_batch_step", "lle_batch_set_state", "lle_batch_update_sources", "lle_batch_observe",
-    "lle_batch_stats", "lle_batch_kernel_info", "lle_batch_set_envs_per_wave",
+    "lle_batch_stats", "lle_batch_kernel_info", "lle_batch_set_envs_per_wave", "lle_batch_step_stamped",
 ]
 
 
@@ -121,6 +121,8 @@ def lib():
     L.lle_batch_stats.argtypes = [vp, C.POINTER(C.c_int64), i32, vp]
     L.lle_batch_kernel_info.restype = i32
     L.lle_batch_kernel_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.lle_batch_step_stamped.restype = i32
+    L.lle_batch_step_stamped.argtypes = [vp, u32, u64, u64, vp, vp]
     L.lle_batch_set_envs_per_wave.restype = i32
     L.lle_batch_set_envs_per_wave.argtypes = [vp, i32]
     _lib = L

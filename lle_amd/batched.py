@@ -74,18 +74,18 @@ class BatchedWorld:
             self._check(L.lle_batch_get_buffer(self.h, which, C.byref(d)))
             name = BUFFER_NAMES[which]
             dt = _TORCH_DTYPES[name]
-            self._desc[name] = (int(d.arena_offset), int(d.bytes), [int(d.shape[k]) for k in range(d.ndim)], int(d.elem_bytes))
+            self._desc[name] = (int(d.arena_offset), int(d.bytes), [int(d.shape[k]) for k in range(d.ndim)], int(d.elem_bytes),
+                                [int(d.stride[k]) for k in range(d.ndim)])
             raw = self._base[d.arena_offset:d.arena_offset + d.bytes]
             if name == "obs":
                 t = raw.view(torch.int8)[: self.n_envs * m.obs_stride].view(self.n_envs, m.obs_stride)
                 self.obs_rows = t
                 t = t[:, : m.obs_bytes].unflatten(1, (m.n_layers, m.height, m.width))
             else:
+                # per-agent buffers are strided by the kernel's agent bound (lle_buffer_desc.stride, in elements)
                 shape = [int(d.shape[k]) for k in range(d.ndim)]
-                count = 1
-                for s in shape:
-                    count *= s
-                t = raw[: count * d.elem_bytes].view(dt).view(shape)
+                stride = [int(d.stride[k]) for k in range(d.ndim)]
+                t = torch.as_strided(raw.view(dt), shape, stride)
             setattr(self, "stats_blocks" if name == "stats" else name, t)
 
     def __del__(self):
@@ -201,11 +201,9 @@ class BatchedWorld:
                  "actions": np.uint8, "err": np.uint8, "evcount": np.uint8, "events": np.uint8, "done": np.uint8}
         out = {}
         for name, dt in np_dt.items():
-            off, _nbytes, shape, elem = self._desc[name]
-            count = 1
-            for v in shape:
-                count *= v
-            out[name] = host[off - lo: off - lo + count * elem].view(dt).reshape(shape)
+            off, nbytes, shape, elem, stride = self._desc[name]
+            flat = host[off - lo: off - lo + nbytes].view(dt)
+            out[name] = np.lib.stride_tricks.as_strided(flat, shape, [v * elem for v in stride])
         return out
 
     def host_buffers(self, names=("pos", "bits", "gems", "beams", "avail", "actions", "err", "evcount", "events", "done", "obs")):

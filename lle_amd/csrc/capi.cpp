@@ -50,7 +50,8 @@ struct Layout {
 
 Layout make_layout(const MapHeader& h, int64_t n) {
     Layout l{};
-    const int64_t A = h.A, L = h.L;
+    const int64_t L = h.L;
+    const int64_t A = agent_stride((int)h.A, (int)h.L);  // per-agent buffers are strided by the kernel's agent bound
     const int64_t n_pad = (n + 1 + 63) / 64 * 64;  // + one hidden env (slot n) used to compute the reset state on the device
     l.n_stat_blocks = (n + MIN_ENVS_PER_WAVE - 1) / MIN_ENVS_PER_WAVE;
     int64_t sz[LLE_BUF_COUNT];
@@ -251,7 +252,7 @@ static int refresh_init_record(lle_batch* b, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(launch_world_kernel(KMODE_RESET, b->hdr, b->ptrs, K, st));
     uint8_t* rec = b->arena + b->layout.off_init;
-    const int64_t n = b->n_envs, A = b->hdr.A, L = b->hdr.L;
+    const int64_t n = b->n_envs, L = b->hdr.L, A = agent_stride((int)b->hdr.A, (int)b->hdr.L);
     HIP_TRY(hipMemcpyAsync(rec + offsetof(InitRecord, pos), b->ptrs.pos + n * A, (size_t)A * 2, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(rec + offsetof(InitRecord, bits), b->ptrs.bits + n, 8, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(rec + offsetof(InitRecord, gems), b->ptrs.gems + n, 4, hipMemcpyDeviceToDevice, st));
@@ -269,7 +270,7 @@ static int create_impl(lle_batch* b, const lle_map* map, void* arena, int64_t ar
     HIP_TRY(hipSetDevice(b->device));
     MapHeader worst = b->hdr;
     worst.lds_table_bytes += worst.blob_capacity - worst.blob_bytes;
-    const uint32_t lds = kernel_lds_bytes(worst);
+    const uint32_t lds = kernel_lds_bytes(worst, 1);
     if (lds > 64 * 1024) return fail(LLE_ERR_UNSUPPORTED, "map tables need " + std::to_string(lds) + " B of LDS per wave (> 64 KiB)");
     b->layout = make_layout(b->hdr, b->n_envs);
     if (arena) {
@@ -328,7 +329,7 @@ int64_t lle_batch_n_envs(const lle_batch* b) { return b ? b->n_envs : 0; }
 int lle_batch_get_buffer(const lle_batch* b, int which, lle_buffer_desc* out) {
     if (!b || !out) return fail(LLE_ERR_NULL, "NULL argument");
     if (which < 0 || which >= LLE_BUF_COUNT) return fail(LLE_ERR_ARG, "unknown buffer");
-    const int64_t n = b->n_envs, A = b->hdr.A, L = b->hdr.L;
+    const int64_t n = b->n_envs, A = b->hdr.A, L = b->hdr.L, As = agent_stride((int)b->hdr.A, (int)b->hdr.L);
     lle_buffer_desc d{};
     d.ptr = b->arena + b->layout.off[which];
     d.arena_offset = b->layout.off[which];
@@ -339,13 +340,13 @@ int lle_batch_get_buffer(const lle_batch* b, int which, lle_buffer_desc* out) {
         d.stride[0] = t0; d.stride[1] = t1; d.stride[2] = t2;
     };
     switch (which) {
-        case LLE_BUF_POS: case LLE_BUF_REQ_POS: set(1, 3, n, A, 2, 2 * A, 2, 1); break;
+        case LLE_BUF_POS: case LLE_BUF_REQ_POS: set(1, 3, n, A, 2, 2 * As, 2, 1); break;
         case LLE_BUF_BITS: set(8, 1, n, 1, 1, 1, 1, 1); break;
         case LLE_BUF_GEMS: case LLE_BUF_REQ_GEMS: set(4, 1, n, 1, 1, 1, 1, 1); break;
         case LLE_BUF_BEAMS: set(4, 2, n, L, 1, L, 1, 1); break;
-        case LLE_BUF_AVAIL: case LLE_BUF_ACTIONS: set(1, 2, n, A, 1, A, 1, 1); break;
+        case LLE_BUF_AVAIL: case LLE_BUF_ACTIONS: set(1, 2, n, A, 1, As, 1, 1); break;
         case LLE_BUF_ERR: case LLE_BUF_EVCOUNT: case LLE_BUF_DONE: set(1, 1, n, 1, 1, 1, 1, 1); break;
-        case LLE_BUF_EVENTS: set(1, 2, n, 2 * A, 1, 2 * A, 1, 1); break;
+        case LLE_BUF_EVENTS: set(1, 2, n, 2 * A, 1, 2 * As, 1, 1); break;
         case LLE_BUF_OBS: set(1, 2, n, b->hdr.obs_bytes, 1, b->hdr.obs_stride, 1, 1); break;
         case LLE_BUF_STATS: set(8, 2, b->layout.n_stat_blocks, 8, 1, 8, 1, 1); break;
         case LLE_BUF_REQ_ALIVE: set(2, 1, n, 1, 1, 1, 1, 1); break;
@@ -414,9 +415,18 @@ int lle_batch_stats(lle_batch* b, int64_t out[8], int reset_counters, void* stre
 int lle_batch_kernel_info(const lle_batch* b, char* name_buf, size_t cap, int32_t* lds_bytes, int32_t* envs_per_wave) {
     if (!b) return fail(LLE_ERR_NULL, "NULL batch");
     if (name_buf && cap) std::snprintf(name_buf, cap, "%s", kernel_variant_name(kernel_variant((int)b->hdr.A, (int)b->hdr.L)));
-    if (lds_bytes) *lds_bytes = (int32_t)kernel_lds_bytes(b->hdr);
+    if (lds_bytes) *lds_bytes = (int32_t)kernel_lds_bytes(b->hdr, kernel_waves_per_wg(b->hdr));
     if (envs_per_wave) *envs_per_wave = (int32_t)b->envs_per_wave;
     return LLE_OK;
+}
+
+// Profiling aid (not part of the stable ABI surface documented in the header's main section): one step with
+// per-wave s_memrealtime stamps written to `stamps_dev` ([n_blocks][8] u64).
+int lle_batch_step_stamped(lle_batch* b, uint32_t flags, uint64_t seed, uint64_t t, uint64_t* stamps_dev, void* stream) {
+    if (!b || !stamps_dev) return fail(LLE_ERR_NULL, "NULL argument");
+    LaunchArgs K{};
+    K.flags = flags; K.seed = seed; K.t = t; K.stamps = stamps_dev;
+    return launch(b, KMODE_STEP, K, stream);
 }
 
 int lle_batch_set_envs_per_wave(lle_batch* b, int epw) {

@@ -10,8 +10,10 @@ enum { KMODE_STEP = 0, KMODE_RESET = 1, KMODE_SET_STATE = 2, KMODE_OBSERVE = 3, 
 constexpr uint32_t MIN_ENVS_PER_WAVE = 8;
 
 int kernel_variant(int A, int L);
+int agent_stride(int A, int L);  // agents per env record in the per-agent buffers (= the variant's agent bound)
 const char* kernel_variant_name(int variant);
-uint32_t kernel_lds_bytes(const MapHeader& h);
+uint32_t kernel_lds_bytes(const MapHeader& h, uint32_t waves_per_wg);
+uint32_t kernel_waves_per_wg(const MapHeader& h);
 hipError_t launch_world_kernel(int mode, const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K, hipStream_t stream);
 
 }  // namespace lle

@@ -355,9 +355,17 @@ void Map::compile() {
     h.off_cell_meta = (uint32_t)off; off = align16(off + cell_meta.size() * 4);
     h.off_dyn = (uint32_t)off; off = align16(off + dyn_tab.size() * 8);
     h.off_template = (uint32_t)off; off = align16(off + tmpl.size());
+    // the kernel copies [off_cell_lay, blob_bytes) to LDS in rows of 64 lanes x 16 B: pad to whole rows
+    off = h.off_cell_lay + ((off - h.off_cell_lay + 1023) & ~(size_t)1023);
     h.blob_bytes = (uint32_t)off;
-    // recolouring can split merged dyn entries: at most one per exposed laser tile plus one per gem
-    h.blob_capacity = (uint32_t)align16(off + ((size_t)n_laser_tiles() + (size_t)G - dyn_tab.size()) * 8);
+    // recolouring can split merged dyn entries: at most one per exposed laser tile plus one per gem.  The capacity
+    // is the blob size with that largest dyn table, so it does not depend on the current colours.
+    {
+        size_t cap = h.off_dyn;
+        cap = align16(cap + ((size_t)n_laser_tiles() + (size_t)G) * 8);
+        cap = align16(cap + tmpl.size());
+        h.blob_capacity = (uint32_t)(h.off_cell_lay + ((cap - h.off_cell_lay + 1023) & ~(size_t)1023));
+    }
     h.lds_table_bytes = h.blob_bytes - h.off_cell_lay;
     blob.assign(off, 0);
     std::memcpy(blob.data() + h.off_cell_lay, cell_lay.data(), cell_lay.size() * 8);

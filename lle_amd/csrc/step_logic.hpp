@@ -111,6 +111,23 @@ struct Events {
 
 LLE_HD uint32_t cell_of(uint32_t p, int W) { return (p & 0xFFu) * (uint32_t)W + (p >> 8); }
 
+// Table entries of the cells the agents stand on.  Looked up for all agents at once: the lookups are LDS reads with
+// a ~100-cycle round trip each, so they are issued back to back and waited for once instead of one by one.
+template <int AM>
+struct Cells {
+    uint64_t lay[AM];
+    uint32_t meta[AM];
+};
+template <int AM>
+LLE_HD void load_cells(const MapView& mv, const uint32_t (&pos)[AM], Cells<AM>& out) {
+#pragma unroll
+    for (int a = 0; a < AM; a++) {
+        const uint32_t c = (a < mv.A) ? cell_of(pos[a], mv.W) : 0u;
+        out.lay[a] = mv.cell_lay[c];
+        out.meta[a] = mv.cell_meta[c];
+    }
+}
+
 template <int LM>
 LLE_HD uint32_t beam_get(const uint32_t (&b)[LM], uint32_t idx) {
     uint32_t r = 0;
@@ -169,11 +186,10 @@ LLE_HD bool lasers_block(const uint32_t (&beams)[LM], uint64_t lay, uint32_t age
 //   otherwise the innermost tile takes the agent as occupant; Exit: arrive once (AgentExit, no alive check);
 //   Gem: collect once (GemCollected, no alive check); Void: dies if alive (AgentDied).
 template <int AM, int LM, bool EMIT>
-LLE_HD bool enter_agent(Env<AM, LM>& s, uint32_t a, uint32_t cell, const MapView& mv, Events<AM>& ev) {
+LLE_HD bool enter_agent(Env<AM, LM>& s, uint32_t a, uint64_t lay, uint32_t meta, const MapView& mv, Events<AM>& ev) {
     const uint32_t bit = 1u << a;
     const bool is_alive = (s.alive & bit) != 0;
-    const bool blocked = lasers_block<LM>(s.beams, mv.cell_lay[cell], a, mv);
-    const uint32_t meta = mv.cell_meta[cell];
+    const bool blocked = lasers_block<LM>(s.beams, lay, a, mv);
     const uint32_t kind = meta & 7u;
     const uint32_t gbit = 1u << ((meta >> 3) & 31u);
     const bool inner = !blocked;
@@ -188,22 +204,22 @@ LLE_HD bool enter_agent(Env<AM, LM>& s, uint32_t a, uint32_t cell, const MapView
     return died;
 }
 
-// One call of World::move_agents (world.rs:477-505).  old_pos: where alive agents leave from.
+// One call of World::move_agents (world.rs:477-505).  old_lay: laser stacks of the cells alive agents leave from;
+// nw: table entries of the cells every agent enters.
 template <int AM, int LM>
-LLE_HD bool move_agents(Env<AM, LM>& s, const uint32_t (&old_pos)[AM], const uint32_t (&new_pos)[AM], const MapView& mv,
-                        Events<AM>& ev) {
+LLE_HD bool move_agents(Env<AM, LM>& s, const uint64_t (&old_lay)[AM], const Cells<AM>& nw, const MapView& mv, Events<AM>& ev) {
     const uint32_t alive0 = s.alive;  // leave and pre_enter both see the flags of before this pass's enter loop
     s.occ &= ~alive0;                 // Tile::leave: `slot.take()` for every alive agent
 #pragma unroll
     for (int a = 0; a < AM; a++)
-        if (a < mv.A) lasers_leave<LM>(s.beams, mv.cell_lay[cell_of(old_pos[a], mv.W)], (alive0 >> a) & 1u, mv);
+        if (a < mv.A) lasers_leave<LM>(s.beams, old_lay[a], (alive0 >> a) & 1u, mv);
 #pragma unroll
     for (int a = 0; a < AM; a++)
-        if (a < mv.A) lasers_pre_enter<LM>(s.beams, mv.cell_lay[cell_of(new_pos[a], mv.W)], (uint32_t)a, (alive0 >> a) & 1u, mv);
+        if (a < mv.A) lasers_pre_enter<LM>(s.beams, nw.lay[a], (uint32_t)a, (alive0 >> a) & 1u, mv);
     bool died = false;
 #pragma unroll
     for (int a = 0; a < AM; a++)
-        if (a < mv.A) died |= enter_agent<AM, LM, true>(s, (uint32_t)a, cell_of(new_pos[a], mv.W), mv, ev);
+        if (a < mv.A) died |= enter_agent<AM, LM, true>(s, (uint32_t)a, nw.lay[a], nw.meta[a], mv, ev);
     return died;
 }
 
@@ -217,12 +233,12 @@ LLE_HD void canonicalise(Env<AM, LM>& s, const MapView& mv) {
 
 // compute_available_actions (world.rs:343-363) as 5-bit masks (bit = Action value).
 template <int AM, int LM>
-LLE_HD void compute_avail(const Env<AM, LM>& s, const MapView& mv, uint32_t (&avail)[AM]) {
+LLE_HD void compute_avail(const Env<AM, LM>& s, const MapView& mv, const Cells<AM>& at, uint32_t (&avail)[AM]) {
 #pragma unroll
     for (int a = 0; a < AM; a++) {
         if (a >= mv.A) { avail[a] = 0; continue; }
         const bool can_move = ((s.alive >> a) & 1u) && !((s.arrived >> a) & 1u);
-        const uint32_t walk = (mv.cell_meta[cell_of(s.pos[a], mv.W)] >> 8) & 15u;
+        const uint32_t walk = (at.meta[a] >> 8) & 15u;  // `at`: table entries of the agents' current cells
         uint32_t blocked = 0;
 #pragma unroll
         for (int o = 0; o < AM; o++) {
@@ -245,9 +261,11 @@ LLE_HD uint32_t apply_action(uint32_t p, uint32_t act) {
     return (uint32_t)((int)p + d);
 }
 
-// World::step after the availability check.  Returns the number of move_agents passes.
+// World::step after the availability check.  cur: table entries of the agents' cells before the step; on return
+// `fin` holds those of the cells they end on (for compute_avail).
 template <int AM, int LM>
-LLE_HD void step_env(Env<AM, LM>& s, const uint32_t (&actions)[AM], const MapView& mv, Events<AM>& ev) {
+LLE_HD void step_env(Env<AM, LM>& s, const uint32_t (&actions)[AM], const MapView& mv, Events<AM>& ev, const Cells<AM>& cur,
+                     Cells<AM>& fin) {
     uint32_t np[AM];
 #pragma unroll
     for (int a = 0; a < AM; a++) np[a] = (a < mv.A) ? apply_action(s.pos[a], actions[a]) : 0xFFFF0000u + (uint32_t)a;
@@ -265,10 +283,11 @@ LLE_HD void step_env(Env<AM, LM>& s, const uint32_t (&actions)[AM], const MapVie
         for (int i = 0; i < AM; i++) np[i] = ((dup >> i) & 1u) ? s.pos[i] : np[i];
         conflict = dup != 0;
     }
-    bool died = move_agents<AM, LM>(s, s.pos, np, mv, ev);
+    load_cells<AM>(mv, np, fin);
+    bool died = move_agents<AM, LM>(s, cur.lay, fin, mv, ev);
 #pragma unroll
     for (int a = 0; a < AM; a++) s.pos[a] = np[a];
-    while (died) died = move_agents<AM, LM>(s, np, np, mv, ev);
+    while (died) died = move_agents<AM, LM>(s, fin.lay, fin, mv, ev);
     canonicalise<AM, LM>(s, mv);
 }
 
@@ -282,22 +301,23 @@ LLE_HD void reset_tiles(Env<AM, LM>& s, const MapView& mv) {
     for (int b = 0; b < LM; b++) s.beams[b] = (b < mv.L && ((mv.enabled >> b) & 1u)) ? mv.hdr->beam_full[b] : 0u;
 }
 
-// World::reset (world.rs:411-432); events of the initial enter are dropped.
+// World::reset (world.rs:411-432); events of the initial enter are dropped.  `at`: table entries of the start cells.
 template <int AM, int LM>
-LLE_HD void reset_env(Env<AM, LM>& s, const MapView& mv) {
+LLE_HD void reset_env(Env<AM, LM>& s, const MapView& mv, Cells<AM>& at) {
     reset_tiles<AM, LM>(s, mv);
     s.alive = (mv.A >= 32) ? 0xFFFFFFFFu : ((1u << mv.A) - 1u);
     s.arrived = 0;
 #pragma unroll
     for (int a = 0; a < AM; a++) s.pos[a] = (a < mv.A) ? (uint32_t)mv.hdr->start[a] : 0xFFFF0000u + (uint32_t)a;
+    load_cells<AM>(mv, s.pos, at);
 #pragma unroll
     for (int a = 0; a < AM; a++)
-        if (a < mv.A) lasers_pre_enter<LM>(s.beams, mv.cell_lay[cell_of(s.pos[a], mv.W)], (uint32_t)a, true, mv);
+        if (a < mv.A) lasers_pre_enter<LM>(s.beams, at.lay[a], (uint32_t)a, true, mv);
     Events<AM> ev;
     ev.clear();
 #pragma unroll
     for (int a = 0; a < AM; a++)
-        if (a < mv.A) enter_agent<AM, LM, false>(s, (uint32_t)a, cell_of(s.pos[a], mv.W), mv, ev);
+        if (a < mv.A) enter_agent<AM, LM, false>(s, (uint32_t)a, at.lay[a], at.meta[a], mv, ev);
     canonicalise<AM, LM>(s, mv);
 }
 
@@ -306,12 +326,13 @@ LLE_HD void reset_env(Env<AM, LM>& s, const MapView& mv) {
 // get_state() equals the target (world.rs:588-589).
 template <int AM, int LM, bool EMIT>
 LLE_HD bool apply_state(Env<AM, LM>& s, const uint32_t (&tpos)[AM], uint32_t tgems, uint32_t talive, const MapView& mv,
-                        Events<AM>& ev) {
+                        Events<AM>& ev, Cells<AM>& at) {
+    load_cells<AM>(mv, tpos, at);
     reset_tiles<AM, LM>(s, mv);
     s.gems = tgems & mv.hdr->direct_gems;  // only direct Tile::Gem are collected up-front (world.rs:550-554)
 #pragma unroll
     for (int a = 0; a < AM; a++)
-        if (a < mv.A) lasers_pre_enter<LM>(s.beams, mv.cell_lay[cell_of(tpos[a], mv.W)], (uint32_t)a, (s.alive >> a) & 1u, mv);
+        if (a < mv.A) lasers_pre_enter<LM>(s.beams, at.lay[a], (uint32_t)a, (s.alive >> a) & 1u, mv);
 #pragma unroll
     for (int a = 0; a < AM; a++)
         if (a < mv.A) s.pos[a] = tpos[a];
@@ -321,7 +342,7 @@ LLE_HD bool apply_state(Env<AM, LM>& s, const uint32_t (&tpos)[AM], uint32_t tge
             const uint32_t bit = 1u << a;
             s.alive |= bit;      // agent.reset()
             s.arrived &= ~bit;
-            enter_agent<AM, LM, EMIT>(s, (uint32_t)a, cell_of(tpos[a], mv.W), mv, ev);
+            enter_agent<AM, LM, EMIT>(s, (uint32_t)a, at.lay[a], at.meta[a], mv, ev);
             if (!((talive >> a) & 1u)) s.alive &= ~bit;
         }
     }
@@ -335,7 +356,7 @@ LLE_HD bool apply_state(Env<AM, LM>& s, const uint32_t (&tpos)[AM], uint32_t tge
 // `avail_dirty`: whether compute_available_actions ran in the reference.
 template <int AM, int LM>
 LLE_HD uint8_t set_state_env(Env<AM, LM>& s, const uint32_t (&req_pos)[AM], uint32_t req_gems, uint32_t req_alive,
-                             const MapView& mv, Events<AM>& ev, bool& avail_dirty) {
+                             const MapView& mv, Events<AM>& ev, bool& avail_dirty, Cells<AM>& at) {
     avail_dirty = false;
     const uint32_t amask = (1u << mv.A) - 1u, gmask = (mv.G >= 32) ? 0xFFFFFFFFu : ((1u << mv.G) - 1u);
     req_alive &= amask;
@@ -366,10 +387,10 @@ LLE_HD uint8_t set_state_env(Env<AM, LM>& s, const uint32_t (&req_pos)[AM], uint
         dropped.clear();
         // the reference `.unwrap()`s this inner call: if the snapshot cannot be restored (a collected gem under a
         // beam) it panics before compute_available_actions; otherwise the availability lists were recomputed
-        avail_dirty = apply_state<AM, LM, false>(s, cur_pos, s.gems, s.alive, mv, dropped);
+        avail_dirty = apply_state<AM, LM, false>(s, cur_pos, s.gems, s.alive, mv, dropped, at);
         return ENV_INVALID_AGENT_POSITION;
     }
-    if (!apply_state<AM, LM, true>(s, req_pos, req_gems, req_alive, mv, ev)) return ENV_INVALID_WORLD_STATE;
+    if (!apply_state<AM, LM, true>(s, req_pos, req_gems, req_alive, mv, ev, at)) return ENV_INVALID_WORLD_STATE;
     avail_dirty = true;
     return ENV_OK;
 }

@@ -89,6 +89,7 @@ struct LaunchArgs {
     const uint8_t* actions_in; // step: optional u8[n][A]
     uint32_t old_enabled;      // update_sources: enabled mask before the update
     uint32_t pad;
+    uint64_t* stamps;          // profiling aid: [n_blocks][8] s_memrealtime stamps (10 ns ticks) of lane 0, or NULL
 };
 
 // State of a freshly reset environment (identical for every env of a map: v1 maps have one start per agent).

@@ -58,10 +58,13 @@ static void run(hs_batch* b, int mode, uint32_t flags, uint64_t seed, uint64_t t
         if (mode == M_STEP) {
             for (int a = 0; a < AM; a++) avail[a] = (a < A) ? (uint32_t)b->avail[env * A + a] : 0u;
             if ((flags & STEP_AUTO_RESET) && (s.alive != amask || s.arrived == amask)) {
-                reset_env<AM, LM>(s, mv);
-                compute_avail<AM, LM>(s, mv, avail);
+                Cells<AM> at;
+                reset_env<AM, LM>(s, mv, at);
+                compute_avail<AM, LM>(s, mv, at, avail);
                 was_reset = 1;
             }
+            Cells<AM> cur;
+            load_cells<AM>(mv, s.pos, cur);
             uint32_t act[AM];
             if (flags & STEP_SAMPLE_ACTIONS) {
                 const uint64_t he = action_hash_env(seed, (uint64_t)(env_offset + env), t);
@@ -80,13 +83,14 @@ static void run(hs_batch* b, int mode, uint32_t flags, uint64_t seed, uint64_t t
                     // `avail` is the cached list of the reference (world.rs:444-453).  It can only disagree with the
                     // static walk mask after a failed set_state left it stale (world.rs:588-594 returns before
                     // recomputing it); the reference would then index out of the grid and panic, we refuse the action.
-                    const uint32_t walk = ((mv.cell_meta[cell_of(s.pos[a], mv.W)] >> 8) & 15u) | 16u;
+                    const uint32_t walk = ((cur.meta[a] >> 8) & 15u) | 16u;
                     if (act[a] > 4u || !((avail[a] >> act[a]) & 1u) || !((walk >> act[a]) & 1u)) err = (uint32_t)a + 1u;
                 }
             }
             if (err == 0) {
-                step_env<AM, LM>(s, act, mv, ev);
-                compute_avail<AM, LM>(s, mv, avail);
+                Cells<AM> fin;
+                step_env<AM, LM>(s, act, mv, ev, cur, fin);
+                compute_avail<AM, LM>(s, mv, fin, avail);
                 store_avail = true;
             } else {
                 store_state = was_reset != 0;
@@ -94,8 +98,9 @@ static void run(hs_batch* b, int mode, uint32_t flags, uint64_t seed, uint64_t t
             }
         } else if (mode == M_RESET) {
             if (!env_mask || env_mask[env]) {
-                reset_env<AM, LM>(s, mv);
-                compute_avail<AM, LM>(s, mv, avail);
+                Cells<AM> at;
+                reset_env<AM, LM>(s, mv, at);
+                compute_avail<AM, LM>(s, mv, at, avail);
                 store_avail = true;
             } else {
                 store_state = false;
@@ -105,9 +110,10 @@ static void run(hs_batch* b, int mode, uint32_t flags, uint64_t seed, uint64_t t
             uint32_t rp[AM];
             for (int a = 0; a < AM; a++) rp[a] = (a < A) ? (uint32_t)b->req_pos[env * A + a] : 0xFFFF0000u + (uint32_t)a;
             bool dirty = false;
-            err = set_state_env<AM, LM>(s, rp, b->req_gems[env], (uint32_t)b->req_alive[env], mv, ev, dirty);
+            Cells<AM> at;
+            err = set_state_env<AM, LM>(s, rp, b->req_gems[env], (uint32_t)b->req_alive[env], mv, ev, dirty, at);
             if (err != 0) ev.clear();
-            if (dirty) { compute_avail<AM, LM>(s, mv, avail); store_avail = true; }
+            if (dirty) { load_cells<AM>(mv, s.pos, at); compute_avail<AM, LM>(s, mv, at, avail); store_avail = true; }
         } else if (mode == M_SOURCES) {
             for (int k = 0; k < LM; k++) {
                 if (k < L) {
