@@ -209,7 +209,8 @@ int lle_batch_kernel_info(const lle_batch* b, char* name_buf, size_t cap, int32_
  * (10 ns ticks: entry, tables in LDS, state requested, logic done, state stored, observation stores issued, drained)
  * to stamps_dev [n_waves][8] u64. */
 int lle_batch_step_stamped(lle_batch* b, uint32_t flags, uint64_t seed, uint64_t t, uint64_t* stamps_dev, void* stream);
-/* Tuning knob: environments per wavefront in the step kernel (8, 16, 32 or 64). */
+/* Diagnostic knob: step with the one-environment-per-lane kernel at 8, 16, 32 or 64 environments per wavefront
+ * instead of the default one-lane-per-agent step kernel (64 / G environments per wavefront). */
 int lle_batch_set_envs_per_wave(lle_batch* b, int envs_per_wave);
 
 #ifdef __cplusplus

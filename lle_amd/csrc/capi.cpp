@@ -86,6 +86,7 @@ Layout make_layout(const MapHeader& h, int64_t n) {
 }  // namespace
 
 struct lle_batch {
+    bool lane_per_env_step;  // tuning/diagnostic: step with world_kernel (one env per lane) instead of step_kernel
     MapHeader hdr;
     int64_t n_envs;
     int device;
@@ -236,7 +237,10 @@ static int launch(lle_batch* b, int mode, LaunchArgs K, void* stream) {
     K.envs_per_wave = b->envs_per_wave;
     K.env_base = 0;
     K.env_limit = b->n_envs;
-    HIP_TRY(launch_world_kernel(mode, b->hdr, b->ptrs, K, (hipStream_t)stream));
+    if (mode == KMODE_STEP && !b->lane_per_env_step)
+        HIP_TRY(launch_step_kernel(b->hdr, b->ptrs, K, (hipStream_t)stream));
+    else
+        HIP_TRY(launch_world_kernel(mode, b->hdr, b->ptrs, K, (hipStream_t)stream));
     g_status = LLE_OK;
     return LLE_OK;
 }
@@ -307,6 +311,7 @@ lle_batch* lle_batch_create(const lle_map* map, int64_t n_envs, int device_id, v
     b->device = device_id;
     b->arena = nullptr;
     b->owns_arena = false;
+    b->lane_per_env_step = false;
     // enough waves to cover the 256 CUs several times over, at most 32 envs per wave (measured best on level 6)
     b->envs_per_wave = 32;
     while (b->envs_per_wave > MIN_ENVS_PER_WAVE && n_envs / b->envs_per_wave < 2048) b->envs_per_wave /= 2;
@@ -414,9 +419,12 @@ int lle_batch_stats(lle_batch* b, int64_t out[8], int reset_counters, void* stre
 
 int lle_batch_kernel_info(const lle_batch* b, char* name_buf, size_t cap, int32_t* lds_bytes, int32_t* envs_per_wave) {
     if (!b) return fail(LLE_ERR_NULL, "NULL batch");
-    if (name_buf && cap) std::snprintf(name_buf, cap, "%s", kernel_variant_name(kernel_variant((int)b->hdr.A, (int)b->hdr.L)));
+    if (name_buf && cap) {
+        if (b->lane_per_env_step) std::snprintf(name_buf, cap, "%s", kernel_variant_name(kernel_variant((int)b->hdr.A, (int)b->hdr.L)));
+        else std::snprintf(name_buf, cap, "step_kernel<%d,%d>", step_group((int)b->hdr.A), step_lm((int)b->hdr.L));
+    }
     if (lds_bytes) *lds_bytes = (int32_t)kernel_lds_bytes(b->hdr, kernel_waves_per_wg(b->hdr));
-    if (envs_per_wave) *envs_per_wave = (int32_t)b->envs_per_wave;
+    if (envs_per_wave) *envs_per_wave = b->lane_per_env_step ? (int32_t)b->envs_per_wave : 64 / step_group((int)b->hdr.A);
     return LLE_OK;
 }
 
@@ -433,6 +441,7 @@ int lle_batch_set_envs_per_wave(lle_batch* b, int epw) {
     if (!b) return fail(LLE_ERR_NULL, "NULL batch");
     if (epw < (int)MIN_ENVS_PER_WAVE || epw > 64 || (epw & (epw - 1))) return fail(LLE_ERR_ARG, "envs_per_wave must be 8, 16, 32 or 64");
     b->envs_per_wave = (uint32_t)epw;
+    b->lane_per_env_step = true;  // the knob belongs to the lane-per-env step kernel
     return LLE_OK;
 }
 

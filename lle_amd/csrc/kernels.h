@@ -7,7 +7,7 @@
 namespace lle {
 
 enum { KMODE_STEP = 0, KMODE_RESET = 1, KMODE_SET_STATE = 2, KMODE_OBSERVE = 3, KMODE_SOURCES = 4 };
-constexpr uint32_t MIN_ENVS_PER_WAVE = 8;
+constexpr uint32_t MIN_ENVS_PER_WAVE = 4;  // step_kernel<16, .>: 4 environments per wavefront
 
 int kernel_variant(int A, int L);
 int agent_stride(int A, int L);  // agents per env record in the per-agent buffers (= the variant's agent bound)
@@ -15,5 +15,9 @@ const char* kernel_variant_name(int variant);
 uint32_t kernel_lds_bytes(const MapHeader& h, uint32_t waves_per_wg);
 uint32_t kernel_waves_per_wg(const MapHeader& h);
 hipError_t launch_world_kernel(int mode, const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K, hipStream_t stream);
+// World.step with one lane per agent (the default step path)
+hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K, hipStream_t stream);
+int step_group(int A);
+int step_lm(int L);
 
 }  // namespace lle

@@ -40,6 +40,103 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
     return v;
 }
 
+// ---- static tables -> LDS, once per workgroup (section offsets are those of the blob).  The section is a whole
+// number of 1 KiB rows; every thread requests all of its rows (up to four) before the first LDS write.
+__device__ __forceinline__ void copy_tables_to_lds(const uint8_t* __restrict__ tables, uint8_t* lds, uint32_t tab_bytes,
+                                                   uint32_t lane, uint32_t wave_in_wg, uint32_t waves_per_wg) {
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(tables) + lane;
+    uint4* dst = reinterpret_cast<uint4*>(lds) + lane;
+    const uint32_t rows = tab_bytes / 1024;
+    for (uint32_t r0 = wave_in_wg; r0 < rows; r0 += 4 * waves_per_wg) {
+        uint4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (r0 + q * waves_per_wg < rows) v[q] = src[(r0 + q * waves_per_wg) * 64];
+        __builtin_amdgcn_sched_barrier(0);  // keep the loads together, ahead of the LDS writes
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (r0 + q * waves_per_wg < rows) dst[(r0 + q * waves_per_wg) * 64] = v[q];
+    }
+}
+
+// ---- phase 2: layered observation of the wave's environments, one environment at a time.
+// `scratch` holds one hand-over record per environment: [0 | beam masks | ~gem bits | byte index of each agent].
+__device__ __forceinline__ void write_observations(const MapHeader* __restrict__ hdr, const uint64_t* dyn, int8_t* tmpl,
+                                                   const uint32_t* scratch, uint32_t scr_stride, int8_t* __restrict__ obs,
+                                                   int64_t env0, int64_t n_here, uint32_t lane) {
+    const int A = (int)hdr->A, L = (int)hdr->L;
+    const uint64_t obs_stride = hdr->obs_stride;
+    const uint32_t D = hdr->D, n_chunks = hdr->n_chunks;
+    // Each lane serves the same dyn entry for every environment: decode it once.
+    // A laser / gem reference becomes (dword of the hand-over record, bit); an absent one points at the record's
+    // zero word, so the per-environment evaluation is branch-free.
+    const bool has_d0 = lane < D;
+    const uint64_t e0 = has_d0 ? dyn[lane] : 0ull;
+    const uint32_t d0_idx = (uint32_t)e0 & 0xFFFFFu;
+    const int32_t d0_base = (int8_t)(uint8_t)(e0 >> 20);
+    const uint32_t d0_refs = (uint32_t)(e0 >> 28) & 3u, d0_gem = (uint32_t)(e0 >> 50) & 63u;
+    const uint32_t d0_r0 = (uint32_t)(e0 >> 30) & 0x3FFu, d0_r1 = (uint32_t)(e0 >> 40) & 0x3FFu;
+    const uint32_t d0_w0 = d0_refs >= 1 ? 1u + (d0_r0 & 31u) : 0u, d0_s0 = d0_refs >= 1 ? d0_r0 >> 5 : 0u;
+    const uint32_t d0_w1 = d0_refs >= 2 ? 1u + (d0_r1 & 31u) : 0u, d0_s1 = d0_refs >= 2 ? d0_r1 >> 5 : 0u;
+    const uint32_t d0_wg = d0_gem != NO_GEM ? (uint32_t)L + 1u : 0u, d0_sg = d0_gem != NO_GEM ? (d0_gem & 31u) : 0u;
+    const bool is_agent_lane = (int)lane < A;
+    const uint4* srcv = reinterpret_cast<const uint4*>(tmpl);
+
+    for (int64_t k = 0; k < n_here; k++) {
+        const uint32_t* sc = scratch + (uint32_t)k * scr_stride;
+        // (a) bytes that depend on beams / gems
+        {
+            const uint32_t lit = ((sc[d0_w0] >> d0_s0) | (sc[d0_w1] >> d0_s1) | (sc[d0_wg] >> d0_sg)) & 1u;
+            if (has_d0) tmpl[d0_idx] = (int8_t)(lit ? 1 : d0_base);
+        }
+        for (uint32_t d = lane + 64u; d < D; d += 64) {  // maps with more than 64 dynamic bytes
+            const uint64_t e = dyn[d];
+            const uint32_t refs = (uint32_t)(e >> 28) & 3u, gem = (uint32_t)(e >> 50) & 63u;
+            const uint32_t r0 = (uint32_t)(e >> 30) & 0x3FFu, r1 = (uint32_t)(e >> 40) & 0x3FFu;
+            const uint32_t w0 = refs >= 1 ? 1u + (r0 & 31u) : 0u, w1 = refs >= 2 ? 1u + (r1 & 31u) : 0u;
+            const uint32_t wg = gem != NO_GEM ? (uint32_t)L + 1u : 0u;
+            const uint32_t lit = ((sc[w0] >> (refs >= 1 ? r0 >> 5 : 0u)) | (sc[w1] >> (refs >= 2 ? r1 >> 5 : 0u)) |
+                                  (sc[wg] >> (gem != NO_GEM ? (gem & 31u) : 0u))) & 1u;
+            tmpl[(uint32_t)e & 0xFFFFFu] = (int8_t)(lit ? 1 : (int32_t)(int8_t)(uint8_t)(e >> 20));
+        }
+        // (b) agents (dead ones included, observations.py:264-265)
+        const uint32_t agent_idx = is_agent_lane ? sc[L + 2 + lane] : 0u;
+        if (is_agent_lane) tmpl[agent_idx] = 1;
+        wave_sync();
+        // (c) stream the patched copy as one contiguous row: 16 B per lane, 1 KiB per wave instruction
+        uint4* __restrict__ dst = reinterpret_cast<uint4*>(obs + (uint64_t)(env0 + k) * obs_stride);
+        {
+            const uint32_t c0 = lane, c1 = lane + 64u;
+            const uint4 v0 = srcv[c0 < n_chunks ? c0 : 0u], v1 = srcv[c1 < n_chunks ? c1 : 0u];
+            // plain stores: `nt` measured 40 % slower and `sc0 sc1` (write-through) no faster at 65 536 envs and
+            // 50 % slower at 262 144
+            if (c0 < n_chunks) dst[c0] = v0;
+            if (c1 < n_chunks) dst[c1] = v1;
+        }
+        for (uint32_t c = lane + 128u; c < n_chunks; c += 64) dst[c] = srcv[c];  // rows longer than 2 KiB
+        wave_sync();
+        // (d) agents off again (their layers are all-zero in the static copy); LDS is in order, so this lands after
+        // the reads above and before the next environment's patches
+        if (is_agent_lane) tmpl[agent_idx] = 0;
+    }
+}
+
+// per-wave partial counters, written last so that their read-modify-write latency is off the observation's path;
+// the slot of a wave is private, so no atomics
+__device__ __forceinline__ void flush_stats(int64_t* __restrict__ stats, uint32_t wave_id, uint64_t stat1, uint64_t stat2, int A,
+                                            uint32_t lane) {
+    const uint64_t p1 = wave_sum_u64(stat1);
+    const uint64_t p2 = wave_sum_u64(stat2);
+    if (lane == 0) {
+        int64_t* out = stats + (int64_t)wave_id * 8;
+        const int64_t gems = p1 & 0xFFF, exits = (p1 >> 12) & 0xFFF, died = (p1 >> 24) & 0xFFF;
+        const int64_t invalid = (p1 >> 36) & 0xFFF, resets = (p1 >> 48) & 0xFFF;
+        const int64_t steps = p2 & 0xFFF, bonus = (p2 >> 12) & 0xFFF;
+        out[0] += steps; out[1] += steps * A; out[2] += gems; out[3] += exits; out[4] += died;
+        out[5] += invalid; out[6] += resets; out[7] += gems + exits - died + bonus;
+    }
+}
+
 // ---- per-env record I/O.  The per-agent buffers (pos, avail, actions, events) are laid out with a stride of AM
 // agents per env (AM = the kernel instantiation's bound, >= the map's A), so a record is a whole number of dwords
 // whatever A is, and moves as dwords (the compiler merges neighbours into dwordx2/x4).
@@ -91,24 +188,8 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
         if (K.stamps && lane == 0) K.stamps[(uint64_t)wave_id * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
     LLE_STAMP(0);
-    // ---- static tables -> LDS, once per workgroup (section offsets are those of the blob).  The section is a whole
-    // number of 1 KiB rows; every thread requests all of its rows (up to four) before the first LDS write.
     const uint32_t tab_bytes = hdr->lds_table_bytes, tab_off = hdr->off_cell_lay;
-    {
-        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(P.tables + tab_off) + lane;
-        uint4* dst = reinterpret_cast<uint4*>(lds) + lane;
-        const uint32_t rows = tab_bytes / 1024;
-        for (uint32_t r0 = wave_in_wg; r0 < rows; r0 += 4 * waves_per_wg) {
-            uint4 v[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                if (r0 + q * waves_per_wg < rows) v[q] = src[(r0 + q * waves_per_wg) * 64];
-            __builtin_amdgcn_sched_barrier(0);  // keep the loads together, ahead of the LDS writes
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                if (r0 + q * waves_per_wg < rows) dst[(r0 + q * waves_per_wg) * 64] = v[q];
-        }
-    }
+    copy_tables_to_lds(P.tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
     LLE_STAMP(7);
     __syncthreads();  // the only workgroup barrier: nothing is in flight yet but the loads above
     // ---- the env's packed state and (for auto-reset) the reset-state record, requested raw and together.  (Issued
@@ -330,78 +411,328 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
 
     LLE_STAMP(4);
     // ---- phase 2: layered observation, one environment of the wave at a time
-    if (write_obs && n_here > 0) {
-    const uint32_t D = hdr->D, n_chunks = hdr->n_chunks;
-    // Each lane serves the same dyn entry for every environment: decode it once.
-    // A laser / gem reference becomes (dword of the hand-over record, bit); an absent one points at the record's
-    // zero word, so the per-environment evaluation is branch-free.
-    const bool has_d0 = lane < D;
-    const uint64_t e0 = has_d0 ? dyn[lane] : 0ull;
-    const uint32_t d0_idx = (uint32_t)e0 & 0xFFFFFu;
-    const int32_t d0_base = (int8_t)(uint8_t)(e0 >> 20);
-    const uint32_t d0_refs = (uint32_t)(e0 >> 28) & 3u, d0_gem = (uint32_t)(e0 >> 50) & 63u;
-    const uint32_t d0_r0 = (uint32_t)(e0 >> 30) & 0x3FFu, d0_r1 = (uint32_t)(e0 >> 40) & 0x3FFu;
-    const uint32_t d0_w0 = d0_refs >= 1 ? 1u + (d0_r0 & 31u) : 0u, d0_s0 = d0_refs >= 1 ? d0_r0 >> 5 : 0u;
-    const uint32_t d0_w1 = d0_refs >= 2 ? 1u + (d0_r1 & 31u) : 0u, d0_s1 = d0_refs >= 2 ? d0_r1 >> 5 : 0u;
-    const uint32_t d0_wg = d0_gem != NO_GEM ? (uint32_t)L + 1u : 0u, d0_sg = d0_gem != NO_GEM ? (d0_gem & 31u) : 0u;
-    const bool is_agent_lane = (int)lane < A;
-    const uint4* srcv = reinterpret_cast<const uint4*>(tmpl);
-
-    for (int64_t k = 0; k < n_here; k++) {
-        const uint32_t* sc = scratch + (uint32_t)k * scr_stride;
-        // (a) bytes that depend on beams / gems
-        {
-            const uint32_t lit = ((sc[d0_w0] >> d0_s0) | (sc[d0_w1] >> d0_s1) | (sc[d0_wg] >> d0_sg)) & 1u;
-            if (has_d0) tmpl[d0_idx] = (int8_t)(lit ? 1 : d0_base);
-        }
-        for (uint32_t d = lane + 64u; d < D; d += 64) {  // maps with more than 64 dynamic bytes
-            const uint64_t e = dyn[d];
-            const uint32_t refs = (uint32_t)(e >> 28) & 3u, gem = (uint32_t)(e >> 50) & 63u;
-            const uint32_t r0 = (uint32_t)(e >> 30) & 0x3FFu, r1 = (uint32_t)(e >> 40) & 0x3FFu;
-            const uint32_t w0 = refs >= 1 ? 1u + (r0 & 31u) : 0u, w1 = refs >= 2 ? 1u + (r1 & 31u) : 0u;
-            const uint32_t wg = gem != NO_GEM ? (uint32_t)L + 1u : 0u;
-            const uint32_t lit = ((sc[w0] >> (refs >= 1 ? r0 >> 5 : 0u)) | (sc[w1] >> (refs >= 2 ? r1 >> 5 : 0u)) |
-                                  (sc[wg] >> (gem != NO_GEM ? (gem & 31u) : 0u))) & 1u;
-            tmpl[(uint32_t)e & 0xFFFFFu] = (int8_t)(lit ? 1 : (int32_t)(int8_t)(uint8_t)(e >> 20));
-        }
-        // (b) agents (dead ones included, observations.py:264-265)
-        const uint32_t agent_idx = is_agent_lane ? sc[L + 2 + lane] : 0u;
-        if (is_agent_lane) tmpl[agent_idx] = 1;
-        wave_sync();
-        // (c) stream the patched copy as one contiguous row: 16 B per lane, 1 KiB per wave instruction
-        uint4* __restrict__ dst = reinterpret_cast<uint4*>(P.obs + (uint64_t)(env0 + k) * obs_stride);
-        {
-            const uint32_t c0 = lane, c1 = lane + 64u;
-            const uint4 v0 = srcv[c0 < n_chunks ? c0 : 0u], v1 = srcv[c1 < n_chunks ? c1 : 0u];
-            // plain stores: `nt` measured 40 % slower and `sc0 sc1` (write-through) no faster at 65 536 envs and
-            // 50 % slower at 262 144
-            if (c0 < n_chunks) dst[c0] = v0;
-            if (c1 < n_chunks) dst[c1] = v1;
-        }
-        for (uint32_t c = lane + 128u; c < n_chunks; c += 64) dst[c] = srcv[c];  // rows longer than 2 KiB
-        wave_sync();
-        // (d) agents off again (their layers are all-zero in the static copy); LDS is in order, so this lands after
-        // the reads above and before the next environment's patches
-        if (is_agent_lane) tmpl[agent_idx] = 0;
-    }
-    }
+    if (write_obs && n_here > 0)
+        write_observations(hdr, dyn, tmpl, scratch, scr_stride, P.obs, env0, n_here, lane);
     LLE_STAMP(5);
-    if (MODE == MODE_STEP) {
-        // per-wave partial counters, last so that their read-modify-write latency is off the observation's path;
-        // the slot of this wave is private, so no atomics
-        const uint64_t p1 = wave_sum_u64(stat1);
-        const uint64_t p2 = wave_sum_u64(stat2);
-        if (lane == 0) {
-            int64_t* out = P.stats + (int64_t)wave_id * 8;
-            const int64_t gems = p1 & 0xFFF, exits = (p1 >> 12) & 0xFFF, died = (p1 >> 24) & 0xFFF;
-            const int64_t invalid = (p1 >> 36) & 0xFFF, resets = (p1 >> 48) & 0xFFF;
-            const int64_t steps = p2 & 0xFFF, bonus = (p2 >> 12) & 0xFFF;
-            out[0] += steps; out[1] += steps * A; out[2] += gems; out[3] += exits; out[4] += died;
-            out[5] += invalid; out[6] += resets; out[7] += gems + exits - died + bonus;
-        }
+    if (MODE == MODE_STEP) flush_stats(P.stats, wave_id, stat1, stat2, A, lane);
+
+    if (K.stamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        LLE_STAMP(6);
+    }
+}
+
+// ================================================================================================
+// step_kernel<G, LM>: World.step() with one LANE PER AGENT (G = lanes per environment = power of two >= A).
+//
+// world_kernel<.., MODE_STEP> above runs one environment per lane: simple, but phase 1 is then a ~4k-instruction
+// dependency chain of ONE wave that no amount of occupancy shortens, and every wave runs it at the same time
+// (launch cost = chain + observation stream).  Here the agents of an environment sit in G neighbouring lanes, so the
+// per-agent loops of move_agents / compute_available_actions / the sampler become lane-parallel and the chain is
+// ~G times shorter; a 64-lane wave carries 64/G environments and four times as many waves share each SIMD.
+//
+// What makes the split legal (same results as the sequential reference, src/core/world.rs:477-505):
+//   * leaves of one pass commute (each only turns bits ON, and a leave skipped because an earlier one already lit its
+//     bit would have been a no-op): beam |= OR over the group of every lane's suffix;
+//   * pre-enters commute (each only clears a suffix): beam &= AND over the group of every lane's prefix;
+//   * enter reads the beams (final after leave+pre-enter) and touches only the agent's own flags, its own cell's
+//     gem and the occupant slot of its own cell (agents never share a cell), so the enters of one pass are
+//     independent; their events are ordered by agent id = lane order (prefix count inside the group);
+//   * the three loops stay in the reference's order, and passes repeat while any agent of the environment died.
+// Cross-lane traffic is DPP quad permutes (G <= 4) / ds_swizzle (G = 8, 16); nothing goes through memory.
+
+template <int J>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
+    static_assert(J >= 1 && J < 16, "group offsets only");
+    if (J == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+    if (J == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+    if (J == 3) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x1B, 0xF, 0xF, true);  // quad_perm [3,2,1,0]
+    return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (J << 10));                     // lane ^ J within 32 lanes
+}
+template <int G>
+__device__ __forceinline__ uint32_t grp_or(uint32_t v) {
+    if (G > 1) v |= lane_xor<1>(v);
+    if (G > 2) v |= lane_xor<2>(v);
+    if (G > 4) v |= lane_xor<4>(v);
+    if (G > 8) v |= lane_xor<8>(v);
+    return v;
+}
+template <int G>
+__device__ __forceinline__ uint64_t grp_or64(uint64_t v) {
+    return (uint64_t)grp_or<G>((uint32_t)v) | ((uint64_t)grp_or<G>((uint32_t)(v >> 32)) << 32);
+}
+
+// value of `v` in the group lane whose agent id is (a ^ J), for every J in 1..G-1, fed to f(other_agent_offset J, value)
+template <int G, int J = 1, typename F>
+__device__ __forceinline__ void for_each_other(uint32_t v, F&& f) {
+    if constexpr (J < G) {
+        f(J, lane_xor<J>(v));
+        for_each_other<G, J + 1>(v, f);
+    }
+}
+
+template <int G, int LM>
+__global__ void __launch_bounds__(256) step_kernel(BatchPtrs P, LaunchArgs K) {
+    constexpr int EPW = 64 / G;                     // environments per wavefront
+    constexpr int NW = (2 * G + 7) / 8;             // 64-bit words of the event list (2 events per agent at most)
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const MapHeader* __restrict__ hdr = reinterpret_cast<const MapHeader*>(P.tables);
+    const uint32_t lane = threadIdx.x & 63u, wave_in_wg = threadIdx.x >> 6, waves_per_wg = blockDim.x >> 6;
+    const uint32_t wave_id = blockIdx.x * waves_per_wg + wave_in_wg;
+    const int A = (int)hdr->A, L = (int)hdr->L, W = (int)hdr->W;
+    const uint32_t a = lane & (G - 1), grp = lane / G;  // agent id, environment slot in the wave
+    const int64_t As = agent_stride_of(A, L);           // env pitch of the per-agent buffers
+    const int64_t env0 = K.env_base + (int64_t)wave_id * EPW;
+    const int64_t env = env0 + grp;
+    const bool env_ok = env < K.env_limit;
+    const bool me = env_ok && (int)a < A;           // this lane carries a real agent
+    const bool write_obs = hdr->obs_supported && !(K.flags & STEP_NO_OBS);
+    const int64_t n_here = (K.env_limit - env0) < (int64_t)EPW ? (K.env_limit - env0) : (int64_t)EPW;
+    const uint32_t bit = 1u << a, amask = (1u << A) - 1u;
+    LLE_STAMP(0);
+
+    const uint32_t tab_bytes = hdr->lds_table_bytes, tab_off = hdr->off_cell_lay;
+    copy_tables_to_lds(P.tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
+    LLE_STAMP(7);
+    __syncthreads();  // the only workgroup barrier
+
+    // ---- packed state: own position / availability, and the env-wide words replicated in the group's lanes
+    uint32_t pos = 0xFFFF0000u + a, avail = 0, beams[LM];
+    uint64_t raw_bits = 0;
+    uint32_t gems = 0;
+#pragma unroll
+    for (int b = 0; b < LM; b++) beams[b] = 0;
+    if (env_ok) {
+        raw_bits = P.bits[env];
+        gems = P.gems[env];
+#pragma unroll
+        for (int b = 0; b < LM; b++)
+            if (b < L) beams[b] = P.beams[env * L + b];
+    }
+    if (me) {
+        pos = (uint32_t)P.pos[env * As + a];
+        avail = (uint32_t)P.avail[env * As + a];
+    }
+    const uint64_t init_bits = P.init->bits;
+    const uint32_t init_gems = P.init->gems;
+
+    const uint64_t* cell_lay = reinterpret_cast<const uint64_t*>(lds);
+    const uint32_t* cell_meta = reinterpret_cast<const uint32_t*>(lds + (hdr->off_cell_meta - tab_off));
+    const uint64_t* dyn = reinterpret_cast<const uint64_t*>(lds + (hdr->off_dyn - tab_off));
+    const uint32_t scr_stride = (uint32_t)(L + A + 2) | 1u;
+    const uint32_t priv_bytes = hdr->obs_stride + 64u * scr_stride * 4u;
+    int8_t* tmpl = reinterpret_cast<int8_t*>(lds + tab_bytes + wave_in_wg * priv_bytes);
+    uint32_t* scratch = reinterpret_cast<uint32_t*>(tmpl + hdr->obs_stride);
+    {
+        const uint4* pristine = reinterpret_cast<const uint4*>(lds + (hdr->off_template - tab_off));
+        uint4* mine = reinterpret_cast<uint4*>(tmpl);
+        for (uint32_t c = lane; c < hdr->n_chunks; c += 64) mine[c] = pristine[c];
+    }
+    wave_sync();
+    LLE_STAMP(1);
+
+    uint32_t alive = (uint32_t)raw_bits & 0xFFFFu, arrived = (uint32_t)(raw_bits >> 16) & 0xFFFFu, occ = (uint32_t)(raw_bits >> 32) & 0xFFFFu;
+    const uint32_t enabled = hdr->enabled_mask, max_layers = hdr->max_layers;
+    LLE_STAMP(2);
+
+    // ---- auto-reset: a finished env restarts from the reset state (identical for every env, see InitRecord)
+    uint32_t was_reset = 0;
+    if (K.flags & STEP_AUTO_RESET) {
+        const bool over = env_ok && (alive != amask || arrived == amask);
+        const uint32_t ipos = me ? (uint32_t)P.init->pos[a] : pos, iav = me ? (uint32_t)P.init->avail[a] : avail;
+        pos = over ? ipos : pos;
+        avail = over ? iav : avail;
+        alive = over ? ((uint32_t)init_bits & 0xFFFFu) : alive;
+        arrived = over ? ((uint32_t)(init_bits >> 16) & 0xFFFFu) : arrived;
+        occ = over ? ((uint32_t)(init_bits >> 32) & 0xFFFFu) : occ;
+        gems = over ? init_gems : gems;
+#pragma unroll
+        for (int b = 0; b < LM; b++)
+            if (b < L) beams[b] = over ? P.init->beams[b] : beams[b];
+        was_reset = over ? 1u : 0u;
     }
 
+    // ---- joint action: sampled on the device, or given
+    uint32_t act = 4u;
+    if (K.flags & STEP_SAMPLE_ACTIONS) {
+        const uint64_t he = action_hash_env(K.seed, (uint64_t)(K.env_offset + env), K.t);
+        const uint64_t hg = action_hash_group(he, (uint64_t)(a >> 2));
+        act = sample_action(avail, action_field(hg, a));
+        if (me) P.actions[env * As + a] = (uint8_t)act;
+    } else if (K.actions_in) {
+        if (me) {
+            act = (uint32_t)K.actions_in[env * A + a];  // caller's buffer: contiguous [n][A]
+            P.actions[env * As + a] = (uint8_t)act;
+        }
+    } else if (me) {
+        act = (uint32_t)P.actions[env * As + a];
+    }
 
+    // ---- availability check (world.rs:444-453): lowest offending agent, before any mutation.  The cached list can
+    // only disagree with the static walk mask after a failed set_state left it stale; such an action is refused.
+    const uint32_t cur_cell = me ? cell_of(pos, W) : 0u;
+    const uint64_t lay_cur = cell_lay[cur_cell];
+    const uint32_t meta_cur = cell_meta[cur_cell];
+    const uint32_t walk_cur = ((meta_cur >> 8) & 15u) | 16u;
+    const bool bad = me && (act > 4u || !(((avail & walk_cur) >> (act & 7u)) & 1u));
+    const uint32_t badmask = grp_or<G>(bad ? bit : 0u);
+    const uint32_t err = badmask ? (uint32_t)__ffs((int)badmask) : 0u;
+
+    uint64_t evw[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++) evw[k] = 0;
+    uint32_t n_ev = 0;
+    uint32_t meta_fin = meta_cur;
+
+    if (env_ok && err == 0) {
+        // target cell (src/action.rs:18-26 on the packed i | j << 8 form); lanes without an agent keep a unique sentinel
+        uint32_t np = me ? apply_action(pos, act) : pos;
+        // solve_vertex_conflicts (world.rs:365-378): every agent whose target is shared goes back to its cell
+        bool again = true;
+        while (__any(again)) {
+            bool dup = false;
+            for_each_other<G>(np, [&](int, uint32_t other) { dup |= (other == np); });
+            np = dup ? pos : np;
+            again = grp_or<G>(dup ? 1u : 0u) != 0;
+        }
+        const uint32_t new_cell = me ? cell_of(np, W) : 0u;
+        const uint64_t lay_new = cell_lay[new_cell];
+        const uint32_t meta_new = cell_meta[new_cell];
+        meta_fin = meta_new;
+        const uint32_t kind = meta_new & 7u;
+        const uint32_t gbit = 1u << ((meta_new >> 3) & 31u);
+
+        // move_agents passes (world.rs:464-472)
+        bool go = true;
+        uint64_t lay_from = lay_cur;  // pass 1 leaves the old cells, later passes the new ones
+        while (__any(go)) {
+            if (go) {
+                const uint32_t alive0 = alive;
+                const bool me_alive = me && (alive0 & bit);
+                occ &= ~alive0;  // Tile::leave: slot.take() for every alive agent
+#pragma unroll
+                for (int b = 0; b < LM; b++) {
+                    if (b < L) {
+                        uint32_t light = 0, keep = 0xFFFFFFFFu;
+                        for (uint32_t k = 0; k < max_layers; k++) {
+                            const uint32_t eo = (uint32_t)(lay_from >> (16 * k)) & 0xFFFFu;  // leave (laser.rs:199-202,157-162)
+                            const bool lo = me_alive && (eo & LAY_VALID) && ((eo >> 1) & 31u) == (uint32_t)b &&
+                                            !((beams[b] >> ((eo >> 6) & 31u)) & 1u);
+                            light |= lo ? (0xFFFFFFFFu << ((eo >> 6) & 31u)) : 0u;
+                            const uint32_t en = (uint32_t)(lay_new >> (16 * k)) & 0xFFFFu;   // pre_enter (laser.rs:173-182)
+                            const bool pe = me_alive && (en & LAY_VALID) && ((en >> 1) & 31u) == (uint32_t)b && (en >> 11) == a;
+                            keep &= pe ? ((1u << ((en >> 6) & 31u)) - 1u) : 0xFFFFFFFFu;
+                        }
+                        const bool on = (enabled >> b) & 1u;
+                        const uint32_t lit = grp_or<G>(on ? light : 0u);
+                        const uint32_t cut = grp_or<G>(on ? ~keep : 0u);
+                        beams[b] = (beams[b] | lit) & ~cut;
+                    }
+                }
+                // enter (tile.rs:29-50, laser.rs:184-197)
+                bool blocked = false;
+                for (uint32_t k = 0; k < max_layers; k++) {
+                    const uint32_t en = (uint32_t)(lay_new >> (16 * k)) & 0xFFFFu;
+                    const uint32_t m = beam_get<LM>(beams, (en >> 1) & 31u);
+                    blocked |= (en & LAY_VALID) && ((m >> ((en >> 6) & 31u)) & 1u) && ((en >> 11) != a);
+                }
+                const bool is_alive = (alive & bit) != 0;
+                const bool inner = me && !blocked;
+                const bool ev_exit = inner && kind == K_EXIT && !(arrived & bit);
+                const bool ev_gem = inner && kind == K_GEM && !(gems & gbit);
+                const bool died = me && is_alive && (blocked || kind == K_VOID);
+                const bool has_ev = died || ev_exit || ev_gem;
+                const uint32_t p1 = grp_or<G>((died ? bit : 0u) | (ev_exit ? bit << 16 : 0u));
+                const uint32_t p2 = grp_or<G>((inner ? bit : 0u) | (has_ev ? bit << 16 : 0u));
+                gems |= grp_or<G>(ev_gem ? gbit : 0u);
+                alive &= ~(p1 & 0xFFFFu);
+                arrived |= p1 >> 16;
+                occ |= p2 & 0xFFFFu;
+                const uint32_t evmask = p2 >> 16;  // agents with an event this pass: ordered by agent id
+                const uint32_t slot = n_ev + (uint32_t)__popc(evmask & (bit - 1u));
+                const uint64_t byte = has_ev ? (uint64_t)(((died ? EV_DIED : (ev_gem ? EV_GEM : EV_EXIT)) << 4) | a) : 0ull;
+#pragma unroll
+                for (int k = 0; k < NW; k++) evw[k] |= (NW == 1 || (slot >> 3) == (uint32_t)k) ? (byte << ((slot & 7u) * 8u)) : 0ull;
+                n_ev += (uint32_t)__popc(evmask);
+                go = (p1 & 0xFFFFu) != 0;  // while agent_died
+            }
+            lay_from = lay_new;
+        }
+        pos = np;
+#pragma unroll
+        for (int b = 0; b < LM; b++)
+            if (b < L) beams[b] &= hdr->beam_full[b];
+        // compute_available_actions (world.rs:343-363)
+        const bool can_move = me && (alive & bit) && !(arrived & bit);
+        uint32_t blocked_dirs = 0;
+        for_each_other<G>(pos, [&](int j, uint32_t other) {
+            const int d = (int)other - (int)pos;
+            uint32_t hit = (d == -1) ? 1u : 0u;
+            hit |= (d == 1) ? 2u : 0u;
+            hit |= (d == 256) ? 4u : 0u;
+            hit |= (d == -256) ? 8u : 0u;
+            blocked_dirs |= ((occ >> (a ^ (uint32_t)j)) & 1u) ? hit : 0u;
+        });
+        avail = 16u | (can_move ? (((meta_new >> 8) & 15u) & ~blocked_dirs) : 0u);
+    }
+    LLE_STAMP(3);
+
+    // ---- store
+    const bool touched = env_ok && (err == 0 || was_reset);
+    if (me && touched) {
+        P.pos[env * As + a] = (uint16_t)pos;
+        P.avail[env * As + a] = (uint8_t)avail;
+    }
+#pragma unroll
+    for (int k = 0; k < NW; k++) evw[k] = grp_or64<G>(evw[k]);
+    uint64_t stat1 = 0, stat2 = 0;
+    if (env_ok && a == 0) {
+        if (touched) {
+            P.bits[env] = (uint64_t)alive | ((uint64_t)arrived << 16) | ((uint64_t)occ << 32);
+            P.gems[env] = gems;
+#pragma unroll
+            for (int b = 0; b < LM; b++)
+                if (b < L) P.beams[env * L + b] = beams[b];
+        }
+        P.err[env] = (uint8_t)err;
+        P.evcount[env] = (uint8_t)(n_ev | (was_reset << 7));
+        {
+            uint8_t* row = P.events + env * 2 * As;  // 2*As bytes per env; this kernel fills the first 2*G
+            if (G >= 2) {
+                uint32_t* __restrict__ w = reinterpret_cast<uint32_t*>(row);
+#pragma unroll
+                for (int k = 0; k < G / 2; k++) w[k] = (uint32_t)(evw[k >> 1] >> ((k & 1) * 32));
+            } else {
+                *reinterpret_cast<uint16_t*>(row) = (uint16_t)evw[0];
+            }
+        }
+        P.done[env] = (alive != amask || arrived == amask) ? 1 : 0;
+        uint32_t n_died = 0, n_gem = 0;
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            n_died += (uint32_t)__popcll(evw[k] & 0x2020202020202020ull);
+            n_gem += (uint32_t)__popcll(evw[k] & 0x1010101010101010ull);
+        }
+        const uint32_t n_exit = n_ev - n_died - n_gem;
+        const uint32_t bonus = (err == 0 && arrived == amask) ? 1u : 0u;
+        stat1 = (uint64_t)n_gem | ((uint64_t)n_exit << 12) | ((uint64_t)n_died << 24) | ((uint64_t)(err != 0) << 36) |
+                ((uint64_t)was_reset << 48);
+        stat2 = 1ull | ((uint64_t)bonus << 12);
+        // hand-over record of this env for phase 2: [0 | beam masks | ~gem bits | ...
+        uint32_t* sc = scratch + grp * scr_stride;
+        sc[0] = 0u;
+#pragma unroll
+        for (int b = 0; b < LM; b++)
+            if (b < L) sc[1 + b] = beams[b];
+        sc[L + 1] = ~gems;
+    }
+    if (me) scratch[grp * scr_stride + L + 2 + a] = a * hdr->HW + cell_of(pos, W);  // ... | byte index of each agent]
+    wave_sync();
+    LLE_STAMP(4);
+
+    if (write_obs && n_here > 0) write_observations(hdr, dyn, tmpl, scratch, scr_stride, P.obs, env0, n_here, lane);
+    LLE_STAMP(5);
+    flush_stats(P.stats, wave_id, stat1, stat2, A, lane);
     if (K.stamps) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         LLE_STAMP(6);
@@ -431,10 +762,7 @@ int kernel_variant(int A, int L) {
     return 3;
 }
 
-int agent_stride(int A, int L) {
-    static const int strides[4] = {4, 8, 16, 16};
-    return strides[kernel_variant(A, L)];
-}
+int agent_stride(int A, int L) { return agent_stride_of(A, L); }
 
 const char* kernel_variant_name(int variant) {
     static const char* names[4] = {"world_kernel<4,4>", "world_kernel<8,8>", "world_kernel<16,16>", "world_kernel<16,32>"};
@@ -463,6 +791,41 @@ hipError_t launch_world_kernel(int mode, const MapHeader& h, const BatchPtrs& P,
         case 1: return launch_mode<8, 8>(mode, P, K, h, n_waves, wpw, lds, stream);
         case 2: return launch_mode<16, 16>(mode, P, K, h, n_waves, wpw, lds, stream);
         default: return launch_mode<16, 32>(mode, P, K, h, n_waves, wpw, lds, stream);
+    }
+}
+
+// ---- step_kernel<G, LM> dispatch: G = lanes per environment (power of two >= A), LM = beam registers (>= L)
+int step_group(int A) { return A <= 1 ? 1 : (A <= 2 ? 2 : (A <= 4 ? 4 : (A <= 8 ? 8 : 16))); }
+int step_lm(int L) { return L <= 4 ? 4 : (L <= 8 ? 8 : (L <= 16 ? 16 : 32)); }
+
+template <int G, int LM>
+static hipError_t launch_step_gl(const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
+    dim3 grid((n_waves + wpw - 1) / wpw), block(64 * wpw);
+    hipLaunchKernelGGL((step_kernel<G, LM>), grid, block, lds, stream, P, K);
+    return hipGetLastError();
+}
+template <int G>
+static hipError_t launch_step_g(int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
+    switch (lm) {
+        case 4: return launch_step_gl<G, 4>(P, K, n_waves, wpw, lds, stream);
+        case 8: return launch_step_gl<G, 8>(P, K, n_waves, wpw, lds, stream);
+        case 16: return launch_step_gl<G, 16>(P, K, n_waves, wpw, lds, stream);
+        default: return launch_step_gl<G, 32>(P, K, n_waves, wpw, lds, stream);
+    }
+}
+
+hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K, hipStream_t stream) {
+    const int G = step_group((int)h.A), lm = step_lm((int)h.L);
+    const uint32_t epw = 64u / (uint32_t)G;
+    const uint32_t n_waves = (uint32_t)((K.env_limit - K.env_base + epw - 1) / epw);
+    const uint32_t wpw = kernel_waves_per_wg(h);
+    const uint32_t lds = kernel_lds_bytes(h, wpw);
+    switch (G) {
+        case 1: return launch_step_g<1>(lm, P, K, n_waves, wpw, lds, stream);
+        case 2: return launch_step_g<2>(lm, P, K, n_waves, wpw, lds, stream);
+        case 4: return launch_step_g<4>(lm, P, K, n_waves, wpw, lds, stream);
+        case 8: return launch_step_g<8>(lm, P, K, n_waves, wpw, lds, stream);
+        default: return launch_step_g<16>(lm, P, K, n_waves, wpw, lds, stream);
     }
 }
 

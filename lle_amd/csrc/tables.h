@@ -59,6 +59,13 @@ static_assert(sizeof(MapHeader) % 16 == 0, "sections must stay 16-byte aligned")
 
 constexpr uint32_t MAP_MAGIC = 0x31454C4Cu;
 
+// Agents per env record in the per-agent buffers (pos, avail, actions, events): the agent bound of the lane-per-env
+// kernel instantiation that serves the map, so that a record is a whole number of dwords.
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int agent_stride_of(int A, int L) { return (A <= 4 && L <= 4) ? 4 : ((A <= 8 && L <= 8) ? 8 : 16); }
+
 // ---- cell_lay entry helpers
 constexpr uint32_t LAY_VALID = 1u;
 inline constexpr uint32_t lay_pack(uint32_t beam, uint32_t off, uint32_t colour) {

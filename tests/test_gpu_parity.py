@@ -245,7 +245,7 @@ def test_config5_generated_32x32(oracle_mod):
     n = 4096
     ob = oracle_mod.OracleBatch(text, n)
     bw = BatchedWorld(text, n)
-    assert bw.kernel_info()["kernel"] == "world_kernel<8,8>"
+    assert bw.kernel_info()["kernel"] == "step_kernel<8,8>"
     for t in range(30):
         bw.step(sample=True, auto_reset=(t % 2 == 0), seed=11, t=t)
         check(bw, ob, ob.step(None, auto_reset=(t % 2 == 0), seed=11, t=t), f"t={t}")

@@ -25,12 +25,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--sizes", type=str, default="65536,262144")
-    ap.add_argument("--epws", type=str, default="16,32")
+    ap.add_argument("--epws", type=str, default="0,32")
     args = ap.parse_args()
     text = LEVELS[args.level]
     for n in [int(x) for x in args.sizes.split(",")]:
         for epw in [int(x) for x in args.epws.split(",")]:
-            bw = BatchedWorld(text, n, envs_per_wave=epw)
+            bw = BatchedWorld(text, n, envs_per_wave=epw or None)  # 0 = default step kernel (one lane per agent)
             B = 1937 if args.level == 6 else bw.map.obs_bytes
             t = [0]
 

@@ -7,9 +7,9 @@ from lle_amd import BatchedWorld, _capi
 from oracle.levels import LEVELS
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-for epw in (16, 32, 64):
-    bw = BatchedWorld(LEVELS[6], n, envs_per_wave=epw)
-    nb = (n + epw - 1) // epw
+for epw in (0, 32):
+    bw = BatchedWorld(LEVELS[6], n, envs_per_wave=epw or None)
+    nb = (n + (epw or 16) - 1) // (epw or 16)
     stamps = torch.zeros(nb, 8, dtype=torch.int64, device="cuda")
     for t in range(30):
         bw.step(sample=True, auto_reset=True, seed=1, t=t)
