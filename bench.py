@@ -39,13 +39,18 @@ def cpu_baseline(level_text, n_envs, seconds_target=12.0):
 
     from oracle import oracle
 
-    threads = min(os.cpu_count() or 1, 256)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 64))  # the GPU box gives one GPU a share of the host cores; more threads only thrash
     ob = oracle.OracleBatch(level_text, n_envs)
     obs = np.zeros((n_envs, ob.C * ob.H * ob.W), np.int8)
-    ob.rollout(2, SEED, threads, obs)  # warm-up
+    ob.rollout(4, SEED, threads, obs)  # warm-up
+    cal = 16
     t0 = time.perf_counter()
-    ob.rollout(8, SEED, threads, obs)
-    rate = n_envs * 8 / (time.perf_counter() - t0)
+    ob.rollout(cal, SEED, threads, obs)
+    rate = n_envs * cal / (time.perf_counter() - t0)
     steps = max(8, int(seconds_target * rate / n_envs))
     t0 = time.perf_counter()
     ob.rollout(steps, SEED, threads, obs)

@@ -42,20 +42,25 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 
 // ---- static tables -> LDS, once per workgroup (section offsets are those of the blob).  The section is a whole
 // number of 1 KiB rows; every thread requests all of its rows (up to four) before the first LDS write.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void copy_tables_to_lds(const uint8_t* __restrict__ tables, uint8_t* lds, uint32_t tab_bytes,
                                                    uint32_t lane, uint32_t wave_in_wg, uint32_t waves_per_wg) {
-    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(tables) + lane;
-    uint4* dst = reinterpret_cast<uint4*>(lds) + lane;
+    const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(tables) + lane;
+    u32x4* dst = reinterpret_cast<u32x4*>(lds) + lane;
     const uint32_t rows = tab_bytes / 1024;
     for (uint32_t r0 = wave_in_wg; r0 < rows; r0 += 4 * waves_per_wg) {
-        uint4 v[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (r0 + q * waves_per_wg < rows) v[q] = src[(r0 + q * waves_per_wg) * 64];
+        // rows r0, r0 + W, r0 + 2W, r0 + 3W of this wavefront (named scalars, not an array: an indexed private array
+        // here ended up in scratch memory)
+        const uint32_t r1 = r0 + waves_per_wg, r2 = r1 + waves_per_wg, r3 = r2 + waves_per_wg;
+        u32x4 v0 = src[r0 * 64], v1 = {0, 0, 0, 0}, v2 = {0, 0, 0, 0}, v3 = {0, 0, 0, 0};
+        if (r1 < rows) v1 = src[r1 * 64];
+        if (r2 < rows) v2 = src[r2 * 64];
+        if (r3 < rows) v3 = src[r3 * 64];
         __builtin_amdgcn_sched_barrier(0);  // keep the loads together, ahead of the LDS writes
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (r0 + q * waves_per_wg < rows) dst[(r0 + q * waves_per_wg) * 64] = v[q];
+        dst[r0 * 64] = v0;
+        if (r1 < rows) dst[r1 * 64] = v1;
+        if (r2 < rows) dst[r2 * 64] = v2;
+        if (r3 < rows) dst[r3 * 64] = v3;
     }
 }
 
@@ -472,7 +477,7 @@ __device__ __forceinline__ void for_each_other(uint32_t v, F&& f) {
 }
 
 template <int G, int LM>
-__global__ void __launch_bounds__(256) step_kernel(BatchPtrs P, LaunchArgs K) {
+__global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K) {
     constexpr int EPW = 64 / G;                     // environments per wavefront
     constexpr int NW = (2 * G + 7) / 8;             // 64-bit words of the event list (2 events per agent at most)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];

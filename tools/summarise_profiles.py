@@ -22,7 +22,7 @@ def one(pattern):
 stats = one("stats/*/*_kernel_stats.csv")
 shutil.copy(stats, os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats)))
-step = next(r for r in rows if "world_kernel" in r["Name"] and ", 0>" in r["Name"])
+step = max((r for r in rows if "step_kernel" in r["Name"] or ("world_kernel" in r["Name"] and ", 0>" in r["Name"])), key=lambda r: float(r["TotalDurationNs"]))
 trace = list(csv.DictReader(open(one("stats/*/*_kernel_trace.csv"))))
 step_rows = [r for r in trace if r["Kernel_Name"] == step["Name"]]
 dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in step_rows]
