@@ -138,6 +138,8 @@ enum {
     LLE_BUF_REQ_POS,   /* u8  [n][A][2]   set_state request */
     LLE_BUF_REQ_GEMS,  /* u32 [n] */
     LLE_BUF_REQ_ALIVE, /* u16 [n] */
+    LLE_BUF_REWARD,    /* u8  [n][4]      per-step (gems collected, exits, deaths, all agents arrived) of the last step:
+                          the inputs of the reference's reward strategies (python/lle/env/reward_strategy.py:58-109) */
     LLE_BUF_COUNT
 };
 
@@ -166,6 +168,13 @@ void lle_batch_free(lle_batch* b);
 
 int lle_batch_get_buffer(const lle_batch* b, int which, lle_buffer_desc* out);
 int64_t lle_batch_n_envs(const lle_batch* b);
+
+/* Exact checkpoint of the dynamic state (positions, alive/arrived/occupant bits, gems, beam masks, availability):
+ * unlike World.get_state/set_state (world_state.rs:5-9) nothing is re-derived, so it is valid mid-episode, corpses
+ * included.  `dst_dev` / `src_dev`: device memory of lle_batch_snapshot_bytes() bytes. */
+int64_t lle_batch_snapshot_bytes(const lle_batch* b);
+int lle_batch_snapshot(lle_batch* b, void* dst_dev, void* stream);
+int lle_batch_restore(lle_batch* b, const void* src_dev, void* stream);
 
 /* World.reset (src/core/world.rs:411-432) for every env, or for envs whose byte in env_mask (device, u8[n]) != 0. */
 int lle_batch_reset(lle_batch* b, const uint8_t* env_mask_dev, void* stream);

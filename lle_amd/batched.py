@@ -14,7 +14,7 @@ from ._capi import (LLE_BUF_COUNT, BUFFER_NAMES, LLE_STEP_AUTO_RESET, LLE_STEP_N
 _TORCH_DTYPES = {
     "pos": torch.uint8, "bits": torch.int64, "gems": torch.int32, "beams": torch.int32, "avail": torch.uint8,
     "actions": torch.uint8, "err": torch.uint8, "evcount": torch.uint8, "events": torch.uint8, "done": torch.uint8,
-    "obs": torch.int8, "stats": torch.int64, "req_pos": torch.uint8, "req_gems": torch.int32, "req_alive": torch.int16,
+    "obs": torch.int8, "stats": torch.int64, "req_pos": torch.uint8, "req_gems": torch.int32, "req_alive": torch.int16, "reward": torch.uint8,
 }
 
 
@@ -166,6 +166,36 @@ class BatchedWorld:
         """Profiling aid: a launch that loads the tables and the state and does nothing else (step with every
         action invalid and no observation write is the closest public equivalent)."""
         self._check(_capi.lib().lle_batch_step(self.h, None, LLE_STEP_NO_OBS | 0x100, 0, 0, 0, self._stream()))
+
+    # ---- reward / done epilogue (SURVEY section 8(f) rank 1): `reward` holds the per-step counts the reference's
+    # strategies are functions of; the two strategies themselves are two lines of torch
+    def reward_single_objective(self):
+        """SingleObjective.compute_reward (python/lle/env/reward_strategy.py:58-75): +1 per gem, +1 per exit, -1 per
+        death, +1 when every agent has arrived (the death override of that class never fires: `death_reward` is never
+        assigned).  float32 [n]."""
+        r = self.reward.to(torch.float32)
+        return r[:, 0] + r[:, 1] - r[:, 2] + r[:, 3]
+
+    def reward_multi_objective(self):
+        """MultiObjective.compute_reward (reward_strategy.py:90-109): [gem, exit, death, done]; a death zeroes the others.
+        float32 [n, 4]."""
+        r = self.reward.to(torch.float32)
+        dead = r[:, 2] > 0
+        out = torch.stack([r[:, 0], r[:, 1], -r[:, 2], r[:, 3]], dim=1)
+        out[dead, 0] = 0
+        out[dead, 1] = 0
+        out[dead, 3] = 0
+        return out
+
+    def snapshot(self):
+        """Exact checkpoint of the dynamic state (nothing re-derived, unlike get_state/set_state): a uint8 tensor."""
+        n = _capi.lib().lle_batch_snapshot_bytes(self.h)
+        buf = torch.empty(n, dtype=torch.uint8, device=self.device)
+        self._check(_capi.lib().lle_batch_snapshot(self.h, buf.data_ptr(), self._stream()))
+        return buf
+
+    def restore(self, snapshot):
+        self._check(_capi.lib().lle_batch_restore(self.h, snapshot.data_ptr(), self._stream()))
 
     def stats(self, reset=False):
         out = (C.c_int64 * 8)()

@@ -70,6 +70,7 @@ Layout make_layout(const MapHeader& h, int64_t n) {
     sz[LLE_BUF_REQ_POS] = n_pad * A * 2;
     sz[LLE_BUF_REQ_GEMS] = n_pad * 4;
     sz[LLE_BUF_REQ_ALIVE] = n_pad * 2;
+    sz[LLE_BUF_REWARD] = n_pad * 4;
     int64_t off = 0;
     l.off_tables = off;
     off = align_up(off + h.blob_capacity);
@@ -230,6 +231,7 @@ static void bind_ptrs(lle_batch* b) {
     p.req_pos = reinterpret_cast<const uint16_t*>(base + l.off[LLE_BUF_REQ_POS]);
     p.req_gems = reinterpret_cast<const uint32_t*>(base + l.off[LLE_BUF_REQ_GEMS]);
     p.req_alive = reinterpret_cast<const uint16_t*>(base + l.off[LLE_BUF_REQ_ALIVE]);
+    p.reward = reinterpret_cast<uint32_t*>(base + l.off[LLE_BUF_REWARD]);
     p.n_envs = b->n_envs;
 }
 
@@ -355,9 +357,29 @@ int lle_batch_get_buffer(const lle_batch* b, int which, lle_buffer_desc* out) {
         case LLE_BUF_OBS: set(1, 2, n, b->hdr.obs_bytes, 1, b->hdr.obs_stride, 1, 1); break;
         case LLE_BUF_STATS: set(8, 2, b->layout.n_stat_blocks, 8, 1, 8, 1, 1); break;
         case LLE_BUF_REQ_ALIVE: set(2, 1, n, 1, 1, 1, 1, 1); break;
+        case LLE_BUF_REWARD: set(1, 2, n, 4, 1, 4, 1, 1); break;
     }
     *out = d;
     return LLE_OK;
+}
+
+// the dynamic state is the contiguous arena range [pos, actions): pos, bits, gems, beams, avail
+int64_t lle_batch_snapshot_bytes(const lle_batch* b) {
+    if (!b) return fail(LLE_ERR_NULL, "NULL batch");
+    return b->layout.off[LLE_BUF_ACTIONS] - b->layout.off[LLE_BUF_POS];
+}
+int lle_batch_snapshot(lle_batch* b, void* dst_dev, void* stream) {
+    if (!b || !dst_dev) return fail(LLE_ERR_NULL, "NULL argument");
+    HIP_TRY(hipMemcpyAsync(dst_dev, b->arena + b->layout.off[LLE_BUF_POS], (size_t)lle_batch_snapshot_bytes(b), hipMemcpyDeviceToDevice,
+                           (hipStream_t)stream));
+    return LLE_OK;
+}
+int lle_batch_restore(lle_batch* b, const void* src_dev, void* stream) {
+    if (!b || !src_dev) return fail(LLE_ERR_NULL, "NULL argument");
+    HIP_TRY(hipMemcpyAsync(b->arena + b->layout.off[LLE_BUF_POS], src_dev, (size_t)lle_batch_snapshot_bytes(b), hipMemcpyDeviceToDevice,
+                           (hipStream_t)stream));
+    LaunchArgs K{};
+    return launch(b, KMODE_OBSERVE, K, stream);  // bring the observation in line with the restored state
 }
 
 int lle_batch_reset(lle_batch* b, const uint8_t* env_mask_dev, void* stream) {

@@ -407,6 +407,7 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
             }
             const uint32_t n_exit = ev.n - n_died - n_gem;
             const uint32_t bonus = (err == 0 && s.arrived == amask) ? 1u : 0u;
+            P.reward[env] = n_gem | (n_exit << 8) | (n_died << 16) | (bonus << 24);
             stat1 = (uint64_t)n_gem | ((uint64_t)n_exit << 12) | ((uint64_t)n_died << 24) |
                     ((uint64_t)(err != 0) << 36) | ((uint64_t)was_reset << 48);
             stat2 = 1ull | ((uint64_t)bonus << 12);
@@ -720,6 +721,7 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
         }
         const uint32_t n_exit = n_ev - n_died - n_gem;
         const uint32_t bonus = (err == 0 && arrived == amask) ? 1u : 0u;
+        P.reward[env] = n_gem | (n_exit << 8) | (n_died << 16) | (bonus << 24);
         stat1 = (uint64_t)n_gem | ((uint64_t)n_exit << 12) | ((uint64_t)n_died << 24) | ((uint64_t)(err != 0) << 36) |
                 ((uint64_t)was_reset << 48);
         stat2 = 1ull | ((uint64_t)bonus << 12);

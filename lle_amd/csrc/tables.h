@@ -123,6 +123,7 @@ struct BatchPtrs {
     uint8_t* evcount;        // [n]
     uint8_t* events;         // [n][2A]
     uint8_t* done;           // [n]
+    uint32_t* reward;        // [n] gems | exits << 8 | deaths << 16 | all_arrived << 24 of the last step
     int8_t* obs;             // [n][obs_stride]
     int64_t* stats;          // [n_blocks][8]
     const uint16_t* req_pos; // [n][A]

@@ -263,3 +263,38 @@ def test_config5_generated_32x32(oracle_mod):
     agent_layers = a.obs[:, :A].reshape(n, A, H * W)
     assert torch.equal(agent_layers.sum(-1).to(torch.int64), torch.ones(n, A, dtype=torch.int64, device="cuda"))
     assert torch.all(agent_layers.gather(2, cell.unsqueeze(-1)) == 1)
+
+
+def test_reward_counts_and_snapshot(oracle_mod):
+    """Reward epilogue (per-step gem/exit/death counts + all-arrived flag) against the oracle's events, and the exact
+    snapshot/restore of the dynamic state mid-episode (corpses and stale beams included)."""
+    import torch
+
+    from lle_amd import BatchedWorld
+
+    text = EXTRA_MAPS["q1"]
+    n = 700
+    ob = oracle_mod.OracleBatch(text, n)
+    bw = BatchedWorld(text, n)
+    snap = None
+    for t in range(25):
+        bw.step(sample=True, auto_reset=(t > 12), seed=21, t=t)
+        o = ob.step(None, auto_reset=(t > 12), seed=21, t=t)
+        cnt = (o["ev_count"] & 0x7F).astype(np.int64)
+        valid = np.arange(o["events"].shape[1])[None, :] < cnt[:, None]
+        ty = o["events"][:, :, 0]
+        want = np.stack([((ty == 1) & valid).sum(1), ((ty == 0) & valid).sum(1), ((ty == 2) & valid).sum(1),
+                         ob.dump()["arrived"].all(1).astype(np.int64)], axis=1)
+        got = bw.reward.cpu().numpy().astype(np.int64)
+        assert np.array_equal(got, want), t
+        single = bw.reward_single_objective().cpu().numpy()
+        assert np.array_equal(single, want[:, 0] + want[:, 1] - want[:, 2] + want[:, 3])
+        multi = bw.reward_multi_objective().cpu().numpy()
+        assert np.all(multi[want[:, 2] > 0][:, [0, 1, 3]] == 0)
+        if t == 9:
+            snap = bw.snapshot()
+            ref = {k: v.copy() for k, v in bw.host_buffers().items()}
+    bw.restore(snap)
+    now = bw.host_buffers()
+    for k in ("pos", "bits", "gems", "beams", "avail", "obs"):
+        assert np.array_equal(now[k], ref[k]), k
