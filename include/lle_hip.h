@@ -190,6 +190,23 @@ enum {
 int lle_batch_step(lle_batch* b, const uint8_t* actions_dev, uint32_t flags, uint64_t seed, uint64_t t,
                    int64_t env_offset, void* stream);
 
+/* Fused rollout: `n_steps` consecutive steps in ONE launch, actions sampled on the device (flags must include
+ * LLE_STEP_SAMPLE_ACTIONS; step j uses time index t0 + j).  Identical results to n_steps calls of lle_batch_step;
+ * the state stays in registers between steps and the waves drift apart, so the integer work of one step overlaps
+ * the observation stream of another.  Per-step outputs go to slot (ring_pos + j) % ring_slots of caller-provided
+ * trajectory rings (device memory), or in place (LLE_BUF_OBS / ACTIONS / REWARD, each step overwriting the last)
+ * when `ring` is NULL.  Events / err / evcount / done always reflect the last step. */
+typedef struct lle_rollout_ring {
+    int32_t ring_slots;   /* R >= 1 */
+    int32_t pad;
+    uint64_t ring_pos;    /* slot of the first step */
+    int8_t* obs;          /* [R][n_envs][obs_stride] */
+    uint8_t* actions;     /* [R][n_envs][agent pitch] (pitch: lle_buffer_desc.stride[0] of LLE_BUF_ACTIONS) */
+    uint32_t* reward;     /* [R][n_envs]  gems | exits << 8 | deaths << 16 | all_arrived << 24 */
+} lle_rollout_ring;
+int lle_batch_rollout(lle_batch* b, uint32_t n_steps, uint32_t flags, uint64_t seed, uint64_t t0, int64_t env_offset,
+                      const lle_rollout_ring* ring, void* stream);
+
 /* World.set_state (src/core/world.rs:515-597) with the reference's semantics (incl. its lossy re-derivation of
  * beams and its rollback rules) from LLE_BUF_REQ_*; per-env result in LLE_BUF_ERR, events in LLE_BUF_EVENTS. */
 int lle_batch_set_state(lle_batch* b, void* stream);

@@ -33,7 +33,7 @@ EXPORTS = [
     "lle_map_parse", "lle_map_level", "lle_map_free", "lle_map_get_info", "lle_map_positions", "lle_map_sources",
     "lle_map_set_source", "lle_map_laser_tiles", "lle_map_world_string",
     "lle_batch_arena_bytes", "lle_batch_create", "lle_batch_free", "lle_batch_get_buffer", "lle_batch_n_envs",
-    "lle_batch_reset", "lle_batch_step", "lle_batch_set_state", "lle_batch_update_sources", "lle_batch_observe",
+    "lle_batch_reset", "lle_batch_step", "lle_batch_rollout", "lle_batch_set_state", "lle_batch_update_sources", "lle_batch_observe",
     "lle_batch_snapshot_bytes", "lle_batch_snapshot", "lle_batch_restore",
     "lle_batch_stats", "lle_batch_kernel_info", "lle_batch_set_envs_per_wave", "lle_batch_step_stamped",
 ]
@@ -51,6 +51,11 @@ class SourceInfo(C.Structure):
 
 class LaserTile(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("i", "j", "laser_id", "offset", "layer")]
+
+
+class RolloutRing(C.Structure):
+    _fields_ = [("ring_slots", C.c_int32), ("pad", C.c_int32), ("ring_pos", C.c_uint64), ("obs", C.c_void_p),
+                ("actions", C.c_void_p), ("reward", C.c_void_p)]
 
 
 class BufferDesc(C.Structure):
@@ -118,6 +123,8 @@ def lib():
     L.lle_batch_reset.argtypes = [vp, vp, vp]
     L.lle_batch_step.restype = i32
     L.lle_batch_step.argtypes = [vp, vp, u32, u64, u64, i64, vp]
+    L.lle_batch_rollout.restype = i32
+    L.lle_batch_rollout.argtypes = [vp, u32, u32, u64, u64, i64, C.POINTER(RolloutRing), vp]
     L.lle_batch_set_state.restype = i32
     L.lle_batch_set_state.argtypes = [vp, vp]
     L.lle_batch_update_sources.restype = i32

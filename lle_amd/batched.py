@@ -143,6 +143,34 @@ class BatchedWorld:
         self._check(_capi.lib().lle_batch_step(self.h, ap, flags, int(seed), int(t), int(env_offset), self._stream()))
         self.t = t + 1
 
+    def make_ring(self, slots):
+        """Trajectory rings for `rollout`: obs [R,n,C,H,W] int8, actions [R,n,A] uint8, reward [R,n,4] uint8."""
+        m = self.map
+        pitch = self._desc["actions"][4][0]
+        ring = {
+            "slots": int(slots),
+            "obs_rows": torch.zeros(slots, self.n_envs, m.obs_stride, dtype=torch.int8, device=self.device),
+            "actions_rows": torch.zeros(slots, self.n_envs, pitch, dtype=torch.uint8, device=self.device),
+            "reward": torch.zeros(slots, self.n_envs, 4, dtype=torch.uint8, device=self.device),
+        }
+        ring["obs"] = ring["obs_rows"][:, :, : m.obs_bytes].unflatten(2, (m.n_layers, m.height, m.width))
+        ring["actions"] = ring["actions_rows"][:, :, : m.n_agents]
+        return ring
+
+    def rollout(self, n_steps, auto_reset=True, seed=0, t=None, env_offset=0, ring=None, ring_pos=0, write_obs=True):
+        """n_steps fused steps in one launch with on-device action sampling (lle_batch_rollout); identical results to
+        n_steps calls of step(sample=True).  With a ring (make_ring) step j lands in slot (ring_pos + j) % slots."""
+        flags = LLE_STEP_SAMPLE_ACTIONS | (LLE_STEP_AUTO_RESET if auto_reset else 0) | (0 if write_obs else LLE_STEP_NO_OBS)
+        if t is None:
+            t = self.t
+        rp = None
+        if ring is not None:
+            r = _capi.RolloutRing(ring["slots"], 0, int(ring_pos), ring["obs_rows"].data_ptr(), ring["actions_rows"].data_ptr(),
+                                  ring["reward"].data_ptr())
+            rp = C.byref(r)
+        self._check(_capi.lib().lle_batch_rollout(self.h, int(n_steps), flags, int(seed), int(t), int(env_offset), rp, self._stream()))
+        self.t = t + n_steps
+
     def set_state(self, positions, gems_collected, agents_alive):
         """World.set_state for every env.  positions u8 [n,A,2]; gems_collected bool [n,G]; agents_alive bool [n,A].
         Per-env result in `err` (0, or LLE_ENV_*), events in `events`/`evcount`."""

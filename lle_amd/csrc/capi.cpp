@@ -397,6 +397,22 @@ int lle_batch_step(lle_batch* b, const uint8_t* actions_dev, uint32_t flags, uin
     return launch(b, KMODE_STEP, K, stream);
 }
 
+int lle_batch_rollout(lle_batch* b, uint32_t n_steps, uint32_t flags, uint64_t seed, uint64_t t0, int64_t env_offset,
+                      const lle_rollout_ring* ring, void* stream) {
+    if (!b) return fail(LLE_ERR_NULL, "NULL batch");
+    if (n_steps == 0 || n_steps > 4096) return fail(LLE_ERR_ARG, "n_steps must be 1..4096");
+    if (!(flags & LLE_STEP_SAMPLE_ACTIONS)) return fail(LLE_ERR_ARG, "a fused rollout samples its actions on the device");
+    if (b->lane_per_env_step) return fail(LLE_ERR_ARG, "the fused rollout runs on the default step kernel only");
+    LaunchArgs K{};
+    K.flags = flags; K.seed = seed; K.t = t0; K.env_offset = env_offset; K.n_steps = n_steps;
+    if (ring) {
+        if (ring->ring_slots < 1 || !ring->obs || !ring->actions || !ring->reward) return fail(LLE_ERR_ARG, "incomplete ring");
+        K.ring_slots = (uint32_t)ring->ring_slots; K.ring_pos = ring->ring_pos; K.ring_env_count = b->n_envs;
+        K.ring_obs = ring->obs; K.ring_actions = ring->actions; K.ring_reward = ring->reward;
+    }
+    return launch(b, KMODE_STEP, K, stream);
+}
+
 int lle_batch_set_state(lle_batch* b, void* stream) {
     if (!b) return fail(LLE_ERR_NULL, "NULL batch");
     LaunchArgs K{};

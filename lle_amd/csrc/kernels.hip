@@ -128,15 +128,18 @@ __device__ __forceinline__ void write_observations(const MapHeader* __restrict__
 
 // per-wave partial counters, written last so that their read-modify-write latency is off the observation's path;
 // the slot of a wave is private, so no atomics
-__device__ __forceinline__ void flush_stats(int64_t* __restrict__ stats, uint32_t wave_id, uint64_t stat1, uint64_t stat2, int A,
-                                            uint32_t lane) {
-    const uint64_t p1 = wave_sum_u64(stat1);
-    const uint64_t p2 = wave_sum_u64(stat2);
+struct StepCounts { uint32_t steps, gems, exits, died, invalid, resets, bonus; };
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ void flush_stats(int64_t* __restrict__ stats, uint32_t wave_id, const StepCounts& c, int A, uint32_t lane) {
+    const int64_t steps = wave_sum_u32(c.steps), gems = wave_sum_u32(c.gems), exits = wave_sum_u32(c.exits);
+    const int64_t died = wave_sum_u32(c.died), invalid = wave_sum_u32(c.invalid), resets = wave_sum_u32(c.resets);
+    const int64_t bonus = wave_sum_u32(c.bonus);
     if (lane == 0) {
         int64_t* out = stats + (int64_t)wave_id * 8;
-        const int64_t gems = p1 & 0xFFF, exits = (p1 >> 12) & 0xFFF, died = (p1 >> 24) & 0xFFF;
-        const int64_t invalid = (p1 >> 36) & 0xFFF, resets = (p1 >> 48) & 0xFFF;
-        const int64_t steps = p2 & 0xFFF, bonus = (p2 >> 12) & 0xFFF;
         out[0] += steps; out[1] += steps * A; out[2] += gems; out[3] += exits; out[4] += died;
         out[5] += invalid; out[6] += resets; out[7] += gems + exits - died + bonus;
     }
@@ -252,7 +255,7 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
     mv.W = (int)hdr->W; mv.A = A; mv.L = L; mv.G = (int)hdr->G;
     mv.enabled = hdr->enabled_mask; mv.max_layers = hdr->max_layers;
     const uint32_t amask = (1u << A) - 1u;
-    uint64_t stat1 = 0, stat2 = 0;  // packed per-env counters, summed over the wave below
+    StepCounts cnt = {0, 0, 0, 0, 0, 0, 0};  // per-env counters, summed over the wave at the end
 
     LLE_STAMP(2);
     if (active) {
@@ -408,9 +411,7 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
             const uint32_t n_exit = ev.n - n_died - n_gem;
             const uint32_t bonus = (err == 0 && s.arrived == amask) ? 1u : 0u;
             P.reward[env] = n_gem | (n_exit << 8) | (n_died << 16) | (bonus << 24);
-            stat1 = (uint64_t)n_gem | ((uint64_t)n_exit << 12) | ((uint64_t)n_died << 24) |
-                    ((uint64_t)(err != 0) << 36) | ((uint64_t)was_reset << 48);
-            stat2 = 1ull | ((uint64_t)bonus << 12);
+            cnt = StepCounts{1u, n_gem, n_exit, n_died, err != 0 ? 1u : 0u, was_reset, bonus};
         }
     }
     wave_sync();
@@ -420,7 +421,7 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
     if (write_obs && n_here > 0)
         write_observations(hdr, dyn, tmpl, scratch, scr_stride, P.obs, env0, n_here, lane);
     LLE_STAMP(5);
-    if (MODE == MODE_STEP) flush_stats(P.stats, wave_id, stat1, stat2, A, lane);
+    if (MODE == MODE_STEP) flush_stats(P.stats, wave_id, cnt, A, lane);
 
     if (K.stamps) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -541,6 +542,17 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
     const uint32_t enabled = hdr->enabled_mask, max_layers = hdr->max_layers;
     LLE_STAMP(2);
 
+    // ---- n_steps consecutive steps of the wave's environments; the state stays in registers in between.
+    // (n_steps = 1 is World.step; more is a fused rollout with on-device action sampling, lle_batch_rollout.)
+    StepCounts cnt = {0, 0, 0, 0, 0, 0, 0};
+    const uint32_t n_steps = K.n_steps ? K.n_steps : 1u;
+    for (uint32_t it = 0; it < n_steps; it++) {
+    const uint64_t t_now = K.t + it;
+    const uint32_t slot = K.ring_slots ? (uint32_t)((K.ring_pos + it) % K.ring_slots) : 0u;
+    uint8_t* __restrict__ actions_out = K.ring_slots ? K.ring_actions + (int64_t)slot * K.ring_env_count * As : P.actions;
+    uint32_t* __restrict__ reward_out = K.ring_slots ? K.ring_reward + (int64_t)slot * K.ring_env_count : P.reward;
+    int8_t* __restrict__ obs_out = K.ring_slots ? K.ring_obs + (int64_t)slot * K.ring_env_count * (int64_t)hdr->obs_stride : P.obs;
+
     // ---- auto-reset: a finished env restarts from the reset state (identical for every env, see InitRecord)
     uint32_t was_reset = 0;
     if (K.flags & STEP_AUTO_RESET) {
@@ -561,10 +573,10 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
     // ---- joint action: sampled on the device, or given
     uint32_t act = 4u;
     if (K.flags & STEP_SAMPLE_ACTIONS) {
-        const uint64_t he = action_hash_env(K.seed, (uint64_t)(K.env_offset + env), K.t);
+        const uint64_t he = action_hash_env(K.seed, (uint64_t)(K.env_offset + env), t_now);
         const uint64_t hg = action_hash_group(he, (uint64_t)(a >> 2));
         act = sample_action(avail, action_field(hg, a));
-        if (me) P.actions[env * As + a] = (uint8_t)act;
+        if (me) actions_out[env * As + a] = (uint8_t)act;
     } else if (K.actions_in) {
         if (me) {
             act = (uint32_t)K.actions_in[env * A + a];  // caller's buffer: contiguous [n][A]
@@ -683,23 +695,10 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
     }
     LLE_STAMP(3);
 
-    // ---- store
-    const bool touched = env_ok && (err == 0 || was_reset);
-    if (me && touched) {
-        P.pos[env * As + a] = (uint16_t)pos;
-        P.avail[env * As + a] = (uint8_t)avail;
-    }
+    // ---- per-step outputs (the state itself stays in registers until the last step)
 #pragma unroll
     for (int k = 0; k < NW; k++) evw[k] = grp_or64<G>(evw[k]);
-    uint64_t stat1 = 0, stat2 = 0;
     if (env_ok && a == 0) {
-        if (touched) {
-            P.bits[env] = (uint64_t)alive | ((uint64_t)arrived << 16) | ((uint64_t)occ << 32);
-            P.gems[env] = gems;
-#pragma unroll
-            for (int b = 0; b < LM; b++)
-                if (b < L) P.beams[env * L + b] = beams[b];
-        }
         P.err[env] = (uint8_t)err;
         P.evcount[env] = (uint8_t)(n_ev | (was_reset << 7));
         {
@@ -721,10 +720,9 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
         }
         const uint32_t n_exit = n_ev - n_died - n_gem;
         const uint32_t bonus = (err == 0 && arrived == amask) ? 1u : 0u;
-        P.reward[env] = n_gem | (n_exit << 8) | (n_died << 16) | (bonus << 24);
-        stat1 = (uint64_t)n_gem | ((uint64_t)n_exit << 12) | ((uint64_t)n_died << 24) | ((uint64_t)(err != 0) << 36) |
-                ((uint64_t)was_reset << 48);
-        stat2 = 1ull | ((uint64_t)bonus << 12);
+        reward_out[env] = n_gem | (n_exit << 8) | (n_died << 16) | (bonus << 24);
+        cnt.steps += 1u; cnt.gems += n_gem; cnt.exits += n_exit; cnt.died += n_died;
+        cnt.invalid += err != 0 ? 1u : 0u; cnt.resets += was_reset; cnt.bonus += bonus;
         // hand-over record of this env for phase 2: [0 | beam masks | ~gem bits | ...
         uint32_t* sc = scratch + grp * scr_stride;
         sc[0] = 0u;
@@ -737,9 +735,25 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
     wave_sync();
     LLE_STAMP(4);
 
-    if (write_obs && n_here > 0) write_observations(hdr, dyn, tmpl, scratch, scr_stride, P.obs, env0, n_here, lane);
+    if (write_obs && n_here > 0) write_observations(hdr, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane);
+    wave_sync();
+    }  // steps
     LLE_STAMP(5);
-    flush_stats(P.stats, wave_id, stat1, stat2, A, lane);
+
+    // ---- final state.  Written unconditionally: an env whose action was refused kept its registers unchanged
+    // (world.rs:436-453: errors precede any mutation), so this rewrites the same bytes.
+    if (me) {
+        P.pos[env * As + a] = (uint16_t)pos;
+        P.avail[env * As + a] = (uint8_t)avail;
+    }
+    if (env_ok && a == 0) {
+        P.bits[env] = (uint64_t)alive | ((uint64_t)arrived << 16) | ((uint64_t)occ << 32);
+        P.gems[env] = gems;
+#pragma unroll
+        for (int b = 0; b < LM; b++)
+            if (b < L) P.beams[env * L + b] = beams[b];
+    }
+    flush_stats(P.stats, wave_id, cnt, A, lane);
     if (K.stamps) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         LLE_STAMP(6);

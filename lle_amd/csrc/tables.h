@@ -96,6 +96,14 @@ struct LaunchArgs {
     const uint8_t* actions_in; // step: optional u8[n][A]
     uint32_t old_enabled;      // update_sources: enabled mask before the update
     uint32_t pad;
+    // fused rollout (step_kernel only): n_steps consecutive steps per launch; per-step observation / actions / reward
+    // counts go to slot (ring_pos + step) % ring_slots of caller-provided trajectory rings (ring_slots = 0: in place)
+    uint32_t n_steps, ring_slots;
+    uint64_t ring_pos;
+    int64_t ring_env_count;    // envs per ring slot (= the batch's n_envs)
+    int8_t* ring_obs;          // [ring_slots][n][obs_stride]
+    uint8_t* ring_actions;     // [ring_slots][n][agent stride]
+    uint32_t* ring_reward;     // [ring_slots][n]
     uint64_t* stamps;          // profiling aid: [n_blocks][8] s_memrealtime stamps (10 ns ticks) of lane 0, or NULL
 };
 

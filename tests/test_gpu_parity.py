@@ -298,3 +298,36 @@ def test_reward_counts_and_snapshot(oracle_mod):
     now = bw.host_buffers()
     for k in ("pos", "bits", "gems", "beams", "avail", "obs"):
         assert np.array_equal(now[k], ref[k]), k
+
+
+@pytest.mark.parametrize("name", ["level6", "nested", "many_agents"])
+def test_fused_rollout_equals_single_steps(oracle_mod, name):
+    """lle_batch_rollout: T steps in one launch == T single steps of the oracle, per-step outputs in the rings."""
+    from lle_amd import BatchedWorld
+
+    text = MAPS[name]
+    n, T, R = 900, 12, 5
+    ob = oracle_mod.OracleBatch(text, n)
+    bw = BatchedWorld(text, n)
+    ring = bw.make_ring(R)
+    t0 = 0
+    for chunk in (T, 7):
+        bw.rollout(chunk, auto_reset=True, seed=99, t=t0, env_offset=11, ring=ring, ring_pos=t0)
+        steps = [ob.step(None, auto_reset=True, seed=99, t=t0 + j, env_offset=11) for j in range(chunk)]
+        eng = unpack_engine(bw.host_buffers(), *dims_of(ob))
+        assert_state_equal(eng, ob.dump(), f"{name} after rollout of {chunk}")
+        for key in ("err", "ev_count"):  # events / err / evcount reflect the last step
+            assert np.array_equal(eng[key], steps[-1][key]), key
+        obs_ring = ring["obs"].cpu().numpy()
+        act_ring = ring["actions"].cpu().numpy()
+        rew_ring = ring["reward"].cpu().numpy()
+        for j in range(max(0, chunk - R), chunk):  # the slots that were not overwritten within this chunk
+            slot = (t0 + j) % R
+            assert np.array_equal(obs_ring[slot], steps[j]["obs"]), (name, j)
+            assert np.array_equal(act_ring[slot], steps[j]["actions"]), (name, j)
+            cnt = (steps[j]["ev_count"] & 0x7F).astype(np.int64)
+            valid = np.arange(steps[j]["events"].shape[1])[None, :] < cnt[:, None]
+            ty = steps[j]["events"][:, :, 0]
+            assert np.array_equal(rew_ring[slot][:, 0], ((ty == 1) & valid).sum(1)), (name, j)
+            assert np.array_equal(rew_ring[slot][:, 2], ((ty == 2) & valid).sum(1)), (name, j)
+        t0 += chunk
