@@ -86,6 +86,9 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--envs-per-wave", type=int, default=0, help="0 = library default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused", action="store_true", help="skip the secondary fused-rollout measurement")
+    ap.add_argument("--fused-steps", type=int, default=16, help="steps per launch of the fused rollout")
+    ap.add_argument("--ring-slots", type=int, default=8, help="trajectory ring slots of the fused rollout")
     args = ap.parse_args()
 
     import torch
@@ -137,6 +140,30 @@ def main():
     stats = bw.stats()
     stats = allreduce_stats(stats, dev) if world > 1 else stats
 
+    # ---- secondary measurement: the same random rollout with lle_batch_rollout (several steps per launch, every
+    # step's observation / actions / reward counts written to a trajectory ring larger than the caches)
+    fused = None
+    if not args.no_fused:
+        T, R = args.fused_steps, args.ring_slots
+        ring = bw.make_ring(R)
+        launches = max(1, args.steps // T)
+        for _ in range(2):
+            bw.rollout(T, auto_reset=True, seed=SEED, env_offset=offset, ring=ring, ring_pos=bw.t)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        tf = time.perf_counter()
+        for _ in range(launches):
+            bw.rollout(T, auto_reset=True, seed=SEED, env_offset=offset, ring=ring, ring_pos=bw.t)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        fused_elapsed = time.perf_counter() - tf
+        fused_elapsed = allreduce_max(fused_elapsed, dev) if world > 1 else fused_elapsed
+        fused = (T, R, launches, fused_elapsed)
+        del ring
+
     if rank == 0:
         A = bw.map.n_agents
         total_envs = n * world
@@ -160,6 +187,18 @@ def main():
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n, "kernel_ms": kernel_ms},
             "rollout_stats": stats,
         }
+        if fused is not None:
+            T, R, launches, fe = fused
+            # per env-step: obs 1872 + actions 4 + reward 4 + err/evcount/done 3 + events 8, state r/w (48 B) once per launch
+            fused_bytes = 1891 + 48.0 / T
+            out["fused_rollout"] = {
+                "what": "lle_batch_rollout: same random rollout, several steps per launch, per-step obs/actions/reward to a trajectory ring",
+                "steps_per_launch": T, "ring_slots": R, "steps": launches * T, "ms_per_step": fe / (launches * T) * 1e3,
+                "env_steps_per_s": total_envs * launches * T / fe, "agent_steps_per_s": A * total_envs * launches * T / fe,
+                "algorithmic_bytes_per_env_step": fused_bytes,
+                "achieved_GBps_per_gpu": fused_bytes * n * launches * T / fe / 1e9,
+                "frac_of_hbm_peak": fused_bytes * n * launches * T / fe / 1e9 / HBM_PEAK_GBS,
+            }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(text, n)
         print(json.dumps(out), flush=True)

@@ -47,7 +47,7 @@ json.dump({"hbm_bytes_per_launch": traffic, "fetch_kib_raw": f_kb, "write_kib": 
 g = step_rows[len(step_rows) // 2]
 with open(os.path.join(ROOT, "profiles", f"{tag}_summary.md"), "w") as f:
     f.write(f"# rocprofv3 summary ({tag}): `python bench.py` on one MI355X\n\n")
-    f.write("Command (tools/collect_profiles.sh): `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline`; "
+    f.write("Command (tools/collect_profiles.sh): `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-fused` (single-step launches only); "
             "PMC counters in separate passes (`--pmc WRITE_SIZE`, `--pmc FETCH_SIZE`).\n\n")
     f.write("## Kernel stats (`--kernel-trace --stats`)\n\n| kernel | calls | avg ns | min ns | max ns | % |\n|---|---|---|---|---|---|\n")
     for r in rows:
