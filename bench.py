@@ -91,6 +91,12 @@ def main():
     ap.add_argument("--ring-slots", type=int, default=8, help="trajectory ring slots of the fused rollout")
     args = ap.parse_args()
 
+    # Everything but the final JSON line goes to stderr, at the file-descriptor level: RCCL and the HIP runtime print
+    # banners to fd 1 from C code (e.g. "Librccl path : ...") and the contract is ONE line on stdout.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -101,14 +107,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU execution path)"
+    # one process per GPU under torch.distributed.run (RCCL = backend "nccl"); a plain `python bench.py` is rank 0 of 1
+    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    dev = torch.device("cuda", local_rank if use_dist else 0)
+    torch.cuda.set_device(dev)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU execution path)"
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
-    torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", device_id=dev)
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
     n = args.envs_per_gpu
     text = LEVELS[LEVEL]
@@ -122,7 +131,7 @@ def main():
     run(args.warmup, 0)
     torch.cuda.synchronize(dev)
     bw.stats(reset=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -131,14 +140,14 @@ def main():
     run(args.steps, args.warmup)
     ev1.record()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # average launch-to-launch duration on the launch stream
 
-    elapsed = allreduce_max(elapsed, dev) if world > 1 else elapsed
+    elapsed = allreduce_max(elapsed, dev) if use_dist else elapsed
     stats = bw.stats()
-    stats = allreduce_stats(stats, dev) if world > 1 else stats
+    stats = allreduce_stats(stats, dev) if use_dist else stats
 
     # ---- secondary measurement: the same random rollout with lle_batch_rollout (several steps per launch, every
     # step's observation / actions / reward counts written to a trajectory ring larger than the caches)
@@ -150,17 +159,17 @@ def main():
         for _ in range(2):
             bw.rollout(T, auto_reset=True, seed=SEED, env_offset=offset, ring=ring, ring_pos=bw.t)
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
         tf = time.perf_counter()
         for _ in range(launches):
             bw.rollout(T, auto_reset=True, seed=SEED, env_offset=offset, ring=ring, ring_pos=bw.t)
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         fused_elapsed = time.perf_counter() - tf
-        fused_elapsed = allreduce_max(fused_elapsed, dev) if world > 1 else fused_elapsed
+        fused_elapsed = allreduce_max(fused_elapsed, dev) if use_dist else fused_elapsed
         fused = (T, R, launches, fused_elapsed)
         del ring
 
@@ -201,8 +210,9 @@ def main():
             }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(text, n)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if use_dist:
         dist.destroy_process_group()
 
 
