@@ -331,3 +331,22 @@ def test_fused_rollout_equals_single_steps(oracle_mod, name):
             assert np.array_equal(rew_ring[slot][:, 0], ((ty == 1) & valid).sum(1)), (name, j)
             assert np.array_equal(rew_ring[slot][:, 2], ((ty == 2) & valid).sum(1)), (name, j)
         t0 += chunk
+
+
+def test_fuzz_maps_gpu(oracle_mod):
+    """The random small maps of tests/test_hostsim_parity.py::test_fuzz_maps through the HIP kernels (every lane-group
+    size G = 1, 2, 4, 8 occurs)."""
+    from lle_amd import BatchedWorld
+    from tests.test_hostsim_parity import _fuzz_maps
+
+    groups = set()
+    for name, text in _fuzz_maps():
+        n = 333
+        ob = oracle_mod.OracleBatch(text, n)
+        bw = BatchedWorld(text, n)
+        groups.add(bw.kernel_info()["kernel"])
+        for t in range(30):
+            ar = t % 3 != 0
+            bw.step(sample=True, auto_reset=ar, seed=5, t=t)
+            check(bw, ob, ob.step(None, auto_reset=ar, seed=5, t=t), f"{name} t={t}")
+    assert len(groups) >= 3, groups

@@ -100,3 +100,42 @@ def test_set_state_random_requests(oracle_mod):
         sb.L.hs_reset(sb.h, poisoned.ctypes.data)
         for e in np.nonzero(poisoned)[0]:
             ob.world(int(e)).reset()
+
+
+def _fuzz_maps():
+    from lle_amd import mapgen
+
+    rng = np.random.default_rng(7)
+    out = []
+    for seed in range(24):
+        h, w = int(rng.integers(4, 14)), int(rng.integers(4, 14))
+        agents = int(rng.integers(1, 7))
+        lasers = int(rng.integers(0, 7))
+        try:
+            out.append((f"fuzz{seed}_{h}x{w}_a{agents}_l{lasers}",
+                        mapgen.generate(h, w, agents, lasers, n_gems=int(rng.integers(0, 5)), wall_fraction=0.08,
+                                        n_voids=int(rng.integers(0, 3)), seed=100 + seed)))
+        except RuntimeError:
+            pass  # the rejection sampler found no valid placement for these sizes
+    return out
+
+
+@pytest.mark.parametrize("name,text", _fuzz_maps())
+def test_fuzz_maps(oracle_mod, name, text):
+    """Random small maps (crossing beams of random colours, beams over gems and exits, voids): the two independent
+    formulations of the rules must agree on every step, with and without auto-reset."""
+    from lle_amd import _capi
+    from tests import hostsim
+
+    n, steps = 48, 40
+    for auto_reset in (False, True):
+        ob = oracle_mod.OracleBatch(text, n)
+        sb = hostsim.SimBatch(text, n)
+        dims = (ob.A, ob.G, ob.Ls, ob.beam_stride, ob.C, ob.H, ob.W)
+        flags = _capi.LLE_STEP_SAMPLE_ACTIONS | (_capi.LLE_STEP_AUTO_RESET if auto_reset else 0)
+        for t in range(steps):
+            ostep = ob.step(None, auto_reset=auto_reset, seed=5, t=t)
+            sb.step(None, flags=flags, seed=5, t=t)
+            eng = unpack_engine(sim_bufs(sb), *dims)
+            assert_step_equal(eng, ostep, f"{name} t={t}")
+            assert_state_equal(eng, ob.dump(), f"{name} t={t}")
