@@ -31,14 +31,16 @@ ALGO_BYTES_PER_ENV_STEP = 1937
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(level_text, n_envs, seconds_target=12.0):
+def cpu_baseline(n_envs, seconds_target=12.0):
     """The CPU oracle (C restatement of the reference algorithm, kind "port") on a bounded sample of the same workload:
     the same n_envs level-6 environments, sampled actions + auto-reset + int8 layered observation, for about
     `seconds_target` seconds on every host core (one thread per core over disjoint env ranges)."""
     import numpy as np
 
     from oracle import oracle
+    from oracle.levels import LEVELS
 
+    level_text = LEVELS[LEVEL]
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -100,9 +102,8 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from lle_amd import BatchedWorld
+    from lle_amd import BatchedWorld, Map
     from lle_amd.distributed import allreduce_max, allreduce_stats, shard_offset
-    from oracle.levels import LEVELS  # map text only (data)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -120,8 +121,7 @@ def main():
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
     n = args.envs_per_gpu
-    text = LEVELS[LEVEL]
-    bw = BatchedWorld(text, n, device=dev, envs_per_wave=args.envs_per_wave or None)
+    bw = BatchedWorld(Map(level=LEVEL), n, device=dev, envs_per_wave=args.envs_per_wave or None)
     offset = shard_offset(n, rank)
 
     def run(k, t0):
@@ -209,7 +209,7 @@ def main():
                 "frac_of_hbm_peak": fused_bytes * n * launches * T / fe / 1e9 / HBM_PEAK_GBS,
             }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(text, n)
+            out["cpu_baseline"] = cpu_baseline(n)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:

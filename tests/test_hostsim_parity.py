@@ -139,3 +139,24 @@ def test_fuzz_maps(oracle_mod, name, text):
             eng = unpack_engine(sim_bufs(sb), *dims)
             assert_step_equal(eng, ostep, f"{name} t={t}")
             assert_state_equal(eng, ob.dump(), f"{name} t={t}")
+
+
+def test_config1_single_env_10k_steps(oracle_mod):
+    """BASELINE.json configs[0]: World("S0 G X"), one env, 10 000 random-action steps (auto-reset when done):
+    oracle vs the host build of the device state machine, every step."""
+    from lle_amd import _capi
+    from tests import hostsim
+
+    text = "S0 G X"
+    ob = oracle_mod.OracleBatch(text, 1)
+    sb = hostsim.SimBatch(text, 1)
+    dims = (ob.A, ob.G, ob.Ls, ob.beam_stride, ob.C, ob.H, ob.W)
+    stats = np.zeros(8, np.int64)
+    for t in range(10_000):
+        ostep = ob.step(None, auto_reset=True, seed=3, t=t, stats=stats)
+        sb.step(None, flags=_capi.LLE_STEP_SAMPLE_ACTIONS | _capi.LLE_STEP_AUTO_RESET, seed=3, t=t)
+        if t % 97 == 0 or t > 9_900:
+            eng = unpack_engine(sim_bufs(sb), *dims)
+            assert_step_equal(eng, ostep, f"t={t}")
+            assert_state_equal(eng, ob.dump(), f"t={t}")
+    assert np.array_equal(sb.buf("stats")[:7], stats[:7]) and stats[0] == 10_000 and stats[3] > 100  # many exits

@@ -4,8 +4,7 @@ import argparse
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from lle_amd import BatchedWorld
-from oracle.levels import LEVELS
+from lle_amd import BatchedWorld, Map
 
 
 def timeit(fn, iters=100, warm=10):
@@ -27,7 +26,7 @@ def main():
     ap.add_argument("--sizes", type=str, default="65536,262144")
     ap.add_argument("--epws", type=str, default="0,32")
     args = ap.parse_args()
-    text = LEVELS[args.level]
+    text = Map(level=args.level)
     for n in [int(x) for x in args.sizes.split(",")]:
         for epw in [int(x) for x in args.epws.split(",")]:
             bw = BatchedWorld(text, n, envs_per_wave=epw or None)  # 0 = default step kernel (one lane per agent)

@@ -2,13 +2,12 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from lle_amd import BatchedWorld
-from oracle.levels import LEVELS
+from lle_amd import BatchedWorld, Map
 from tools.microbench import timeit
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 for epw in (32, 64):
-    bw = BatchedWorld(LEVELS[6], n, envs_per_wave=epw)
+    bw = BatchedWorld(Map(level=6), n, envs_per_wave=epw)
     stay = torch.full((n, 4), 4, dtype=torch.uint8, device="cuda")
     t = [0]
     def v1():

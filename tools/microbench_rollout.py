@@ -2,11 +2,10 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from lle_amd import BatchedWorld
-from oracle.levels import LEVELS
+from lle_amd import BatchedWorld, Map
 
 def run(n, T, R, launches=20):
-    bw = BatchedWorld(LEVELS[6], n)
+    bw = BatchedWorld(Map(level=6), n)
     ring = bw.make_ring(R) if R else None
     for _ in range(3):
         bw.rollout(T, seed=1, ring=ring, ring_pos=bw.t)

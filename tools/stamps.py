@@ -3,12 +3,11 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C
 import torch
-from lle_amd import BatchedWorld, _capi
-from oracle.levels import LEVELS
+from lle_amd import BatchedWorld, Map, _capi
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 for epw in (0, 32):
-    bw = BatchedWorld(LEVELS[6], n, envs_per_wave=epw or None)
+    bw = BatchedWorld(Map(level=6), n, envs_per_wave=epw or None)
     nb = (n + (epw or 16) - 1) // (epw or 16)
     stamps = torch.zeros(nb, 8, dtype=torch.int64, device="cuda")
     for t in range(30):

@@ -2,11 +2,10 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from lle_amd import BatchedWorld, _capi
-from oracle.levels import LEVELS
+from lle_amd import BatchedWorld, Map, _capi
 
 n = 65536
-bw = BatchedWorld(LEVELS[6], n)
+bw = BatchedWorld(Map(level=6), n)
 nb = n // 16
 stamps = torch.zeros(nb, 8, dtype=torch.int64, device="cuda")
 for t in range(30):
