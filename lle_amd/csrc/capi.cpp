@@ -5,6 +5,7 @@
 // dynamic entry point needs a HIP device and fails loudly without one.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
@@ -53,7 +54,7 @@ Layout make_layout(const MapHeader& h, int64_t n) {
     const int64_t L = h.L;
     const int64_t A = agent_stride((int)h.A, (int)h.L);  // per-agent buffers are strided by the kernel's agent bound
     const int64_t n_pad = (n + 1 + 63) / 64 * 64;  // + one hidden env (slot n) used to compute the reset state on the device
-    l.n_stat_blocks = (n + MIN_ENVS_PER_WAVE - 1) / MIN_ENVS_PER_WAVE;
+    l.n_stat_blocks = std::max<int64_t>(8192, (n + MIN_ENVS_PER_WAVE - 1) / MIN_ENVS_PER_WAVE);  // one slot per wavefront
     int64_t sz[LLE_BUF_COUNT];
     sz[LLE_BUF_POS] = n_pad * A * 2;
     sz[LLE_BUF_BITS] = n_pad * 8;
@@ -239,8 +240,10 @@ static int launch(lle_batch* b, int mode, LaunchArgs K, void* stream) {
     K.envs_per_wave = b->envs_per_wave;
     K.env_base = 0;
     K.env_limit = b->n_envs;
-    if (mode == KMODE_STEP && !b->lane_per_env_step)
+    if (mode == KMODE_STEP && !b->lane_per_env_step) {
+        K.envs_per_wave = step_envs_per_wave(b->n_envs, (int)b->hdr.A);
         HIP_TRY(launch_step_kernel(b->hdr, b->ptrs, K, (hipStream_t)stream));
+    }
     else
         HIP_TRY(launch_world_kernel(mode, b->hdr, b->ptrs, K, (hipStream_t)stream));
     g_status = LLE_OK;
@@ -277,7 +280,7 @@ static int create_impl(lle_batch* b, const lle_map* map, void* arena, int64_t ar
     MapHeader worst = b->hdr;
     worst.lds_table_bytes += worst.blob_capacity - worst.blob_bytes;
     const uint32_t lds = kernel_lds_bytes(worst, 1);
-    if (lds > 64 * 1024) return fail(LLE_ERR_UNSUPPORTED, "map tables need " + std::to_string(lds) + " B of LDS per wave (> 64 KiB)");
+    if (lds > 160 * 1024) return fail(LLE_ERR_UNSUPPORTED, "map tables need " + std::to_string(lds) + " B of LDS per wavefront (> 160 KiB)");
     b->layout = make_layout(b->hdr, b->n_envs);
     if (arena) {
         if (arena_bytes < b->layout.total || (reinterpret_cast<uintptr_t>(arena) % ALIGN) != 0)
@@ -462,7 +465,7 @@ int lle_batch_kernel_info(const lle_batch* b, char* name_buf, size_t cap, int32_
         else std::snprintf(name_buf, cap, "step_kernel<%d,%d>", step_group((int)b->hdr.A), step_lm((int)b->hdr.L));
     }
     if (lds_bytes) *lds_bytes = (int32_t)kernel_lds_bytes(b->hdr, kernel_waves_per_wg(b->hdr));
-    if (envs_per_wave) *envs_per_wave = b->lane_per_env_step ? (int32_t)b->envs_per_wave : 64 / step_group((int)b->hdr.A);
+    if (envs_per_wave) *envs_per_wave = b->lane_per_env_step ? (int32_t)b->envs_per_wave : (int32_t)step_envs_per_wave(b->n_envs, (int)b->hdr.A);
     return LLE_OK;
 }
 

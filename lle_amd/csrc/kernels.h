@@ -18,6 +18,7 @@ hipError_t launch_world_kernel(int mode, const MapHeader& h, const BatchPtrs& P,
 // World.step with one lane per agent (the default step path)
 hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K, hipStream_t stream);
 int step_group(int A);
+uint32_t step_envs_per_wave(int64_t n, int A);
 int step_lm(int L);
 
 }  // namespace lle

@@ -480,7 +480,9 @@ __device__ __forceinline__ void for_each_other(uint32_t v, F&& f) {
 
 template <int G, int LM>
 __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K) {
-    constexpr int EPW = 64 / G;                     // environments per wavefront
+    // environments per wavefront: at most 64 / G; fewer (lanes left idle) when the batch is small, so that there
+    // are enough wavefronts to spread phase 2 over the chip
+    const uint32_t EPW = K.envs_per_wave < (uint32_t)(64 / G) ? K.envs_per_wave : (uint32_t)(64 / G);
     constexpr int NW = (2 * G + 7) / 8;             // 64-bit words of the event list (2 events per agent at most)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const MapHeader* __restrict__ hdr = reinterpret_cast<const MapHeader*>(P.tables);
@@ -491,7 +493,7 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
     const int64_t As = agent_stride_of(A, L);           // env pitch of the per-agent buffers
     const int64_t env0 = K.env_base + (int64_t)wave_id * EPW;
     const int64_t env = env0 + grp;
-    const bool env_ok = env < K.env_limit;
+    const bool env_ok = grp < EPW && env < K.env_limit;
     const bool me = env_ok && (int)a < A;           // this lane carries a real agent
     const bool write_obs = hdr->obs_supported && !(K.flags & STEP_NO_OBS);
     const int64_t n_here = (K.env_limit - env0) < (int64_t)EPW ? (K.env_limit - env0) : (int64_t)EPW;
@@ -765,6 +767,19 @@ template <int AM, int LM>
 static hipError_t launch_mode(int mode, const BatchPtrs& P, const LaunchArgs& K, const MapHeader& H, uint32_t n_waves,
                               uint32_t waves_per_wg, uint32_t lds_bytes, hipStream_t stream) {
     dim3 grid((n_waves + waves_per_wg - 1) / waves_per_wg), block(64 * waves_per_wg);
+    if (lds_bytes > 64 * 1024) {
+        static uint32_t granted[5] = {0, 0, 0, 0, 0};
+        if (mode >= 0 && mode < 5 && lds_bytes > granted[mode]) {
+            const void* fn = mode == MODE_STEP ? reinterpret_cast<const void*>(&world_kernel<AM, LM, MODE_STEP>)
+                           : mode == MODE_RESET ? reinterpret_cast<const void*>(&world_kernel<AM, LM, MODE_RESET>)
+                           : mode == MODE_SET_STATE ? reinterpret_cast<const void*>(&world_kernel<AM, LM, MODE_SET_STATE>)
+                           : mode == MODE_OBSERVE ? reinterpret_cast<const void*>(&world_kernel<AM, LM, MODE_OBSERVE>)
+                                                  : reinterpret_cast<const void*>(&world_kernel<AM, LM, MODE_SOURCES>);
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return e;
+            granted[mode] = lds_bytes;
+        }
+    }
     switch (mode) {
         case MODE_STEP: hipLaunchKernelGGL((world_kernel<AM, LM, MODE_STEP>), grid, block, lds_bytes, stream, P, K); break;
         case MODE_RESET: hipLaunchKernelGGL((world_kernel<AM, LM, MODE_RESET>), grid, block, lds_bytes, stream, P, K); break;
@@ -795,10 +810,12 @@ uint32_t kernel_lds_bytes(const MapHeader& h, uint32_t waves_per_wg) {
     return h.lds_table_bytes + waves_per_wg * (h.obs_stride + 64 * scr_stride * 4) + 64;
 }
 
-// wavefronts per workgroup: as many (4, 2, 1) as keep the workgroup's LDS under 64 KiB
+// wavefronts per workgroup: four when that fits a CU's LDS twice over (two workgroups per CU), else as many (4, 2, 1)
+// as fit the 160 KiB at all
+constexpr uint32_t LDS_PER_CU = 160 * 1024;
 uint32_t kernel_waves_per_wg(const MapHeader& h) {
     for (uint32_t w = 4; w > 1; w >>= 1)
-        if (kernel_lds_bytes(h, w) <= 64 * 1024) return w;
+        if (kernel_lds_bytes(h, w) <= LDS_PER_CU) return w;
     return 1;
 }
 
@@ -822,6 +839,14 @@ int step_lm(int L) { return L <= 4 ? 4 : (L <= 8 ? 8 : (L <= 16 ? 16 : 32)); }
 template <int G, int LM>
 static hipError_t launch_step_gl(const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
     dim3 grid((n_waves + wpw - 1) / wpw), block(64 * wpw);
+    if (lds > 64 * 1024) {  // gfx950 has 160 KiB of LDS per CU; more than 64 KiB per workgroup is opt-in
+        static uint32_t granted = 0;
+        if (lds > granted) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<G, LM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            granted = lds;
+        }
+    }
     hipLaunchKernelGGL((step_kernel<G, LM>), grid, block, lds, stream, P, K);
     return hipGetLastError();
 }
@@ -835,9 +860,17 @@ static hipError_t launch_step_g(int lm, const BatchPtrs& P, const LaunchArgs& K,
     }
 }
 
+// environments per wavefront of the step kernel for a batch of n: as many as fit (64 / G) once that still leaves
+// ~4096 wavefronts (16 per CU), fewer for small batches
+uint32_t step_envs_per_wave(int64_t n, int A) {
+    uint32_t e = 64u / (uint32_t)step_group(A);
+    while (e > 1 && n / e < 4096) e >>= 1;
+    return e;
+}
+
 hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K, hipStream_t stream) {
     const int G = step_group((int)h.A), lm = step_lm((int)h.L);
-    const uint32_t epw = 64u / (uint32_t)G;
+    const uint32_t epw = K.envs_per_wave;
     const uint32_t n_waves = (uint32_t)((K.env_limit - K.env_base + epw - 1) / epw);
     const uint32_t wpw = kernel_waves_per_wg(h);
     const uint32_t lds = kernel_lds_bytes(h, wpw);
