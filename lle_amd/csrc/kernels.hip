@@ -11,6 +11,7 @@
 // No MFMA: there is no contraction anywhere on this path.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "kernels.h"
 #include "step_logic.hpp"
@@ -864,6 +865,10 @@ static hipError_t launch_step_g(int lm, const BatchPtrs& P, const LaunchArgs& K,
 // ~4096 wavefronts (16 per CU), fewer for small batches
 uint32_t step_envs_per_wave(int64_t n, int A) {
     uint32_t e = 64u / (uint32_t)step_group(A);
+    if (const char* o = getenv("LLE_STEP_EPW")) {  // tuning override
+        const uint32_t v = (uint32_t)atoi(o);
+        if (v >= 1 && v <= e && !(v & (v - 1))) return v;
+    }
     while (e > 1 && n / e < 4096) e >>= 1;
     return e;
 }
