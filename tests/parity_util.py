@@ -92,6 +92,9 @@ EXTRA_MAPS = {
         "S0 S1 G S2 . ."
     ),
     "corridor": "S0 S1 S2 S3 . . G X X X X",
+    # cell (2,2) lies under four beams (one per direction): the deepest stack possible; World.lasers() and the
+    # observation only expose the two outer layers (quirk Q4) while all four act on agents
+    "four_layers": ". . L0S . .\n. . . . .\nL1E . G . L2W\n. . . . .\nS0 S1 L3N X X",
     # python/tests/test_world.py:855-874: 14 agents, 14 sources (the 16x16 kernel instantiation)
     "many_agents": " .   .   . . . .\n" + "".join(f"S{k}  L{k}W  . . . X\n" for k in range(14)),
 }
@@ -101,6 +104,7 @@ def _add_generated():
     from lle_amd import mapgen
     EXTRA_MAPS["config5_32x32"] = mapgen.config5(0)          # BASELINE.json configs[4]: 8 agents, 8 lasers, crossings
     EXTRA_MAPS["gen_16x16_12agents"] = mapgen.generate(16, 16, 12, 10, 6, seed=3, n_voids=3)
+    EXTRA_MAPS["gen_20_lasers"] = mapgen.generate(18, 18, 3, 20, 5, seed=11, wall_fraction=0.05, n_voids=2)  # LM = 32
 
 
 _add_generated()
