@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblle_hip.so")
+LIB_PATH = os.environ.get("LLE_HIP_LIB") or os.path.join(_HERE, "liblle_hip.so")  # override: A/B runs of two builds
 
 # enum lle_hip.h
 (LLE_BUF_POS, LLE_BUF_BITS, LLE_BUF_GEMS, LLE_BUF_BEAMS, LLE_BUF_AVAIL, LLE_BUF_ACTIONS, LLE_BUF_ERR, LLE_BUF_EVCOUNT,
