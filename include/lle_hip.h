@@ -218,6 +218,44 @@ int lle_batch_update_sources(lle_batch* b, const lle_map* map, void* stream);
 /* Rebuild LLE_BUF_OBS from the current state. */
 int lle_batch_observe(lle_batch* b, void* stream);
 
+/* ---- the other observation builders of python/lle/observations.py, from the same device state -------------------
+ * kind / param                      reference generator (file:line)                       element, logical shape per env
+ * LLE_OBS_LAYERED           0       Layered            observations.py:274-276            i8  (C, H, W), C = 2A+4
+ * LLE_OBS_LAYERED_PADDED    p >= 0  LayeredPadded      observations.py:196-266            i8  (2(A+p)+4, H, W)
+ * LLE_OBS_PERSPECTIVE       0       AgentZeroPerspective observations.py:372-395          i8  (A, C, H, W)   (one slice per agent)
+ * LLE_OBS_PARTIAL            k odd  PartialGenerator   observations.py:312-369            i8  (A, 2A+3, k, k)
+ * LLE_OBS_STATE             0       StateGenerator(normalize=False) observations.py:137-159 f32 (3A+G,)
+ * LLE_OBS_NORMALIZED_STATE  0       StateGenerator(normalize=True)                          f32 (3A+G,)
+ * "flattened" (FlattenedLayered, observations.py:279-290) is LLE_OBS_LAYERED read as one row of C*H*W values.
+ * The reference returns the tensor tiled n_agents times (np.tile) for every kind but PARTIAL and PERSPECTIVE; one copy
+ * per env is written here (expose the tiling as a broadcast view).  int8 holds the values {-1, 0, 1} exactly.
+ * Rows are padded to a multiple of 16 bytes: lle_obs_desc.stride gives the element strides (env first). */
+enum lle_obs_kind {
+    LLE_OBS_LAYERED = 0, LLE_OBS_LAYERED_PADDED = 1, LLE_OBS_PERSPECTIVE = 2, LLE_OBS_PARTIAL = 3, LLE_OBS_STATE = 4,
+    LLE_OBS_NORMALIZED_STATE = 5
+};
+
+typedef struct lle_obs_desc {
+    int32_t kind, param;
+    int32_t elem_bytes;  /* 1 (int8) or 4 (float32) */
+    int32_t ndim;        /* dimensions incl. the env axis: shape[0] = n_envs */
+    int64_t shape[6];
+    int64_t stride[6];   /* in elements */
+    int64_t bytes;       /* size of the output buffer for all envs */
+    int32_t supported;   /* 0: the reference raises IndexError for this map (a laser colour has no layer) */
+    int32_t pad;
+} lle_obs_desc;
+
+/* Shape, strides and size of the buffer lle_batch_observe_as writes for (kind, param). */
+int lle_batch_obs_desc(lle_batch* b, int kind, int param, lle_obs_desc* out);
+
+/* Write the observation of every env to `out_dev` (device memory, 256-byte aligned, >= desc.bytes). */
+int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64_t out_bytes, void* stream);
+
+/* LLE.available_actions (python/lle/env/env.py:146-163): u8 bools [n_envs][A][5] in Action value order N,S,E,W,STAY.
+ * walkable_lasers = 0 drops the actions that lead onto an active laser of another colour. */
+int lle_batch_available_actions(lle_batch* b, int walkable_lasers, uint8_t* out_dev, void* stream);
+
 /* Sum the per-block counters (synchronises `stream`):
  * out[0] env_steps, [1] agent_steps, [2] gems, [3] exits, [4] deaths, [5] invalid, [6] auto_resets, [7] reward_sum */
 int lle_batch_stats(lle_batch* b, int64_t out[8], int reset_counters, void* stream);

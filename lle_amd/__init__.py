@@ -14,12 +14,13 @@ def __getattr__(name):
     if name == "BatchedWorld":
         from .batched import BatchedWorld
         return BatchedWorld
-    if name in ("Layered", "LayeredPadded"):
+    if name in ("Layered", "LayeredPadded", "ObservationType", "StateGenerator", "FlattenedLayered", "PartialGenerator",
+                "AgentZeroPerspective"):
         from . import observations
         return getattr(observations, name)
     raise AttributeError(name)
 
 
-__all__ = ["Action", "Agent", "BatchedWorld", "Direction", "EventType", "Gem", "InvalidActionError", "InvalidLevelError",
+__all__ = ["Action", "Agent", "AgentZeroPerspective", "BatchedWorld", "Direction", "EventType", "FlattenedLayered", "Gem", "InvalidActionError", "InvalidLevelError",
            "InvalidWorldStateError", "Laser", "LaserSource", "Layered", "LayeredPadded", "Map", "MapParseError",
-           "ParsingError", "World", "WorldEvent", "WorldState"]
+           "ObservationType", "ParsingError", "PartialGenerator", "StateGenerator", "World", "WorldEvent", "WorldState"]

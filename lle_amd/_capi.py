@@ -21,6 +21,9 @@ LLE_POS_START, LLE_POS_EXIT, LLE_POS_WALL, LLE_POS_VOID, LLE_POS_GEM = range(5)
 LLE_STEP_SAMPLE_ACTIONS, LLE_STEP_AUTO_RESET, LLE_STEP_NO_OBS = 1, 2, 4
 LLE_ENV_INVALID_WORLD_STATE, LLE_ENV_OUT_OF_WORLD_POSITION, LLE_ENV_INVALID_AGENT_POSITION = 0x40, 0x41, 0x42
 LLE_ERR_NO_DEVICE = -5
+LLE_ERR_UNSUPPORTED = -4
+(LLE_OBS_LAYERED, LLE_OBS_LAYERED_PADDED, LLE_OBS_PERSPECTIVE, LLE_OBS_PARTIAL, LLE_OBS_STATE,
+ LLE_OBS_NORMALIZED_STATE) = range(6)
 
 PARSE_ERROR_NAMES = {
     1: "EmptyWorld", 2: "NoAgents", 3: "InvalidTile", 4: "NotEnoughExitTiles", 5: "DuplicateStartTile",
@@ -35,6 +38,7 @@ EXPORTS = [
     "lle_batch_arena_bytes", "lle_batch_create", "lle_batch_free", "lle_batch_get_buffer", "lle_batch_n_envs",
     "lle_batch_reset", "lle_batch_step", "lle_batch_rollout", "lle_batch_set_state", "lle_batch_update_sources", "lle_batch_observe",
     "lle_batch_snapshot_bytes", "lle_batch_snapshot", "lle_batch_restore",
+    "lle_batch_obs_desc", "lle_batch_observe_as", "lle_batch_available_actions",
     "lle_batch_stats", "lle_batch_kernel_info", "lle_batch_set_envs_per_wave", "lle_batch_step_stamped",
 ]
 
@@ -61,6 +65,12 @@ class RolloutRing(C.Structure):
 class BufferDesc(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("arena_offset", C.c_int64), ("bytes", C.c_int64), ("elem_bytes", C.c_int32),
                 ("ndim", C.c_int32), ("shape", C.c_int64 * 3), ("stride", C.c_int64 * 3)]
+
+
+class ObsDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("param", C.c_int32), ("elem_bytes", C.c_int32), ("ndim", C.c_int32),
+                ("shape", C.c_int64 * 6), ("stride", C.c_int64 * 6), ("bytes", C.c_int64), ("supported", C.c_int32),
+                ("pad", C.c_int32)]
 
 
 _lib = None
@@ -131,6 +141,12 @@ def lib():
     L.lle_batch_update_sources.argtypes = [vp, vp, vp]
     L.lle_batch_observe.restype = i32
     L.lle_batch_observe.argtypes = [vp, vp]
+    L.lle_batch_obs_desc.restype = i32
+    L.lle_batch_obs_desc.argtypes = [vp, i32, i32, C.POINTER(ObsDesc)]
+    L.lle_batch_observe_as.restype = i32
+    L.lle_batch_observe_as.argtypes = [vp, i32, i32, vp, i64, vp]
+    L.lle_batch_available_actions.restype = i32
+    L.lle_batch_available_actions.argtypes = [vp, i32, vp, vp]
     L.lle_batch_stats.restype = i32
     L.lle_batch_stats.argtypes = [vp, C.POINTER(C.c_int64), i32, vp]
     L.lle_batch_kernel_info.restype = i32

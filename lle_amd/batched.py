@@ -190,6 +190,36 @@ class BatchedWorld:
         self._check(_capi.lib().lle_batch_observe(self.h, self._stream()))
         return self.obs
 
+    # ---- the other observation builders (python/lle/observations.py)
+    def obs_desc(self, kind, param=0):
+        d = _capi.ObsDesc()
+        self._check(_capi.lib().lle_batch_obs_desc(self.h, int(kind), int(param), C.byref(d)))
+        return d
+
+    def observe_as(self, kind, param=0, out=None):
+        """Observation `kind` (lle_amd._capi.LLE_OBS_*) of every env, written by the kernels of observers.hip into `out`
+        (a uint8 device tensor of obs_desc(kind, param).bytes bytes; allocated when None).  Returns a strided view of
+        that buffer with the reference's per-env shape behind the env axis: int8 for the layered kinds, float32 for
+        the state kinds.  Raises IndexError where the reference does (a laser colour without a layer)."""
+        d = self.obs_desc(kind, param)
+        if not d.supported:
+            raise IndexError("a laser colour has no layer in this observation (the reference raises IndexError too)")
+        if out is None:
+            out = torch.empty(int(d.bytes) + 256, dtype=torch.uint8, device=self.device)
+            out = out[(-out.data_ptr()) % 256:][: int(d.bytes)]
+        assert out.dtype == torch.uint8 and out.is_contiguous() and out.numel() >= d.bytes and out.data_ptr() % 16 == 0
+        self._check(_capi.lib().lle_batch_observe_as(self.h, int(kind), int(param), out.data_ptr(), out.numel(), self._stream()))
+        dt = torch.int8 if d.elem_bytes == 1 else torch.float32
+        flat = out[: int(d.bytes)].view(dt)
+        return torch.as_strided(flat, [int(d.shape[k]) for k in range(d.ndim)], [int(d.stride[k]) for k in range(d.ndim)])
+
+    def available_actions(self, walkable_lasers=True, out=None):
+        """LLE.available_actions (python/lle/env/env.py:146-163) for every env: bool [n, A, 5] in Action value order."""
+        if out is None:
+            out = torch.empty((self.n_envs, self.map.n_agents, 5), dtype=torch.uint8, device=self.device)
+        self._check(_capi.lib().lle_batch_available_actions(self.h, int(bool(walkable_lasers)), out.data_ptr(), self._stream()))
+        return out.view(torch.bool)
+
     def _noop_launch(self):
         """Profiling aid: a launch that loads the tables and the state and does nothing else (step with every
         action invalid and no observation write is the closest public equivalent)."""
@@ -240,10 +270,6 @@ class BatchedWorld:
 
     def gems_collected(self):
         return ((self.gems.to(torch.int64).unsqueeze(1) >> torch.arange(self.map.n_gems, device=self.device)) & 1).bool()
-
-    def available_actions(self):
-        """bool [n, A, 5], the layout of LLE.available_actions (python/lle/env/env.py:146-152)."""
-        return ((self.avail.to(torch.int64).unsqueeze(2) >> torch.arange(5, device=self.device)) & 1).bool()
 
     def observation(self):
         """(n, A, C, H, W) view of the layered observation: the reference tiles one (C,H,W) slice A times

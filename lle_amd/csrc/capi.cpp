@@ -9,6 +9,7 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <new>
 #include <string>
 #include <vector>
@@ -97,6 +98,11 @@ struct lle_batch {
     Layout layout;
     BatchPtrs ptrs;
     uint32_t envs_per_wave;
+    // observation views (layered-padded / perspective): the map they are compiled from, and the device blobs compiled
+    // so far, keyed by (kind, param); dropped when the sources change
+    Map map;
+    struct View { ViewHeader hdr; uint8_t* dev; };
+    std::map<std::pair<int, int>, View> views;
 };
 
 extern "C" {
@@ -312,6 +318,7 @@ lle_batch* lle_batch_create(const lle_map* map, int64_t n_envs, int device_id, v
     lle_batch* b = new (std::nothrow) lle_batch();
     if (!b) return nullptr;
     b->hdr = map->m.header;
+    b->map = map->m;
     b->n_envs = n_envs;
     b->device = device_id;
     b->arena = nullptr;
@@ -328,8 +335,15 @@ lle_batch* lle_batch_create(const lle_map* map, int64_t n_envs, int device_id, v
     return b;
 }
 
+static void drop_views(lle_batch* b) {
+    for (auto& kv : b->views)
+        if (kv.second.dev) (void)hipFree(kv.second.dev);
+    b->views.clear();
+}
+
 void lle_batch_free(lle_batch* b) {
     if (!b) return;
+    drop_views(b);
     if (b->owns_arena && b->arena) (void)hipFree(b->arena);
     delete b;
 }
@@ -428,6 +442,162 @@ int lle_batch_observe(lle_batch* b, void* stream) {
     return launch(b, KMODE_OBSERVE, K, stream);
 }
 
+// ---- the other observation builders (observers.hip)
+static int obs_desc(const lle_batch* b, int kind, int param, lle_obs_desc* d) {
+    const MapHeader& h = b->hdr;
+    const int64_t n = b->n_envs, A = h.A, H = h.H, W = h.W;
+    *d = lle_obs_desc{};
+    d->kind = kind; d->param = param; d->supported = 1;
+    auto set = [&](int elem, std::initializer_list<int64_t> shape, int64_t env_pitch_elems) {
+        d->elem_bytes = elem;
+        d->ndim = (int32_t)shape.size();
+        int k = 0;
+        for (int64_t v : shape) d->shape[k++] = v;
+        int64_t st = 1;
+        for (int q = d->ndim - 1; q >= 1; q--) { d->stride[q] = st; st *= d->shape[q]; }
+        d->stride[0] = env_pitch_elems;
+        d->bytes = n * env_pitch_elems * elem;
+    };
+    auto align16 = [](int64_t x) { return (x + 15) / 16 * 16; };
+    switch (kind) {
+        case LLE_OBS_LAYERED:
+            if (param != 0) return fail(LLE_ERR_ARG, "LLE_OBS_LAYERED takes no parameter");
+            set(1, {n, (int64_t)h.C, H, W}, h.obs_stride);
+            d->supported = (int32_t)h.obs_supported;
+            return LLE_OK;
+        case LLE_OBS_LAYERED_PADDED: {
+            if (param < 0 || A + param > 32) return fail(LLE_ERR_ARG, "padding out of range (n_agents + padding <= 32)");
+            const int64_t C = 2 * (A + param) + 4;
+            if (C * H * W >= (1 << 20)) return fail(LLE_ERR_UNSUPPORTED, "padded observation too large");
+            set(1, {n, C, H, W}, align16(C * H * W));
+            for (const Source& s : b->map.sources)
+                if (s.agent_id >= C - (A + param)) d->supported = 0;
+            return LLE_OK;
+        }
+        case LLE_OBS_PERSPECTIVE: {
+            if (param != 0) return fail(LLE_ERR_ARG, "LLE_OBS_PERSPECTIVE takes no parameter");
+            set(1, {n, A, (int64_t)h.C, H, W}, A * (int64_t)h.obs_stride);
+            d->stride[1] = h.obs_stride;  // one padded layered row per observer
+            d->supported = (int32_t)h.obs_supported;
+            return LLE_OK;
+        }
+        case LLE_OBS_PARTIAL: {
+            if (param < 1 || param > 15 || param % 2 == 0) return fail(LLE_ERR_ARG, "square size must be odd, 1..15");
+            set(1, {n, A, 2 * A + 3, (int64_t)param, (int64_t)param}, partial_pitch((int)A, param));
+            for (const Source& s : b->map.sources)
+                if (s.agent_id > (int)A + 1) d->supported = 0;  // LASER_0 + colour must be a layer (< 2A+3)
+            return LLE_OK;
+        }
+        case LLE_OBS_STATE:
+        case LLE_OBS_NORMALIZED_STATE:
+            if (param != 0) return fail(LLE_ERR_ARG, "the state observation takes no parameter");
+            set(4, {n, 3 * A + (int64_t)h.G}, 3 * A + (int64_t)h.G);
+            return LLE_OK;
+        default:
+            return fail(LLE_ERR_ARG, "unknown observation kind");
+    }
+}
+
+int lle_batch_obs_desc(lle_batch* b, int kind, int param, lle_obs_desc* out) {
+    if (!b || !out) return fail(LLE_ERR_NULL, "NULL argument");
+    int rc = obs_desc(b, kind, param, out);
+    if (rc == LLE_OK) g_status = LLE_OK;
+    return rc;
+}
+
+// Device copy of the view blob(s) for (kind, param).  (OBS_PERSPECTIVE, -1) = the blobs of all observers back to back.
+static int get_view(lle_batch* b, int kind, int param, hipStream_t st, const lle_batch::View** out) {
+    auto key = std::make_pair(kind, param);
+    auto it = b->views.find(key);
+    if (it == b->views.end()) {
+        std::vector<uint8_t> blob;
+        if (kind == LLE_OBS_PERSPECTIVE && param < 0) {
+            for (int k = 0; k < (int)b->hdr.A; k++) {
+                std::vector<uint8_t> one = b->map.compile_view(kind, k);
+                blob.insert(blob.end(), one.begin(), one.end());
+            }
+        } else {
+            blob = b->map.compile_view(kind, param);
+        }
+        lle_batch::View v{};
+        std::memcpy(&v.hdr, blob.data(), sizeof v.hdr);
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, blob.size()));
+        v.dev = static_cast<uint8_t*>(p);
+        hipError_t e = hipMemcpyAsync(v.dev, blob.data(), blob.size(), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);  // the blob is a host temporary
+        if (e != hipSuccess) {
+            (void)hipFree(p);
+            return fail(LLE_ERR_HIP, std::string("view upload: ") + hipGetErrorString(e));
+        }
+        it = b->views.emplace(key, v).first;
+    }
+    *out = &it->second;
+    return LLE_OK;
+}
+
+int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64_t out_bytes, void* stream) {
+    if (!b || !out_dev) return fail(LLE_ERR_NULL, "NULL argument");
+    lle_obs_desc d;
+    int rc = obs_desc(b, kind, param, &d);
+    if (rc != LLE_OK) return rc;
+    if (!d.supported) return fail(LLE_ERR_UNSUPPORTED, "a laser colour has no layer in this observation (the reference raises IndexError)");
+    if (out_bytes < d.bytes || (reinterpret_cast<uintptr_t>(out_dev) % 16) != 0)
+        return fail(LLE_ERR_ARENA, "output buffer too small or not 16-byte aligned");
+    HIP_TRY(hipSetDevice(b->device));
+    hipStream_t st = (hipStream_t)stream;
+    const MapHeader& h = b->hdr;
+    switch (kind) {
+        case LLE_OBS_LAYERED:
+        case LLE_OBS_PERSPECTIVE: {
+            // observer k of the perspective = the layered tensor with two layer pairs swapped; k = 0 is Layered itself
+            const int n_views = kind == LLE_OBS_PERSPECTIVE ? (int)h.A : 1;
+            const lle_batch::View* v;
+            rc = get_view(b, LLE_OBS_PERSPECTIVE, 0, st, &v);
+            if (rc != LLE_OK) return rc;
+            if (n_views > 1 && view_kernel_fits(v->hdr, (uint32_t)n_views)) {
+                // small maps: one launch, the rows of all observers of an env written back to back
+                rc = get_view(b, LLE_OBS_PERSPECTIVE, -1, st, &v);
+                if (rc != LLE_OK) return rc;
+                HIP_TRY(launch_view_observe(v->hdr, b->ptrs, v->dev, (uint32_t)n_views, static_cast<int8_t*>(out_dev),
+                                            (int64_t)n_views * h.obs_stride, (int64_t)h.obs_stride, b->n_envs, st));
+                break;
+            }
+            for (int k = 0; k < n_views; k++) {  // big rows: one launch per observer, rows strided by A * obs_stride
+                rc = get_view(b, LLE_OBS_PERSPECTIVE, k, st, &v);
+                if (rc != LLE_OK) return rc;
+                HIP_TRY(launch_view_observe(v->hdr, b->ptrs, v->dev, 1u, static_cast<int8_t*>(out_dev) + (int64_t)k * h.obs_stride,
+                                            (int64_t)n_views * h.obs_stride, 0, b->n_envs, st));
+            }
+            break;
+        }
+        case LLE_OBS_LAYERED_PADDED: {
+            const lle_batch::View* v;
+            rc = get_view(b, kind, param, st, &v);
+            if (rc != LLE_OK) return rc;
+            HIP_TRY(launch_view_observe(v->hdr, b->ptrs, v->dev, 1u, static_cast<int8_t*>(out_dev), (int64_t)v->hdr.obs_stride, 0,
+                                        b->n_envs, st));
+            break;
+        }
+        case LLE_OBS_PARTIAL:
+            HIP_TRY(launch_partial_observe(h, b->ptrs, static_cast<int8_t*>(out_dev), param, b->n_envs, st));
+            break;
+        default:
+            HIP_TRY(launch_state_observe(h, b->ptrs, static_cast<float*>(out_dev), kind == LLE_OBS_NORMALIZED_STATE, b->n_envs, st));
+            break;
+    }
+    g_status = LLE_OK;
+    return LLE_OK;
+}
+
+int lle_batch_available_actions(lle_batch* b, int walkable_lasers, uint8_t* out_dev, void* stream) {
+    if (!b || !out_dev) return fail(LLE_ERR_NULL, "NULL argument");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(launch_avail(b->hdr, b->ptrs, out_dev, walkable_lasers, b->n_envs, (hipStream_t)stream));
+    g_status = LLE_OK;
+    return LLE_OK;
+}
+
 int lle_batch_update_sources(lle_batch* b, const lle_map* map, void* stream) {
     if (!b || !map) return fail(LLE_ERR_NULL, "NULL argument");
     const MapHeader& nh = map->m.header;
@@ -441,6 +611,8 @@ int lle_batch_update_sources(lle_batch* b, const lle_map* map, void* stream) {
     HIP_TRY(hipMemcpyAsync(b->arena + b->layout.off_tables, map->m.blob.data(), map->m.blob.size(), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
     b->hdr = nh;
+    b->map = map->m;
+    drop_views(b);  // their channel tables depend on the colours (the stream is idle: synchronised above)
     int rc = refresh_init_record(b, stream);
     if (rc != LLE_OK) return rc;
     return launch(b, KMODE_SOURCES, K, stream);

@@ -21,4 +21,13 @@ int step_group(int A);
 uint32_t step_envs_per_wave(int64_t n, int A);
 int step_lm(int L);
 
+// observers.hip
+hipError_t launch_view_observe(const ViewHeader& v, const BatchPtrs& P, const uint8_t* views_dev, uint32_t n_views, int8_t* out,
+                               int64_t row_pitch, int64_t view_pitch, int64_t n_envs, hipStream_t stream);
+bool view_kernel_fits(const ViewHeader& v, uint32_t n_views);  // do n_views views fit the LDS of one workgroup together?
+uint32_t partial_pitch(int A, int k);
+hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t* out, int k, int64_t n_envs, hipStream_t stream);
+hipError_t launch_state_observe(const MapHeader& h, const BatchPtrs& P, float* out, int normalize, int64_t n_envs, hipStream_t stream);
+hipError_t launch_avail(const MapHeader& h, const BatchPtrs& P, uint8_t* out, int walkable_lasers, int64_t n_envs, hipStream_t stream);
+
 }  // namespace lle

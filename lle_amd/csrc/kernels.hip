@@ -14,22 +14,13 @@
 #include <stdlib.h>
 
 #include "kernels.h"
+#include "obs_stream.hpp"
 #include "step_logic.hpp"
 #include "tables.h"
 
 namespace lle {
 
 enum Mode : int { MODE_STEP = 0, MODE_RESET = 1, MODE_SET_STATE = 2, MODE_OBSERVE = 3, MODE_SOURCES = 4 };
-
-// The workgroup IS one wavefront, and a wave's LDS operations execute in issue order, so lanes of the wave may hand
-// data to each other through LDS without `s_barrier` and without the `s_waitcnt vmcnt(0)` that `__syncthreads()`
-// emits (which would stall every environment of phase 2 on the completion of the previous environment's global
-// stores).  wave_sync() only pins the compiler's ordering.
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 #pragma unroll
@@ -39,92 +30,6 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
         v += ((uint64_t)hi << 32) | lo;
     }
     return v;
-}
-
-// ---- static tables -> LDS, once per workgroup (section offsets are those of the blob).  The section is a whole
-// number of 1 KiB rows; every thread requests all of its rows (up to four) before the first LDS write.
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void copy_tables_to_lds(const uint8_t* __restrict__ tables, uint8_t* lds, uint32_t tab_bytes,
-                                                   uint32_t lane, uint32_t wave_in_wg, uint32_t waves_per_wg) {
-    const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(tables) + lane;
-    u32x4* dst = reinterpret_cast<u32x4*>(lds) + lane;
-    const uint32_t rows = tab_bytes / 1024;
-    for (uint32_t r0 = wave_in_wg; r0 < rows; r0 += 4 * waves_per_wg) {
-        // rows r0, r0 + W, r0 + 2W, r0 + 3W of this wavefront (named scalars, not an array: an indexed private array
-        // here ended up in scratch memory)
-        const uint32_t r1 = r0 + waves_per_wg, r2 = r1 + waves_per_wg, r3 = r2 + waves_per_wg;
-        u32x4 v0 = src[r0 * 64], v1 = {0, 0, 0, 0}, v2 = {0, 0, 0, 0}, v3 = {0, 0, 0, 0};
-        if (r1 < rows) v1 = src[r1 * 64];
-        if (r2 < rows) v2 = src[r2 * 64];
-        if (r3 < rows) v3 = src[r3 * 64];
-        __builtin_amdgcn_sched_barrier(0);  // keep the loads together, ahead of the LDS writes
-        dst[r0 * 64] = v0;
-        if (r1 < rows) dst[r1 * 64] = v1;
-        if (r2 < rows) dst[r2 * 64] = v2;
-        if (r3 < rows) dst[r3 * 64] = v3;
-    }
-}
-
-// ---- phase 2: layered observation of the wave's environments, one environment at a time.
-// `scratch` holds one hand-over record per environment: [0 | beam masks | ~gem bits | byte index of each agent].
-__device__ __forceinline__ void write_observations(const MapHeader* __restrict__ hdr, const uint64_t* dyn, int8_t* tmpl,
-                                                   const uint32_t* scratch, uint32_t scr_stride, int8_t* __restrict__ obs,
-                                                   int64_t env0, int64_t n_here, uint32_t lane) {
-    const int A = (int)hdr->A, L = (int)hdr->L;
-    const uint64_t obs_stride = hdr->obs_stride;
-    const uint32_t D = hdr->D, n_chunks = hdr->n_chunks;
-    // Each lane serves the same dyn entry for every environment: decode it once.
-    // A laser / gem reference becomes (dword of the hand-over record, bit); an absent one points at the record's
-    // zero word, so the per-environment evaluation is branch-free.
-    const bool has_d0 = lane < D;
-    const uint64_t e0 = has_d0 ? dyn[lane] : 0ull;
-    const uint32_t d0_idx = (uint32_t)e0 & 0xFFFFFu;
-    const int32_t d0_base = (int8_t)(uint8_t)(e0 >> 20);
-    const uint32_t d0_refs = (uint32_t)(e0 >> 28) & 3u, d0_gem = (uint32_t)(e0 >> 50) & 63u;
-    const uint32_t d0_r0 = (uint32_t)(e0 >> 30) & 0x3FFu, d0_r1 = (uint32_t)(e0 >> 40) & 0x3FFu;
-    const uint32_t d0_w0 = d0_refs >= 1 ? 1u + (d0_r0 & 31u) : 0u, d0_s0 = d0_refs >= 1 ? d0_r0 >> 5 : 0u;
-    const uint32_t d0_w1 = d0_refs >= 2 ? 1u + (d0_r1 & 31u) : 0u, d0_s1 = d0_refs >= 2 ? d0_r1 >> 5 : 0u;
-    const uint32_t d0_wg = d0_gem != NO_GEM ? (uint32_t)L + 1u : 0u, d0_sg = d0_gem != NO_GEM ? (d0_gem & 31u) : 0u;
-    const bool is_agent_lane = (int)lane < A;
-    const uint4* srcv = reinterpret_cast<const uint4*>(tmpl);
-
-    for (int64_t k = 0; k < n_here; k++) {
-        const uint32_t* sc = scratch + (uint32_t)k * scr_stride;
-        // (a) bytes that depend on beams / gems
-        {
-            const uint32_t lit = ((sc[d0_w0] >> d0_s0) | (sc[d0_w1] >> d0_s1) | (sc[d0_wg] >> d0_sg)) & 1u;
-            if (has_d0) tmpl[d0_idx] = (int8_t)(lit ? 1 : d0_base);
-        }
-        for (uint32_t d = lane + 64u; d < D; d += 64) {  // maps with more than 64 dynamic bytes
-            const uint64_t e = dyn[d];
-            const uint32_t refs = (uint32_t)(e >> 28) & 3u, gem = (uint32_t)(e >> 50) & 63u;
-            const uint32_t r0 = (uint32_t)(e >> 30) & 0x3FFu, r1 = (uint32_t)(e >> 40) & 0x3FFu;
-            const uint32_t w0 = refs >= 1 ? 1u + (r0 & 31u) : 0u, w1 = refs >= 2 ? 1u + (r1 & 31u) : 0u;
-            const uint32_t wg = gem != NO_GEM ? (uint32_t)L + 1u : 0u;
-            const uint32_t lit = ((sc[w0] >> (refs >= 1 ? r0 >> 5 : 0u)) | (sc[w1] >> (refs >= 2 ? r1 >> 5 : 0u)) |
-                                  (sc[wg] >> (gem != NO_GEM ? (gem & 31u) : 0u))) & 1u;
-            tmpl[(uint32_t)e & 0xFFFFFu] = (int8_t)(lit ? 1 : (int32_t)(int8_t)(uint8_t)(e >> 20));
-        }
-        // (b) agents (dead ones included, observations.py:264-265)
-        const uint32_t agent_idx = is_agent_lane ? sc[L + 2 + lane] : 0u;
-        if (is_agent_lane) tmpl[agent_idx] = 1;
-        wave_sync();
-        // (c) stream the patched copy as one contiguous row: 16 B per lane, 1 KiB per wave instruction
-        uint4* __restrict__ dst = reinterpret_cast<uint4*>(obs + (uint64_t)(env0 + k) * obs_stride);
-        {
-            const uint32_t c0 = lane, c1 = lane + 64u;
-            const uint4 v0 = srcv[c0 < n_chunks ? c0 : 0u], v1 = srcv[c1 < n_chunks ? c1 : 0u];
-            // plain stores: `nt` measured 40 % slower and `sc0 sc1` (write-through) no faster at 65 536 envs and
-            // 50 % slower at 262 144
-            if (c0 < n_chunks) dst[c0] = v0;
-            if (c1 < n_chunks) dst[c1] = v1;
-        }
-        for (uint32_t c = lane + 128u; c < n_chunks; c += 64) dst[c] = srcv[c];  // rows longer than 2 KiB
-        wave_sync();
-        // (d) agents off again (their layers are all-zero in the static copy); LDS is in order, so this lands after
-        // the reads above and before the next environment's patches
-        if (is_agent_lane) tmpl[agent_idx] = 0;
-    }
 }
 
 // per-wave partial counters, written last so that their read-modify-write latency is off the observation's path;
@@ -420,7 +325,7 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
     LLE_STAMP(4);
     // ---- phase 2: layered observation, one environment of the wave at a time
     if (write_obs && n_here > 0)
-        write_observations(hdr, dyn, tmpl, scratch, scr_stride, P.obs, env0, n_here, lane);
+        write_observations(A, L, hdr->D, hdr->n_chunks, hdr->obs_stride, dyn, tmpl, scratch, scr_stride, P.obs, env0, n_here, lane);
     LLE_STAMP(5);
     if (MODE == MODE_STEP) flush_stats(P.stats, wave_id, cnt, A, lane);
 
@@ -738,7 +643,7 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
     wave_sync();
     LLE_STAMP(4);
 
-    if (write_obs && n_here > 0) write_observations(hdr, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane);
+    if (write_obs && n_here > 0) write_observations(A, L, hdr->D, hdr->n_chunks, hdr->obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane);
     wave_sync();
     }  // steps
     LLE_STAMP(5);

@@ -262,6 +262,95 @@ int Map::n_laser_tiles() const {
     return n;
 }
 
+// Static template + dynamic-byte table of a layered-style observation whose channels are given by `lm`
+// (python/lle/observations.py:216-266; write order: WALL, VOID, EXIT, -1 at sources | lasers on, gems | agents).
+// Returns false when some laser colour has no layer (the reference raises IndexError there).
+bool Map::build_obs_tables(const LayerMap& lm, std::vector<int8_t>& tmpl, std::vector<uint64_t>& dyn_tab) const {
+    const int HW = H * W, G = (int)gems.size();
+    bool supported = true;
+    const uint32_t obs_stride = ((uint32_t)(lm.C * HW) + 15u) & ~15u;
+    tmpl.assign(obs_stride, 0);
+    auto at = [&](int layer, Pos q) -> int8_t& { return tmpl[(size_t)layer * HW + q.i * W + q.j]; };
+    for (auto& q : walls) at(lm.wall, q) = 1;
+    for (auto& q : voids) at(lm.void_, q) = 1;
+    for (auto& q : exits) at(lm.exit, q) = 1;
+    for (auto& s : sources) {
+        if (s.agent_id >= lm.n_laser) { supported = false; continue; }
+        at(lm.laser[s.agent_id], s.pos) = -1;
+    }
+    // dynamic bytes: laser tiles that World.lasers() exposes (outer layer + the one directly below,
+    // world.rs:159-172), then uncollected gems
+    struct Dyn { int n_refs = 0; uint32_t ref[2] = {0, 0}; uint32_t gem = NO_GEM; };
+    std::map<uint32_t, Dyn> dyn;
+    for (int c = 0; c < HW; c++) {
+        const auto& layers = cell_layers[c];
+        for (size_t k = 0; k < layers.size() && k < 2; k++) {
+            const Source& src = sources[layers[k].laser_id];
+            if (src.agent_id >= lm.n_laser) { supported = false; continue; }
+            uint32_t idx = (uint32_t)(lm.laser[src.agent_id] * HW + c);
+            Dyn& d = dyn[idx];
+            d.ref[d.n_refs++] = (uint32_t)layers[k].laser_id | ((uint32_t)layers[k].offset << 5);
+        }
+    }
+    for (int g = 0; g < G; g++) dyn[(uint32_t)(lm.gem * HW + gems[g].i * W + gems[g].j)].gem = (uint32_t)g;
+    dyn_tab.clear();
+    for (auto& kv : dyn) {
+        const Dyn& d = kv.second;
+        uint64_t e = kv.first | ((uint64_t)(uint8_t)tmpl[kv.first] << 20) | ((uint64_t)d.n_refs << 28) |
+                     ((uint64_t)d.ref[0] << 30) | ((uint64_t)d.ref[1] << 40) | ((uint64_t)d.gem << 50);
+        dyn_tab.push_back(e);
+    }
+    return supported;
+}
+
+// View blob of a layered-style observation with another channel layout (tables.h ViewHeader):
+//   OBS_LAYERED_PADDED (param = padding p): LayeredPadded, observations.py:196-214 -- n_agents + p agent layers and as
+//     many laser layers, so colours in [A, A+p) get a layer of their own instead of aliasing;
+//   OBS_PERSPECTIVE (param = observer k): AgentZeroPerspective, observations.py:372-395 -- the Layered tensor with
+//     layers A0 <-> A0+k and LASER_0 <-> LASER_0+k swapped (a permutation of the finished layers).
+std::vector<uint8_t> Map::compile_view(int kind, int param) const {
+    const int A = n_agents(), HW = H * W;
+    LayerMap lm;
+    if (kind == OBS_LAYERED_PADDED) {
+        const int Ap = A + param;
+        lm.C = 2 * Ap + 4;
+        for (int a = 0; a < A; a++) lm.agent[a] = a;
+        lm.n_laser = lm.C - Ap;
+        for (int c = 0; c < lm.n_laser; c++) lm.laser[c] = Ap + c;
+        lm.wall = 2 * Ap; lm.void_ = lm.wall + 1; lm.gem = lm.wall + 2; lm.exit = lm.wall + 3;
+    } else {  // OBS_PERSPECTIVE (k = 0 is the plain layered tensor)
+        const int k = param;
+        lm.C = 2 * A + 4;
+        auto sigma = [&](int l) { return l == 0 ? k : (l == k ? 0 : (l == A ? A + k : (l == A + k ? A : l))); };
+        for (int a = 0; a < A; a++) lm.agent[a] = sigma(a);
+        lm.n_laser = lm.C - A;
+        for (int c = 0; c < lm.n_laser; c++) lm.laser[c] = sigma(A + c);
+        lm.wall = sigma(2 * A); lm.void_ = sigma(2 * A + 1); lm.gem = sigma(2 * A + 2); lm.exit = sigma(2 * A + 3);
+    }
+    std::vector<int8_t> tmpl;
+    std::vector<uint64_t> dyn_tab;
+    ViewHeader v{};
+    v.magic = VIEW_MAGIC;
+    v.supported = build_obs_tables(lm, tmpl, dyn_tab) ? 1u : 0u;
+    v.A = (uint32_t)A; v.L = (uint32_t)sources.size(); v.H = (uint32_t)H; v.W = (uint32_t)W; v.HW = (uint32_t)HW;
+    v.C = (uint32_t)lm.C;
+    v.obs_bytes = (uint32_t)(lm.C * HW);
+    v.obs_stride = (v.obs_bytes + 15u) & ~15u;
+    v.n_chunks = v.obs_stride / 16;
+    v.D = (uint32_t)dyn_tab.size();
+    for (int a = 0; a < A; a++) v.agent_layer[a] = (uint8_t)lm.agent[a];
+    size_t off = sizeof(ViewHeader);
+    v.off_dyn = (uint32_t)off; off = (off + dyn_tab.size() * 8 + 15) & ~(size_t)15;
+    v.off_template = (uint32_t)off; off += tmpl.size();
+    off = (off + 1023) & ~(size_t)1023;  // the kernel copies the whole blob to LDS in 1-KiB rows
+    v.blob_bytes = (uint32_t)off;
+    std::vector<uint8_t> out(off, 0);
+    if (!dyn_tab.empty()) std::memcpy(out.data() + v.off_dyn, dyn_tab.data(), dyn_tab.size() * 8);
+    std::memcpy(out.data() + v.off_template, tmpl.data(), tmpl.size());
+    std::memcpy(out.data(), &v, sizeof v);
+    return out;
+}
+
 void Map::compile() {
     const int A = n_agents(), G = (int)gems.size(), L = (int)sources.size(), C = n_layers(), HW = H * W;
     MapHeader h{};
@@ -309,42 +398,23 @@ void Map::compile() {
                 if (k != K_WALL && k != K_SOURCE) walk |= 1u << d;
             }
             uint32_t gi = gem_index[c] >= 0 ? (uint32_t)gem_index[c] : 31u;
+            if (kind[c] == K_SOURCE)  // the field holds the laser_id of a source cell (read by the partial observer)
+                for (const Source& src : sources)
+                    if (src.pos.i == i && src.pos.j == j) gi = (uint32_t)src.laser_id;
             cell_meta[c] = kind[c] | (gi << 3) | (walk << 8) | ((uint32_t)layers.size() << 12);
         }
 
-    // ---- static observation (observations.py:216-237): WALL, VOID, EXIT, then -1 at each source on its colour layer
-    const int LASER_0 = A, WALL = 2 * A, VOID = WALL + 1, GEM = VOID + 1, EXIT = GEM + 1;
-    std::vector<int8_t> tmpl(h.obs_stride, 0);
-    auto at = [&](int layer, Pos q) -> int8_t& { return tmpl[(size_t)layer * HW + q.i * W + q.j]; };
-    for (auto& q : walls) at(WALL, q) = 1;
-    for (auto& q : voids) at(VOID, q) = 1;
-    for (auto& q : exits) at(EXIT, q) = 1;
-    for (auto& s : sources) {
-        if (LASER_0 + s.agent_id >= C) { h.obs_supported = 0; continue; }
-        at(LASER_0 + s.agent_id, s.pos) = -1;
-    }
-
-    // ---- dynamic observation bytes (observations.py:254-263): laser tiles that World.lasers() exposes
-    // (outer layer + the one directly below, world.rs:159-172), then uncollected gems
-    struct Dyn { int n_refs = 0; uint32_t ref[2] = {0, 0}; uint32_t gem = NO_GEM; };
-    std::map<uint32_t, Dyn> dyn;
-    for (int c = 0; c < HW; c++) {
-        const auto& layers = cell_layers[c];
-        for (size_t k = 0; k < layers.size() && k < 2; k++) {
-            const Source& src = sources[layers[k].laser_id];
-            if (LASER_0 + src.agent_id >= C) { h.obs_supported = 0; continue; }
-            uint32_t idx = (uint32_t)((LASER_0 + src.agent_id) * HW + c);
-            Dyn& d = dyn[idx];
-            d.ref[d.n_refs++] = (uint32_t)layers[k].laser_id | ((uint32_t)layers[k].offset << 5);
-        }
-    }
-    for (int g = 0; g < G; g++) dyn[(uint32_t)(GEM * HW + gems[g].i * W + gems[g].j)].gem = (uint32_t)g;
+    // ---- layered observation tables (static template + dynamic bytes) with the Layered channel order
+    std::vector<int8_t> tmpl;
     std::vector<uint64_t> dyn_tab;
-    for (auto& kv : dyn) {
-        const Dyn& d = kv.second;
-        uint64_t e = kv.first | ((uint64_t)(uint8_t)tmpl[kv.first] << 20) | ((uint64_t)d.n_refs << 28) |
-                     ((uint64_t)d.ref[0] << 30) | ((uint64_t)d.ref[1] << 40) | ((uint64_t)d.gem << 50);
-        dyn_tab.push_back(e);
+    {
+        LayerMap lm;
+        lm.C = C;
+        for (int a = 0; a < A; a++) lm.agent[a] = a;
+        lm.n_laser = C - A;  // LASER_0 + colour is a plain index: colours >= A alias WALL/VOID/GEM/EXIT (Q5)
+        for (int c = 0; c < lm.n_laser; c++) lm.laser[c] = A + c;
+        lm.wall = 2 * A; lm.void_ = 2 * A + 1; lm.gem = 2 * A + 2; lm.exit = 2 * A + 3;
+        if (!build_obs_tables(lm, tmpl, dyn_tab)) h.obs_supported = 0;
     }
     h.D = (uint32_t)dyn_tab.size();
 

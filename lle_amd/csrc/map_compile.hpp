@@ -43,6 +43,17 @@ struct Map {
     int n_layers() const { return 2 * n_agents() + 4; }
     int n_laser_tiles() const;
 
+    // channel layout of a layered-style observation: layer index of each agent, of each laser colour, and of
+    // the four fixed layers
+    struct LayerMap {
+        int C = 0, n_laser = 0;
+        int agent[MAX_AGENTS] = {0};
+        int laser[2 * MAX_AGENTS + 8] = {0};
+        int wall = 0, void_ = 0, gem = 0, exit = 0;
+    };
+    bool build_obs_tables(const LayerMap& lm, std::vector<int8_t>& tmpl, std::vector<uint64_t>& dyn_tab) const;
+    std::vector<uint8_t> compile_view(int kind, int param) const;  // ViewHeader + dyn + template (tables.h)
+
     // compiled form
     MapHeader header{};
     std::vector<uint8_t> blob;  // header + sections

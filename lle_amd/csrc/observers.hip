@@ -1,0 +1,257 @@
+// observers.hip -- gfx950 kernels of the observation builders other than the layered tensor the step kernel emits
+// (reference python/lle/observations.py, python/lle/env/env.py:146-163).
+//
+//   view_observe_kernel    layered-padded / agent-zero perspective: the layered streamer of obs_stream.hpp run on a
+//                          "view" blob (other channel layout, map_compile.cpp compile_view) -- HBM-write bound
+//   partial_observe_kernel k x k windows centred on each agent, assembled in LDS per environment and streamed as one
+//                          16-byte-aligned row -- HBM-write bound
+//   state_observe_kernel   [i0, j0, ..., gems, alive] as f32, optionally normalised -- one thread per element
+//   avail_kernel           availability as bools, optionally without moves into foreign active lasers
+//
+// All of them read the packed state the step kernel keeps (pos, bits, gems, beams, avail) and write to a caller buffer.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+#include "obs_stream.hpp"
+#include "observers_logic.hpp"
+#include "tables.h"
+
+namespace lle {
+
+constexpr uint32_t OBS_ENVS_PER_WAVE = 16;
+constexpr uint32_t OBS_LDS_LIMIT = 160 * 1024;
+
+// ---------------------------------------------------------------------------------------------- layered views
+// `views` = n_views view blobs of equal size back to back (one for layered-padded; one per observer for the
+// perspective when they fit in LDS together).  LDS: [the blobs] then per wave, per view
+// [patchable template copy | OBS_ENVS_PER_WAVE records].  Row of (env, view v) = out + env * row_pitch + v * view_pitch:
+// with several views the wave writes the rows of one environment back to back (one contiguous span per env).
+__global__ void __launch_bounds__(256) view_observe_kernel(BatchPtrs P, const uint8_t* __restrict__ views, uint32_t n_views,
+                                                           int8_t* __restrict__ out, int64_t row_pitch, int64_t view_pitch,
+                                                           int64_t env_base, int64_t env_limit) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const ViewHeader* __restrict__ gh = reinterpret_cast<const ViewHeader*>(views);
+    const uint32_t lane = threadIdx.x & 63u, wave_in_wg = threadIdx.x >> 6, waves_per_wg = blockDim.x >> 6;
+    const uint32_t wave_id = blockIdx.x * waves_per_wg + wave_in_wg;
+    const uint32_t blob_bytes = gh->blob_bytes;
+    copy_tables_to_lds(views, lds, blob_bytes * n_views, lane, wave_in_wg, waves_per_wg);
+    __syncthreads();
+    const ViewHeader* vh0 = reinterpret_cast<const ViewHeader*>(lds);
+    const int A = (int)vh0->A, L = (int)vh0->L, W = (int)vh0->W;
+    const int64_t As = agent_stride_of(A, L);
+    const uint32_t obs_stride = vh0->obs_stride, n_chunks = vh0->n_chunks;
+    const uint32_t scr_stride = (uint32_t)(L + A + 2) | 1u;
+    const uint32_t view_priv = obs_stride + OBS_ENVS_PER_WAVE * scr_stride * 4u;
+    uint8_t* priv = lds + blob_bytes * n_views + wave_in_wg * n_views * view_priv;
+    for (uint32_t v = 0; v < n_views; v++) {
+        const ViewHeader* vh = reinterpret_cast<const ViewHeader*>(lds + v * blob_bytes);
+        const uint4* pristine = reinterpret_cast<const uint4*>(lds + v * blob_bytes + vh->off_template);
+        uint4* mine = reinterpret_cast<uint4*>(priv + v * view_priv);
+        for (uint32_t c = lane; c < n_chunks; c += 64) mine[c] = pristine[c];
+    }
+    const int64_t env0 = env_base + (int64_t)wave_id * OBS_ENVS_PER_WAVE;
+    int64_t n_here = env_limit - env0;
+    n_here = n_here < 0 ? 0 : (n_here > (int64_t)OBS_ENVS_PER_WAVE ? (int64_t)OBS_ENVS_PER_WAVE : n_here);
+    // hand-over records [0 | beam masks | ~gem bits | byte index of each agent], all loads of the wave in flight together
+    const uint32_t per_env = (uint32_t)(L + A + 2);
+    for (uint32_t idx = lane; idx < (uint32_t)n_here * per_env; idx += 64) {
+        const uint32_t k = idx / per_env, f = idx - k * per_env;
+        const int64_t env = env0 + k;
+        uint32_t v = 0, cell = 0;
+        const bool is_agent = f > (uint32_t)L + 1u;
+        if (f >= 1 && f <= (uint32_t)L) v = P.beams[env * L + (f - 1)];
+        else if (f == (uint32_t)L + 1u) v = ~P.gems[env];
+        else if (is_agent) cell = cell_of((uint32_t)P.pos[env * As + (f - (uint32_t)L - 2u)], W);
+        for (uint32_t q = 0; q < n_views; q++) {
+            const ViewHeader* vh = reinterpret_cast<const ViewHeader*>(lds + q * blob_bytes);
+            uint32_t* scratch = reinterpret_cast<uint32_t*>(priv + q * view_priv + obs_stride);
+            scratch[k * scr_stride + f] = is_agent ? (uint32_t)vh->agent_layer[f - (uint32_t)L - 2u] * vh->HW + cell : v;
+        }
+    }
+    wave_sync();
+    if (n_views == 1) {
+        const uint64_t* dyn = reinterpret_cast<const uint64_t*>(lds + vh0->off_dyn);
+        int8_t* tmpl = reinterpret_cast<int8_t*>(priv);
+        if (n_here > 0)
+            write_observations(A, L, vh0->D, n_chunks, (uint64_t)row_pitch, dyn, tmpl, reinterpret_cast<const uint32_t*>(tmpl + obs_stride),
+                               scr_stride, out, env0, n_here, lane);
+        return;
+    }
+    for (int64_t k = 0; k < n_here; k++)
+        for (uint32_t q = 0; q < n_views; q++) {
+            const ViewHeader* vh = reinterpret_cast<const ViewHeader*>(lds + q * blob_bytes);
+            const uint64_t* dyn = reinterpret_cast<const uint64_t*>(lds + q * blob_bytes + vh->off_dyn);
+            int8_t* tmpl = reinterpret_cast<int8_t*>(priv + q * view_priv);
+            const uint32_t* scratch = reinterpret_cast<const uint32_t*>(tmpl + obs_stride) + (uint32_t)k * scr_stride;
+            write_observations(A, L, vh->D, n_chunks, (uint64_t)row_pitch, dyn, tmpl, scratch, scr_stride,
+                               out + (int64_t)q * view_pitch, env0 + k, 1, lane);
+        }
+}
+
+// ---------------------------------------------------------------------------------------------- partial k x k
+// LDS: [map tables (cell stacks, cell meta, ...)] [unit table: (agent, wi, wj) of every window cell] then per wave
+// [row buffer (pitch bytes) | records of its envs].  record of an env: pos as u16[As] | gems u32 | beams u32[L].
+// Per environment the wave clears its row with 16-byte LDS stores, every lane evaluates its window cells (only
+// non-zero bytes are written), and the row is streamed as 16 B per lane.
+__global__ void __launch_bounds__(256) partial_observe_kernel(BatchPtrs P, int8_t* __restrict__ out, int k, uint32_t pitch,
+                                                              int64_t env_base, int64_t env_limit) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const MapHeader* __restrict__ hdr = reinterpret_cast<const MapHeader*>(P.tables);
+    const uint32_t lane = threadIdx.x & 63u, wave_in_wg = threadIdx.x >> 6, waves_per_wg = blockDim.x >> 6;
+    const uint32_t wave_id = blockIdx.x * waves_per_wg + wave_in_wg;
+    const int A = (int)hdr->A, L = (int)hdr->L;
+    const int64_t As = agent_stride_of(A, L);
+    const uint32_t tab_bytes = hdr->lds_table_bytes, tab_off = hdr->off_cell_lay;
+    copy_tables_to_lds(P.tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
+    const uint32_t kk = (uint32_t)(k * k), units = (uint32_t)A * kk, row_bytes = units * (uint32_t)(2 * A + 3);
+    const uint32_t unit_bytes = (units * 4u + 15u) & ~15u;
+    uint32_t* unit_tab = reinterpret_cast<uint32_t*>(lds + tab_bytes);
+    for (uint32_t u = threadIdx.x; u < units; u += blockDim.x) {
+        const uint32_t a = u / kk, w = u - a * kk, wi = w / (uint32_t)k;
+        unit_tab[u] = a | (wi << 8) | ((w - wi * (uint32_t)k) << 16);
+    }
+    __syncthreads();
+    ObsTables T;
+    T.cell_lay = reinterpret_cast<const uint64_t*>(lds);
+    T.cell_meta = reinterpret_cast<const uint32_t*>(lds + (hdr->off_cell_meta - tab_off));
+    T.beam_colour = hdr->beam_colour;
+    T.A = A; T.H = (int)hdr->H; T.W = (int)hdr->W;
+    const uint32_t rec_dwords = (uint32_t)(As / 2 + 1 + L);
+    const uint32_t priv_bytes = pitch + OBS_ENVS_PER_WAVE * rec_dwords * 4u;
+    int8_t* row = reinterpret_cast<int8_t*>(lds + tab_bytes + unit_bytes + wave_in_wg * priv_bytes);
+    uint32_t* recs = reinterpret_cast<uint32_t*>(row + pitch);
+    const int64_t env0 = env_base + (int64_t)wave_id * OBS_ENVS_PER_WAVE;
+    int64_t n_here = env_limit - env0;
+    n_here = n_here < 0 ? 0 : (n_here > (int64_t)OBS_ENVS_PER_WAVE ? (int64_t)OBS_ENVS_PER_WAVE : n_here);
+    for (uint32_t idx = lane; idx < (uint32_t)n_here * rec_dwords; idx += 64) {
+        const uint32_t e = idx / rec_dwords, f = idx - e * rec_dwords;
+        const int64_t env = env0 + e;
+        uint32_t v;
+        if (f < (uint32_t)(As / 2)) v = reinterpret_cast<const uint32_t*>(P.pos)[env * (As / 2) + f];
+        else if (f == (uint32_t)(As / 2)) v = P.gems[env];
+        else v = P.beams[env * L + (f - (uint32_t)(As / 2) - 1u)];
+        recs[idx] = v;
+    }
+    wave_sync();
+    const uint32_t n_chunks = pitch / 16;
+    (void)row_bytes;
+    uint4* row16 = reinterpret_cast<uint4*>(row);
+    for (int64_t e = 0; e < n_here; e++) {
+        const uint32_t* rec = recs + (uint32_t)e * rec_dwords;
+        const uint16_t* pos = reinterpret_cast<const uint16_t*>(rec);
+        const uint32_t gems = rec[As / 2];
+        const uint32_t* beams = rec + As / 2 + 1;
+        for (uint32_t c = lane; c < n_chunks; c += 64) row16[c] = make_uint4(0u, 0u, 0u, 0u);
+        wave_sync();  // LDS operations of a wave execute in order: the byte writes below land after the clears
+        for (uint32_t u = lane; u < units; u += 64) {
+            const uint32_t t = unit_tab[u];
+            partial_cell<false>(T, pos, gems, beams, (int)(t & 0xFFu), (int)((t >> 8) & 0xFFu), (int)(t >> 16), k, row);
+        }
+        wave_sync();
+        uint4* __restrict__ dst = reinterpret_cast<uint4*>(out + (uint64_t)(env0 + e) * pitch);
+        for (uint32_t c = lane; c < n_chunks; c += 64) dst[c] = row16[c];
+        wave_sync();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- state vector
+__global__ void __launch_bounds__(256) state_observe_kernel(BatchPtrs P, float* __restrict__ out, int normalize, int64_t n_envs) {
+    const MapHeader* __restrict__ hdr = reinterpret_cast<const MapHeader*>(P.tables);
+    const int A = (int)hdr->A, G = (int)hdr->G, L = (int)hdr->L;
+    const int64_t As = agent_stride_of(A, L);
+    const int len = 3 * A + G;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_envs * len) return;
+    const int64_t env = idx / len;
+    const int e = (int)(idx - env * len);
+    out[idx] = state_elem(A, G, (int)hdr->H, (int)hdr->W, P.pos + env * As, P.gems[env], (uint32_t)P.bits[env] & 0xFFFFu, e, normalize != 0);
+}
+
+// ---------------------------------------------------------------------------------------------- availability bools
+__global__ void __launch_bounds__(256) avail_kernel(BatchPtrs P, uint8_t* __restrict__ out, int walkable_lasers, int64_t n_envs) {
+    const MapHeader* __restrict__ hdr = reinterpret_cast<const MapHeader*>(P.tables);
+    const int A = (int)hdr->A, L = (int)hdr->L;
+    const int64_t As = agent_stride_of(A, L);
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_envs * A) return;
+    const int64_t env = idx / A;
+    const int a = (int)(idx - env * A);
+    ObsTables T;
+    T.cell_lay = reinterpret_cast<const uint64_t*>(P.tables + hdr->off_cell_lay);
+    T.cell_meta = reinterpret_cast<const uint32_t*>(P.tables + hdr->off_cell_meta);
+    T.beam_colour = hdr->beam_colour;
+    T.A = A; T.H = (int)hdr->H; T.W = (int)hdr->W;
+    const uint32_t m = avail_bools(T, P.pos + env * As, P.beams + env * L, a, (uint32_t)P.avail[env * As + a], walkable_lasers != 0);
+    uint8_t* o = out + idx * 5;
+    for (int act = 0; act < 5; act++) o[act] = (uint8_t)((m >> act) & 1u);
+}
+
+// ---------------------------------------------------------------------------------------------- launchers
+static hipError_t grant_lds(const void* fn, uint32_t lds, uint32_t& granted) {
+    if (lds > 64 * 1024 && lds > granted) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        granted = lds;
+    }
+    return hipSuccess;
+}
+
+// LDS bytes of the view kernel for n_views views per launch and wpw wavefronts per workgroup
+static uint32_t view_lds(const ViewHeader& v, uint32_t n_views, uint32_t wpw) {
+    const uint32_t scr_stride = (v.L + v.A + 2) | 1u;
+    return n_views * v.blob_bytes + wpw * n_views * (v.obs_stride + OBS_ENVS_PER_WAVE * scr_stride * 4u);
+}
+
+bool view_kernel_fits(const ViewHeader& v, uint32_t n_views) { return view_lds(v, n_views, 1) <= OBS_LDS_LIMIT; }
+
+hipError_t launch_view_observe(const ViewHeader& v, const BatchPtrs& P, const uint8_t* views_dev, uint32_t n_views, int8_t* out,
+                               int64_t row_pitch, int64_t view_pitch, int64_t n_envs, hipStream_t stream) {
+    uint32_t wpw = 4;
+    while (wpw > 1 && view_lds(v, n_views, wpw) > OBS_LDS_LIMIT) wpw >>= 1;
+    const uint32_t lds = view_lds(v, n_views, wpw);
+    if (lds > OBS_LDS_LIMIT) return hipErrorInvalidValue;
+    static uint32_t granted = 0;
+    hipError_t e = grant_lds(reinterpret_cast<const void*>(&view_observe_kernel), lds, granted);
+    if (e != hipSuccess) return e;
+    const uint32_t n_waves = (uint32_t)((n_envs + OBS_ENVS_PER_WAVE - 1) / OBS_ENVS_PER_WAVE);
+    hipLaunchKernelGGL(view_observe_kernel, dim3((n_waves + wpw - 1) / wpw), dim3(64 * wpw), lds, stream, P, views_dev, n_views, out,
+                       row_pitch, view_pitch, (int64_t)0, n_envs);
+    return hipGetLastError();
+}
+
+uint32_t partial_pitch(int A, int k) { return ((uint32_t)(A * (2 * A + 3) * k * k) + 15u) & ~15u; }
+
+hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t* out, int k, int64_t n_envs, hipStream_t stream) {
+    const uint32_t pitch = partial_pitch((int)h.A, k);
+    const uint32_t As = (uint32_t)agent_stride_of((int)h.A, (int)h.L);
+    const uint32_t priv = pitch + OBS_ENVS_PER_WAVE * (As / 2 + 1 + h.L) * 4u;
+    const uint32_t shared = h.lds_table_bytes + (((uint32_t)(h.A * k * k) * 4u + 15u) & ~15u);
+    uint32_t wpw = 4;
+    while (wpw > 1 && shared + wpw * priv > OBS_LDS_LIMIT) wpw >>= 1;
+    const uint32_t lds = shared + wpw * priv;
+    if (lds > OBS_LDS_LIMIT) return hipErrorInvalidValue;
+    static uint32_t granted = 0;
+    hipError_t e = grant_lds(reinterpret_cast<const void*>(&partial_observe_kernel), lds, granted);
+    if (e != hipSuccess) return e;
+    const uint32_t n_waves = (uint32_t)((n_envs + OBS_ENVS_PER_WAVE - 1) / OBS_ENVS_PER_WAVE);
+    hipLaunchKernelGGL(partial_observe_kernel, dim3((n_waves + wpw - 1) / wpw), dim3(64 * wpw), lds, stream, P, out, k, pitch,
+                       (int64_t)0, n_envs);
+    return hipGetLastError();
+}
+
+hipError_t launch_state_observe(const MapHeader& h, const BatchPtrs& P, float* out, int normalize, int64_t n_envs, hipStream_t stream) {
+    const int64_t total = n_envs * (int64_t)(3 * h.A + h.G);
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(state_observe_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, P, out, normalize, n_envs);
+    return hipGetLastError();
+}
+
+hipError_t launch_avail(const MapHeader& h, const BatchPtrs& P, uint8_t* out, int walkable_lasers, int64_t n_envs, hipStream_t stream) {
+    const int64_t total = n_envs * (int64_t)h.A;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(avail_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, P, out, walkable_lasers, n_envs);
+    return hipGetLastError();
+}
+
+}  // namespace lle

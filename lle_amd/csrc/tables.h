@@ -59,6 +59,26 @@ static_assert(sizeof(MapHeader) % 16 == 0, "sections must stay 16-byte aligned")
 
 constexpr uint32_t MAP_MAGIC = 0x31454C4Cu;
 
+// Observation kinds (mirror include/lle_hip.h LLE_OBS_*; reference python/lle/observations.py:38-60)
+enum ObsKind : int {
+    OBS_LAYERED = 0, OBS_LAYERED_PADDED = 1, OBS_PERSPECTIVE = 2, OBS_PARTIAL = 3, OBS_STATE = 4, OBS_NORMALIZED_STATE = 5
+};
+
+// A "view": the tables of a layered-style observation with another channel layout (agent padding, agent-zero
+// perspective), compiled from the same map.  Blob = ViewHeader, dyn table, static template (same entry formats as
+// the map blob), padded to whole 1-KiB rows; the view kernel copies all of it to LDS.
+struct ViewHeader {
+    uint32_t magic;          // 'LLV1'
+    uint32_t A, L, H, W, HW, C;
+    uint32_t obs_bytes, obs_stride, n_chunks, D;
+    uint32_t off_dyn, off_template, blob_bytes;
+    uint32_t supported;      // 0: some laser colour has no layer (the reference raises IndexError)
+    uint32_t pad;
+    uint8_t agent_layer[MAX_AGENTS];  // layer that shows agent a
+};
+static_assert(sizeof(ViewHeader) % 16 == 0, "sections must stay 16-byte aligned");
+constexpr uint32_t VIEW_MAGIC = 0x31564C4Cu;
+
 // Agents per env record in the per-agent buffers (pos, avail, actions, events): the agent bound of the lane-per-env
 // kernel instantiation that serves the map, so that a record is a whole number of dwords.
 #if defined(__HIPCC__)

@@ -538,6 +538,23 @@ class World:
         torch.cuda.synchronize(b.device)
         return b.obs[0].cpu().numpy()
 
+    def observation(self, kind, param=0):
+        """Observation `kind` (lle_amd._capi.LLE_OBS_*) of the current state as a numpy array, from the GPU kernels of
+        observers.hip.  Raises IndexError where the reference does."""
+        import torch
+        b = self._batch
+        out = b.observe_as(kind, param)[0]
+        torch.cuda.synchronize(b.device)
+        return out.cpu().numpy()
+
+    def available_actions_mask(self, walkable_lasers=True):
+        """LLE.available_actions (python/lle/env/env.py:146-163): bool (n_agents, 5) in Action value order."""
+        import torch
+        b = self._batch
+        out = b.available_actions(walkable_lasers)[0]
+        torch.cuda.synchronize(b.device)
+        return out.cpu().numpy()
+
     # ---- copy / pickle (pyworld.rs:546-604): (world_string, state), restored through set_state
     def __getstate__(self):
         return (self.world_string, self.get_state())

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 _LIB = os.path.join(_HERE, "libhostsim.so")
 _SRCS = [os.path.join(_HERE, "hostsim.cpp"), os.path.join(_ROOT, "lle_amd", "csrc", "map_compile.cpp")]
-_DEPS = _SRCS + [os.path.join(_ROOT, "lle_amd", "csrc", f) for f in ("step_logic.hpp", "tables.h", "map_compile.hpp")]
+_DEPS = _SRCS + [os.path.join(_ROOT, "lle_amd", "csrc", f) for f in ("step_logic.hpp", "observers_logic.hpp", "tables.h", "map_compile.hpp")]
 
 
 def build():
@@ -35,6 +35,9 @@ def lib():
         L.hs_set_state.argtypes = [C.c_void_p]
         L.hs_observe.argtypes = [C.c_void_p]
         L.hs_set_source.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.hs_observe_as.restype = C.c_int
+        L.hs_observe_as.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.hs_available_actions.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.hs_buffer.restype = C.c_void_p
         L.hs_buffer.argtypes = [C.c_void_p, C.c_int]
         _lib = L
@@ -94,6 +97,28 @@ class SimBatch:
 
     def set_state(self):
         self.L.hs_set_state(self.h)
+
+    def observe_as(self, kind, param=0):
+        """Logical (unpadded) array of observation `kind` for every env, or None when the reference would raise
+        IndexError (a laser colour without a layer)."""
+        m, n = self.map, self.n
+        A, H, W, G = m.n_agents, m.height, m.width, m.n_gems
+        shape, dtype = {
+            _capi.LLE_OBS_LAYERED: ((n, 2 * A + 4, H, W), np.int8),
+            _capi.LLE_OBS_LAYERED_PADDED: ((n, 2 * (A + param) + 4, H, W), np.int8),
+            _capi.LLE_OBS_PERSPECTIVE: ((n, A, 2 * A + 4, H, W), np.int8),
+            _capi.LLE_OBS_PARTIAL: ((n, A, 2 * A + 3, param, param), np.int8),
+            _capi.LLE_OBS_STATE: ((n, 3 * A + G), np.float32),
+            _capi.LLE_OBS_NORMALIZED_STATE: ((n, 3 * A + G), np.float32),
+        }[kind]
+        out = np.zeros(shape, dtype)
+        rc = self.L.hs_observe_as(self.h, kind, param, out.ctypes.data)
+        return out if rc == 0 else None
+
+    def available_actions(self, walkable_lasers=True):
+        out = np.zeros((self.n, self.map.n_agents, 5), np.uint8)
+        self.L.hs_available_actions(self.h, int(walkable_lasers), out.ctypes.data)
+        return out.astype(bool)
 
     def set_source(self, laser_id, enabled=None, colour=None):
         self.L.hs_set_source(self.h, laser_id, -1 if enabled is None else int(enabled), -1 if colour is None else int(colour))

@@ -11,6 +11,7 @@
 
 #include "../../include/lle_hip.h"
 #include "../../lle_amd/csrc/map_compile.hpp"
+#include "../../lle_amd/csrc/observers_logic.hpp"
 #include "../../lle_amd/csrc/step_logic.hpp"
 
 using namespace lle;
@@ -208,6 +209,94 @@ void hs_set_source(hs_batch* b, int laser_id, int enabled, int agent_id) {
     b->map.compile();
     dispatch(b, M_SOURCES, 0, 0, 0, 0, nullptr, nullptr, old);
 }
+// ---- the other observation builders: the same per-element logic (observers_logic.hpp) and the same view tables
+// (Map::compile_view) as observers.hip, evaluated on the host.  Output is the unpadded logical array.
+static void view_rows(hs_batch* b, int kind, int param, int8_t* out, int64_t env_pitch, bool* supported) {
+    std::vector<uint8_t> blob = b->map.compile_view(kind, param);
+    ViewHeader v;
+    std::memcpy(&v, blob.data(), sizeof v);
+    *supported = v.supported != 0;
+    const uint64_t* dyn = reinterpret_cast<const uint64_t*>(blob.data() + v.off_dyn);
+    const int A = (int)v.A, L = (int)v.L;
+    for (int64_t env = 0; env < b->n; env++) {
+        std::vector<int8_t> row(blob.data() + v.off_template, blob.data() + v.off_template + v.obs_bytes);
+        for (uint32_t d = 0; d < v.D; d++) {  // same evaluation as write_observations (obs_stream.hpp)
+            const uint64_t e = dyn[d];
+            const uint32_t refs = (uint32_t)(e >> 28) & 3u, gem = (uint32_t)(e >> 50) & 63u;
+            const uint32_t r0 = (uint32_t)(e >> 30) & 0x3FFu, r1 = (uint32_t)(e >> 40) & 0x3FFu;
+            uint32_t lit = 0;
+            if (refs >= 1) lit |= (b->beams[env * (L ? L : 1) + (r0 & 31u)] >> (r0 >> 5)) & 1u;
+            if (refs >= 2) lit |= (b->beams[env * (L ? L : 1) + (r1 & 31u)] >> (r1 >> 5)) & 1u;
+            if (gem != NO_GEM) lit |= (~b->gems[env] >> gem) & 1u;
+            row[(uint32_t)e & 0xFFFFFu] = (int8_t)(lit ? 1 : (int32_t)(int8_t)(uint8_t)(e >> 20));
+        }
+        for (int a = 0; a < A; a++) row[(uint32_t)v.agent_layer[a] * v.HW + cell_of(b->pos[env * A + a], (int)v.W)] = 1;
+        std::memcpy(out + env * env_pitch, row.data(), v.obs_bytes);
+    }
+}
+
+int hs_observe_as(hs_batch* b, int kind, int param, void* out) {
+    const MapHeader& h = b->map.header;
+    const int A = (int)h.A, L = (int)h.L, G = (int)h.G;
+    bool ok = true;
+    ObsTables T;
+    T.cell_lay = reinterpret_cast<const uint64_t*>(b->map.blob.data() + h.off_cell_lay);
+    T.cell_meta = reinterpret_cast<const uint32_t*>(b->map.blob.data() + h.off_cell_meta);
+    T.beam_colour = h.beam_colour;
+    T.A = A; T.H = (int)h.H; T.W = (int)h.W;
+    switch (kind) {
+        case OBS_LAYERED:
+            view_rows(b, OBS_PERSPECTIVE, 0, static_cast<int8_t*>(out), (int64_t)h.obs_bytes, &ok);
+            break;
+        case OBS_LAYERED_PADDED:
+            view_rows(b, kind, param, static_cast<int8_t*>(out), (int64_t)(2 * (A + param) + 4) * h.HW, &ok);
+            break;
+        case OBS_PERSPECTIVE:
+            for (int k = 0; k < A; k++) {
+                bool okk = true;
+                view_rows(b, kind, k, static_cast<int8_t*>(out) + (int64_t)k * h.obs_bytes, (int64_t)A * h.obs_bytes, &okk);
+                ok = ok && okk;
+            }
+            break;
+        case OBS_PARTIAL: {
+            for (const Source& s : b->map.sources)
+                if (s.agent_id > A + 1) ok = false;
+            if (!ok) break;
+            const int k = param, row_bytes = A * (2 * A + 3) * k * k;
+            for (int64_t env = 0; env < b->n; env++) {
+                int8_t* row = static_cast<int8_t*>(out) + env * row_bytes;
+                for (int a = 0; a < A; a++)
+                    for (int w = 0; w < k * k; w++)
+                        partial_cell(T, &b->pos[env * A], b->gems[env], &b->beams[env * (L ? L : 1)], a, w / k, w % k, k, row);
+            }
+            break;
+        }
+        default: {
+            const int len = 3 * A + G;
+            for (int64_t env = 0; env < b->n; env++)
+                for (int e = 0; e < len; e++)
+                    static_cast<float*>(out)[env * len + e] = state_elem(A, G, (int)h.H, (int)h.W, &b->pos[env * A], b->gems[env],
+                                                                        (uint32_t)b->bits[env] & 0xFFFFu, e, kind == OBS_NORMALIZED_STATE);
+        }
+    }
+    return ok ? 0 : -1;
+}
+
+void hs_available_actions(hs_batch* b, int walkable_lasers, uint8_t* out) {
+    const MapHeader& h = b->map.header;
+    const int A = (int)h.A, L = (int)h.L;
+    ObsTables T;
+    T.cell_lay = reinterpret_cast<const uint64_t*>(b->map.blob.data() + h.off_cell_lay);
+    T.cell_meta = reinterpret_cast<const uint32_t*>(b->map.blob.data() + h.off_cell_meta);
+    T.beam_colour = h.beam_colour;
+    T.A = A; T.H = (int)h.H; T.W = (int)h.W;
+    for (int64_t env = 0; env < b->n; env++)
+        for (int a = 0; a < A; a++) {
+            const uint32_t m = avail_bools(T, &b->pos[env * A], &b->beams[env * (L ? L : 1)], a, b->avail[env * A + a], walkable_lasers != 0);
+            for (int act = 0; act < 5; act++) out[(env * A + a) * 5 + act] = (uint8_t)((m >> act) & 1u);
+        }
+}
+
 void* hs_buffer(hs_batch* b, int which) {
     switch (which) {
         case LLE_BUF_POS: return b->pos.data();

@@ -1,0 +1,187 @@
+"""The observation builders of observers.hip (layered-padded, perspective, partial k x k, state, availability bools)
+through the C ABI: the reference's own tests via the lle_amd generator classes, a differential against the oracle's
+restatement of python/lle/observations.py along random rollouts, and size-independent properties at 65 536 envs."""
+import numpy as np
+import pytest
+
+from oracle.levels import LEVELS
+from tests.kat_observers_runner import _Base, load_cases, run_case
+from tests.observer_checks import compare_all
+from tests.parity_util import EXTRA_MAPS
+
+pytestmark = pytest.mark.gpu
+
+MAPS = {f"level{k}": v for k, v in LEVELS.items()}
+MAPS.update(EXTRA_MAPS)
+CASES = load_cases()
+
+
+class GpuAdapter(_Base):
+    """The reference's calling convention on lle_amd: ObservationType(...).get_observation_generator(world).observe()."""
+
+    def __init__(self, case):
+        from lle_amd import World
+        self.w = World.level(case["level"]) if "level" in case else World(case["map"])
+        w = self.w
+        self.n_agents, self.n_gems, self.height, self.width = w.n_agents, w.n_gems, w.height, w.width
+
+    def reset(self):
+        self.w.reset()
+
+    def step(self, actions):
+        from lle_amd import Action
+        self.w.step([Action(a) for a in actions])
+
+    def get_state(self):
+        s = self.w.get_state()
+        return s.agents_positions, s.gems_collected, s.agents_alive
+
+    def _generator(self, kind, param):
+        from lle_amd.observations import LayeredPadded, ObservationType, PartialGenerator
+        if kind == "partial":
+            return PartialGenerator(self.w, param)
+        if kind == "layered-padded":
+            return LayeredPadded(self.w, param)
+        return ObservationType.from_str(kind).get_observation_generator(self.w)
+
+    def announced_shape(self, kind, param):
+        return self._generator(kind, param).shape
+
+    def observe(self, kind, param):
+        return self._generator(kind, param).observe()
+
+    def avail(self, walkable):
+        return self.w.available_actions_mask(walkable)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_gpu_observers_kat(case):
+    run_case(GpuAdapter, case)
+
+
+def _engine(bw):
+    import torch
+
+    def observe(kind, param):
+        try:
+            out = bw.observe_as(kind, param)
+        except IndexError:
+            return None
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+
+    def avail(walkable):
+        out = bw.available_actions(walkable)
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+
+    return observe, avail
+
+
+@pytest.mark.parametrize("name", list(MAPS))
+def test_observers_along_rollout(oracle_mod, name):
+    from lle_amd import BatchedWorld
+
+    text = MAPS[name]
+    n, steps = 200, 24  # ragged last wave of the 16-env-per-wave observer kernels
+    ob = oracle_mod.OracleBatch(text, n)
+    bw = BatchedWorld(text, n)
+    observe, avail = _engine(bw)
+    envs = list(range(0, n, 23)) + [n - 1]
+    compare_all(observe, avail, ob, envs, f"{name} after reset")
+    for t in range(steps):
+        auto_reset = t >= steps // 2
+        ob.step(None, auto_reset=auto_reset, seed=99, t=t, env_offset=3, want_obs=False)
+        bw.step(sample=True, auto_reset=auto_reset, seed=99, t=t, env_offset=3)
+        if t % 6 == 5:
+            compare_all(observe, avail, ob, envs, f"{name} t={t}")
+
+
+def test_observers_follow_source_updates(oracle_mod):
+    """Views are compiled from the sources' current colours: recolour / disable through the map, push, compare."""
+    from lle_amd import BatchedWorld
+
+    text = EXTRA_MAPS["nested"]
+    n = 64
+    ob = oracle_mod.OracleBatch(text, n)
+    bw = BatchedWorld(text, n)
+    observe, avail = _engine(bw)
+    for t in range(6):
+        ob.step(None, seed=5, t=t, want_obs=False)
+        bw.step(sample=True, seed=5, t=t)
+    for lid, kw in ((0, dict(colour=1)), (1, dict(enabled=False)), (0, dict(colour=3)), (1, dict(enabled=True, colour=5))):
+        for e in range(n):
+            ob.world(e).set_source(lid, **kw)
+        bw.map.set_source(lid, enabled=kw.get("enabled"), agent_id=kw.get("colour"))
+        bw.update_sources()
+        compare_all(observe, avail, ob, range(0, n, 9), f"nested after set_source({lid}, {kw})")
+
+
+def test_full_size_properties():
+    """65 536 level-6 envs: relations between the builders that hold for any state."""
+    import torch
+
+    from lle_amd import BatchedWorld, _capi
+
+    n = 65536
+    bw = BatchedWorld(LEVELS[6], n)
+    for t in range(12):
+        bw.step(sample=True, auto_reset=(t % 3 == 0), seed=3, t=t)
+    A, G, H, W = bw.map.n_agents, bw.map.n_gems, bw.map.height, bw.map.width
+    layered = bw.observe_as(_capi.LLE_OBS_LAYERED)
+    assert torch.equal(layered, bw.obs)                      # the view kernel reproduces the step kernel's tensor
+    persp = bw.observe_as(_capi.LLE_OBS_PERSPECTIVE)
+    assert persp.shape == (n, A, 2 * A + 4, H, W)
+    assert torch.equal(persp[:, 0], layered)
+    for k in range(1, A):
+        perm = list(range(2 * A + 4))
+        perm[0], perm[k] = perm[k], perm[0]
+        perm[A], perm[A + k] = perm[A + k], perm[A]
+        assert torch.equal(persp[:, k], layered[:, perm]), k
+    p = 2
+    padded = bw.observe_as(_capi.LLE_OBS_LAYERED_PADDED, p)
+    assert padded.shape == (n, 2 * (A + p) + 4, H, W)
+    assert torch.equal(padded[:, :A], layered[:, :A]) and torch.all(padded[:, A:A + p] == 0)
+    assert torch.equal(padded[:, A + p:2 * A + p], layered[:, A:2 * A]) and torch.all(padded[:, 2 * A + p:2 * (A + p)] == 0)
+    assert torch.equal(padded[:, 2 * (A + p):], layered[:, 2 * A:])
+    state = bw.observe_as(_capi.LLE_OBS_STATE)
+    assert state.shape == (n, 3 * A + G) and state.dtype == torch.float32
+    assert torch.equal(state[:, :2 * A].reshape(n, A, 2), bw.pos.to(torch.float32))
+    alive = ((bw.bits.unsqueeze(1) >> torch.arange(A, device="cuda")) & 1).to(torch.float32)
+    assert torch.equal(state[:, 2 * A + G:], alive)
+    norm = bw.observe_as(_capi.LLE_OBS_NORMALIZED_STATE)
+    dims = torch.tensor([H, W] * A, device="cuda", dtype=torch.float64)
+    assert torch.equal(norm[:, :2 * A], (state[:, :2 * A].to(torch.float64) / dims).to(torch.float32))
+    for k in (3, 7):
+        part = bw.observe_as(_capi.LLE_OBS_PARTIAL, k)
+        assert part.shape == (n, A, 2 * A + 3, k, k)
+        c = k // 2
+        for a in range(A):
+            assert torch.all(part[:, a, a, c, c] == 1)      # every agent is at the centre of its own window
+        # the window of agent a is the crop of the full map around it: compare the agent layers with the layered tensor
+        pos = bw.pos.to(torch.int64)
+        e = torch.arange(n, device="cuda")
+        for a in range(A):
+            for a2 in range(A):
+                di = pos[:, a2, 0] - pos[:, a, 0] + c
+                dj = pos[:, a2, 1] - pos[:, a, 1] + c
+                inside = (di >= 0) & (di < k) & (dj >= 0) & (dj < k)
+                assert torch.equal(part[:, a, a2].sum((-1, -2)).to(torch.int64), inside.to(torch.int64))
+                assert torch.all(part[e[inside], a, a2, di[inside], dj[inside]] == 1)
+    walk = bw.available_actions(True)
+    assert torch.equal(walk, ((bw.avail.unsqueeze(-1) >> torch.arange(5, device="cuda")) & 1).to(torch.bool))
+    strict = bw.available_actions(False)
+    assert torch.all(walk | ~strict)                          # the laser filter only removes actions
+
+
+def test_unsupported_colour_raises_index_error():
+    """A laser colour without a layer: IndexError like the reference (python/lle/observations.py:229, 259, 356)."""
+    from lle_amd import BatchedWorld, _capi
+
+    bw = BatchedWorld("S0 . X\nL7E . .", 8)
+    with pytest.raises(IndexError):
+        bw.observe_as(_capi.LLE_OBS_PARTIAL, 3)
+    with pytest.raises(IndexError):
+        bw.observe_as(_capi.LLE_OBS_LAYERED)
+    assert bw.observe_as(_capi.LLE_OBS_LAYERED_PADDED, 4).shape == (8, 14, 2, 3)  # 5 agent + 9 laser-and-fixed layers: colour 7 fits
+    assert bw.observe_as(_capi.LLE_OBS_STATE).shape == (8, 3)
