@@ -76,7 +76,9 @@ enum {
     /* 1..LLE_MAX_AGENTS: InvalidAction by agent (code - 1), lowest offending agent id */
     LLE_ENV_INVALID_WORLD_STATE = 0x40,
     LLE_ENV_OUT_OF_WORLD_POSITION = 0x41,
-    LLE_ENV_INVALID_AGENT_POSITION = 0x42
+    LLE_ENV_INVALID_AGENT_POSITION = 0x42,
+    LLE_ENV_INVALID_COLOUR = 0x43  /* lle_batch_set_sources: a colour >= n_agents ("Agent ID is greater than the number of
+                                      agents", pylaser_source.rs:108-112); the env's sources are left unchanged */
 };
 
 /* ================================================================== maps (host only)
@@ -140,6 +142,8 @@ enum {
     LLE_BUF_REQ_ALIVE, /* u16 [n] */
     LLE_BUF_REWARD,    /* u8  [n][4]      per-step (gems collected, exits, deaths, all agents arrived) of the last step:
                           the inputs of the reference's reward strategies (python/lle/env/reward_strategy.py:58-109) */
+    LLE_BUF_SRC_COLOUR,  /* u8  [n][L]     colour (agent_id) of every source of this env; valid after lle_batch_set_sources */
+    LLE_BUF_SRC_ENABLED, /* u32 [n]        bit l = source l of this env enabled;          valid after lle_batch_set_sources */
     LLE_BUF_COUNT
 };
 
@@ -214,6 +218,21 @@ int lle_batch_set_state(lle_batch* b, void* stream);
 /* Push the map's current source colours / enabled flags to the device tables and apply
  * LaserBeam::enable/disable (laser.rs:69-77) to the beam masks of every env; rewrites the observation. */
 int lle_batch_update_sources(lle_batch* b, const lle_map* map, void* stream);
+
+/* Per-ENVIRONMENT sources: what LLE.reset does with randomize_lasers (python/lle/env/env.py:198-200:
+ * `source.set_colour(random.randint(0, n_agents - 1))`) and LaserSource.enable / disable, for every env at once.
+ *   colours_dev  u8  [n_envs][L]  new colour of every source, or NULL (keep)   -> LaserBeam::set_agent_id (laser.rs:84-86)
+ *   enabled_dev  u32 [n_envs]     bit l = source l enabled, or NULL (keep)     -> LaserBeam::enable / disable where the
+ *                                 flag CHANGES (pylaser_source.rs:55-75): enable re-lights the whole beam, disable
+ *                                 clears it (laser.rs:69-77)
+ *   env_mask_dev u8  [n_envs] or NULL: envs to touch.
+ * A colour >= n_agents is refused per env (LLE_BUF_ERR = LLE_ENV_INVALID_COLOUR, sources unchanged); the start-crossing
+ * check of pylaser_source.rs:121-139 is a property of the map and stays with the caller.  Rewrites LLE_BUF_OBS.
+ * From the first call on the batch keeps colours and flags per env (LLE_BUF_SRC_*): reset, step (auto-reset restarts an
+ * env from ITS reset state), set_state and every observation builder use them; lle_batch_update_sources then
+ * broadcasts the map's sources to every env. */
+int lle_batch_set_sources(lle_batch* b, const uint8_t* colours_dev, const uint32_t* enabled_dev, const uint8_t* env_mask_dev,
+                          void* stream);
 
 /* Rebuild LLE_BUF_OBS from the current state. */
 int lle_batch_observe(lle_batch* b, void* stream);

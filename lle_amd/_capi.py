@@ -14,12 +14,13 @@ LIB_PATH = os.environ.get("LLE_HIP_LIB") or os.path.join(_HERE, "liblle_hip.so")
 # enum lle_hip.h
 (LLE_BUF_POS, LLE_BUF_BITS, LLE_BUF_GEMS, LLE_BUF_BEAMS, LLE_BUF_AVAIL, LLE_BUF_ACTIONS, LLE_BUF_ERR, LLE_BUF_EVCOUNT,
  LLE_BUF_EVENTS, LLE_BUF_DONE, LLE_BUF_OBS, LLE_BUF_STATS, LLE_BUF_REQ_POS, LLE_BUF_REQ_GEMS, LLE_BUF_REQ_ALIVE,
- LLE_BUF_REWARD, LLE_BUF_COUNT) = range(17)
+ LLE_BUF_REWARD, LLE_BUF_SRC_COLOUR, LLE_BUF_SRC_ENABLED, LLE_BUF_COUNT) = range(19)
 BUFFER_NAMES = ["pos", "bits", "gems", "beams", "avail", "actions", "err", "evcount", "events", "done", "obs", "stats",
-                "req_pos", "req_gems", "req_alive", "reward"]
+                "req_pos", "req_gems", "req_alive", "reward", "src_colour", "src_enabled"]
 LLE_POS_START, LLE_POS_EXIT, LLE_POS_WALL, LLE_POS_VOID, LLE_POS_GEM = range(5)
 LLE_STEP_SAMPLE_ACTIONS, LLE_STEP_AUTO_RESET, LLE_STEP_NO_OBS = 1, 2, 4
 LLE_ENV_INVALID_WORLD_STATE, LLE_ENV_OUT_OF_WORLD_POSITION, LLE_ENV_INVALID_AGENT_POSITION = 0x40, 0x41, 0x42
+LLE_ENV_INVALID_COLOUR = 0x43
 LLE_ERR_NO_DEVICE = -5
 LLE_ERR_UNSUPPORTED = -4
 (LLE_OBS_LAYERED, LLE_OBS_LAYERED_PADDED, LLE_OBS_PERSPECTIVE, LLE_OBS_PARTIAL, LLE_OBS_STATE,
@@ -38,7 +39,7 @@ EXPORTS = [
     "lle_batch_arena_bytes", "lle_batch_create", "lle_batch_free", "lle_batch_get_buffer", "lle_batch_n_envs",
     "lle_batch_reset", "lle_batch_step", "lle_batch_rollout", "lle_batch_set_state", "lle_batch_update_sources", "lle_batch_observe",
     "lle_batch_snapshot_bytes", "lle_batch_snapshot", "lle_batch_restore",
-    "lle_batch_obs_desc", "lle_batch_observe_as", "lle_batch_available_actions",
+    "lle_batch_set_sources", "lle_batch_obs_desc", "lle_batch_observe_as", "lle_batch_available_actions",
     "lle_batch_stats", "lle_batch_kernel_info", "lle_batch_set_envs_per_wave", "lle_batch_step_stamped",
 ]
 
@@ -141,6 +142,8 @@ def lib():
     L.lle_batch_update_sources.argtypes = [vp, vp, vp]
     L.lle_batch_observe.restype = i32
     L.lle_batch_observe.argtypes = [vp, vp]
+    L.lle_batch_set_sources.restype = i32
+    L.lle_batch_set_sources.argtypes = [vp, vp, vp, vp, vp]
     L.lle_batch_obs_desc.restype = i32
     L.lle_batch_obs_desc.argtypes = [vp, i32, i32, C.POINTER(ObsDesc)]
     L.lle_batch_observe_as.restype = i32

@@ -15,6 +15,7 @@ _TORCH_DTYPES = {
     "pos": torch.uint8, "bits": torch.int64, "gems": torch.int32, "beams": torch.int32, "avail": torch.uint8,
     "actions": torch.uint8, "err": torch.uint8, "evcount": torch.uint8, "events": torch.uint8, "done": torch.uint8,
     "obs": torch.int8, "stats": torch.int64, "req_pos": torch.uint8, "req_gems": torch.int32, "req_alive": torch.int16, "reward": torch.uint8,
+    "src_colour": torch.uint8, "src_enabled": torch.int32,
 }
 
 
@@ -185,6 +186,25 @@ class BatchedWorld:
     def update_sources(self):
         """Push self.map's current source colours / enabled flags to the device (LaserSource.enable/disable/set_colour)."""
         self._check(_capi.lib().lle_batch_update_sources(self.h, self.map.h, self._stream()))
+
+    def set_sources(self, colours=None, enabled=None, env_mask=None):
+        """Per-environment laser sources (LLE.reset with randomize_lasers, python/lle/env/env.py:198-200; LaserSource
+        enable / disable): colours u8 [n, L] and/or enabled masks i32 [n] (bit l = source l on), optionally only for the
+        envs with env_mask != 0.  An env given a colour >= n_agents is left unchanged with err = LLE_ENV_INVALID_COLOUR.
+        From the first call on `src_colour` / `src_enabled` hold each env's sources."""
+        cp = ep = mp = None
+        if colours is not None:
+            colours = colours.to(self.device, torch.uint8).contiguous()
+            assert colours.shape == (self.n_envs, self.map.n_sources)
+            cp = colours.data_ptr()
+        if enabled is not None:
+            enabled = enabled.to(self.device, torch.int32).contiguous()
+            assert enabled.shape == (self.n_envs,)
+            ep = enabled.data_ptr()
+        if env_mask is not None:
+            env_mask = env_mask.to(self.device, torch.uint8).contiguous()
+            mp = env_mask.data_ptr()
+        self._check(_capi.lib().lle_batch_set_sources(self.h, cp, ep, mp, self._stream()))
 
     def observe(self):
         self._check(_capi.lib().lle_batch_observe(self.h, self._stream()))

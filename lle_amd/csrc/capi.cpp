@@ -46,6 +46,7 @@ struct Layout {
     int64_t bytes[LLE_BUF_COUNT];
     int64_t off_tables;
     int64_t off_init;
+    int64_t off_env_init[5];  // per-env reset state (pos, bits, gems, beams, avail), used with per-env sources
     int64_t total;
     int64_t n_stat_blocks;
 };
@@ -73,15 +74,22 @@ Layout make_layout(const MapHeader& h, int64_t n) {
     sz[LLE_BUF_REQ_GEMS] = n_pad * 4;
     sz[LLE_BUF_REQ_ALIVE] = n_pad * 2;
     sz[LLE_BUF_REWARD] = n_pad * 4;
+    sz[LLE_BUF_SRC_COLOUR] = n_pad * src_stride_of((int)h.L);
+    sz[LLE_BUF_SRC_ENABLED] = n_pad * 4;
     int64_t off = 0;
     l.off_tables = off;
-    off = align_up(off + h.blob_capacity);
+    off = align_up(off + h.blob_capacity + h.ext_bytes);
     l.off_init = off;
     off = align_up(off + (int64_t)sizeof(InitRecord));
     for (int k = 0; k < LLE_BUF_COUNT; k++) {
         l.off[k] = off;
         l.bytes[k] = sz[k];
         off = align_up(off + sz[k]);
+    }
+    const int64_t init_sz[5] = {sz[LLE_BUF_POS], sz[LLE_BUF_BITS], sz[LLE_BUF_GEMS], sz[LLE_BUF_BEAMS], sz[LLE_BUF_AVAIL]};
+    for (int k = 0; k < 5; k++) {
+        l.off_env_init[k] = off;
+        off = align_up(off + init_sz[k]);
     }
     l.total = off;
     return l;
@@ -98,6 +106,7 @@ struct lle_batch {
     Layout layout;
     BatchPtrs ptrs;
     uint32_t envs_per_wave;
+    bool per_env_sources;  // lle_batch_set_sources was called: colours / enabled flags / reset state live per env
     // observation views (layered-padded / perspective): the map they are compiled from, and the device blobs compiled
     // so far, keyed by (kind, param); dropped when the sources change
     Map map;
@@ -240,12 +249,20 @@ static void bind_ptrs(lle_batch* b) {
     p.req_alive = reinterpret_cast<const uint16_t*>(base + l.off[LLE_BUF_REQ_ALIVE]);
     p.reward = reinterpret_cast<uint32_t*>(base + l.off[LLE_BUF_REWARD]);
     p.n_envs = b->n_envs;
+    p.src_colour = base + l.off[LLE_BUF_SRC_COLOUR];
+    p.src_enabled = reinterpret_cast<uint32_t*>(base + l.off[LLE_BUF_SRC_ENABLED]);
+    p.init_pos = reinterpret_cast<uint16_t*>(base + l.off_env_init[0]);
+    p.init_bits = reinterpret_cast<uint64_t*>(base + l.off_env_init[1]);
+    p.init_gems = reinterpret_cast<uint32_t*>(base + l.off_env_init[2]);
+    p.init_beams = reinterpret_cast<uint32_t*>(base + l.off_env_init[3]);
+    p.init_avail = base + l.off_env_init[4];
 }
 
 static int launch(lle_batch* b, int mode, LaunchArgs K, void* stream) {
     K.envs_per_wave = b->envs_per_wave;
     K.env_base = 0;
     K.env_limit = b->n_envs;
+    if (b->per_env_sources) K.flags |= LAUNCH_PER_ENV_SOURCES;
     if (mode == KMODE_STEP && !b->lane_per_env_step) {
         K.envs_per_wave = step_envs_per_wave(b->n_envs, (int)b->hdr.A);
         HIP_TRY(launch_step_kernel(b->hdr, b->ptrs, K, (hipStream_t)stream));
@@ -324,6 +341,7 @@ lle_batch* lle_batch_create(const lle_map* map, int64_t n_envs, int device_id, v
     b->arena = nullptr;
     b->owns_arena = false;
     b->lane_per_env_step = false;
+    b->per_env_sources = false;
     // enough waves to cover the 256 CUs several times over, at most 32 envs per wave (measured best on level 6)
     b->envs_per_wave = 32;
     while (b->envs_per_wave > MIN_ENVS_PER_WAVE && n_envs / b->envs_per_wave < 2048) b->envs_per_wave /= 2;
@@ -375,26 +393,47 @@ int lle_batch_get_buffer(const lle_batch* b, int which, lle_buffer_desc* out) {
         case LLE_BUF_STATS: set(8, 2, b->layout.n_stat_blocks, 8, 1, 8, 1, 1); break;
         case LLE_BUF_REQ_ALIVE: set(2, 1, n, 1, 1, 1, 1, 1); break;
         case LLE_BUF_REWARD: set(1, 2, n, 4, 1, 4, 1, 1); break;
+        case LLE_BUF_SRC_COLOUR: set(1, 2, n, L, 1, src_stride_of((int)L), 1, 1); break;
+        case LLE_BUF_SRC_ENABLED: set(4, 1, n, 1, 1, 1, 1, 1); break;
     }
     *out = d;
     return LLE_OK;
 }
 
-// the dynamic state is the contiguous arena range [pos, actions): pos, bits, gems, beams, avail
+// the dynamic state is the contiguous arena range [pos, actions): pos, bits, gems, beams, avail; followed in a snapshot
+// by the per-env sources and reset states (meaningful once lle_batch_set_sources has been called)
+static int64_t state_bytes(const lle_batch* b) { return b->layout.off[LLE_BUF_ACTIONS] - b->layout.off[LLE_BUF_POS]; }
+static int64_t sources_bytes(const lle_batch* b) { return b->layout.total - b->layout.off[LLE_BUF_SRC_COLOUR]; }
 int64_t lle_batch_snapshot_bytes(const lle_batch* b) {
     if (!b) return fail(LLE_ERR_NULL, "NULL batch");
-    return b->layout.off[LLE_BUF_ACTIONS] - b->layout.off[LLE_BUF_POS];
+    return state_bytes(b) + sources_bytes(b) + 256;
 }
 int lle_batch_snapshot(lle_batch* b, void* dst_dev, void* stream) {
     if (!b || !dst_dev) return fail(LLE_ERR_NULL, "NULL argument");
-    HIP_TRY(hipMemcpyAsync(dst_dev, b->arena + b->layout.off[LLE_BUF_POS], (size_t)lle_batch_snapshot_bytes(b), hipMemcpyDeviceToDevice,
+    uint8_t* dst = static_cast<uint8_t*>(dst_dev);
+    const uint64_t mode = b->per_env_sources ? 1 : 0;
+    HIP_TRY(hipMemcpyAsync(dst, &mode, 8, hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // `mode` is a stack variable
+    HIP_TRY(hipMemcpyAsync(dst + 256, b->arena + b->layout.off[LLE_BUF_POS], (size_t)state_bytes(b), hipMemcpyDeviceToDevice,
                            (hipStream_t)stream));
+    if (b->per_env_sources)
+        HIP_TRY(hipMemcpyAsync(dst + 256 + state_bytes(b), b->arena + b->layout.off[LLE_BUF_SRC_COLOUR], (size_t)sources_bytes(b),
+                               hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return LLE_OK;
 }
 int lle_batch_restore(lle_batch* b, const void* src_dev, void* stream) {
     if (!b || !src_dev) return fail(LLE_ERR_NULL, "NULL argument");
-    HIP_TRY(hipMemcpyAsync(b->arena + b->layout.off[LLE_BUF_POS], src_dev, (size_t)lle_batch_snapshot_bytes(b), hipMemcpyDeviceToDevice,
+    const uint8_t* src = static_cast<const uint8_t*>(src_dev);
+    uint64_t mode = 0;
+    HIP_TRY(hipMemcpyAsync(&mode, src, 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if ((mode != 0) != b->per_env_sources)
+        return fail(LLE_ERR_ARG, "snapshot and batch disagree on per-environment sources");
+    HIP_TRY(hipMemcpyAsync(b->arena + b->layout.off[LLE_BUF_POS], src + 256, (size_t)state_bytes(b), hipMemcpyDeviceToDevice,
                            (hipStream_t)stream));
+    if (b->per_env_sources)
+        HIP_TRY(hipMemcpyAsync(b->arena + b->layout.off[LLE_BUF_SRC_COLOUR], src + 256 + state_bytes(b), (size_t)sources_bytes(b),
+                               hipMemcpyDeviceToDevice, (hipStream_t)stream));
     LaunchArgs K{};
     return launch(b, KMODE_OBSERVE, K, stream);  // bring the observation in line with the restored state
 }
@@ -434,6 +473,27 @@ int lle_batch_set_state(lle_batch* b, void* stream) {
     if (!b) return fail(LLE_ERR_NULL, "NULL batch");
     LaunchArgs K{};
     return launch(b, KMODE_SET_STATE, K, stream);
+}
+
+int lle_batch_set_sources(lle_batch* b, const uint8_t* colours_dev, const uint32_t* enabled_dev, const uint8_t* env_mask_dev,
+                          void* stream) {
+    if (!b) return fail(LLE_ERR_NULL, "NULL batch");
+    HIP_TRY(hipSetDevice(b->device));
+    if (kernel_lds_bytes(b->hdr, 1, true) > 160 * 1024)
+        return fail(LLE_ERR_UNSUPPORTED, "map tables with per-environment sources exceed the LDS of a workgroup");
+    if (!b->per_env_sources) {
+        // first call: every env gets the map's sources and the shared reset state as its own
+        b->per_env_sources = true;
+        LaunchArgs K0{};
+        K0.flags = LAUNCH_FILL_DEFAULTS | LAUNCH_ARRAYS_INVALID;
+        int rc = launch(b, KMODE_ENV_SOURCES, K0, stream);
+        if (rc != LLE_OK) { b->per_env_sources = false; return rc; }
+    }
+    LaunchArgs K{};
+    K.colours_in = colours_dev;
+    K.enabled_in = enabled_dev;
+    K.env_mask = env_mask_dev;
+    return launch(b, KMODE_ENV_SOURCES, K, stream);
 }
 
 int lle_batch_observe(lle_batch* b, void* stream) {
@@ -542,6 +602,20 @@ int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64
     int rc = obs_desc(b, kind, param, &d);
     if (rc != LLE_OK) return rc;
     if (!d.supported) return fail(LLE_ERR_UNSUPPORTED, "a laser colour has no layer in this observation (the reference raises IndexError)");
+    if (b->per_env_sources && (kind == LLE_OBS_LAYERED_PADDED || kind == LLE_OBS_PERSPECTIVE))
+        return fail(LLE_ERR_UNSUPPORTED, "layered-padded / perspective are not built for batches with per-environment sources yet");
+    if (b->per_env_sources && kind == LLE_OBS_LAYERED) {  // the env-coloured layered writer of the world kernel, into `out_dev`
+        HIP_TRY(hipSetDevice(b->device));
+        BatchPtrs P = b->ptrs;
+        P.obs = static_cast<int8_t*>(out_dev);
+        LaunchArgs K{};
+        K.envs_per_wave = b->envs_per_wave;
+        K.env_limit = b->n_envs;
+        K.flags = LAUNCH_PER_ENV_SOURCES;
+        HIP_TRY(launch_world_kernel(KMODE_OBSERVE, b->hdr, P, K, (hipStream_t)stream));
+        g_status = LLE_OK;
+        return LLE_OK;
+    }
     if (out_bytes < d.bytes || (reinterpret_cast<uintptr_t>(out_dev) % 16) != 0)
         return fail(LLE_ERR_ARENA, "output buffer too small or not 16-byte aligned");
     HIP_TRY(hipSetDevice(b->device));
@@ -580,7 +654,7 @@ int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64
             break;
         }
         case LLE_OBS_PARTIAL:
-            HIP_TRY(launch_partial_observe(h, b->ptrs, static_cast<int8_t*>(out_dev), param, b->n_envs, st));
+            HIP_TRY(launch_partial_observe(h, b->ptrs, static_cast<int8_t*>(out_dev), param, b->n_envs, b->per_env_sources, st));
             break;
         default:
             HIP_TRY(launch_state_observe(h, b->ptrs, static_cast<float*>(out_dev), kind == LLE_OBS_NORMALIZED_STATE, b->n_envs, st));
@@ -593,7 +667,7 @@ int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64
 int lle_batch_available_actions(lle_batch* b, int walkable_lasers, uint8_t* out_dev, void* stream) {
     if (!b || !out_dev) return fail(LLE_ERR_NULL, "NULL argument");
     HIP_TRY(hipSetDevice(b->device));
-    HIP_TRY(launch_avail(b->hdr, b->ptrs, out_dev, walkable_lasers, b->n_envs, (hipStream_t)stream));
+    HIP_TRY(launch_avail(b->hdr, b->ptrs, out_dev, walkable_lasers, b->n_envs, b->per_env_sources, (hipStream_t)stream));
     g_status = LLE_OK;
     return LLE_OK;
 }
@@ -615,6 +689,10 @@ int lle_batch_update_sources(lle_batch* b, const lle_map* map, void* stream) {
     drop_views(b);  // their channel tables depend on the colours (the stream is idle: synchronised above)
     int rc = refresh_init_record(b, stream);
     if (rc != LLE_OK) return rc;
+    if (b->per_env_sources) {  // broadcast the map's sources to every env (enable / disable applied per env)
+        K.flags = LAUNCH_FILL_DEFAULTS;
+        return launch(b, KMODE_ENV_SOURCES, K, stream);
+    }
     return launch(b, KMODE_SOURCES, K, stream);
 }
 

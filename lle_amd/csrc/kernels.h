@@ -6,14 +6,14 @@
 
 namespace lle {
 
-enum { KMODE_STEP = 0, KMODE_RESET = 1, KMODE_SET_STATE = 2, KMODE_OBSERVE = 3, KMODE_SOURCES = 4 };
+enum { KMODE_STEP = 0, KMODE_RESET = 1, KMODE_SET_STATE = 2, KMODE_OBSERVE = 3, KMODE_SOURCES = 4, KMODE_ENV_SOURCES = 5 };
 constexpr uint32_t MIN_ENVS_PER_WAVE = 4;  // step_kernel<16, .>: 4 environments per wavefront
 
 int kernel_variant(int A, int L);
 int agent_stride(int A, int L);  // agents per env record in the per-agent buffers (= the variant's agent bound)
 const char* kernel_variant_name(int variant);
-uint32_t kernel_lds_bytes(const MapHeader& h, uint32_t waves_per_wg);
-uint32_t kernel_waves_per_wg(const MapHeader& h);
+uint32_t kernel_lds_bytes(const MapHeader& h, uint32_t waves_per_wg, bool pes = false);
+uint32_t kernel_waves_per_wg(const MapHeader& h, bool pes = false);
 hipError_t launch_world_kernel(int mode, const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K, hipStream_t stream);
 // World.step with one lane per agent (the default step path)
 hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K, hipStream_t stream);
@@ -26,8 +26,10 @@ hipError_t launch_view_observe(const ViewHeader& v, const BatchPtrs& P, const ui
                                int64_t row_pitch, int64_t view_pitch, int64_t n_envs, hipStream_t stream);
 bool view_kernel_fits(const ViewHeader& v, uint32_t n_views);  // do n_views views fit the LDS of one workgroup together?
 uint32_t partial_pitch(int A, int k);
-hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t* out, int k, int64_t n_envs, hipStream_t stream);
+hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t* out, int k, int64_t n_envs, bool per_env_sources,
+                                  hipStream_t stream);
 hipError_t launch_state_observe(const MapHeader& h, const BatchPtrs& P, float* out, int normalize, int64_t n_envs, hipStream_t stream);
-hipError_t launch_avail(const MapHeader& h, const BatchPtrs& P, uint8_t* out, int walkable_lasers, int64_t n_envs, hipStream_t stream);
+hipError_t launch_avail(const MapHeader& h, const BatchPtrs& P, uint8_t* out, int walkable_lasers, int64_t n_envs, bool per_env_sources,
+                        hipStream_t stream);
 
 }  // namespace lle

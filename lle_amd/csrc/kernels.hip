@@ -20,7 +20,7 @@
 
 namespace lle {
 
-enum Mode : int { MODE_STEP = 0, MODE_RESET = 1, MODE_SET_STATE = 2, MODE_OBSERVE = 3, MODE_SOURCES = 4 };
+enum Mode : int { MODE_STEP = 0, MODE_RESET = 1, MODE_SET_STATE = 2, MODE_OBSERVE = 3, MODE_SOURCES = 4, MODE_ENV_SOURCES = 5 };
 
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 #pragma unroll
@@ -104,6 +104,10 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
     LLE_STAMP(0);
     const uint32_t tab_bytes = hdr->lds_table_bytes, tab_off = hdr->off_cell_lay;
     copy_tables_to_lds(P.tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
+    // per-environment sources (lle_batch_set_sources): the bare static observation + element list follow in LDS
+    const bool pes = (K.flags & LAUNCH_PER_ENV_SOURCES) != 0;
+    const uint32_t ext_bytes = pes ? hdr->ext_bytes : 0u;
+    if (pes) copy_tables_to_lds(P.tables + hdr->off_bare, lds + tab_bytes, ext_bytes, lane, wave_in_wg, waves_per_wg);
     LLE_STAMP(7);
     __syncthreads();  // the only workgroup barrier: nothing is in flight yet but the loads above
     // ---- the env's packed state and (for auto-reset) the reset-state record, requested raw and together.  (Issued
@@ -130,17 +134,39 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
     }
     InitRecord init;
     if (MODE == MODE_STEP) init = *P.init;
+    const int CW = src_stride_of(L) / 4;  // colour words per env
+    uint32_t env_enabled = hdr->enabled_mask, colw[LM / 4];
+#pragma unroll
+    for (int q = 0; q < LM / 4; q++) colw[q] = 0;
+    if (pes && active && !(K.flags & LAUNCH_ARRAYS_INVALID)) {
+        env_enabled = P.src_enabled[env];
+#pragma unroll
+        for (int q = 0; q < LM / 4; q++)
+            if (q < CW) colw[q] = reinterpret_cast<const uint32_t*>(P.src_colour)[env * CW + q];
+        if (MODE == MODE_STEP && (K.flags & STEP_AUTO_RESET)) {  // the env's own reset state
+#pragma unroll
+            for (int a = 0; a < AM; a++)
+                if (a < A) { init.pos[a] = P.init_pos[env * AM + a]; init.avail[a] = P.init_avail[env * AM + a]; }
+            init.bits = P.init_bits[env];
+            init.gems = P.init_gems[env];
+#pragma unroll
+            for (int b = 0; b < LM; b++)
+                if (b < L) init.beams[b] = P.init_beams[env * L + b];
+        }
+    }
     const uint64_t* cell_lay = reinterpret_cast<const uint64_t*>(lds);
     const uint32_t* cell_meta = reinterpret_cast<const uint32_t*>(lds + (hdr->off_cell_meta - tab_off));
     const uint64_t* dyn = reinterpret_cast<const uint64_t*>(lds + (hdr->off_dyn - tab_off));
     // private to this wavefront: a patchable copy of the static observation and the phase-1 -> phase-2 hand-over
-    const uint32_t scr_stride = (uint32_t)(L + A + 2) | 1u;  // odd: lanes spread over banks
+    const uint32_t scr_stride = (uint32_t)(L + A + 2 + (pes ? CW : 0)) | 1u;  // odd: lanes spread over banks
     const uint32_t priv_bytes = hdr->obs_stride + 64u * scr_stride * 4u;
-    int8_t* tmpl = reinterpret_cast<int8_t*>(lds + tab_bytes + wave_in_wg * priv_bytes);
+    int8_t* tmpl = reinterpret_cast<int8_t*>(lds + tab_bytes + ext_bytes + wave_in_wg * priv_bytes);
+    const int8_t* bare = reinterpret_cast<const int8_t*>(lds + tab_bytes);
+    const uint32_t* elems = reinterpret_cast<const uint32_t*>(lds + tab_bytes + (hdr->off_elems - hdr->off_bare));
     uint32_t* scratch = reinterpret_cast<uint32_t*>(tmpl + hdr->obs_stride);
     const uint64_t obs_stride = hdr->obs_stride;
     {
-        const uint4* pristine = reinterpret_cast<const uint4*>(lds + (hdr->off_template - tab_off));
+        const uint4* pristine = pes ? reinterpret_cast<const uint4*>(bare) : reinterpret_cast<const uint4*>(lds + (hdr->off_template - tab_off));
         uint4* mine = reinterpret_cast<uint4*>(tmpl);
         for (uint32_t c = lane; c < hdr->n_chunks; c += 64) mine[c] = pristine[c];
     }
@@ -159,7 +185,10 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
     MapView mv;
     mv.cell_lay = cell_lay; mv.cell_meta = cell_meta; mv.hdr = hdr;
     mv.W = (int)hdr->W; mv.A = A; mv.L = L; mv.G = (int)hdr->G;
-    mv.enabled = hdr->enabled_mask; mv.max_layers = hdr->max_layers;
+    mv.enabled = env_enabled; mv.max_layers = hdr->max_layers;
+    mv.per_env = pes;
+#pragma unroll
+    for (int q = 0; q < MAX_SOURCES / 4; q++) mv.colw[q] = q < LM / 4 ? colw[q < LM / 4 ? q : 0] : 0u;
     const uint32_t amask = (1u << A) - 1u;
     StepCounts cnt = {0, 0, 0, 0, 0, 0, 0};  // per-env counters, summed over the wave at the end
 
@@ -270,6 +299,61 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
                     if (!was && now) s.beams[b] = hdr->beam_full[b];
                 }
             }
+        } else if (MODE == MODE_ENV_SOURCES) {
+            // LaserSource.set_colour / enable / disable for this env (pylaser_source.rs:55-75,107-142; laser.rs:69-86)
+            // and the env's reset state with the new sources (copied by the auto-reset path of the step kernel)
+            const bool fill = (K.flags & LAUNCH_FILL_DEFAULTS) != 0;
+            if (!K.env_mask || K.env_mask[env]) {
+                uint32_t new_en = fill ? hdr->enabled_mask : (K.enabled_in ? K.enabled_in[env] : mv.enabled);
+                new_en &= L >= 32 ? 0xFFFFFFFFu : ((1u << L) - 1u);
+                uint32_t ncol[LM / 4];
+#pragma unroll
+                for (int q = 0; q < LM / 4; q++) ncol[q] = colw[q];
+                bool bad = false;
+#pragma unroll
+                for (int b = 0; b < LM; b++) {
+                    if (b < L && (fill || K.colours_in)) {
+                        const uint32_t c = fill ? (uint32_t)hdr->beam_colour[b] : (uint32_t)K.colours_in[env * L + b];
+                        bad |= !fill && c >= (uint32_t)A;  // "Agent ID is greater than the number of agents"
+                        ncol[b >> 2] = (ncol[b >> 2] & ~(0xFFu << ((b & 3) * 8))) | ((c & 0xFFu) << ((b & 3) * 8));
+                    }
+                }
+                err = bad ? ENV_INVALID_COLOUR : 0u;
+                if (!bad) {
+#pragma unroll
+                    for (int b = 0; b < LM; b++) {
+                        if (b < L) {
+                            const bool was = (mv.enabled >> b) & 1u, now = (new_en >> b) & 1u;
+                            if (was && !now) s.beams[b] = 0u;
+                            if (!was && now) s.beams[b] = hdr->beam_full[b];
+                        }
+                    }
+                    mv.enabled = new_en;
+#pragma unroll
+                    for (int q = 0; q < LM / 4; q++) { mv.colw[q] = ncol[q]; colw[q] = ncol[q]; }
+                    P.src_enabled[env] = new_en;
+#pragma unroll
+                    for (int q = 0; q < LM / 4; q++)
+                        if (q < CW) reinterpret_cast<uint32_t*>(P.src_colour)[env * CW + q] = ncol[q];
+                    Env<AM, LM> r = s;
+                    uint32_t ravail[AM];
+                    Cells<AM> at;
+                    reset_env<AM, LM>(r, mv, at);
+                    compute_avail<AM, LM>(r, mv, at, ravail);
+                    store_u16_record<AM>(P.init_pos, env, r.pos);
+                    store_u8_record<AM>(P.init_avail, env, ravail);
+                    P.init_bits[env] = (uint64_t)r.alive | ((uint64_t)r.arrived << 16) | ((uint64_t)r.occ << 32);
+                    P.init_gems[env] = r.gems;
+#pragma unroll
+                    for (int b = 0; b < LM; b++)
+                        if (b < L) P.init_beams[env * L + b] = r.beams[b];
+                } else {
+                    store_state = false;
+                }
+                P.err[env] = (uint8_t)err;
+            } else {
+                store_state = false;
+            }
         } else {
             store_state = false;
         }
@@ -306,6 +390,12 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
         for (int a = 0; a < AM; a++)
             if (a < A) sc[L + 2 + a] = (uint32_t)a * hdr->HW + cell_of(s.pos[a], mv.W);
 
+        if (pes) {
+#pragma unroll
+            for (int q = 0; q < LM / 4; q++)
+                if (q < CW) sc[L + 2 + A + q] = colw[q];
+        }
+
         if (MODE == MODE_STEP) {
             // event bytes are type << 4 | agent: DIED sets bit 5, GEM bit 4, EXIT neither
             uint32_t n_died = 0, n_gem = 0;
@@ -324,8 +414,13 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
 
     LLE_STAMP(4);
     // ---- phase 2: layered observation, one environment of the wave at a time
-    if (write_obs && n_here > 0)
-        write_observations(A, L, hdr->D, hdr->n_chunks, hdr->obs_stride, dyn, tmpl, scratch, scr_stride, P.obs, env0, n_here, lane);
+    if (write_obs && n_here > 0) {
+        if (pes)
+            write_observations_env(A, L, hdr->HW, hdr->n_elems, hdr->n_chunks, hdr->obs_stride, elems, bare, tmpl, scratch, scr_stride,
+                                   P.obs, env0, n_here, lane);
+        else
+            write_observations(A, L, hdr->D, hdr->n_chunks, hdr->obs_stride, dyn, tmpl, scratch, scr_stride, P.obs, env0, n_here, lane);
+    }
     LLE_STAMP(5);
     if (MODE == MODE_STEP) flush_stats(P.stats, wave_id, cnt, A, lane);
 
@@ -384,7 +479,9 @@ __device__ __forceinline__ void for_each_other(uint32_t v, F&& f) {
     }
 }
 
-template <int G, int LM>
+// PES: every environment has its own source colours / enabled flags (lle_batch_set_sources) -- a separate instantiation,
+// so the default path is compiled exactly as before.
+template <int G, int LM, bool PES>
 __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K) {
     // environments per wavefront: at most 64 / G; fewer (lanes left idle) when the batch is small, so that there
     // are enough wavefronts to spread phase 2 over the chip
@@ -408,6 +505,8 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
 
     const uint32_t tab_bytes = hdr->lds_table_bytes, tab_off = hdr->off_cell_lay;
     copy_tables_to_lds(P.tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
+    const uint32_t ext_bytes = PES ? hdr->ext_bytes : 0u;
+    if (PES) copy_tables_to_lds(P.tables + hdr->off_bare, lds + tab_bytes, ext_bytes, lane, wave_in_wg, waves_per_wg);
     LLE_STAMP(7);
     __syncthreads();  // the only workgroup barrier
 
@@ -428,18 +527,36 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
         pos = (uint32_t)P.pos[env * As + a];
         avail = (uint32_t)P.avail[env * As + a];
     }
-    const uint64_t init_bits = P.init->bits;
-    const uint32_t init_gems = P.init->gems;
+    uint64_t init_bits = P.init->bits;
+    uint32_t init_gems = P.init->gems;
+    // per-environment sources: colours (4 per word), enabled mask, and the env's own reset state
+    constexpr int CWM = LM / 4;
+    const int CW = src_stride_of(L) / 4;
+    uint32_t colw[CWM], env_enabled = hdr->enabled_mask;
+#pragma unroll
+    for (int q = 0; q < CWM; q++) colw[q] = 0;
+    if (PES && env_ok) {
+        env_enabled = P.src_enabled[env];
+#pragma unroll
+        for (int q = 0; q < CWM; q++)
+            if (q < CW) colw[q] = reinterpret_cast<const uint32_t*>(P.src_colour)[env * CW + q];
+        if (K.flags & STEP_AUTO_RESET) {
+            init_bits = P.init_bits[env];
+            init_gems = P.init_gems[env];
+        }
+    }
 
     const uint64_t* cell_lay = reinterpret_cast<const uint64_t*>(lds);
     const uint32_t* cell_meta = reinterpret_cast<const uint32_t*>(lds + (hdr->off_cell_meta - tab_off));
     const uint64_t* dyn = reinterpret_cast<const uint64_t*>(lds + (hdr->off_dyn - tab_off));
-    const uint32_t scr_stride = (uint32_t)(L + A + 2) | 1u;
+    const uint32_t scr_stride = (uint32_t)(L + A + 2 + (PES ? CW : 0)) | 1u;
     const uint32_t priv_bytes = hdr->obs_stride + 64u * scr_stride * 4u;
-    int8_t* tmpl = reinterpret_cast<int8_t*>(lds + tab_bytes + wave_in_wg * priv_bytes);
+    int8_t* tmpl = reinterpret_cast<int8_t*>(lds + tab_bytes + ext_bytes + wave_in_wg * priv_bytes);
     uint32_t* scratch = reinterpret_cast<uint32_t*>(tmpl + hdr->obs_stride);
+    const int8_t* bare = reinterpret_cast<const int8_t*>(lds + tab_bytes);
+    const uint32_t* elems = reinterpret_cast<const uint32_t*>(lds + tab_bytes + (hdr->off_elems - hdr->off_bare));
     {
-        const uint4* pristine = reinterpret_cast<const uint4*>(lds + (hdr->off_template - tab_off));
+        const uint4* pristine = PES ? reinterpret_cast<const uint4*>(bare) : reinterpret_cast<const uint4*>(lds + (hdr->off_template - tab_off));
         uint4* mine = reinterpret_cast<uint4*>(tmpl);
         for (uint32_t c = lane; c < hdr->n_chunks; c += 64) mine[c] = pristine[c];
     }
@@ -447,7 +564,7 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
     LLE_STAMP(1);
 
     uint32_t alive = (uint32_t)raw_bits & 0xFFFFu, arrived = (uint32_t)(raw_bits >> 16) & 0xFFFFu, occ = (uint32_t)(raw_bits >> 32) & 0xFFFFu;
-    const uint32_t enabled = hdr->enabled_mask, max_layers = hdr->max_layers;
+    const uint32_t enabled = PES ? env_enabled : hdr->enabled_mask, max_layers = hdr->max_layers;
     LLE_STAMP(2);
 
     // ---- n_steps consecutive steps of the wave's environments; the state stays in registers in between.
@@ -465,7 +582,11 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
     uint32_t was_reset = 0;
     if (K.flags & STEP_AUTO_RESET) {
         const bool over = env_ok && (alive != amask || arrived == amask);
-        const uint32_t ipos = me ? (uint32_t)P.init->pos[a] : pos, iav = me ? (uint32_t)P.init->avail[a] : avail;
+        uint32_t ipos = pos, iav = avail;
+        if (me) {
+            ipos = PES ? (uint32_t)P.init_pos[env * As + a] : (uint32_t)P.init->pos[a];
+            iav = PES ? (uint32_t)P.init_avail[env * As + a] : (uint32_t)P.init->avail[a];
+        }
         pos = over ? ipos : pos;
         avail = over ? iav : avail;
         alive = over ? ((uint32_t)init_bits & 0xFFFFu) : alive;
@@ -474,7 +595,7 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
         gems = over ? init_gems : gems;
 #pragma unroll
         for (int b = 0; b < LM; b++)
-            if (b < L) beams[b] = over ? P.init->beams[b] : beams[b];
+            if (b < L) beams[b] = over ? (PES ? P.init_beams[env_ok ? env * L + b : 0] : P.init->beams[b]) : beams[b];
         was_reset = over ? 1u : 0u;
     }
 
@@ -497,7 +618,8 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
     // ---- availability check (world.rs:444-453): lowest offending agent, before any mutation.  The cached list can
     // only disagree with the static walk mask after a failed set_state left it stale; such an action is refused.
     const uint32_t cur_cell = me ? cell_of(pos, W) : 0u;
-    const uint64_t lay_cur = cell_lay[cur_cell];
+    uint64_t lay_cur = cell_lay[cur_cell];
+    if (PES) lay_cur = recolour_lay<CWM>(lay_cur, colw);
     const uint32_t meta_cur = cell_meta[cur_cell];
     const uint32_t walk_cur = ((meta_cur >> 8) & 15u) | 16u;
     const bool bad = me && (act > 4u || !(((avail & walk_cur) >> (act & 7u)) & 1u));
@@ -522,7 +644,8 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
             again = grp_or<G>(dup ? 1u : 0u) != 0;
         }
         const uint32_t new_cell = me ? cell_of(np, W) : 0u;
-        const uint64_t lay_new = cell_lay[new_cell];
+        uint64_t lay_new = cell_lay[new_cell];
+        if (PES) lay_new = recolour_lay<CWM>(lay_new, colw);
         const uint32_t meta_new = cell_meta[new_cell];
         meta_fin = meta_new;
         const uint32_t kind = meta_new & 7u;
@@ -638,12 +761,23 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
         for (int b = 0; b < LM; b++)
             if (b < L) sc[1 + b] = beams[b];
         sc[L + 1] = ~gems;
+        if (PES) {
+#pragma unroll
+            for (int q = 0; q < CWM; q++)
+                if (q < CW) sc[L + 2 + A + q] = colw[q];
+        }
     }
     if (me) scratch[grp * scr_stride + L + 2 + a] = a * hdr->HW + cell_of(pos, W);  // ... | byte index of each agent]
     wave_sync();
     LLE_STAMP(4);
 
-    if (write_obs && n_here > 0) write_observations(A, L, hdr->D, hdr->n_chunks, hdr->obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane);
+    if (write_obs && n_here > 0) {
+        if (PES)
+            write_observations_env(A, L, hdr->HW, hdr->n_elems, hdr->n_chunks, hdr->obs_stride, elems, bare, tmpl, scratch, scr_stride,
+                                   obs_out, env0, n_here, lane);
+        else
+            write_observations(A, L, hdr->D, hdr->n_chunks, hdr->obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane);
+    }
     wave_sync();
     }  // steps
     LLE_STAMP(5);
@@ -674,13 +808,14 @@ static hipError_t launch_mode(int mode, const BatchPtrs& P, const LaunchArgs& K,
                               uint32_t waves_per_wg, uint32_t lds_bytes, hipStream_t stream) {
     dim3 grid((n_waves + waves_per_wg - 1) / waves_per_wg), block(64 * waves_per_wg);
     if (lds_bytes > 64 * 1024) {
-        static uint32_t granted[5] = {0, 0, 0, 0, 0};
-        if (mode >= 0 && mode < 5 && lds_bytes > granted[mode]) {
+        static uint32_t granted[6] = {0, 0, 0, 0, 0, 0};
+        if (mode >= 0 && mode < 6 && lds_bytes > granted[mode]) {
             const void* fn = mode == MODE_STEP ? reinterpret_cast<const void*>(&world_kernel<AM, LM, MODE_STEP>)
                            : mode == MODE_RESET ? reinterpret_cast<const void*>(&world_kernel<AM, LM, MODE_RESET>)
                            : mode == MODE_SET_STATE ? reinterpret_cast<const void*>(&world_kernel<AM, LM, MODE_SET_STATE>)
                            : mode == MODE_OBSERVE ? reinterpret_cast<const void*>(&world_kernel<AM, LM, MODE_OBSERVE>)
-                                                  : reinterpret_cast<const void*>(&world_kernel<AM, LM, MODE_SOURCES>);
+                           : mode == MODE_SOURCES ? reinterpret_cast<const void*>(&world_kernel<AM, LM, MODE_SOURCES>)
+                                                  : reinterpret_cast<const void*>(&world_kernel<AM, LM, MODE_ENV_SOURCES>);
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             if (e != hipSuccess) return e;
             granted[mode] = lds_bytes;
@@ -692,6 +827,7 @@ static hipError_t launch_mode(int mode, const BatchPtrs& P, const LaunchArgs& K,
         case MODE_SET_STATE: hipLaunchKernelGGL((world_kernel<AM, LM, MODE_SET_STATE>), grid, block, lds_bytes, stream, P, K); break;
         case MODE_OBSERVE: hipLaunchKernelGGL((world_kernel<AM, LM, MODE_OBSERVE>), grid, block, lds_bytes, stream, P, K); break;
         case MODE_SOURCES: hipLaunchKernelGGL((world_kernel<AM, LM, MODE_SOURCES>), grid, block, lds_bytes, stream, P, K); break;
+        case MODE_ENV_SOURCES: hipLaunchKernelGGL((world_kernel<AM, LM, MODE_ENV_SOURCES>), grid, block, lds_bytes, stream, P, K); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -711,25 +847,27 @@ const char* kernel_variant_name(int variant) {
     return names[variant & 3];
 }
 
-uint32_t kernel_lds_bytes(const MapHeader& h, uint32_t waves_per_wg) {
-    const uint32_t scr_stride = (h.L + h.A + 2) | 1u;
-    return h.lds_table_bytes + waves_per_wg * (h.obs_stride + 64 * scr_stride * 4) + 64;
+// `pes`: per-environment sources (the second table section in LDS, colour words in the hand-over records)
+uint32_t kernel_lds_bytes(const MapHeader& h, uint32_t waves_per_wg, bool pes) {
+    const uint32_t scr_stride = (h.L + h.A + 2 + (pes ? (uint32_t)src_stride_of((int)h.L) / 4u : 0u)) | 1u;
+    return h.lds_table_bytes + (pes ? h.ext_bytes : 0u) + waves_per_wg * (h.obs_stride + 64 * scr_stride * 4) + 64;
 }
 
 // wavefronts per workgroup: four when that fits a CU's LDS twice over (two workgroups per CU), else as many (4, 2, 1)
 // as fit the 160 KiB at all
 constexpr uint32_t LDS_PER_CU = 160 * 1024;
-uint32_t kernel_waves_per_wg(const MapHeader& h) {
+uint32_t kernel_waves_per_wg(const MapHeader& h, bool pes) {
     for (uint32_t w = 4; w > 1; w >>= 1)
-        if (kernel_lds_bytes(h, w) <= LDS_PER_CU) return w;
+        if (kernel_lds_bytes(h, w, pes) <= LDS_PER_CU) return w;
     return 1;
 }
 
 hipError_t launch_world_kernel(int mode, const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K, hipStream_t stream) {
     const uint32_t epw = K.envs_per_wave;
     const uint32_t n_waves = (uint32_t)((K.env_limit - K.env_base + epw - 1) / epw);
-    const uint32_t wpw = kernel_waves_per_wg(h);
-    const uint32_t lds = kernel_lds_bytes(h, wpw);
+    const bool pes = (K.flags & LAUNCH_PER_ENV_SOURCES) != 0;
+    const uint32_t wpw = kernel_waves_per_wg(h, pes);
+    const uint32_t lds = kernel_lds_bytes(h, wpw, pes);
     switch (kernel_variant((int)h.A, (int)h.L)) {
         case 0: return launch_mode<4, 4>(mode, P, K, h, n_waves, wpw, lds, stream);
         case 1: return launch_mode<8, 8>(mode, P, K, h, n_waves, wpw, lds, stream);
@@ -742,19 +880,24 @@ hipError_t launch_world_kernel(int mode, const MapHeader& h, const BatchPtrs& P,
 int step_group(int A) { return A <= 1 ? 1 : (A <= 2 ? 2 : (A <= 4 ? 4 : (A <= 8 ? 8 : 16))); }
 int step_lm(int L) { return L <= 4 ? 4 : (L <= 8 ? 8 : (L <= 16 ? 16 : 32)); }
 
-template <int G, int LM>
-static hipError_t launch_step_gl(const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
+template <int G, int LM, bool PES>
+static hipError_t launch_step_glp(const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
     dim3 grid((n_waves + wpw - 1) / wpw), block(64 * wpw);
     if (lds > 64 * 1024) {  // gfx950 has 160 KiB of LDS per CU; more than 64 KiB per workgroup is opt-in
         static uint32_t granted = 0;
         if (lds > granted) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<G, LM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<G, LM, PES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             granted = lds;
         }
     }
-    hipLaunchKernelGGL((step_kernel<G, LM>), grid, block, lds, stream, P, K);
+    hipLaunchKernelGGL((step_kernel<G, LM, PES>), grid, block, lds, stream, P, K);
     return hipGetLastError();
+}
+template <int G, int LM>
+static hipError_t launch_step_gl(const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
+    return (K.flags & LAUNCH_PER_ENV_SOURCES) ? launch_step_glp<G, LM, true>(P, K, n_waves, wpw, lds, stream)
+                                              : launch_step_glp<G, LM, false>(P, K, n_waves, wpw, lds, stream);
 }
 template <int G>
 static hipError_t launch_step_g(int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
@@ -782,8 +925,9 @@ hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const Laun
     const int G = step_group((int)h.A), lm = step_lm((int)h.L);
     const uint32_t epw = K.envs_per_wave;
     const uint32_t n_waves = (uint32_t)((K.env_limit - K.env_base + epw - 1) / epw);
-    const uint32_t wpw = kernel_waves_per_wg(h);
-    const uint32_t lds = kernel_lds_bytes(h, wpw);
+    const bool pes = (K.flags & LAUNCH_PER_ENV_SOURCES) != 0;
+    const uint32_t wpw = kernel_waves_per_wg(h, pes);
+    const uint32_t lds = kernel_lds_bytes(h, wpw, pes);
     switch (G) {
         case 1: return launch_step_g<1>(lm, P, K, n_waves, wpw, lds, stream);
         case 2: return launch_step_g<2>(lm, P, K, n_waves, wpw, lds, stream);

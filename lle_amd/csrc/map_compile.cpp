@@ -437,7 +437,29 @@ void Map::compile() {
         h.blob_capacity = (uint32_t)(h.off_cell_lay + ((cap - h.off_cell_lay + 1023) & ~(size_t)1023));
     }
     h.lds_table_bytes = h.blob_bytes - h.off_cell_lay;
+    // ---- second section (per-environment sources), at an offset that does not depend on the colours
+    std::vector<int8_t> bare(h.obs_stride, 0);
+    {
+        auto bat = [&](int layer, Pos q) -> int8_t& { return bare[(size_t)layer * HW + q.i * W + q.j]; };
+        for (auto& q : walls) bat(2 * A, q) = 1;
+        for (auto& q : voids) bat(2 * A + 1, q) = 1;
+        for (auto& q : exits) bat(2 * A + 3, q) = 1;
+    }
+    std::vector<uint32_t> elems;
+    for (auto& s : sources) elems.push_back((uint32_t)(s.pos.i * W + s.pos.j) | ((uint32_t)s.laser_id << 16) | (ELEM_SOURCE << 26));
+    for (int c = 0; c < HW; c++)
+        for (size_t k = 0; k < cell_layers[c].size() && k < 2; k++)
+            elems.push_back((uint32_t)c | ((uint32_t)cell_layers[c][k].laser_id << 16) | ((uint32_t)cell_layers[c][k].offset << 21) |
+                            (ELEM_TILE << 26));
+    for (int g = 0; g < G; g++) elems.push_back((uint32_t)(gems[g].i * W + gems[g].j) | ((uint32_t)g << 16) | (ELEM_GEM << 26));
+    h.off_bare = h.blob_capacity;
+    h.off_elems = h.off_bare + h.obs_stride;
+    h.n_elems = (uint32_t)elems.size();
+    h.ext_bytes = (h.obs_stride + h.n_elems * 4u + 1023u) & ~1023u;
+    off = (size_t)h.blob_capacity + h.ext_bytes;
     blob.assign(off, 0);
+    std::memcpy(blob.data() + h.off_bare, bare.data(), bare.size());
+    if (!elems.empty()) std::memcpy(blob.data() + h.off_elems, elems.data(), elems.size() * 4);
     std::memcpy(blob.data() + h.off_cell_lay, cell_lay.data(), cell_lay.size() * 8);
     std::memcpy(blob.data() + h.off_cell_meta, cell_meta.data(), cell_meta.size() * 4);
     if (!dyn_tab.empty()) std::memcpy(blob.data() + h.off_dyn, dyn_tab.data(), dyn_tab.size() * 8);

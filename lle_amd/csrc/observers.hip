@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(256) view_observe_kernel(BatchPtrs P, const ui
 // Per environment the wave clears its row with 16-byte LDS stores, every lane evaluates its window cells (only
 // non-zero bytes are written), and the row is streamed as 16 B per lane.
 __global__ void __launch_bounds__(256) partial_observe_kernel(BatchPtrs P, int8_t* __restrict__ out, int k, uint32_t pitch,
-                                                              int64_t env_base, int64_t env_limit) {
+                                                              int64_t env_base, int64_t env_limit, int per_env_sources) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const MapHeader* __restrict__ hdr = reinterpret_cast<const MapHeader*>(P.tables);
     const uint32_t lane = threadIdx.x & 63u, wave_in_wg = threadIdx.x >> 6, waves_per_wg = blockDim.x >> 6;
@@ -142,6 +142,7 @@ __global__ void __launch_bounds__(256) partial_observe_kernel(BatchPtrs P, int8_
         const uint16_t* pos = reinterpret_cast<const uint16_t*>(rec);
         const uint32_t gems = rec[As / 2];
         const uint32_t* beams = rec + As / 2 + 1;
+        if (per_env_sources) T.beam_colour = P.src_colour + (env0 + e) * src_stride_of(L);  // this env's colours
         for (uint32_t c = lane; c < n_chunks; c += 64) row16[c] = make_uint4(0u, 0u, 0u, 0u);
         wave_sync();  // LDS operations of a wave execute in order: the byte writes below land after the clears
         for (uint32_t u = lane; u < units; u += 64) {
@@ -169,7 +170,8 @@ __global__ void __launch_bounds__(256) state_observe_kernel(BatchPtrs P, float* 
 }
 
 // ---------------------------------------------------------------------------------------------- availability bools
-__global__ void __launch_bounds__(256) avail_kernel(BatchPtrs P, uint8_t* __restrict__ out, int walkable_lasers, int64_t n_envs) {
+__global__ void __launch_bounds__(256) avail_kernel(BatchPtrs P, uint8_t* __restrict__ out, int walkable_lasers, int64_t n_envs,
+                                                    int per_env_sources) {
     const MapHeader* __restrict__ hdr = reinterpret_cast<const MapHeader*>(P.tables);
     const int A = (int)hdr->A, L = (int)hdr->L;
     const int64_t As = agent_stride_of(A, L);
@@ -180,7 +182,7 @@ __global__ void __launch_bounds__(256) avail_kernel(BatchPtrs P, uint8_t* __rest
     ObsTables T;
     T.cell_lay = reinterpret_cast<const uint64_t*>(P.tables + hdr->off_cell_lay);
     T.cell_meta = reinterpret_cast<const uint32_t*>(P.tables + hdr->off_cell_meta);
-    T.beam_colour = hdr->beam_colour;
+    T.beam_colour = per_env_sources ? P.src_colour + env * src_stride_of(L) : hdr->beam_colour;
     T.A = A; T.H = (int)hdr->H; T.W = (int)hdr->W;
     const uint32_t m = avail_bools(T, P.pos + env * As, P.beams + env * L, a, (uint32_t)P.avail[env * As + a], walkable_lasers != 0);
     uint8_t* o = out + idx * 5;
@@ -222,7 +224,8 @@ hipError_t launch_view_observe(const ViewHeader& v, const BatchPtrs& P, const ui
 
 uint32_t partial_pitch(int A, int k) { return ((uint32_t)(A * (2 * A + 3) * k * k) + 15u) & ~15u; }
 
-hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t* out, int k, int64_t n_envs, hipStream_t stream) {
+hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t* out, int k, int64_t n_envs, bool per_env_sources,
+                                  hipStream_t stream) {
     const uint32_t pitch = partial_pitch((int)h.A, k);
     const uint32_t As = (uint32_t)agent_stride_of((int)h.A, (int)h.L);
     const uint32_t priv = pitch + OBS_ENVS_PER_WAVE * (As / 2 + 1 + h.L) * 4u;
@@ -236,7 +239,7 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
     if (e != hipSuccess) return e;
     const uint32_t n_waves = (uint32_t)((n_envs + OBS_ENVS_PER_WAVE - 1) / OBS_ENVS_PER_WAVE);
     hipLaunchKernelGGL(partial_observe_kernel, dim3((n_waves + wpw - 1) / wpw), dim3(64 * wpw), lds, stream, P, out, k, pitch,
-                       (int64_t)0, n_envs);
+                       (int64_t)0, n_envs, per_env_sources ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -247,10 +250,12 @@ hipError_t launch_state_observe(const MapHeader& h, const BatchPtrs& P, float* o
     return hipGetLastError();
 }
 
-hipError_t launch_avail(const MapHeader& h, const BatchPtrs& P, uint8_t* out, int walkable_lasers, int64_t n_envs, hipStream_t stream) {
+hipError_t launch_avail(const MapHeader& h, const BatchPtrs& P, uint8_t* out, int walkable_lasers, int64_t n_envs, bool per_env_sources,
+                        hipStream_t stream) {
     const int64_t total = n_envs * (int64_t)h.A;
     if (total == 0) return hipSuccess;
-    hipLaunchKernelGGL(avail_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, P, out, walkable_lasers, n_envs);
+    hipLaunchKernelGGL(avail_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, P, out, walkable_lasers, n_envs,
+                       per_env_sources ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -77,7 +77,33 @@ struct MapView {
     int W, A, L, G;
     uint32_t enabled;      // bit b: source b enabled
     uint32_t max_layers;
+    // per-environment source colours (lle_batch_set_sources): 4 colours per word, colour of beam b = byte b; when
+    // `per_env` is set they replace the colours baked into cell_lay
+    bool per_env;
+    uint32_t colw[MAX_SOURCES / 4];
 };
+
+// colour of beam b from the env's packed colour words (compile-time indexed selects: no private-array indexing)
+template <int NWORDS>
+LLE_HD uint32_t colour_get(const uint32_t (&colw)[NWORDS], uint32_t b) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int k = 0; k < NWORDS; k++) w = ((b >> 2) == (uint32_t)k) ? colw[k] : w;
+    return (w >> ((b & 3u) * 8u)) & 0xFFu;
+}
+// cell_lay entry with the colour field of every valid layer replaced by the env's colour of that layer's beam
+template <int NWORDS>
+LLE_HD uint64_t recolour_lay(uint64_t lay, const uint32_t (&colw)[NWORDS]) {
+    uint64_t out = 0;
+#pragma unroll
+    for (int q = 0; q < MAX_CELL_LAYERS; q++) {
+        uint32_t e = (uint32_t)(lay >> (16 * q)) & 0xFFFFu;
+        const uint32_t c = colour_get<NWORDS>(colw, (e >> 1) & 31u);
+        e = (e & LAY_VALID) ? ((e & 0x7FFu) | (c << 11)) : e;
+        out |= (uint64_t)e << (16 * q);
+    }
+    return out;
+}
 
 template <int AM, int LM>
 struct Env {
@@ -124,6 +150,7 @@ LLE_HD void load_cells(const MapView& mv, const uint32_t (&pos)[AM], Cells<AM>& 
     for (int a = 0; a < AM; a++) {
         const uint32_t c = (a < mv.A) ? cell_of(pos[a], mv.W) : 0u;
         out.lay[a] = mv.cell_lay[c];
+        if (mv.per_env) out.lay[a] = recolour_lay<MAX_SOURCES / 4>(out.lay[a], mv.colw);
         out.meta[a] = mv.cell_meta[c];
     }
 }

@@ -17,6 +17,11 @@
 //                       value = base; any ref on -> 1; gem present and not collected -> 1
 //                       (write order of reference python/lle/observations.py:216-266)
 //   template [obs_stride] i8 : static observation (walls, voids, exits, -1 at sources), dyn bytes at their base
+// Second section, used when every environment has its own source colours / enabled flags (lle_batch_set_sources):
+//   bare     [obs_stride] i8 : walls, voids, exits only
+//   elems    [E]  u32 : what depends on colours or dynamic state: bits 0-15 cell | 16-20 beam or gem index |
+//                       21-25 offset | 26-27 type (0 source: -1 on layer LASER_0 + colour; 1 laser tile exposed by
+//                       World.lasers(): 1 on that layer when the beam bit is on; 2 gem: 1 on GEM when not collected)
 #pragma once
 #include <stdint.h>
 
@@ -54,6 +59,9 @@ struct MapHeader {
     uint8_t beam_len[MAX_SOURCES];
     uint8_t beam_colour[MAX_SOURCES];  // min(colour, 31)
     uint16_t gem_cell[MAX_GEMS];       // cell of each gem, i | j << 8
+    // per-environment sources (kernels instantiated with PES = true): a second LDS section right behind the first,
+    // [off_bare, off_bare + ext_bytes): the static observation WITHOUT the sources' -1 marks, and the element list
+    uint32_t off_bare, off_elems, n_elems, ext_bytes;
 };
 static_assert(sizeof(MapHeader) % 16 == 0, "sections must stay 16-byte aligned");
 
@@ -97,9 +105,14 @@ constexpr uint8_t ENV_OK = 0;
 constexpr uint8_t ENV_INVALID_WORLD_STATE = 0x40;
 constexpr uint8_t ENV_OUT_OF_WORLD_POSITION = 0x41;
 constexpr uint8_t ENV_INVALID_AGENT_POSITION = 0x42;
+constexpr uint8_t ENV_INVALID_COLOUR = 0x43;
 
 // ---- step flags (mirror include/lle_hip.h)
 constexpr uint32_t STEP_SAMPLE_ACTIONS = 1, STEP_AUTO_RESET = 2, STEP_NO_OBS = 4;
+constexpr uint32_t LAUNCH_PER_ENV_SOURCES = 0x10000;  // internal: the batch keeps colours / enabled flags per env
+constexpr uint32_t LAUNCH_FILL_DEFAULTS = 0x20000;    // internal (MODE_ENV_SOURCES): take them from the map header
+constexpr uint32_t LAUNCH_ARRAYS_INVALID = 0x40000;   // internal (MODE_ENV_SOURCES): first call, nothing stored per env yet
+constexpr uint32_t ELEM_SOURCE = 0, ELEM_TILE = 1, ELEM_GEM = 2;
 
 // ---- event codes
 constexpr uint32_t EV_EXIT = 0, EV_GEM = 1, EV_DIED = 2;
@@ -125,6 +138,8 @@ struct LaunchArgs {
     uint8_t* ring_actions;     // [ring_slots][n][agent stride]
     uint32_t* ring_reward;     // [ring_slots][n]
     uint64_t* stamps;          // profiling aid: [n_blocks][8] s_memrealtime stamps (10 ns ticks) of lane 0, or NULL
+    const uint8_t* colours_in;   // set_sources: optional u8[n][L] new colours
+    const uint32_t* enabled_in;  // set_sources: optional u32[n] new enabled masks
 };
 
 // State of a freshly reset environment (identical for every env of a map: v1 maps have one start per agent).
@@ -158,6 +173,23 @@ struct BatchPtrs {
     const uint32_t* req_gems;
     const uint16_t* req_alive;
     int64_t n_envs;
+    // per-environment sources (lle_batch_set_sources): colour of every source (4 per dword, stride src_stride bytes),
+    // enabled mask, and the env's own reset state (what World.reset gives with those colours / flags), which the
+    // auto-reset path copies instead of the shared InitRecord
+    uint8_t* src_colour;     // [n][src_stride]
+    uint32_t* src_enabled;   // [n]
+    uint16_t* init_pos;      // [n][A]
+    uint64_t* init_bits;     // [n]
+    uint32_t* init_gems;     // [n]
+    uint32_t* init_beams;    // [n][L]
+    uint8_t* init_avail;     // [n][A]
 };
+
+// bytes of one env's colour record: L rounded up to whole dwords
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int src_stride_of(int L) { return L <= 4 ? 4 : (L <= 8 ? 8 : (L <= 16 ? 16 : 32)); }
+
 
 }  // namespace lle

@@ -40,6 +40,7 @@ static void run(hs_batch* b, int mode, uint32_t flags, uint64_t seed, uint64_t t
     mv.cell_meta = reinterpret_cast<const uint32_t*>(blob + hdr->off_cell_meta);
     mv.hdr = hdr; mv.W = (int)hdr->W; mv.A = A; mv.L = L; mv.G = (int)hdr->G;
     mv.enabled = hdr->enabled_mask; mv.max_layers = hdr->max_layers;
+    mv.per_env = false;
     const uint64_t* dyn = reinterpret_cast<const uint64_t*>(blob + hdr->off_dyn);
     std::vector<int8_t> tmpl(blob + hdr->off_template, blob + hdr->off_template + hdr->obs_stride);
     const uint32_t amask = (1u << A) - 1u;

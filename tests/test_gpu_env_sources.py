@@ -1,0 +1,196 @@
+"""Per-environment laser sources (lle_batch_set_sources; SURVEY.md section 8(f) rank 4: LLE.reset with randomize_lasers,
+python/lle/env/env.py:198-200, and LaserSource.enable / disable, pylaser_source.rs:55-75) against the oracle, where every
+env is its own world object and takes the same set_colour / enable / disable calls."""
+import numpy as np
+import pytest
+
+from oracle.levels import LEVELS
+from tests.parity_util import EXTRA_MAPS, assert_state_equal, assert_step_equal, unpack_engine
+
+pytestmark = pytest.mark.gpu
+
+MAPS = {"level6": LEVELS[6], "level5": LEVELS[5], "nested": EXTRA_MAPS["nested"], "three_beams": EXTRA_MAPS["three_beams"],
+        "four_layers": EXTRA_MAPS["four_layers"], "q1": EXTRA_MAPS["q1"], "many_agents": EXTRA_MAPS["many_agents"],
+        "gen_20_lasers": EXTRA_MAPS["gen_20_lasers"]}
+
+
+def dims_of(ob):
+    return (ob.A, ob.G, ob.Ls, ob.beam_stride, ob.C, ob.H, ob.W)
+
+
+def check(bw, ob, ostep, where):
+    eng = unpack_engine(bw.host_buffers(), *dims_of(ob))
+    if ostep is not None:
+        assert_step_equal(eng, ostep, where)
+    assert_state_equal(eng, ob.dump(), where)
+
+
+class Mirror:
+    """Applies the same per-env source changes to the oracle worlds, with the Python binding's semantics: enable /
+    disable only act when the flag changes (pylaser_source.rs:55-75)."""
+
+    def __init__(self, ob, n, L):
+        self.ob, self.n, self.L = ob, n, L
+        srcs = ob.world(0).sources()
+        self.enabled = np.array([[bool(s[4]) for s in srcs]] * n)
+
+    def apply(self, colours=None, enabled=None, mask=None):
+        for e in range(self.n):
+            if mask is not None and not mask[e]:
+                continue
+            w = self.ob.world(e)
+            for l in range(self.L):
+                if colours is not None:
+                    w.set_source(l, colour=int(colours[e, l]))
+                if enabled is not None:
+                    want = bool((int(enabled[e]) >> l) & 1)
+                    if want != self.enabled[e, l]:
+                        w.set_source(l, enabled=want)
+                        self.enabled[e, l] = want
+
+
+@pytest.mark.parametrize("name", list(MAPS))
+def test_random_colours_and_flags_per_env(oracle_mod, name):
+    import torch
+
+    from lle_amd import BatchedWorld
+
+    text = MAPS[name]
+    n = 300
+    ob = oracle_mod.OracleBatch(text, n)
+    bw = BatchedWorld(text, n)
+    A, L = ob.A, bw.map.n_sources
+    mirror = Mirror(ob, n, L)
+    rng = np.random.default_rng(7)
+    t = 0
+    for episode in range(4):
+        # a few steps, then re-colour / switch sources of a random subset of envs mid-episode (beams keep their state)
+        for _ in range(6):
+            auto = episode % 2 == 1
+            bw.step(sample=True, auto_reset=auto, seed=21, t=t, env_offset=5)
+            ostep = ob.step(None, auto_reset=auto, seed=21, t=t, env_offset=5)
+            check(bw, ob, ostep, f"{name} episode {episode} t={t}")
+            t += 1
+        colours = rng.integers(0, A, size=(n, L), dtype=np.uint8)
+        enabled = rng.integers(0, 1 << L, size=n, dtype=np.int64).astype(np.int32) if episode != 2 else None
+        mask = (rng.random(n) < 0.7).astype(np.uint8) if episode != 0 else None
+        bw.set_sources(torch.from_numpy(colours), None if enabled is None else torch.from_numpy(enabled),
+                       None if mask is None else torch.from_numpy(mask))
+        mirror.apply(colours, enabled, mask)
+        check(bw, ob, None, f"{name} after set_sources {episode}")
+        assert int(bw.err.max()) == 0
+        if episode == 1:  # LLE.reset: world.reset() with the current colours, for a subset
+            rmask = (rng.random(n) < 0.5).astype(np.uint8)
+            bw.reset(torch.from_numpy(rmask))
+            for e in np.nonzero(rmask)[0]:
+                ob.world(int(e)).reset()
+            check(bw, ob, None, f"{name} after masked reset {episode}")
+    got_c = bw.src_colour.cpu().numpy()
+    got_e = bw.src_enabled.cpu().numpy()
+    for e in range(0, n, 37):
+        srcs = ob.world(e).sources()
+        assert [int(c) for c in got_c[e]] == [s[3] for s in srcs]
+        assert [(int(got_e[e]) >> l) & 1 for l in range(L)] == [int(s[4]) for s in srcs]
+
+
+def test_invalid_colour_is_refused_per_env(oracle_mod):
+    import torch
+
+    from lle_amd import BatchedWorld, _capi
+
+    text = LEVELS[6]
+    n = 64
+    ob = oracle_mod.OracleBatch(text, n)
+    bw = BatchedWorld(text, n)
+    A, L = ob.A, bw.map.n_sources
+    colours = np.ones((n, L), np.uint8)
+    colours[5, 1] = A          # "Agent ID is greater than the number of agents"
+    colours[9, 0] = 200
+    bw.set_sources(torch.from_numpy(colours))
+    err = bw.err.cpu().numpy()
+    assert err[5] == _capi.LLE_ENV_INVALID_COLOUR and err[9] == _capi.LLE_ENV_INVALID_COLOUR and err.sum() == 2 * 0x43
+    for e in range(n):
+        if e not in (5, 9):
+            for l in range(L):
+                ob.world(e).set_source(l, colour=1)
+    check(bw, ob, None, "after partial refusal")
+
+
+def test_other_builders_and_modes_with_per_env_sources(oracle_mod):
+    """partial k x k, availability without foreign lasers and the layered tensor written by lle_batch_observe_as use the
+    env's colours; the map-wide update broadcasts; snapshots carry the sources; the fused rollout and the
+    lane-per-env diagnostic kernel agree with single steps."""
+    import torch
+
+    from lle_amd import BatchedWorld, _capi
+    from oracle import observers as oo
+
+    text = EXTRA_MAPS["nested"]
+    n = 128
+    ob = oracle_mod.OracleBatch(text, n)
+    bw = BatchedWorld(text, n)
+    A, L = ob.A, bw.map.n_sources
+    mirror = Mirror(ob, n, L)
+    rng = np.random.default_rng(3)
+    colours = rng.integers(0, A, size=(n, L), dtype=np.uint8)
+    enabled = rng.integers(0, 1 << L, size=n).astype(np.int32)
+    bw.set_sources(torch.from_numpy(colours), torch.from_numpy(enabled))
+    mirror.apply(colours, enabled)
+    for t in range(5):
+        bw.step(sample=True, seed=2, t=t)
+        check(bw, ob, ob.step(None, seed=2, t=t), f"t={t}")
+    part = bw.observe_as(_capi.LLE_OBS_PARTIAL, 5).cpu().numpy()
+    lay = bw.observe_as(_capi.LLE_OBS_LAYERED).cpu().numpy()
+    strict = bw.available_actions(False).cpu().numpy()
+    for e in range(0, n, 11):
+        w = ob.world(e)
+        assert np.array_equal(part[e].astype(np.float32), oo.partial_observe(w, 5)), e
+        assert np.array_equal(lay[e].astype(np.float32), oo.layered_observe(w)[0]), e
+        assert np.array_equal(strict[e], oo.available_actions(w, False)), e
+    with pytest.raises(RuntimeError):
+        bw.observe_as(_capi.LLE_OBS_PERSPECTIVE)
+
+    # snapshot / restore carry colours, flags and the per-env reset states
+    snap = bw.snapshot()
+    before = {k: getattr(bw, k).clone() for k in ("pos", "bits", "gems", "beams", "avail", "src_colour", "src_enabled", "obs")}
+    bw.set_sources(torch.zeros((n, L), dtype=torch.uint8), torch.zeros(n, dtype=torch.int32))
+    for t in range(3):
+        bw.step(sample=True, auto_reset=True, seed=9, t=t)
+    bw.restore(snap)
+    for k, v in before.items():
+        assert torch.equal(getattr(bw, k), v), k
+    for t in range(5, 9):  # the restored batch continues exactly like the oracle (auto-reset uses each env's reset state)
+        bw.step(sample=True, auto_reset=True, seed=2, t=t)
+        check(bw, ob, ob.step(None, auto_reset=True, seed=2, t=t), f"after restore t={t}")
+
+    # fused rollout == single steps, and the lane-per-env diagnostic kernel == the lane-per-agent kernel
+    twin = BatchedWorld(text, n)
+    twin.set_sources(bw.src_colour.clone(), bw.src_enabled.clone())
+    twin.restore(bw.snapshot())
+    diag = BatchedWorld(text, n, envs_per_wave=16)
+    diag.set_sources(bw.src_colour.clone(), bw.src_enabled.clone())
+    diag.restore(bw.snapshot())
+    twin.rollout(6, auto_reset=True, seed=4, t=100)
+    for t in range(100, 106):
+        bw.step(sample=True, auto_reset=True, seed=4, t=t)
+        diag.step(sample=True, auto_reset=True, seed=4, t=t)
+        check(bw, ob, ob.step(None, auto_reset=True, seed=4, t=t), f"t={t}")
+    for k in ("pos", "bits", "gems", "beams", "avail", "obs"):
+        assert torch.equal(getattr(bw, k), getattr(twin, k)), k
+        assert torch.equal(getattr(bw, k), getattr(diag, k)), k
+
+    # the map-wide update broadcasts the map's sources to every env
+    bw.map.set_source(0, enabled=False)
+    bw.map.set_source(1, agent_id=0)
+    bw.update_sources()
+    for e in range(n):
+        w = ob.world(e)
+        for l, s in enumerate(bw.map.sources()):
+            w.set_source(l, colour=int(s.agent_id))
+            if bool(s.enabled) != mirror.enabled[e, l]:
+                w.set_source(l, enabled=bool(s.enabled))
+                mirror.enabled[e, l] = bool(s.enabled)
+    check(bw, ob, None, "after the map-wide update")
+    for t in range(200, 204):
+        bw.step(sample=True, auto_reset=True, seed=6, t=t)
+        check(bw, ob, ob.step(None, auto_reset=True, seed=6, t=t), f"t={t}")
