@@ -602,8 +602,6 @@ int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64
     int rc = obs_desc(b, kind, param, &d);
     if (rc != LLE_OK) return rc;
     if (!d.supported) return fail(LLE_ERR_UNSUPPORTED, "a laser colour has no layer in this observation (the reference raises IndexError)");
-    if (b->per_env_sources && (kind == LLE_OBS_LAYERED_PADDED || kind == LLE_OBS_PERSPECTIVE))
-        return fail(LLE_ERR_UNSUPPORTED, "layered-padded / perspective are not built for batches with per-environment sources yet");
     if (b->per_env_sources && kind == LLE_OBS_LAYERED) {  // the env-coloured layered writer of the world kernel, into `out_dev`
         HIP_TRY(hipSetDevice(b->device));
         BatchPtrs P = b->ptrs;
@@ -621,6 +619,7 @@ int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64
     HIP_TRY(hipSetDevice(b->device));
     hipStream_t st = (hipStream_t)stream;
     const MapHeader& h = b->hdr;
+    const bool pes = b->per_env_sources;
     switch (kind) {
         case LLE_OBS_LAYERED:
         case LLE_OBS_PERSPECTIVE: {
@@ -629,19 +628,19 @@ int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64
             const lle_batch::View* v;
             rc = get_view(b, LLE_OBS_PERSPECTIVE, 0, st, &v);
             if (rc != LLE_OK) return rc;
-            if (n_views > 1 && view_kernel_fits(v->hdr, (uint32_t)n_views)) {
+            if (n_views > 1 && view_kernel_fits(v->hdr, (uint32_t)n_views, pes, h.n_elems)) {
                 // small maps: one launch, the rows of all observers of an env written back to back
                 rc = get_view(b, LLE_OBS_PERSPECTIVE, -1, st, &v);
                 if (rc != LLE_OK) return rc;
                 HIP_TRY(launch_view_observe(v->hdr, b->ptrs, v->dev, (uint32_t)n_views, static_cast<int8_t*>(out_dev),
-                                            (int64_t)n_views * h.obs_stride, (int64_t)h.obs_stride, b->n_envs, st));
+                                            (int64_t)n_views * h.obs_stride, (int64_t)h.obs_stride, b->n_envs, pes, h.n_elems, st));
                 break;
             }
             for (int k = 0; k < n_views; k++) {  // big rows: one launch per observer, rows strided by A * obs_stride
                 rc = get_view(b, LLE_OBS_PERSPECTIVE, k, st, &v);
                 if (rc != LLE_OK) return rc;
                 HIP_TRY(launch_view_observe(v->hdr, b->ptrs, v->dev, 1u, static_cast<int8_t*>(out_dev) + (int64_t)k * h.obs_stride,
-                                            (int64_t)n_views * h.obs_stride, 0, b->n_envs, st));
+                                            (int64_t)n_views * h.obs_stride, 0, b->n_envs, pes, h.n_elems, st));
             }
             break;
         }
@@ -650,7 +649,7 @@ int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64
             rc = get_view(b, kind, param, st, &v);
             if (rc != LLE_OK) return rc;
             HIP_TRY(launch_view_observe(v->hdr, b->ptrs, v->dev, 1u, static_cast<int8_t*>(out_dev), (int64_t)v->hdr.obs_stride, 0,
-                                        b->n_envs, st));
+                                        b->n_envs, pes, h.n_elems, st));
             break;
         }
         case LLE_OBS_PARTIAL:

@@ -339,14 +339,26 @@ std::vector<uint8_t> Map::compile_view(int kind, int param) const {
     v.n_chunks = v.obs_stride / 16;
     v.D = (uint32_t)dyn_tab.size();
     for (int a = 0; a < A; a++) v.agent_layer[a] = (uint8_t)lm.agent[a];
+    std::vector<int8_t> bare(v.obs_stride, 0);
+    {
+        auto bat = [&](int layer, Pos q) -> int8_t& { return bare[(size_t)layer * HW + q.i * W + q.j]; };
+        for (auto& q : walls) bat(lm.wall, q) = 1;
+        for (auto& q : voids) bat(lm.void_, q) = 1;
+        for (auto& q : exits) bat(lm.exit, q) = 1;
+    }
+    v.gem_layer = (uint32_t)lm.gem;
+    v.n_laser = (uint32_t)std::min(lm.n_laser, 48);
+    for (uint32_t c = 0; c < v.n_laser; c++) v.laser_layer[c] = (uint8_t)lm.laser[c];
     size_t off = sizeof(ViewHeader);
     v.off_dyn = (uint32_t)off; off = (off + dyn_tab.size() * 8 + 15) & ~(size_t)15;
     v.off_template = (uint32_t)off; off += tmpl.size();
+    v.off_bare = (uint32_t)off; off += bare.size();
     off = (off + 1023) & ~(size_t)1023;  // the kernel copies the whole blob to LDS in 1-KiB rows
     v.blob_bytes = (uint32_t)off;
     std::vector<uint8_t> out(off, 0);
     if (!dyn_tab.empty()) std::memcpy(out.data() + v.off_dyn, dyn_tab.data(), dyn_tab.size() * 8);
     std::memcpy(out.data() + v.off_template, tmpl.data(), tmpl.size());
+    std::memcpy(out.data() + v.off_bare, bare.data(), bare.size());
     std::memcpy(out.data(), &v, sizeof v);
     return out;
 }

@@ -48,7 +48,7 @@ struct Map {
     struct LayerMap {
         int C = 0, n_laser = 0;
         int agent[MAX_AGENTS] = {0};
-        int laser[2 * MAX_AGENTS + 8] = {0};
+        int laser[2 * MAX_AGENTS + 40] = {0};
         int wall = 0, void_ = 0, gem = 0, exit = 0;
     };
     bool build_obs_tables(const LayerMap& lm, std::vector<int8_t>& tmpl, std::vector<uint64_t>& dyn_tab) const;

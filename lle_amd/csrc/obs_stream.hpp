@@ -111,18 +111,23 @@ __device__ __forceinline__ void write_observations(int A, int L, uint32_t D, uin
 // byte; a source and a tile never share a cell), so one pass in any lane order reproduces the reference's write order
 // (python/lle/observations.py:216-266), colour aliasing (Q5) included.
 // record: [0 | beam masks | ~gem bits | byte index of each agent | colour words (4 colours per dword)]
-__device__ __forceinline__ void elem_eval(uint32_t e, const uint32_t* sc, int A, int L, uint32_t HW, uint32_t& idx, int32_t& val, bool& on) {
+// `laser_layer` (views: layer of colour c) or NULL (Layered: LASER_0 + c); `gem_layer` = the GEM channel.
+__device__ __forceinline__ void elem_eval(uint32_t e, const uint32_t* sc, int A, int L, uint32_t HW, const uint8_t* laser_layer,
+                                          uint32_t gem_layer, uint32_t& idx, int32_t& val, bool& on) {
     const uint32_t cell = e & 0xFFFFu, i5 = (e >> 16) & 31u, off = (e >> 21) & 31u, type = (e >> 26) & 3u;
     const uint32_t colour = (sc[L + 2 + A + (i5 >> 2)] >> ((i5 & 3u) * 8u)) & 0xFFu;
     const bool is_gem = type == ELEM_GEM;
-    idx = (is_gem ? (uint32_t)(2 * A + 2) : (uint32_t)A + colour) * HW + cell;
+    const uint32_t llayer = laser_layer ? (uint32_t)laser_layer[colour] : (uint32_t)A + colour;
+    idx = (is_gem ? gem_layer : llayer) * HW + cell;
     val = type == ELEM_SOURCE ? -1 : 1;
     on = type == ELEM_SOURCE ? true : (is_gem ? ((sc[L + 1] >> i5) & 1u) != 0 : ((sc[1 + i5] >> off) & 1u) != 0);
 }
 __device__ __forceinline__ void write_observations_env(int A, int L, uint32_t HW, uint32_t n_elems, uint32_t n_chunks,
                                                        uint64_t obs_stride, const uint32_t* elems, const int8_t* bare,
                                                        int8_t* tmpl, const uint32_t* scratch, uint32_t scr_stride,
-                                                       int8_t* __restrict__ obs, int64_t env0, int64_t n_here, uint32_t lane) {
+                                                       int8_t* __restrict__ obs, int64_t env0, int64_t n_here, uint32_t lane,
+                                                       const uint8_t* laser_layer = nullptr, uint32_t gem_layer_in = 0xFFFFFFFFu) {
+    const uint32_t gem_layer = gem_layer_in == 0xFFFFFFFFu ? (uint32_t)(2 * A + 2) : gem_layer_in;
     const bool has_e0 = lane < n_elems;
     const uint32_t e0 = has_e0 ? elems[lane] : 0u;
     const bool is_agent_lane = (int)lane < A;
@@ -130,12 +135,12 @@ __device__ __forceinline__ void write_observations_env(int A, int L, uint32_t HW
     for (int64_t k = 0; k < n_here; k++) {
         const uint32_t* sc = scratch + (uint32_t)k * scr_stride;
         uint32_t idx0; int32_t val0; bool on0;
-        elem_eval(e0, sc, A, L, HW, idx0, val0, on0);
+        elem_eval(e0, sc, A, L, HW, laser_layer, gem_layer, idx0, val0, on0);
         on0 = on0 && has_e0;
         if (on0) tmpl[idx0] = (int8_t)val0;
         for (uint32_t d = lane + 64u; d < n_elems; d += 64) {
             uint32_t idx; int32_t val; bool on;
-            elem_eval(elems[d], sc, A, L, HW, idx, val, on);
+            elem_eval(elems[d], sc, A, L, HW, laser_layer, gem_layer, idx, val, on);
             if (on) tmpl[idx] = (int8_t)val;
         }
         const uint32_t agent_idx = is_agent_lane ? sc[L + 2 + lane] : 0u;
@@ -148,7 +153,7 @@ __device__ __forceinline__ void write_observations_env(int A, int L, uint32_t HW
         if (on0) tmpl[idx0] = bare[idx0];
         for (uint32_t d = lane + 64u; d < n_elems; d += 64) {
             uint32_t idx; int32_t val; bool on;
-            elem_eval(elems[d], sc, A, L, HW, idx, val, on);
+            elem_eval(elems[d], sc, A, L, HW, laser_layer, gem_layer, idx, val, on);
             if (on) tmpl[idx] = bare[idx];
         }
         if (is_agent_lane) tmpl[agent_idx] = 0;

@@ -24,45 +24,56 @@ constexpr uint32_t OBS_LDS_LIMIT = 160 * 1024;
 
 // ---------------------------------------------------------------------------------------------- layered views
 // `views` = n_views view blobs of equal size back to back (one for layered-padded; one per observer for the
-// perspective when they fit in LDS together).  LDS: [the blobs] then per wave, per view
-// [patchable template copy | OBS_ENVS_PER_WAVE records].  Row of (env, view v) = out + env * row_pitch + v * view_pitch:
-// with several views the wave writes the rows of one environment back to back (one contiguous span per env).
+// perspective when they fit in LDS together).  LDS: [the blobs] [element list of the map, per-env sources only] then per
+// wave, per view [patchable template copy | OBS_ENVS_PER_WAVE records].  Row of (env, view v) = out + env * row_pitch +
+// v * view_pitch: with several views the wave writes the rows of one environment back to back.
+// pes: the batch keeps source colours per environment -- the copy starts from the view's bare static observation and
+// every env writes its laser / gem bytes through the view's colour -> layer table (write_observations_env).
 __global__ void __launch_bounds__(256) view_observe_kernel(BatchPtrs P, const uint8_t* __restrict__ views, uint32_t n_views,
                                                            int8_t* __restrict__ out, int64_t row_pitch, int64_t view_pitch,
-                                                           int64_t env_base, int64_t env_limit) {
+                                                           int64_t env_base, int64_t env_limit, int pes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const ViewHeader* __restrict__ gh = reinterpret_cast<const ViewHeader*>(views);
+    const MapHeader* __restrict__ mh = reinterpret_cast<const MapHeader*>(P.tables);
     const uint32_t lane = threadIdx.x & 63u, wave_in_wg = threadIdx.x >> 6, waves_per_wg = blockDim.x >> 6;
     const uint32_t wave_id = blockIdx.x * waves_per_wg + wave_in_wg;
     const uint32_t blob_bytes = gh->blob_bytes;
     copy_tables_to_lds(views, lds, blob_bytes * n_views, lane, wave_in_wg, waves_per_wg);
+    const uint32_t n_elems = pes ? mh->n_elems : 0u, elem_bytes = (n_elems * 4u + 15u) & ~15u;
+    uint32_t* elems = reinterpret_cast<uint32_t*>(lds + blob_bytes * n_views);
+    if (pes) {
+        const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(P.tables + mh->off_elems);
+        for (uint32_t i = threadIdx.x; i < n_elems; i += blockDim.x) elems[i] = src[i];
+    }
     __syncthreads();
     const ViewHeader* vh0 = reinterpret_cast<const ViewHeader*>(lds);
     const int A = (int)vh0->A, L = (int)vh0->L, W = (int)vh0->W;
     const int64_t As = agent_stride_of(A, L);
+    const int CW = pes ? src_stride_of(L) / 4 : 0;
     const uint32_t obs_stride = vh0->obs_stride, n_chunks = vh0->n_chunks;
-    const uint32_t scr_stride = (uint32_t)(L + A + 2) | 1u;
+    const uint32_t scr_stride = (uint32_t)(L + A + 2 + CW) | 1u;
     const uint32_t view_priv = obs_stride + OBS_ENVS_PER_WAVE * scr_stride * 4u;
-    uint8_t* priv = lds + blob_bytes * n_views + wave_in_wg * n_views * view_priv;
+    uint8_t* priv = lds + blob_bytes * n_views + elem_bytes + wave_in_wg * n_views * view_priv;
     for (uint32_t v = 0; v < n_views; v++) {
         const ViewHeader* vh = reinterpret_cast<const ViewHeader*>(lds + v * blob_bytes);
-        const uint4* pristine = reinterpret_cast<const uint4*>(lds + v * blob_bytes + vh->off_template);
+        const uint4* pristine = reinterpret_cast<const uint4*>(lds + v * blob_bytes + (pes ? vh->off_bare : vh->off_template));
         uint4* mine = reinterpret_cast<uint4*>(priv + v * view_priv);
         for (uint32_t c = lane; c < n_chunks; c += 64) mine[c] = pristine[c];
     }
     const int64_t env0 = env_base + (int64_t)wave_id * OBS_ENVS_PER_WAVE;
     int64_t n_here = env_limit - env0;
     n_here = n_here < 0 ? 0 : (n_here > (int64_t)OBS_ENVS_PER_WAVE ? (int64_t)OBS_ENVS_PER_WAVE : n_here);
-    // hand-over records [0 | beam masks | ~gem bits | byte index of each agent], all loads of the wave in flight together
-    const uint32_t per_env = (uint32_t)(L + A + 2);
+    // hand-over records [0 | beam masks | ~gem bits | byte index of each agent | colour words], all loads in flight together
+    const uint32_t per_env = (uint32_t)(L + A + 2 + CW);
     for (uint32_t idx = lane; idx < (uint32_t)n_here * per_env; idx += 64) {
         const uint32_t k = idx / per_env, f = idx - k * per_env;
         const int64_t env = env0 + k;
         uint32_t v = 0, cell = 0;
-        const bool is_agent = f > (uint32_t)L + 1u;
+        const bool is_agent = f > (uint32_t)L + 1u && f < (uint32_t)(L + 2 + A);
         if (f >= 1 && f <= (uint32_t)L) v = P.beams[env * L + (f - 1)];
         else if (f == (uint32_t)L + 1u) v = ~P.gems[env];
         else if (is_agent) cell = cell_of((uint32_t)P.pos[env * As + (f - (uint32_t)L - 2u)], W);
+        else if (f >= (uint32_t)(L + 2 + A)) v = reinterpret_cast<const uint32_t*>(P.src_colour)[env * CW + (f - (uint32_t)(L + 2 + A))];
         for (uint32_t q = 0; q < n_views; q++) {
             const ViewHeader* vh = reinterpret_cast<const ViewHeader*>(lds + q * blob_bytes);
             uint32_t* scratch = reinterpret_cast<uint32_t*>(priv + q * view_priv + obs_stride);
@@ -70,22 +81,22 @@ __global__ void __launch_bounds__(256) view_observe_kernel(BatchPtrs P, const ui
         }
     }
     wave_sync();
-    if (n_views == 1) {
-        const uint64_t* dyn = reinterpret_cast<const uint64_t*>(lds + vh0->off_dyn);
-        int8_t* tmpl = reinterpret_cast<int8_t*>(priv);
-        if (n_here > 0)
-            write_observations(A, L, vh0->D, n_chunks, (uint64_t)row_pitch, dyn, tmpl, reinterpret_cast<const uint32_t*>(tmpl + obs_stride),
-                               scr_stride, out, env0, n_here, lane);
-        return;
-    }
-    for (int64_t k = 0; k < n_here; k++)
+    // one environment at a time, its views back to back (a single view: all environments in one call)
+    const int64_t outer = n_views == 1 ? (n_here > 0 ? 1 : 0) : n_here, inner_envs = n_views == 1 ? n_here : 1;
+    for (int64_t k = 0; k < outer; k++)
         for (uint32_t q = 0; q < n_views; q++) {
             const ViewHeader* vh = reinterpret_cast<const ViewHeader*>(lds + q * blob_bytes);
-            const uint64_t* dyn = reinterpret_cast<const uint64_t*>(lds + q * blob_bytes + vh->off_dyn);
             int8_t* tmpl = reinterpret_cast<int8_t*>(priv + q * view_priv);
             const uint32_t* scratch = reinterpret_cast<const uint32_t*>(tmpl + obs_stride) + (uint32_t)k * scr_stride;
-            write_observations(A, L, vh->D, n_chunks, (uint64_t)row_pitch, dyn, tmpl, scratch, scr_stride,
-                               out + (int64_t)q * view_pitch, env0 + k, 1, lane);
+            if (pes) {
+                const int8_t* bare = reinterpret_cast<const int8_t*>(lds + q * blob_bytes + vh->off_bare);
+                write_observations_env(A, L, vh->HW, n_elems, n_chunks, (uint64_t)row_pitch, elems, bare, tmpl, scratch, scr_stride,
+                                       out + (int64_t)q * view_pitch, env0 + k, inner_envs, lane, vh->laser_layer, vh->gem_layer);
+            } else {
+                const uint64_t* dyn = reinterpret_cast<const uint64_t*>(lds + q * blob_bytes + vh->off_dyn);
+                write_observations(A, L, vh->D, n_chunks, (uint64_t)row_pitch, dyn, tmpl, scratch, scr_stride,
+                                   out + (int64_t)q * view_pitch, env0 + k, inner_envs, lane);
+            }
         }
 }
 
@@ -200,25 +211,28 @@ static hipError_t grant_lds(const void* fn, uint32_t lds, uint32_t& granted) {
 }
 
 // LDS bytes of the view kernel for n_views views per launch and wpw wavefronts per workgroup
-static uint32_t view_lds(const ViewHeader& v, uint32_t n_views, uint32_t wpw) {
-    const uint32_t scr_stride = (v.L + v.A + 2) | 1u;
-    return n_views * v.blob_bytes + wpw * n_views * (v.obs_stride + OBS_ENVS_PER_WAVE * scr_stride * 4u);
+static uint32_t view_lds(const ViewHeader& v, uint32_t n_views, uint32_t wpw, bool pes, uint32_t n_elems) {
+    const uint32_t scr_stride = (v.L + v.A + 2 + (pes ? (uint32_t)src_stride_of((int)v.L) / 4u : 0u)) | 1u;
+    const uint32_t elem_bytes = pes ? ((n_elems * 4u + 15u) & ~15u) : 0u;
+    return n_views * v.blob_bytes + elem_bytes + wpw * n_views * (v.obs_stride + OBS_ENVS_PER_WAVE * scr_stride * 4u);
 }
 
-bool view_kernel_fits(const ViewHeader& v, uint32_t n_views) { return view_lds(v, n_views, 1) <= OBS_LDS_LIMIT; }
+bool view_kernel_fits(const ViewHeader& v, uint32_t n_views, bool pes, uint32_t n_elems) {
+    return view_lds(v, n_views, 1, pes, n_elems) <= OBS_LDS_LIMIT;
+}
 
 hipError_t launch_view_observe(const ViewHeader& v, const BatchPtrs& P, const uint8_t* views_dev, uint32_t n_views, int8_t* out,
-                               int64_t row_pitch, int64_t view_pitch, int64_t n_envs, hipStream_t stream) {
+                               int64_t row_pitch, int64_t view_pitch, int64_t n_envs, bool pes, uint32_t n_elems, hipStream_t stream) {
     uint32_t wpw = 4;
-    while (wpw > 1 && view_lds(v, n_views, wpw) > OBS_LDS_LIMIT) wpw >>= 1;
-    const uint32_t lds = view_lds(v, n_views, wpw);
+    while (wpw > 1 && view_lds(v, n_views, wpw, pes, n_elems) > OBS_LDS_LIMIT) wpw >>= 1;
+    const uint32_t lds = view_lds(v, n_views, wpw, pes, n_elems);
     if (lds > OBS_LDS_LIMIT) return hipErrorInvalidValue;
     static uint32_t granted = 0;
     hipError_t e = grant_lds(reinterpret_cast<const void*>(&view_observe_kernel), lds, granted);
     if (e != hipSuccess) return e;
     const uint32_t n_waves = (uint32_t)((n_envs + OBS_ENVS_PER_WAVE - 1) / OBS_ENVS_PER_WAVE);
     hipLaunchKernelGGL(view_observe_kernel, dim3((n_waves + wpw - 1) / wpw), dim3(64 * wpw), lds, stream, P, views_dev, n_views, out,
-                       row_pitch, view_pitch, (int64_t)0, n_envs);
+                       row_pitch, view_pitch, (int64_t)0, n_envs, pes ? 1 : 0);
     return hipGetLastError();
 }
 

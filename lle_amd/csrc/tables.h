@@ -83,6 +83,10 @@ struct ViewHeader {
     uint32_t supported;      // 0: some laser colour has no layer (the reference raises IndexError)
     uint32_t pad;
     uint8_t agent_layer[MAX_AGENTS];  // layer that shows agent a
+    // for batches with per-environment sources (the layer of a laser byte depends on the env's colours):
+    uint32_t off_bare;       // static observation of this view without the sources' -1 marks
+    uint32_t gem_layer, n_laser, pad2;
+    uint8_t laser_layer[48]; // layer of laser colour c, c < n_laser
 };
 static_assert(sizeof(ViewHeader) % 16 == 0, "sections must stay 16-byte aligned");
 constexpr uint32_t VIEW_MAGIC = 0x31564C4Cu;

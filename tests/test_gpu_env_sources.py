@@ -117,8 +117,7 @@ def test_invalid_colour_is_refused_per_env(oracle_mod):
 
 
 def test_other_builders_and_modes_with_per_env_sources(oracle_mod):
-    """partial k x k, availability without foreign lasers and the layered tensor written by lle_batch_observe_as use the
-    env's colours; the map-wide update broadcasts; snapshots carry the sources; the fused rollout and the
+    """Every observation builder and the availability mask without foreign lasers use the env's colours; the map-wide update broadcasts; snapshots carry the sources; the fused rollout and the
     lane-per-env diagnostic kernel agree with single steps."""
     import torch
 
@@ -147,8 +146,12 @@ def test_other_builders_and_modes_with_per_env_sources(oracle_mod):
         assert np.array_equal(part[e].astype(np.float32), oo.partial_observe(w, 5)), e
         assert np.array_equal(lay[e].astype(np.float32), oo.layered_observe(w)[0]), e
         assert np.array_equal(strict[e], oo.available_actions(w, False)), e
-    with pytest.raises(RuntimeError):
-        bw.observe_as(_capi.LLE_OBS_PERSPECTIVE)
+    persp = bw.observe_as(_capi.LLE_OBS_PERSPECTIVE).cpu().numpy()
+    padded = bw.observe_as(_capi.LLE_OBS_LAYERED_PADDED, 2).cpu().numpy()
+    for e in range(0, n, 11):
+        w = ob.world(e)
+        assert np.array_equal(persp[e].astype(np.float32), oo.perspective_observe(w)), e
+        assert np.array_equal(padded[e].astype(np.float32), oo.layered_padded_observe(w, 2)[0]), e
 
     # snapshot / restore carry colours, flags and the per-env reset states
     snap = bw.snapshot()
