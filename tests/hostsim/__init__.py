@@ -35,6 +35,7 @@ def lib():
         L.hs_set_state.argtypes = [C.c_void_p]
         L.hs_observe.argtypes = [C.c_void_p]
         L.hs_set_source.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.hs_set_sources.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hs_observe_as.restype = C.c_int
         L.hs_observe_as.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.hs_available_actions.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -97,6 +98,19 @@ class SimBatch:
 
     def set_state(self):
         self.L.hs_set_state(self.h)
+
+    def set_sources(self, colours=None, enabled=None, env_mask=None):
+        """Per-environment source colours u8 [n, L] / enabled masks u32 [n] (lle_batch_set_sources)."""
+        keep = []
+
+        def ptr(a, dt):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=dt)
+            keep.append(a)
+            return a.ctypes.data
+
+        self.L.hs_set_sources(self.h, ptr(colours, np.uint8), ptr(enabled, np.uint32), ptr(env_mask, np.uint8))
 
     def observe_as(self, kind, param=0):
         """Logical (unpadded) array of observation `kind` for every env, or None when the reference would raise

@@ -25,6 +25,10 @@ struct hs_batch {
     std::vector<uint8_t> avail, actions, err, evcount, events, done;
     std::vector<int8_t> obs;
     int64_t stats[8];
+    // per-environment sources (hs_set_sources): colour bytes [n][32], enabled masks [n]
+    bool per_env = false;
+    std::vector<uint8_t> src_colour;
+    std::vector<uint32_t> src_enabled;
 };
 
 enum { M_STEP = 0, M_RESET = 1, M_SET_STATE = 2, M_OBSERVE = 3, M_SOURCES = 4 };
@@ -45,7 +49,17 @@ static void run(hs_batch* b, int mode, uint32_t flags, uint64_t seed, uint64_t t
     std::vector<int8_t> tmpl(blob + hdr->off_template, blob + hdr->off_template + hdr->obs_stride);
     const uint32_t amask = (1u << A) - 1u;
 
+    const int8_t* bare = reinterpret_cast<const int8_t*>(blob + hdr->off_bare);
+    const uint32_t* elems = reinterpret_cast<const uint32_t*>(blob + hdr->off_elems);
     for (int64_t env = 0; env < b->n; env++) {
+        if (b->per_env) {  // this env's colours / enabled flags replace the map's (kernels: LAUNCH_PER_ENV_SOURCES)
+            mv.per_env = true;
+            mv.enabled = b->src_enabled[env];
+            for (int q = 0; q < MAX_SOURCES / 4; q++) {
+                const uint8_t* c = &b->src_colour[env * 32 + 4 * q];
+                mv.colw[q] = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | ((uint32_t)c[3] << 24);
+            }
+        }
         Env<AM, LM> s;
         for (int a = 0; a < AM; a++) s.pos[a] = (a < A) ? (uint32_t)b->pos[env * A + a] : 0xFFFF0000u + (uint32_t)a;
         const uint64_t bits = b->bits[env];
@@ -152,6 +166,19 @@ static void run(hs_batch* b, int mode, uint32_t flags, uint64_t seed, uint64_t t
         }
         // phase 2
         if ((mode == M_STEP && (flags & STEP_NO_OBS)) || !hdr->obs_supported) continue;
+        if (b->per_env) {  // same element evaluation as write_observations_env (obs_stream.hpp)
+            std::vector<int8_t> row(bare, bare + hdr->obs_stride);
+            for (uint32_t d = 0; d < hdr->n_elems; d++) {
+                const uint32_t e = elems[d], cell = e & 0xFFFFu, i5 = (e >> 16) & 31u, off = (e >> 21) & 31u, type = (e >> 26) & 3u;
+                const uint32_t colour = b->src_colour[env * 32 + i5];
+                if (type == ELEM_SOURCE) row[((uint32_t)A + colour) * hdr->HW + cell] = -1;
+                else if (type == ELEM_TILE) { if ((s.beams[i5] >> off) & 1u) row[((uint32_t)A + colour) * hdr->HW + cell] = 1; }
+                else if (!((s.gems >> i5) & 1u)) row[(uint32_t)(2 * A + 2) * hdr->HW + cell] = 1;
+            }
+            for (int a = 0; a < A; a++) row[(uint32_t)a * hdr->HW + cell_of(s.pos[a], mv.W)] = 1;
+            std::memcpy(b->obs.data() + (size_t)env * hdr->obs_stride, row.data(), hdr->obs_stride);
+            continue;
+        }
         for (uint32_t d = 0; d < hdr->D; d++) {
             const uint64_t e = dyn[d];
             const uint32_t idx = (uint32_t)e & 0xFFFFFu;
@@ -210,6 +237,37 @@ void hs_set_source(hs_batch* b, int laser_id, int enabled, int agent_id) {
     b->map.compile();
     dispatch(b, M_SOURCES, 0, 0, 0, 0, nullptr, nullptr, old);
 }
+// LaserSource.set_colour / enable / disable per environment (lle_batch_set_sources; kernels.hip MODE_ENV_SOURCES)
+void hs_set_sources(hs_batch* b, const uint8_t* colours, const uint32_t* enabled, const uint8_t* mask) {
+    const MapHeader& h = b->map.header;
+    const int A = (int)h.A, L = (int)h.L;
+    if (!b->per_env) {
+        b->per_env = true;
+        b->src_colour.assign((size_t)b->n * 32, 0);
+        b->src_enabled.assign((size_t)b->n, h.enabled_mask);
+        for (int64_t env = 0; env < b->n; env++)
+            for (int l = 0; l < L; l++) b->src_colour[env * 32 + l] = h.beam_colour[l];
+    }
+    for (int64_t env = 0; env < b->n; env++) {
+        if (mask && !mask[env]) continue;
+        bool bad = false;
+        if (colours)
+            for (int l = 0; l < L; l++) bad |= colours[env * L + l] >= A;
+        b->err[env] = bad ? ENV_INVALID_COLOUR : 0;
+        if (bad) continue;
+        const uint32_t lmask = L >= 32 ? 0xFFFFFFFFu : ((1u << L) - 1u);
+        const uint32_t new_en = enabled ? (enabled[env] & lmask) : b->src_enabled[env];
+        for (int l = 0; l < L; l++) {
+            const bool was = (b->src_enabled[env] >> l) & 1u, now = (new_en >> l) & 1u;
+            if (was && !now) b->beams[env * L + l] = 0u;                 // LaserBeam::disable (laser.rs:74-77)
+            if (!was && now) b->beams[env * L + l] = h.beam_full[l];     // LaserBeam::enable  (laser.rs:69-72)
+            if (colours) b->src_colour[env * 32 + l] = colours[env * L + l];
+        }
+        b->src_enabled[env] = new_en;
+    }
+    dispatch(b, M_OBSERVE, 0, 0, 0, 0, nullptr, nullptr, 0);
+}
+
 // ---- the other observation builders: the same per-element logic (observers_logic.hpp) and the same view tables
 // (Map::compile_view) as observers.hip, evaluated on the host.  Output is the unpadded logical array.
 static void view_rows(hs_batch* b, int kind, int param, int8_t* out, int64_t env_pitch, bool* supported) {
