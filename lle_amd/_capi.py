@@ -36,7 +36,7 @@ EXPORTS = [
     "lle_abi_version", "lle_last_status", "lle_last_error", "lle_action_hash",
     "lle_map_parse", "lle_map_level", "lle_map_free", "lle_map_get_info", "lle_map_positions", "lle_map_sources",
     "lle_map_set_source", "lle_map_laser_tiles", "lle_map_world_string",
-    "lle_batch_arena_bytes", "lle_batch_create", "lle_batch_free", "lle_batch_get_buffer", "lle_batch_n_envs",
+    "lle_batch_arena_bytes", "lle_batch_create", "lle_batch_arena_bytes_multi", "lle_batch_create_multi", "lle_batch_n_maps", "lle_batch_free", "lle_batch_get_buffer", "lle_batch_n_envs",
     "lle_batch_reset", "lle_batch_step", "lle_batch_rollout", "lle_batch_set_state", "lle_batch_update_sources", "lle_batch_observe",
     "lle_batch_snapshot_bytes", "lle_batch_snapshot", "lle_batch_restore",
     "lle_batch_set_sources", "lle_batch_obs_desc", "lle_batch_observe_as", "lle_batch_available_actions",
@@ -119,6 +119,12 @@ def lib():
     L.lle_batch_arena_bytes.argtypes = [vp, i64]
     L.lle_batch_create.restype = vp
     L.lle_batch_create.argtypes = [vp, i64, i32, vp, i64, vp]
+    L.lle_batch_arena_bytes_multi.restype = i64
+    L.lle_batch_arena_bytes_multi.argtypes = [C.POINTER(vp), i32, i64]
+    L.lle_batch_create_multi.restype = vp
+    L.lle_batch_create_multi.argtypes = [C.POINTER(vp), i32, i64, i32, vp, i64, vp]
+    L.lle_batch_n_maps.restype = i32
+    L.lle_batch_n_maps.argtypes = [vp]
     L.lle_batch_free.argtypes = [vp]
     L.lle_batch_get_buffer.restype = i32
     L.lle_batch_get_buffer.argtypes = [vp, i32, C.POINTER(BufferDesc)]

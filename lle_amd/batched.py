@@ -35,22 +35,39 @@ class BatchedWorld:
     """
 
     def __init__(self, map_or_text, n_envs, device=None, envs_per_wave=None):
+        """`map_or_text`: a Map / map text, or a LIST of them for a batch of several maps -- map m then owns the envs
+        [m * n_envs / len(maps), (m + 1) * n_envs / len(maps)); the maps must agree on height, width and the numbers of
+        agents, sources and gems, and each must own a multiple of 64 envs."""
         _require_gpu()
-        self.map = map_or_text if isinstance(map_or_text, Map) else Map(map_or_text)
+        many = isinstance(map_or_text, (list, tuple))
+        self.maps = [m if isinstance(m, Map) else Map(m) for m in (map_or_text if many else [map_or_text])]
+        self.map = self.maps[0]  # common dimensions
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = torch.device(device)
         self.n_envs = int(n_envs)
         L = _capi.lib()
-        nbytes = L.lle_batch_arena_bytes(self.map.h, self.n_envs)
+        if many:
+            if self.n_envs % len(self.maps) != 0:
+                raise ValueError("n_envs must be a multiple of the number of maps")
+            self.envs_per_map = self.n_envs // len(self.maps)
+            handles = (C.c_void_p * len(self.maps))(*[m.h for m in self.maps])
+            nbytes = L.lle_batch_arena_bytes_multi(handles, len(self.maps), self.envs_per_map)
+        else:
+            self.envs_per_map = self.n_envs
+            nbytes = L.lle_batch_arena_bytes(self.map.h, self.n_envs)
         if nbytes <= 0:
             raise RuntimeError(L.lle_last_error().decode())
         with torch.cuda.device(self.device):
             self.arena = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
             skew = (-self.arena.data_ptr()) % 256
             self._base = self.arena[skew:skew + nbytes]
-            self.h = L.lle_batch_create(self.map.h, self.n_envs, self.device.index or 0, self._base.data_ptr(), nbytes,
-                                        self._stream())
+            if many:
+                self.h = L.lle_batch_create_multi(handles, len(self.maps), self.envs_per_map, self.device.index or 0,
+                                                  self._base.data_ptr(), nbytes, self._stream())
+            else:
+                self.h = L.lle_batch_create(self.map.h, self.n_envs, self.device.index or 0, self._base.data_ptr(), nbytes,
+                                            self._stream())
         if not self.h:
             raise RuntimeError(f"lle_batch_create failed: {L.lle_last_error().decode()}")
         if envs_per_wave is not None:

@@ -46,12 +46,14 @@ struct Layout {
     int64_t bytes[LLE_BUF_COUNT];
     int64_t off_tables;
     int64_t off_init;
+    int64_t table_stride;     // bytes between the table blobs of consecutive maps
     int64_t off_env_init[5];  // per-env reset state (pos, bits, gems, beams, avail), used with per-env sources
     int64_t total;
     int64_t n_stat_blocks;
 };
 
-Layout make_layout(const MapHeader& h, int64_t n) {
+// `h`: the common header (dimensions; table sizes = the largest of the batch's maps); n_maps blobs and reset records
+Layout make_layout(const MapHeader& h, int64_t n, int64_t n_maps = 1) {
     Layout l{};
     const int64_t L = h.L;
     const int64_t A = agent_stride((int)h.A, (int)h.L);  // per-agent buffers are strided by the kernel's agent bound
@@ -78,9 +80,10 @@ Layout make_layout(const MapHeader& h, int64_t n) {
     sz[LLE_BUF_SRC_ENABLED] = n_pad * 4;
     int64_t off = 0;
     l.off_tables = off;
-    off = align_up(off + h.blob_capacity + h.ext_bytes);
+    l.table_stride = align_up((int64_t)h.blob_capacity + h.ext_bytes);
+    off = align_up(off + n_maps * l.table_stride);
     l.off_init = off;
-    off = align_up(off + (int64_t)sizeof(InitRecord));
+    off = align_up(off + n_maps * (int64_t)sizeof(InitRecord));
     for (int k = 0; k < LLE_BUF_COUNT; k++) {
         l.off[k] = off;
         l.bytes[k] = sz[k];
@@ -107,10 +110,14 @@ struct lle_batch {
     BatchPtrs ptrs;
     uint32_t envs_per_wave;
     bool per_env_sources;  // lle_batch_set_sources was called: colours / enabled flags / reset state live per env
-    // observation views (layered-padded / perspective): the map they are compiled from, and the device blobs compiled
-    // so far, keyed by (kind, param); dropped when the sources change
-    Map map;
-    struct View { ViewHeader hdr; uint8_t* dev; };
+    // batches of several maps (lle_batch_create_multi): map m owns envs [m * envs_per_map, (m + 1) * envs_per_map);
+    // `hdr` then holds the common dimensions and the LARGEST table sizes.  One map: maps.size() == 1, envs_per_map = 0.
+    std::vector<Map> maps;
+    int64_t envs_per_map;
+    uint32_t worst_table_bytes;  // largest table section any recolouring of any map can need (LDS check)
+    // observation views (layered-padded / perspective): compiled from the maps, and the device blobs compiled so far
+    // (one per map, `stride` bytes apart), keyed by (kind, param); dropped when the sources change
+    struct View { ViewHeader hdr; uint8_t* dev; uint32_t stride; };
     std::map<std::pair<int, int>, View> views;
 };
 
@@ -263,6 +270,8 @@ static int launch(lle_batch* b, int mode, LaunchArgs K, void* stream) {
     K.env_base = 0;
     K.env_limit = b->n_envs;
     if (b->per_env_sources) K.flags |= LAUNCH_PER_ENV_SOURCES;
+    K.envs_per_map = b->envs_per_map;
+    K.table_stride = (uint32_t)b->layout.table_stride;
     if (mode == KMODE_STEP && !b->lane_per_env_step) {
         K.envs_per_wave = step_envs_per_wave(b->n_envs, (int)b->hdr.A);
         HIP_TRY(launch_step_kernel(b->hdr, b->ptrs, K, (hipStream_t)stream));
@@ -276,35 +285,39 @@ static int launch(lle_batch* b, int mode, LaunchArgs K, void* stream) {
 // World::reset is deterministic for v1 maps, so its result is the same for every env: run it once on the hidden env
 // (slot n_envs) with the current tables and keep the result as the InitRecord the auto-reset path copies from.
 static int refresh_init_record(lle_batch* b, void* stream) {
-    LaunchArgs K{};
-    K.envs_per_wave = MIN_ENVS_PER_WAVE;
-    K.env_base = b->n_envs;
-    K.env_limit = b->n_envs + 1;
-    K.flags = STEP_NO_OBS;
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(launch_world_kernel(KMODE_RESET, b->hdr, b->ptrs, K, st));
-    uint8_t* rec = b->arena + b->layout.off_init;
     const int64_t n = b->n_envs, L = b->hdr.L, A = agent_stride((int)b->hdr.A, (int)b->hdr.L);
-    HIP_TRY(hipMemcpyAsync(rec + offsetof(InitRecord, pos), b->ptrs.pos + n * A, (size_t)A * 2, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(rec + offsetof(InitRecord, bits), b->ptrs.bits + n, 8, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(rec + offsetof(InitRecord, gems), b->ptrs.gems + n, 4, hipMemcpyDeviceToDevice, st));
-    if (L > 0)
-        HIP_TRY(hipMemcpyAsync(rec + offsetof(InitRecord, beams), b->ptrs.beams + n * L, (size_t)L * 4, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(rec + offsetof(InitRecord, avail), b->ptrs.avail + n * A, (size_t)A, hipMemcpyDeviceToDevice, st));
+    for (size_t m = 0; m < b->maps.size(); m++) {
+        LaunchArgs K{};
+        K.envs_per_wave = MIN_ENVS_PER_WAVE;
+        K.env_base = b->n_envs;
+        K.env_limit = b->n_envs + 1;
+        K.flags = STEP_NO_OBS;
+        K.table_stride = (uint32_t)b->layout.table_stride;
+        K.map_override = (uint32_t)m + 1u;
+        HIP_TRY(launch_world_kernel(KMODE_RESET, b->hdr, b->ptrs, K, st));
+        uint8_t* rec = b->arena + b->layout.off_init + (int64_t)m * (int64_t)sizeof(InitRecord);
+        HIP_TRY(hipMemcpyAsync(rec + offsetof(InitRecord, pos), b->ptrs.pos + n * A, (size_t)A * 2, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(rec + offsetof(InitRecord, bits), b->ptrs.bits + n, 8, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(rec + offsetof(InitRecord, gems), b->ptrs.gems + n, 4, hipMemcpyDeviceToDevice, st));
+        if (L > 0)
+            HIP_TRY(hipMemcpyAsync(rec + offsetof(InitRecord, beams), b->ptrs.beams + n * L, (size_t)L * 4, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(rec + offsetof(InitRecord, avail), b->ptrs.avail + n * A, (size_t)A, hipMemcpyDeviceToDevice, st));
+    }
     return LLE_OK;
 }
 
-static int create_impl(lle_batch* b, const lle_map* map, void* arena, int64_t arena_bytes, void* stream) {
+static int create_impl(lle_batch* b, void* arena, int64_t arena_bytes, void* stream) {
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
         return fail(LLE_ERR_NO_DEVICE, "no HIP device: lle_amd has no CPU execution path");
     if (b->device < 0 || b->device >= n_dev) return fail(LLE_ERR_ARG, "device_id out of range");
     HIP_TRY(hipSetDevice(b->device));
     MapHeader worst = b->hdr;
-    worst.lds_table_bytes += worst.blob_capacity - worst.blob_bytes;
+    worst.lds_table_bytes = b->worst_table_bytes;
     const uint32_t lds = kernel_lds_bytes(worst, 1);
     if (lds > 160 * 1024) return fail(LLE_ERR_UNSUPPORTED, "map tables need " + std::to_string(lds) + " B of LDS per wavefront (> 160 KiB)");
-    b->layout = make_layout(b->hdr, b->n_envs);
+    b->layout = make_layout(b->hdr, b->n_envs, (int64_t)b->maps.size());
     if (arena) {
         if (arena_bytes < b->layout.total || (reinterpret_cast<uintptr_t>(arena) % ALIGN) != 0)
             return fail(LLE_ERR_ARENA, "arena too small or not 256-byte aligned");
@@ -321,21 +334,44 @@ static int create_impl(lle_batch* b, const lle_map* map, void* arena, int64_t ar
     HIP_TRY(hipMemsetAsync(b->arena, 0, (size_t)b->layout.off[LLE_BUF_OBS], st));
     HIP_TRY(hipMemsetAsync(b->arena + b->layout.off[LLE_BUF_STATS], 0,
                            (size_t)(b->layout.total - b->layout.off[LLE_BUF_STATS]), st));
-    HIP_TRY(hipMemcpyAsync(b->arena + b->layout.off_tables, map->m.blob.data(), map->m.blob.size(), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));  // the blob is a host vector: make the copy complete before returning
+    for (size_t m = 0; m < b->maps.size(); m++)
+        HIP_TRY(hipMemcpyAsync(b->arena + b->layout.off_tables + (int64_t)m * b->layout.table_stride, b->maps[m].blob.data(),
+                               b->maps[m].blob.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));  // the blobs are host vectors: make the copies complete before returning
     int rc = refresh_init_record(b, stream);
     if (rc != LLE_OK) return rc;
     LaunchArgs K{};
     return launch(b, KMODE_RESET, K, stream);
 }
 
-lle_batch* lle_batch_create(const lle_map* map, int64_t n_envs, int device_id, void* arena, int64_t arena_bytes, void* stream) {
-    if (!map) { fail(LLE_ERR_NULL, "NULL map"); return nullptr; }
-    if (n_envs <= 0) { fail(LLE_ERR_ARG, "n_envs must be positive"); return nullptr; }
+// common header of a set of maps: the dimensions must agree; table sizes are the largest
+static int common_header(const lle_map* const* maps, int n_maps, MapHeader* out, uint32_t* worst_table_bytes) {
+    MapHeader h = maps[0]->m.header;
+    uint32_t worst = h.lds_table_bytes + (h.blob_capacity - h.blob_bytes);  // table section with the largest possible dyn table
+    for (int m = 1; m < n_maps; m++) {
+        const MapHeader& o = maps[m]->m.header;
+        if (o.H != h.H || o.W != h.W || o.A != h.A || o.L != h.L || o.G != h.G)
+            return fail(LLE_ERR_ARG, "the maps of a batch must agree on height, width and the numbers of agents, sources and gems");
+        worst = std::max(worst, o.lds_table_bytes + (o.blob_capacity - o.blob_bytes));
+        h.lds_table_bytes = std::max(h.lds_table_bytes, o.lds_table_bytes);
+        h.blob_capacity = std::max(h.blob_capacity, o.blob_capacity);
+        h.ext_bytes = std::max(h.ext_bytes, o.ext_bytes);
+        h.n_elems = std::max(h.n_elems, o.n_elems);
+        h.obs_supported = h.obs_supported && o.obs_supported;
+        h.max_layers = std::max(h.max_layers, o.max_layers);
+    }
+    *out = h;
+    if (worst_table_bytes) *worst_table_bytes = worst;
+    return LLE_OK;
+}
+
+static lle_batch* create_batch(const lle_map* const* maps, int n_maps, int64_t n_envs, int device_id, void* arena, int64_t arena_bytes,
+                               void* stream) {
     lle_batch* b = new (std::nothrow) lle_batch();
     if (!b) return nullptr;
-    b->hdr = map->m.header;
-    b->map = map->m;
+    if (common_header(maps, n_maps, &b->hdr, &b->worst_table_bytes) != LLE_OK) { delete b; return nullptr; }
+    for (int m = 0; m < n_maps; m++) b->maps.push_back(maps[m]->m);
+    b->envs_per_map = n_maps > 1 ? n_envs / n_maps : 0;
     b->n_envs = n_envs;
     b->device = device_id;
     b->arena = nullptr;
@@ -345,13 +381,43 @@ lle_batch* lle_batch_create(const lle_map* map, int64_t n_envs, int device_id, v
     // enough waves to cover the 256 CUs several times over, at most 32 envs per wave (measured best on level 6)
     b->envs_per_wave = 32;
     while (b->envs_per_wave > MIN_ENVS_PER_WAVE && n_envs / b->envs_per_wave < 2048) b->envs_per_wave /= 2;
-    if (create_impl(b, map, arena, arena_bytes, stream) != LLE_OK) {
+    if (create_impl(b, arena, arena_bytes, stream) != LLE_OK) {
         if (b->owns_arena && b->arena) (void)hipFree(b->arena);
         delete b;
         return nullptr;
     }
     return b;
 }
+
+lle_batch* lle_batch_create(const lle_map* map, int64_t n_envs, int device_id, void* arena, int64_t arena_bytes, void* stream) {
+    if (!map) { fail(LLE_ERR_NULL, "NULL map"); return nullptr; }
+    if (n_envs <= 0) { fail(LLE_ERR_ARG, "n_envs must be positive"); return nullptr; }
+    return create_batch(&map, 1, n_envs, device_id, arena, arena_bytes, stream);
+}
+
+int64_t lle_batch_arena_bytes_multi(const lle_map* const* maps, int n_maps, int64_t envs_per_map) {
+    if (!maps || n_maps <= 0 || envs_per_map <= 0) return fail(LLE_ERR_ARG, "bad arguments");
+    for (int m = 0; m < n_maps; m++)
+        if (!maps[m]) return fail(LLE_ERR_NULL, "NULL map");
+    MapHeader h;
+    int rc = common_header(maps, n_maps, &h, nullptr);
+    if (rc != LLE_OK) return rc;
+    return make_layout(h, envs_per_map * n_maps, n_maps).total;
+}
+
+lle_batch* lle_batch_create_multi(const lle_map* const* maps, int n_maps, int64_t envs_per_map, int device_id, void* arena,
+                                  int64_t arena_bytes, void* stream) {
+    if (!maps || n_maps <= 0) { fail(LLE_ERR_ARG, "no maps"); return nullptr; }
+    for (int m = 0; m < n_maps; m++)
+        if (!maps[m]) { fail(LLE_ERR_NULL, "NULL map"); return nullptr; }
+    if (envs_per_map <= 0 || (n_maps > 1 && envs_per_map % 64 != 0)) {
+        fail(LLE_ERR_ARG, "envs_per_map must be a positive multiple of 64 (a workgroup serves one map)");
+        return nullptr;
+    }
+    return create_batch(maps, n_maps, envs_per_map * n_maps, device_id, arena, arena_bytes, stream);
+}
+
+int lle_batch_n_maps(const lle_batch* b) { return b ? (int)b->maps.size() : 0; }
 
 static void drop_views(lle_batch* b) {
     for (auto& kv : b->views)
@@ -530,8 +596,9 @@ static int obs_desc(const lle_batch* b, int kind, int param, lle_obs_desc* d) {
             const int64_t C = 2 * (A + param) + 4;
             if (C * H * W >= (1 << 20)) return fail(LLE_ERR_UNSUPPORTED, "padded observation too large");
             set(1, {n, C, H, W}, align16(C * H * W));
-            for (const Source& s : b->map.sources)
-                if (s.agent_id >= C - (A + param)) d->supported = 0;
+            for (const Map& mp : b->maps)
+                for (const Source& s : mp.sources)
+                    if (s.agent_id >= C - (A + param)) d->supported = 0;
             return LLE_OK;
         }
         case LLE_OBS_PERSPECTIVE: {
@@ -544,8 +611,9 @@ static int obs_desc(const lle_batch* b, int kind, int param, lle_obs_desc* d) {
         case LLE_OBS_PARTIAL: {
             if (param < 1 || param > 15 || param % 2 == 0) return fail(LLE_ERR_ARG, "square size must be odd, 1..15");
             set(1, {n, A, 2 * A + 3, (int64_t)param, (int64_t)param}, partial_pitch((int)A, param));
-            for (const Source& s : b->map.sources)
-                if (s.agent_id > (int)A + 1) d->supported = 0;  // LASER_0 + colour must be a layer (< 2A+3)
+            for (const Map& mp : b->maps)
+                for (const Source& s : mp.sources)
+                    if (s.agent_id > (int)A + 1) d->supported = 0;  // LASER_0 + colour must be a layer (< 2A+3)
             return LLE_OK;
         }
         case LLE_OBS_STATE:
@@ -565,26 +633,41 @@ int lle_batch_obs_desc(lle_batch* b, int kind, int param, lle_obs_desc* out) {
     return rc;
 }
 
-// Device copy of the view blob(s) for (kind, param).  (OBS_PERSPECTIVE, -1) = the blobs of all observers back to back.
+// Device copy of the view blob(s) for (kind, param), one per map, `stride` bytes apart.
+// (OBS_PERSPECTIVE, -1) = per map, the blobs of all observers back to back.
 static int get_view(lle_batch* b, int kind, int param, hipStream_t st, const lle_batch::View** out) {
     auto key = std::make_pair(kind, param);
     auto it = b->views.find(key);
     if (it == b->views.end()) {
-        std::vector<uint8_t> blob;
-        if (kind == LLE_OBS_PERSPECTIVE && param < 0) {
-            for (int k = 0; k < (int)b->hdr.A; k++) {
-                std::vector<uint8_t> one = b->map.compile_view(kind, k);
-                blob.insert(blob.end(), one.begin(), one.end());
+        std::vector<std::vector<uint8_t>> blobs;
+        size_t stride = 0;
+        for (const Map& mp : b->maps) {
+            std::vector<uint8_t> blob;
+            if (kind == LLE_OBS_PERSPECTIVE && param < 0) {
+                for (int k = 0; k < (int)b->hdr.A; k++) {
+                    std::vector<uint8_t> one = mp.compile_view(kind, k);
+                    blob.insert(blob.end(), one.begin(), one.end());
+                }
+            } else {
+                blob = mp.compile_view(kind, param);
             }
-        } else {
-            blob = b->map.compile_view(kind, param);
+            stride = std::max(stride, blob.size());
+            blobs.push_back(std::move(blob));
         }
         lle_batch::View v{};
-        std::memcpy(&v.hdr, blob.data(), sizeof v.hdr);
+        // the header the launcher sizes LDS with: the largest blob of the set
+        for (const auto& blob : blobs) {
+            ViewHeader vh;
+            std::memcpy(&vh, blob.data(), sizeof vh);
+            if (vh.blob_bytes >= v.hdr.blob_bytes) v.hdr = vh;
+        }
+        v.stride = (uint32_t)stride;
+        std::vector<uint8_t> all(stride * blobs.size(), 0);
+        for (size_t m = 0; m < blobs.size(); m++) std::memcpy(all.data() + m * stride, blobs[m].data(), blobs[m].size());
         void* p = nullptr;
-        HIP_TRY(hipMalloc(&p, blob.size()));
+        HIP_TRY(hipMalloc(&p, all.size()));
         v.dev = static_cast<uint8_t*>(p);
-        hipError_t e = hipMemcpyAsync(v.dev, blob.data(), blob.size(), hipMemcpyHostToDevice, st);
+        hipError_t e = hipMemcpyAsync(v.dev, all.data(), all.size(), hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);  // the blob is a host temporary
         if (e != hipSuccess) {
             (void)hipFree(p);
@@ -610,6 +693,8 @@ int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64
         K.envs_per_wave = b->envs_per_wave;
         K.env_limit = b->n_envs;
         K.flags = LAUNCH_PER_ENV_SOURCES;
+        K.envs_per_map = b->envs_per_map;
+        K.table_stride = (uint32_t)b->layout.table_stride;
         HIP_TRY(launch_world_kernel(KMODE_OBSERVE, b->hdr, P, K, (hipStream_t)stream));
         g_status = LLE_OK;
         return LLE_OK;
@@ -620,6 +705,7 @@ int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64
     hipStream_t st = (hipStream_t)stream;
     const MapHeader& h = b->hdr;
     const bool pes = b->per_env_sources;
+    const MapSel M{b->envs_per_map, (uint32_t)b->layout.table_stride, 0u};
     switch (kind) {
         case LLE_OBS_LAYERED:
         case LLE_OBS_PERSPECTIVE: {
@@ -633,14 +719,14 @@ int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64
                 rc = get_view(b, LLE_OBS_PERSPECTIVE, -1, st, &v);
                 if (rc != LLE_OK) return rc;
                 HIP_TRY(launch_view_observe(v->hdr, b->ptrs, v->dev, (uint32_t)n_views, static_cast<int8_t*>(out_dev),
-                                            (int64_t)n_views * h.obs_stride, (int64_t)h.obs_stride, b->n_envs, pes, h.n_elems, st));
+                                            (int64_t)n_views * h.obs_stride, (int64_t)h.obs_stride, b->n_envs, pes, h.n_elems, M, v->stride, st));
                 break;
             }
             for (int k = 0; k < n_views; k++) {  // big rows: one launch per observer, rows strided by A * obs_stride
                 rc = get_view(b, LLE_OBS_PERSPECTIVE, k, st, &v);
                 if (rc != LLE_OK) return rc;
                 HIP_TRY(launch_view_observe(v->hdr, b->ptrs, v->dev, 1u, static_cast<int8_t*>(out_dev) + (int64_t)k * h.obs_stride,
-                                            (int64_t)n_views * h.obs_stride, 0, b->n_envs, pes, h.n_elems, st));
+                                            (int64_t)n_views * h.obs_stride, 0, b->n_envs, pes, h.n_elems, M, v->stride, st));
             }
             break;
         }
@@ -649,11 +735,11 @@ int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64
             rc = get_view(b, kind, param, st, &v);
             if (rc != LLE_OK) return rc;
             HIP_TRY(launch_view_observe(v->hdr, b->ptrs, v->dev, 1u, static_cast<int8_t*>(out_dev), (int64_t)v->hdr.obs_stride, 0,
-                                        b->n_envs, pes, h.n_elems, st));
+                                        b->n_envs, pes, h.n_elems, M, v->stride, st));
             break;
         }
         case LLE_OBS_PARTIAL:
-            HIP_TRY(launch_partial_observe(h, b->ptrs, static_cast<int8_t*>(out_dev), param, b->n_envs, b->per_env_sources, st));
+            HIP_TRY(launch_partial_observe(h, b->ptrs, static_cast<int8_t*>(out_dev), param, b->n_envs, b->per_env_sources, M, st));
             break;
         default:
             HIP_TRY(launch_state_observe(h, b->ptrs, static_cast<float*>(out_dev), kind == LLE_OBS_NORMALIZED_STATE, b->n_envs, st));
@@ -666,13 +752,16 @@ int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64
 int lle_batch_available_actions(lle_batch* b, int walkable_lasers, uint8_t* out_dev, void* stream) {
     if (!b || !out_dev) return fail(LLE_ERR_NULL, "NULL argument");
     HIP_TRY(hipSetDevice(b->device));
-    HIP_TRY(launch_avail(b->hdr, b->ptrs, out_dev, walkable_lasers, b->n_envs, b->per_env_sources, (hipStream_t)stream));
+    const MapSel M{b->envs_per_map, (uint32_t)b->layout.table_stride, 0u};
+    HIP_TRY(launch_avail(b->hdr, b->ptrs, out_dev, walkable_lasers, b->n_envs, b->per_env_sources, M, (hipStream_t)stream));
     g_status = LLE_OK;
     return LLE_OK;
 }
 
 int lle_batch_update_sources(lle_batch* b, const lle_map* map, void* stream) {
     if (!b || !map) return fail(LLE_ERR_NULL, "NULL argument");
+    if (b->maps.size() != 1)
+        return fail(LLE_ERR_UNSUPPORTED, "lle_batch_update_sources serves one-map batches; use lle_batch_set_sources per environment");
     const MapHeader& nh = map->m.header;
     if (nh.H != b->hdr.H || nh.W != b->hdr.W || nh.A != b->hdr.A || nh.L != b->hdr.L || nh.G != b->hdr.G ||
         nh.blob_capacity != b->hdr.blob_capacity || nh.blob_bytes > nh.blob_capacity)
@@ -684,7 +773,7 @@ int lle_batch_update_sources(lle_batch* b, const lle_map* map, void* stream) {
     HIP_TRY(hipMemcpyAsync(b->arena + b->layout.off_tables, map->m.blob.data(), map->m.blob.size(), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
     b->hdr = nh;
-    b->map = map->m;
+    b->maps[0] = map->m;
     drop_views(b);  // their channel tables depend on the colours (the stream is idle: synchronised above)
     int rc = refresh_init_record(b, stream);
     if (rc != LLE_OK) return rc;

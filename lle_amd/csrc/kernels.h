@@ -23,14 +23,15 @@ int step_lm(int L);
 
 // observers.hip
 hipError_t launch_view_observe(const ViewHeader& v, const BatchPtrs& P, const uint8_t* views_dev, uint32_t n_views, int8_t* out,
-                               int64_t row_pitch, int64_t view_pitch, int64_t n_envs, bool pes, uint32_t n_elems, hipStream_t stream);
+                               int64_t row_pitch, int64_t view_pitch, int64_t n_envs, bool pes, uint32_t n_elems, MapSel M,
+                               uint32_t views_stride, hipStream_t stream);
 // do n_views views fit the LDS of one workgroup together?
 bool view_kernel_fits(const ViewHeader& v, uint32_t n_views, bool pes, uint32_t n_elems);
 uint32_t partial_pitch(int A, int k);
 hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t* out, int k, int64_t n_envs, bool per_env_sources,
-                                  hipStream_t stream);
+                                  MapSel M, hipStream_t stream);
 hipError_t launch_state_observe(const MapHeader& h, const BatchPtrs& P, float* out, int normalize, int64_t n_envs, hipStream_t stream);
 hipError_t launch_avail(const MapHeader& h, const BatchPtrs& P, uint8_t* out, int walkable_lasers, int64_t n_envs, bool per_env_sources,
-                        hipStream_t stream);
+                        MapSel M, hipStream_t stream);
 
 }  // namespace lle

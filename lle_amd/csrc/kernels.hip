@@ -1,12 +1,16 @@
 // kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the batched World.
 //
-// One workgroup = up to four 64-lane wavefronts sharing the map tables in LDS.  Phase 1 (lane = environment): load the env's packed state, run the
-// state machine of step_logic.hpp in registers, store the new state / events / availability masks.
-// Phase 2 (wave = one environment at a time): the wave owns a private LDS copy of the map's static observation;
-// for each of its environments it patches the few dynamic bytes (laser on/off bits, gems, agents) into that copy
-// and streams it to HBM with one 16-byte store per lane, i.e. 1 KiB fully coalesced per wave instruction.
-// The observation is >= 95 % of all bytes moved, so phase 2 is what the HBM roofline measures; phase 1 is
-// integer work hidden behind it by running several waves per SIMD.
+//   step_kernel<G, LM, PES>      World.step, the hot path: one LANE PER AGENT (G lanes per environment, 64/G environments
+//                                per wavefront), state machine on bitmasks with DPP / ds_swizzle group reductions.
+//   world_kernel<AM, LM, MODE>   one lane per environment, the state machine of step_logic.hpp: reset, set_state,
+//                                observe, source updates (and step, as a diagnostic).
+//
+// Both: a workgroup = up to four 64-lane wavefronts sharing ONE copy of the map tables in LDS.  Phase 1: load the
+// packed state, run the state machine in registers, store state / events / availability masks.  Phase 2 (wave = one
+// environment at a time): the wave owns a private LDS copy of the map's static observation; for each of its
+// environments it patches the few dynamic bytes (laser on/off bits, gems, agents) into that copy and streams it to HBM
+// with one 16-byte store per lane, i.e. 1 KiB fully coalesced per wave instruction (obs_stream.hpp).
+// The observation is >= 95 % of all bytes moved, so phase 2 is what the HBM roofline measures.
 //
 // No MFMA: there is no contraction anywhere on this path.
 #include <hip/hip_runtime.h>
@@ -84,7 +88,10 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
     // 400-byte header by value in the kernel-argument segment measured ~2.4 us SLOWER per launch: the kernarg
     // segment is fetched with a much longer latency than device memory.
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const MapHeader* __restrict__ hdr = reinterpret_cast<const MapHeader*>(P.tables);
+    const uint32_t map_idx = map_index_of(K, K.env_base + (int64_t)(blockIdx.x * (blockDim.x >> 6)) * K.envs_per_wave);
+    const uint8_t* __restrict__ tables = P.tables + (uint64_t)map_idx * K.table_stride;  // this workgroup's map
+    const InitRecord* __restrict__ initp = P.init + map_idx;
+    const MapHeader* __restrict__ hdr = reinterpret_cast<const MapHeader*>(tables);
     // A workgroup is 1, 2 or 4 wavefronts that share ONE copy of the cell / dyn tables in LDS (a quarter of the L2
     // traffic and of the copy latency of a per-wave copy); everything else is private to a wavefront.
     const uint32_t lane = threadIdx.x & 63u, wave_in_wg = threadIdx.x >> 6, waves_per_wg = blockDim.x >> 6;
@@ -103,11 +110,11 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
     } while (0)
     LLE_STAMP(0);
     const uint32_t tab_bytes = hdr->lds_table_bytes, tab_off = hdr->off_cell_lay;
-    copy_tables_to_lds(P.tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
+    copy_tables_to_lds(tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
     // per-environment sources (lle_batch_set_sources): the bare static observation + element list follow in LDS
     const bool pes = (K.flags & LAUNCH_PER_ENV_SOURCES) != 0;
     const uint32_t ext_bytes = pes ? hdr->ext_bytes : 0u;
-    if (pes) copy_tables_to_lds(P.tables + hdr->off_bare, lds + tab_bytes, ext_bytes, lane, wave_in_wg, waves_per_wg);
+    if (pes) copy_tables_to_lds(tables + hdr->off_bare, lds + tab_bytes, ext_bytes, lane, wave_in_wg, waves_per_wg);
     LLE_STAMP(7);
     __syncthreads();  // the only workgroup barrier: nothing is in flight yet but the loads above
     // ---- the env's packed state and (for auto-reset) the reset-state record, requested raw and together.  (Issued
@@ -133,7 +140,7 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
         for (int b = 0; b < LM; b++) s.beams[b] = (b < L) ? P.beams[env * L + b] : 0u;
     }
     InitRecord init;
-    if (MODE == MODE_STEP) init = *P.init;
+    if (MODE == MODE_STEP) init = *initp;
     const int CW = src_stride_of(L) / 4;  // colour words per env
     uint32_t env_enabled = hdr->enabled_mask, colw[LM / 4];
 #pragma unroll
@@ -164,7 +171,6 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
     const int8_t* bare = reinterpret_cast<const int8_t*>(lds + tab_bytes);
     const uint32_t* elems = reinterpret_cast<const uint32_t*>(lds + tab_bytes + (hdr->off_elems - hdr->off_bare));
     uint32_t* scratch = reinterpret_cast<uint32_t*>(tmpl + hdr->obs_stride);
-    const uint64_t obs_stride = hdr->obs_stride;
     {
         const uint4* pristine = pes ? reinterpret_cast<const uint4*>(bare) : reinterpret_cast<const uint4*>(lds + (hdr->off_template - tab_off));
         uint4* mine = reinterpret_cast<uint4*>(tmpl);
@@ -479,18 +485,28 @@ __device__ __forceinline__ void for_each_other(uint32_t v, F&& f) {
     }
 }
 
-// PES: every environment has its own source colours / enabled flags (lle_batch_set_sources) -- a separate instantiation,
-// so the default path is compiled exactly as before.
-template <int G, int LM, bool PES>
+// GEN: the general instantiation -- environments with their own source colours / enabled flags (lle_batch_set_sources)
+// and/or batches of several maps (lle_batch_create_multi).  A separate instantiation, so that the default path (one
+// map, sources of the map) is compiled exactly as before: every `PES` / `tables` / `initp` below folds to a constant.
+template <int G, int LM, bool GEN>
 __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K) {
+    const bool PES = GEN && (K.flags & LAUNCH_PER_ENV_SOURCES) != 0;
     // environments per wavefront: at most 64 / G; fewer (lanes left idle) when the batch is small, so that there
     // are enough wavefronts to spread phase 2 over the chip
     const uint32_t EPW = K.envs_per_wave < (uint32_t)(64 / G) ? K.envs_per_wave : (uint32_t)(64 / G);
     constexpr int NW = (2 * G + 7) / 8;             // 64-bit words of the event list (2 events per agent at most)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const MapHeader* __restrict__ hdr = reinterpret_cast<const MapHeader*>(P.tables);
     const uint32_t lane = threadIdx.x & 63u, wave_in_wg = threadIdx.x >> 6, waves_per_wg = blockDim.x >> 6;
     const uint32_t wave_id = blockIdx.x * waves_per_wg + wave_in_wg;
+    const uint8_t* __restrict__ tables = P.tables;
+    const InitRecord* __restrict__ initp = P.init;
+    if (GEN) {  // this workgroup's map (its envs never straddle two maps: the launcher sizes workgroups accordingly)
+        const uint32_t EPW0 = K.envs_per_wave < (uint32_t)(64 / G) ? K.envs_per_wave : (uint32_t)(64 / G);
+        const uint32_t map_idx = map_index_of(K, K.env_base + (int64_t)(blockIdx.x * waves_per_wg) * EPW0);
+        tables += (uint64_t)map_idx * K.table_stride;
+        initp += map_idx;
+    }
+    const MapHeader* __restrict__ hdr = reinterpret_cast<const MapHeader*>(tables);
     const int A = (int)hdr->A, L = (int)hdr->L, W = (int)hdr->W;
     const uint32_t a = lane & (G - 1), grp = lane / G;  // agent id, environment slot in the wave
     const int64_t As = agent_stride_of(A, L);           // env pitch of the per-agent buffers
@@ -504,9 +520,9 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
     LLE_STAMP(0);
 
     const uint32_t tab_bytes = hdr->lds_table_bytes, tab_off = hdr->off_cell_lay;
-    copy_tables_to_lds(P.tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
+    copy_tables_to_lds(tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
     const uint32_t ext_bytes = PES ? hdr->ext_bytes : 0u;
-    if (PES) copy_tables_to_lds(P.tables + hdr->off_bare, lds + tab_bytes, ext_bytes, lane, wave_in_wg, waves_per_wg);
+    if (PES) copy_tables_to_lds(tables + hdr->off_bare, lds + tab_bytes, ext_bytes, lane, wave_in_wg, waves_per_wg);
     LLE_STAMP(7);
     __syncthreads();  // the only workgroup barrier
 
@@ -527,8 +543,8 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
         pos = (uint32_t)P.pos[env * As + a];
         avail = (uint32_t)P.avail[env * As + a];
     }
-    uint64_t init_bits = P.init->bits;
-    uint32_t init_gems = P.init->gems;
+    uint64_t init_bits = initp->bits;
+    uint32_t init_gems = initp->gems;
     // per-environment sources: colours (4 per word), enabled mask, and the env's own reset state
     constexpr int CWM = LM / 4;
     const int CW = src_stride_of(L) / 4;
@@ -584,8 +600,8 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
         const bool over = env_ok && (alive != amask || arrived == amask);
         uint32_t ipos = pos, iav = avail;
         if (me) {
-            ipos = PES ? (uint32_t)P.init_pos[env * As + a] : (uint32_t)P.init->pos[a];
-            iav = PES ? (uint32_t)P.init_avail[env * As + a] : (uint32_t)P.init->avail[a];
+            ipos = PES ? (uint32_t)P.init_pos[env * As + a] : (uint32_t)initp->pos[a];
+            iav = PES ? (uint32_t)P.init_avail[env * As + a] : (uint32_t)initp->avail[a];
         }
         pos = over ? ipos : pos;
         avail = over ? iav : avail;
@@ -595,7 +611,7 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
         gems = over ? init_gems : gems;
 #pragma unroll
         for (int b = 0; b < LM; b++)
-            if (b < L) beams[b] = over ? (PES ? P.init_beams[env_ok ? env * L + b : 0] : P.init->beams[b]) : beams[b];
+            if (b < L) beams[b] = over ? (PES ? P.init_beams[env_ok ? env * L + b : 0] : initp->beams[b]) : beams[b];
         was_reset = over ? 1u : 0u;
     }
 
@@ -630,7 +646,6 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
 #pragma unroll
     for (int k = 0; k < NW; k++) evw[k] = 0;
     uint32_t n_ev = 0;
-    uint32_t meta_fin = meta_cur;
 
     if (env_ok && err == 0) {
         // target cell (src/action.rs:18-26 on the packed i | j << 8 form); lanes without an agent keep a unique sentinel
@@ -647,7 +662,6 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
         uint64_t lay_new = cell_lay[new_cell];
         if (PES) lay_new = recolour_lay<CWM>(lay_new, colw);
         const uint32_t meta_new = cell_meta[new_cell];
-        meta_fin = meta_new;
         const uint32_t kind = meta_new & 7u;
         const uint32_t gbit = 1u << ((meta_new >> 3) & 31u);
 
@@ -862,11 +876,16 @@ uint32_t kernel_waves_per_wg(const MapHeader& h, bool pes) {
     return 1;
 }
 
-hipError_t launch_world_kernel(int mode, const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K, hipStream_t stream) {
+hipError_t launch_world_kernel(int mode, const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K_in, hipStream_t stream) {
+    LaunchArgs K = K_in;
+    const bool pes = (K.flags & LAUNCH_PER_ENV_SOURCES) != 0;
+    uint32_t wpw = kernel_waves_per_wg(h, pes);
+    if (K.envs_per_map && !K.map_override) {  // a workgroup's environments must belong to one map
+        while (K.envs_per_wave > 1 && K.envs_per_map % (int64_t)K.envs_per_wave != 0) K.envs_per_wave >>= 1;
+        while (wpw > 1 && K.envs_per_map % (int64_t)(wpw * K.envs_per_wave) != 0) wpw >>= 1;
+    }
     const uint32_t epw = K.envs_per_wave;
     const uint32_t n_waves = (uint32_t)((K.env_limit - K.env_base + epw - 1) / epw);
-    const bool pes = (K.flags & LAUNCH_PER_ENV_SOURCES) != 0;
-    const uint32_t wpw = kernel_waves_per_wg(h, pes);
     const uint32_t lds = kernel_lds_bytes(h, wpw, pes);
     switch (kernel_variant((int)h.A, (int)h.L)) {
         case 0: return launch_mode<4, 4>(mode, P, K, h, n_waves, wpw, lds, stream);
@@ -880,24 +899,24 @@ hipError_t launch_world_kernel(int mode, const MapHeader& h, const BatchPtrs& P,
 int step_group(int A) { return A <= 1 ? 1 : (A <= 2 ? 2 : (A <= 4 ? 4 : (A <= 8 ? 8 : 16))); }
 int step_lm(int L) { return L <= 4 ? 4 : (L <= 8 ? 8 : (L <= 16 ? 16 : 32)); }
 
-template <int G, int LM, bool PES>
+template <int G, int LM, bool GEN>
 static hipError_t launch_step_glp(const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
     dim3 grid((n_waves + wpw - 1) / wpw), block(64 * wpw);
     if (lds > 64 * 1024) {  // gfx950 has 160 KiB of LDS per CU; more than 64 KiB per workgroup is opt-in
         static uint32_t granted = 0;
         if (lds > granted) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<G, LM, PES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<G, LM, GEN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             granted = lds;
         }
     }
-    hipLaunchKernelGGL((step_kernel<G, LM, PES>), grid, block, lds, stream, P, K);
+    hipLaunchKernelGGL((step_kernel<G, LM, GEN>), grid, block, lds, stream, P, K);
     return hipGetLastError();
 }
 template <int G, int LM>
 static hipError_t launch_step_gl(const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
-    return (K.flags & LAUNCH_PER_ENV_SOURCES) ? launch_step_glp<G, LM, true>(P, K, n_waves, wpw, lds, stream)
-                                              : launch_step_glp<G, LM, false>(P, K, n_waves, wpw, lds, stream);
+    return (K.flags & LAUNCH_GENERAL) ? launch_step_glp<G, LM, true>(P, K, n_waves, wpw, lds, stream)
+                                      : launch_step_glp<G, LM, false>(P, K, n_waves, wpw, lds, stream);
 }
 template <int G>
 static hipError_t launch_step_g(int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
@@ -921,12 +940,20 @@ uint32_t step_envs_per_wave(int64_t n, int A) {
     return e;
 }
 
-hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K, hipStream_t stream) {
+hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K_in, hipStream_t stream) {
+    LaunchArgs K = K_in;
     const int G = step_group((int)h.A), lm = step_lm((int)h.L);
+    const bool pes = (K.flags & LAUNCH_PER_ENV_SOURCES) != 0;
+    if (pes || K.envs_per_map) K.flags |= LAUNCH_GENERAL;
+    uint32_t wpw = kernel_waves_per_wg(h, pes);
+    if (K.envs_per_map) {  // a workgroup's environments must belong to one map
+        const uint32_t cap = 64u / (uint32_t)G;
+        while (K.envs_per_wave > 1 && K.envs_per_map % (int64_t)(K.envs_per_wave < cap ? K.envs_per_wave : cap) != 0) K.envs_per_wave >>= 1;
+        const uint32_t e = K.envs_per_wave < cap ? K.envs_per_wave : cap;
+        while (wpw > 1 && K.envs_per_map % (int64_t)(wpw * e) != 0) wpw >>= 1;
+    }
     const uint32_t epw = K.envs_per_wave;
     const uint32_t n_waves = (uint32_t)((K.env_limit - K.env_base + epw - 1) / epw);
-    const bool pes = (K.flags & LAUNCH_PER_ENV_SOURCES) != 0;
-    const uint32_t wpw = kernel_waves_per_wg(h, pes);
     const uint32_t lds = kernel_lds_bytes(h, wpw, pes);
     switch (G) {
         case 1: return launch_step_g<1>(lm, P, K, n_waves, wpw, lds, stream);

@@ -20,6 +20,11 @@
 namespace lle {
 
 constexpr uint32_t OBS_ENVS_PER_WAVE = 16;
+
+// tables of the map that owns env (batches of several maps: lle_batch_create_multi; envs_per_map = 0: one map)
+__device__ __forceinline__ const uint8_t* tables_of(const BatchPtrs& P, const MapSel& M, int64_t env) {
+    return P.tables + (M.envs_per_map ? (uint64_t)env / (uint64_t)M.envs_per_map : 0ull) * M.table_stride;
+}
 constexpr uint32_t OBS_LDS_LIMIT = 160 * 1024;
 
 // ---------------------------------------------------------------------------------------------- layered views
@@ -31,18 +36,21 @@ constexpr uint32_t OBS_LDS_LIMIT = 160 * 1024;
 // every env writes its laser / gem bytes through the view's colour -> layer table (write_observations_env).
 __global__ void __launch_bounds__(256) view_observe_kernel(BatchPtrs P, const uint8_t* __restrict__ views, uint32_t n_views,
                                                            int8_t* __restrict__ out, int64_t row_pitch, int64_t view_pitch,
-                                                           int64_t env_base, int64_t env_limit, int pes) {
+                                                           int64_t env_base, int64_t env_limit, int pes, MapSel M, uint32_t views_stride) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const ViewHeader* __restrict__ gh = reinterpret_cast<const ViewHeader*>(views);
-    const MapHeader* __restrict__ mh = reinterpret_cast<const MapHeader*>(P.tables);
     const uint32_t lane = threadIdx.x & 63u, wave_in_wg = threadIdx.x >> 6, waves_per_wg = blockDim.x >> 6;
     const uint32_t wave_id = blockIdx.x * waves_per_wg + wave_in_wg;
+    const int64_t wg_env0 = env_base + (int64_t)(blockIdx.x * waves_per_wg) * OBS_ENVS_PER_WAVE;
+    const uint8_t* __restrict__ map_tables = tables_of(P, M, wg_env0);   // this workgroup's map and its views
+    views += (M.envs_per_map ? (uint64_t)wg_env0 / (uint64_t)M.envs_per_map : 0ull) * views_stride;
+    const ViewHeader* __restrict__ gh = reinterpret_cast<const ViewHeader*>(views);
+    const MapHeader* __restrict__ mh = reinterpret_cast<const MapHeader*>(map_tables);
     const uint32_t blob_bytes = gh->blob_bytes;
     copy_tables_to_lds(views, lds, blob_bytes * n_views, lane, wave_in_wg, waves_per_wg);
     const uint32_t n_elems = pes ? mh->n_elems : 0u, elem_bytes = (n_elems * 4u + 15u) & ~15u;
     uint32_t* elems = reinterpret_cast<uint32_t*>(lds + blob_bytes * n_views);
     if (pes) {
-        const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(P.tables + mh->off_elems);
+        const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(map_tables + mh->off_elems);
         for (uint32_t i = threadIdx.x; i < n_elems; i += blockDim.x) elems[i] = src[i];
     }
     __syncthreads();
@@ -106,15 +114,16 @@ __global__ void __launch_bounds__(256) view_observe_kernel(BatchPtrs P, const ui
 // Per environment the wave clears its row with 16-byte LDS stores, every lane evaluates its window cells (only
 // non-zero bytes are written), and the row is streamed as 16 B per lane.
 __global__ void __launch_bounds__(256) partial_observe_kernel(BatchPtrs P, int8_t* __restrict__ out, int k, uint32_t pitch,
-                                                              int64_t env_base, int64_t env_limit, int per_env_sources) {
+                                                              int64_t env_base, int64_t env_limit, int per_env_sources, MapSel M) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const MapHeader* __restrict__ hdr = reinterpret_cast<const MapHeader*>(P.tables);
     const uint32_t lane = threadIdx.x & 63u, wave_in_wg = threadIdx.x >> 6, waves_per_wg = blockDim.x >> 6;
     const uint32_t wave_id = blockIdx.x * waves_per_wg + wave_in_wg;
+    const uint8_t* __restrict__ tables = tables_of(P, M, env_base + (int64_t)(blockIdx.x * waves_per_wg) * OBS_ENVS_PER_WAVE);
+    const MapHeader* __restrict__ hdr = reinterpret_cast<const MapHeader*>(tables);
     const int A = (int)hdr->A, L = (int)hdr->L;
     const int64_t As = agent_stride_of(A, L);
     const uint32_t tab_bytes = hdr->lds_table_bytes, tab_off = hdr->off_cell_lay;
-    copy_tables_to_lds(P.tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
+    copy_tables_to_lds(tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
     const uint32_t kk = (uint32_t)(k * k), units = (uint32_t)A * kk, row_bytes = units * (uint32_t)(2 * A + 3);
     const uint32_t unit_bytes = (units * 4u + 15u) & ~15u;
     uint32_t* unit_tab = reinterpret_cast<uint32_t*>(lds + tab_bytes);
@@ -169,7 +178,7 @@ __global__ void __launch_bounds__(256) partial_observe_kernel(BatchPtrs P, int8_
 
 // ---------------------------------------------------------------------------------------------- state vector
 __global__ void __launch_bounds__(256) state_observe_kernel(BatchPtrs P, float* __restrict__ out, int normalize, int64_t n_envs) {
-    const MapHeader* __restrict__ hdr = reinterpret_cast<const MapHeader*>(P.tables);
+    const MapHeader* __restrict__ hdr = reinterpret_cast<const MapHeader*>(P.tables);  // dimensions are common to all maps
     const int A = (int)hdr->A, G = (int)hdr->G, L = (int)hdr->L;
     const int64_t As = agent_stride_of(A, L);
     const int len = 3 * A + G;
@@ -182,17 +191,19 @@ __global__ void __launch_bounds__(256) state_observe_kernel(BatchPtrs P, float* 
 
 // ---------------------------------------------------------------------------------------------- availability bools
 __global__ void __launch_bounds__(256) avail_kernel(BatchPtrs P, uint8_t* __restrict__ out, int walkable_lasers, int64_t n_envs,
-                                                    int per_env_sources) {
-    const MapHeader* __restrict__ hdr = reinterpret_cast<const MapHeader*>(P.tables);
-    const int A = (int)hdr->A, L = (int)hdr->L;
+                                                    int per_env_sources, MapSel M) {
+    const MapHeader* __restrict__ hdr0 = reinterpret_cast<const MapHeader*>(P.tables);
+    const int A = (int)hdr0->A, L = (int)hdr0->L;
     const int64_t As = agent_stride_of(A, L);
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_envs * A) return;
     const int64_t env = idx / A;
+    const uint8_t* __restrict__ tables = tables_of(P, M, env);
+    const MapHeader* __restrict__ hdr = reinterpret_cast<const MapHeader*>(tables);
     const int a = (int)(idx - env * A);
     ObsTables T;
-    T.cell_lay = reinterpret_cast<const uint64_t*>(P.tables + hdr->off_cell_lay);
-    T.cell_meta = reinterpret_cast<const uint32_t*>(P.tables + hdr->off_cell_meta);
+    T.cell_lay = reinterpret_cast<const uint64_t*>(tables + hdr->off_cell_lay);
+    T.cell_meta = reinterpret_cast<const uint32_t*>(tables + hdr->off_cell_meta);
     T.beam_colour = per_env_sources ? P.src_colour + env * src_stride_of(L) : hdr->beam_colour;
     T.A = A; T.H = (int)hdr->H; T.W = (int)hdr->W;
     const uint32_t m = avail_bools(T, P.pos + env * As, P.beams + env * L, a, (uint32_t)P.avail[env * As + a], walkable_lasers != 0);
@@ -221,9 +232,16 @@ bool view_kernel_fits(const ViewHeader& v, uint32_t n_views, bool pes, uint32_t 
     return view_lds(v, n_views, 1, pes, n_elems) <= OBS_LDS_LIMIT;
 }
 
+// workgroups must not straddle two maps: envs_per_map is a multiple of 64 = 4 waves x OBS_ENVS_PER_WAVE
+static uint32_t cap_wpw(uint32_t wpw, const MapSel& M) {
+    while (wpw > 1 && M.envs_per_map && M.envs_per_map % (int64_t)(wpw * OBS_ENVS_PER_WAVE) != 0) wpw >>= 1;
+    return wpw;
+}
+
 hipError_t launch_view_observe(const ViewHeader& v, const BatchPtrs& P, const uint8_t* views_dev, uint32_t n_views, int8_t* out,
-                               int64_t row_pitch, int64_t view_pitch, int64_t n_envs, bool pes, uint32_t n_elems, hipStream_t stream) {
-    uint32_t wpw = 4;
+                               int64_t row_pitch, int64_t view_pitch, int64_t n_envs, bool pes, uint32_t n_elems, MapSel M,
+                               uint32_t views_stride, hipStream_t stream) {
+    uint32_t wpw = cap_wpw(4, M);
     while (wpw > 1 && view_lds(v, n_views, wpw, pes, n_elems) > OBS_LDS_LIMIT) wpw >>= 1;
     const uint32_t lds = view_lds(v, n_views, wpw, pes, n_elems);
     if (lds > OBS_LDS_LIMIT) return hipErrorInvalidValue;
@@ -232,19 +250,19 @@ hipError_t launch_view_observe(const ViewHeader& v, const BatchPtrs& P, const ui
     if (e != hipSuccess) return e;
     const uint32_t n_waves = (uint32_t)((n_envs + OBS_ENVS_PER_WAVE - 1) / OBS_ENVS_PER_WAVE);
     hipLaunchKernelGGL(view_observe_kernel, dim3((n_waves + wpw - 1) / wpw), dim3(64 * wpw), lds, stream, P, views_dev, n_views, out,
-                       row_pitch, view_pitch, (int64_t)0, n_envs, pes ? 1 : 0);
+                       row_pitch, view_pitch, (int64_t)0, n_envs, pes ? 1 : 0, M, views_stride);
     return hipGetLastError();
 }
 
 uint32_t partial_pitch(int A, int k) { return ((uint32_t)(A * (2 * A + 3) * k * k) + 15u) & ~15u; }
 
 hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t* out, int k, int64_t n_envs, bool per_env_sources,
-                                  hipStream_t stream) {
+                                  MapSel M, hipStream_t stream) {
     const uint32_t pitch = partial_pitch((int)h.A, k);
     const uint32_t As = (uint32_t)agent_stride_of((int)h.A, (int)h.L);
     const uint32_t priv = pitch + OBS_ENVS_PER_WAVE * (As / 2 + 1 + h.L) * 4u;
     const uint32_t shared = h.lds_table_bytes + (((uint32_t)(h.A * k * k) * 4u + 15u) & ~15u);
-    uint32_t wpw = 4;
+    uint32_t wpw = cap_wpw(4, M);
     while (wpw > 1 && shared + wpw * priv > OBS_LDS_LIMIT) wpw >>= 1;
     const uint32_t lds = shared + wpw * priv;
     if (lds > OBS_LDS_LIMIT) return hipErrorInvalidValue;
@@ -253,7 +271,7 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
     if (e != hipSuccess) return e;
     const uint32_t n_waves = (uint32_t)((n_envs + OBS_ENVS_PER_WAVE - 1) / OBS_ENVS_PER_WAVE);
     hipLaunchKernelGGL(partial_observe_kernel, dim3((n_waves + wpw - 1) / wpw), dim3(64 * wpw), lds, stream, P, out, k, pitch,
-                       (int64_t)0, n_envs, per_env_sources ? 1 : 0);
+                       (int64_t)0, n_envs, per_env_sources ? 1 : 0, M);
     return hipGetLastError();
 }
 
@@ -265,11 +283,11 @@ hipError_t launch_state_observe(const MapHeader& h, const BatchPtrs& P, float* o
 }
 
 hipError_t launch_avail(const MapHeader& h, const BatchPtrs& P, uint8_t* out, int walkable_lasers, int64_t n_envs, bool per_env_sources,
-                        hipStream_t stream) {
+                        MapSel M, hipStream_t stream) {
     const int64_t total = n_envs * (int64_t)h.A;
     if (total == 0) return hipSuccess;
     hipLaunchKernelGGL(avail_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, P, out, walkable_lasers, n_envs,
-                       per_env_sources ? 1 : 0);
+                       per_env_sources ? 1 : 0, M);
     return hipGetLastError();
 }
 

@@ -115,6 +115,7 @@ constexpr uint8_t ENV_INVALID_COLOUR = 0x43;
 constexpr uint32_t STEP_SAMPLE_ACTIONS = 1, STEP_AUTO_RESET = 2, STEP_NO_OBS = 4;
 constexpr uint32_t LAUNCH_PER_ENV_SOURCES = 0x10000;  // internal: the batch keeps colours / enabled flags per env
 constexpr uint32_t LAUNCH_FILL_DEFAULTS = 0x20000;    // internal (MODE_ENV_SOURCES): take them from the map header
+constexpr uint32_t LAUNCH_GENERAL = 0x80000;          // internal: the general step_kernel instantiation (per-env sources / several maps)
 constexpr uint32_t LAUNCH_ARRAYS_INVALID = 0x40000;   // internal (MODE_ENV_SOURCES): first call, nothing stored per env yet
 constexpr uint32_t ELEM_SOURCE = 0, ELEM_TILE = 1, ELEM_GEM = 2;
 
@@ -144,6 +145,11 @@ struct LaunchArgs {
     uint64_t* stamps;          // profiling aid: [n_blocks][8] s_memrealtime stamps (10 ns ticks) of lane 0, or NULL
     const uint8_t* colours_in;   // set_sources: optional u8[n][L] new colours
     const uint32_t* enabled_in;  // set_sources: optional u32[n] new enabled masks
+    // batches of several maps (lle_batch_create_multi): map m owns the envs [m * envs_per_map, (m + 1) * envs_per_map);
+    // its tables are BatchPtrs.tables + m * table_stride and its reset record BatchPtrs.init[m].  envs_per_map = 0:
+    // one map.  map_override = m + 1 forces map m (the hidden env that computes a map's reset record).
+    int64_t envs_per_map;
+    uint32_t table_stride, map_override;
 };
 
 // State of a freshly reset environment (identical for every env of a map: v1 maps have one start per agent).
@@ -194,6 +200,18 @@ struct BatchPtrs {
 __host__ __device__
 #endif
 inline int src_stride_of(int L) { return L <= 4 ? 4 : (L <= 8 ? 8 : (L <= 16 ? 16 : 32)); }
+
+// which map owns an env, for the observer kernels (same meaning as the LaunchArgs fields)
+struct MapSel { int64_t envs_per_map; uint32_t table_stride, pad; };
+
+// map index of the wave whose first env is env0 (see LaunchArgs.envs_per_map)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint32_t map_index_of(const LaunchArgs& K, int64_t env0) {
+    if (K.map_override) return K.map_override - 1u;
+    return K.envs_per_map ? (uint32_t)((uint64_t)env0 / (uint64_t)K.envs_per_map) : 0u;
+}
 
 
 }  // namespace lle

@@ -1,0 +1,132 @@
+"""Batches of several maps (lle_batch_create_multi): map m owns a block of environments.  Every block is compared with
+its own oracle batch on the same global action stream, bit-exact, through step / auto-reset / reset / set_state /
+per-env sources / every observation builder."""
+import numpy as np
+import pytest
+
+from tests.observer_checks import compare_all
+from tests.parity_util import assert_state_equal, assert_step_equal, unpack_engine
+
+pytestmark = pytest.mark.gpu
+
+
+def _maps(k, **kw):
+    from lle_amd import mapgen
+    return [mapgen.generate(seed=100 + s, **kw) for s in range(k)]
+
+
+def dims_of(ob):
+    return (ob.A, ob.G, ob.Ls, ob.beam_stride, ob.C, ob.H, ob.W)
+
+
+def check_blocks(bw, obs, osteps, per, where):
+    bufs = bw.host_buffers()
+    for m, ob in enumerate(obs):
+        sl = slice(m * per, (m + 1) * per)
+        eng = unpack_engine({k: v[sl] for k, v in bufs.items()}, *dims_of(ob))
+        if osteps is not None:
+            assert_step_equal(eng, osteps[m], f"{where} map {m}")
+        assert_state_equal(eng, ob.dump(), f"{where} map {m}")
+
+
+@pytest.mark.parametrize("shape", [dict(height=9, width=11, n_agents=3, n_lasers=4, n_gems=3, n_voids=2),
+                                   dict(height=16, width=16, n_agents=6, n_lasers=7, n_gems=5, n_voids=3),
+                                   dict(height=6, width=7, n_agents=1, n_lasers=2, n_gems=2, n_voids=1)])
+def test_blocks_of_maps_match_their_oracles(oracle_mod, shape):
+    import torch
+
+    from lle_amd import BatchedWorld
+
+    texts = _maps(5, **shape)
+    per = 192  # a multiple of 64, not of 256: workgroups are narrowed so that none straddles two maps
+    n = per * len(texts)
+    bw = BatchedWorld(texts, n)
+    obs = [oracle_mod.OracleBatch(t, per) for t in texts]
+    check_blocks(bw, obs, None, per, "after creation")
+    for t in range(30):
+        auto = t >= 10
+        bw.step(sample=True, auto_reset=auto, seed=8, t=t, env_offset=1000)
+        osteps = [ob.step(None, auto_reset=auto, seed=8, t=t, env_offset=1000 + m * per) for m, ob in enumerate(obs)]
+        check_blocks(bw, obs, osteps, per, f"t={t}")
+    # masked reset, then the fused rollout against single steps of a twin
+    rng = np.random.default_rng(1)
+    mask = (rng.random(n) < 0.5).astype(np.uint8)
+    bw.reset(torch.from_numpy(mask))
+    for m, ob in enumerate(obs):
+        for e in np.nonzero(mask[m * per:(m + 1) * per])[0]:
+            ob.world(int(e)).reset()
+    check_blocks(bw, obs, None, per, "after masked reset")
+    twin = BatchedWorld(texts, n)
+    twin.restore(bw.snapshot())
+    twin.rollout(5, auto_reset=True, seed=3, t=50)
+    for t in range(50, 55):
+        bw.step(sample=True, auto_reset=True, seed=3, t=t)
+    for k in ("pos", "bits", "gems", "beams", "avail", "obs"):
+        assert torch.equal(getattr(bw, k), getattr(twin, k)), k
+
+
+def test_observers_and_per_env_sources_on_blocks_of_maps(oracle_mod):
+    import torch
+
+    from lle_amd import BatchedWorld
+
+    shape = dict(height=8, width=9, n_agents=3, n_lasers=3, n_gems=2, n_voids=1)
+    texts = _maps(4, **shape)
+    per = 64
+    n = per * len(texts)
+    bw = BatchedWorld(texts, n)
+    obs = [oracle_mod.OracleBatch(t, per) for t in texts]
+    for t in range(8):
+        bw.step(sample=True, seed=4, t=t)
+        for m, ob in enumerate(obs):
+            ob.step(None, seed=4, t=t, env_offset=m * per, want_obs=False)
+
+    def engine(m):
+        def observe(kind, param):
+            try:
+                out = bw.observe_as(kind, param)
+            except IndexError:
+                return None
+            torch.cuda.synchronize()
+            return out[m * per:(m + 1) * per].cpu().numpy()
+
+        def avail(walkable):
+            out = bw.available_actions(walkable)
+            torch.cuda.synchronize()
+            return out[m * per:(m + 1) * per].cpu().numpy()
+        return observe, avail
+
+    for m, ob in enumerate(obs):
+        compare_all(*engine(m), ob, range(0, per, 13), f"map {m}")
+
+    # per-environment sources on top: random colours / flags for every env of every map
+    A, L = obs[0].A, bw.map.n_sources
+    rng = np.random.default_rng(2)
+    colours = rng.integers(0, A, size=(n, L), dtype=np.uint8)
+    enabled = rng.integers(0, 1 << L, size=n).astype(np.int32)
+    bw.set_sources(torch.from_numpy(colours), torch.from_numpy(enabled))
+    for m, ob in enumerate(obs):
+        was = [bool(s[4]) for s in ob.world(0).sources()]
+        for e in range(per):
+            w = ob.world(e)
+            for l in range(L):
+                w.set_source(l, colour=int(colours[m * per + e, l]))
+                want = bool((int(enabled[m * per + e]) >> l) & 1)
+                if want != was[l]:
+                    w.set_source(l, enabled=want)
+    check_blocks(bw, obs, None, per, "after set_sources")
+    for t in range(20, 30):
+        bw.step(sample=True, auto_reset=True, seed=4, t=t)
+        osteps = [ob.step(None, auto_reset=True, seed=4, t=t, env_offset=m * per) for m, ob in enumerate(obs)]
+        check_blocks(bw, obs, osteps, per, f"per-env sources t={t}")
+    for m, ob in enumerate(obs):
+        compare_all(*engine(m), ob, range(0, per, 17), f"per-env sources map {m}")
+
+
+def test_mismatched_maps_are_refused():
+    from lle_amd import BatchedWorld
+
+    with pytest.raises(RuntimeError, match="agree"):
+        BatchedWorld(["S0 . X", "S0 . . X"], 128)
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        BatchedWorld(["S0 . X", "S0 X ."], 100)
