@@ -14,6 +14,9 @@ def __getattr__(name):
     if name == "BatchedWorld":
         from .batched import BatchedWorld
         return BatchedWorld
+    if name == "BatchedLLE":
+        from .env import BatchedLLE
+        return BatchedLLE
     if name in ("Layered", "LayeredPadded", "ObservationType", "StateGenerator", "FlattenedLayered", "PartialGenerator",
                 "AgentZeroPerspective"):
         from . import observations
@@ -21,6 +24,6 @@ def __getattr__(name):
     raise AttributeError(name)
 
 
-__all__ = ["Action", "Agent", "AgentZeroPerspective", "BatchedWorld", "Direction", "EventType", "FlattenedLayered", "Gem", "InvalidActionError", "InvalidLevelError",
+__all__ = ["Action", "Agent", "AgentZeroPerspective", "BatchedLLE", "BatchedWorld", "Direction", "EventType", "FlattenedLayered", "Gem", "InvalidActionError", "InvalidLevelError",
            "InvalidWorldStateError", "Laser", "LaserSource", "Layered", "LayeredPadded", "Map", "MapParseError",
            "ObservationType", "ParsingError", "PartialGenerator", "StateGenerator", "World", "WorldEvent", "WorldState"]

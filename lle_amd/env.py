@@ -1,0 +1,138 @@
+"""BatchedLLE: n lock-stepped `LLE` environments on one MI355X.
+
+The reference's `LLE` (python/lle/env/env.py:39-255) is a thin host class around `World.step`: events -> reward
+strategy, `compute_done`, observation / state generators, `available_actions` (optionally without moves into foreign
+lasers), `randomize_lasers` on reset.  Every one of those pieces already runs on the GPU behind the C ABI
+(include/lle_hip.h); this class strings them together with the reference's argument names and meanings and returns
+device tensors with a leading env axis.  No marlenv dependency, no extras generators, no PBRS shaping and no rendering
+ -- the hot path and its immediate callers only.
+
+    env = BatchedLLE(Map(level=6), 65536, obs_type="layered", randomize_lasers=True)
+    obs, state = env.reset()
+    step = env.step(actions)            # dict: obs, state, reward, done, available_actions
+"""
+import torch
+
+from . import _capi
+from .batched import BatchedWorld
+
+_OBS_KINDS = {
+    "layered": (_capi.LLE_OBS_LAYERED, 0), "flattened": (_capi.LLE_OBS_LAYERED, 0),
+    "partial3x3": (_capi.LLE_OBS_PARTIAL, 3), "partial5x5": (_capi.LLE_OBS_PARTIAL, 5), "partial7x7": (_capi.LLE_OBS_PARTIAL, 7),
+    "state": (_capi.LLE_OBS_STATE, 0), "normalized-state": (_capi.LLE_OBS_NORMALIZED_STATE, 0),
+    "perspective": (_capi.LLE_OBS_PERSPECTIVE, 0),
+    "layered-padded-1": (_capi.LLE_OBS_LAYERED_PADDED, 1), "layered-padded-2": (_capi.LLE_OBS_LAYERED_PADDED, 2),
+    "layered-padded-3": (_capi.LLE_OBS_LAYERED_PADDED, 3),
+}
+
+
+class BatchedLLE:
+    """Arguments follow `LLE.__init__` / `Builder` (python/lle/env/env.py:72-114, builder.py:30-116):
+    obs_type / state_type: ObservationType values ("layered", "flattened", "partial3x3", ..., "state", "normalized-state",
+    "perspective", "layered-padded[-k]"; padding_size for plain "layered-padded"); walkable_lasers; randomize_lasers;
+    multi_objective (MultiObjective instead of SingleObjective); death_strategy "end" only, like the reference."""
+
+    def __init__(self, maps, n_envs, obs_type="layered", state_type="state", walkable_lasers=True, randomize_lasers=False,
+                 multi_objective=False, death_strategy="end", padding_size=0, device=None, seed=0):
+        if death_strategy == "respawn":
+            raise NotImplementedError("Respawn strategy is not implemented yet")  # env.py:106-107
+        if death_strategy != "end":
+            raise ValueError(f"Unknown death strategy: {death_strategy}")
+        self.world = BatchedWorld(maps, n_envs, device=device)
+        self.n_envs, self.n_agents, self.n_actions = self.world.n_envs, self.world.map.n_agents, 5
+        self.obs_type, self.state_type = str(obs_type), str(state_type)
+        self._obs_kind = self._kind(self.obs_type, padding_size)
+        self._state_kind = self._kind(self.state_type, padding_size)
+        self.walkable_lasers = bool(walkable_lasers)
+        self.randomize_lasers = bool(randomize_lasers)
+        self.multi_objective = bool(multi_objective)
+        self._gen = torch.Generator(device=self.world.device)
+        self._gen.manual_seed(int(seed))
+        self._t = 0
+
+    @staticmethod
+    def _kind(name, padding_size):
+        if name == "layered-padded":
+            return (_capi.LLE_OBS_LAYERED_PADDED, int(padding_size))
+        if name == "rgb-image":
+            raise NotImplementedError("rendering is outside the scope of lle_amd (SURVEY.md section 2, row 11)")
+        try:
+            return _OBS_KINDS[name]
+        except KeyError:
+            raise ValueError(f"Unknown observation type: {name}") from None
+
+    # ------------------------------------------------------------------ LLE API, batched
+    def seed(self, seed_value):
+        """LLE.seed (env.py:245-247): seeds the colour randomisation (v1 maps have a single start per agent)."""
+        self._gen.manual_seed(int(seed_value))
+
+    @property
+    def done(self):
+        """bool [n]: LLE.compute_done (env.py:253-254) -- every agent arrived, or somebody died."""
+        return self.world.done.bool()
+
+    def reset(self, env_mask=None, seed=None, colours=None):
+        """LLE.reset (env.py:189-203) for every env, or those with env_mask != 0: world.reset(), then -- with
+        randomize_lasers -- a fresh colour in [0, n_agents) for every source (`colours` u8 [n, L] overrides the draw)."""
+        if seed is not None:
+            self.seed(seed)
+        w = self.world
+        w.reset(env_mask)
+        if self.randomize_lasers or colours is not None:
+            if colours is None:
+                colours = torch.randint(0, self.n_agents, (self.n_envs, w.map.n_sources), generator=self._gen,
+                                        device=w.device, dtype=torch.int64).to(torch.uint8)
+            w.set_sources(colours=colours, env_mask=env_mask)
+        return self.get_observation(), self.get_state()
+
+    def _observe(self, kind):
+        k, p = kind
+        if k == _capi.LLE_OBS_LAYERED:
+            return self.world.obs  # written by the step / reset / set_sources kernel itself
+        return self.world.observe_as(k, p)
+
+    def get_observation(self):
+        """The observation of every env with the reference's per-env shape behind the env axis.  Kinds whose agents all
+        see the same tensor carry ONE copy (the reference tiles it n_agents times, observations.py:151,266):
+        broadcast with `.unsqueeze(1).expand(-1, n_agents, ...)` if the learner wants the tiled layout."""
+        obs = self._observe(self._obs_kind)
+        return obs.flatten(1) if self.obs_type == "flattened" else obs
+
+    def get_state(self):
+        """LLE.get_state (env.py:205-206): the state generator's observation of agent 0."""
+        st = self._observe(self._state_kind)
+        if self._state_kind[0] in (_capi.LLE_OBS_PARTIAL, _capi.LLE_OBS_PERSPECTIVE):
+            st = st[:, 0]
+        return st.flatten(1) if self.state_type == "flattened" else st
+
+    def available_actions(self):
+        """LLE.available_actions (env.py:146-163): bool [n, n_agents, 5]."""
+        return self.world.available_actions(self.walkable_lasers)
+
+    def reward(self):
+        """Reward of the last step: SingleObjective float32 [n, 1] or MultiObjective float32 [n, 4]
+        (reward_strategy.py:58-75, 90-109)."""
+        if self.multi_objective:
+            return self.world.reward_multi_objective()
+        return self.world.reward_single_objective().unsqueeze(1)
+
+    def step(self, actions, auto_reset=False):
+        """LLE.step (env.py:165-187) for every env.  actions: integer tensor [n, n_agents] (Action values).
+        The reference refuses to step a finished environment (`Cannot step in a done environment`); here such an env
+        is the caller's to reset -- or pass auto_reset=True: an env that is done when the step starts is reset first
+        (with fresh colours under randomize_lasers), the usual vector-env convention.
+        Returns a dict of device tensors: obs, state, reward, done, available_actions, err (per-env error code of
+        World.step: 0 or 1 + the agent whose action was not available, the env then being left untouched)."""
+        w = self.world
+        actions = actions.to(w.device, torch.uint8).contiguous()
+        if auto_reset:
+            if self.randomize_lasers:
+                self.reset(env_mask=w.done.clone())
+                w.step(actions)
+            else:
+                w.step(actions, auto_reset=True)
+        else:
+            w.step(actions)
+        self._t += 1
+        return {"obs": self.get_observation(), "state": self.get_state(), "reward": self.reward(), "done": self.done,
+                "available_actions": self.available_actions(), "err": w.err}
