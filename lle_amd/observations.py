@@ -1,10 +1,11 @@
-"""Observation generators with the reference's interface (python/lle/observations.py), computed on the GPU.
+"""The reference's observation generators (python/lle/observations.py) over the GPU observer kernels.
 
-Every tensor is produced by a HIP kernel from the world's device state (layered: the step kernel / observe kernel;
-the others: lle_amd/csrc/observers.hip behind `lle_batch_observe_as`); the classes here only adapt it to the
-reference's `ObservationGenerator` protocol -- same class names, attributes (`A0`, `LASER_0`, `WALL`, ...), `shape`,
-`observe()` returning float32 with the reference's (n_agents, ...) leading axis, `to_world_state`.
-"rgb-image" is out of scope (rendering).
+Every tensor comes from a HIP kernel reading the world's device state (layered: the step / observe kernel; the other
+kinds: lle_amd/csrc/observers.hip behind `lle_batch_observe_as`).  The classes below only give those tensors the
+reference's protocol -- class names, the channel attributes (`A0`, `LASER_0`, `WALL`, ...), `shape`, `obs_type`,
+`observe()` as float32 with the (n_agents, ...) leading axis, `to_world_state` -- so that code written against
+`ObservationType(...).get_observation_generator(world)` runs unchanged.  "rgb-image" (rendering) is out of scope
+(SURVEY.md section 2 row 11).
 """
 from enum import Enum
 
@@ -15,7 +16,7 @@ from .world import WorldState
 
 
 class ObservationType(str, Enum):
-    """python/lle/observations.py:38-60"""
+    """The presets of python/lle/observations.py:38-60 (same names, same string values)."""
 
     NORMALIZED_STATE = "normalized-state"
     STATE = "state"
@@ -36,37 +37,56 @@ class ObservationType(str, Enum):
         return ObservationType(s)
 
     def get_observation_generator(self, world, padding_size=0):
-        """python/lle/observations.py:66-97"""
-        T = ObservationType
-        if self is T.NORMALIZED_STATE:
-            return StateGenerator(world, normalize=True)
-        if self is T.STATE:
-            return StateGenerator(world, normalize=False)
-        if self is T.RGB_IMAGE:
+        """Same dispatch as python/lle/observations.py:66-97, as a table."""
+        if self is ObservationType.RGB_IMAGE:
             raise NotImplementedError("rendering is outside the scope of lle_amd (SURVEY.md section 2, row 11)")
-        if self is T.LAYERED:
-            return Layered(world)
-        if self is T.FLATTENED:
-            return FlattenedLayered(world)
-        if self in (T.PARTIAL_3x3, T.PARTIAL_5x5, T.PARTIAL_7x7):
-            return PartialGenerator(world, {T.PARTIAL_3x3: 3, T.PARTIAL_5x5: 5, T.PARTIAL_7x7: 7}[self])
-        if self is T.LAYERED_PADDED:
-            return LayeredPadded(world, padding_size)
-        if self in (T.LAYERED_PADDED_1AGENT, T.LAYERED_PADDED_2AGENTS, T.LAYERED_PADDED_3AGENTS):
-            return LayeredPadded(world, {T.LAYERED_PADDED_1AGENT: 1, T.LAYERED_PADDED_2AGENTS: 2, T.LAYERED_PADDED_3AGENTS: 3}[self])
-        if self is T.AGENT0_PERSPECTIVE_LAYERED:
-            return AgentZeroPerspective(world)
-        raise ValueError(f"Unknown observation type: {self}")
+        make = {
+            "normalized-state": lambda: StateGenerator(world, normalize=True),
+            "state": lambda: StateGenerator(world, normalize=False),
+            "layered": lambda: Layered(world),
+            "flattened": lambda: FlattenedLayered(world),
+            "partial3x3": lambda: PartialGenerator(world, 3),
+            "partial5x5": lambda: PartialGenerator(world, 5),
+            "partial7x7": lambda: PartialGenerator(world, 7),
+            "layered-padded": lambda: LayeredPadded(world, padding_size),
+            "layered-padded-1": lambda: LayeredPadded(world, 1),
+            "layered-padded-2": lambda: LayeredPadded(world, 2),
+            "layered-padded-3": lambda: LayeredPadded(world, 3),
+            "perspective": lambda: AgentZeroPerspective(world),
+        }
+        return make[self.value]()
 
 
 class ObservationGenerator:
-    """python/lle/observations.py:100-143"""
+    """Protocol of python/lle/observations.py:100-143.  `_obs_type` / `_kind` / `_param` are set by the subclasses;
+    `_tile` says whether the reference repeats the tensor once per agent (np.tile) or already returns one per agent."""
+
+    _obs_type = None
+    _kind = None
+    _param = 0
+    _tile = True
 
     def __init__(self, world):
         self._world = world
 
+    @property
+    def obs_type(self):
+        return self._obs_type
+
+    @property
+    def shape(self):
+        return self._shape
+
+    def _device_tensor(self):
+        """One copy of the observation, from the GPU (IndexError where the reference raises it)."""
+        return self._world.observation(self._kind, self._param)
+
     def observe(self):
-        raise NotImplementedError
+        single = self._device_tensor().astype(np.float32)
+        if not self._tile:
+            return single
+        reps = getattr(self, "n_agents", self._world.n_agents)
+        return np.tile(single, (reps,) + (1,) * single.ndim)
 
     def get_state(self):
         return self.observe()[0]
@@ -78,84 +98,53 @@ class ObservationGenerator:
         self._world = new_world
 
     def reset(self):
-        """Static layers live in the device tables and follow the world's sources by themselves; nothing is cached here."""
+        """The static layers live in the device tables and follow the world's sources; nothing is cached on the host."""
 
 
 class StateGenerator(ObservationGenerator):
-    """python/lle/observations.py:137-175"""
+    """[i0, j0, ..., gems, alive], optionally divided by (height, width): python/lle/observations.py:137-175."""
+
+    _obs_type = ObservationType.STATE
 
     def __init__(self, world, normalize):
         super().__init__(world)
-        self.n_gems = world.n_gems
-        self.n_agents = world.n_agents
-        self.normalize = normalize
-        if normalize:
-            self.dimensions = np.array([world.height, world.width] * world.n_agents)
-        else:
-            self.dimensions = np.array([1.0, 1.0] * world.n_agents)
-
-    def observe(self):
-        kind = _capi.LLE_OBS_NORMALIZED_STATE if self.normalize else _capi.LLE_OBS_STATE
-        state = self._world.observation(kind)
-        return np.tile(state, reps=(self._world.n_agents, 1))
+        self.n_gems, self.n_agents, self.normalize = world.n_gems, world.n_agents, normalize
+        self._kind = _capi.LLE_OBS_NORMALIZED_STATE if normalize else _capi.LLE_OBS_STATE
+        self.dimensions = np.array(([world.height, world.width] if normalize else [1.0, 1.0]) * world.n_agents)
+        self._shape = (world.n_agents * 3 + world.n_gems,)
+        self.unit_size = 2
 
     def to_world_state(self, data):
-        data[: self._world.n_agents * 2] = data[: self._world.n_agents * 2] * self.dimensions
+        k = 2 * self._world.n_agents
+        data[:k] = data[:k] * self.dimensions
         return WorldState.from_array(data.tolist(), self.n_agents, self.n_gems)
-
-    @property
-    def obs_type(self):
-        return ObservationType.STATE
-
-    @property
-    def shape(self):
-        return (self._world.n_agents * 3 + self.n_gems,)
-
-    @property
-    def unit_size(self):
-        return 2
 
 
 class LayeredPadded(ObservationGenerator):
-    """python/lle/observations.py:196-271"""
+    """(2(A+p)+4, H, W) channels: agents, laser colours, WALL, VOID, GEM, EXIT (python/lle/observations.py:196-271)."""
+
+    _obs_type = ObservationType.LAYERED
+    _kind = _capi.LLE_OBS_LAYERED_PADDED
 
     def __init__(self, world, padding_size=0):
         super().__init__(world)
-        self.padding_size = padding_size
+        self._param = self.padding_size = int(padding_size)
         self.width, self.height = world.width, world.height
-        self.n_agents = world.n_agents + padding_size
-        self.A0 = 0
-        self.LASER_0 = self.A0 + self.n_agents
-        self.WALL = self.LASER_0 + self.n_agents
-        self.VOID = self.WALL + 1
-        self.GEM = self.VOID + 1
-        self.EXIT = self.GEM + 1
-        self._shape = (self.EXIT + 1, world.height, world.width)
-        self.ordered_gem_pos = sorted(gem.pos for gem in world.gems) if hasattr(world, "gems") else []
+        n = self.n_agents = world.n_agents + self.padding_size
+        self.A0, self.LASER_0, self.WALL, self.VOID, self.GEM, self.EXIT = 0, n, 2 * n, 2 * n + 1, 2 * n + 2, 2 * n + 3
+        self._shape = (2 * n + 4, world.height, world.width)
+        self.ordered_gem_pos = sorted(g.pos for g in world.gems)
 
-    @property
-    def shape(self):
-        return self._shape
-
-    @property
-    def obs_type(self):
-        return ObservationType.LAYERED
-
-    def _single(self):
+    def _device_tensor(self):
         if self.padding_size == 0:
-            return self._world.layered_observation()
-        return self._world.observation(_capi.LLE_OBS_LAYERED_PADDED, self.padding_size)
-
-    def observe(self):
-        obs = self._single().astype(np.float32)
-        return np.tile(obs, (self.n_agents, 1, 1, 1))
+            return self._world.layered_observation()  # the tensor the step kernel keeps up to date
+        return super()._device_tensor()
 
     def to_world_state(self, data):
-        """python/lle/observations.py:243-252 (assumes every agent alive)"""
-        _, i, j = np.nonzero(data[self.A0: self.A0 + self.n_agents])
-        agents_positions = [(int(i[n]), int(j[n])) for n in range(self.n_agents)]
-        gems_collected = [bool(data[self.GEM, gi, gj] == 0.0) for gi, gj in self.ordered_gem_pos]
-        return WorldState(agents_positions, gems_collected)
+        """observations.py:243-252 (assumes that every agent is alive)."""
+        _, rows, cols = np.nonzero(data[self.A0: self.A0 + self.n_agents])
+        positions = [(int(rows[k]), int(cols[k])) for k in range(self.n_agents)]
+        return WorldState(positions, [bool(data[self.GEM, i, j] == 0.0) for i, j in self.ordered_gem_pos])
 
 
 class Layered(LayeredPadded):
@@ -164,68 +153,47 @@ class Layered(LayeredPadded):
 
 
 class FlattenedLayered(ObservationGenerator):
-    """python/lle/observations.py:279-303"""
+    """The layered tensor as one row per agent (python/lle/observations.py:279-303)."""
+
+    _obs_type = ObservationType.FLATTENED
 
     def __init__(self, world):
         super().__init__(world)
         self.layered = Layered(world)
-        size = 1
-        for s in self.layered.shape:
-            size = size * s
-        self._shape = (size,)
+        self._shape = (int(np.prod(self.layered.shape)),)
+        self.unit_size = 0
 
     def observe(self):
         return self.layered.observe().reshape(self._world.n_agents, -1)
 
-    @property
-    def obs_type(self):
-        return ObservationType.FLATTENED
-
-    @property
-    def shape(self):
-        return self._shape
-
-    @property
-    def unit_size(self):
-        return 0
-
     def set_world(self, new_world):
         self.layered.set_world(new_world)
-        return super().set_world(new_world)
+        super().set_world(new_world)
 
 
 class PartialGenerator(ObservationGenerator):
-    """python/lle/observations.py:306-369"""
+    """(A, 2A+3, k, k): a k x k window around every agent (python/lle/observations.py:306-369)."""
+
+    _obs_type = ObservationType.PARTIAL_3x3
+    _kind = _capi.LLE_OBS_PARTIAL
+    _tile = False
 
     def __init__(self, world, square_size):
         super().__init__(world)
         assert square_size % 2 == 1, "Can only use odd numbers for the square size"
-        self.size = square_size
-        self._shape = (world.n_agents + world.n_agents + 3, self.size, self.size)
-        self._center = self.size // 2
-        self.WALL = world.n_agents
-        self.LASER_0 = self.WALL + 1
-        self.GEM = self.LASER_0 + world.n_agents
-        self.EXIT = self.GEM + 1
-
-    @property
-    def shape(self):
-        return self._shape
-
-    @property
-    def obs_type(self):
-        return ObservationType.PARTIAL_3x3
-
-    def observe(self):
-        return self._world.observation(_capi.LLE_OBS_PARTIAL, self.size).astype(np.float32)
+        a = world.n_agents
+        self._param = self.size = square_size
+        self._center = square_size // 2
+        self.WALL, self.LASER_0, self.GEM, self.EXIT = a, a + 1, 2 * a + 1, 2 * a + 2
+        self._shape = (2 * a + 3, square_size, square_size)
 
 
 class AgentZeroPerspective(Layered):
-    """python/lle/observations.py:372-395"""
+    """Observer k sees itself and its laser colour in channels 0 / LASER_0 (python/lle/observations.py:372-395)."""
 
-    @property
-    def obs_type(self):
-        return ObservationType.AGENT0_PERSPECTIVE_LAYERED
+    _obs_type = ObservationType.AGENT0_PERSPECTIVE_LAYERED
+    _kind = _capi.LLE_OBS_PERSPECTIVE
+    _tile = False
 
-    def observe(self):
-        return self._world.observation(_capi.LLE_OBS_PERSPECTIVE).astype(np.float32)
+    def _device_tensor(self):
+        return self._world.observation(self._kind, 0)
