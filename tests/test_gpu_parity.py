@@ -52,25 +52,26 @@ def test_envs_per_wave_variants(oracle_mod, epw):
 
 
 def test_config2_level1_batch4096(oracle_mod):
-    """BASELINE.json configs[1]: level 1, batch 4096, bit-exact."""
+    """BASELINE.json configs[1]: level 1, batch 4096, bit-exact over 256 steps (> 10^6 env-steps)."""
     from lle_amd import BatchedWorld
 
     n = 4096
     ob = oracle_mod.OracleBatch(LEVELS[1], n)
     bw = BatchedWorld(LEVELS[1], n)
-    for t in range(100):
+    for t in range(256):
         bw.step(sample=True, auto_reset=True, seed=1234, t=t)
         check(bw, ob, ob.step(None, auto_reset=True, seed=1234, t=t), f"t={t}")
 
 
 def test_config3_level6_batch65536(oracle_mod):
-    """BASELINE.json configs[2] at full size: level 6, batch 65536 + layered obs, bit-exact for 12 steps."""
+    """BASELINE.json configs[2] at full size: level 6, batch 65536 + layered obs, bit-exact for 32 steps
+    (> 2 x 10^6 env-steps: state, ordered events, availability, the full int8 observation of every env, every step)."""
     from lle_amd import BatchedWorld
 
     n = 65536
     ob = oracle_mod.OracleBatch(LEVELS[6], n)
     bw = BatchedWorld(LEVELS[6], n)
-    for t in range(12):
+    for t in range(32):
         bw.step(sample=True, auto_reset=True, seed=1234, t=t)
         check(bw, ob, ob.step(None, auto_reset=True, seed=1234, t=t), f"t={t}")
 
