@@ -9,7 +9,7 @@ from tests.parity_util import EXTRA_MAPS, assert_state_equal, assert_step_equal,
 
 pytestmark = pytest.mark.gpu
 
-MAPS = {"level6": LEVELS[6], "level5": LEVELS[5], "nested": EXTRA_MAPS["nested"], "three_beams": EXTRA_MAPS["three_beams"],
+MAPS = {"level6": LEVELS[6], "level5": LEVELS[5], "level1_no_lasers": LEVELS[1], "nested": EXTRA_MAPS["nested"], "three_beams": EXTRA_MAPS["three_beams"],
         "four_layers": EXTRA_MAPS["four_layers"], "q1": EXTRA_MAPS["q1"], "many_agents": EXTRA_MAPS["many_agents"],
         "gen_20_lasers": EXTRA_MAPS["gen_20_lasers"]}
 
