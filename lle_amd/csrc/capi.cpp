@@ -529,7 +529,7 @@ int lle_batch_rollout(lle_batch* b, uint32_t n_steps, uint32_t flags, uint64_t s
     K.flags = flags; K.seed = seed; K.t = t0; K.env_offset = env_offset; K.n_steps = n_steps;
     if (ring) {
         if (ring->ring_slots < 1 || !ring->obs || !ring->actions || !ring->reward) return fail(LLE_ERR_ARG, "incomplete ring");
-        K.ring_slots = (uint32_t)ring->ring_slots; K.ring_pos = ring->ring_pos; K.ring_env_count = b->n_envs;
+        K.ring_slots = (uint32_t)ring->ring_slots; K.ring_pos = ring->ring_pos % (uint64_t)ring->ring_slots; K.ring_env_count = b->n_envs;
         K.ring_obs = ring->obs; K.ring_actions = ring->actions; K.ring_reward = ring->reward;
     }
     return launch(b, KMODE_STEP, K, stream);

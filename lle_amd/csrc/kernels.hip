@@ -488,9 +488,19 @@ __device__ __forceinline__ void for_each_other(uint32_t v, F&& f) {
 // GEN: the general instantiation -- environments with their own source colours / enabled flags (lle_batch_set_sources)
 // and/or batches of several maps (lle_batch_create_multi).  A separate instantiation, so that the default path (one
 // map, sources of the map) is compiled exactly as before: every `PES` / `tables` / `initp` below folds to a constant.
-template <int G, int LM, bool GEN>
+// ML1: no cell of the map carries more than one laser layer (every level of the reference; no crossing beams): the
+// per-layer loops run exactly once and unroll (no variable 64-bit shifts of the layer word).
+template <int G, int LM, bool GEN, bool ML1>
 __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K) {
     const bool PES = GEN && (K.flags & LAUNCH_PER_ENV_SOURCES) != 0;
+    // The default instantiation is one step in place and nothing else: the fused rollout (n_steps, trajectory rings)
+    // and the timeline stamps run on the general one, so that their arguments do not occupy scalar registers here.
+    uint64_t* const stamps = GEN ? K.stamps : nullptr;
+#undef LLE_STAMP
+#define LLE_STAMP(i)                                                                              \
+    do {                                                                                          \
+        if (GEN && stamps && lane == 0) stamps[(uint64_t)wave_id * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
     // environments per wavefront: at most 64 / G; fewer (lanes left idle) when the batch is small, so that there
     // are enough wavefronts to spread phase 2 over the chip
     const uint32_t EPW = K.envs_per_wave < (uint32_t)(64 / G) ? K.envs_per_wave : (uint32_t)(64 / G);
@@ -580,19 +590,28 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
     LLE_STAMP(1);
 
     uint32_t alive = (uint32_t)raw_bits & 0xFFFFu, arrived = (uint32_t)(raw_bits >> 16) & 0xFFFFu, occ = (uint32_t)(raw_bits >> 32) & 0xFFFFu;
-    const uint32_t enabled = PES ? env_enabled : hdr->enabled_mask, max_layers = hdr->max_layers;
+    const uint32_t enabled = PES ? env_enabled : hdr->enabled_mask, max_layers = ML1 ? 1u : hdr->max_layers;
     LLE_STAMP(2);
 
     // ---- n_steps consecutive steps of the wave's environments; the state stays in registers in between.
     // (n_steps = 1 is World.step; more is a fused rollout with on-device action sampling, lle_batch_rollout.)
     StepCounts cnt = {0, 0, 0, 0, 0, 0, 0};
-    const uint32_t n_steps = K.n_steps ? K.n_steps : 1u;
+    const uint32_t n_steps = GEN ? (K.n_steps ? K.n_steps : 1u) : 1u;
     for (uint32_t it = 0; it < n_steps; it++) {
     const uint64_t t_now = K.t + it;
-    const uint32_t slot = K.ring_slots ? (uint32_t)((K.ring_pos + it) % K.ring_slots) : 0u;
-    uint8_t* __restrict__ actions_out = K.ring_slots ? K.ring_actions + (int64_t)slot * K.ring_env_count * As : P.actions;
-    uint32_t* __restrict__ reward_out = K.ring_slots ? K.ring_reward + (int64_t)slot * K.ring_env_count : P.reward;
-    int8_t* __restrict__ obs_out = K.ring_slots ? K.ring_obs + (int64_t)slot * K.ring_env_count * (int64_t)hdr->obs_stride : P.obs;
+    // where this step's observation / actions / reward counts go: in place, or slot (ring_pos + step) % ring_slots of
+    // the trajectory rings (the launcher passes ring_pos already reduced modulo ring_slots; the slot advances by
+    // increment, so the single-step path carries no 64-bit division)
+    uint8_t* __restrict__ actions_out = P.actions;
+    uint32_t* __restrict__ reward_out = P.reward;
+    int8_t* __restrict__ obs_out = P.obs;
+    if (GEN && K.ring_slots) {
+        uint32_t slot = (uint32_t)K.ring_pos + it;
+        while (slot >= K.ring_slots) slot -= K.ring_slots;
+        actions_out = K.ring_actions + (int64_t)slot * K.ring_env_count * As;
+        reward_out = K.ring_reward + (int64_t)slot * K.ring_env_count;
+        obs_out = K.ring_obs + (int64_t)slot * K.ring_env_count * (int64_t)hdr->obs_stride;
+    }
 
     // ---- auto-reset: a finished env restarts from the reset state (identical for every env, see InitRecord)
     uint32_t was_reset = 0;
@@ -810,7 +829,7 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
             if (b < L) P.beams[env * L + b] = beams[b];
     }
     flush_stats(P.stats, wave_id, cnt, A, lane);
-    if (K.stamps) {
+    if (GEN && stamps) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         LLE_STAMP(6);
     }
@@ -899,24 +918,25 @@ hipError_t launch_world_kernel(int mode, const MapHeader& h, const BatchPtrs& P,
 int step_group(int A) { return A <= 1 ? 1 : (A <= 2 ? 2 : (A <= 4 ? 4 : (A <= 8 ? 8 : 16))); }
 int step_lm(int L) { return L <= 4 ? 4 : (L <= 8 ? 8 : (L <= 16 ? 16 : 32)); }
 
-template <int G, int LM, bool GEN>
+template <int G, int LM, bool GEN, bool ML1>
 static hipError_t launch_step_glp(const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
     dim3 grid((n_waves + wpw - 1) / wpw), block(64 * wpw);
     if (lds > 64 * 1024) {  // gfx950 has 160 KiB of LDS per CU; more than 64 KiB per workgroup is opt-in
         static uint32_t granted = 0;
         if (lds > granted) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<G, LM, GEN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<G, LM, GEN, ML1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             granted = lds;
         }
     }
-    hipLaunchKernelGGL((step_kernel<G, LM, GEN>), grid, block, lds, stream, P, K);
+    hipLaunchKernelGGL((step_kernel<G, LM, GEN, ML1>), grid, block, lds, stream, P, K);
     return hipGetLastError();
 }
 template <int G, int LM>
 static hipError_t launch_step_gl(const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
-    return (K.flags & LAUNCH_GENERAL) ? launch_step_glp<G, LM, true>(P, K, n_waves, wpw, lds, stream)
-                                      : launch_step_glp<G, LM, false>(P, K, n_waves, wpw, lds, stream);
+    if (K.flags & LAUNCH_GENERAL) return launch_step_glp<G, LM, true, false>(P, K, n_waves, wpw, lds, stream);
+    return (K.flags & LAUNCH_SINGLE_LAYER) ? launch_step_glp<G, LM, false, true>(P, K, n_waves, wpw, lds, stream)
+                                           : launch_step_glp<G, LM, false, false>(P, K, n_waves, wpw, lds, stream);
 }
 template <int G>
 static hipError_t launch_step_g(int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
@@ -944,7 +964,8 @@ hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const Laun
     LaunchArgs K = K_in;
     const int G = step_group((int)h.A), lm = step_lm((int)h.L);
     const bool pes = (K.flags & LAUNCH_PER_ENV_SOURCES) != 0;
-    if (pes || K.envs_per_map) K.flags |= LAUNCH_GENERAL;
+    if (pes || K.envs_per_map || K.n_steps > 1 || K.ring_slots || K.stamps) K.flags |= LAUNCH_GENERAL;
+    else if (h.max_layers <= 1) K.flags |= LAUNCH_SINGLE_LAYER;
     uint32_t wpw = kernel_waves_per_wg(h, pes);
     if (K.envs_per_map) {  // a workgroup's environments must belong to one map
         const uint32_t cap = 64u / (uint32_t)G;
