@@ -542,16 +542,29 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
     uint32_t gems = 0;
 #pragma unroll
     for (int b = 0; b < LM; b++) beams[b] = 0;
+    // Per-lane addresses of this env's / agent's records, computed once and kept in vector registers for the stores at
+    // the end: the scalar base pointers are then dead during the state machine (scalar registers are the scarce
+    // resource of this kernel, vector registers are not).
+    const int64_t env_c = env_ok ? env : 0;
+    uint64_t* const p_bits = P.bits + env_c;
+    uint32_t* const p_gems = P.gems + env_c;
+    uint32_t* const p_beams = P.beams + env_c * L;
+    uint16_t* const p_pos = P.pos + env_c * As + a;
+    uint8_t* const p_avail = P.avail + env_c * As + a;
+    uint8_t* const p_err = P.err + env_c;
+    uint8_t* const p_evcount = P.evcount + env_c;
+    uint8_t* const p_events = P.events + env_c * 2 * As;
+    uint8_t* const p_done = P.done + env_c;
     if (env_ok) {
-        raw_bits = P.bits[env];
-        gems = P.gems[env];
+        raw_bits = *p_bits;
+        gems = *p_gems;
 #pragma unroll
         for (int b = 0; b < LM; b++)
-            if (b < L) beams[b] = P.beams[env * L + b];
+            if (b < L) beams[b] = p_beams[b];
     }
     if (me) {
-        pos = (uint32_t)P.pos[env * As + a];
-        avail = (uint32_t)P.avail[env * As + a];
+        pos = (uint32_t)*p_pos;
+        avail = (uint32_t)*p_avail;
     }
     uint64_t init_bits = initp->bits;
     uint32_t init_gems = initp->gems;
@@ -686,29 +699,46 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
 
         // move_agents passes (world.rs:464-472)
         bool go = true;
+        bool first_pass = true;
         uint64_t lay_from = lay_cur;  // pass 1 leaves the old cells, later passes the new ones
         while (__any(go)) {
+            // leave (laser.rs:199-202,157-162): what the alive agents of the env re-light, per beam
+            const uint32_t alive0 = alive;
+            const bool me_alive = go && me && (alive0 & bit);
+            uint32_t lit[LM], any_lit = 0;
+#pragma unroll
+            for (int b = 0; b < LM; b++) {
+                lit[b] = 0;
+                if (b < L) {
+                    uint32_t light = 0;
+                    for (uint32_t k = 0; k < max_layers; k++) {
+                        const uint32_t eo = (uint32_t)(lay_from >> (16 * k)) & 0xFFFFu;
+                        const bool lo = me_alive && (eo & LAY_VALID) && ((eo >> 1) & 31u) == (uint32_t)b &&
+                                        !((beams[b] >> ((eo >> 6) & 31u)) & 1u);
+                        light |= lo ? (0xFFFFFFFFu << ((eo >> 6) & 31u)) : 0u;
+                    }
+                    lit[b] = grp_or<G>(((enabled >> b) & 1u) ? light : 0u);
+                    any_lit |= lit[b];
+                }
+            }
+            // A pass after the first one leaves and re-enters the SAME cells.  If no alive agent re-lights anything, the
+            // beams cannot change (the owners' cuts are repeated as they are), so every enter repeats its outcome: alive
+            // agents stay alive, occupants / arrivals / gems are already recorded, the dead stay blocked or buried.
+            // The pass is then a no-op and `while agent_died` ends (world.rs:468-472).
+            if (!first_pass && any_lit == 0u) go = false;
             if (go) {
-                const uint32_t alive0 = alive;
-                const bool me_alive = me && (alive0 & bit);
                 occ &= ~alive0;  // Tile::leave: slot.take() for every alive agent
 #pragma unroll
                 for (int b = 0; b < LM; b++) {
                     if (b < L) {
-                        uint32_t light = 0, keep = 0xFFFFFFFFu;
+                        uint32_t keep = 0xFFFFFFFFu;
                         for (uint32_t k = 0; k < max_layers; k++) {
-                            const uint32_t eo = (uint32_t)(lay_from >> (16 * k)) & 0xFFFFu;  // leave (laser.rs:199-202,157-162)
-                            const bool lo = me_alive && (eo & LAY_VALID) && ((eo >> 1) & 31u) == (uint32_t)b &&
-                                            !((beams[b] >> ((eo >> 6) & 31u)) & 1u);
-                            light |= lo ? (0xFFFFFFFFu << ((eo >> 6) & 31u)) : 0u;
                             const uint32_t en = (uint32_t)(lay_new >> (16 * k)) & 0xFFFFu;   // pre_enter (laser.rs:173-182)
                             const bool pe = me_alive && (en & LAY_VALID) && ((en >> 1) & 31u) == (uint32_t)b && (en >> 11) == a;
                             keep &= pe ? ((1u << ((en >> 6) & 31u)) - 1u) : 0xFFFFFFFFu;
                         }
-                        const bool on = (enabled >> b) & 1u;
-                        const uint32_t lit = grp_or<G>(on ? light : 0u);
-                        const uint32_t cut = grp_or<G>(on ? ~keep : 0u);
-                        beams[b] = (beams[b] | lit) & ~cut;
+                        const uint32_t cut = grp_or<G>(((enabled >> b) & 1u) ? ~keep : 0u);
+                        beams[b] = (beams[b] | lit[b]) & ~cut;
                     }
                 }
                 // enter (tile.rs:29-50, laser.rs:184-197)
@@ -739,6 +769,7 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
                 go = (p1 & 0xFFFFu) != 0;  // while agent_died
             }
             lay_from = lay_new;
+            first_pass = false;
         }
         pos = np;
 #pragma unroll
@@ -763,10 +794,10 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
 #pragma unroll
     for (int k = 0; k < NW; k++) evw[k] = grp_or64<G>(evw[k]);
     if (env_ok && a == 0) {
-        P.err[env] = (uint8_t)err;
-        P.evcount[env] = (uint8_t)(n_ev | (was_reset << 7));
+        *p_err = (uint8_t)err;
+        *p_evcount = (uint8_t)(n_ev | (was_reset << 7));
         {
-            uint8_t* row = P.events + env * 2 * As;  // 2*As bytes per env; this kernel fills the first 2*G
+            uint8_t* row = p_events;  // 2*As bytes per env; this kernel fills the first 2*G
             if (G >= 2) {
                 uint32_t* __restrict__ w = reinterpret_cast<uint32_t*>(row);
 #pragma unroll
@@ -775,7 +806,7 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
                 *reinterpret_cast<uint16_t*>(row) = (uint16_t)evw[0];
             }
         }
-        P.done[env] = (alive != amask || arrived == amask) ? 1 : 0;
+        *p_done = (alive != amask || arrived == amask) ? 1 : 0;
         uint32_t n_died = 0, n_gem = 0;
 #pragma unroll
         for (int k = 0; k < NW; k++) {
@@ -818,15 +849,15 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
     // ---- final state.  Written unconditionally: an env whose action was refused kept its registers unchanged
     // (world.rs:436-453: errors precede any mutation), so this rewrites the same bytes.
     if (me) {
-        P.pos[env * As + a] = (uint16_t)pos;
-        P.avail[env * As + a] = (uint8_t)avail;
+        *p_pos = (uint16_t)pos;
+        *p_avail = (uint8_t)avail;
     }
     if (env_ok && a == 0) {
-        P.bits[env] = (uint64_t)alive | ((uint64_t)arrived << 16) | ((uint64_t)occ << 32);
-        P.gems[env] = gems;
+        *p_bits = (uint64_t)alive | ((uint64_t)arrived << 16) | ((uint64_t)occ << 32);
+        *p_gems = gems;
 #pragma unroll
         for (int b = 0; b < LM; b++)
-            if (b < L) P.beams[env * L + b] = beams[b];
+            if (b < L) p_beams[b] = beams[b];
     }
     flush_stats(P.stats, wave_id, cnt, A, lane);
     if (GEN && stamps) {
