@@ -1,6 +1,6 @@
 // kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the batched World.
 //
-//   step_kernel<G, LM, PES>      World.step, the hot path: one LANE PER AGENT (G lanes per environment, 64/G environments
+//   step_kernel<G, LM, MODE, ML1> World.step, the hot path: one LANE PER AGENT (G lanes per environment, 64/G environments
 //                                per wavefront), state machine on bitmasks with DPP / ds_swizzle group reductions.
 //   world_kernel<AM, LM, MODE>   one lane per environment, the state machine of step_logic.hpp: reset, set_state,
 //                                observe, source updates (and step, as a diagnostic).
@@ -490,16 +490,19 @@ __device__ __forceinline__ void for_each_other(uint32_t v, F&& f) {
 // map, sources of the map) is compiled exactly as before: every `PES` / `tables` / `initp` below folds to a constant.
 // ML1: no cell of the map carries more than one laser layer (every level of the reference; no crossing beams): the
 // per-layer loops run exactly once and unroll (no variable 64-bit shifts of the layer word).
-template <int G, int LM, bool GEN, bool ML1>
+// MODE 0: one step in place, one map, the map's sources (the default).  MODE 1: + fused rollout (n_steps, trajectory
+// rings) and timeline stamps.  MODE 2 (general): + per-env sources and several maps.
+template <int G, int LM, int MODE, bool ML1>
 __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K) {
+    constexpr bool GEN = MODE == 2, ROLL = MODE >= 1;
     const bool PES = GEN && (K.flags & LAUNCH_PER_ENV_SOURCES) != 0;
     // The default instantiation is one step in place and nothing else: the fused rollout (n_steps, trajectory rings)
     // and the timeline stamps run on the general one, so that their arguments do not occupy scalar registers here.
-    uint64_t* const stamps = GEN ? K.stamps : nullptr;
+    uint64_t* const stamps = ROLL ? K.stamps : nullptr;
 #undef LLE_STAMP
 #define LLE_STAMP(i)                                                                              \
     do {                                                                                          \
-        if (GEN && stamps && lane == 0) stamps[(uint64_t)wave_id * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+        if (ROLL && stamps && lane == 0) stamps[(uint64_t)wave_id * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
     // environments per wavefront: at most 64 / G; fewer (lanes left idle) when the batch is small, so that there
     // are enough wavefronts to spread phase 2 over the chip
@@ -609,7 +612,7 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
     // ---- n_steps consecutive steps of the wave's environments; the state stays in registers in between.
     // (n_steps = 1 is World.step; more is a fused rollout with on-device action sampling, lle_batch_rollout.)
     StepCounts cnt = {0, 0, 0, 0, 0, 0, 0};
-    const uint32_t n_steps = GEN ? (K.n_steps ? K.n_steps : 1u) : 1u;
+    const uint32_t n_steps = ROLL ? (K.n_steps ? K.n_steps : 1u) : 1u;
     for (uint32_t it = 0; it < n_steps; it++) {
     const uint64_t t_now = K.t + it;
     // where this step's observation / actions / reward counts go: in place, or slot (ring_pos + step) % ring_slots of
@@ -618,7 +621,7 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
     uint8_t* __restrict__ actions_out = P.actions;
     uint32_t* __restrict__ reward_out = P.reward;
     int8_t* __restrict__ obs_out = P.obs;
-    if (GEN && K.ring_slots) {
+    if (ROLL && K.ring_slots) {
         uint32_t slot = (uint32_t)K.ring_pos + it;
         while (slot >= K.ring_slots) slot -= K.ring_slots;
         actions_out = K.ring_actions + (int64_t)slot * K.ring_env_count * As;
@@ -860,7 +863,7 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
             if (b < L) p_beams[b] = beams[b];
     }
     flush_stats(P.stats, wave_id, cnt, A, lane);
-    if (GEN && stamps) {
+    if (ROLL && stamps) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         LLE_STAMP(6);
     }
@@ -949,25 +952,27 @@ hipError_t launch_world_kernel(int mode, const MapHeader& h, const BatchPtrs& P,
 int step_group(int A) { return A <= 1 ? 1 : (A <= 2 ? 2 : (A <= 4 ? 4 : (A <= 8 ? 8 : 16))); }
 int step_lm(int L) { return L <= 4 ? 4 : (L <= 8 ? 8 : (L <= 16 ? 16 : 32)); }
 
-template <int G, int LM, bool GEN, bool ML1>
+template <int G, int LM, int MODE, bool ML1>
 static hipError_t launch_step_glp(const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
     dim3 grid((n_waves + wpw - 1) / wpw), block(64 * wpw);
     if (lds > 64 * 1024) {  // gfx950 has 160 KiB of LDS per CU; more than 64 KiB per workgroup is opt-in
         static uint32_t granted = 0;
         if (lds > granted) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<G, LM, GEN, ML1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<G, LM, MODE, ML1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             granted = lds;
         }
     }
-    hipLaunchKernelGGL((step_kernel<G, LM, GEN, ML1>), grid, block, lds, stream, P, K);
+    hipLaunchKernelGGL((step_kernel<G, LM, MODE, ML1>), grid, block, lds, stream, P, K);
     return hipGetLastError();
 }
 template <int G, int LM>
 static hipError_t launch_step_gl(const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
-    if (K.flags & LAUNCH_GENERAL) return launch_step_glp<G, LM, true, false>(P, K, n_waves, wpw, lds, stream);
-    return (K.flags & LAUNCH_SINGLE_LAYER) ? launch_step_glp<G, LM, false, true>(P, K, n_waves, wpw, lds, stream)
-                                           : launch_step_glp<G, LM, false, false>(P, K, n_waves, wpw, lds, stream);
+    if (K.flags & LAUNCH_GENERAL) return launch_step_glp<G, LM, 2, false>(P, K, n_waves, wpw, lds, stream);
+    const bool ml1 = (K.flags & LAUNCH_SINGLE_LAYER) != 0;
+    if (K.flags & LAUNCH_ROLLOUT)
+        return ml1 ? launch_step_glp<G, LM, 1, true>(P, K, n_waves, wpw, lds, stream) : launch_step_glp<G, LM, 1, false>(P, K, n_waves, wpw, lds, stream);
+    return ml1 ? launch_step_glp<G, LM, 0, true>(P, K, n_waves, wpw, lds, stream) : launch_step_glp<G, LM, 0, false>(P, K, n_waves, wpw, lds, stream);
 }
 template <int G>
 static hipError_t launch_step_g(int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
@@ -995,8 +1000,11 @@ hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const Laun
     LaunchArgs K = K_in;
     const int G = step_group((int)h.A), lm = step_lm((int)h.L);
     const bool pes = (K.flags & LAUNCH_PER_ENV_SOURCES) != 0;
-    if (pes || K.envs_per_map || K.n_steps > 1 || K.ring_slots || K.stamps) K.flags |= LAUNCH_GENERAL;
-    else if (h.max_layers <= 1) K.flags |= LAUNCH_SINGLE_LAYER;
+    if (pes || K.envs_per_map) K.flags |= LAUNCH_GENERAL;
+    else {
+        if (K.n_steps > 1 || K.ring_slots || K.stamps) K.flags |= LAUNCH_ROLLOUT;
+        if (h.max_layers <= 1) K.flags |= LAUNCH_SINGLE_LAYER;
+    }
     uint32_t wpw = kernel_waves_per_wg(h, pes);
     if (K.envs_per_map) {  // a workgroup's environments must belong to one map
         const uint32_t cap = 64u / (uint32_t)G;

@@ -117,6 +117,7 @@ constexpr uint32_t LAUNCH_PER_ENV_SOURCES = 0x10000;  // internal: the batch kee
 constexpr uint32_t LAUNCH_FILL_DEFAULTS = 0x20000;    // internal (MODE_ENV_SOURCES): take them from the map header
 constexpr uint32_t LAUNCH_GENERAL = 0x80000;          // internal: the general step_kernel instantiation (per-env sources / several maps)
 constexpr uint32_t LAUNCH_SINGLE_LAYER = 0x100000;    // internal: no cell has more than one laser layer (step_kernel ML1 instantiation)
+constexpr uint32_t LAUNCH_ROLLOUT = 0x200000;         // internal: step_kernel MODE 1 (fused rollout / stamps; one map, map-wide sources)
 constexpr uint32_t LAUNCH_ARRAYS_INVALID = 0x40000;   // internal (MODE_ENV_SOURCES): first call, nothing stored per env yet
 constexpr uint32_t ELEM_SOURCE = 0, ELEM_TILE = 1, ELEM_GEM = 2;
 
