@@ -128,7 +128,7 @@ int lle_last_status(void) { return g_status; }
 const char* lle_last_error(void) { return g_error.c_str(); }
 
 uint64_t lle_action_hash(uint64_t seed, uint64_t env, uint64_t t, uint64_t agent) {
-    return action_field(action_hash_group(action_hash_env(seed, env, t), agent >> 2), (uint32_t)agent);
+    return action_field(action_hash_pair(action_step_key(seed, t), env, (uint32_t)(agent >> 1)), (uint32_t)agent);
 }
 
 // ------------------------------------------------------------------------------------------------ maps

@@ -230,12 +230,12 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
             }
             uint32_t act[AM];
             if (K.flags & STEP_SAMPLE_ACTIONS) {
-                const uint64_t he = action_hash_env(K.seed, (uint64_t)(K.env_offset + env), K.t);
-                uint64_t hg = 0;
+                const uint64_t key = action_step_key(K.seed, K.t);
+                uint32_t hp = 0;
 #pragma unroll
                 for (int a = 0; a < AM; a++) {
-                    if ((a & 3) == 0 && a < A) hg = action_hash_group(he, (uint64_t)(a >> 2));
-                    act[a] = (a < A) ? sample_action(avail[a], action_field(hg, (uint32_t)a)) : 4u;
+                    if ((a & 1) == 0 && a < A) hp = action_hash_pair(key, (uint64_t)(K.env_offset + env), (uint32_t)(a >> 1));
+                    act[a] = (a < A) ? sample_action(avail[a], action_field(hp, (uint32_t)a)) : 4u;
                 }
                 store_u8_record<AM>(P.actions, env, act);
             } else if (K.actions_in) {
@@ -653,9 +653,8 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
     // ---- joint action: sampled on the device, or given
     uint32_t act = 4u;
     if (K.flags & STEP_SAMPLE_ACTIONS) {
-        const uint64_t he = action_hash_env(K.seed, (uint64_t)(K.env_offset + env), t_now);
-        const uint64_t hg = action_hash_group(he, (uint64_t)(a >> 2));
-        act = sample_action(avail, action_field(hg, a));
+        const uint32_t hp = action_hash_pair(action_step_key(K.seed, t_now), (uint64_t)(K.env_offset + env), a >> 1);
+        act = sample_action(avail, action_field(hp, a));
         if (me) actions_out[env * As + a] = (uint8_t)act;
     } else if (K.actions_in) {
         if (me) {

@@ -37,17 +37,23 @@ LLE_HD uint64_t mix64(uint64_t x) {
     return x;
 }
 // Counter-based action sampler (DESIGN.md "Action stream"): stateless in (seed, env, t, agent).
-// One 64-bit hash serves a group of four agents, 16 bits each; the action is the k-th available one with
-// k = (field16 * popcount(mask)) >> 16, i.e. uniform up to a 2^-16 bias.
-LLE_HD uint64_t action_hash_env(uint64_t seed, uint64_t env, uint64_t t) {
-    uint64_t x = seed + 0x9E3779B97F4A7C15ULL * (env + 1);
-    x ^= 0xD1B54A32D192ED03ULL * (t + 1);
-    return mix64(x);
+//   key   = mix64(seed + 0x9E3779B97F4A7C15 * (t + 1))                      uniform over a launch: scalar work
+//   h     = lowbias32((lo(key) ^ lo(env) * 0x9E3779B1) + rotl(hi(key) ^ hi(env), 15) + rotl(0xC2B2AE35, 3 * pair + 1))
+//   field = 16 bits of h per agent of the pair (agents 2 * pair and 2 * pair + 1)
+// and the action is the k-th available one with k = (field16 * popcount(mask)) >> 16, uniform up to a 2^-16 bias.
+// Three 32-bit multiplies per lane (integer multiplies run at quarter rate on the vector ALU; the 64-bit mixing this
+// replaced cost twenty).
+LLE_HD uint32_t rotl32(uint32_t x, uint32_t s) { return (x << (s & 31u)) | (x >> ((32u - s) & 31u)); }
+LLE_HD uint64_t action_step_key(uint64_t seed, uint64_t t) { return mix64(seed + 0x9E3779B97F4A7C15ULL * (t + 1)); }
+LLE_HD uint32_t action_hash_pair(uint64_t key, uint64_t env, uint32_t pair) {
+    uint32_t h = ((uint32_t)key ^ ((uint32_t)env * 0x9E3779B1u)) + rotl32((uint32_t)(key >> 32) ^ (uint32_t)(env >> 32), 15u) +
+                 rotl32(0xC2B2AE35u, 3u * pair + 1u);
+    h ^= h >> 16; h *= 0x7FEB352Du;   // lowbias32 finaliser
+    h ^= h >> 15; h *= 0x846CA68Bu;
+    h ^= h >> 16;
+    return h;
 }
-LLE_HD uint64_t action_hash_group(uint64_t env_hash, uint64_t group) {
-    return mix64(env_hash + 0x8CB92BA72F3D8DD7ULL * (group + 1));
-}
-LLE_HD uint32_t action_field(uint64_t group_hash, uint32_t agent) { return (uint32_t)(group_hash >> (16u * (agent & 3u))) & 0xFFFFu; }
+LLE_HD uint32_t action_field(uint32_t pair_hash, uint32_t agent) { return (pair_hash >> (16u * (agent & 1u))) & 0xFFFFu; }
 
 LLE_HD uint32_t popc5(uint32_t m) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -817,13 +817,18 @@ static uint64_t mix64(uint64_t x) { /* splitmix64 finaliser */
     x ^= x >> 31;
     return x;
 }
-/* 16-bit field of (seed, env, t, agent): one 64-bit hash serves four agents (DESIGN.md "Action stream") */
+static uint32_t rotl32(uint32_t x, uint32_t s) { return (x << (s & 31u)) | (x >> ((32u - s) & 31u)); }
+/* 16-bit field of (seed, env, t, agent) (DESIGN.md "Action stream"): a 64-bit key per (seed, t), one 32-bit hash
+ * (lowbias32 finaliser) per pair of agents, 16 bits per agent */
 uint64_t ow_action_hash(uint64_t seed, uint64_t env, uint64_t t, uint64_t agent) {
-    uint64_t x = seed + 0x9E3779B97F4A7C15ULL * (env + 1);
-    x ^= 0xD1B54A32D192ED03ULL * (t + 1);
-    x = mix64(x);
-    x = mix64(x + 0x8CB92BA72F3D8DD7ULL * ((agent >> 2) + 1));
-    return (x >> (16 * (agent & 3))) & 0xFFFF;
+    uint64_t key = mix64(seed + 0x9E3779B97F4A7C15ULL * (t + 1));
+    uint32_t pair = (uint32_t)(agent >> 1);
+    uint32_t h = ((uint32_t)key ^ ((uint32_t)env * 0x9E3779B1u)) + rotl32((uint32_t)(key >> 32) ^ (uint32_t)(env >> 32), 15u) +
+                 rotl32(0xC2B2AE35u, 3u * pair + 1u);
+    h ^= h >> 16; h *= 0x7FEB352Du;
+    h ^= h >> 15; h *= 0x846CA68Bu;
+    h ^= h >> 16;
+    return (h >> (16 * (agent & 1))) & 0xFFFF;
 }
 /* uniform (up to 2^-16) over the set bits of the 5-bit availability mask: k-th set bit in enum order N,S,E,W,STAY */
 int ow_sample_action(uint8_t mask, uint64_t seed, uint64_t env, uint64_t t, uint64_t agent) {

@@ -83,11 +83,11 @@ static void run(hs_batch* b, int mode, uint32_t flags, uint64_t seed, uint64_t t
             load_cells<AM>(mv, s.pos, cur);
             uint32_t act[AM];
             if (flags & STEP_SAMPLE_ACTIONS) {
-                const uint64_t he = action_hash_env(seed, (uint64_t)(env_offset + env), t);
-                uint64_t hg = 0;
+                const uint64_t key = action_step_key(seed, t);
+                uint32_t hp = 0;
                 for (int a = 0; a < AM; a++) {
-                    if ((a & 3) == 0 && a < A) hg = action_hash_group(he, (uint64_t)(a >> 2));
-                    act[a] = (a < A) ? sample_action(avail[a], action_field(hg, (uint32_t)a)) : 4u;
+                    if ((a & 1) == 0 && a < A) hp = action_hash_pair(key, (uint64_t)(env_offset + env), (uint32_t)(a >> 1));
+                    act[a] = (a < A) ? sample_action(avail[a], action_field(hp, (uint32_t)a)) : 4u;
                 }
             } else {
                 const uint8_t* src = actions_in ? actions_in : b->actions.data();

@@ -160,3 +160,21 @@ def test_config1_single_env_10k_steps(oracle_mod):
             assert_step_equal(eng, ostep, f"t={t}")
             assert_state_equal(eng, ob.dump(), f"t={t}")
     assert np.array_equal(sb.buf("stats")[:7], stats[:7]) and stats[0] == 10_000 and stats[3] > 100  # many exits
+
+
+def test_sampler_is_uniform_and_decorrelated(oracle_mod):
+    """The 16-bit fields of the counter-based sampler: flat histogram, no visible dependence
+    between neighbouring envs / steps / agents (chi-square bounds loose enough to be deterministic)."""
+    f = np.array([[[oracle_mod.action_hash(1234, e, t, a) for a in range(4)] for t in range(16)] for e in range(512)], dtype=np.int64)
+    assert f.min() >= 0 and f.max() < 65536
+    n = f.size
+    hist = np.bincount((f >> 10).ravel(), minlength=64)            # 64 bins
+    chi2 = float(((hist - n / 64) ** 2 / (n / 64)).sum())
+    assert chi2 < 120, chi2                                       # 63 dof: mean 63, 120 is far in the tail
+    act = (f * 5) >> 16                                           # five available actions
+    for axis in range(3):                                         # neighbours along env / t / agent
+        a0 = np.take(act, range(0, act.shape[axis] - 1), axis=axis).ravel()
+        a1 = np.take(act, range(1, act.shape[axis]), axis=axis).ravel()
+        joint = np.bincount(a0 * 5 + a1, minlength=25).astype(float)
+        exp = joint.sum() / 25
+        assert float(((joint - exp) ** 2 / exp).sum()) < 60, axis  # 24 dof
