@@ -680,6 +680,8 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
 #pragma unroll
     for (int k = 0; k < NW; k++) evw[k] = 0;
     uint32_t n_ev = 0;
+    uint32_t meta_step = 0;   // cell meta of the agent's new cell, for the availability mask computed in post_step()
+    bool stepped = false;
 
     if (env_ok && err == 0) {
         // target cell (src/action.rs:18-26 on the packed i | j << 8 form); lanes without an agent keep a unique sentinel
@@ -777,7 +779,18 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
 #pragma unroll
         for (int b = 0; b < LM; b++)
             if (b < L) beams[b] &= hdr->beam_full[b];
-        // compute_available_actions (world.rs:343-363)
+        meta_step = meta_new;
+        stepped = true;
+    }
+    LLE_STAMP(3);
+
+    // ---- everything of the step that the observation does not need: availability masks (compute_available_actions,
+    // world.rs:343-363), error code, ordered event list, done flag, reward counts, counters.  The observation needs
+    // positions, beams and gems only, so a wavefront of the OLDER half of the grid (the one the SIMD serves first, i.e.
+    // the one whose first store ends the idle time of the memory system) does this after its stream, a younger one --
+    // which waits for memory anyway and would otherwise add it to the end of the launch -- before.
+    auto post_step = [&]() {
+    if (stepped) {
         const bool can_move = me && (alive & bit) && !(arrived & bit);
         uint32_t blocked_dirs = 0;
         for_each_other<G>(pos, [&](int j, uint32_t other) {
@@ -788,11 +801,8 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
             hit |= (d == -256) ? 8u : 0u;
             blocked_dirs |= ((occ >> (a ^ (uint32_t)j)) & 1u) ? hit : 0u;
         });
-        avail = 16u | (can_move ? (((meta_new >> 8) & 15u) & ~blocked_dirs) : 0u);
+        avail = 16u | (can_move ? (((meta_step >> 8) & 15u) & ~blocked_dirs) : 0u);
     }
-    LLE_STAMP(3);
-
-    // ---- per-step outputs (the state itself stays in registers until the last step)
 #pragma unroll
     for (int k = 0; k < NW; k++) evw[k] = grp_or64<G>(evw[k]);
     if (env_ok && a == 0) {
@@ -820,6 +830,10 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
         reward_out[env] = n_gem | (n_exit << 8) | (n_died << 16) | (bonus << 24);
         cnt.steps += 1u; cnt.gems += n_gem; cnt.exits += n_exit; cnt.died += n_died;
         cnt.invalid += err != 0 ? 1u : 0u; cnt.resets += was_reset; cnt.bonus += bonus;
+    }
+    };  // post_step
+
+    if (env_ok && a == 0) {
         // hand-over record of this env for phase 2: [0 | beam masks | ~gem bits | ...
         uint32_t* sc = scratch + grp * scr_stride;
         sc[0] = 0u;
@@ -836,6 +850,8 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
     if (me) scratch[grp * scr_stride + L + 2 + a] = a * hdr->HW + cell_of(pos, W);  // ... | byte index of each agent]
     wave_sync();
     LLE_STAMP(4);
+    const bool post_first = MODE != 0 || blockIdx.x * 4u >= gridDim.x * 3u;
+    if (post_first) post_step();
 
     if (write_obs && n_here > 0) {
         if (PES)
@@ -845,6 +861,7 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
             write_observations(A, L, hdr->D, hdr->n_chunks, hdr->obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane);
     }
     wave_sync();
+    if (!post_first) post_step();
     }  // steps
     LLE_STAMP(5);
 
