@@ -351,3 +351,23 @@ def test_fuzz_maps_gpu(oracle_mod):
             bw.step(sample=True, auto_reset=ar, seed=5, t=t)
             check(bw, ob, ob.step(None, auto_reset=ar, seed=5, t=t), f"{name} t={t}")
     assert len(groups) >= 3, groups
+
+
+def test_large_batch_byte_offsets_beyond_32_bits():
+    """2.5 million envs = 4.7 GB of observations in one batch (a fraction of the 288 GB of HBM): a window of the big
+    batch equals a 65 536-env batch stepped with the matching env_offset, on every buffer."""
+    import torch
+
+    from lle_amd import BatchedWorld, Map
+
+    m = Map(level=6)
+    first = 2_400_000
+    big = BatchedWorld(m, 2_500_000)
+    small = BatchedWorld(m, 65536)
+    for t in range(6):
+        big.step(sample=True, auto_reset=True, seed=3, t=t)
+        small.step(sample=True, auto_reset=True, seed=3, t=t, env_offset=first)
+    sl = slice(first, first + 65536)
+    for k in ("pos", "bits", "gems", "beams", "avail", "events", "evcount", "done", "obs"):
+        assert torch.equal(getattr(big, k)[sl], getattr(small, k)), k
+    assert big.stats()["env_steps"] == 6 * 2_500_000
