@@ -152,6 +152,7 @@ struct LaunchArgs {
     // one map.  map_override = m + 1 forces map m (the hidden env that computes a map's reset record).
     int64_t envs_per_map;
     uint32_t table_stride, map_override;
+    uint32_t n_sources, pad3;  // host side only: MapHeader.L, for the launcher's choice of instantiation
 };
 
 // State of a freshly reset environment (identical for every env of a map: v1 maps have one start per agent).
