@@ -530,6 +530,17 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
     const bool env_ok = grp < EPW && env < K.env_limit;
     const bool me = env_ok && (int)a < A;           // this lane carries a real agent
     const bool write_obs = hdr->obs_supported && !(K.flags & STEP_NO_OBS);
+    // Header fields that are needed late (after the first stores) are read HERE, as scalar loads next to the kernel
+    // arguments: read where they are used they become vector loads from global memory with a full wait each, three of
+    // them in a row between the state machine and the first observation store.
+    const uint32_t h_HW = hdr->HW, h_obs_stride = hdr->obs_stride, h_n_chunks = hdr->n_chunks, h_D = hdr->D;
+    uint32_t h_beam_full[LM];
+#pragma unroll
+    for (int b = 0; b < LM; b++) h_beam_full[b] = (b < L) ? hdr->beam_full[b] : 0u;
+    const uint32_t h_enabled = hdr->enabled_mask;
+    uint32_t h_init_beams[LM];  // the reset state's beams (shared record; the per-env one is read where it is used)
+#pragma unroll
+    for (int b = 0; b < LM; b++) h_init_beams[b] = (b < L) ? initp->beams[b] : 0u;
     const int64_t n_here = (K.env_limit - env0) < (int64_t)EPW ? (K.env_limit - env0) : (int64_t)EPW;
     const uint32_t bit = 1u << a, amask = (1u << A) - 1u;
     LLE_STAMP(0);
@@ -567,16 +578,19 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
         for (int b = 0; b < LM; b++)
             if (b < L) beams[b] = p_beams[b];
     }
+    uint32_t init_pos_a = 0xFFFF0000u + a, init_avail_a = 0;  // this agent's reset position / availability
     if (me) {
         pos = (uint32_t)*p_pos;
         avail = (uint32_t)*p_avail;
+        init_pos_a = PES ? (uint32_t)P.init_pos[env * As + a] : (uint32_t)initp->pos[a];
+        init_avail_a = PES ? (uint32_t)P.init_avail[env * As + a] : (uint32_t)initp->avail[a];
     }
     uint64_t init_bits = initp->bits;
     uint32_t init_gems = initp->gems;
     // per-environment sources: colours (4 per word), enabled mask, and the env's own reset state
     constexpr int CWM = LM / 4;
     const int CW = src_stride_of(L) / 4;
-    uint32_t colw[CWM], env_enabled = hdr->enabled_mask;
+    uint32_t colw[CWM], env_enabled = h_enabled;
 #pragma unroll
     for (int q = 0; q < CWM; q++) colw[q] = 0;
     if (PES && env_ok) {
@@ -594,21 +608,21 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
     const uint32_t* cell_meta = reinterpret_cast<const uint32_t*>(lds + (hdr->off_cell_meta - tab_off));
     const uint64_t* dyn = reinterpret_cast<const uint64_t*>(lds + (hdr->off_dyn - tab_off));
     const uint32_t scr_stride = (uint32_t)(L + A + 2 + (PES ? CW : 0)) | 1u;
-    const uint32_t priv_bytes = hdr->obs_stride + 64u * scr_stride * 4u;
+    const uint32_t priv_bytes = h_obs_stride + 64u * scr_stride * 4u;
     int8_t* tmpl = reinterpret_cast<int8_t*>(lds + tab_bytes + ext_bytes + wave_in_wg * priv_bytes);
-    uint32_t* scratch = reinterpret_cast<uint32_t*>(tmpl + hdr->obs_stride);
+    uint32_t* scratch = reinterpret_cast<uint32_t*>(tmpl + h_obs_stride);
     const int8_t* bare = reinterpret_cast<const int8_t*>(lds + tab_bytes);
     const uint32_t* elems = reinterpret_cast<const uint32_t*>(lds + tab_bytes + (hdr->off_elems - hdr->off_bare));
     {
         const uint4* pristine = PES ? reinterpret_cast<const uint4*>(bare) : reinterpret_cast<const uint4*>(lds + (hdr->off_template - tab_off));
         uint4* mine = reinterpret_cast<uint4*>(tmpl);
-        for (uint32_t c = lane; c < hdr->n_chunks; c += 64) mine[c] = pristine[c];
+        for (uint32_t c = lane; c < h_n_chunks; c += 64) mine[c] = pristine[c];
     }
     wave_sync();
     LLE_STAMP(1);
 
     uint32_t alive = (uint32_t)raw_bits & 0xFFFFu, arrived = (uint32_t)(raw_bits >> 16) & 0xFFFFu, occ = (uint32_t)(raw_bits >> 32) & 0xFFFFu;
-    const uint32_t enabled = PES ? env_enabled : hdr->enabled_mask, max_layers = ML1 ? 1u : hdr->max_layers;
+    const uint32_t enabled = PES ? env_enabled : h_enabled, max_layers = ML1 ? 1u : hdr->max_layers;
     LLE_STAMP(2);
 
     // ---- n_steps consecutive steps of the wave's environments; the state stays in registers in between.
@@ -628,27 +642,22 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
         while (slot >= K.ring_slots) slot -= K.ring_slots;
         actions_out = K.ring_actions + (int64_t)slot * K.ring_env_count * As;
         reward_out = K.ring_reward + (int64_t)slot * K.ring_env_count;
-        obs_out = K.ring_obs + (int64_t)slot * K.ring_env_count * (int64_t)hdr->obs_stride;
+        obs_out = K.ring_obs + (int64_t)slot * K.ring_env_count * (int64_t)h_obs_stride;
     }
 
     // ---- auto-reset: a finished env restarts from the reset state (identical for every env, see InitRecord)
     uint32_t was_reset = 0;
     if (K.flags & STEP_AUTO_RESET) {
         const bool over = env_ok && (alive != amask || arrived == amask);
-        uint32_t ipos = pos, iav = avail;
-        if (me) {
-            ipos = PES ? (uint32_t)P.init_pos[env * As + a] : (uint32_t)initp->pos[a];
-            iav = PES ? (uint32_t)P.init_avail[env * As + a] : (uint32_t)initp->avail[a];
-        }
-        pos = over ? ipos : pos;
-        avail = over ? iav : avail;
+        pos = (over && me) ? init_pos_a : pos;
+        avail = (over && me) ? init_avail_a : avail;
         alive = over ? ((uint32_t)init_bits & 0xFFFFu) : alive;
         arrived = over ? ((uint32_t)(init_bits >> 16) & 0xFFFFu) : arrived;
         occ = over ? ((uint32_t)(init_bits >> 32) & 0xFFFFu) : occ;
         gems = over ? init_gems : gems;
 #pragma unroll
         for (int b = 0; b < LM; b++)
-            if (b < L) beams[b] = over ? (PES ? P.init_beams[env_ok ? env * L + b : 0] : initp->beams[b]) : beams[b];
+            if (b < L) beams[b] = over ? (PES ? P.init_beams[env_ok ? env * L + b : 0] : h_init_beams[b]) : beams[b];
         was_reset = over ? 1u : 0u;
     }
 
@@ -780,7 +789,7 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
         pos = np;
 #pragma unroll
         for (int b = 0; b < LM; b++)
-            if (b < L) beams[b] &= hdr->beam_full[b];
+            if (b < L) beams[b] &= h_beam_full[b];
         meta_step = meta_new;
         stepped = true;
     }
@@ -849,7 +858,7 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
                 if (q < CW) sc[L + 2 + A + q] = colw[q];
         }
     }
-    if (me) scratch[grp * scr_stride + L + 2 + a] = a * hdr->HW + cell_of(pos, W);  // ... | byte index of each agent]
+    if (me) scratch[grp * scr_stride + L + 2 + a] = a * h_HW + cell_of(pos, W);  // ... | byte index of each agent]
     wave_sync();
     LLE_STAMP(4);
     const bool post_first = MODE != 0 || blockIdx.x * 4u >= gridDim.x * 3u;
@@ -857,10 +866,10 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
 
     if (write_obs && n_here > 0) {
         if (PES)
-            write_observations_env(A, L, hdr->HW, hdr->n_elems, hdr->n_chunks, hdr->obs_stride, elems, bare, tmpl, scratch, scr_stride,
+            write_observations_env(A, L, h_HW, hdr->n_elems, h_n_chunks, h_obs_stride, elems, bare, tmpl, scratch, scr_stride,
                                    obs_out, env0, n_here, lane);
         else
-            write_observations(A, L, hdr->D, hdr->n_chunks, hdr->obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane);
+            write_observations(A, L, h_D, h_n_chunks, h_obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane);
     }
     wave_sync();
     if (!post_first) post_step();
