@@ -997,20 +997,22 @@ template <int G, int LM>
 static hipError_t launch_step_gl(const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
     if (K.flags & LAUNCH_GENERAL) return launch_step_glp<G, LM, 2, false>(P, K, n_waves, wpw, lds, stream);
     const bool ml1 = (K.flags & LAUNCH_SINGLE_LAYER) != 0;
-    if (K.flags & LAUNCH_ROLLOUT)
-        return ml1 ? launch_step_glp<G, LM, 1, true>(P, K, n_waves, wpw, lds, stream) : launch_step_glp<G, LM, 1, false>(P, K, n_waves, wpw, lds, stream);
-    if constexpr (LM == 4) {  // the default path of small maps: exact source count
+    const bool roll = (K.flags & LAUNCH_ROLLOUT) != 0;
+    if constexpr (LM == 4) {  // maps with at most four sources and no crossing beams: exact source count at compile time
         if (ml1) {
+#define LLE_STEP_LX(X)                                                                                    \
+    case X:                                                                                               \
+        return roll ? launch_step_glp<G, LM, 1, true, X>(P, K, n_waves, wpw, lds, stream)                 \
+                    : launch_step_glp<G, LM, 0, true, X>(P, K, n_waves, wpw, lds, stream);
             switch (K.n_sources) {
-                case 0: return launch_step_glp<G, LM, 0, true, 0>(P, K, n_waves, wpw, lds, stream);
-                case 1: return launch_step_glp<G, LM, 0, true, 1>(P, K, n_waves, wpw, lds, stream);
-                case 2: return launch_step_glp<G, LM, 0, true, 2>(P, K, n_waves, wpw, lds, stream);
-                case 3: return launch_step_glp<G, LM, 0, true, 3>(P, K, n_waves, wpw, lds, stream);
-                case 4: return launch_step_glp<G, LM, 0, true, 4>(P, K, n_waves, wpw, lds, stream);
+                LLE_STEP_LX(0) LLE_STEP_LX(1) LLE_STEP_LX(2) LLE_STEP_LX(3) LLE_STEP_LX(4)
                 default: break;
             }
+#undef LLE_STEP_LX
         }
     }
+    if (roll)
+        return ml1 ? launch_step_glp<G, LM, 1, true>(P, K, n_waves, wpw, lds, stream) : launch_step_glp<G, LM, 1, false>(P, K, n_waves, wpw, lds, stream);
     return ml1 ? launch_step_glp<G, LM, 0, true>(P, K, n_waves, wpw, lds, stream) : launch_step_glp<G, LM, 0, false>(P, K, n_waves, wpw, lds, stream);
 }
 template <int G>
