@@ -85,6 +85,25 @@ class BatchedLLE:
             w.set_sources(colours=colours, env_mask=env_mask)
         return self.get_observation(), self.get_state()
 
+    def set_state(self, positions, gems_collected, agents_alive=None):
+        """LLE.set_state (env.py:208-217) for every env: World.set_state with the reference's semantics (lossy
+        re-derivation of the beams, InvalidWorldState rules); `done` is recomputed from the new state.  positions u8
+        [n, A, 2], gems_collected bool [n, G], agents_alive bool [n, A] (default: all alive).  Returns the per-env error
+        codes (0, or LLE_ENV_*; such an env keeps / gets the state World.set_state leaves it in)."""
+        w = self.world
+        if agents_alive is None:
+            agents_alive = torch.ones((self.n_envs, self.n_agents), dtype=torch.bool, device=w.device)
+        w.set_state(positions, gems_collected, agents_alive)
+        return w.err
+
+    def agents_alive(self):
+        """bool [n, A]: the `is-alive-k` entries of Step.info (env.py:174-176)."""
+        return ((self.world.bits.unsqueeze(1) >> torch.arange(self.n_agents, device=self.world.device)) & 1).bool()
+
+    def agents_arrived(self):
+        """bool [n, A]: the `has-arrived-k` entries of Step.info."""
+        return ((self.world.bits.unsqueeze(1) >> (16 + torch.arange(self.n_agents, device=self.world.device))) & 1).bool()
+
     def _observe(self, kind):
         k, p = kind
         if k == _capi.LLE_OBS_LAYERED:

@@ -1,0 +1,69 @@
+"""Known-answer tests for the LLE host class (reward strategies, done, set_state, per-agent metrics), hand-transcribed
+from the reference's python/tests/test_env.py.  Same rules as make_kat.py: each case restates ONE reference test as data
+(map, script, the assertions that test makes; `ref` = file:line); nothing here imports or executes the reference.
+
+Running this file rewrites tests/golden/kat_env.json.
+
+Script ops: {"op": "reset"} | {"op": "step", "actions": [...], "reward": r | [gem, exit, death, done] | null,
+             "done": bool | null, "metrics": {"has-arrived": [...], "is-alive": [...]} | null}
+            {"op": "set_state", "positions": [[i, j]...], "gems": [...], "alive": [...] | null}
+            (set_state = LLE.set_state, python/lle/env/env.py:208-217: reward counters restart, World.set_state, the
+             events of set_state count towards arrivals / deaths, done is recomputed)
+Codes: actions N=0 S=1 E=2 W=3 STAY=4.  Reward constants of python/lle/env/reward_strategy.py:20-23:
+GEM = EXIT = DONE = 1, DEATH = -1.
+"""
+import json
+import os
+
+N, S, E, W, STAY = 0, 1, 2, 3, 4
+GEM = EXIT = DONE = 1.0
+DEATH = -1.0
+CASES = []
+
+
+def case(name, ref, map, script, multi_objective=False):
+    CASES.append({"name": name, "ref": ref, "map": map, "multi_objective": multi_objective, "script": script})
+
+
+reset = {"op": "reset"}
+
+
+def step(actions, reward=None, done=None, metrics=None):
+    return {"op": "step", "actions": list(actions), "reward": reward, "done": done, "metrics": metrics}
+
+
+case("void_reward", "python/tests/test_env.py:10-15", "S0 V X", [reset, step([E], DEATH, True)])
+case("collect_reward", "python/tests/test_env.py:18-27", "S0 X . .\n.  . . .\nG  . . .", [reset, step([S]), step([S], GEM)])
+case("time_reward", "python/tests/test_env.py:30-40", "\n    . .  . X\n    . S0 . .\n    . .  . .",
+     [reset] + [step([a], 0.0) for a in (N, S, E, W, STAY)])
+case("finish_reward", "python/tests/test_env.py:43-54",
+     "@ @ @  @ @ @\n@ . .  . . @\n@ . S0 . . @\n@ . .  X . @\n@ @ @  @ @ @", [reset, step([E]), step([S], DONE + EXIT)])
+case("arrive_reward_only_once", "python/tests/test_env.py:57-77", "\n    S0 . G\n    S1 X X\n",
+     [reset, step([E, STAY], 0), step([STAY, E], 1), step([STAY, STAY], 0), step([STAY, STAY], 0), step([E, STAY], 1),
+      step([STAY, STAY], 0), step([S, STAY], 2)])
+_play = [reset, step([S]), step([S], GEM, False), step([N], 0), step([N], 0), step([E], DONE + EXIT, True)]
+case("reward_after_reset", "python/tests/test_env.py:80-105", "\n    S0 X . .\n    .  . . .\n    G  . . .\n    ", _play * 3)
+case("reward_after_set_state", "python/tests/test_env.py:108-120", "\n    S0 . G\n    S1 X X",
+     [reset, {"op": "set_state", "positions": [[0, 1], [1, 1]], "gems": [False], "alive": None}, step([E, STAY], GEM)])
+case("reward_set_state_all_arrived", "python/tests/test_env.py:123-141", "\n    S0 . G\n    S1 X X",
+     # the test sets the world state, reads it back as an env state, resets, and hands that state to LLE.set_state
+     [reset, {"op": "set_state", "positions": [[0, 2], [1, 1]], "gems": [True], "alive": None}, step([S, STAY], DONE + EXIT)])
+case("reward", "python/tests/test_env.py:183-193", "\n    S0 G .\n    .  . X\n    ",
+     [reset, step([E], GEM), step([E], 0.0), step([S], EXIT + DONE)])
+case("reward_death", "python/tests/test_env.py:196-206", "\n    S0 L0S X\n    S1  .  X\n    ", [reset, step([STAY, E], DEATH, True)])
+case("step_info_arrival_metrics", "python/tests/test_env.py:209-224", "\n    S0 X\n    S1 X\n    ",
+     [reset, step([E, STAY], metrics={"has-arrived": [True, False], "is-alive": [True, True]})])
+case("step_info_death_metrics", "python/tests/test_env.py:227-242", "\n    S0 L0S X\n    S1  .  X\n    ",
+     [reset, step([STAY, E], metrics={"has-arrived": [False, False], "is-alive": [True, False]})])
+case("reward_collect_and_death", "python/tests/test_env.py:245-255", "\n    S0 L0S X\n    S1  G  X\n    ",
+     [reset, step([STAY, E], DEATH, True)])
+case("multi_objective_rewards", "python/tests/test_env.py:258-284", "\n    S0 G .\n    .  . X\n    ",
+     [reset, step([E], [1.0, 0, 0, 0]), step([E], [0, 0, 0, 0]), step([S], [0, EXIT, 0, DONE], True)], multi_objective=True)
+case("multi_objective_death", "python/tests/test_env.py:287-302", "\n    S0 L0S X\n    S1  G  X\n    ",
+     [reset, step([STAY, E], [0, 0, DEATH, 0])], multi_objective=True)
+
+if __name__ == "__main__":
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kat_env.json")
+    with open(out, "w") as f:
+        json.dump({"format": 1, "cases": CASES}, f, indent=1)
+    print(f"wrote {len(CASES)} cases to {out}")

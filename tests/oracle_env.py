@@ -75,6 +75,15 @@ class OracleLLE:
             reward += 1.0
         return np.array([reward], np.float32)
 
+    def set_state(self, positions, gems, alive):   # LLE.set_state, env.py:208-217
+        self.n_arrived = self.n_deads = 0
+        events = self.w.set_state(positions, gems, alive)
+        self.compute_reward(events)
+        self.done = self.n_arrived == self.n_agents or self.n_deads > 0
+
+    def metrics(self):                              # the per-agent entries of Step.info, env.py:174-176
+        return {"has-arrived": [bool(x) for x in self.w.arrived()], "is-alive": [bool(x) for x in self.w.alive()]}
+
     def step(self, actions):                        # env.py:165-187
         assert not self.done, "Cannot step in a done environment"
         events = self.w.step([int(a) for a in actions])

@@ -1,0 +1,15 @@
+"""The reference's LLE-level tests (tests/golden/kat_env.json, from python/tests/test_env.py) against the per-env
+restatement of env.py + reward_strategy.py on the oracle (tests/oracle_env.py): this pins that restatement."""
+import pytest
+
+from tests.kat_env_runner import load_cases, run_case
+from tests.oracle_env import OracleLLE
+
+CASES = load_cases()
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_oracle_env_kat(oracle_mod, case):
+    def make(c):
+        return OracleLLE(oracle_mod.OracleWorld(c["map"]), multi_objective=c["multi_objective"])
+    run_case(make, case)

@@ -82,3 +82,43 @@ def test_batched_lle_matches_per_env_restatement(oracle_mod, name, kw, randomize
         rewards = [refs[e].step(actions[e])[0] for e in range(n)]
         assert int(out["err"].max()) == 0
         compare(out, rewards, f"t={t}")
+
+
+# ---- the reference's own LLE tests (tests/golden/kat_env.json) through BatchedLLE
+from tests.kat_env_runner import load_cases, run_case  # noqa: E402
+
+ENV_CASES = load_cases()
+
+
+class _BatchedAdapter:
+    def __init__(self, case):
+        from lle_amd import BatchedLLE
+        self.n = 70  # every env plays the same script; the first and the last are checked
+        self.env = BatchedLLE(case["map"], self.n, multi_objective=case["multi_objective"])
+
+    def reset(self):
+        self.env.reset()
+
+    def step(self, actions):
+        import torch
+        out = self.env.step(torch.tensor([actions] * self.n, dtype=torch.uint8))
+        assert int(out["err"].max()) == 0
+        r, d = out["reward"].cpu().numpy(), out["done"].cpu().numpy()
+        assert np.array_equal(r[0], r[-1]) and d[0] == d[-1]
+        return r[0], d[0]
+
+    def set_state(self, positions, gems, alive):
+        import torch
+        n = self.n
+        err = self.env.set_state(torch.tensor([positions] * n, dtype=torch.uint8), torch.tensor([gems] * n, dtype=torch.bool),
+                                 torch.tensor([alive] * n, dtype=torch.bool))
+        assert int(err.max()) == 0
+
+    def metrics(self):
+        return {"has-arrived": [bool(x) for x in self.env.agents_arrived()[-1].cpu().numpy()],
+                "is-alive": [bool(x) for x in self.env.agents_alive()[-1].cpu().numpy()]}
+
+
+@pytest.mark.parametrize("case", ENV_CASES, ids=[c["name"] for c in ENV_CASES])
+def test_batched_lle_env_kat(case):
+    run_case(_BatchedAdapter, case)
