@@ -201,7 +201,10 @@ class Map:
 
     def __del__(self):
         if getattr(self, "h", None):
-            lib().lle_map_free(self.h)
+            try:
+                lib().lle_map_free(self.h)
+            except Exception:  # noqa: BLE001  (interpreter shutdown)
+                pass
             self.h = None
 
     def positions(self, which):

@@ -109,7 +109,10 @@ class BatchedWorld:
     def __del__(self):
         h = getattr(self, "h", None)
         if h:
-            _capi.lib().lle_batch_free(h)
+            try:
+                _capi.lib().lle_batch_free(h)
+            except Exception:  # noqa: BLE001  (interpreter shutdown: module globals may already be gone)
+                pass
             self.h = None
 
     def set_envs_per_wave(self, epw):
