@@ -138,9 +138,11 @@ __global__ void __launch_bounds__(256) partial_observe_kernel(BatchPtrs P, int8_
     T.beam_colour = hdr->beam_colour;
     T.A = A; T.H = (int)hdr->H; T.W = (int)hdr->W;
     const uint32_t rec_dwords = (uint32_t)(As / 2 + 1 + L);
-    const uint32_t priv_bytes = pitch + OBS_ENVS_PER_WAVE * rec_dwords * 4u;
+    const uint32_t occ_bytes = ((hdr->HW + 1u) / 2u * 4u + 15u) & ~15u;  // which agents stand on a cell: u16 per cell
+    const uint32_t priv_bytes = pitch + OBS_ENVS_PER_WAVE * rec_dwords * 4u + occ_bytes;
     int8_t* row = reinterpret_cast<int8_t*>(lds + tab_bytes + unit_bytes + wave_in_wg * priv_bytes);
     uint32_t* recs = reinterpret_cast<uint32_t*>(row + pitch);
+    uint32_t* occ = recs + OBS_ENVS_PER_WAVE * rec_dwords;
     const int64_t env0 = env_base + (int64_t)wave_id * OBS_ENVS_PER_WAVE;
     int64_t n_here = env_limit - env0;
     n_here = n_here < 0 ? 0 : (n_here > (int64_t)OBS_ENVS_PER_WAVE ? (int64_t)OBS_ENVS_PER_WAVE : n_here);
@@ -164,10 +166,43 @@ __global__ void __launch_bounds__(256) partial_observe_kernel(BatchPtrs P, int8_
         const uint32_t* beams = rec + As / 2 + 1;
         if (per_env_sources) T.beam_colour = P.src_colour + (env0 + e) * src_stride_of(L);  // this env's colours
         for (uint32_t c = lane; c < n_chunks; c += 64) row16[c] = make_uint4(0u, 0u, 0u, 0u);
-        wave_sync();  // LDS operations of a wave execute in order: the byte writes below land after the clears
+        for (uint32_t c = lane; c < occ_bytes / 16u; c += 64) reinterpret_cast<uint4*>(occ)[c] = make_uint4(0u, 0u, 0u, 0u);
+        wave_sync();  // LDS operations of a wave execute in order: the writes below land after the clears
+        if ((int)lane < A) {  // dead agents included (agents_positions), so two agents may share a cell: a bit each
+            const uint32_t cell = (uint32_t)(pos[lane] & 0xFFu) * (uint32_t)T.W + (uint32_t)(pos[lane] >> 8);
+            atomicOr(&occ[cell >> 1], (1u << lane) << (16u * (cell & 1u)));
+        }
+        wave_sync();
+        const int layers = 2 * A + 3, centre = k / 2;
         for (uint32_t u = lane; u < units; u += 64) {
             const uint32_t t = unit_tab[u];
-            partial_cell<false>(T, pos, gems, beams, (int)(t & 0xFFu), (int)((t >> 8) & 0xFFu), (int)(t >> 16), k, row);
+            const int a = (int)(t & 0xFFu), wi = (int)((t >> 8) & 0xFFu), wj = (int)(t >> 16);
+            const int i = (int)(pos[a] & 0xFFu) - centre + wi, j = (int)(pos[a] >> 8) - centre + wj;
+            if (i < 0 || j < 0 || i >= T.H || j >= T.W) continue;
+            const int cell = i * T.W + j;
+            uint32_t here = (occ[cell >> 1] >> (16 * (cell & 1))) & 0xFFFFu;
+            const uint32_t meta = T.cell_meta[cell];
+            const uint64_t lay = T.cell_lay[cell];
+            int8_t* cp = row + (a * layers) * (int)kk + wi * k + wj;
+            while (here) {  // agents first (observations.py:345-346)
+                const int a2 = __ffs((int)here) - 1;
+                here &= here - 1u;
+                cp[a2 * (int)kk] = 1;
+            }
+            if ((meta & 7u) == K_FLOOR && lay == 0ull) continue;  // nothing else can be on the cell
+            // gems, exits, walls, lasers that are on, -1 at sources: the reference's order (partial_cell, observers_logic.hpp)
+            const uint32_t kind = meta & 7u, idx = (meta >> 3) & 31u;
+            const int WALL = A, LASER_0 = A + 1, GEM = 2 * A + 1, EXIT = 2 * A + 2;
+            if (kind == K_GEM && !((gems >> idx) & 1u)) cp[GEM * (int)kk] = 1;
+            if (kind == K_EXIT) cp[EXIT * (int)kk] = 1;
+            if (kind == K_WALL || kind == K_SOURCE) cp[WALL * (int)kk] = 1;
+            for (int q = 0; q < 2; q++) {
+                const uint32_t e2 = (uint32_t)(lay >> (16 * q)) & 0xFFFFu;
+                if (!(e2 & LAY_VALID)) break;
+                const uint32_t beam = (e2 >> 1) & 31u, off = (e2 >> 6) & 31u;
+                if ((beams[beam] >> off) & 1u) cp[(LASER_0 + (int)T.beam_colour[beam]) * (int)kk] = 1;
+            }
+            if (kind == K_SOURCE) cp[(LASER_0 + (int)T.beam_colour[idx]) * (int)kk] = -1;
         }
         wave_sync();
         uint4* __restrict__ dst = reinterpret_cast<uint4*>(out + (uint64_t)(env0 + e) * pitch);
@@ -260,7 +295,7 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
                                   MapSel M, hipStream_t stream) {
     const uint32_t pitch = partial_pitch((int)h.A, k);
     const uint32_t As = (uint32_t)agent_stride_of((int)h.A, (int)h.L);
-    const uint32_t priv = pitch + OBS_ENVS_PER_WAVE * (As / 2 + 1 + h.L) * 4u;
+    const uint32_t priv = pitch + OBS_ENVS_PER_WAVE * (As / 2 + 1 + h.L) * 4u + (((h.HW + 1u) / 2u * 4u + 15u) & ~15u);
     const uint32_t shared = h.lds_table_bytes + (((uint32_t)(h.A * k * k) * 4u + 15u) & ~15u);
     uint32_t wpw = cap_wpw(4, M);
     while (wpw > 1 && shared + wpw * priv > OBS_LDS_LIMIT) wpw >>= 1;
