@@ -421,11 +421,16 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
     LLE_STAMP(4);
     // ---- phase 2: layered observation, one environment of the wave at a time
     if (write_obs && n_here > 0) {
-        if (pes)
-            write_observations_env(A, L, hdr->HW, hdr->n_elems, hdr->n_chunks, hdr->obs_stride, elems, bare, tmpl, scratch, scr_stride,
-                                   P.obs, env0, n_here, lane);
-        else
-            write_observations(A, L, hdr->D, hdr->n_chunks, hdr->obs_stride, dyn, tmpl, scratch, scr_stride, P.obs, env0, n_here, lane);
+        const bool wt = (K.flags & LAUNCH_WRITE_THROUGH) != 0;
+        if (pes) {
+            if (wt) write_observations_env<true>(A, L, hdr->HW, hdr->n_elems, hdr->n_chunks, hdr->obs_stride, elems, bare, tmpl, scratch,
+                                                 scr_stride, P.obs, env0, n_here, lane);
+            else write_observations_env<false>(A, L, hdr->HW, hdr->n_elems, hdr->n_chunks, hdr->obs_stride, elems, bare, tmpl, scratch,
+                                               scr_stride, P.obs, env0, n_here, lane);
+        } else {
+            if (wt) write_observations<true>(A, L, hdr->D, hdr->n_chunks, hdr->obs_stride, dyn, tmpl, scratch, scr_stride, P.obs, env0, n_here, lane);
+            else write_observations<false>(A, L, hdr->D, hdr->n_chunks, hdr->obs_stride, dyn, tmpl, scratch, scr_stride, P.obs, env0, n_here, lane);
+        }
     }
     LLE_STAMP(5);
     if (MODE == MODE_STEP) flush_stats(P.stats, wave_id, cnt, A, lane);
@@ -865,11 +870,16 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
     if (post_first) post_step();
 
     if (write_obs && n_here > 0) {
-        if (PES)
-            write_observations_env(A, L, h_HW, hdr->n_elems, h_n_chunks, h_obs_stride, elems, bare, tmpl, scratch, scr_stride,
-                                   obs_out, env0, n_here, lane);
-        else
-            write_observations(A, L, h_D, h_n_chunks, h_obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane);
+        const bool wt = (K.flags & LAUNCH_WRITE_THROUGH) != 0;  // see stream_store (obs_stream.hpp)
+        if (PES) {
+            if (wt) write_observations_env<true>(A, L, h_HW, hdr->n_elems, h_n_chunks, h_obs_stride, elems, bare, tmpl, scratch, scr_stride,
+                                                 obs_out, env0, n_here, lane);
+            else write_observations_env<false>(A, L, h_HW, hdr->n_elems, h_n_chunks, h_obs_stride, elems, bare, tmpl, scratch, scr_stride,
+                                               obs_out, env0, n_here, lane);
+        } else {
+            if (wt) write_observations<true>(A, L, h_D, h_n_chunks, h_obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane);
+            else write_observations<false>(A, L, h_D, h_n_chunks, h_obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane);
+        }
     }
     wave_sync();
     if (!post_first) post_step();
@@ -956,8 +966,19 @@ uint32_t kernel_waves_per_wg(const MapHeader& h, bool pes) {
     return 1;
 }
 
+// Store policy of a launch that writes `bytes` of observation rows (WRITE_THROUGH_MAX_BYTES, tables.h).
+// LLE_WRITE_THROUGH=0 / 1 forces it (tuning aid).
+bool write_through_pays(uint64_t bytes) {
+    static const int forced = [] {
+        const char* o = getenv("LLE_WRITE_THROUGH");
+        return o && (o[0] == '0' || o[0] == '1') ? o[0] - '0' : -1;
+    }();
+    return forced >= 0 ? forced != 0 : bytes <= WRITE_THROUGH_MAX_BYTES;
+}
+
 hipError_t launch_world_kernel(int mode, const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K_in, hipStream_t stream) {
     LaunchArgs K = K_in;
+    if (write_through_pays((uint64_t)(K.env_limit - K.env_base) * h.obs_stride)) K.flags |= LAUNCH_WRITE_THROUGH;
     const bool pes = (K.flags & LAUNCH_PER_ENV_SOURCES) != 0;
     uint32_t wpw = kernel_waves_per_wg(h, pes);
     if (K.envs_per_map && !K.map_override) {  // a workgroup's environments must belong to one map
@@ -1042,6 +1063,10 @@ hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const Laun
     const int G = step_group((int)h.A), lm = step_lm((int)h.L);
     const bool pes = (K.flags & LAUNCH_PER_ENV_SOURCES) != 0;
     K.n_sources = h.L;
+    {   // a ring keeps the rows of min(n_steps, ring_slots) steps; without one every step overwrites the same rows
+        const uint64_t slots = K.ring_slots ? (K.n_steps < K.ring_slots ? (K.n_steps ? K.n_steps : 1u) : K.ring_slots) : 1u;
+        if (write_through_pays((uint64_t)(K.env_limit - K.env_base) * h.obs_stride * slots)) K.flags |= LAUNCH_WRITE_THROUGH;
+    }
     if (pes || K.envs_per_map) K.flags |= LAUNCH_GENERAL;
     else {
         if (K.n_steps > 1 || K.ring_slots || K.stamps) K.flags |= LAUNCH_ROLLOUT;

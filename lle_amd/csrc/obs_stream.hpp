@@ -42,9 +42,45 @@ __device__ __forceinline__ void copy_tables_to_lds(const uint8_t* __restrict__ t
     }
 }
 
+// ---- the stores of an observation stream.
+// WT = write-through (`sc1`: agent scope, so the line leaves the XCD's L2 for the Infinity Cache as it is written).
+// A plain store leaves the row dirty in L2 and the end of the kernel writes all of it back before the next launch can
+// start; measured on level 6 (1 872 B rows): 65 536 envs 22.8 -> 21.3 us per launch, 16 384 envs 11.4 -> 9.7 us.  Once
+// the rows of one launch no longer fit the 256 MB Infinity Cache the order flips (262 144 envs: 108 us plain, 166 us
+// written through), so the launcher picks the policy from the bytes a launch writes (LAUNCH_WRITE_THROUGH).
+// `nt` stores measured 50 % slower than plain ones at every size.
+template <bool WT>
+__device__ __forceinline__ void stream_store(uint4* p, const uint4& v) {
+    if constexpr (WT) {
+        const u32x4 w = {v.x, v.y, v.z, v.w};
+        // `s_nop 1`: a store of more than 64 bits reads its data VGPRs late, and a VALU write to them within the next two
+        // wait states corrupts the stored value (the compiler pads its own stores; it cannot see inside the asm --
+        // without the nop the lanes that finish last stored the next store's address instead of the row's bytes)
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(w));
+    } else {
+        *p = v;
+    }
+}
+
+// Chunks [first + lane, n_chunks) of a row from LDS, 1 KiB per wave instruction; four LDS reads are in flight before the
+// first store so that a long row is not one LDS round trip per KiB.
+template <bool WT>
+__device__ __forceinline__ void stream_row(uint4* __restrict__ dst, const uint4* srcv, uint32_t first, uint32_t n_chunks, uint32_t lane) {
+    uint32_t c = first + lane;
+    for (; c + 192u < n_chunks; c += 256u) {
+        const uint4 q0 = srcv[c], q1 = srcv[c + 64u], q2 = srcv[c + 128u], q3 = srcv[c + 192u];
+        stream_store<WT>(dst + c, q0);
+        stream_store<WT>(dst + c + 64u, q1);
+        stream_store<WT>(dst + c + 128u, q2);
+        stream_store<WT>(dst + c + 192u, q3);
+    }
+    for (; c < n_chunks; c += 64u) stream_store<WT>(dst + c, srcv[c]);
+}
+
 // ---- phase 2: layered observation of the wave's environments, one environment at a time.
 // `scratch` holds one hand-over record per environment: [0 | beam masks | ~gem bits | byte index of each agent].
 // `obs_stride` = bytes between the rows of consecutive environments in `obs`.
+template <bool WT>
 __device__ __forceinline__ void write_observations(int A, int L, uint32_t D, uint32_t n_chunks, uint64_t obs_stride,
                                                    const uint64_t* dyn, int8_t* tmpl, const uint32_t* scratch,
                                                    uint32_t scr_stride, int8_t* __restrict__ obs, int64_t env0,
@@ -90,12 +126,10 @@ __device__ __forceinline__ void write_observations(int A, int L, uint32_t D, uin
         {
             const uint32_t c0 = lane, c1 = lane + 64u;
             const uint4 v0 = srcv[c0 < n_chunks ? c0 : 0u], v1 = srcv[c1 < n_chunks ? c1 : 0u];
-            // plain stores: `nt` measured 40 % slower and `sc0 sc1` (write-through) no faster at 65 536 envs and
-            // 50 % slower at 262 144
-            if (c0 < n_chunks) dst[c0] = v0;
-            if (c1 < n_chunks) dst[c1] = v1;
+            if (c0 < n_chunks) stream_store<WT>(dst + c0, v0);
+            if (c1 < n_chunks) stream_store<WT>(dst + c1, v1);
         }
-        for (uint32_t c = lane + 128u; c < n_chunks; c += 64) dst[c] = srcv[c];  // rows longer than 2 KiB
+        if (n_chunks > 128u) stream_row<WT>(dst, srcv, 128u, n_chunks, lane);  // rows longer than 2 KiB
         wave_sync();
         // (d) agents off again (their layers are all-zero in the static copy); LDS is in order, so this lands after
         // the reads above and before the next environment's patches
@@ -122,6 +156,7 @@ __device__ __forceinline__ void elem_eval(uint32_t e, const uint32_t* sc, int A,
     val = type == ELEM_SOURCE ? -1 : 1;
     on = type == ELEM_SOURCE ? true : (is_gem ? ((sc[L + 1] >> i5) & 1u) != 0 : ((sc[1 + i5] >> off) & 1u) != 0);
 }
+template <bool WT>
 __device__ __forceinline__ void write_observations_env(int A, int L, uint32_t HW, uint32_t n_elems, uint32_t n_chunks,
                                                        uint64_t obs_stride, const uint32_t* elems, const int8_t* bare,
                                                        int8_t* tmpl, const uint32_t* scratch, uint32_t scr_stride,
@@ -147,7 +182,7 @@ __device__ __forceinline__ void write_observations_env(int A, int L, uint32_t HW
         if (is_agent_lane) tmpl[agent_idx] = 1;
         wave_sync();
         uint4* __restrict__ dst = reinterpret_cast<uint4*>(obs + (uint64_t)(env0 + k) * obs_stride);
-        for (uint32_t c = lane; c < n_chunks; c += 64) dst[c] = srcv[c];
+        stream_row<WT>(dst, srcv, 0u, n_chunks, lane);
         wave_sync();
         // bare bytes back (LDS is in order: after the reads above, before the next environment's writes)
         if (on0) tmpl[idx0] = bare[idx0];
