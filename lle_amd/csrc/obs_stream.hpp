@@ -77,6 +77,17 @@ __device__ __forceinline__ void stream_row(uint4* __restrict__ dst, const uint4*
     for (; c < n_chunks; c += 64u) stream_store<WT>(dst + c, srcv[c]);
 }
 
+// A whole row: the first 2 KiB as two unconditional LDS reads ahead of their stores (most maps' rows end there), the
+// rest through stream_row.
+template <bool WT>
+__device__ __forceinline__ void stream_whole_row(uint4* __restrict__ dst, const uint4* srcv, uint32_t n_chunks, uint32_t lane) {
+    const uint32_t c0 = lane, c1 = lane + 64u;
+    const uint4 v0 = srcv[c0 < n_chunks ? c0 : 0u], v1 = srcv[c1 < n_chunks ? c1 : 0u];
+    if (c0 < n_chunks) stream_store<WT>(dst + c0, v0);
+    if (c1 < n_chunks) stream_store<WT>(dst + c1, v1);
+    if (n_chunks > 128u) stream_row<WT>(dst, srcv, 128u, n_chunks, lane);
+}
+
 // ---- phase 2: layered observation of the wave's environments, one environment at a time.
 // `scratch` holds one hand-over record per environment: [0 | beam masks | ~gem bits | byte index of each agent].
 // `obs_stride` = bytes between the rows of consecutive environments in `obs`.
@@ -123,13 +134,7 @@ __device__ __forceinline__ void write_observations(int A, int L, uint32_t D, uin
         wave_sync();
         // (c) stream the patched copy as one contiguous row: 16 B per lane, 1 KiB per wave instruction
         uint4* __restrict__ dst = reinterpret_cast<uint4*>(obs + (uint64_t)(env0 + k) * obs_stride);
-        {
-            const uint32_t c0 = lane, c1 = lane + 64u;
-            const uint4 v0 = srcv[c0 < n_chunks ? c0 : 0u], v1 = srcv[c1 < n_chunks ? c1 : 0u];
-            if (c0 < n_chunks) stream_store<WT>(dst + c0, v0);
-            if (c1 < n_chunks) stream_store<WT>(dst + c1, v1);
-        }
-        if (n_chunks > 128u) stream_row<WT>(dst, srcv, 128u, n_chunks, lane);  // rows longer than 2 KiB
+        stream_whole_row<WT>(dst, srcv, n_chunks, lane);
         wave_sync();
         // (d) agents off again (their layers are all-zero in the static copy); LDS is in order, so this lands after
         // the reads above and before the next environment's patches
@@ -182,7 +187,7 @@ __device__ __forceinline__ void write_observations_env(int A, int L, uint32_t HW
         if (is_agent_lane) tmpl[agent_idx] = 1;
         wave_sync();
         uint4* __restrict__ dst = reinterpret_cast<uint4*>(obs + (uint64_t)(env0 + k) * obs_stride);
-        stream_row<WT>(dst, srcv, 0u, n_chunks, lane);
+        stream_whole_row<WT>(dst, srcv, n_chunks, lane);
         wave_sync();
         // bare bytes back (LDS is in order: after the reads above, before the next environment's writes)
         if (on0) tmpl[idx0] = bare[idx0];

@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(256) partial_observe_kernel(BatchPtrs P, int8_
         wave_sync();
         uint4* __restrict__ dst = reinterpret_cast<uint4*>(out + (uint64_t)(env0 + e) * pitch);
         // plain stores: written through (stream_store<true>) this kernel measured 5-10 % slower at every size
-        stream_row<false>(dst, row16, 0u, n_chunks, lane);
+        stream_whole_row<false>(dst, row16, n_chunks, lane);
         wave_sync();
     }
 }
