@@ -969,11 +969,9 @@ uint32_t kernel_waves_per_wg(const MapHeader& h, bool pes) {
 // Store policy of a launch that writes `bytes` of observation rows (WRITE_THROUGH_MAX_BYTES, tables.h).
 // LLE_WRITE_THROUGH=0 / 1 forces it (tuning aid).
 bool write_through_pays(uint64_t bytes) {
-    static const int forced = [] {
-        const char* o = getenv("LLE_WRITE_THROUGH");
-        return o && (o[0] == '0' || o[0] == '1') ? o[0] - '0' : -1;
-    }();
-    return forced >= 0 ? forced != 0 : bytes <= WRITE_THROUGH_MAX_BYTES;
+    const char* o = getenv("LLE_WRITE_THROUGH");  // read per launch: the parity tests run both policies in one process
+    if (o && (o[0] == '0' || o[0] == '1') && !o[1]) return o[0] == '1';
+    return bytes <= WRITE_THROUGH_MAX_BYTES;
 }
 
 hipError_t launch_world_kernel(int mode, const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K_in, hipStream_t stream) {

@@ -371,3 +371,49 @@ def test_large_batch_byte_offsets_beyond_32_bits():
     for k in ("pos", "bits", "gems", "beams", "avail", "events", "evcount", "done", "obs"):
         assert torch.equal(getattr(big, k)[sl], getattr(small, k)), k
     assert big.stats()["env_steps"] == 6 * 2_500_000
+
+
+@pytest.mark.parametrize("policy", ["0", "1"])
+def test_store_policies_agree_with_oracle(oracle_mod, policy, monkeypatch):
+    """The observation rows are stored written-through (`sc1`) or plain depending on the bytes a launch writes
+    (obs_stream.hpp: stream_store).  Force each policy (LLE_WRITE_THROUGH) on short rows (level 6: 1 872 B), on rows
+    longer than 2 KiB (12 agents on 16x16: 7 168 B, the 4-deep stream_row path) and on the per-env-sources stream."""
+    import torch
+
+    from lle_amd import BatchedWorld
+
+    monkeypatch.setenv("LLE_WRITE_THROUGH", policy)
+    for name, n in (("level6", 2048), ("gen_16x16_12agents", 1000)):
+        text = MAPS[name]
+        ob = oracle_mod.OracleBatch(text, n)
+        bw = BatchedWorld(text, n)
+        check(bw, ob, None, f"{name} policy={policy} after reset")
+        for t in range(12):
+            bw.step(sample=True, auto_reset=True, seed=77, t=t)
+            check(bw, ob, ob.step(None, auto_reset=True, seed=77, t=t), f"{name} policy={policy} t={t}")
+    # per-env sources: same colours in every env == the map-wide stream
+    text = MAPS["level6"]
+    a, b = BatchedWorld(text, 2048), BatchedWorld(text, 2048)
+    L = a.map.n_sources
+    cols = torch.tensor([s.agent_id for s in a.map.sources()], dtype=torch.uint8, device="cuda").repeat(2048, 1)
+    assert cols.shape == (2048, L)
+    b.set_sources(colours=cols)
+    for t in range(8):
+        a.step(sample=True, auto_reset=True, seed=9, t=t)
+        b.step(sample=True, auto_reset=True, seed=9, t=t)
+        assert torch.equal(a.obs, b.obs), t
+
+
+def test_config5_plain_store_path(oracle_mod):
+    """config5 rows (20 480 B) at 16 384 envs = 335 MB per launch: beyond the write-through threshold, so the long-row
+    path with plain stores, bit-exact against the oracle."""
+    from lle_amd import BatchedWorld, mapgen
+
+    text = mapgen.config5(0)
+    n = 16384
+    ob = oracle_mod.OracleBatch(text, n)
+    bw = BatchedWorld(text, n)
+    for t in range(4):
+        bw.step(sample=True, auto_reset=True, seed=21, t=t)
+        check(bw, ob, ob.step(None, auto_reset=True, seed=21, t=t), f"t={t}")
+

@@ -46,6 +46,51 @@ __global__ void __launch_bounds__(256) fill_envs_wg(uint4* __restrict__ out, uin
     }
 }
 
+// observation-shaped stream with the store policy of stream_store (obs_stream.hpp): WT = `sc1` write-through.
+// `pitch` = 16-byte chunks between the rows of consecutive envs (117 = packed 1 872 B rows, 120 = rows padded to a
+// whole number of 128-byte lines).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <bool WT>
+__global__ void __launch_bounds__(256) fill_envs_policy(uint4* __restrict__ out, uint32_t epw, uint32_t chunks, uint32_t pitch, uint4 v) {
+    const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const u32x4 w = {v.x, v.y, v.z, v.w};
+    for (uint32_t k = 0; k < epw; k++) {
+        uint4* p = out + ((size_t)wave * epw + k) * pitch;
+        for (uint32_t c = lane; c < chunks; c += 64) {
+            if constexpr (WT) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p + c), "v"(w));
+            else p[c] = v;
+        }
+    }
+}
+
+// the step kernel's phase-2 shape: per env the wave patches a private LDS copy of the row, reads it back (2 x 16 B per
+// lane) and stores it; `lds_bytes` of dynamic LDS per workgroup bound the occupancy like the real kernel's tables do;
+// `reads` = 4-byte global loads per lane in front (the state arrays).  unroll2: two envs' LDS reads before the stores.
+template <int UNROLL>
+__global__ void __launch_bounds__(256) fill_envs_lds(uint4* __restrict__ out, const uint32_t* __restrict__ state, uint32_t epw, uint32_t chunks,
+                                                     uint32_t reads, uint4 v) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t lane = threadIdx.x & 63u, wiw = threadIdx.x >> 6, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint4* row = reinterpret_cast<uint4*>(lds + wiw * 4096u);
+    uint32_t acc = 0;
+    for (uint32_t r = 0; r < reads; r++) acc += state[((size_t)r * gridDim.x * 4 + wave) * 64 + lane];
+    row[lane] = v; row[lane + 64u] = v;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (uint32_t k = 0; k < epw; k += UNROLL) {
+        uint4 a[UNROLL], b[UNROLL];
+        for (int u = 0; u < UNROLL; u++) {
+            reinterpret_cast<uint8_t*>(row)[(lane * 29u + k + u + acc) % 1872u] = (uint8_t)(k + u);  // the patch
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            a[u] = row[lane]; b[u] = row[lane + 64u < chunks ? lane + 64u : 0u];
+        }
+        for (int u = 0; u < UNROLL; u++) {
+            uint4* p = out + ((size_t)wave * epw + k + u) * chunks;
+            p[lane] = a[u];
+            if (lane + 64u < chunks) p[lane + 64u] = b[u];
+        }
+    }
+}
+
 int main(int argc, char** argv) {
     const size_t total = (size_t)65536 * 1872;  // bytes, level-6 observation batch
     const size_t rows = total / 1024;            // 1-KiB rows
@@ -94,5 +139,30 @@ int main(int argc, char** argv) {
     }
     bench("envs: 4096 waves x 16 envs, interleaved within the workgroup", [&] { hipLaunchKernelGGL(fill_envs_wg, dim3(1024), dim3(256), 0, st, buf, 16u, 117u, v); });
     bench("hipMemsetAsync", [&] { hipMemsetAsync(buf, 1, total, st); });
+    // store policy x row pitch x batch size (GB/s below are per 65 536 x 1 872 B: scale by the env count)
+    uint4* big;
+    hipMalloc(&big, (size_t)524288 * 1920 + (1 << 20));
+    for (uint32_t envs : {65536u, 131072u, 262144u, 524288u})
+        for (uint32_t pitch : {117u, 120u})
+            for (int wt = 0; wt < 2; wt++) {
+                snprintf(name, sizeof name, "policy: %u envs, pitch %u B, %s (x%u bytes)", envs, pitch * 16, wt ? "sc1" : "plain", envs / 65536);
+                bench(name, [&] {
+                    if (wt) hipLaunchKernelGGL(fill_envs_policy<true>, dim3(envs / 64), dim3(256), 0, st, big, 16u, 117u, pitch, v);
+                    else hipLaunchKernelGGL(fill_envs_policy<false>, dim3(envs / 64), dim3(256), 0, st, big, 16u, 117u, pitch, v);
+                });
+            }
+    uint32_t* state;
+    hipMalloc(&state, (size_t)16 * 32768 * 64 * 4);
+    hipMemset(state, 0, (size_t)16 * 32768 * 64 * 4);
+    for (uint32_t envs : {65536u, 524288u})
+        for (uint32_t lds_bytes : {16384u, 21504u, 40960u})
+            for (uint32_t reads : {0u, 10u})
+                for (int unroll = 1; unroll <= 2; unroll++) {
+                    snprintf(name, sizeof name, "lds-shaped: %u envs, %u B LDS/WG, %u state loads, unroll %d (x%u bytes)", envs, lds_bytes, reads, unroll, envs / 65536);
+                    bench(name, [&] {
+                        if (unroll == 1) hipLaunchKernelGGL(fill_envs_lds<1>, dim3(envs / 64), dim3(256), lds_bytes, st, big, state, 16u, 117u, reads, v);
+                        else hipLaunchKernelGGL(fill_envs_lds<2>, dim3(envs / 64), dim3(256), lds_bytes, st, big, state, 16u, 117u, reads, v);
+                    });
+                }
     return 0;
 }
