@@ -285,6 +285,30 @@ int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64
  * walkable_lasers = 0 drops the actions that lead onto an active laser of another colour. */
 int lle_batch_available_actions(lle_batch* b, int walkable_lasers, uint8_t* out_dev, void* stream);
 
+/* Everything LLE.step returns besides the observation, for every env, in ONE launch (python/lle/env/env.py:165-187:
+ * `Step(obs, state, available_actions, reward, done, ...)`).  Each output is optional (NULL = not wanted):
+ *   state      f32 [n][3A+G]  WorldState.as_array (src/bindings/world/pyworld_state.rs:79-101), divided by (H, W) per
+ *                             coordinate when normalize_state != 0 (python/lle/observations.py:145-175)
+ *   reward     f32 [n][1]     reward_kind 0: SingleObjective.compute_reward (python/lle/env/reward_strategy.py:58-75)
+ *              f32 [n][4]     reward_kind 1: MultiObjective.compute_reward  (reward_strategy.py:90-109)
+ *   done       u8  [n]        LLE.compute_done (env.py:253-254)
+ *   available  u8  [n][A][5]  LLE.available_actions (env.py:146-163), walkable_lasers as in lle_batch_available_actions
+ *   alive, arrived u8 [n][A]  the is-alive / has-arrived entries of Step.info (env.py:174-176)
+ * All pointers are device memory. */
+typedef struct lle_env_outputs {
+    float* state;
+    float* reward;
+    uint8_t* done;
+    uint8_t* available;
+    uint8_t* alive;
+    uint8_t* arrived;
+    int32_t normalize_state;
+    int32_t reward_kind;
+    int32_t walkable_lasers;
+    int32_t pad;
+} lle_env_outputs;
+int lle_batch_env_outputs(lle_batch* b, const lle_env_outputs* out, void* stream);
+
 /* Sum the per-block counters (synchronises `stream`):
  * out[0] env_steps, [1] agent_steps, [2] gems, [3] exits, [4] deaths, [5] invalid, [6] auto_resets, [7] reward_sum */
 int lle_batch_stats(lle_batch* b, int64_t out[8], int reset_counters, void* stream);

@@ -39,7 +39,7 @@ EXPORTS = [
     "lle_batch_arena_bytes", "lle_batch_create", "lle_batch_arena_bytes_multi", "lle_batch_create_multi", "lle_batch_n_maps", "lle_batch_free", "lle_batch_get_buffer", "lle_batch_n_envs",
     "lle_batch_reset", "lle_batch_step", "lle_batch_rollout", "lle_batch_set_state", "lle_batch_update_sources", "lle_batch_observe",
     "lle_batch_snapshot_bytes", "lle_batch_snapshot", "lle_batch_restore",
-    "lle_batch_set_sources", "lle_batch_obs_desc", "lle_batch_observe_as", "lle_batch_available_actions",
+    "lle_batch_set_sources", "lle_batch_obs_desc", "lle_batch_observe_as", "lle_batch_available_actions", "lle_batch_env_outputs",
     "lle_batch_stats", "lle_batch_kernel_info", "lle_batch_set_envs_per_wave", "lle_batch_step_stamped",
 ]
 
@@ -56,6 +56,13 @@ class SourceInfo(C.Structure):
 
 class LaserTile(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("i", "j", "laser_id", "offset", "layer")]
+
+
+class EnvOutputs(C.Structure):
+    """lle_env_outputs (include/lle_hip.h)."""
+    _fields_ = [("state", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p), ("available", C.c_void_p),
+                ("alive", C.c_void_p), ("arrived", C.c_void_p), ("normalize_state", C.c_int32), ("reward_kind", C.c_int32),
+                ("walkable_lasers", C.c_int32), ("pad", C.c_int32)]
 
 
 class RolloutRing(C.Structure):
@@ -156,6 +163,8 @@ def lib():
     L.lle_batch_observe_as.argtypes = [vp, i32, i32, vp, i64, vp]
     L.lle_batch_available_actions.restype = i32
     L.lle_batch_available_actions.argtypes = [vp, i32, vp, vp]
+    L.lle_batch_env_outputs.restype = i32
+    L.lle_batch_env_outputs.argtypes = [vp, C.POINTER(EnvOutputs), vp]
     L.lle_batch_stats.restype = i32
     L.lle_batch_stats.argtypes = [vp, C.POINTER(C.c_int64), i32, vp]
     L.lle_batch_kernel_info.restype = i32

@@ -260,6 +260,19 @@ class BatchedWorld:
         self._check(_capi.lib().lle_batch_available_actions(self.h, int(bool(walkable_lasers)), out.data_ptr(), self._stream()))
         return out.view(torch.bool)
 
+    def env_outputs(self, state=None, normalize_state=False, reward=None, multi_objective=False, done=None, available=None,
+                    walkable_lasers=True, alive=None, arrived=None):
+        """Everything `LLE.step` returns besides the observation, in one launch (lle_batch_env_outputs): pass the
+        tensors to fill -- state f32 [n, 3A+G], reward f32 [n, 1] ([n, 4] with multi_objective), done / available
+        [n, A, 5] / alive / arrived [n, A] as uint8 or bool -- and leave the others None."""
+        o = _capi.EnvOutputs()
+        for name, t in (("state", state), ("reward", reward), ("done", done), ("available", available), ("alive", alive), ("arrived", arrived)):
+            if t is not None:
+                assert t.is_contiguous() and t.device == self.device, name
+                setattr(o, name, t.data_ptr())
+        o.normalize_state, o.reward_kind, o.walkable_lasers = int(bool(normalize_state)), int(bool(multi_objective)), int(bool(walkable_lasers))
+        self._check(_capi.lib().lle_batch_env_outputs(self.h, C.byref(o), self._stream()))
+
     def _noop_launch(self):
         """Profiling aid: a launch that loads the tables and the state and does nothing else (step with every
         action invalid and no observation write is the closest public equivalent)."""

@@ -758,6 +758,18 @@ int lle_batch_available_actions(lle_batch* b, int walkable_lasers, uint8_t* out_
     return LLE_OK;
 }
 
+int lle_batch_env_outputs(lle_batch* b, const lle_env_outputs* out, void* stream) {
+    if (!b || !out) return fail(LLE_ERR_NULL, "NULL argument");
+    if (out->reward_kind != 0 && out->reward_kind != 1) return fail(LLE_ERR_ARG, "reward_kind must be 0 (single objective) or 1 (multi objective)");
+    HIP_TRY(hipSetDevice(b->device));
+    const MapSel M{b->envs_per_map, (uint32_t)b->layout.table_stride, 0u};
+    EnvOutputs O{out->state, out->reward, out->done, out->available, out->alive, out->arrived,
+                 out->normalize_state, out->reward_kind, out->walkable_lasers, b->per_env_sources ? 1 : 0};
+    HIP_TRY(launch_env_outputs(b->hdr, b->ptrs, O, b->n_envs, M, (hipStream_t)stream));
+    g_status = LLE_OK;
+    return LLE_OK;
+}
+
 int lle_batch_update_sources(lle_batch* b, const lle_map* map, void* stream) {
     if (!b || !map) return fail(LLE_ERR_NULL, "NULL argument");
     if (b->maps.size() != 1)

@@ -251,6 +251,57 @@ __global__ void __launch_bounds__(256) avail_kernel(BatchPtrs P, uint8_t* __rest
     for (int act = 0; act < 5; act++) o[act] = (uint8_t)((m >> act) & 1u);
 }
 
+// ---------------------------------------------------------------------------------------------- LLE.step outputs
+// One thread per (env, agent): its availability bools and alive / arrived flags, a share of the state vector
+// (elements a, a + A, ...), and -- agent 0 -- the env's reward and done.  One launch instead of the four or more a
+// host class needs when it assembles `Step` from the separate entry points.
+__global__ void __launch_bounds__(256) env_outputs_kernel(BatchPtrs P, EnvOutputs O, int64_t n_envs, MapSel M) {
+    const MapHeader* __restrict__ hdr0 = reinterpret_cast<const MapHeader*>(P.tables);
+    const int A = (int)hdr0->A, L = (int)hdr0->L, G = (int)hdr0->G;
+    const int64_t As = agent_stride_of(A, L);
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_envs * A) return;
+    const int64_t env = idx / A;
+    const int a = (int)(idx - env * A);
+    const uint64_t bits = P.bits[env];
+    const uint32_t alive = (uint32_t)bits & 0xFFFFu, arrived = (uint32_t)(bits >> 16) & 0xFFFFu;
+    if (O.alive) O.alive[idx] = (uint8_t)((alive >> a) & 1u);
+    if (O.arrived) O.arrived[idx] = (uint8_t)((arrived >> a) & 1u);
+    if (O.available) {
+        const uint8_t* __restrict__ tables = tables_of(P, M, env);
+        const MapHeader* __restrict__ hdr = reinterpret_cast<const MapHeader*>(tables);
+        ObsTables T;
+        T.cell_lay = reinterpret_cast<const uint64_t*>(tables + hdr->off_cell_lay);
+        T.cell_meta = reinterpret_cast<const uint32_t*>(tables + hdr->off_cell_meta);
+        T.beam_colour = O.per_env_sources ? P.src_colour + env * src_stride_of(L) : hdr->beam_colour;
+        T.A = A; T.H = (int)hdr->H; T.W = (int)hdr->W;
+        const uint32_t m = avail_bools(T, P.pos + env * As, P.beams + env * L, a, (uint32_t)P.avail[env * As + a], O.walkable_lasers != 0);
+        uint8_t* o = O.available + idx * 5;
+        for (int act = 0; act < 5; act++) o[act] = (uint8_t)((m >> act) & 1u);
+    }
+    if (O.state) {
+        const int len = 3 * A + G;
+        const uint32_t gems = P.gems[env];
+        for (int e = a; e < len; e += A)
+            O.state[env * len + e] = state_elem(A, G, (int)hdr0->H, (int)hdr0->W, P.pos + env * As, gems, alive, e, O.normalize_state != 0);
+    }
+    if (a == 0) {
+        if (O.done) O.done[env] = P.done[env];
+        if (O.reward) {
+            // counts of the last step: gems | exits << 8 | deaths << 16 | all-arrived bonus << 24
+            const uint32_t r = P.reward[env];
+            const float gem = (float)(r & 255u), ex = (float)((r >> 8) & 255u), died = (float)((r >> 16) & 255u), bonus = (float)(r >> 24);
+            if (O.reward_kind == 0) {
+                O.reward[env] = gem + ex - died + bonus;  // reward_strategy.py:58-75 (the death override never fires)
+            } else {  // reward_strategy.py:90-109: [gem, exit, death, done]; a death zeroes the others
+                const bool dead = died > 0.f;
+                float* o = O.reward + env * 4;
+                o[0] = dead ? 0.f : gem; o[1] = dead ? 0.f : ex; o[2] = -died; o[3] = dead ? 0.f : bonus;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- launchers
 static hipError_t grant_lds(const void* fn, uint32_t lds, uint32_t& granted) {
     if (lds > 64 * 1024 && lds > granted) {
@@ -320,6 +371,13 @@ hipError_t launch_state_observe(const MapHeader& h, const BatchPtrs& P, float* o
     const int64_t total = n_envs * (int64_t)(3 * h.A + h.G);
     if (total == 0) return hipSuccess;
     hipLaunchKernelGGL(state_observe_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, P, out, normalize, n_envs);
+    return hipGetLastError();
+}
+
+hipError_t launch_env_outputs(const MapHeader& h, const BatchPtrs& P, const EnvOutputs& O, int64_t n_envs, MapSel M, hipStream_t stream) {
+    const int64_t total = n_envs * (int64_t)h.A;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(env_outputs_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, P, O, n_envs, M);
     return hipGetLastError();
 }
 

@@ -69,7 +69,7 @@ class BatchedLLE:
     @property
     def done(self):
         """bool [n]: LLE.compute_done (env.py:253-254) -- every agent arrived, or somebody died."""
-        return self.world.done.bool()
+        return self.world.done.view(torch.bool)  # the kernel writes 0 / 1: a view, no launch
 
     def reset(self, env_mask=None, seed=None, colours=None):
         """LLE.reset (env.py:189-203) for every env, or those with env_mask != 0: world.reset(), then -- with
@@ -153,5 +153,19 @@ class BatchedLLE:
         else:
             w.step(actions)
         self._t += 1
-        return {"obs": self.get_observation(), "state": self.get_state(), "reward": self.reward(), "done": self.done,
-                "available_actions": self.available_actions(), "err": w.err}
+        return self._outputs()
+
+    def _outputs(self):
+        """obs / state / reward / done / available_actions / err after a step: one launch of lle_batch_env_outputs for
+        the small tensors (the layered observation was written by the step kernel itself); only a state type other than
+        "state" / "normalized-state" or an observation type other than layered costs a further observer launch.
+        The tensors are freshly allocated except `obs` (layered), `done` and `err`, which view the world's buffers."""
+        w, n, dev = self.world, self.n_envs, self.world.device
+        fused_state = self._state_kind[0] in (_capi.LLE_OBS_STATE, _capi.LLE_OBS_NORMALIZED_STATE)
+        state = torch.empty((n, 3 * self.n_agents + w.map.n_gems), dtype=torch.float32, device=dev) if fused_state else None
+        reward = torch.empty((n, 4 if self.multi_objective else 1), dtype=torch.float32, device=dev)
+        avail = torch.empty((n, self.n_agents, 5), dtype=torch.uint8, device=dev)
+        w.env_outputs(state=state, normalize_state=self._state_kind[0] == _capi.LLE_OBS_NORMALIZED_STATE, reward=reward,
+                      multi_objective=self.multi_objective, available=avail, walkable_lasers=self.walkable_lasers)
+        return {"obs": self.get_observation(), "state": state if fused_state else self.get_state(), "reward": reward,
+                "done": self.done, "available_actions": avail.view(torch.bool), "err": w.err}

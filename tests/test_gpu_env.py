@@ -122,3 +122,44 @@ class _BatchedAdapter:
 @pytest.mark.parametrize("case", ENV_CASES, ids=[c["name"] for c in ENV_CASES])
 def test_batched_lle_env_kat(case):
     run_case(_BatchedAdapter, case)
+
+
+@pytest.mark.parametrize("name", ["level6", "nested"])
+@pytest.mark.parametrize("per_env", [False, True])
+def test_env_outputs_equals_separate_entry_points(name, per_env):
+    """lle_batch_env_outputs (one launch) against the entry points it fuses: observe_as(state / normalized-state),
+    available_actions(walkable_lasers), the two reward strategies, done, alive / arrived."""
+    import torch
+
+    from lle_amd import BatchedWorld, _capi
+
+    text = LEVELS[6] if name == "level6" else EXTRA_MAPS[name]
+    n = 1000
+    w = BatchedWorld(text, n)
+    A, G = w.map.n_agents, w.map.n_gems
+    if per_env:
+        g = torch.Generator(device="cuda").manual_seed(3)
+        w.set_sources(colours=torch.randint(0, A, (n, w.map.n_sources), generator=g, device="cuda").to(torch.uint8))
+    for t in range(25):
+        w.step(sample=True, auto_reset=(t % 5 == 4), seed=17, t=t)
+        for normalize in (False, True):
+            for multi in (False, True):
+                for walkable in (False, True):
+                    state = torch.full((n, 3 * A + G), -7.0, device="cuda")
+                    reward = torch.full((n, 4 if multi else 1), -7.0, device="cuda")
+                    done, avail = torch.empty(n, dtype=torch.uint8, device="cuda"), torch.empty((n, A, 5), dtype=torch.uint8, device="cuda")
+                    alive, arrived = torch.empty((n, A), dtype=torch.uint8, device="cuda"), torch.empty((n, A), dtype=torch.uint8, device="cuda")
+                    w.env_outputs(state=state, normalize_state=normalize, reward=reward, multi_objective=multi, done=done,
+                                  available=avail, walkable_lasers=walkable, alive=alive, arrived=arrived)
+                    kind = _capi.LLE_OBS_NORMALIZED_STATE if normalize else _capi.LLE_OBS_STATE
+                    assert torch.equal(state.view(torch.int32), w.observe_as(kind, 0).view(torch.int32)), (t, "state")
+                    want_r = w.reward_multi_objective() if multi else w.reward_single_objective().unsqueeze(1)
+                    assert torch.equal(reward, want_r), (t, "reward")
+                    assert torch.equal(done, w.done), (t, "done")
+                    assert torch.equal(avail.view(torch.bool), w.available_actions(walkable)), (t, "available")
+                    assert torch.equal(alive.bool(), w.agents_alive()) and torch.equal(arrived.bool(), w.agents_arrived()), (t, "flags")
+    # every output is optional
+    w.env_outputs()
+    only = torch.empty((n, 1), device="cuda")
+    w.env_outputs(reward=only)
+    assert torch.equal(only, w.reward_single_objective().unsqueeze(1))
