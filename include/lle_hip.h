@@ -234,6 +234,14 @@ int lle_batch_update_sources(lle_batch* b, const lle_map* map, void* stream);
 int lle_batch_set_sources(lle_batch* b, const uint8_t* colours_dev, const uint32_t* enabled_dev, const uint8_t* env_mask_dev,
                           void* stream);
 
+/* LLE.reset with randomize_lasers in one launch (python/lle/env/env.py:189-203): lle_batch_reset of the selected envs
+ * followed by lle_batch_set_sources on the same envs -- World::reset under the sources the env HAD, then the new
+ * colours / flags on the live world, exactly the state the two calls in a row leave (events cleared, LLE_BUF_ERR =
+ * LLE_ENV_INVALID_COLOUR for a refused env, which is reset all the same).  `env_mask_dev` may be LLE_BUF_DONE itself.
+ * flags: 0, or LLE_STEP_NO_OBS when the caller steps next and does not read the observation in between. */
+int lle_batch_reset_sources(lle_batch* b, const uint8_t* colours_dev, const uint32_t* enabled_dev, const uint8_t* env_mask_dev,
+                            uint32_t flags, void* stream);
+
 /* Rebuild LLE_BUF_OBS from the current state. */
 int lle_batch_observe(lle_batch* b, void* stream);
 

@@ -207,11 +207,14 @@ class BatchedWorld:
         """Push self.map's current source colours / enabled flags to the device (LaserSource.enable/disable/set_colour)."""
         self._check(_capi.lib().lle_batch_update_sources(self.h, self.map.h, self._stream()))
 
-    def set_sources(self, colours=None, enabled=None, env_mask=None):
+    def set_sources(self, colours=None, enabled=None, env_mask=None, reset_first=False, write_obs=True):
         """Per-environment laser sources (LLE.reset with randomize_lasers, python/lle/env/env.py:198-200; LaserSource
         enable / disable): colours u8 [n, L] and/or enabled masks i32 [n] (bit l = source l on), optionally only for the
         envs with env_mask != 0.  An env given a colour >= n_agents is left unchanged with err = LLE_ENV_INVALID_COLOUR.
-        From the first call on `src_colour` / `src_enabled` hold each env's sources."""
+        From the first call on `src_colour` / `src_enabled` hold each env's sources.
+        reset_first: World.reset of the selected envs in the same launch, before the update (lle_batch_reset_sources:
+        what `reset(env_mask)` followed by this call leaves; env_mask may then be `self.done` itself; write_obs=False when
+        a step follows before anybody reads the observation)."""
         cp = ep = mp = None
         if colours is not None:
             colours = colours.to(self.device, torch.uint8).contiguous()
@@ -224,7 +227,11 @@ class BatchedWorld:
         if env_mask is not None:
             env_mask = env_mask.to(self.device, torch.uint8).contiguous()
             mp = env_mask.data_ptr()
-        self._check(_capi.lib().lle_batch_set_sources(self.h, cp, ep, mp, self._stream()))
+        if reset_first:
+            self._check(_capi.lib().lle_batch_reset_sources(self.h, cp, ep, mp, 0 if write_obs else LLE_STEP_NO_OBS, self._stream()))
+        else:
+            assert write_obs, "lle_batch_set_sources always rewrites the observation"
+            self._check(_capi.lib().lle_batch_set_sources(self.h, cp, ep, mp, self._stream()))
 
     def observe(self):
         self._check(_capi.lib().lle_batch_observe(self.h, self._stream()))

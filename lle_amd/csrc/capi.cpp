@@ -541,8 +541,8 @@ int lle_batch_set_state(lle_batch* b, void* stream) {
     return launch(b, KMODE_SET_STATE, K, stream);
 }
 
-int lle_batch_set_sources(lle_batch* b, const uint8_t* colours_dev, const uint32_t* enabled_dev, const uint8_t* env_mask_dev,
-                          void* stream) {
+static int set_sources(lle_batch* b, const uint8_t* colours_dev, const uint32_t* enabled_dev, const uint8_t* env_mask_dev,
+                       uint32_t flags, void* stream) {
     if (!b) return fail(LLE_ERR_NULL, "NULL batch");
     HIP_TRY(hipSetDevice(b->device));
     if (kernel_lds_bytes(b->hdr, 1, true) > 160 * 1024)
@@ -556,10 +556,22 @@ int lle_batch_set_sources(lle_batch* b, const uint8_t* colours_dev, const uint32
         if (rc != LLE_OK) { b->per_env_sources = false; return rc; }
     }
     LaunchArgs K{};
+    K.flags = flags;
     K.colours_in = colours_dev;
     K.enabled_in = enabled_dev;
     K.env_mask = env_mask_dev;
     return launch(b, KMODE_ENV_SOURCES, K, stream);
+}
+
+int lle_batch_set_sources(lle_batch* b, const uint8_t* colours_dev, const uint32_t* enabled_dev, const uint8_t* env_mask_dev,
+                          void* stream) {
+    return set_sources(b, colours_dev, enabled_dev, env_mask_dev, 0u, stream);
+}
+
+int lle_batch_reset_sources(lle_batch* b, const uint8_t* colours_dev, const uint32_t* enabled_dev, const uint8_t* env_mask_dev,
+                            uint32_t flags, void* stream) {
+    if (flags & ~(uint32_t)LLE_STEP_NO_OBS) return fail(LLE_ERR_ARG, "lle_batch_reset_sources takes LLE_STEP_NO_OBS or 0");
+    return set_sources(b, colours_dev, enabled_dev, env_mask_dev, LAUNCH_RESET_FIRST | (flags & LLE_STEP_NO_OBS), stream);
 }
 
 int lle_batch_observe(lle_batch* b, void* stream) {

@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
 
     LLE_STAMP(2);
     if (active) {
-        bool store_state = true, store_avail = false, touched = true;
+        bool store_state = true, store_avail = false, touched = true, reset_first = false;
         Events<AM> ev;
         ev.clear();
         uint32_t err = 0, was_reset = 0;
@@ -310,6 +310,15 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
             // and the env's reset state with the new sources (copied by the auto-reset path of the step kernel)
             const bool fill = (K.flags & LAUNCH_FILL_DEFAULTS) != 0;
             if (!K.env_mask || K.env_mask[env]) {
+                if (K.flags & LAUNCH_RESET_FIRST) {
+                    // LLE.reset with randomize_lasers (python/lle/env/env.py:189-203): world.reset() under the sources the
+                    // env has, THEN the new colours on the live world (beams blocked at reset stay as they are)
+                    Cells<AM> at0;
+                    reset_env<AM, LM>(s, mv, at0);
+                    compute_avail<AM, LM>(s, mv, at0, avail);
+                    store_avail = true;
+                    reset_first = true;
+                }
                 uint32_t new_en = fill ? hdr->enabled_mask : (K.enabled_in ? K.enabled_in[env] : mv.enabled);
                 new_en &= L >= 32 ? 0xFFFFFFFFu : ((1u << L) - 1u);
                 uint32_t ncol[LM / 4];
@@ -354,7 +363,7 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
                     for (int b = 0; b < LM; b++)
                         if (b < L) P.init_beams[env * L + b] = r.beams[b];
                 } else {
-                    store_state = false;
+                    store_state = reset_first;
                 }
                 P.err[env] = (uint8_t)err;
             } else {
@@ -374,7 +383,7 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
                 if (b < L) P.beams[env * L + b] = s.beams[b];
         }
         if (store_avail) store_u8_record<AM>(P.avail, env, avail);
-        if ((MODE == MODE_STEP || MODE == MODE_RESET || MODE == MODE_SET_STATE) && touched) {
+        if ((MODE == MODE_STEP || MODE == MODE_RESET || MODE == MODE_SET_STATE || (MODE == MODE_ENV_SOURCES && reset_first)) && touched) {
             P.err[env] = (uint8_t)err;
             P.evcount[env] = (uint8_t)(ev.n | (was_reset << 7));
             {

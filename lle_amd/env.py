@@ -76,14 +76,20 @@ class BatchedLLE:
         randomize_lasers -- a fresh colour in [0, n_agents) for every source (`colours` u8 [n, L] overrides the draw)."""
         if seed is not None:
             self.seed(seed)
+        self._reset_world(env_mask, colours)
+        return self.get_observation(), self.get_state()
+
+    def _reset_world(self, env_mask, colours=None, write_obs=True):
+        """world.reset() and, with randomize_lasers, the recolouring of the same envs: one launch either way
+        (lle_batch_reset or lle_batch_reset_sources)."""
         w = self.world
-        w.reset(env_mask)
         if self.randomize_lasers or colours is not None:
             if colours is None:
                 colours = torch.randint(0, self.n_agents, (self.n_envs, w.map.n_sources), generator=self._gen,
-                                        device=w.device, dtype=torch.int64).to(torch.uint8)
-            w.set_sources(colours=colours, env_mask=env_mask)
-        return self.get_observation(), self.get_state()
+                                        device=w.device, dtype=torch.uint8)
+            w.set_sources(colours=colours, env_mask=env_mask, reset_first=True, write_obs=write_obs)
+        else:
+            w.reset(env_mask)
 
     def set_state(self, positions, gems_collected, agents_alive=None):
         """LLE.set_state (env.py:208-217) for every env: World.set_state with the reference's semantics (lossy
@@ -146,7 +152,8 @@ class BatchedLLE:
         actions = actions.to(w.device, torch.uint8).contiguous()
         if auto_reset:
             if self.randomize_lasers:
-                self.reset(env_mask=w.done.clone())
+                # (the kernel reads an env's mask byte before it rewrites its `done`; the step rewrites the observation)
+                self._reset_world(w.done, write_obs=False)
                 w.step(actions)
             else:
                 w.step(actions, auto_reset=True)

@@ -197,3 +197,62 @@ def test_other_builders_and_modes_with_per_env_sources(oracle_mod):
     for t in range(200, 204):
         bw.step(sample=True, auto_reset=True, seed=6, t=t)
         check(bw, ob, ob.step(None, auto_reset=True, seed=6, t=t), f"t={t}")
+
+
+@pytest.mark.parametrize("name", ["level6", "nested", "gen_16x16_12agents"])
+def test_reset_sources_equals_reset_then_set_sources(name):
+    """lle_batch_reset_sources (LLE.reset with randomize_lasers in one launch) leaves every buffer exactly as
+    lle_batch_reset followed by lle_batch_set_sources on the same envs -- refused colours and `done` as the mask included."""
+    import torch
+
+    from lle_amd import BatchedWorld
+
+    text = LEVELS[6] if name == "level6" else EXTRA_MAPS[name]
+    n = 1000
+    a, b = BatchedWorld(text, n), BatchedWorld(text, n)
+    A, L = a.map.n_agents, a.map.n_sources
+    g = torch.Generator(device="cuda").manual_seed(11)
+    names = ("pos", "bits", "gems", "beams", "avail", "err", "evcount", "events", "done", "obs", "src_colour", "src_enabled")
+    for rnd in range(12):
+        for t in range(4):
+            for w in (a, b):
+                w.step(sample=True, auto_reset=False, seed=5, t=4 * rnd + t)
+        colours = torch.randint(0, A, (n, L), generator=g, device="cuda", dtype=torch.uint8)
+        if rnd % 3 == 1:
+            colours[::7, 0] = A + 1  # refused envs: reset all the same, sources unchanged
+        enabled = torch.randint(0, 1 << L, (n,), generator=g, device="cuda", dtype=torch.int32) if rnd % 2 else None
+        if rnd % 4 == 3:
+            mask_a, mask_b = None, None
+        elif rnd % 4 == 2:
+            mask_a, mask_b = a.done.clone(), b.done  # the live buffer itself
+        else:
+            mask_a = (torch.rand(n, generator=g, device="cuda") < 0.4).to(torch.uint8)
+            mask_b = mask_a
+        a.reset(mask_a)
+        a.set_sources(colours=colours, enabled=enabled, env_mask=mask_a)
+        b.set_sources(colours=colours, enabled=enabled, env_mask=mask_b, reset_first=True)
+        for k in names:
+            assert torch.equal(getattr(a, k), getattr(b, k)), (rnd, k)
+
+
+def test_reset_sources_without_observation_then_step():
+    """LLE_STEP_NO_OBS on lle_batch_reset_sources: the state is the same, and the step that follows writes the same
+    observation as after a reset that wrote one."""
+    import torch
+
+    from lle_amd import BatchedWorld
+
+    n = 777
+    a, b = BatchedWorld(LEVELS[6], n), BatchedWorld(LEVELS[6], n)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    for rnd in range(6):
+        colours = torch.randint(0, 4, (n, a.map.n_sources), generator=g, device="cuda", dtype=torch.uint8)
+        mask = (torch.rand(n, generator=g, device="cuda") < 0.5).to(torch.uint8)
+        a.set_sources(colours=colours, env_mask=mask, reset_first=True)
+        b.set_sources(colours=colours, env_mask=mask, reset_first=True, write_obs=False)
+        for k in ("pos", "bits", "gems", "beams", "avail", "done", "src_colour"):
+            assert torch.equal(getattr(a, k), getattr(b, k)), (rnd, k)
+        for t in range(3):
+            a.step(sample=True, seed=1, t=3 * rnd + t)
+            b.step(sample=True, seed=1, t=3 * rnd + t)
+            assert torch.equal(a.obs, b.obs), (rnd, t)
