@@ -11,6 +11,7 @@
 // All of them read the packed state the step kernel keeps (pos, bits, gems, beams, avail) and write to a caller buffer.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "kernels.h"
 #include "obs_stream.hpp"
@@ -118,11 +119,12 @@ __global__ void __launch_bounds__(256) view_observe_kernel(BatchPtrs P, const ui
 // Per environment the wave clears its row with 16-byte LDS stores, every lane evaluates its window cells (only
 // non-zero bytes are written), and the row is streamed as 16 B per lane.
 __global__ void __launch_bounds__(256) partial_observe_kernel(BatchPtrs P, int8_t* __restrict__ out, int k, uint32_t pitch,
-                                                              int64_t env_base, int64_t env_limit, int per_env_sources, MapSel M) {
+                                                              int64_t env_base, int64_t env_limit, int per_env_sources, MapSel M,
+                                                              uint32_t epw) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t lane = threadIdx.x & 63u, wave_in_wg = threadIdx.x >> 6, waves_per_wg = blockDim.x >> 6;
     const uint32_t wave_id = blockIdx.x * waves_per_wg + wave_in_wg;
-    const uint8_t* __restrict__ tables = tables_of(P, M, env_base + (int64_t)(blockIdx.x * waves_per_wg) * OBS_ENVS_PER_WAVE);
+    const uint8_t* __restrict__ tables = tables_of(P, M, env_base + (int64_t)(blockIdx.x * waves_per_wg) * epw);
     const MapHeader* __restrict__ hdr = reinterpret_cast<const MapHeader*>(tables);
     const int A = (int)hdr->A, L = (int)hdr->L;
     const int64_t As = agent_stride_of(A, L);
@@ -143,13 +145,13 @@ __global__ void __launch_bounds__(256) partial_observe_kernel(BatchPtrs P, int8_
     T.A = A; T.H = (int)hdr->H; T.W = (int)hdr->W;
     const uint32_t rec_dwords = (uint32_t)(As / 2 + 1 + L);
     const uint32_t occ_bytes = ((hdr->HW + 1u) / 2u * 4u + 15u) & ~15u;  // which agents stand on a cell: u16 per cell
-    const uint32_t priv_bytes = pitch + OBS_ENVS_PER_WAVE * rec_dwords * 4u + occ_bytes;
+    const uint32_t priv_bytes = pitch + ((epw * rec_dwords * 4u + 15u) & ~15u) + occ_bytes;
     int8_t* row = reinterpret_cast<int8_t*>(lds + tab_bytes + unit_bytes + wave_in_wg * priv_bytes);
     uint32_t* recs = reinterpret_cast<uint32_t*>(row + pitch);
-    uint32_t* occ = recs + OBS_ENVS_PER_WAVE * rec_dwords;
-    const int64_t env0 = env_base + (int64_t)wave_id * OBS_ENVS_PER_WAVE;
+    uint32_t* occ = reinterpret_cast<uint32_t*>(row + pitch + ((epw * rec_dwords * 4u + 15u) & ~15u));
+    const int64_t env0 = env_base + (int64_t)wave_id * epw;
     int64_t n_here = env_limit - env0;
-    n_here = n_here < 0 ? 0 : (n_here > (int64_t)OBS_ENVS_PER_WAVE ? (int64_t)OBS_ENVS_PER_WAVE : n_here);
+    n_here = n_here < 0 ? 0 : (n_here > (int64_t)epw ? (int64_t)epw : n_here);
     for (uint32_t idx = lane; idx < (uint32_t)n_here * rec_dwords; idx += 64) {
         const uint32_t e = idx / rec_dwords, f = idx - e * rec_dwords;
         const int64_t env = env0 + e;
@@ -352,7 +354,15 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
                                   MapSel M, hipStream_t stream) {
     const uint32_t pitch = partial_pitch((int)h.A, k);
     const uint32_t As = (uint32_t)agent_stride_of((int)h.A, (int)h.L);
-    const uint32_t priv = pitch + OBS_ENVS_PER_WAVE * (As / 2 + 1 + h.L) * 4u + (((h.HW + 1u) / 2u * 4u + 15u) & ~15u);
+    // envs per wavefront: the chain of one env (clear, agents, cells, stream) is latency, so fewer envs per wave = more
+    // waves in flight; measured at 65 536 envs, level 6 7x7: 16 -> 58 us, 8 -> 46, 4 -> 45, 2 -> 48; 32x32 maps (21 KB of
+    // tables per workgroup) 7x7: 166 / 172 / 185 / 209 us, 3x3: 54 / 48 / 52 / 63.  LLE_PARTIAL_EPW: tuning override.
+    uint32_t epw = 8;
+    if (const char* o = getenv("LLE_PARTIAL_EPW")) {
+        const uint32_t v = (uint32_t)atoi(o);
+        if (v >= 1 && v <= OBS_ENVS_PER_WAVE && !(v & (v - 1))) epw = v;
+    }
+    const uint32_t priv = pitch + ((epw * (As / 2 + 1 + h.L) * 4u + 15u) & ~15u) + (((h.HW + 1u) / 2u * 4u + 15u) & ~15u);
     const uint32_t shared = h.lds_table_bytes + (((uint32_t)(h.A * k * k) * 4u + 15u) & ~15u);
     uint32_t wpw = cap_wpw(4, M);
     while (wpw > 1 && shared + wpw * priv > OBS_LDS_LIMIT) wpw >>= 1;
@@ -361,9 +371,9 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
     static uint32_t granted = 0;
     hipError_t e = grant_lds(reinterpret_cast<const void*>(&partial_observe_kernel), lds, granted);
     if (e != hipSuccess) return e;
-    const uint32_t n_waves = (uint32_t)((n_envs + OBS_ENVS_PER_WAVE - 1) / OBS_ENVS_PER_WAVE);
+    const uint32_t n_waves = (uint32_t)((n_envs + epw - 1) / epw);
     hipLaunchKernelGGL(partial_observe_kernel, dim3((n_waves + wpw - 1) / wpw), dim3(64 * wpw), lds, stream, P, out, k, pitch,
-                       (int64_t)0, n_envs, per_env_sources ? 1 : 0, M);
+                       (int64_t)0, n_envs, per_env_sources ? 1 : 0, M, epw);
     return hipGetLastError();
 }
 
