@@ -1,7 +1,5 @@
-for v in 16 8 4 2 1; do
-  export LLE_PARTIAL_EPW=$v
-  echo "== partial epw $v"
-  timeout -k 10 200 python tools/microbench_observers.py 2>&1 | grep partial
-done
-unset LLE_PARTIAL_EPW
-timeout -k 10 600 python -m pytest tests/test_gpu_observers.py tests/test_gpu_env.py tests/test_gpu_multi_map.py -x -q -m gpu 2>&1 | tail -3
+for r in 1 2 3; do
+for v in base swt; do
+  if [ $v = base ]; then unset LLE_HIP_LIB; else export LLE_HIP_LIB=$PWD/lle_amd/liblle_hip_$v.so; fi
+  echo "state stores $v: $(timeout -k 10 200 python tools/microbench.py --sizes 65536,524288 --epws 0 2>&1 | grep -v amdgpu | tr '\n' '|')"
+done; done
