@@ -875,6 +875,8 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
     if (me) scratch[grp * scr_stride + L + 2 + a] = a * h_HW + cell_of(pos, W);  // ... | byte index of each agent]
     wave_sync();
     LLE_STAMP(4);
+    // (deferring it in the single-step launches of MODE 1 / 2 as well measured 1.3-1.5 us SLOWER there: those
+    // instantiations already spill, and the deferral lengthens the live ranges)
     const bool post_first = MODE != 0 || blockIdx.x * 4u >= gridDim.x * 3u;
     if (post_first) post_step();
 
@@ -1023,8 +1025,18 @@ static hipError_t launch_step_glp(const BatchPtrs& P, const LaunchArgs& K, uint3
 }
 template <int G, int LM>
 static hipError_t launch_step_gl(const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
-    if (K.flags & LAUNCH_GENERAL) return launch_step_glp<G, LM, 2, false>(P, K, n_waves, wpw, lds, stream);
     const bool ml1 = (K.flags & LAUNCH_SINGLE_LAYER) != 0;
+    if (K.flags & LAUNCH_GENERAL) {
+        if constexpr (LM == 4) {
+            if (ml1) {
+#define LLE_STEP_LX_GEN(X) case X: return launch_step_glp<G, 4, 2, true, X>(P, K, n_waves, wpw, lds, stream);
+                switch (K.n_sources) { LLE_STEP_LX_GEN(0) LLE_STEP_LX_GEN(1) LLE_STEP_LX_GEN(2) LLE_STEP_LX_GEN(3) LLE_STEP_LX_GEN(4) default: break; }
+#undef LLE_STEP_LX_GEN
+            }
+        }
+        return ml1 ? launch_step_glp<G, LM, 2, true>(P, K, n_waves, wpw, lds, stream)
+                   : launch_step_glp<G, LM, 2, false>(P, K, n_waves, wpw, lds, stream);
+    }
     const bool roll = (K.flags & LAUNCH_ROLLOUT) != 0;
     if constexpr (LM == 4) {  // maps with at most four sources and no crossing beams: exact source count at compile time
         if (ml1) {
@@ -1075,10 +1087,8 @@ hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const Laun
         if (write_through_pays((uint64_t)(K.env_limit - K.env_base) * h.obs_stride * slots)) K.flags |= LAUNCH_WRITE_THROUGH;
     }
     if (pes || K.envs_per_map) K.flags |= LAUNCH_GENERAL;
-    else {
-        if (K.n_steps > 1 || K.ring_slots || K.stamps) K.flags |= LAUNCH_ROLLOUT;
-        if (h.max_layers <= 1) K.flags |= LAUNCH_SINGLE_LAYER;
-    }
+    else if (K.n_steps > 1 || K.ring_slots || K.stamps) K.flags |= LAUNCH_ROLLOUT;
+    if (h.max_layers <= 1) K.flags |= LAUNCH_SINGLE_LAYER;  // several maps: `h` carries the maximum over the maps
     uint32_t wpw = kernel_waves_per_wg(h, pes);
     if (K.envs_per_map) {  // a workgroup's environments must belong to one map
         const uint32_t cap = 64u / (uint32_t)G;

@@ -218,7 +218,10 @@ __host__ __device__
 #endif
 inline uint32_t map_index_of(const LaunchArgs& K, int64_t env0) {
     if (K.map_override) return K.map_override - 1u;
-    return K.envs_per_map ? (uint32_t)((uint64_t)env0 / (uint64_t)K.envs_per_map) : 0u;
+    if (!K.envs_per_map) return 0u;
+    // (a 64-bit division is a long software sequence on the device, and it sits in front of the first table load)
+    if ((((uint64_t)env0 | (uint64_t)K.envs_per_map) >> 32) == 0) return (uint32_t)env0 / (uint32_t)K.envs_per_map;
+    return (uint32_t)((uint64_t)env0 / (uint64_t)K.envs_per_map);
 }
 
 

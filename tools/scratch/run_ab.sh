@@ -1,5 +1,4 @@
-for r in 1 2 3; do
-for v in base swt; do
-  if [ $v = base ]; then unset LLE_HIP_LIB; else export LLE_HIP_LIB=$PWD/lle_amd/liblle_hip_$v.so; fi
-  echo "state stores $v: $(timeout -k 10 200 python tools/microbench.py --sizes 65536,524288 --epws 0 2>&1 | grep -v amdgpu | tr '\n' '|')"
-done; done
+timeout -k 10 200 python tools/scratch/pes_parts.py 2>&1 | grep -v amdgpu
+timeout -k 10 200 python tools/microbench_multi_map.py 2>&1 | grep -v amdgpu | tail -4
+timeout -k 10 200 python tools/microbench_rollout.py 2>&1 | grep -v amdgpu | tail -6
+timeout -k 10 600 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
