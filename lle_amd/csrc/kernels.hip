@@ -585,6 +585,10 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
     uint8_t* const p_evcount = P.evcount + env_c;
     uint8_t* const p_events = P.events + env_c * 2 * As;
     uint8_t* const p_done = P.done + env_c;
+    // The general mode is short of VECTOR registers instead (it spilled eight to scratch, and a scratch reload inside
+    // the state machine is a memory round trip): there the addresses of the late stores are rebuilt from the scalar
+    // bases where they are used, and the per-lane copies above die after the loads.
+#define LLE_LATE(field, offset) (GEN ? P.field + (offset) : p_##field)
     if (env_ok) {
         raw_bits = *p_bits;
         gems = *p_gems;
@@ -831,10 +835,10 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
 #pragma unroll
     for (int k = 0; k < NW; k++) evw[k] = grp_or64<G>(evw[k]);
     if (env_ok && a == 0) {
-        *p_err = (uint8_t)err;
-        *p_evcount = (uint8_t)(n_ev | (was_reset << 7));
+        *LLE_LATE(err, env_c) = (uint8_t)err;
+        *LLE_LATE(evcount, env_c) = (uint8_t)(n_ev | (was_reset << 7));
         {
-            uint8_t* row = p_events;  // 2*As bytes per env; this kernel fills the first 2*G
+            uint8_t* row = LLE_LATE(events, env_c * 2 * As);  // 2*As bytes per env; this kernel fills the first 2*G
             if (G >= 2) {
                 uint32_t* __restrict__ w = reinterpret_cast<uint32_t*>(row);
 #pragma unroll
@@ -843,7 +847,7 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
                 *reinterpret_cast<uint16_t*>(row) = (uint16_t)evw[0];
             }
         }
-        *p_done = (alive != amask || arrived == amask) ? 1 : 0;
+        *LLE_LATE(done, env_c) = (alive != amask || arrived == amask) ? 1 : 0;
         uint32_t n_died = 0, n_gem = 0;
 #pragma unroll
         for (int k = 0; k < NW; k++) {
@@ -900,15 +904,17 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
     // ---- final state.  Written unconditionally: an env whose action was refused kept its registers unchanged
     // (world.rs:436-453: errors precede any mutation), so this rewrites the same bytes.
     if (me) {
-        *p_pos = (uint16_t)pos;
-        *p_avail = (uint8_t)avail;
+        *LLE_LATE(pos, env_c * As + a) = (uint16_t)pos;
+        *LLE_LATE(avail, env_c * As + a) = (uint8_t)avail;
     }
     if (env_ok && a == 0) {
-        *p_bits = (uint64_t)alive | ((uint64_t)arrived << 16) | ((uint64_t)occ << 32);
-        *p_gems = gems;
+        *LLE_LATE(bits, env_c) = (uint64_t)alive | ((uint64_t)arrived << 16) | ((uint64_t)occ << 32);
+        *LLE_LATE(gems, env_c) = gems;
+        uint32_t* const beams_out = LLE_LATE(beams, env_c * L);
 #pragma unroll
         for (int b = 0; b < LM; b++)
-            if (b < L) p_beams[b] = beams[b];
+            if (b < L) beams_out[b] = beams[b];
+#undef LLE_LATE
     }
     flush_stats(P.stats, wave_id, cnt, A, lane);
     if (ROLL && stamps) {
