@@ -505,13 +505,15 @@ __device__ __forceinline__ void for_each_other(uint32_t v, F&& f) {
 // ML1: no cell of the map carries more than one laser layer (every level of the reference; no crossing beams): the
 // per-layer loops run exactly once and unroll (no variable 64-bit shifts of the layer word).
 // MODE 0: one step in place, one map, the map's sources (the default).  MODE 1: + fused rollout (n_steps, trajectory
-// rings) and timeline stamps.  MODE 2 (general): + per-env sources and several maps.
+// rings) and timeline stamps.  MODE 2 (general): + several maps.  MODE 3: + per-env sources (a mode of its own, not a
+// run-time flag of MODE 2, so that neither keeps the other's reset state and colour words in registers: both are short
+// of them).
 // LX >= 0: the exact number of sources, known at compile time (instantiated for the default path of maps with at
 // most four sources: the per-beam loops lose their guards and the unused beam registers disappear; 0.4 us on level 6).
 template <int G, int LM, int MODE, bool ML1, int LX = -1>
 __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K) {
-    constexpr bool GEN = MODE == 2, ROLL = MODE >= 1;
-    const bool PES = GEN && (K.flags & LAUNCH_PER_ENV_SOURCES) != 0;
+    constexpr bool GEN = MODE >= 2, ROLL = MODE >= 1;
+    constexpr bool PES = MODE == 3;  // (the launcher picks MODE 3 exactly when LAUNCH_PER_ENV_SOURCES is set)
     // The default instantiation is one step in place and nothing else: the fused rollout (n_steps, trajectory rings)
     // and the timeline stamps run on the general one, so that their arguments do not occupy scalar registers here.
     uint64_t* const stamps = ROLL ? K.stamps : nullptr;
@@ -1033,13 +1035,20 @@ template <int G, int LM>
 static hipError_t launch_step_gl(const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
     const bool ml1 = (K.flags & LAUNCH_SINGLE_LAYER) != 0;
     if (K.flags & LAUNCH_GENERAL) {
+        const bool pes_mode = (K.flags & LAUNCH_PER_ENV_SOURCES) != 0;  // MODE 3: + per-env sources
         if constexpr (LM == 4) {
             if (ml1) {
-#define LLE_STEP_LX_GEN(X) case X: return launch_step_glp<G, 4, 2, true, X>(P, K, n_waves, wpw, lds, stream);
+#define LLE_STEP_LX_GEN(X)                                                                                 \
+    case X:                                                                                                \
+        return pes_mode ? launch_step_glp<G, 4, 3, true, X>(P, K, n_waves, wpw, lds, stream)               \
+                        : launch_step_glp<G, 4, 2, true, X>(P, K, n_waves, wpw, lds, stream);
                 switch (K.n_sources) { LLE_STEP_LX_GEN(0) LLE_STEP_LX_GEN(1) LLE_STEP_LX_GEN(2) LLE_STEP_LX_GEN(3) LLE_STEP_LX_GEN(4) default: break; }
 #undef LLE_STEP_LX_GEN
             }
         }
+        if (pes_mode)
+            return ml1 ? launch_step_glp<G, LM, 3, true>(P, K, n_waves, wpw, lds, stream)
+                       : launch_step_glp<G, LM, 3, false>(P, K, n_waves, wpw, lds, stream);
         return ml1 ? launch_step_glp<G, LM, 2, true>(P, K, n_waves, wpw, lds, stream)
                    : launch_step_glp<G, LM, 2, false>(P, K, n_waves, wpw, lds, stream);
     }
