@@ -43,6 +43,8 @@ class BatchedLLE:
         self.obs_type, self.state_type = str(obs_type), str(state_type)
         self._obs_kind = self._kind(self.obs_type, padding_size)
         self._state_kind = self._kind(self.state_type, padding_size)
+        # the step kernel's own (layered) observation is only written when somebody reads it
+        self._needs_layered = _capi.LLE_OBS_LAYERED in (self._obs_kind[0], self._state_kind[0])
         self.walkable_lasers = bool(walkable_lasers)
         self.randomize_lasers = bool(randomize_lasers)
         self.multi_objective = bool(multi_objective)
@@ -146,6 +148,7 @@ class BatchedLLE:
         The reference refuses to step a finished environment (`Cannot step in a done environment`); here such an env
         is the caller's to reset -- or pass auto_reset=True: an env that is done when the step starts is reset first
         (with fresh colours under randomize_lasers), the usual vector-env convention.
+        The step kernel's layered observation (`world.obs`) is only refreshed when obs_type or state_type is layered.
         Returns a dict of device tensors: obs, state, reward, done, available_actions, err (per-env error code of
         World.step: 0 or 1 + the agent whose action was not available, the env then being left untouched)."""
         w = self.world
@@ -154,11 +157,11 @@ class BatchedLLE:
             if self.randomize_lasers:
                 # (the kernel reads an env's mask byte before it rewrites its `done`; the step rewrites the observation)
                 self._reset_world(w.done, write_obs=False)
-                w.step(actions)
+                w.step(actions, write_obs=self._needs_layered)
             else:
-                w.step(actions, auto_reset=True)
+                w.step(actions, auto_reset=True, write_obs=self._needs_layered)
         else:
-            w.step(actions)
+            w.step(actions, write_obs=self._needs_layered)
         self._t += 1
         return self._outputs()
 
