@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 def build_native(force=False, verbose=False):
     csrc = os.path.join(_HERE, "csrc")
-    cmd = ["make", "-C", csrc, "-j4"] + (["-B"] if force else [])
+    cmd = ["make", "-C", csrc, "-j8"] + (["-B"] if force else [])
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or res.returncode != 0:
         print(res.stdout)

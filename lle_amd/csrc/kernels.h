@@ -14,6 +14,11 @@ int agent_stride(int A, int L);  // agents per env record in the per-agent buffe
 const char* kernel_variant_name(int variant);
 uint32_t kernel_lds_bytes(const MapHeader& h, uint32_t waves_per_wg, bool pes = false);
 uint32_t kernel_waves_per_wg(const MapHeader& h, bool pes = false);
+// step_kernel instantiations, one translation unit per MODE (step_mode<N>.hip; step_kernel.hpp)
+hipError_t launch_step_mode0(int G, int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream);
+hipError_t launch_step_mode1(int G, int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream);
+hipError_t launch_step_mode2(int G, int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream);
+hipError_t launch_step_mode3(int G, int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream);
 bool write_through_pays(uint64_t bytes);  // store policy of an observation stream (obs_stream.hpp: stream_store)
 hipError_t launch_world_kernel(int mode, const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K, hipStream_t stream);
 // World.step with one lane per agent (the default step path)

@@ -1,0 +1,533 @@
+// step_kernel.hpp -- World.step with one lane per agent (the hot path) and the dispatch over its instantiations.
+// Included by one translation unit per MODE (step_mode0.hip ... step_mode3.hip), so that the ~260 instantiations compile
+// in parallel; kernels.hip holds world_kernel and the host-side launch logic.
+#pragma once
+#include "kernel_common.hpp"
+
+namespace lle {
+
+// ================================================================================================
+// step_kernel<G, LM>: World.step() with one LANE PER AGENT (G = lanes per environment = power of two >= A).
+//
+// world_kernel<.., MODE_STEP> above runs one environment per lane: simple, but phase 1 is then a ~4k-instruction
+// dependency chain of ONE wave that no amount of occupancy shortens, and every wave runs it at the same time
+// (launch cost = chain + observation stream).  Here the agents of an environment sit in G neighbouring lanes, so the
+// per-agent loops of move_agents / compute_available_actions / the sampler become lane-parallel and the chain is
+// ~G times shorter; a 64-lane wave carries 64/G environments and four times as many waves share each SIMD.
+//
+// What makes the split legal (same results as the sequential reference, src/core/world.rs:477-505):
+//   * leaves of one pass commute (each only turns bits ON, and a leave skipped because an earlier one already lit its
+//     bit would have been a no-op): beam |= OR over the group of every lane's suffix;
+//   * pre-enters commute (each only clears a suffix): beam &= AND over the group of every lane's prefix;
+//   * enter reads the beams (final after leave+pre-enter) and touches only the agent's own flags, its own cell's
+//     gem and the occupant slot of its own cell (agents never share a cell), so the enters of one pass are
+//     independent; their events are ordered by agent id = lane order (prefix count inside the group);
+//   * the three loops stay in the reference's order, and passes repeat while any agent of the environment died.
+// Cross-lane traffic is DPP quad permutes (G <= 4) / ds_swizzle (G = 8, 16); nothing goes through memory.
+
+template <int J>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
+    static_assert(J >= 1 && J < 16, "group offsets only");
+    if (J == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+    if (J == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+    if (J == 3) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x1B, 0xF, 0xF, true);  // quad_perm [3,2,1,0]
+    return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (J << 10));                     // lane ^ J within 32 lanes
+}
+template <int G>
+__device__ __forceinline__ uint32_t grp_or(uint32_t v) {
+    if (G > 1) v |= lane_xor<1>(v);
+    if (G > 2) v |= lane_xor<2>(v);
+    if (G > 4) v |= lane_xor<4>(v);
+    if (G > 8) v |= lane_xor<8>(v);
+    return v;
+}
+template <int G>
+__device__ __forceinline__ uint64_t grp_or64(uint64_t v) {
+    return (uint64_t)grp_or<G>((uint32_t)v) | ((uint64_t)grp_or<G>((uint32_t)(v >> 32)) << 32);
+}
+
+// value of `v` in the group lane whose agent id is (a ^ J), for every J in 1..G-1, fed to f(other_agent_offset J, value)
+template <int G, int J = 1, typename F>
+__device__ __forceinline__ void for_each_other(uint32_t v, F&& f) {
+    if constexpr (J < G) {
+        f(J, lane_xor<J>(v));
+        for_each_other<G, J + 1>(v, f);
+    }
+}
+
+// GEN: the general instantiation -- environments with their own source colours / enabled flags (lle_batch_set_sources)
+// and/or batches of several maps (lle_batch_create_multi).  A separate instantiation, so that the default path (one
+// map, sources of the map) is compiled exactly as before: every `PES` / `tables` / `initp` below folds to a constant.
+// ML1: no cell of the map carries more than one laser layer (every level of the reference; no crossing beams): the
+// per-layer loops run exactly once and unroll (no variable 64-bit shifts of the layer word).
+// MODE 0: one step in place, one map, the map's sources (the default).  MODE 1: + fused rollout (n_steps, trajectory
+// rings) and timeline stamps.  MODE 2 (general): + several maps.  MODE 3: + per-env sources (a mode of its own, not a
+// run-time flag of MODE 2, so that neither keeps the other's reset state and colour words in registers: both are short
+// of them).
+// LX >= 0: the exact number of sources, known at compile time (instantiated for the default path of maps with at
+// most four sources: the per-beam loops lose their guards and the unused beam registers disappear; 0.4 us on level 6).
+template <int G, int LM, int MODE, bool ML1, int LX = -1>
+__global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K) {
+    constexpr bool GEN = MODE >= 2, ROLL = MODE >= 1;
+    constexpr bool PES = MODE == 3;  // (the launcher picks MODE 3 exactly when LAUNCH_PER_ENV_SOURCES is set)
+    // The default instantiation is one step in place and nothing else: the fused rollout (n_steps, trajectory rings)
+    // and the timeline stamps run on the general one, so that their arguments do not occupy scalar registers here.
+    uint64_t* const stamps = ROLL ? K.stamps : nullptr;
+#undef LLE_STAMP
+#define LLE_STAMP(i)                                                                              \
+    do {                                                                                          \
+        if (ROLL && stamps && lane == 0) stamps[(uint64_t)wave_id * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+    // environments per wavefront: at most 64 / G; fewer (lanes left idle) when the batch is small, so that there
+    // are enough wavefronts to spread phase 2 over the chip
+    const uint32_t EPW = K.envs_per_wave < (uint32_t)(64 / G) ? K.envs_per_wave : (uint32_t)(64 / G);
+    constexpr int NW = (2 * G + 7) / 8;             // 64-bit words of the event list (2 events per agent at most)
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t lane = threadIdx.x & 63u, wave_in_wg = threadIdx.x >> 6, waves_per_wg = blockDim.x >> 6;
+    const uint32_t wave_id = blockIdx.x * waves_per_wg + wave_in_wg;
+    const uint8_t* __restrict__ tables = P.tables;
+    const InitRecord* __restrict__ initp = P.init;
+    if (GEN) {  // this workgroup's map (its envs never straddle two maps: the launcher sizes workgroups accordingly)
+        const uint32_t EPW0 = K.envs_per_wave < (uint32_t)(64 / G) ? K.envs_per_wave : (uint32_t)(64 / G);
+        const uint32_t map_idx = map_index_of(K, K.env_base + (int64_t)(blockIdx.x * waves_per_wg) * EPW0);
+        tables += (uint64_t)map_idx * K.table_stride;
+        initp += map_idx;
+    }
+    const MapHeader* __restrict__ hdr = reinterpret_cast<const MapHeader*>(tables);
+    const int A = (int)hdr->A, L = LX >= 0 ? LX : (int)hdr->L, W = (int)hdr->W;
+    const uint32_t a = lane & (G - 1), grp = lane / G;  // agent id, environment slot in the wave
+    const int64_t As = agent_stride_of(A, L);           // env pitch of the per-agent buffers
+    const int64_t env0 = K.env_base + (int64_t)wave_id * EPW;
+    const int64_t env = env0 + grp;
+    const bool env_ok = grp < EPW && env < K.env_limit;
+    const bool me = env_ok && (int)a < A;           // this lane carries a real agent
+    const bool write_obs = hdr->obs_supported && !(K.flags & STEP_NO_OBS);
+    // Header fields that are needed late (after the first stores) are read HERE, as scalar loads next to the kernel
+    // arguments: read where they are used they become vector loads from global memory with a full wait each, three of
+    // them in a row between the state machine and the first observation store.
+    const uint32_t h_HW = hdr->HW, h_obs_stride = hdr->obs_stride, h_n_chunks = hdr->n_chunks, h_D = hdr->D;
+    uint32_t h_beam_full[LM];
+#pragma unroll
+    for (int b = 0; b < LM; b++) h_beam_full[b] = (b < L) ? hdr->beam_full[b] : 0u;
+    const uint32_t h_enabled = hdr->enabled_mask;
+    uint32_t h_init_beams[LM];  // the reset state's beams (shared record; the per-env one is read where it is used)
+#pragma unroll
+    for (int b = 0; b < LM; b++) h_init_beams[b] = (b < L) ? initp->beams[b] : 0u;
+    const int64_t n_here = (K.env_limit - env0) < (int64_t)EPW ? (K.env_limit - env0) : (int64_t)EPW;
+    const uint32_t bit = 1u << a, amask = (1u << A) - 1u;
+    LLE_STAMP(0);
+
+    const uint32_t tab_bytes = hdr->lds_table_bytes, tab_off = hdr->off_cell_lay;
+    copy_tables_to_lds(tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
+    const uint32_t ext_bytes = PES ? hdr->ext_bytes : 0u;
+    if (PES) copy_tables_to_lds(tables + hdr->off_bare, lds + tab_bytes, ext_bytes, lane, wave_in_wg, waves_per_wg);
+    LLE_STAMP(7);
+    __syncthreads();  // the only workgroup barrier
+
+    // ---- packed state: own position / availability, and the env-wide words replicated in the group's lanes
+    uint32_t pos = 0xFFFF0000u + a, avail = 0, beams[LM];
+    uint64_t raw_bits = 0;
+    uint32_t gems = 0;
+#pragma unroll
+    for (int b = 0; b < LM; b++) beams[b] = 0;
+    // Per-lane addresses of this env's / agent's records, computed once and kept in vector registers for the stores at
+    // the end: the scalar base pointers are then dead during the state machine (scalar registers are the scarce
+    // resource of this kernel, vector registers are not).
+    const int64_t env_c = env_ok ? env : 0;
+    uint64_t* const p_bits = P.bits + env_c;
+    uint32_t* const p_gems = P.gems + env_c;
+    uint32_t* const p_beams = P.beams + env_c * L;
+    uint16_t* const p_pos = P.pos + env_c * As + a;
+    uint8_t* const p_avail = P.avail + env_c * As + a;
+    uint8_t* const p_err = P.err + env_c;
+    uint8_t* const p_evcount = P.evcount + env_c;
+    uint8_t* const p_events = P.events + env_c * 2 * As;
+    uint8_t* const p_done = P.done + env_c;
+    // The general mode is short of VECTOR registers instead (it spilled eight to scratch, and a scratch reload inside
+    // the state machine is a memory round trip): there the addresses of the late stores are rebuilt from the scalar
+    // bases where they are used, and the per-lane copies above die after the loads.
+#define LLE_LATE(field, offset) (GEN ? P.field + (offset) : p_##field)
+    if (env_ok) {
+        raw_bits = *p_bits;
+        gems = *p_gems;
+#pragma unroll
+        for (int b = 0; b < LM; b++)
+            if (b < L) beams[b] = p_beams[b];
+    }
+    uint32_t init_pos_a = 0xFFFF0000u + a, init_avail_a = 0;  // this agent's reset position / availability
+    if (me) {
+        pos = (uint32_t)*p_pos;
+        avail = (uint32_t)*p_avail;
+        init_pos_a = PES ? (uint32_t)P.init_pos[env * As + a] : (uint32_t)initp->pos[a];
+        init_avail_a = PES ? (uint32_t)P.init_avail[env * As + a] : (uint32_t)initp->avail[a];
+    }
+    uint64_t init_bits = initp->bits;
+    uint32_t init_gems = initp->gems;
+    // per-environment sources: colours (4 per word), enabled mask, and the env's own reset state
+    constexpr int CWM = LM / 4;
+    const int CW = src_stride_of(L) / 4;
+    uint32_t colw[CWM], env_enabled = h_enabled;
+#pragma unroll
+    for (int q = 0; q < CWM; q++) colw[q] = 0;
+    if (PES && env_ok) {
+        env_enabled = P.src_enabled[env];
+#pragma unroll
+        for (int q = 0; q < CWM; q++)
+            if (q < CW) colw[q] = reinterpret_cast<const uint32_t*>(P.src_colour)[env * CW + q];
+        if (K.flags & STEP_AUTO_RESET) {
+            init_bits = P.init_bits[env];
+            init_gems = P.init_gems[env];
+        }
+    }
+
+    const uint64_t* cell_lay = reinterpret_cast<const uint64_t*>(lds);
+    const uint32_t* cell_meta = reinterpret_cast<const uint32_t*>(lds + (hdr->off_cell_meta - tab_off));
+    const uint64_t* dyn = reinterpret_cast<const uint64_t*>(lds + (hdr->off_dyn - tab_off));
+    const uint32_t scr_stride = (uint32_t)(L + A + 2 + (PES ? CW : 0)) | 1u;
+    const uint32_t priv_bytes = h_obs_stride + 64u * scr_stride * 4u;
+    int8_t* tmpl = reinterpret_cast<int8_t*>(lds + tab_bytes + ext_bytes + wave_in_wg * priv_bytes);
+    uint32_t* scratch = reinterpret_cast<uint32_t*>(tmpl + h_obs_stride);
+    const int8_t* bare = reinterpret_cast<const int8_t*>(lds + tab_bytes);
+    const uint32_t* elems = reinterpret_cast<const uint32_t*>(lds + tab_bytes + (hdr->off_elems - hdr->off_bare));
+    {
+        const uint4* pristine = PES ? reinterpret_cast<const uint4*>(bare) : reinterpret_cast<const uint4*>(lds + (hdr->off_template - tab_off));
+        uint4* mine = reinterpret_cast<uint4*>(tmpl);
+        for (uint32_t c = lane; c < h_n_chunks; c += 64) mine[c] = pristine[c];
+    }
+    wave_sync();
+    LLE_STAMP(1);
+
+    uint32_t alive = (uint32_t)raw_bits & 0xFFFFu, arrived = (uint32_t)(raw_bits >> 16) & 0xFFFFu, occ = (uint32_t)(raw_bits >> 32) & 0xFFFFu;
+    const uint32_t enabled = PES ? env_enabled : h_enabled, max_layers = ML1 ? 1u : hdr->max_layers;
+    LLE_STAMP(2);
+
+    // ---- n_steps consecutive steps of the wave's environments; the state stays in registers in between.
+    // (n_steps = 1 is World.step; more is a fused rollout with on-device action sampling, lle_batch_rollout.)
+    StepCounts cnt = {0, 0, 0, 0, 0, 0, 0};
+    const uint32_t n_steps = ROLL ? (K.n_steps ? K.n_steps : 1u) : 1u;
+    for (uint32_t it = 0; it < n_steps; it++) {
+    const uint64_t t_now = K.t + it;
+    // where this step's observation / actions / reward counts go: in place, or slot (ring_pos + step) % ring_slots of
+    // the trajectory rings (the launcher passes ring_pos already reduced modulo ring_slots; the slot advances by
+    // increment, so the single-step path carries no 64-bit division)
+    uint8_t* __restrict__ actions_out = P.actions;
+    uint32_t* __restrict__ reward_out = P.reward;
+    int8_t* __restrict__ obs_out = P.obs;
+    if (ROLL && K.ring_slots) {
+        uint32_t slot = (uint32_t)K.ring_pos + it;
+        while (slot >= K.ring_slots) slot -= K.ring_slots;
+        actions_out = K.ring_actions + (int64_t)slot * K.ring_env_count * As;
+        reward_out = K.ring_reward + (int64_t)slot * K.ring_env_count;
+        obs_out = K.ring_obs + (int64_t)slot * K.ring_env_count * (int64_t)h_obs_stride;
+    }
+
+    // ---- auto-reset: a finished env restarts from the reset state (identical for every env, see InitRecord)
+    uint32_t was_reset = 0;
+    if (K.flags & STEP_AUTO_RESET) {
+        const bool over = env_ok && (alive != amask || arrived == amask);
+        pos = (over && me) ? init_pos_a : pos;
+        avail = (over && me) ? init_avail_a : avail;
+        alive = over ? ((uint32_t)init_bits & 0xFFFFu) : alive;
+        arrived = over ? ((uint32_t)(init_bits >> 16) & 0xFFFFu) : arrived;
+        occ = over ? ((uint32_t)(init_bits >> 32) & 0xFFFFu) : occ;
+        gems = over ? init_gems : gems;
+#pragma unroll
+        for (int b = 0; b < LM; b++)
+            if (b < L) beams[b] = over ? (PES ? P.init_beams[env_ok ? env * L + b : 0] : h_init_beams[b]) : beams[b];
+        was_reset = over ? 1u : 0u;
+    }
+
+    // ---- joint action: sampled on the device, or given
+    uint32_t act = 4u;
+    if (K.flags & STEP_SAMPLE_ACTIONS) {
+        const uint32_t hp = action_hash_pair(action_step_key(K.seed, t_now), (uint64_t)(K.env_offset + env), a >> 1);
+        act = sample_action(avail, action_field(hp, a));
+        if (me) actions_out[env * As + a] = (uint8_t)act;
+    } else if (K.actions_in) {
+        if (me) {
+            act = (uint32_t)K.actions_in[env * A + a];  // caller's buffer: contiguous [n][A]
+            P.actions[env * As + a] = (uint8_t)act;
+        }
+    } else if (me) {
+        act = (uint32_t)P.actions[env * As + a];
+    }
+
+    // ---- availability check (world.rs:444-453): lowest offending agent, before any mutation.  The cached list can
+    // only disagree with the static walk mask after a failed set_state left it stale; such an action is refused.
+    const uint32_t cur_cell = me ? cell_of(pos, W) : 0u;
+    uint64_t lay_cur = cell_lay[cur_cell];
+    if (PES) lay_cur = recolour_lay<CWM>(lay_cur, colw);
+    const uint32_t meta_cur = cell_meta[cur_cell];
+    const uint32_t walk_cur = ((meta_cur >> 8) & 15u) | 16u;
+    const bool bad = me && (act > 4u || !(((avail & walk_cur) >> (act & 7u)) & 1u));
+    const uint32_t badmask = grp_or<G>(bad ? bit : 0u);
+    const uint32_t err = badmask ? (uint32_t)__ffs((int)badmask) : 0u;
+
+    uint64_t evw[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++) evw[k] = 0;
+    uint32_t n_ev = 0;
+    uint32_t meta_step = 0;   // cell meta of the agent's new cell, for the availability mask computed in post_step()
+    bool stepped = false;
+
+    if (env_ok && err == 0) {
+        // target cell (src/action.rs:18-26 on the packed i | j << 8 form); lanes without an agent keep a unique sentinel
+        uint32_t np = me ? apply_action(pos, act) : pos;
+        // solve_vertex_conflicts (world.rs:365-378): every agent whose target is shared goes back to its cell
+        bool again = true;
+        while (__any(again)) {
+            bool dup = false;
+            for_each_other<G>(np, [&](int, uint32_t other) { dup |= (other == np); });
+            np = dup ? pos : np;
+            again = grp_or<G>(dup ? 1u : 0u) != 0;
+        }
+        const uint32_t new_cell = me ? cell_of(np, W) : 0u;
+        uint64_t lay_new = cell_lay[new_cell];
+        if (PES) lay_new = recolour_lay<CWM>(lay_new, colw);
+        const uint32_t meta_new = cell_meta[new_cell];
+        const uint32_t kind = meta_new & 7u;
+        const uint32_t gbit = 1u << ((meta_new >> 3) & 31u);
+
+        // move_agents passes (world.rs:464-472)
+        bool go = true;
+        bool first_pass = true;
+        uint64_t lay_from = lay_cur;  // pass 1 leaves the old cells, later passes the new ones
+        while (__any(go)) {
+            // leave (laser.rs:199-202,157-162): what the alive agents of the env re-light, per beam
+            const uint32_t alive0 = alive;
+            const bool me_alive = go && me && (alive0 & bit);
+            uint32_t lit[LM], any_lit = 0;
+#pragma unroll
+            for (int b = 0; b < LM; b++) {
+                lit[b] = 0;
+                if (b < L) {
+                    uint32_t light = 0;
+                    for (uint32_t k = 0; k < max_layers; k++) {
+                        const uint32_t eo = (uint32_t)(lay_from >> (16 * k)) & 0xFFFFu;
+                        const bool lo = me_alive && (eo & LAY_VALID) && ((eo >> 1) & 31u) == (uint32_t)b &&
+                                        !((beams[b] >> ((eo >> 6) & 31u)) & 1u);
+                        light |= lo ? (0xFFFFFFFFu << ((eo >> 6) & 31u)) : 0u;
+                    }
+                    lit[b] = grp_or<G>(((enabled >> b) & 1u) ? light : 0u);
+                    any_lit |= lit[b];
+                }
+            }
+            // A pass after the first one leaves and re-enters the SAME cells.  If no alive agent re-lights anything, the
+            // beams cannot change (the owners' cuts are repeated as they are), so every enter repeats its outcome: alive
+            // agents stay alive, occupants / arrivals / gems are already recorded, the dead stay blocked or buried.
+            // The pass is then a no-op and `while agent_died` ends (world.rs:468-472).
+            if (!first_pass && any_lit == 0u) go = false;
+            if (go) {
+                occ &= ~alive0;  // Tile::leave: slot.take() for every alive agent
+#pragma unroll
+                for (int b = 0; b < LM; b++) {
+                    if (b < L) {
+                        uint32_t keep = 0xFFFFFFFFu;
+                        for (uint32_t k = 0; k < max_layers; k++) {
+                            const uint32_t en = (uint32_t)(lay_new >> (16 * k)) & 0xFFFFu;   // pre_enter (laser.rs:173-182)
+                            const bool pe = me_alive && (en & LAY_VALID) && ((en >> 1) & 31u) == (uint32_t)b && (en >> 11) == a;
+                            keep &= pe ? ((1u << ((en >> 6) & 31u)) - 1u) : 0xFFFFFFFFu;
+                        }
+                        const uint32_t cut = grp_or<G>(((enabled >> b) & 1u) ? ~keep : 0u);
+                        beams[b] = (beams[b] | lit[b]) & ~cut;
+                    }
+                }
+                // enter (tile.rs:29-50, laser.rs:184-197)
+                bool blocked = false;
+                for (uint32_t k = 0; k < max_layers; k++) {
+                    const uint32_t en = (uint32_t)(lay_new >> (16 * k)) & 0xFFFFu;
+                    const uint32_t m = beam_get<LM>(beams, (en >> 1) & 31u);
+                    blocked |= (en & LAY_VALID) && ((m >> ((en >> 6) & 31u)) & 1u) && ((en >> 11) != a);
+                }
+                const bool is_alive = (alive & bit) != 0;
+                const bool inner = me && !blocked;
+                const bool ev_exit = inner && kind == K_EXIT && !(arrived & bit);
+                const bool ev_gem = inner && kind == K_GEM && !(gems & gbit);
+                const bool died = me && is_alive && (blocked || kind == K_VOID);
+                const bool has_ev = died || ev_exit || ev_gem;
+                const uint32_t p1 = grp_or<G>((died ? bit : 0u) | (ev_exit ? bit << 16 : 0u));
+                const uint32_t p2 = grp_or<G>((inner ? bit : 0u) | (has_ev ? bit << 16 : 0u));
+                gems |= grp_or<G>(ev_gem ? gbit : 0u);
+                alive &= ~(p1 & 0xFFFFu);
+                arrived |= p1 >> 16;
+                occ |= p2 & 0xFFFFu;
+                const uint32_t evmask = p2 >> 16;  // agents with an event this pass: ordered by agent id
+                const uint32_t slot = n_ev + (uint32_t)__popc(evmask & (bit - 1u));
+                const uint64_t byte = has_ev ? (uint64_t)(((died ? EV_DIED : (ev_gem ? EV_GEM : EV_EXIT)) << 4) | a) : 0ull;
+#pragma unroll
+                for (int k = 0; k < NW; k++) evw[k] |= (NW == 1 || (slot >> 3) == (uint32_t)k) ? (byte << ((slot & 7u) * 8u)) : 0ull;
+                n_ev += (uint32_t)__popc(evmask);
+                go = (p1 & 0xFFFFu) != 0;  // while agent_died
+            }
+            lay_from = lay_new;
+            first_pass = false;
+        }
+        pos = np;
+#pragma unroll
+        for (int b = 0; b < LM; b++)
+            if (b < L) beams[b] &= h_beam_full[b];
+        meta_step = meta_new;
+        stepped = true;
+    }
+    LLE_STAMP(3);
+
+    // ---- everything of the step that the observation does not need: availability masks (compute_available_actions,
+    // world.rs:343-363), error code, ordered event list, done flag, reward counts, counters.  The observation needs
+    // positions, beams and gems only, so a wavefront of the OLDER half of the grid (the one the SIMD serves first, i.e.
+    // the one whose first store ends the idle time of the memory system) does this after its stream, a younger one --
+    // which waits for memory anyway and would otherwise add it to the end of the launch -- before.
+    auto post_step = [&]() {
+    if (stepped) {
+        const bool can_move = me && (alive & bit) && !(arrived & bit);
+        uint32_t blocked_dirs = 0;
+        for_each_other<G>(pos, [&](int j, uint32_t other) {
+            const int d = (int)other - (int)pos;
+            uint32_t hit = (d == -1) ? 1u : 0u;
+            hit |= (d == 1) ? 2u : 0u;
+            hit |= (d == 256) ? 4u : 0u;
+            hit |= (d == -256) ? 8u : 0u;
+            blocked_dirs |= ((occ >> (a ^ (uint32_t)j)) & 1u) ? hit : 0u;
+        });
+        avail = 16u | (can_move ? (((meta_step >> 8) & 15u) & ~blocked_dirs) : 0u);
+    }
+#pragma unroll
+    for (int k = 0; k < NW; k++) evw[k] = grp_or64<G>(evw[k]);
+    if (env_ok && a == 0) {
+        *LLE_LATE(err, env_c) = (uint8_t)err;
+        *LLE_LATE(evcount, env_c) = (uint8_t)(n_ev | (was_reset << 7));
+        {
+            uint8_t* row = LLE_LATE(events, env_c * 2 * As);  // 2*As bytes per env; this kernel fills the first 2*G
+            if (G >= 2) {
+                uint32_t* __restrict__ w = reinterpret_cast<uint32_t*>(row);
+#pragma unroll
+                for (int k = 0; k < G / 2; k++) w[k] = (uint32_t)(evw[k >> 1] >> ((k & 1) * 32));
+            } else {
+                *reinterpret_cast<uint16_t*>(row) = (uint16_t)evw[0];
+            }
+        }
+        *LLE_LATE(done, env_c) = (alive != amask || arrived == amask) ? 1 : 0;
+        uint32_t n_died = 0, n_gem = 0;
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            n_died += (uint32_t)__popcll(evw[k] & 0x2020202020202020ull);
+            n_gem += (uint32_t)__popcll(evw[k] & 0x1010101010101010ull);
+        }
+        const uint32_t n_exit = n_ev - n_died - n_gem;
+        const uint32_t bonus = (err == 0 && arrived == amask) ? 1u : 0u;
+        reward_out[env] = n_gem | (n_exit << 8) | (n_died << 16) | (bonus << 24);
+        cnt.steps += 1u; cnt.gems += n_gem; cnt.exits += n_exit; cnt.died += n_died;
+        cnt.invalid += err != 0 ? 1u : 0u; cnt.resets += was_reset; cnt.bonus += bonus;
+    }
+    };  // post_step
+
+    if (env_ok && a == 0) {
+        // hand-over record of this env for phase 2: [0 | beam masks | ~gem bits | ...
+        uint32_t* sc = scratch + grp * scr_stride;
+        sc[0] = 0u;
+#pragma unroll
+        for (int b = 0; b < LM; b++)
+            if (b < L) sc[1 + b] = beams[b];
+        sc[L + 1] = ~gems;
+        if (PES) {
+#pragma unroll
+            for (int q = 0; q < CWM; q++)
+                if (q < CW) sc[L + 2 + A + q] = colw[q];
+        }
+    }
+    if (me) scratch[grp * scr_stride + L + 2 + a] = a * h_HW + cell_of(pos, W);  // ... | byte index of each agent]
+    wave_sync();
+    LLE_STAMP(4);
+    // (deferring it in the single-step launches of MODE 1 / 2 as well measured 1.3-1.5 us SLOWER there: those
+    // instantiations already spill, and the deferral lengthens the live ranges)
+    const bool post_first = MODE != 0 || blockIdx.x * 4u >= gridDim.x * 3u;
+    if (post_first) post_step();
+
+    if (write_obs && n_here > 0) {
+        const bool wt = (K.flags & LAUNCH_WRITE_THROUGH) != 0;  // see stream_store (obs_stream.hpp)
+        if (PES) {
+            if (wt) write_observations_env<true>(A, L, h_HW, hdr->n_elems, h_n_chunks, h_obs_stride, elems, bare, tmpl, scratch, scr_stride,
+                                                 obs_out, env0, n_here, lane);
+            else write_observations_env<false>(A, L, h_HW, hdr->n_elems, h_n_chunks, h_obs_stride, elems, bare, tmpl, scratch, scr_stride,
+                                               obs_out, env0, n_here, lane);
+        } else {
+            if (wt) write_observations<true>(A, L, h_D, h_n_chunks, h_obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane);
+            else write_observations<false>(A, L, h_D, h_n_chunks, h_obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane);
+        }
+    }
+    wave_sync();
+    if (!post_first) post_step();
+    }  // steps
+    LLE_STAMP(5);
+
+    // ---- final state.  Written unconditionally: an env whose action was refused kept its registers unchanged
+    // (world.rs:436-453: errors precede any mutation), so this rewrites the same bytes.
+    if (me) {
+        *LLE_LATE(pos, env_c * As + a) = (uint16_t)pos;
+        *LLE_LATE(avail, env_c * As + a) = (uint8_t)avail;
+    }
+    if (env_ok && a == 0) {
+        *LLE_LATE(bits, env_c) = (uint64_t)alive | ((uint64_t)arrived << 16) | ((uint64_t)occ << 32);
+        *LLE_LATE(gems, env_c) = gems;
+        uint32_t* const beams_out = LLE_LATE(beams, env_c * L);
+#pragma unroll
+        for (int b = 0; b < LM; b++)
+            if (b < L) beams_out[b] = beams[b];
+#undef LLE_LATE
+    }
+    flush_stats(P.stats, wave_id, cnt, A, lane);
+    if (ROLL && stamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        LLE_STAMP(6);
+    }
+}
+
+// ---- dispatch of one MODE over G (lanes per environment), LM (beam registers), ML1 and -- for maps with at most four
+// sources and no crossing beams -- the exact source count LX
+template <int G, int LM, int MODE, bool ML1, int LX = -1>
+static hipError_t launch_step_glp(const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
+    dim3 grid((n_waves + wpw - 1) / wpw), block(64 * wpw);
+    if (lds > 64 * 1024) {  // gfx950 has 160 KiB of LDS per CU; more than 64 KiB per workgroup is opt-in
+        static uint32_t granted = 0;
+        if (lds > granted) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<G, LM, MODE, ML1, LX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            granted = lds;
+        }
+    }
+    hipLaunchKernelGGL((step_kernel<G, LM, MODE, ML1, LX>), grid, block, lds, stream, P, K);
+    return hipGetLastError();
+}
+template <int MODE, int G, int LM>
+static hipError_t launch_step_mode_gl(const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
+    const bool ml1 = (K.flags & LAUNCH_SINGLE_LAYER) != 0;
+    if constexpr (LM == 4) {
+        if (ml1) {
+#define LLE_STEP_LX(X) case X: return launch_step_glp<G, 4, MODE, true, X>(P, K, n_waves, wpw, lds, stream);
+            switch (K.n_sources) { LLE_STEP_LX(0) LLE_STEP_LX(1) LLE_STEP_LX(2) LLE_STEP_LX(3) LLE_STEP_LX(4) default: break; }
+#undef LLE_STEP_LX
+        }
+    }
+    return ml1 ? launch_step_glp<G, LM, MODE, true>(P, K, n_waves, wpw, lds, stream)
+               : launch_step_glp<G, LM, MODE, false>(P, K, n_waves, wpw, lds, stream);
+}
+template <int MODE, int G>
+static hipError_t launch_step_mode_g(int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
+    switch (lm) {
+        case 4: return launch_step_mode_gl<MODE, G, 4>(P, K, n_waves, wpw, lds, stream);
+        case 8: return launch_step_mode_gl<MODE, G, 8>(P, K, n_waves, wpw, lds, stream);
+        case 16: return launch_step_mode_gl<MODE, G, 16>(P, K, n_waves, wpw, lds, stream);
+        default: return launch_step_mode_gl<MODE, G, 32>(P, K, n_waves, wpw, lds, stream);
+    }
+}
+template <int MODE>
+static hipError_t launch_step_mode(int G, int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
+    switch (G) {
+        case 1: return launch_step_mode_g<MODE, 1>(lm, P, K, n_waves, wpw, lds, stream);
+        case 2: return launch_step_mode_g<MODE, 2>(lm, P, K, n_waves, wpw, lds, stream);
+        case 4: return launch_step_mode_g<MODE, 4>(lm, P, K, n_waves, wpw, lds, stream);
+        case 8: return launch_step_mode_g<MODE, 8>(lm, P, K, n_waves, wpw, lds, stream);
+        default: return launch_step_mode_g<MODE, 16>(lm, P, K, n_waves, wpw, lds, stream);
+    }
+}
+
+}  // namespace lle

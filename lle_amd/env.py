@@ -127,6 +127,11 @@ class BatchedLLE:
 
     def get_state(self):
         """LLE.get_state (env.py:205-206): the state generator's observation of agent 0."""
+        if self._state_kind[0] in (_capi.LLE_OBS_STATE, _capi.LLE_OBS_NORMALIZED_STATE):
+            w = self.world
+            st = torch.empty((self.n_envs, 3 * self.n_agents + w.map.n_gems), dtype=torch.float32, device=w.device)
+            w.env_outputs(state=st, normalize_state=self._state_kind[0] == _capi.LLE_OBS_NORMALIZED_STATE)
+            return st
         st = self._observe(self._state_kind)
         if self._state_kind[0] in (_capi.LLE_OBS_PARTIAL, _capi.LLE_OBS_PERSPECTIVE):
             st = st[:, 0]
@@ -139,9 +144,9 @@ class BatchedLLE:
     def reward(self):
         """Reward of the last step: SingleObjective float32 [n, 1] or MultiObjective float32 [n, 4]
         (reward_strategy.py:58-75, 90-109)."""
-        if self.multi_objective:
-            return self.world.reward_multi_objective()
-        return self.world.reward_single_objective().unsqueeze(1)
+        reward = torch.empty((self.n_envs, 4 if self.multi_objective else 1), dtype=torch.float32, device=self.world.device)
+        self.world.env_outputs(reward=reward, multi_objective=self.multi_objective)
+        return reward
 
     def step(self, actions, auto_reset=False):
         """LLE.step (env.py:165-187) for every env.  actions: integer tensor [n, n_agents] (Action values).
