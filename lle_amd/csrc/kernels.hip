@@ -499,7 +499,7 @@ hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const Laun
         if (write_through_pays((uint64_t)(K.env_limit - K.env_base) * h.obs_stride * slots)) K.flags |= LAUNCH_WRITE_THROUGH;
     }
     if (pes || K.envs_per_map) K.flags |= LAUNCH_GENERAL;
-    else if (K.n_steps > 1 || K.ring_slots || K.stamps) K.flags |= LAUNCH_ROLLOUT;
+    if (K.n_steps > 1 || K.ring_slots || K.stamps) K.flags |= LAUNCH_ROLLOUT;
     if (h.max_layers <= 1) K.flags |= LAUNCH_SINGLE_LAYER;  // several maps: `h` carries the maximum over the maps
     uint32_t wpw = kernel_waves_per_wg(h, pes);
     if (K.envs_per_map) {  // a workgroup's environments must belong to one map
@@ -511,11 +511,13 @@ hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const Laun
     const uint32_t epw = K.envs_per_wave;
     const uint32_t n_waves = (uint32_t)((K.env_limit - K.env_base + epw - 1) / epw);
     const uint32_t lds = kernel_lds_bytes(h, wpw, pes);
-    // MODE of the instantiation (step_kernel.hpp): 3 per-env sources, 2 several maps, 1 rollout / rings / stamps, 0 default
-    if (pes) return launch_step_mode3(G, lm, P, K, n_waves, wpw, lds, stream);
-    if (K.flags & LAUNCH_GENERAL) return launch_step_mode2(G, lm, P, K, n_waves, wpw, lds, stream);
-    if (K.flags & LAUNCH_ROLLOUT) return launch_step_mode1(G, lm, P, K, n_waves, wpw, lds, stream);
-    return launch_step_mode0(G, lm, P, K, n_waves, wpw, lds, stream);
+    // MODE of the instantiation (step_kernel.hpp): per-env sources 3 / 5, several maps 2 / 4, one map 1 / 0 -- the
+    // first of each pair with the rollout loop, rings and stamps, the second for single-step launches
+    const bool roll = (K.flags & LAUNCH_ROLLOUT) != 0;
+    if (pes) return roll ? launch_step_mode3(G, lm, P, K, n_waves, wpw, lds, stream) : launch_step_mode5(G, lm, P, K, n_waves, wpw, lds, stream);
+    if (K.flags & LAUNCH_GENERAL)
+        return roll ? launch_step_mode2(G, lm, P, K, n_waves, wpw, lds, stream) : launch_step_mode4(G, lm, P, K, n_waves, wpw, lds, stream);
+    return roll ? launch_step_mode1(G, lm, P, K, n_waves, wpw, lds, stream) : launch_step_mode0(G, lm, P, K, n_waves, wpw, lds, stream);
 }
 
 }  // namespace lle

@@ -63,13 +63,14 @@ __device__ __forceinline__ void for_each_other(uint32_t v, F&& f) {
 // MODE 0: one step in place, one map, the map's sources (the default).  MODE 1: + fused rollout (n_steps, trajectory
 // rings) and timeline stamps.  MODE 2 (general): + several maps.  MODE 3: + per-env sources (a mode of its own, not a
 // run-time flag of MODE 2, so that neither keeps the other's reset state and colour words in registers: both are short
-// of them).
+// of them).  MODE 4 / 5: MODE 2 / 3 without the rollout loop, rings and stamps -- the single-step launches of such
+// batches (the loop-carried state and the ring pointers are what pushes 2 / 3 into scratch).
 // LX >= 0: the exact number of sources, known at compile time (instantiated for the default path of maps with at
 // most four sources: the per-beam loops lose their guards and the unused beam registers disappear; 0.4 us on level 6).
 template <int G, int LM, int MODE, bool ML1, int LX = -1>
 __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K) {
-    constexpr bool GEN = MODE >= 2, ROLL = MODE >= 1;
-    constexpr bool PES = MODE == 3;  // (the launcher picks MODE 3 exactly when LAUNCH_PER_ENV_SOURCES is set)
+    constexpr bool GEN = MODE >= 2, ROLL = MODE >= 1 && MODE <= 3;
+    constexpr bool PES = MODE == 3 || MODE == 5;  // (the launcher picks these exactly when LAUNCH_PER_ENV_SOURCES is set)
     // The default instantiation is one step in place and nothing else: the fused rollout (n_steps, trajectory rings)
     // and the timeline stamps run on the general one, so that their arguments do not occupy scalar registers here.
     uint64_t* const stamps = ROLL ? K.stamps : nullptr;
@@ -439,7 +440,7 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
     LLE_STAMP(4);
     // (deferring it in the single-step launches of MODE 1 / 2 as well measured 1.3-1.5 us SLOWER there: those
     // instantiations already spill, and the deferral lengthens the live ranges)
-    const bool post_first = MODE != 0 || blockIdx.x * 4u >= gridDim.x * 3u;
+    const bool post_first = ROLL || blockIdx.x * 4u >= gridDim.x * 3u;
     if (post_first) post_step();
 
     if (write_obs && n_here > 0) {
