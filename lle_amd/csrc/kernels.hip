@@ -436,10 +436,14 @@ uint32_t kernel_lds_bytes(const MapHeader& h, uint32_t waves_per_wg, bool pes) {
     return h.lds_table_bytes + (pes ? h.ext_bytes : 0u) + waves_per_wg * (h.obs_stride + 64 * scr_stride * 4) + 64;
 }
 
-// wavefronts per workgroup: four when that fits a CU's LDS twice over (two workgroups per CU), else as many (4, 2, 1)
-// as fit the 160 KiB at all
+// wavefronts per workgroup: as many (4, 2, 1) as fit the 160 KiB of a CU.  More wavefronts per table copy beat more
+// workgroups per CU: config 5 (33 KB of tables, 20 KB rows) 4 -> 274 us per step, 2 -> 350, 1 -> 377 (LLE_STEP_WPW)
 constexpr uint32_t LDS_PER_CU = 160 * 1024;
 uint32_t kernel_waves_per_wg(const MapHeader& h, bool pes) {
+    if (const char* o = getenv("LLE_STEP_WPW")) {  // tuning override
+        const uint32_t v = (uint32_t)atoi(o);
+        if ((v == 1 || v == 2 || v == 4) && kernel_lds_bytes(h, v, pes) <= LDS_PER_CU) return v;
+    }
     for (uint32_t w = 4; w > 1; w >>= 1)
         if (kernel_lds_bytes(h, w, pes) <= LDS_PER_CU) return w;
     return 1;

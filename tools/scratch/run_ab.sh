@@ -1,5 +1,6 @@
-for r in 1 2; do
-for v in base sc1nt sc0sc1nt; do
-  if [ $v = base ]; then unset LLE_HIP_LIB; else export LLE_HIP_LIB=$PWD/lle_amd/liblle_hip_$v.so; fi
-  echo "stores $v: $(timeout -k 10 200 python tools/microbench.py --sizes 16384,65536,131072 --epws 0 2>&1 | grep -v amdgpu | tr '\n' '|')"
-done; done
+for v in 4 2 1; do
+  export LLE_STEP_WPW=$v
+  echo "== waves per workgroup $v"
+  timeout -k 10 200 python tools/microbench_multi_map.py 2>&1 | grep -v amdgpu | tail -2 | cut -c1-120
+  timeout -k 10 200 python tools/microbench.py --sizes 65536 --epws 0 2>&1 | grep -v amdgpu
+done
