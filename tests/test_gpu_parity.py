@@ -417,3 +417,45 @@ def test_config5_plain_store_path(oracle_mod):
         bw.step(sample=True, auto_reset=True, seed=21, t=t)
         check(bw, ob, ob.step(None, auto_reset=True, seed=21, t=t), f"t={t}")
 
+
+
+@pytest.mark.parametrize("name", ["level6", "corridor", "nested", "many_agents", "gen_20_lasers", "config5_32x32"])
+@pytest.mark.parametrize("mode", ["per_env_sources", "two_maps", "two_maps_per_env_sources"])
+def test_rollout_with_rings_equals_steps_in_every_general_mode(name, mode):
+    """The step kernel's general instantiations come in pairs (step_kernel.hpp): MODE 4 / 5 for single steps, MODE 2 / 3
+    with the rollout loop and the trajectory rings.  Same batch, same action stream: T single steps (each checked
+    against the oracle elsewhere) == one fused rollout, on every buffer and every ring slot -- over group sizes 1-16
+    and 0-20 sources."""
+    import torch
+
+    from lle_amd import BatchedWorld
+
+    text = MAPS[name]
+    n, T, R = 640, 9, 4
+    maps = [text, text] if mode.startswith("two_maps") else text
+    a, b = BatchedWorld(maps, n), BatchedWorld(maps, n)
+    L, A = a.map.n_sources, a.map.n_agents
+    if mode.endswith("per_env_sources") and L > 0:
+        g = torch.Generator(device="cuda").manual_seed(5)
+        colours = torch.randint(0, A, (n, L), generator=g, device="cuda", dtype=torch.uint8)
+        enabled = torch.randint(0, 1 << min(L, 30), (n,), generator=g, device="cuda", dtype=torch.int32)
+        for w in (a, b):
+            w.set_sources(colours=colours, enabled=enabled)
+    ring = b.make_ring(R)
+    names = ("pos", "bits", "gems", "beams", "avail", "err", "evcount", "events", "done")  # (obs / actions / reward: rings)
+    t0 = 0
+    for chunk in (T, 3):
+        per_step = []
+        for j in range(chunk):
+            a.step(sample=True, auto_reset=True, seed=31, t=t0 + j, env_offset=7)
+            per_step.append((a.obs.clone(), a.actions.clone(), a.reward.clone()))
+        b.rollout(chunk, auto_reset=True, seed=31, t=t0, env_offset=7, ring=ring, ring_pos=t0)
+        for k in names:
+            assert torch.equal(getattr(a, k), getattr(b, k)), (name, mode, chunk, k)
+        for j in range(max(0, chunk - R), chunk):
+            slot = (t0 + j) % R
+            assert torch.equal(ring["obs"][slot], per_step[j][0]), (name, mode, j, "ring obs")
+            assert torch.equal(ring["actions"][slot], per_step[j][1]), (name, mode, j, "ring actions")
+            assert torch.equal(ring["reward"][slot], per_step[j][2]), (name, mode, j, "ring reward")
+        t0 += chunk
+    assert a.stats() == b.stats()
