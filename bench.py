@@ -190,7 +190,7 @@ def main():
             "config": {"workload": f"World.level({LEVEL}) 4 agents 12x13, {n} envs/GPU, sampled actions + auto-reset + "
                                    "int8 layered obs (C=12)", "envs_per_gpu": n, "global_batch": total_envs,
                        "parallelism": f"env-shard x{world}", "kernel": info["kernel"], "envs_per_wave": info["envs_per_wave"],
-                       "lds_bytes_per_wave": info["lds_bytes"]},
+                       "lds_bytes_per_workgroup": info["lds_bytes"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(),
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n, "kernel_ms": kernel_ms},
