@@ -134,8 +134,9 @@ __global__ void __launch_bounds__(256) partial_observe_kernel(BatchPtrs P, int8_
     const uint32_t unit_bytes = (units * 4u + 15u) & ~15u;
     uint32_t* unit_tab = reinterpret_cast<uint32_t*>(lds + tab_bytes);
     for (uint32_t u = threadIdx.x; u < units; u += blockDim.x) {
-        const uint32_t a = u / kk, w = u - a * kk, wi = w / (uint32_t)k;
-        unit_tab[u] = a | (wi << 8) | ((w - wi * (uint32_t)k) << 16);
+        // [row offset of the cell's byte in layer 0 of observer a : 20 | a : 4 | wi : 4 | wj : 4]  (A <= 16, k <= 15)
+        const uint32_t a = u / kk, w = u - a * kk, wi = w / (uint32_t)k, wj = w - wi * (uint32_t)k;
+        unit_tab[u] = (a * (uint32_t)(2 * A + 3) * kk + w) | (a << 20) | (wi << 24) | (wj << 28);
     }
     __syncthreads();
     ObsTables T;
@@ -179,17 +180,18 @@ __global__ void __launch_bounds__(256) partial_observe_kernel(BatchPtrs P, int8_
             atomicOr(&occ[cell >> 1], (1u << lane) << (16u * (cell & 1u)));
         }
         wave_sync();
-        const int layers = 2 * A + 3, centre = k / 2;
+        const int centre = k / 2;
         for (uint32_t u = lane; u < units; u += 64) {
             const uint32_t t = unit_tab[u];
-            const int a = (int)(t & 0xFFu), wi = (int)((t >> 8) & 0xFFu), wj = (int)(t >> 16);
-            const int i = (int)(pos[a] & 0xFFu) - centre + wi, j = (int)(pos[a] >> 8) - centre + wj;
+            const int a = (int)((t >> 20) & 15u), wi = (int)((t >> 24) & 15u), wj = (int)(t >> 28);
+            const uint32_t pa = pos[a];
+            const int i = (int)(pa & 0xFFu) - centre + wi, j = (int)(pa >> 8) - centre + wj;
             if (i < 0 || j < 0 || i >= T.H || j >= T.W) continue;
             const int cell = i * T.W + j;
             uint32_t here = (occ[cell >> 1] >> (16 * (cell & 1))) & 0xFFFFu;
             const uint32_t meta = T.cell_meta[cell];
             const uint64_t lay = T.cell_lay[cell];
-            int8_t* cp = row + (a * layers) * (int)kk + wi * k + wj;
+            int8_t* cp = row + (t & 0xFFFFFu);
             while (here) {  // agents first (observations.py:345-346)
                 const int a2 = __ffs((int)here) - 1;
                 here &= here - 1u;
