@@ -55,8 +55,23 @@ int main(int argc, char** argv) {
     lle_batch* b = lle_batch_create(map, n, 0, arena, arena_bytes, stream);
     if (!b) { fprintf(stderr, "lle_batch_create: %s\n", lle_last_error()); return 1; }
 
-    for (int t = 0; t < steps; t++)
+    hipEvent_t e0, e1;
+    CHECK_HIP(hipEventCreate(&e0));
+    CHECK_HIP(hipEventCreate(&e1));
+    const int warmup = 20;  /* (the first launch loads the code object) */
+    for (int t = 0; t < warmup; t++)
         CHECK_LLE(lle_batch_step(b, NULL, LLE_STEP_SAMPLE_ACTIONS | LLE_STEP_AUTO_RESET, 1234, (uint64_t)t, 0, stream));
+    int64_t zero[8];
+    CHECK_LLE(lle_batch_stats(b, zero, 1, stream)); /* reset the counters */
+    CHECK_HIP(hipEventRecord(e0, stream));
+    for (int t = warmup; t < warmup + steps; t++)
+        CHECK_LLE(lle_batch_step(b, NULL, LLE_STEP_SAMPLE_ACTIONS | LLE_STEP_AUTO_RESET, 1234, (uint64_t)t, 0, stream));
+    CHECK_HIP(hipEventRecord(e1, stream));
+    CHECK_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    printf("%d steps of %lld envs: %.2f us per step, %.2f G agent-steps/s\n", steps, (long long)n, ms * 1e3 / steps,
+           (double)n * A * steps / (ms * 1e-3) / 1e9);
 
     /* everything LLE.step returns besides the observation, one launch */
     float *state = NULL, *reward = NULL;
