@@ -1,9 +1,11 @@
 // kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the batched World.
 //
-//   step_kernel<G, LM, MODE, ML1> World.step, the hot path: one LANE PER AGENT (G lanes per environment, 64/G environments
-//                                per wavefront), state machine on bitmasks with DPP / ds_swizzle group reductions.
-//   world_kernel<AM, LM, MODE>   one lane per environment, the state machine of step_logic.hpp: reset, set_state,
-//                                observe, source updates (and step, as a diagnostic).
+//   step_kernel<G, LM, MODE, ML1, LX>  World.step, the hot path (step_kernel.hpp; one translation unit per MODE,
+//                                step_mode0-5.hip): one LANE PER AGENT (G lanes per environment, 64/G environments per
+//                                wavefront), state machine on bitmasks with DPP / ds_swizzle group reductions.
+//   world_kernel<AM, LM, MODE>   (this file) one lane per environment, the state machine of step_logic.hpp: reset,
+//                                set_state, observe, source updates (and step, as a diagnostic).
+// This file also holds the host-side launch logic of both.
 //
 // Both: a workgroup = up to four 64-lane wavefronts sharing ONE copy of the map tables in LDS.  Phase 1: load the
 // packed state, run the state machine in registers, store state / events / availability masks.  Phase 2 (wave = one

@@ -1,5 +1,5 @@
 // step_kernel.hpp -- World.step with one lane per agent (the hot path) and the dispatch over its instantiations.
-// Included by one translation unit per MODE (step_mode0.hip ... step_mode3.hip), so that the ~260 instantiations compile
+// Included by one translation unit per MODE (step_mode0.hip ... step_mode5.hip), so that the ~390 instantiations compile
 // in parallel; kernels.hip holds world_kernel and the host-side launch logic.
 #pragma once
 #include "kernel_common.hpp"
@@ -9,7 +9,7 @@ namespace lle {
 // ================================================================================================
 // step_kernel<G, LM>: World.step() with one LANE PER AGENT (G = lanes per environment = power of two >= A).
 //
-// world_kernel<.., MODE_STEP> above runs one environment per lane: simple, but phase 1 is then a ~4k-instruction
+// world_kernel<.., MODE_STEP> (kernels.hip) runs one environment per lane: simple, but phase 1 is then a ~4k-instruction
 // dependency chain of ONE wave that no amount of occupancy shortens, and every wave runs it at the same time
 // (launch cost = chain + observation stream).  Here the agents of an environment sit in G neighbouring lanes, so the
 // per-agent loops of move_agents / compute_available_actions / the sampler become lane-parallel and the chain is
@@ -55,9 +55,9 @@ __device__ __forceinline__ void for_each_other(uint32_t v, F&& f) {
     }
 }
 
-// GEN: the general instantiation -- environments with their own source colours / enabled flags (lle_batch_set_sources)
-// and/or batches of several maps (lle_batch_create_multi).  A separate instantiation, so that the default path (one
-// map, sources of the map) is compiled exactly as before: every `PES` / `tables` / `initp` below folds to a constant.
+// GEN: the general instantiations -- environments with their own source colours / enabled flags (lle_batch_set_sources)
+// and/or batches of several maps (lle_batch_create_multi).  Separate instantiations, so that the default path (one
+// map, sources of the map) is compiled without any of it: every `PES` / `tables` / `initp` below folds to a constant.
 // ML1: no cell of the map carries more than one laser layer (every level of the reference; no crossing beams): the
 // per-layer loops run exactly once and unroll (no variable 64-bit shifts of the layer word).
 // MODE 0: one step in place, one map, the map's sources (the default).  MODE 1: + fused rollout (n_steps, trajectory
