@@ -1,6 +1,10 @@
 """Soak differential (GPU box): HIP path vs the CPU oracle on long random rollouts, every buffer of every env compared
 bit-for-bit after every step (state, ordered events, availability, error codes, the full int8 observation).
-Beyond the test suite's sizes; prints env-steps compared per map.  Usage: python tools/soak_parity.py [seconds_per_map]"""
+Beyond the test suite's sizes; prints env-steps compared per map.
+Usage: python tools/soak_parity.py [seconds_per_map] [per-env-sources]
+With `per-env-sources` every env has its own source colours / enabled flags (lle_batch_set_sources; each oracle env is
+its own world object and receives the same set_colour / enable / disable calls), re-drawn every 48 steps for a random
+half of the envs: the general step-kernel modes.  Maps without sources are skipped."""
 import os
 import sys
 import time
@@ -11,17 +15,61 @@ from oracle.levels import LEVELS  # noqa: E402
 from tests.parity_util import EXTRA_MAPS, assert_state_equal, assert_step_equal, unpack_engine  # noqa: E402
 from lle_amd import BatchedWorld, mapgen  # noqa: E402
 
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
 om.build()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
+per_env = len(sys.argv) > 2 and sys.argv[2] == "per-env-sources"
+rng = np.random.default_rng(7)
+
+
+class Mirror:
+    """The same per-env source changes on the oracle worlds, with the Python binding's rule that enable / disable only
+    act when the flag changes (pylaser_source.rs:55-75)."""
+
+    def __init__(self, ob, n, L):
+        self.ob, self.n, self.L = ob, n, L
+        self.enabled = np.array([[bool(s[4]) for s in ob.world(0).sources()]] * n)
+
+    def apply(self, colours, enabled, mask):
+        for e in np.nonzero(mask)[0]:
+            w = self.ob.world(int(e))
+            for l in range(self.L):
+                w.set_source(l, colour=int(colours[e, l]))
+                want = bool((int(enabled[e]) >> l) & 1)
+                if want != self.enabled[e, l]:
+                    w.set_source(l, enabled=want)
+                    self.enabled[e, l] = want
+
+
+def redraw(bw, mirror, A, L, n):
+    colours = rng.integers(0, A, (n, L)).astype(np.uint8)
+    enabled = (rng.integers(0, 1 << min(L, 30), n) | rng.integers(0, 2, n) * ((1 << L) - 1)).astype(np.int64) & ((1 << L) - 1)
+    mask = (rng.random(n) < 0.5).astype(np.uint8)
+    bw.set_sources(colours=torch.from_numpy(colours).cuda(), enabled=torch.from_numpy(enabled.astype(np.int32)).cuda(),
+                   env_mask=torch.from_numpy(mask).cuda())
+    mirror.apply(colours, enabled, mask)
+
 maps = {f"level{k}": (v, 32768) for k, v in LEVELS.items()}
 maps.update({k: (v, 8192) for k, v in EXTRA_MAPS.items()})
 maps["config5"] = (mapgen.config5(0), 4096)
 total = 0
 for name, (text, n) in maps.items():
+    if per_env:
+        n = min(n, 2048)  # (the per-env source calls on the oracle side are Python loops)
     ob, bw = om.OracleBatch(text, n), BatchedWorld(text, n)
     dims = (ob.A, ob.G, ob.Ls, ob.beam_stride, ob.C, ob.H, ob.W)
+    L = bw.map.n_sources
+    if per_env and L == 0:
+        continue
+    mirror = Mirror(ob, n, L) if per_env else None
     t, t0 = 0, time.time()
     while time.time() - t0 < budget:
+        if per_env and t % 48 == 0:
+            redraw(bw, mirror, ob.A, L, n)
+            eng = unpack_engine(bw.host_buffers(), *dims)
+            assert_state_equal(eng, ob.dump(), f"{name} t={t} after set_sources")
         auto = (t // 64) % 2 == 0  # alternate: auto-reset regime / episodes running into all-dead, all-STAY states (Q1, Q2)
         bw.step(sample=True, auto_reset=auto, seed=2026, t=t, env_offset=11)
         ostep = ob.step(None, auto_reset=auto, seed=2026, t=t, env_offset=11)
