@@ -130,3 +130,32 @@ def test_mismatched_maps_are_refused():
         BatchedWorld(["S0 . X", "S0 . . X"], 128)
     with pytest.raises(RuntimeError, match="multiple of 64"):
         BatchedWorld(["S0 . X", "S0 X ."], 100)
+
+
+def test_env_outputs_on_blocks_of_maps():
+    """lle_batch_env_outputs on a batch of several maps (each env's availability bools come from ITS map's tables),
+    with per-env sources on top: equal to the separate entry points."""
+    import torch
+
+    from lle_amd import BatchedWorld, _capi
+
+    texts = _maps(4, height=9, width=11, n_agents=3, n_lasers=4, n_gems=3, n_voids=2)
+    per = 192
+    n = per * len(texts)
+    w = BatchedWorld(texts, n)
+    A, G, L = w.map.n_agents, w.map.n_gems, w.map.n_sources
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for rnd in range(2):
+        if rnd == 1:
+            w.set_sources(colours=torch.randint(0, A, (n, L), generator=g, device="cuda", dtype=torch.uint8))
+        for t in range(12):
+            w.step(sample=True, auto_reset=(t % 4 == 3), seed=8, t=12 * rnd + t)
+            for walkable in (False, True):
+                state = torch.empty((n, 3 * A + G), device="cuda")
+                reward = torch.empty((n, 4), device="cuda")
+                done, avail = torch.empty(n, dtype=torch.uint8, device="cuda"), torch.empty((n, A, 5), dtype=torch.uint8, device="cuda")
+                w.env_outputs(state=state, normalize_state=True, reward=reward, multi_objective=True, done=done, available=avail,
+                              walkable_lasers=walkable)
+                assert torch.equal(state.view(torch.int32), w.observe_as(_capi.LLE_OBS_NORMALIZED_STATE, 0).view(torch.int32)), (rnd, t)
+                assert torch.equal(reward, w.reward_multi_objective()) and torch.equal(done, w.done), (rnd, t)
+                assert torch.equal(avail.view(torch.bool), w.available_actions(walkable)), (rnd, t, walkable)
