@@ -1,7 +1,12 @@
 """bench.py -- env-steps/s of the batched World.step() hot path on MI355X (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+`--gpus N` with N > 1 starts the N ranks ITSELF: this parent process never touches a GPU, checks that N devices are
+visible (exit code 2 otherwise -- it never measures fewer GPUs than asked for) and runs
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...` as a
+child process, one rank per GPU over RCCL.  Launched under torch.distributed.run directly (RANK / WORLD_SIZE in the
+environment) it is one of those ranks.
 
 A "step" is one pass of the hot path over one batch: on-device action sampling (uniform over available actions),
 auto-reset of finished envs, World.step, event / availability emission and the int8 layered observation, for
@@ -10,11 +15,20 @@ All inputs are resident in HBM before the timed region.  Envs shard over GPUs wi
 (weak scaling); the only collective is one RCCL all-reduce of the rollout counters after the timed region.
 
 Prints ONE JSON line (rank 0).  value = agent-steps/s over the whole job (agents x envs x steps / s);
-env-steps/s is reported next to it.  roofline / cpu_baseline objects: see DESIGN.md section "Measurement".
+env-steps/s is reported next to it.  Objects of the line:
+  roofline       the dominant kernel of the --steps region (HIP events on the launch stream).  Each step rewrites the
+                 same 122.7 MB of rows, which the 256 MB Infinity Cache absorbs: bound = "infinity-cache-absorbed".
+  roofline_hbm   the same kernel on a batch whose rows (491 MB per launch) do not fit the Infinity Cache: true HBM writes.
+  sustained      the same launches as the --steps region, >= 1000 of them.
+  configs        BASELINE.json configs[1] (level 1 x 4 096) and configs[4] (32x32, 8 agents, 8 lasers x 65 536).
+  fused_rollout  lle_batch_rollout, 16 steps per launch into a trajectory ring larger than the caches.
+  cpu_baseline   the C restatement of the reference algorithm (oracle/) on the host cores, N = 1 only.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,26 +39,35 @@ if ROOT not in sys.path:
 ENVS_PER_GPU = 65536
 LEVEL = 6
 SEED = 1234
-# algorithmic bytes per env-step of level 6
-#   obs C*H*W = 12*12*13 = 1872, state r/w 2*24 = 48, actions 4, avail 4, events 1 + 2*4 = 9
+# algorithmic bytes per env-step
+#   level 6: obs C*H*W = 12*12*13 = 1872, state r/w 2*24 = 48, actions 4, avail 4, events 1 + 2*4 = 9
 ALGO_BYTES_PER_ENV_STEP = 1937
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ALGO_BYTES_CFG2 = 953      # level 1: 936 + 12 + 1 + 1 + 3
+ALGO_BYTES_CFG5 = 20617    # 32x32, 8 agents, 8 sources: 20480 + 104 + 8 + 8 + 17
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+INFINITY_CACHE_BYTES = 256 << 20
+HBM_REGIME_ENVS = 262144   # rows of one launch: 491 MB > Infinity Cache
+PREROLL_SECONDS = 0.25     # untimed launches that bring the clocks up before the warm-up (reported as preroll_steps)
+
+
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
 
 
 def cpu_baseline(n_envs, seconds_target=12.0):
     """The CPU oracle (C restatement of the reference algorithm, kind "port") on a bounded sample of the same workload:
     the same n_envs level-6 environments, sampled actions + auto-reset + int8 layered observation, for about
-    `seconds_target` seconds on every host core (one thread per core over disjoint env ranges)."""
+    `seconds_target` seconds on the host cores this process may use (one thread per core over disjoint env ranges)."""
     import numpy as np
 
     from oracle import oracle
     from oracle.levels import LEVELS
 
     level_text = LEVELS[LEVEL]
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores = host_cores()
     threads = max(1, min(cores, 64))  # the GPU box gives one GPU a share of the host cores; more threads only thrash
     ob = oracle.OracleBatch(level_text, n_envs)
     obs = np.zeros((n_envs, ob.C * ob.H * ob.W), np.int8)
@@ -63,21 +86,149 @@ def cpu_baseline(n_envs, seconds_target=12.0):
     dt1 = time.perf_counter() - t1
     return {
         "value": ob.A * n_envs * steps / dt, "unit": "agent-steps/s", "cores": threads, "kind": "port",
+        "threads_used": threads, "host_cores_visible": cores, "host_cores_total": os.cpu_count(),
         "env_steps_per_s": n_envs * steps / dt, "seconds": dt,
         "single_thread_env_steps_per_s": n_envs * steps1 / dt1,
         "sample": f"level {LEVEL}, {n_envs} envs x {steps} steps ({dt:.1f} s), sampled actions + auto-reset + int8 layered obs, "
-                  f"C restatement of the Rust reference algorithm (oracle/lle_oracle.c), {threads} threads",
+                  f"C restatement of the Rust reference algorithm (oracle/lle_oracle.c), {threads} threads on {cores} visible host cores",
     }
 
 
-def load_traffic():
+def load_traffic(key="hbm_bytes_per_launch"):
     """HBM bytes per launch from the committed PMC profile of this same command (profiles/), or None."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get("hbm_bytes_per_launch")
+            return json.load(f).get(key)
     except Exception:  # noqa: BLE001
         return None
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args, argv):
+    """Parent of an N-rank run.  Never initialises a GPU (device_count() does not) and never execs: the ranks are child
+    processes of torch.distributed.run, and this process exits with their code."""
+    if not args.plumbing_only:
+        import torch
+        visible = torch.cuda.device_count()
+        if visible < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {visible} GPU(s) visible; refusing to measure fewer GPUs than asked for",
+                  file=sys.stderr)
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(args.master_port or free_port()),
+           os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd, env=env).returncode
+
+
+def plumbing_only(args, real_stdout):
+    """Spawn / rendezvous / one-line check without any GPU (tests/test_bench_spawn.py): every rank contributes known
+    counters through the same allreduce helpers over gloo; rank 0 prints one line.  Not a measurement."""
+    import torch
+    import torch.distributed as dist
+
+    from lle_amd.distributed import STAT_KEYS, allreduce_max, allreduce_stats
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if "RANK" in os.environ:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    stats = {k: (rank + 1) * (i + 1) for i, k in enumerate(STAT_KEYS)}
+    dev = torch.device("cpu")
+    if dist.is_initialized():
+        stats = allreduce_stats(stats, dev)
+        elapsed = allreduce_max(float(rank + 1), dev)
+    else:
+        elapsed = 1.0
+    if rank == 0:
+        line = {"plumbing_only": True, "n_gpus": world, "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+                "backend": "gloo", "rollout_stats": stats, "elapsed_max": elapsed}
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    return 0
+
+
+class Timer:
+    """K launches bracketed the way the contract asks: barrier + synchronize on both sides, wall clock (max over ranks
+    taken by the caller) and HIP events on the launch stream (torch's current stream is the one every launch uses)."""
+
+    def __init__(self, torch, dist, dev, use_dist):
+        self.torch, self.dist, self.dev, self.use_dist = torch, dist, dev, use_dist
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.dev)
+        if self.use_dist:
+            self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+    def run(self, fn, k):
+        torch = self.torch
+        self.sync()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(k):
+            fn()
+        ev1.record()
+        torch.cuda.synchronize(self.dev)
+        if self.use_dist:
+            self.dist.barrier()
+        wall = time.perf_counter() - t0
+        return wall, ev0.elapsed_time(ev1) / k  # seconds, ms per launch
+
+
+def stepper(bw, offset=0):
+    def fn():
+        bw.step(sample=True, auto_reset=True, seed=SEED, env_offset=offset)
+    return fn
+
+
+def preroll(torch, dev, fn, seconds=PREROLL_SECONDS):
+    """Untimed launches until `seconds` of wall time have passed: the clocks of a fresh box ramp up over the first tens of
+    milliseconds, and a 20-step timed region is 0.5 ms long."""
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(256):
+            fn()
+        torch.cuda.synchronize(dev)
+        n += 256
+    return n
+
+
+def measure_config(torch, timer, dev, map_or_text, n_envs, algo_bytes, steps, label, padded=False):
+    """One secondary configuration (N = 1): K single-step launches after a warm-up, HIP-event timed."""
+    from lle_amd import BatchedWorld
+    bw = BatchedWorld(map_or_text, n_envs, device=dev, **({"row_align": 128} if padded else {}))
+    fn = stepper(bw)
+    for _ in range(max(20, steps // 10)):
+        fn()
+    wall, ms = timer.run(fn, steps)
+    info = bw.kernel_info()
+    m = bw.map
+    achieved = algo_bytes * n_envs / (ms * 1e-3) / 1e9
+    rows = n_envs * m.obs_stride
+    out = {
+        "workload": label, "n_envs": n_envs, "agents": m.n_agents, "steps": steps, "ms_per_step": wall / steps * 1e3, "kernel_ms": ms,
+        "env_steps_per_s": n_envs * steps / wall, "agent_steps_per_s": m.n_agents * n_envs * steps / wall,
+        "algorithmic_bytes_per_env_step": algo_bytes, "achieved_GBps": achieved, "frac_of_hbm_peak": achieved / HBM_PEAK_GBS,
+        "row_bytes": m.obs_bytes, "row_stride": m.obs_stride, "rows_MB_per_launch": rows / 1e6,
+        "bound": "hbm" if rows > INFINITY_CACHE_BYTES else "infinity-cache-absorbed",
+        "kernel": info["kernel"], "envs_per_wave": info["envs_per_wave"], "lds_bytes_per_workgroup": info["lds_bytes"],
+        "rollout_stats": bw.stats(),
+    }
+    del bw
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -87,17 +238,29 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--envs-per-wave", type=int, default=0, help="0 = library default")
+    ap.add_argument("--sustained-steps", type=int, default=2000, help="launches of the `sustained` block (0 = skip)")
+    ap.add_argument("--config-steps", type=int, default=200, help="launches per secondary configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused", action="store_true", help="skip the secondary fused-rollout measurement")
+    ap.add_argument("--no-configs", action="store_true", help="skip roofline_hbm and the cfg2 / cfg5 blocks")
     ap.add_argument("--fused-steps", type=int, default=16, help="steps per launch of the fused rollout")
     ap.add_argument("--ring-slots", type=int, default=8, help="trajectory ring slots of the fused rollout")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of a self-spawned N-rank run (0 = pick a free one)")
+    ap.add_argument("--force-spawn", action="store_true", help="go through torch.distributed.run (and RCCL) even for --gpus 1")
+    ap.add_argument("--plumbing-only", action="store_true", help="spawn / rendezvous / one-line check over gloo, no GPU, no measurement")
     args = ap.parse_args()
 
-    # Everything but the final JSON line goes to stderr, at the file-descriptor level: RCCL and the HIP runtime print
-    # banners to fd 1 from C code (e.g. "Librccl path : ...") and the contract is ONE line on stdout.
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not under_launcher and (args.gpus > 1 or args.force_spawn):
+        sys.exit(spawn_ranks(args, [a for a in sys.argv[1:] if a != "--force-spawn"]))
+
+    # Everything but the final JSON line goes to stderr, at the file-descriptor level: RCCL, gloo and the HIP runtime
+    # print banners to fd 1 from C code (e.g. "Librccl path : ...") and the contract is ONE line on stdout.
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    if args.plumbing_only:
+        sys.exit(plumbing_only(args, real_stdout))
 
     import torch
     import torch.distributed as dist
@@ -105,49 +268,49 @@ def main():
     from lle_amd import BatchedWorld, Map
     from lle_amd.distributed import allreduce_max, allreduce_stats, shard_offset
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1")) if under_launcher else 1
+    rank = int(os.environ.get("RANK", "0")) if under_launcher else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if under_launcher else 0
+    if args.gpus != world:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; refusing to report a rank count that was not asked for", file=sys.stderr)
+        sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU execution path)"
+    if torch.cuda.device_count() <= local_rank:
+        print(f"bench.py: rank {rank} has no GPU {local_rank} ({torch.cuda.device_count()} visible)", file=sys.stderr)
+        sys.exit(2)
     # one process per GPU under torch.distributed.run (RCCL = backend "nccl"); a plain `python bench.py` is rank 0 of 1
-    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
-    dev = torch.device("cuda", local_rank if use_dist else 0)
+    use_dist = under_launcher
+    dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    rccl_ranks = 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
-    if args.gpus != world and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+        rccl_ranks = dist.get_world_size()
+    timer = Timer(torch, dist, dev, use_dist)
 
     n = args.envs_per_gpu
     bw = BatchedWorld(Map(level=LEVEL), n, device=dev, envs_per_wave=args.envs_per_wave or None)
     offset = shard_offset(n, rank)
+    step = stepper(bw, offset)
 
-    def run(k, t0):
-        for t in range(t0, t0 + k):
-            bw.step(sample=True, auto_reset=True, seed=SEED, t=t, env_offset=offset)
-
-    run(args.warmup, 0)
+    preroll_steps = preroll(torch, dev, step)
+    for _ in range(args.warmup):
+        step()
     torch.cuda.synchronize(dev)
     bw.stats(reset=True)
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t_start = time.perf_counter()
-    ev0.record()
-    run(args.steps, args.warmup)
-    ev1.record()
-    torch.cuda.synchronize(dev)
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t_start
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # average launch-to-launch duration on the launch stream
-
+    elapsed, kernel_ms = timer.run(step, args.steps)
     elapsed = allreduce_max(elapsed, dev) if use_dist else elapsed
     stats = bw.stats()
     stats = allreduce_stats(stats, dev) if use_dist else stats
+
+    sustained = None
+    if args.sustained_steps > 0:
+        s_wall, s_ms = timer.run(step, args.sustained_steps)
+        s_wall = allreduce_max(s_wall, dev) if use_dist else s_wall
+        sustained = (args.sustained_steps, s_wall, s_ms)
 
     # ---- secondary measurement: the same random rollout with lle_batch_rollout (several steps per launch, every
     # step's observation / actions / reward counts written to a trajectory ring larger than the caches)
@@ -157,35 +320,46 @@ def main():
         # two-slot ring is a double buffer -- a consumer reads slot t while step t + 1 is written -- and stays in it
         for T, R in ((args.fused_steps, args.ring_slots), (args.fused_steps, 2)):
             ring = bw.make_ring(R)
-            launches = max(1, args.steps // T)
+            launches = max(4, max(args.steps, 512) // T)
+
+            def roll():
+                bw.rollout(T, auto_reset=True, seed=SEED, env_offset=offset, ring=ring, ring_pos=bw.t)
             for _ in range(2):
-                bw.rollout(T, auto_reset=True, seed=SEED, env_offset=offset, ring=ring, ring_pos=bw.t)
-            torch.cuda.synchronize(dev)
-            if use_dist:
-                dist.barrier()
-            torch.cuda.synchronize(dev)
-            tf = time.perf_counter()
-            for _ in range(launches):
-                bw.rollout(T, auto_reset=True, seed=SEED, env_offset=offset, ring=ring, ring_pos=bw.t)
-            torch.cuda.synchronize(dev)
-            if use_dist:
-                dist.barrier()
-            fused_elapsed = time.perf_counter() - tf
-            fused_elapsed = allreduce_max(fused_elapsed, dev) if use_dist else fused_elapsed
-            fused.append((T, R, launches, fused_elapsed))
+                roll()
+            fe, _ = timer.run(roll, launches)
+            fe = allreduce_max(fe, dev) if use_dist else fe
+            fused.append((T, R, launches, fe))
             del ring
 
+    A = bw.map.n_agents
+    info = bw.kernel_info()
+    row_stride = bw.map.obs_stride
+    del bw
+    torch.cuda.empty_cache()
+
+    hbm = cfgs = None
+    if world == 1 and not args.no_configs:
+        from lle_amd import mapgen
+        k = args.config_steps
+        hbm = measure_config(torch, timer, dev, Map(level=LEVEL), HBM_REGIME_ENVS, ALGO_BYTES_PER_ENV_STEP, k,
+                             f"World.level({LEVEL}) x {HBM_REGIME_ENVS} envs: rows of one launch exceed the 256 MB Infinity Cache")
+        cfgs = {
+            "cfg2_level1_4096": measure_config(torch, timer, dev, Map(level=1), 4096, ALGO_BYTES_CFG2, max(k, 1000),
+                                               "BASELINE configs[1]: World.level(1), 1 agent, 4096 envs"),
+            "cfg5_32x32_a8_l8_65536": measure_config(torch, timer, dev, mapgen.config5(0), 65536, ALGO_BYTES_CFG5, k,
+                                                     "BASELINE configs[4]: generated 32x32, 8 agents, 8 lasers (mapgen.config5(0)), 65536 envs"),
+        }
+
     if rank == 0:
-        A = bw.map.n_agents
         total_envs = n * world
         env_steps_s = total_envs * args.steps / elapsed
         achieved = ALGO_BYTES_PER_ENV_STEP * n / (kernel_ms * 1e-3) / 1e9
-        info = bw.kernel_info()
+        rows_bytes = n * row_stride
         out = {
             "metric": "env-steps/s (agents x envs x steps/s), level-6 batch 65536",
             "value": A * env_steps_s, "unit": "agent-steps/s",
             "env_steps_per_s": env_steps_s,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup, "preroll_steps": preroll_steps,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
@@ -193,18 +367,35 @@ def main():
                                    "int8 layered obs (C=12)", "envs_per_gpu": n, "global_batch": total_envs,
                        "parallelism": f"env-shard x{world}", "kernel": info["kernel"], "envs_per_wave": info["envs_per_wave"],
                        "lds_bytes_per_workgroup": info["lds_bytes"]},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # `bound`: what the stores of this launch hit.  The rows of one launch (122.7 MB, rewritten in place every
+            # step) stay in the 256 MB Infinity Cache; the DRAM figure is `roofline_hbm`.
+            "roofline": {"bound": "hbm" if rows_bytes > INFINITY_CACHE_BYTES else "infinity-cache-absorbed",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(),
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n, "kernel_ms": kernel_ms},
+                         "traffic_note": "L2<->fabric bytes (WRITE_SIZE + 2 x FETCH_SIZE) from the committed profile, profiles/traffic.json",
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n, "kernel_ms": kernel_ms,
+                         "rows_MB_per_launch": rows_bytes / 1e6},
             "rollout_stats": stats,
         }
+        if sustained:
+            k, s_wall, s_ms = sustained
+            s_ach = ALGO_BYTES_PER_ENV_STEP * n / (s_ms * 1e-3) / 1e9
+            out["sustained"] = {"steps": k, "ms_per_step": s_wall / k * 1e3, "kernel_ms": s_ms,
+                                "env_steps_per_s": total_envs * k / s_wall, "agent_steps_per_s": A * total_envs * k / s_wall,
+                                "achieved_GBps_per_gpu": s_ach, "frac_of_hbm_peak": s_ach / HBM_PEAK_GBS}
+        if hbm:
+            out["roofline_hbm"] = {"bound": "hbm", "achieved": hbm["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": hbm["frac_of_hbm_peak"], "traffic": load_traffic("hbm_regime_bytes_per_launch"),
+                                   "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * hbm["n_envs"], **hbm}
+        if cfgs:
+            out["configs"] = cfgs
         for key, (T, R, launches, fe) in zip(("fused_rollout", "fused_rollout_double_buffer"), fused):
             # per env-step: obs 1872 + actions 4 + reward 4 + err/evcount/done 3 + events 8, state r/w (48 B) once per launch
             fused_bytes = 1891 + 48.0 / T
-            ring_mb = R * n * 1872 / 1e6
+            ring_mb = R * n * row_stride / 1e6
             out[key] = {
                 "what": "lle_batch_rollout: same random rollout, several steps per launch, per-step obs/actions/reward to a trajectory ring"
-                        + (" larger than the 256 MB Infinity Cache (true HBM writes)" if ring_mb > 256 else
+                        + (" larger than the 256 MB Infinity Cache (true HBM writes)" if ring_mb * 1e6 > INFINITY_CACHE_BYTES else
                            " of two slots (double buffer, stays in the 256 MB Infinity Cache: NOT an HBM figure)"),
                 "steps_per_launch": T, "ring_slots": R, "ring_MB": ring_mb, "steps": launches * T, "ms_per_step": fe / (launches * T) * 1e3,
                 "env_steps_per_s": total_envs * launches * T / fe, "agent_steps_per_s": A * total_envs * launches * T / fe,
@@ -217,6 +408,7 @@ def main():
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -35,7 +35,7 @@ PARSE_ERROR_NAMES = {
 EXPORTS = [
     "lle_abi_version", "lle_last_status", "lle_last_error", "lle_action_hash",
     "lle_map_parse", "lle_map_level", "lle_map_free", "lle_map_get_info", "lle_map_positions", "lle_map_sources",
-    "lle_map_set_source", "lle_map_laser_tiles", "lle_map_world_string",
+    "lle_map_set_source", "lle_map_set_row_align", "lle_map_laser_tiles", "lle_map_world_string",
     "lle_batch_arena_bytes", "lle_batch_create", "lle_batch_arena_bytes_multi", "lle_batch_create_multi", "lle_batch_n_maps", "lle_batch_free", "lle_batch_get_buffer", "lle_batch_n_envs",
     "lle_batch_reset", "lle_batch_step", "lle_batch_rollout", "lle_batch_set_state", "lle_batch_update_sources", "lle_batch_observe",
     "lle_batch_snapshot_bytes", "lle_batch_snapshot", "lle_batch_restore",
@@ -118,6 +118,8 @@ def lib():
     L.lle_map_sources.argtypes = [vp, C.POINTER(SourceInfo), i32]
     L.lle_map_set_source.restype = i32
     L.lle_map_set_source.argtypes = [vp, i32, i32, i32]
+    L.lle_map_set_row_align.restype = i32
+    L.lle_map_set_row_align.argtypes = [vp, i32]
     L.lle_map_laser_tiles.restype = i32
     L.lle_map_laser_tiles.argtypes = [vp, C.POINTER(LaserTile), i32]
     L.lle_map_world_string.restype = C.c_size_t
@@ -191,7 +193,8 @@ class MapParseError(ValueError):
 class Map:
     """Host-side compiled map (lle_map*).  Needs no GPU."""
 
-    def __init__(self, text=None, level=None):
+    def __init__(self, text=None, level=None, row_align=None):
+        """`row_align`: pitch of an observation row in bytes (lle_map_set_row_align; default 16, 128 = one cache line)."""
         L = lib()
         err = C.c_int(0)
         if level is not None:
@@ -201,6 +204,8 @@ class Map:
             self.h = L.lle_map_parse(data, len(data), C.byref(err))
         if not self.h:
             raise MapParseError(err.value)
+        if row_align is not None and L.lle_map_set_row_align(self.h, int(row_align)) != 0:
+            raise ValueError(L.lle_last_error().decode())
         self.refresh()
 
     def refresh(self):
@@ -235,6 +240,11 @@ class Map:
         arr = (LaserTile * max(n, 1))()
         lib().lle_map_laser_tiles(self.h, arr, n)
         return [arr[k] for k in range(n)]
+
+    def set_row_align(self, align):
+        if lib().lle_map_set_row_align(self.h, int(align)) != 0:
+            raise ValueError(lib().lle_last_error().decode())
+        self.refresh()
 
     def set_source(self, laser_id, enabled=None, agent_id=None):
         rc = lib().lle_map_set_source(self.h, laser_id, -1 if enabled is None else int(bool(enabled)),

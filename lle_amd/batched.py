@@ -34,13 +34,17 @@ class BatchedWorld:
       err [n] u8 - evcount [n] u8 - events [n,2A] u8 (type<<4|agent) - done [n] u8 - obs [n,C,H,W] i8
     """
 
-    def __init__(self, map_or_text, n_envs, device=None, envs_per_wave=None):
+    def __init__(self, map_or_text, n_envs, device=None, envs_per_wave=None, row_align=None):
         """`map_or_text`: a Map / map text, or a LIST of them for a batch of several maps -- map m then owns the envs
         [m * n_envs / len(maps), (m + 1) * n_envs / len(maps)); the maps must agree on height, width and the numbers of
-        agents, sources and gems, and each must own a multiple of 64 envs."""
+        agents, sources and gems, and each must own a multiple of 64 envs.
+        `row_align`: pitch of the observation rows in bytes (Map.set_row_align: applied to the maps given)."""
         _require_gpu()
         many = isinstance(map_or_text, (list, tuple))
         self.maps = [m if isinstance(m, Map) else Map(m) for m in (map_or_text if many else [map_or_text])]
+        if row_align is not None:
+            for m in self.maps:
+                m.set_row_align(row_align)
         self.map = self.maps[0]  # common dimensions
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())

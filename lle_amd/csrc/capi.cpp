@@ -202,6 +202,14 @@ int lle_map_set_source(lle_map* map, int laser_id, int enabled, int agent_id) {
     return LLE_OK;
 }
 
+int lle_map_set_row_align(lle_map* map, int align) {
+    if (!map) return fail(LLE_ERR_NULL, "NULL map");
+    if (align != 16 && align != 32 && align != 64 && align != 128 && align != 256) return fail(LLE_ERR_ARG, "row alignment must be 16, 32, 64, 128 or 256");
+    map->m.row_align = (uint32_t)align;
+    map->m.compile();
+    return LLE_OK;
+}
+
 int lle_map_laser_tiles(const lle_map* map, lle_laser_tile* out, int cap) {
     if (!map) return fail(LLE_ERR_NULL, "NULL map");
     const Map& m = map->m;
@@ -352,6 +360,7 @@ static int common_header(const lle_map* const* maps, int n_maps, MapHeader* out,
         const MapHeader& o = maps[m]->m.header;
         if (o.H != h.H || o.W != h.W || o.A != h.A || o.L != h.L || o.G != h.G)
             return fail(LLE_ERR_ARG, "the maps of a batch must agree on height, width and the numbers of agents, sources and gems");
+        if (o.obs_stride != h.obs_stride) return fail(LLE_ERR_ARG, "the maps of a batch must agree on the row alignment (lle_map_set_row_align)");
         worst = std::max(worst, o.lds_table_bytes + (o.blob_capacity - o.blob_bytes));
         h.lds_table_bytes = std::max(h.lds_table_bytes, o.lds_table_bytes);
         h.blob_capacity = std::max(h.blob_capacity, o.blob_capacity);
@@ -596,7 +605,6 @@ static int obs_desc(const lle_batch* b, int kind, int param, lle_obs_desc* d) {
         d->stride[0] = env_pitch_elems;
         d->bytes = n * env_pitch_elems * elem;
     };
-    auto align16 = [](int64_t x) { return (x + 15) / 16 * 16; };
     switch (kind) {
         case LLE_OBS_LAYERED:
             if (param != 0) return fail(LLE_ERR_ARG, "LLE_OBS_LAYERED takes no parameter");
@@ -607,7 +615,7 @@ static int obs_desc(const lle_batch* b, int kind, int param, lle_obs_desc* d) {
             if (param < 0 || A + param > 32) return fail(LLE_ERR_ARG, "padding out of range (n_agents + padding <= 32)");
             const int64_t C = 2 * (A + param) + 4;
             if (C * H * W >= (1 << 20)) return fail(LLE_ERR_UNSUPPORTED, "padded observation too large");
-            set(1, {n, C, H, W}, align16(C * H * W));
+            set(1, {n, C, H, W}, (int64_t)b->maps[0].row_pitch_of((uint32_t)(C * H * W)));
             for (const Map& mp : b->maps)
                 for (const Source& s : mp.sources)
                     if (s.agent_id >= C - (A + param)) d->supported = 0;

@@ -268,7 +268,7 @@ int Map::n_laser_tiles() const {
 bool Map::build_obs_tables(const LayerMap& lm, std::vector<int8_t>& tmpl, std::vector<uint64_t>& dyn_tab) const {
     const int HW = H * W, G = (int)gems.size();
     bool supported = true;
-    const uint32_t obs_stride = ((uint32_t)(lm.C * HW) + 15u) & ~15u;
+    const uint32_t obs_stride = row_pitch_of((uint32_t)(lm.C * HW));
     tmpl.assign(obs_stride, 0);
     auto at = [&](int layer, Pos q) -> int8_t& { return tmpl[(size_t)layer * HW + q.i * W + q.j]; };
     for (auto& q : walls) at(lm.wall, q) = 1;
@@ -335,7 +335,7 @@ std::vector<uint8_t> Map::compile_view(int kind, int param) const {
     v.A = (uint32_t)A; v.L = (uint32_t)sources.size(); v.H = (uint32_t)H; v.W = (uint32_t)W; v.HW = (uint32_t)HW;
     v.C = (uint32_t)lm.C;
     v.obs_bytes = (uint32_t)(lm.C * HW);
-    v.obs_stride = (v.obs_bytes + 15u) & ~15u;
+    v.obs_stride = row_pitch_of(v.obs_bytes);
     v.n_chunks = v.obs_stride / 16;
     v.D = (uint32_t)dyn_tab.size();
     for (int a = 0; a < A; a++) v.agent_layer[a] = (uint8_t)lm.agent[a];
@@ -369,7 +369,7 @@ void Map::compile() {
     h.magic = MAP_MAGIC;
     h.H = H; h.W = W; h.A = A; h.G = G; h.L = L; h.C = C; h.HW = HW;
     h.obs_bytes = (uint32_t)(C * HW);
-    h.obs_stride = (h.obs_bytes + 15u) & ~15u;
+    h.obs_stride = row_pitch_of(h.obs_bytes);
     h.n_chunks = h.obs_stride / 16;
     h.obs_supported = 1;
     for (int a = 0; a < A; a++) h.start[a] = (uint16_t)(starts[a][0].i | (starts[a][0].j << 8));

@@ -39,6 +39,12 @@ struct Map {
     std::vector<uint8_t> kind;                        // [HW] CellKind of the innermost tile
     std::vector<int> gem_index;                       // [HW] or -1
 
+    // Pitch of an observation row in HBM (and of its LDS template): C*H*W rounded up to `row_align` bytes.  16 is the
+    // store width; 128 = one cache line, so that the rows of neighbouring environments never share a line (a batch
+    // whose rows do not fit the Infinity Cache then writes whole lines to HBM only; lle_map_set_row_align).
+    uint32_t row_align = 16;
+    uint32_t row_pitch_of(uint32_t bytes) const { return (bytes + row_align - 1u) / row_align * row_align; }
+
     int n_agents() const { return (int)starts.size(); }
     int n_layers() const { return 2 * n_agents() + 4; }
     int n_laser_tiles() const;

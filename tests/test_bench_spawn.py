@@ -1,0 +1,98 @@
+"""bench.py as the driver runs it: `python bench.py --gpus N` must start the N ranks itself, print ONE JSON line, and
+refuse (exit code 2) to measure fewer GPUs than it was asked for (BASELINE configs[3]).
+
+CPU: the spawn / rendezvous / one-line plumbing over gloo (no GPU, `--plumbing-only`: not a measurement) and the
+refusal.  GPU (one card): the same entry point through torch.distributed.run + RCCL with one rank, and the RCCL
+all-reduce of BatchedWorld's counters in this process."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(*flags, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    return subprocess.run([sys.executable, BENCH, *flags], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env,
+                          timeout=timeout, cwd=ROOT)
+
+
+def _one_line(res):
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, f"stdout must carry exactly one line, got {len(lines)}:\n{res.stdout}\n{res.stderr[-2000:]}"
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_parent_spawns_n_ranks_and_prints_one_line(world):
+    res = _run("--gpus", str(world), "--plumbing-only")
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = _one_line(res)
+    assert out["n_gpus"] == world and out["rccl_ranks"] == world and out["plumbing_only"] is True
+    from lle_amd.distributed import STAT_KEYS
+    tri = world * (world + 1) // 2  # rank r contributes (r + 1) * (i + 1) to counter i
+    assert out["rollout_stats"] == {k: tri * (i + 1) for i, k in enumerate(STAT_KEYS)}
+    assert out["elapsed_max"] == float(world)
+
+
+def test_refuses_to_measure_fewer_gpus_than_asked_for():
+    import torch
+    asked = torch.cuda.device_count() + 1
+    if asked < 2:
+        asked = 2
+    res = _run("--gpus", str(asked), "--steps", "2", "--warmup", "1")
+    assert res.returncode == 2, (res.returncode, res.stderr[-2000:])
+    assert res.stdout.strip() == ""
+    assert "refusing" in res.stderr
+
+
+def test_rank_count_mismatch_under_the_launcher_is_an_error():
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    res = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--steps", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, env=env, timeout=300, cwd=ROOT)
+    assert res.returncode == 2 and res.stdout.strip() == "" and "WORLD_SIZE=1" in res.stderr
+
+
+@pytest.mark.gpu
+def test_one_rank_through_the_launcher_and_rccl():
+    steps = 20
+    res = _run("--gpus", "1", "--force-spawn", "--steps", str(steps), "--warmup", "5", "--no-cpu-baseline", "--no-configs",
+               "--no-fused", "--sustained-steps", "0")
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = _one_line(res)
+    assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1
+    assert out["rollout_stats"]["env_steps"] == 65536 * steps
+    assert out["rollout_stats"]["agent_steps"] == 4 * 65536 * steps
+    assert out["roofline"]["bound"] == "infinity-cache-absorbed" and 0.0 < out["roofline"]["frac"] < 1.0
+
+
+@pytest.mark.gpu
+def test_allreduce_of_batched_world_counters_over_rccl():
+    import torch
+    import torch.distributed as dist
+
+    from lle_amd import BatchedWorld, Map
+    from lle_amd.distributed import allreduce_max, allreduce_stats, shard_offset
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        n, steps = 4096, 16
+        bw = BatchedWorld(Map(level=6), n, device=dev)
+        for t in range(steps):
+            bw.step(sample=True, auto_reset=True, seed=7, t=t, env_offset=shard_offset(n, 0))
+        local = bw.stats()
+        total = allreduce_stats(local, dev)
+        assert total == local and total["env_steps"] == n * steps
+        assert allreduce_max(1.5, dev) == 1.5
+    finally:
+        dist.destroy_process_group()

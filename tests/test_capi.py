@@ -127,3 +127,26 @@ def test_world_state_value_type():
     assert WorldState([(0, 0)], [False], [True]) != WorldState([(0, 0)], [False], [False])
     assert hash(WorldState([(0, 0)], [False])) == hash(WorldState([(0, 0)], [False], [True]))
     assert all(WorldState([(0, 0)], [False]).agents_alive)
+
+
+def test_row_alignment_is_validated_and_must_agree_inside_a_batch():
+    """lle_map_set_row_align: pitch of an observation row; host-side only, so checked without a GPU."""
+    import ctypes as C
+
+    from lle_amd import _capi, mapgen
+
+    m = _capi.Map(LEVELS[6])
+    assert (m.obs_bytes, m.obs_stride) == (1872, 1872)
+    m.set_row_align(128)
+    assert (m.obs_bytes, m.obs_stride) == (1872, 1920)
+    assert _capi.Map(LEVELS[1], row_align=256).obs_stride == 1024 and _capi.Map(LEVELS[1]).obs_stride == 944
+    with pytest.raises(ValueError):
+        _capi.Map(LEVELS[6], row_align=48)
+    assert m.positions(_capi.LLE_POS_WALL) == _capi.Map(LEVELS[6]).positions(_capi.LLE_POS_WALL)
+    shape = dict(height=9, width=11, n_agents=3, n_lasers=4, n_gems=3, n_voids=2)
+    a, b = _capi.Map(mapgen.generate(seed=1, **shape), row_align=128), _capi.Map(mapgen.generate(seed=2, **shape))
+    L = _capi.lib()
+    assert L.lle_batch_arena_bytes_multi((C.c_void_p * 2)(a.h, b.h), 2, 64) < 0
+    assert b"row alignment" in L.lle_last_error()
+    b.set_row_align(128)
+    assert L.lle_batch_arena_bytes_multi((C.c_void_p * 2)(a.h, b.h), 2, 64) > 0
