@@ -95,7 +95,7 @@ typedef struct lle_map_info {
     int32_t n_layers;        /* C = 2A + 4 (python/lle/observations.py:204-211) */
     int32_t n_exits, n_walls, n_voids, n_laser_tiles;
     int32_t obs_bytes;       /* C*H*W int8 */
-    int32_t obs_stride;      /* obs_bytes rounded up to the row alignment, 16 by default (per-env pitch of LLE_BUF_OBS) */
+    int32_t obs_stride;      /* obs_bytes rounded up to the row alignment, see lle_map_set_row_align (per-env pitch of LLE_BUF_OBS) */
     int32_t max_beam_len, max_cell_layers;
     int32_t obs_supported;   /* 0 if a laser colour addresses a layer >= C (IndexError in the reference) */
     int32_t table_bytes;     /* size of the device table blob */
@@ -115,10 +115,12 @@ int lle_map_sources(const lle_map* map, lle_source_info* out, int cap);
 int lle_map_set_source(lle_map* map, int laser_id, int enabled, int agent_id);
 
 /* Pitch of an observation row (lle_map_info.obs_stride, the env stride of LLE_BUF_OBS and of every layered-style
- * lle_obs_desc): C*H*W rounded up to `align` bytes (16 -- the default --, 32, 64, 128 or 256).  The first C*H*W bytes
- * of a row are the reference's tensor (python/lle/observations.py:254-266), the rest is zero.  128 keeps the rows of
- * neighbouring environments in separate cache lines: batches whose rows exceed the 256 MB Infinity Cache then write
- * whole lines to HBM.  Call before lle_batch_create (a live batch keeps the pitch it was created with). */
+ * lle_obs_desc): C*H*W rounded up to `align` bytes (16, 32, 64, 128 or 256).  The first C*H*W bytes of a row are the
+ * reference's tensor (python/lle/observations.py:254-266), the rest is zero.  128 keeps the rows of neighbouring
+ * environments in separate cache lines, so that every line goes to HBM once and whole.  0 -- the default -- picks 128
+ * when that pads the row by at most 1/32 of its size (level 6: 1 872 -> 1 920 B) and 16 otherwise.  Always read the
+ * pitch from lle_map_info.obs_stride / the buffer descriptors.  Call before lle_batch_create (a live batch keeps the
+ * pitch it was created with). */
 int lle_map_set_row_align(lle_map* map, int align);
 
 /* static description of World.lasers (src/core/world.rs:159-172): per laser position the outer layer and, if

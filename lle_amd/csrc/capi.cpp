@@ -204,7 +204,8 @@ int lle_map_set_source(lle_map* map, int laser_id, int enabled, int agent_id) {
 
 int lle_map_set_row_align(lle_map* map, int align) {
     if (!map) return fail(LLE_ERR_NULL, "NULL map");
-    if (align != 16 && align != 32 && align != 64 && align != 128 && align != 256) return fail(LLE_ERR_ARG, "row alignment must be 16, 32, 64, 128 or 256");
+    if (align != 0 && align != 16 && align != 32 && align != 64 && align != 128 && align != 256)
+        return fail(LLE_ERR_ARG, "row alignment must be 0 (automatic), 16, 32, 64, 128 or 256");
     map->m.row_align = (uint32_t)align;
     map->m.compile();
     return LLE_OK;

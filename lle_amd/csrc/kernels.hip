@@ -25,14 +25,15 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
     // 400-byte header by value in the kernel-argument segment measured ~2.4 us SLOWER per launch: the kernarg
     // segment is fetched with a much longer latency than device memory.
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const uint32_t map_idx = map_index_of(K, K.env_base + (int64_t)(blockIdx.x * (blockDim.x >> 6)) * K.envs_per_wave);
+    const uint32_t blk = xcd_block(blockIdx.x, gridDim.x);  // the block of environments this workgroup serves (obs_stream.hpp)
+    const uint32_t map_idx = map_index_of(K, K.env_base + (int64_t)(blk * (blockDim.x >> 6)) * K.envs_per_wave);
     const uint8_t* __restrict__ tables = P.tables + (uint64_t)map_idx * K.table_stride;  // this workgroup's map
     const InitRecord* __restrict__ initp = P.init + map_idx;
     const MapHeader* __restrict__ hdr = reinterpret_cast<const MapHeader*>(tables);
     // A workgroup is 1, 2 or 4 wavefronts that share ONE copy of the cell / dyn tables in LDS (a quarter of the L2
     // traffic and of the copy latency of a per-wave copy); everything else is private to a wavefront.
     const uint32_t lane = threadIdx.x & 63u, wave_in_wg = threadIdx.x >> 6, waves_per_wg = blockDim.x >> 6;
-    const uint32_t wave_id = blockIdx.x * waves_per_wg + wave_in_wg;
+    const uint32_t wave_id = blk * waves_per_wg + wave_in_wg;
     const int A = (int)hdr->A, L = (int)hdr->L;
     const uint32_t epw = K.envs_per_wave;
     const int64_t env0 = K.env_base + (int64_t)wave_id * epw;
@@ -453,15 +454,19 @@ uint32_t kernel_waves_per_wg(const MapHeader& h, bool pes) {
 
 // Store policy of a launch that writes `bytes` of observation rows (WRITE_THROUGH_MAX_BYTES, tables.h).
 // LLE_WRITE_THROUGH=0 / 1 forces it (tuning aid).
-bool write_through_pays(uint64_t bytes) {
+// Rows whose pitch is a whole number of 128-byte lines never share a line, so written through each line leaves L2 once
+// and whole: `sc1` then wins at every size (level 6 at 1 920 B: 262 144 envs 99.7 us vs 107.7 plain; 65 536 envs 21.2 vs
+// 23.3).  Packed rows (1 872 B) share lines between neighbours; past the Infinity Cache a shared line written through
+// goes to HBM twice as partial writes (262 144 envs: 163 us vs 98-105 plain), so there the policy follows the size.
+bool write_through_pays(uint64_t bytes, uint32_t row_pitch) {
     const char* o = getenv("LLE_WRITE_THROUGH");  // read per launch: the parity tests run both policies in one process
     if (o && (o[0] == '0' || o[0] == '1') && !o[1]) return o[0] == '1';
-    return bytes <= WRITE_THROUGH_MAX_BYTES;
+    return row_pitch % 128u == 0 || bytes <= WRITE_THROUGH_MAX_BYTES;
 }
 
 hipError_t launch_world_kernel(int mode, const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K_in, hipStream_t stream) {
     LaunchArgs K = K_in;
-    if (write_through_pays((uint64_t)(K.env_limit - K.env_base) * h.obs_stride)) K.flags |= LAUNCH_WRITE_THROUGH;
+    if (write_through_pays((uint64_t)(K.env_limit - K.env_base) * h.obs_stride, h.obs_stride)) K.flags |= LAUNCH_WRITE_THROUGH;
     const bool pes = (K.flags & LAUNCH_PER_ENV_SOURCES) != 0;
     uint32_t wpw = kernel_waves_per_wg(h, pes);
     if (K.envs_per_map && !K.map_override) {  // a workgroup's environments must belong to one map
@@ -502,7 +507,7 @@ hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const Laun
     K.n_sources = h.L;
     {   // a ring keeps the rows of min(n_steps, ring_slots) steps; without one every step overwrites the same rows
         const uint64_t slots = K.ring_slots ? (K.n_steps < K.ring_slots ? (K.n_steps ? K.n_steps : 1u) : K.ring_slots) : 1u;
-        if (write_through_pays((uint64_t)(K.env_limit - K.env_base) * h.obs_stride * slots)) K.flags |= LAUNCH_WRITE_THROUGH;
+        if (write_through_pays((uint64_t)(K.env_limit - K.env_base) * h.obs_stride * slots, h.obs_stride)) K.flags |= LAUNCH_WRITE_THROUGH;
     }
     if (pes || K.envs_per_map) K.flags |= LAUNCH_GENERAL;
     if (K.n_steps > 1 || K.ring_slots || K.stamps) K.flags |= LAUNCH_ROLLOUT;

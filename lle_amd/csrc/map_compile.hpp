@@ -42,8 +42,17 @@ struct Map {
     // Pitch of an observation row in HBM (and of its LDS template): C*H*W rounded up to `row_align` bytes.  16 is the
     // store width; 128 = one cache line, so that the rows of neighbouring environments never share a line (a batch
     // whose rows do not fit the Infinity Cache then writes whole lines to HBM only; lle_map_set_row_align).
-    uint32_t row_align = 16;
-    uint32_t row_pitch_of(uint32_t bytes) const { return (bytes + row_align - 1u) / row_align * row_align; }
+    // 0 = automatic (the default): whole lines when that pads the row by at most 1/32 (level 6: 1 872 -> 1 920 B,
+    // +2.6 % bytes, measured 2 % FASTER inside the Infinity Cache and 5-9 % faster past it), 16 otherwise (level 1:
+    // 936 B would become 1 024, +9.4 %).
+    uint32_t row_align = 0;
+    uint32_t row_pitch_of(uint32_t bytes) const {
+        if (row_align == 0) {
+            const uint32_t lines = (bytes + 127u) & ~127u;
+            return (uint64_t)(lines - bytes) * 32u <= bytes ? lines : ((bytes + 15u) & ~15u);
+        }
+        return (bytes + row_align - 1u) / row_align * row_align;
+    }
 
     int n_agents() const { return (int)starts.size(); }
     int n_layers() const { return 2 * n_agents() + 4; }

@@ -18,6 +18,18 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ---- which block of environments a workgroup serves.
+// Workgroups are dispatched round-robin over the eight XCDs (workgroup b runs on XCD b % 8), and each XCD writes through
+// its own L2.  Serving blocks in dispatch order interleaves the eight XCDs' rows at workgroup granularity; giving XCD x
+// the x-th contiguous eighth of the blocks instead keeps each L2's write stream on one contiguous range of HBM
+// addresses.  Measured with a pure row fill (tools/ceiling/hbm_write_ceiling.hip, 1 920-byte rows, buffers larger than the
+// Infinity Cache): 5.53 -> 5.79 TB/s at 262 144 rows, 5.56 -> 5.98 at 524 288; no change while the rows fit the cache.
+// A bijection of [0, n_blocks) for every n_blocks.
+__device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t n_blocks) {
+    const uint32_t x = b & 7u, q = n_blocks >> 3, r = n_blocks & 7u;
+    return x * q + (x < r ? x : r) + (b >> 3);
+}
+
 // ---- static tables -> LDS, once per workgroup (section offsets are those of the blob).  The section is a whole
 // number of 1 KiB rows; every thread requests all of its rows (up to four) before the first LDS write.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

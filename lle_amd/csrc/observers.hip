@@ -40,8 +40,9 @@ __global__ void __launch_bounds__(256) view_observe_kernel(BatchPtrs P, const ui
                                                            int64_t env_base, int64_t env_limit, int pes, MapSel M, uint32_t views_stride, int wt) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t lane = threadIdx.x & 63u, wave_in_wg = threadIdx.x >> 6, waves_per_wg = blockDim.x >> 6;
-    const uint32_t wave_id = blockIdx.x * waves_per_wg + wave_in_wg;
-    const int64_t wg_env0 = env_base + (int64_t)(blockIdx.x * waves_per_wg) * OBS_ENVS_PER_WAVE;
+    const uint32_t blk = xcd_block(blockIdx.x, gridDim.x);  // the block of environments this workgroup serves (obs_stream.hpp)
+    const uint32_t wave_id = blk * waves_per_wg + wave_in_wg;
+    const int64_t wg_env0 = env_base + (int64_t)(blk * waves_per_wg) * OBS_ENVS_PER_WAVE;
     const uint8_t* __restrict__ map_tables = tables_of(P, M, wg_env0);   // this workgroup's map and its views
     views += (M.envs_per_map ? (uint64_t)wg_env0 / (uint64_t)M.envs_per_map : 0ull) * views_stride;
     const ViewHeader* __restrict__ gh = reinterpret_cast<const ViewHeader*>(views);
@@ -123,8 +124,9 @@ __global__ void __launch_bounds__(256) partial_observe_kernel(BatchPtrs P, int8_
                                                               uint32_t epw) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t lane = threadIdx.x & 63u, wave_in_wg = threadIdx.x >> 6, waves_per_wg = blockDim.x >> 6;
-    const uint32_t wave_id = blockIdx.x * waves_per_wg + wave_in_wg;
-    const uint8_t* __restrict__ tables = tables_of(P, M, env_base + (int64_t)(blockIdx.x * waves_per_wg) * epw);
+    const uint32_t blk = xcd_block(blockIdx.x, gridDim.x);
+    const uint32_t wave_id = blk * waves_per_wg + wave_in_wg;
+    const uint8_t* __restrict__ tables = tables_of(P, M, env_base + (int64_t)(blk * waves_per_wg) * epw);
     const MapHeader* __restrict__ hdr = reinterpret_cast<const MapHeader*>(tables);
     const int A = (int)hdr->A, L = (int)hdr->L;
     const int64_t As = agent_stride_of(A, L);
@@ -346,7 +348,7 @@ hipError_t launch_view_observe(const ViewHeader& v, const BatchPtrs& P, const ui
     const uint32_t n_waves = (uint32_t)((n_envs + OBS_ENVS_PER_WAVE - 1) / OBS_ENVS_PER_WAVE);
     hipLaunchKernelGGL(view_observe_kernel, dim3((n_waves + wpw - 1) / wpw), dim3(64 * wpw), lds, stream, P, views_dev, n_views, out,
                        row_pitch, view_pitch, (int64_t)0, n_envs, pes ? 1 : 0, M, views_stride,
-                       write_through_pays((uint64_t)n_envs * (uint64_t)(n_views > 1 ? view_pitch * n_views : row_pitch)) ? 1 : 0);
+                       write_through_pays((uint64_t)n_envs * (uint64_t)(n_views > 1 ? view_pitch * n_views : row_pitch), (uint32_t)v.obs_stride) ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -85,12 +85,13 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
     constexpr int NW = (2 * G + 7) / 8;             // 64-bit words of the event list (2 events per agent at most)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t lane = threadIdx.x & 63u, wave_in_wg = threadIdx.x >> 6, waves_per_wg = blockDim.x >> 6;
-    const uint32_t wave_id = blockIdx.x * waves_per_wg + wave_in_wg;
+    const uint32_t blk = xcd_block(blockIdx.x, gridDim.x);  // the block of environments this workgroup serves
+    const uint32_t wave_id = blk * waves_per_wg + wave_in_wg;
     const uint8_t* __restrict__ tables = P.tables;
     const InitRecord* __restrict__ initp = P.init;
     if (GEN) {  // this workgroup's map (its envs never straddle two maps: the launcher sizes workgroups accordingly)
         const uint32_t EPW0 = K.envs_per_wave < (uint32_t)(64 / G) ? K.envs_per_wave : (uint32_t)(64 / G);
-        const uint32_t map_idx = map_index_of(K, K.env_base + (int64_t)(blockIdx.x * waves_per_wg) * EPW0);
+        const uint32_t map_idx = map_index_of(K, K.env_base + (int64_t)(blk * waves_per_wg) * EPW0);
         tables += (uint64_t)map_idx * K.table_stride;
         initp += map_idx;
     }

@@ -135,16 +135,20 @@ def test_row_alignment_is_validated_and_must_agree_inside_a_batch():
 
     from lle_amd import _capi, mapgen
 
-    m = _capi.Map(LEVELS[6])
+    m = _capi.Map(LEVELS[6], row_align=16)
     assert (m.obs_bytes, m.obs_stride) == (1872, 1872)
     m.set_row_align(128)
     assert (m.obs_bytes, m.obs_stride) == (1872, 1920)
-    assert _capi.Map(LEVELS[1], row_align=256).obs_stride == 1024 and _capi.Map(LEVELS[1]).obs_stride == 944
+    # automatic (the default): whole 128-byte lines when that pads the row by at most 1/32 of its size
+    assert _capi.Map(LEVELS[6]).obs_stride == 1920 and _capi.Map(LEVELS[1]).obs_stride == 944
+    m.set_row_align(0)
+    assert m.obs_stride == 1920
+    assert _capi.Map(LEVELS[1], row_align=256).obs_stride == 1024 and _capi.Map(LEVELS[1], row_align=16).obs_stride == 944
     with pytest.raises(ValueError):
         _capi.Map(LEVELS[6], row_align=48)
     assert m.positions(_capi.LLE_POS_WALL) == _capi.Map(LEVELS[6]).positions(_capi.LLE_POS_WALL)
     shape = dict(height=9, width=11, n_agents=3, n_lasers=4, n_gems=3, n_voids=2)
-    a, b = _capi.Map(mapgen.generate(seed=1, **shape), row_align=128), _capi.Map(mapgen.generate(seed=2, **shape))
+    a, b = _capi.Map(mapgen.generate(seed=1, **shape), row_align=128), _capi.Map(mapgen.generate(seed=2, **shape), row_align=16)
     L = _capi.lib()
     assert L.lle_batch_arena_bytes_multi((C.c_void_p * 2)(a.h, b.h), 2, 64) < 0
     assert b"row alignment" in L.lle_last_error()
