@@ -366,6 +366,7 @@ static int common_header(const lle_map* const* maps, int n_maps, MapHeader* out,
         h.lds_table_bytes = std::max(h.lds_table_bytes, o.lds_table_bytes);
         h.blob_capacity = std::max(h.blob_capacity, o.blob_capacity);
         h.ext_bytes = std::max(h.ext_bytes, o.ext_bytes);
+        h.lds_split_table_bytes = std::max(h.lds_split_table_bytes, o.lds_split_table_bytes);
         h.n_elems = std::max(h.n_elems, o.n_elems);
         h.obs_supported = h.obs_supported && o.obs_supported;
         h.max_layers = std::max(h.max_layers, o.max_layers);
@@ -835,7 +836,15 @@ int lle_batch_kernel_info(const lle_batch* b, char* name_buf, size_t cap, int32_
         if (b->lane_per_env_step) std::snprintf(name_buf, cap, "%s", kernel_variant_name(kernel_variant((int)b->hdr.A, (int)b->hdr.L)));
         else std::snprintf(name_buf, cap, "step_kernel<%d,%d>", step_group((int)b->hdr.A), step_lm((int)b->hdr.L));
     }
-    if (lds_bytes) *lds_bytes = (int32_t)kernel_lds_bytes(b->hdr, kernel_waves_per_wg(b->hdr));
+    if (lds_bytes) {
+        const bool pes = b->per_env_sources;
+        if (!b->lane_per_env_step && step_splits_rows(b->hdr, pes)) {
+            const uint32_t cap = 64u / (uint32_t)step_group((int)b->hdr.A), e = step_envs_per_wave(b->n_envs, (int)b->hdr.A);
+            *lds_bytes = (int32_t)split_lds_bytes(b->hdr, 4, e < cap ? e : cap);
+        } else {
+            *lds_bytes = (int32_t)kernel_lds_bytes(b->hdr, kernel_waves_per_wg(b->hdr, pes), pes);
+        }
+    }
     if (envs_per_wave) *envs_per_wave = b->lane_per_env_step ? (int32_t)b->envs_per_wave : (int32_t)step_envs_per_wave(b->n_envs, (int)b->hdr.A);
     return LLE_OK;
 }

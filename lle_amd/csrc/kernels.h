@@ -14,6 +14,8 @@ int agent_stride(int A, int L);  // agents per env record in the per-agent buffe
 const char* kernel_variant_name(int variant);
 uint32_t kernel_lds_bytes(const MapHeader& h, uint32_t waves_per_wg, bool pes = false);
 uint32_t kernel_waves_per_wg(const MapHeader& h, bool pes = false);
+bool step_splits_rows(const MapHeader& h, bool pes);                      // step_kernel: rows split over the workgroup's wavefronts
+uint32_t split_lds_bytes(const MapHeader& h, uint32_t wpw, uint32_t epw);
 // step_kernel instantiations, one translation unit per MODE (step_mode<N>.hip; step_kernel.hpp)
 hipError_t launch_step_mode0(int G, int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream);
 hipError_t launch_step_mode1(int G, int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream);

@@ -452,6 +452,22 @@ uint32_t kernel_waves_per_wg(const MapHeader& h, bool pes) {
     return 1;
 }
 
+// ---- split rows (step_kernel, LAUNCH_SPLIT_ROWS): when whole-row private copies would leave ONE workgroup per CU (config
+// 5: 33 KB of tables + 4 x 20.5 KB = 135 KB), every wavefront keeps one slice of the row instead and streams that slice
+// of every environment of the workgroup: tables without the pristine row (13 KB) + the row once (20 KB) + records
+// = 36 KB, four workgroups per CU.  LLE_STEP_SPLIT=0 / 1 forces it (tuning aid; 1 only where the kernels carry it).
+bool step_splits_rows(const MapHeader& h, bool pes) {
+    if (pes || step_group((int)h.A) < 8) return false;
+    if (const char* o = getenv("LLE_STEP_SPLIT")) {
+        if ((o[0] == '0' || o[0] == '1') && !o[1]) return o[0] == '1';
+    }
+    return kernel_lds_bytes(h, 4, false) > LDS_PER_CU / 2;
+}
+uint32_t split_lds_bytes(const MapHeader& h, uint32_t wpw, uint32_t epw) {
+    const uint32_t scr_stride = (h.L + h.A + 2) | 1u, cpw = (h.n_chunks + wpw - 1) / wpw;
+    return h.lds_split_table_bytes + wpw * cpw * 16u + wpw * epw * scr_stride * 4u + 64u;
+}
+
 // Store policy of a launch that writes `bytes` of observation rows (WRITE_THROUGH_MAX_BYTES, tables.h).
 // LLE_WRITE_THROUGH=0 / 1 forces it (tuning aid).
 // Rows whose pitch is a whole number of 128-byte lines never share a line, so written through each line leaves L2 once
@@ -521,7 +537,15 @@ hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const Laun
     }
     const uint32_t epw = K.envs_per_wave;
     const uint32_t n_waves = (uint32_t)((K.env_limit - K.env_base + epw - 1) / epw);
-    const uint32_t lds = kernel_lds_bytes(h, wpw, pes);
+    uint32_t lds = kernel_lds_bytes(h, wpw, pes);
+    if (step_splits_rows(h, pes)) {
+        const uint32_t cap = 64u / (uint32_t)G, e = epw < cap ? epw : cap;
+        wpw = 4;
+        if (K.envs_per_map)
+            while (wpw > 1 && K.envs_per_map % (int64_t)(wpw * e) != 0) wpw >>= 1;
+        lds = split_lds_bytes(h, wpw, e);
+        K.flags |= LAUNCH_SPLIT_ROWS;
+    }
     // MODE of the instantiation (step_kernel.hpp): per-env sources 3 / 5, several maps 2 / 4, one map 1 / 0 -- the
     // first of each pair with the rollout loop, rings and stamps, the second for single-step launches
     const bool roll = (K.flags & LAUNCH_ROLLOUT) != 0;

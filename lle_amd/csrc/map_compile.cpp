@@ -449,6 +449,7 @@ void Map::compile() {
         h.blob_capacity = (uint32_t)(h.off_cell_lay + ((cap - h.off_cell_lay + 1023) & ~(size_t)1023));
     }
     h.lds_table_bytes = h.blob_bytes - h.off_cell_lay;
+    h.lds_split_table_bytes = (h.off_template - h.off_cell_lay + 1023u) & ~1023u;  // (<= lds_table_bytes: the copy stays inside the blob)
     // ---- second section (per-environment sources), at an offset that does not depend on the colours
     std::vector<int8_t> bare(h.obs_stride, 0);
     {

@@ -154,6 +154,68 @@ __device__ __forceinline__ void write_observations(int A, int L, uint32_t D, uin
     }
 }
 
+// ---- phase 2 for BIG rows (config 5: 20 KB per environment): the row is split over the wavefronts of the workgroup.
+// A private copy of the whole row per wavefront limits a CU to one workgroup (4 x 20 KB + tables), i.e. four
+// wavefronts per CU to keep the store pipeline full.  Here wavefront w of the workgroup owns the chunks
+// [w * cpw, (w + 1) * cpw) of EVERY environment of the workgroup: its private copy is one slice (5 KB), it patches the
+// dynamic bytes and agents that fall into its slice and streams the slice of each environment in turn.  The hand-over
+// records of all the workgroup's environments sit in one shared LDS area (one workgroup barrier after phase 1).
+// `tmpl` = the wave's slice (pristine bytes of chunks [lo, hi)), `lo`, `hi` in 16-byte chunks, `dyn` the whole (sorted
+// by byte index) table.  Same bytes as write_observations: every dynamic byte and every agent byte belongs to exactly
+// one slice.
+template <bool WT>
+__device__ __forceinline__ void write_observations_split(int A, int L, uint32_t D, uint32_t lo, uint32_t hi, uint64_t obs_stride,
+                                                         const uint64_t* dyn, int8_t* tmpl, const uint32_t* records,
+                                                         uint32_t scr_stride, int8_t* __restrict__ obs, int64_t wg_env0,
+                                                         int64_t n_wg_here, uint32_t lane) {
+    const uint32_t b_lo = lo * 16u, b_hi = hi * 16u;
+    // the dyn table is sorted by byte index: this slice's entries are [d_lo, d_hi)
+    uint32_t d_lo = 0, d_hi = 0;
+    for (uint32_t d = lane; d < ((D + 63u) & ~63u); d += 64) {
+        const uint32_t idx = d < D ? (uint32_t)dyn[d] & 0xFFFFFu : 0xFFFFFFFFu;
+        d_lo += (uint32_t)__popcll(__ballot(idx < b_lo));
+        d_hi += (uint32_t)__popcll(__ballot(idx < b_hi));
+    }
+    const bool has_d0 = d_lo + lane < d_hi;
+    const uint64_t e0 = has_d0 ? dyn[d_lo + lane] : 0ull;
+    const uint32_t d0_idx = has_d0 ? ((uint32_t)e0 & 0xFFFFFu) - b_lo : 0u;
+    const int32_t d0_base = (int8_t)(uint8_t)(e0 >> 20);
+    const uint32_t d0_refs = (uint32_t)(e0 >> 28) & 3u, d0_gem = (uint32_t)(e0 >> 50) & 63u;
+    const uint32_t d0_r0 = (uint32_t)(e0 >> 30) & 0x3FFu, d0_r1 = (uint32_t)(e0 >> 40) & 0x3FFu;
+    const uint32_t d0_w0 = d0_refs >= 1 ? 1u + (d0_r0 & 31u) : 0u, d0_s0 = d0_refs >= 1 ? d0_r0 >> 5 : 0u;
+    const uint32_t d0_w1 = d0_refs >= 2 ? 1u + (d0_r1 & 31u) : 0u, d0_s1 = d0_refs >= 2 ? d0_r1 >> 5 : 0u;
+    const uint32_t d0_wg = d0_gem != NO_GEM ? (uint32_t)L + 1u : 0u, d0_sg = d0_gem != NO_GEM ? (d0_gem & 31u) : 0u;
+    const bool is_agent_lane = (int)lane < A;
+    const uint4* srcv = reinterpret_cast<const uint4*>(tmpl);
+    const uint32_t n_mine = hi - lo;
+
+    for (int64_t k = 0; k < n_wg_here; k++) {
+        const uint32_t* sc = records + (uint32_t)k * scr_stride;
+        {
+            const uint32_t lit = ((sc[d0_w0] >> d0_s0) | (sc[d0_w1] >> d0_s1) | (sc[d0_wg] >> d0_sg)) & 1u;
+            if (has_d0) tmpl[d0_idx] = (int8_t)(lit ? 1 : d0_base);
+        }
+        for (uint32_t d = d_lo + lane + 64u; d < d_hi; d += 64) {  // slices with more than 64 dynamic bytes
+            const uint64_t e = dyn[d];
+            const uint32_t refs = (uint32_t)(e >> 28) & 3u, gem = (uint32_t)(e >> 50) & 63u;
+            const uint32_t r0 = (uint32_t)(e >> 30) & 0x3FFu, r1 = (uint32_t)(e >> 40) & 0x3FFu;
+            const uint32_t w0 = refs >= 1 ? 1u + (r0 & 31u) : 0u, w1 = refs >= 2 ? 1u + (r1 & 31u) : 0u;
+            const uint32_t wg = gem != NO_GEM ? (uint32_t)L + 1u : 0u;
+            const uint32_t lit = ((sc[w0] >> (refs >= 1 ? r0 >> 5 : 0u)) | (sc[w1] >> (refs >= 2 ? r1 >> 5 : 0u)) |
+                                  (sc[wg] >> (gem != NO_GEM ? (gem & 31u) : 0u))) & 1u;
+            tmpl[((uint32_t)e & 0xFFFFFu) - b_lo] = (int8_t)(lit ? 1 : (int32_t)(int8_t)(uint8_t)(e >> 20));
+        }
+        const uint32_t agent_idx = is_agent_lane ? sc[L + 2 + lane] : 0xFFFFFFFFu;
+        const bool agent_here = agent_idx >= b_lo && agent_idx < b_hi;  // (idle lanes: 0xFFFFFFFF is in no slice)
+        if (agent_here) tmpl[agent_idx - b_lo] = 1;
+        wave_sync();
+        uint4* __restrict__ dst = reinterpret_cast<uint4*>(obs + (uint64_t)(wg_env0 + k) * obs_stride) + lo;
+        stream_whole_row<WT>(dst, srcv, n_mine, lane);
+        wave_sync();
+        if (agent_here) tmpl[agent_idx - b_lo] = 0;
+    }
+}
+
 // ---- the same, for batches whose environments have their own source colours / enabled flags
 // (lle_batch_set_sources).  The layer of a laser byte is LASER_0 + the env's colour of that beam, so it cannot be baked
 // into a table: `tmpl` starts as the BARE static observation (walls, voids, exits) and every env writes its elements

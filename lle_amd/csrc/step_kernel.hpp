@@ -71,6 +71,12 @@ template <int G, int LM, int MODE, bool ML1, int LX = -1>
 __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K) {
     constexpr bool GEN = MODE >= 2, ROLL = MODE >= 1 && MODE <= 3;
     constexpr bool PES = MODE == 3 || MODE == 5;  // (the launcher picks these exactly when LAUNCH_PER_ENV_SOURCES is set)
+    // Big rows (LAUNCH_SPLIT_ROWS, set by the launcher when private whole-row copies would leave one workgroup per CU):
+    // the row is split over the wavefronts of the workgroup, see write_observations_split (obs_stream.hpp).  Only the
+    // instantiations of maps with more than four agents carry it (rows of 16 KB and more with at most four agents
+    // would need maps beyond 36 x 36; those stay on whole-row copies), and not the per-env-sources modes.
+    constexpr bool CAN_SPLIT = G >= 8 && !PES;
+    const bool split = CAN_SPLIT && (K.flags & LAUNCH_SPLIT_ROWS) != 0;
     // The default instantiation is one step in place and nothing else: the fused rollout (n_steps, trajectory rings)
     // and the timeline stamps run on the general one, so that their arguments do not occupy scalar registers here.
     uint64_t* const stamps = ROLL ? K.stamps : nullptr;
@@ -119,7 +125,8 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
     const uint32_t bit = 1u << a, amask = (1u << A) - 1u;
     LLE_STAMP(0);
 
-    const uint32_t tab_bytes = hdr->lds_table_bytes, tab_off = hdr->off_cell_lay;
+    // (split rows: the pristine static observation stays in global memory, every wavefront copies its slice from there)
+    const uint32_t tab_bytes = split ? hdr->lds_split_table_bytes : hdr->lds_table_bytes, tab_off = hdr->off_cell_lay;
     copy_tables_to_lds(tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
     const uint32_t ext_bytes = PES ? hdr->ext_bytes : 0u;
     if (PES) copy_tables_to_lds(tables + hdr->off_bare, lds + tab_bytes, ext_bytes, lane, wave_in_wg, waves_per_wg);
@@ -191,7 +198,17 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
     uint32_t* scratch = reinterpret_cast<uint32_t*>(tmpl + h_obs_stride);
     const int8_t* bare = reinterpret_cast<const int8_t*>(lds + tab_bytes);
     const uint32_t* elems = reinterpret_cast<const uint32_t*>(lds + tab_bytes + (hdr->off_elems - hdr->off_bare));
-    {
+    // split rows: [tables | one slice per wavefront | the hand-over records of all the workgroup's environments]
+    const uint32_t cpw = (h_n_chunks + waves_per_wg - 1u) / waves_per_wg;  // chunks per slice
+    const uint32_t c_lo = wave_in_wg * cpw < h_n_chunks ? wave_in_wg * cpw : h_n_chunks;
+    const uint32_t c_hi = c_lo + cpw < h_n_chunks ? c_lo + cpw : h_n_chunks;
+    if (split) {
+        tmpl = reinterpret_cast<int8_t*>(lds + tab_bytes + wave_in_wg * cpw * 16u);
+        scratch = reinterpret_cast<uint32_t*>(lds + tab_bytes + waves_per_wg * cpw * 16u) + wave_in_wg * EPW * scr_stride;
+        const uint4* __restrict__ pristine = reinterpret_cast<const uint4*>(tables + hdr->off_template) + c_lo;
+        uint4* mine = reinterpret_cast<uint4*>(tmpl);
+        for (uint32_t c = lane; c < c_hi - c_lo; c += 64) mine[c] = pristine[c];
+    } else {
         const uint4* pristine = PES ? reinterpret_cast<const uint4*>(bare) : reinterpret_cast<const uint4*>(lds + (hdr->off_template - tab_off));
         uint4* mine = reinterpret_cast<uint4*>(tmpl);
         for (uint32_t c = lane; c < h_n_chunks; c += 64) mine[c] = pristine[c];
@@ -437,14 +454,32 @@ __global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K)
         }
     }
     if (me) scratch[grp * scr_stride + L + 2 + a] = a * h_HW + cell_of(pos, W);  // ... | byte index of each agent]
-    wave_sync();
+    if (split) {
+        // the records of the whole workgroup must be in LDS before any wavefront streams its slice.  LDS only: waiting
+        // for vmcnt here (what __syncthreads() does) would hold every step of a fused rollout until the previous step's
+        // observation stores have been acknowledged.
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+        wave_sync();
+    }
     LLE_STAMP(4);
     // (deferring it in the single-step launches of MODE 1 / 2 as well measured 1.3-1.5 us SLOWER there: those
     // instantiations already spill, and the deferral lengthens the live ranges)
     const bool post_first = ROLL || blockIdx.x * 4u >= gridDim.x * 3u;
     if (post_first) post_step();
 
-    if (write_obs && n_here > 0) {
+    if (split) {
+        if (write_obs) {
+            const int64_t wg_env0 = K.env_base + (int64_t)(blk * waves_per_wg) * EPW;
+            int64_t n_wg = K.env_limit - wg_env0;
+            n_wg = n_wg < 0 ? 0 : (n_wg > (int64_t)(waves_per_wg * EPW) ? (int64_t)(waves_per_wg * EPW) : n_wg);
+            const uint32_t* records = reinterpret_cast<const uint32_t*>(lds + tab_bytes + waves_per_wg * cpw * 16u);
+            if (K.flags & LAUNCH_WRITE_THROUGH) write_observations_split<true>(A, L, h_D, c_lo, c_hi, h_obs_stride, dyn, tmpl, records, scr_stride, obs_out, wg_env0, n_wg, lane);
+            else write_observations_split<false>(A, L, h_D, c_lo, c_hi, h_obs_stride, dyn, tmpl, records, scr_stride, obs_out, wg_env0, n_wg, lane);
+        }
+        // fused rollout: the next step's records overwrite these
+        if (ROLL && n_steps > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else if (write_obs && n_here > 0) {
         const bool wt = (K.flags & LAUNCH_WRITE_THROUGH) != 0;  // see stream_store (obs_stream.hpp)
         if (PES) {
             if (wt) write_observations_env<true>(A, L, h_HW, hdr->n_elems, h_n_chunks, h_obs_stride, elems, bare, tmpl, scratch, scr_stride,

@@ -53,7 +53,7 @@ struct MapHeader {
     uint32_t obs_supported;
     uint32_t direct_gems;    // bit g: gem g is a direct Tile::Gem (no laser layer on its cell)
     uint32_t blob_capacity;  // blob_bytes with the largest possible dyn table (any recolouring of the sources fits)
-    uint32_t pad1;
+    uint32_t lds_split_table_bytes;  // bytes [off_cell_lay, off_template) in whole 1-KiB rows: the LDS tables of a split-row launch
     uint16_t start[MAX_AGENTS];        // start cell of each agent, i | j << 8
     uint32_t beam_full[MAX_SOURCES];   // (1 << len) - 1
     uint8_t beam_len[MAX_SOURCES];
@@ -120,6 +120,7 @@ constexpr uint32_t LAUNCH_SINGLE_LAYER = 0x100000;    // internal: no cell has m
 constexpr uint32_t LAUNCH_ROLLOUT = 0x200000;         // internal: step_kernel MODE 1 (fused rollout / stamps; one map, map-wide sources)
 constexpr uint32_t LAUNCH_ARRAYS_INVALID = 0x40000;   // internal (MODE_ENV_SOURCES): first call, nothing stored per env yet
 constexpr uint32_t LAUNCH_RESET_FIRST = 0x800000;      // internal (MODE_ENV_SOURCES): World::reset of the env, then the source update
+constexpr uint32_t LAUNCH_SPLIT_ROWS = 0x1000000;      // internal: step_kernel splits every observation row over the wavefronts of a workgroup
 constexpr uint32_t LAUNCH_WRITE_THROUGH = 0x400000;    // internal: observation rows are stored `sc1` (stream_store, obs_stream.hpp)
 // A launch writes its rows through L2 while all of them fit the Infinity Cache (256 MB, MI355X_MICROARCH.md); beyond
 // that plain write-back stores are faster (measured break-even between 245 MB and 490 MB per launch).
