@@ -68,7 +68,7 @@ __device__ __forceinline__ void for_each_other(uint32_t v, F&& f) {
 // LX >= 0: the exact number of sources, known at compile time (instantiated for the default path of maps with at
 // most four sources: the per-beam loops lose their guards and the unused beam registers disappear; 0.4 us on level 6).
 template <int G, int LM, int MODE, bool ML1, int LX = -1>
-__global__ void __launch_bounds__(256, 4) step_kernel(BatchPtrs P, LaunchArgs K) {
+__global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P, LaunchArgs K) {
     constexpr bool GEN = MODE >= 2, ROLL = MODE >= 1 && MODE <= 3;
     constexpr bool PES = MODE == 3 || MODE == 5;  // (the launcher picks these exactly when LAUNCH_PER_ENV_SOURCES is set)
     // Big rows (LAUNCH_SPLIT_ROWS, set by the launcher when private whole-row copies would leave one workgroup per CU):
