@@ -77,8 +77,11 @@ enum {
     LLE_ENV_INVALID_WORLD_STATE = 0x40,
     LLE_ENV_OUT_OF_WORLD_POSITION = 0x41,
     LLE_ENV_INVALID_AGENT_POSITION = 0x42,
-    LLE_ENV_INVALID_COLOUR = 0x43  /* lle_batch_set_sources: a colour >= n_agents ("Agent ID is greater than the number of
+    LLE_ENV_INVALID_COLOUR = 0x43, /* lle_batch_set_sources: a colour >= n_agents ("Agent ID is greater than the number of
                                       agents", pylaser_source.rs:108-112); the env's sources are left unchanged */
+    LLE_ENV_COLOUR_CROSSES_START = 0x44 /* lle_batch_set_sources: "Laser source cannot be changed to agent ID c since it would
+                                      cross the start position of agent a" (pylaser_source.rs:121-139): a start of another agent
+                                      lies on the source's beam; the env's sources are left unchanged */
 };
 
 /* ================================================================== maps (host only)
@@ -113,6 +116,9 @@ int lle_map_sources(const lle_map* map, lle_source_info* out, int cap);
 /* LaserSource.enable/disable/set_agent_id (src/core/tiles/laser_source.rs:37-47).  -1 = leave unchanged.
  * Only changes the host object: call lle_batch_update_sources() to push it to a live batch. */
 int lle_map_set_source(lle_map* map, int laser_id, int enabled, int agent_id);
+/* 1 if source `laser_id` may take colour `agent_id` without a possible start of another agent on its beam (the check of
+ * the binding's LaserSource.set_colour, src/bindings/tiles/pylaser_source.rs:121-139), 0 if not, negative on bad arguments. */
+int lle_map_colour_allowed(const lle_map* map, int laser_id, int agent_id);
 
 /* Pitch of an observation row (lle_map_info.obs_stride, the env stride of LLE_BUF_OBS and of every layered-style
  * lle_obs_desc): C*H*W rounded up to `align` bytes (16, 32, 64, 128 or 256).  The first C*H*W bytes of a row are the
@@ -235,8 +241,12 @@ int lle_batch_update_sources(lle_batch* b, const lle_map* map, void* stream);
  *                                 flag CHANGES (pylaser_source.rs:55-75): enable re-lights the whole beam, disable
  *                                 clears it (laser.rs:69-77)
  *   env_mask_dev u8  [n_envs] or NULL: envs to touch.
- * A colour >= n_agents is refused per env (LLE_BUF_ERR = LLE_ENV_INVALID_COLOUR, sources unchanged); the start-crossing
- * check of pylaser_source.rs:121-139 is a property of the map and stays with the caller.  Rewrites LLE_BUF_OBS.
+ * Refused per env, with NONE of its sources changed: a colour >= n_agents (LLE_BUF_ERR = LLE_ENV_INVALID_COLOUR) and a
+ * colour that would put the start of another agent on the source's beam (LLE_ENV_COLOUR_CROSSES_START: the check of the
+ * binding's LaserSource.set_colour, pylaser_source.rs:121-139, on the tiles World.lasers() exposes; which (source, colour)
+ * pairs pass is a property of the map: lle_map_colour_allowed).  The reference raises ValueError there having ALREADY
+ * recoloured the core source and every source before it in the loop of env.py:198-200; a batch cannot raise per env, and
+ * leaving the env untouched is the state a caller can reason about.  Rewrites LLE_BUF_OBS.
  * From the first call on the batch keeps colours and flags per env (LLE_BUF_SRC_*): reset, step (auto-reset restarts an
  * env from ITS reset state), set_state and every observation builder use them; lle_batch_update_sources then
  * broadcasts the map's sources to every env. */

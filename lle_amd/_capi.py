@@ -21,6 +21,7 @@ LLE_POS_START, LLE_POS_EXIT, LLE_POS_WALL, LLE_POS_VOID, LLE_POS_GEM = range(5)
 LLE_STEP_SAMPLE_ACTIONS, LLE_STEP_AUTO_RESET, LLE_STEP_NO_OBS = 1, 2, 4
 LLE_ENV_INVALID_WORLD_STATE, LLE_ENV_OUT_OF_WORLD_POSITION, LLE_ENV_INVALID_AGENT_POSITION = 0x40, 0x41, 0x42
 LLE_ENV_INVALID_COLOUR = 0x43
+LLE_ENV_COLOUR_CROSSES_START = 0x44
 LLE_ERR_NO_DEVICE = -5
 LLE_ERR_UNSUPPORTED = -4
 (LLE_OBS_LAYERED, LLE_OBS_LAYERED_PADDED, LLE_OBS_PERSPECTIVE, LLE_OBS_PARTIAL, LLE_OBS_STATE,
@@ -35,7 +36,7 @@ PARSE_ERROR_NAMES = {
 EXPORTS = [
     "lle_abi_version", "lle_last_status", "lle_last_error", "lle_action_hash",
     "lle_map_parse", "lle_map_level", "lle_map_free", "lle_map_get_info", "lle_map_positions", "lle_map_sources",
-    "lle_map_set_source", "lle_map_set_row_align", "lle_map_laser_tiles", "lle_map_world_string",
+    "lle_map_set_source", "lle_map_colour_allowed", "lle_map_set_row_align", "lle_map_laser_tiles", "lle_map_world_string",
     "lle_batch_arena_bytes", "lle_batch_create", "lle_batch_arena_bytes_multi", "lle_batch_create_multi", "lle_batch_n_maps", "lle_batch_free", "lle_batch_get_buffer", "lle_batch_n_envs",
     "lle_batch_reset", "lle_batch_step", "lle_batch_rollout", "lle_batch_set_state", "lle_batch_update_sources", "lle_batch_observe",
     "lle_batch_snapshot_bytes", "lle_batch_snapshot", "lle_batch_restore",
@@ -118,6 +119,8 @@ def lib():
     L.lle_map_sources.argtypes = [vp, C.POINTER(SourceInfo), i32]
     L.lle_map_set_source.restype = i32
     L.lle_map_set_source.argtypes = [vp, i32, i32, i32]
+    L.lle_map_colour_allowed.restype = i32
+    L.lle_map_colour_allowed.argtypes = [vp, i32, i32]
     L.lle_map_set_row_align.restype = i32
     L.lle_map_set_row_align.argtypes = [vp, i32]
     L.lle_map_laser_tiles.restype = i32
@@ -240,6 +243,13 @@ class Map:
         arr = (LaserTile * max(n, 1))()
         lib().lle_map_laser_tiles(self.h, arr, n)
         return [arr[k] for k in range(n)]
+
+    def colour_allowed(self, laser_id, agent_id):
+        """May source `laser_id` take colour `agent_id`?  (no start of another agent on its beam, pylaser_source.rs:121-139)"""
+        rc = lib().lle_map_colour_allowed(self.h, int(laser_id), int(agent_id))
+        if rc < 0:
+            raise ValueError(lib().lle_last_error().decode())
+        return bool(rc)
 
     def set_row_align(self, align):
         if lib().lle_map_set_row_align(self.h, int(align)) != 0:

@@ -214,7 +214,8 @@ class BatchedWorld:
     def set_sources(self, colours=None, enabled=None, env_mask=None, reset_first=False, write_obs=True):
         """Per-environment laser sources (LLE.reset with randomize_lasers, python/lle/env/env.py:198-200; LaserSource
         enable / disable): colours u8 [n, L] and/or enabled masks i32 [n] (bit l = source l on), optionally only for the
-        envs with env_mask != 0.  An env given a colour >= n_agents is left unchanged with err = LLE_ENV_INVALID_COLOUR.
+        envs with env_mask != 0.  An env given a colour >= n_agents is left unchanged with err = LLE_ENV_INVALID_COLOUR, one
+        given a colour that puts another agent's start on the beam with err = LLE_ENV_COLOUR_CROSSES_START.
         From the first call on `src_colour` / `src_enabled` hold each env's sources.
         reset_first: World.reset of the selected envs in the same launch, before the update (lle_batch_reset_sources:
         what `reset(env_mask)` followed by this call leaves; env_mask may then be `self.done` itself; write_obs=False when

@@ -202,6 +202,14 @@ int lle_map_set_source(lle_map* map, int laser_id, int enabled, int agent_id) {
     return LLE_OK;
 }
 
+int lle_map_colour_allowed(const lle_map* map, int laser_id, int agent_id) {
+    if (!map) return fail(LLE_ERR_NULL, "NULL map");
+    const Map& m = map->m;
+    if (laser_id < 0 || laser_id >= (int)m.sources.size()) return fail(LLE_ERR_ARG, "laser_id out of range");
+    if (agent_id < 0 || agent_id >= m.n_agents()) return fail(LLE_ERR_ARG, "Agent ID is greater than the number of agents");
+    return (m.header.colour_ok[laser_id] >> agent_id) & 1;
+}
+
 int lle_map_set_row_align(lle_map* map, int align) {
     if (!map) return fail(LLE_ERR_NULL, "NULL map");
     if (align != 0 && align != 16 && align != 32 && align != 64 && align != 128 && align != 256)

@@ -262,16 +262,19 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
                 uint32_t ncol[LM / 4];
 #pragma unroll
                 for (int q = 0; q < LM / 4; q++) ncol[q] = colw[q];
-                bool bad = false;
+                bool bad = false, crosses = false;
 #pragma unroll
                 for (int b = 0; b < LM; b++) {
                     if (b < L && (fill || K.colours_in)) {
                         const uint32_t c = fill ? (uint32_t)hdr->beam_colour[b] : (uint32_t)K.colours_in[env * L + b];
                         bad |= !fill && c >= (uint32_t)A;  // "Agent ID is greater than the number of agents"
+                        // "... would cross the start position of agent ..." (pylaser_source.rs:121-139; MapHeader.colour_ok)
+                        crosses |= !fill && c < (uint32_t)A && !(((uint32_t)hdr->colour_ok[b] >> c) & 1u);
                         ncol[b >> 2] = (ncol[b >> 2] & ~(0xFFu << ((b & 3) * 8))) | ((c & 0xFFu) << ((b & 3) * 8));
                     }
                 }
-                err = bad ? ENV_INVALID_COLOUR : 0u;
+                err = bad ? ENV_INVALID_COLOUR : (crosses ? ENV_COLOUR_CROSSES_START : 0u);
+                bad |= crosses;
                 if (!bad) {
 #pragma unroll
                     for (int b = 0; b < LM; b++) {

@@ -385,6 +385,22 @@ void Map::compile() {
         if (src.enabled) h.enabled_mask |= 1u << s;
     }
 
+    // which colours a source may take (pylaser_source.rs:121-139): its exposed tiles (outer layer and the one directly
+    // below, world.rs:159-172) must not hold a possible start of an agent of another colour
+    for (int s = 0; s < L; s++) {
+        uint32_t on_beam = 0;  // agents with a start on the exposed tiles of source s
+        for (int a = 0; a < A; a++)
+            for (const Pos& st : starts[a]) {
+                const auto& layers = cell_layers[st.i * W + st.j];
+                for (size_t k = 0; k < layers.size() && k < 2; k++)
+                    if (layers[k].laser_id == s) on_beam |= 1u << a;
+            }
+        uint32_t ok = 0;
+        for (int c = 0; c < A; c++)
+            if ((on_beam & ~(1u << c)) == 0) ok |= 1u << c;
+        h.colour_ok[s] = (uint16_t)ok;
+    }
+
     // ---- cell tables
     std::vector<uint64_t> cell_lay(HW, 0);
     std::vector<uint32_t> cell_meta(HW, 0);

@@ -62,6 +62,9 @@ struct MapHeader {
     // per-environment sources (kernels instantiated with PES = true): a second LDS section right behind the first,
     // [off_bare, off_bare + ext_bytes): the static observation WITHOUT the sources' -1 marks, and the element list
     uint32_t off_bare, off_elems, n_elems, ext_bytes;
+    // bit c: source s may take colour c -- no possible start of an agent other than c lies on the tiles World::lasers()
+    // exposes for that source (the check of the binding's LaserSource.set_colour, src/bindings/tiles/pylaser_source.rs:121-139)
+    uint16_t colour_ok[MAX_SOURCES];
 };
 static_assert(sizeof(MapHeader) % 16 == 0, "sections must stay 16-byte aligned");
 
@@ -110,6 +113,7 @@ constexpr uint8_t ENV_INVALID_WORLD_STATE = 0x40;
 constexpr uint8_t ENV_OUT_OF_WORLD_POSITION = 0x41;
 constexpr uint8_t ENV_INVALID_AGENT_POSITION = 0x42;
 constexpr uint8_t ENV_INVALID_COLOUR = 0x43;
+constexpr uint8_t ENV_COLOUR_CROSSES_START = 0x44;
 
 // ---- step flags (mirror include/lle_hip.h)
 constexpr uint32_t STEP_SAMPLE_ACTIONS = 1, STEP_AUTO_RESET = 2, STEP_NO_OBS = 4;

@@ -47,6 +47,16 @@ class BatchedLLE:
         self._needs_layered = _capi.LLE_OBS_LAYERED in (self._obs_kind[0], self._state_kind[0])
         self.walkable_lasers = bool(walkable_lasers)
         self.randomize_lasers = bool(randomize_lasers)
+        if self.randomize_lasers:
+            # LLE.reset draws `source.set_colour(random.randint(0, n_agents - 1))` (env.py:198-200) and set_colour raises
+            # ValueError for a colour that puts another agent's start on the beam (pylaser_source.rs:121-139): on such a
+            # map the reference fails at the first reset that draws the pair; a batch draws every pair at once.
+            for m in self.world.maps:
+                for s in m.sources():
+                    for c in range(m.n_agents):
+                        if not m.colour_allowed(s.laser_id, c):
+                            raise ValueError(f"randomize_lasers: laser source {s.laser_id} at {(s.i, s.j)} cannot be changed to agent ID "
+                                             f"{c} since it would cross the start position of another agent")
         self.multi_objective = bool(multi_objective)
         self._gen = torch.Generator(device=self.world.device)
         self._gen.manual_seed(int(seed))

@@ -256,20 +256,23 @@ class LaserSource:
         self.set_colour(new_agent_id)
 
     def set_colour(self, colour):
+        """PyLaserSource.set_agent_id (src/bindings/tiles/pylaser_source.rs:107-141), quirk included: the world's colour
+        is changed BEFORE the start positions are checked, so a change refused with "would cross the start position"
+        has recoloured the world all the same; only this snapshot keeps the old id."""
         colour = int(colour)
         if colour < 0:
             raise OverflowError("can't convert negative int to unsigned")
         w = self._world
         if colour >= w.n_agents:
             raise ValueError("Agent ID is greater than the number of agents")
-        # pylaser_source.rs:121-139: the beam must not cross a possible start of another agent
+        w._set_source(self.laser_id, colour=colour)  # :114-119
+        # :121-139: the beam must not cross a possible start of another agent
         cells = {(t.i, t.j) for t in w._map.laser_tiles() if t.laser_id == self.laser_id}
         for agent, starts in enumerate(w.random_start_pos):
             hit = cells & set(starts)
             if agent != colour and hit:
                 raise ValueError(f"Laser source cannot be changed to agent ID {colour} since it would cross the start "
                                  f"position of agent {agent} at {sorted(hit)}")
-        w._set_source(self.laser_id, colour=colour)
         self._agent_id = colour
 
     def __eq__(self, other):

@@ -425,6 +425,55 @@ for lvl in range(1, 7):
     case(f"obs_all_shapes_level_{lvl}", "python/tests/test_observations.py:509-518", level=lvl,
          script=[reset(), expect(obs_shape_formula=True, obs_consistent=True)])
 
+# --------------------------------------------------------------------------- round 2: the remaining on-path tests
+# (ops added for them: clone_check = World::clone / deepcopy -- a new world from the config + set_state(get_state()),
+#  world.rs:645-652, pyworld.rs:557-559; set_agent_position = pyworld.rs:282-299; colour = the BINDING's checked setter
+#  LaserSource.set_colour / agent_id, src/bindings/tiles/pylaser_source.rs:107-147, unlike op "source" which is the core
+#  LaserSource::set_agent_id)
+def clone_check():
+    return {"op": "clone_check"}
+
+
+def set_agent_position(agent, pos, **kw):
+    return {"op": "set_agent_position", "agent": agent, "pos": list(pos), **kw}
+
+
+def colour(laser_id, value, **kw):
+    return {"op": "colour", "laser_id": laser_id, "colour": value, **kw}
+
+
+case("clone_after_step", "src/unit_tests/test_world.rs:283-300", map=MAP_S0_G_X2,
+     script=[reset(), step([E]), step([E]), clone_check()])
+# tests/tile.rs:52-62 builds one Laser tile (colour 0, beam of 4) around a floor: it is on, and after reset walkable and
+# not occupied.  As a world: the agent below the first beam cell may walk NORTH onto it (walkable + not occupied).
+case("tile_laser_basic", "tests/tile.rs:52-62", map="L0E . . . . @\n .  S0 . . . X",
+     script=[reset(), expect(laser_colours=[[0, 1, 0]], lasers_on=[[0, 1, True], [0, 4, True]], beam_len={"0": 4},
+                             avail_includes=[[N]])])
+case("py_deepcopy", "python/tests/test_world.py:300-305", map="S0 . X", script=[clone_check()])
+case("py_deepcopy_not_initial_state", "python/tests/test_world.py:308-315", map="S0 . X",
+     script=[reset(), step([E]), clone_check()])
+case("py_set_agent_position", "python/tests/test_world.py:410-414", map="S0 . . X",
+     script=[x for j in range(4) for x in (set_agent_position(0, (0, j)), expect(positions=[[0, j]]))])
+case("py_set_wrong_agent_position", "python/tests/test_world.py:417-423", map="S0 . . X",
+     script=[set_agent_position(25, (0, 0), error="AgentIdOutOfBounds"),      # ValueError in the binding
+             set_agent_position(0, (0, 25), error="OutOfWorldPosition")])      # IndexError in the binding
+case("py_change_laser_colour_to_negative_colour", "python/tests/test_world.py:516-525", map="L0E S0 . X",
+     script=[reset(), colour(0, -1, error="OverflowError"), expect(derived_sources=[[0, 0, 0]])])
+# the binding sets the CORE colour before it checks the start positions (pylaser_source.rs:108-119 vs :121-139): the
+# refused change has recoloured the world, only the caller's snapshot keeps the old id (derived from the source)
+case("py_laser_colour_change_kills_agent_on_start", "python/tests/test_world.py:537-545", map="L0E X X S0 S1",
+     script=[reset(), colour(0, 1, error="ValueError"), expect(derived_sources=[[0, 0, 1]], derived_all_laser_colour=1)])
+case("py_change_laser_colour_to_invalid_colour", "python/tests/test_world.py:548-575", map="L0E S0 . X",
+     script=[reset(), colour(0, 2, error="ValueError"), colour(0, 1, error="ValueError"),
+             colour(0, 2, error="ValueError"), colour(0, 1, error="ValueError"),   # (again through the `agent_id` setter)
+             expect(derived_sources=[[0, 0, 0]])])                                  # refused before anything is set (:109-113)
+case("py_pickled_world_keeps_same_laser_ids", "python/tests/test_serialization.py:41-50", map="L0E L1S S0 S1 X X",
+     static={"sources": [[0, 0, 0], [0, 1, 1]]}, script=[clone_check()])
+# NOT transcribable: python/tests/test_world.py:751-762 (test_laser_on_start_pos_removed) and python/tests/test_env.py:144-180
+# (test_set_state) build their worlds from TOML with several / random start positions: v2 maps are out of scope
+# (SURVEY.md section 2 row 5).  Their v1 counterparts are py_laser_on_start_pos_error above and the get_state -> set_state
+# round trip of tests/test_gpu_env.py::test_set_state_round_trip_along_a_rollout.
+
 if __name__ == "__main__":
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kat_world.json")
     with open(out, "w") as f:

@@ -4,7 +4,10 @@ from the reference's python/tests/test_env.py.  Same rules as make_kat.py: each 
 
 Running this file rewrites tests/golden/kat_env.json.
 
-Script ops: {"op": "reset"} | {"op": "step", "actions": [...], "reward": r | [gem, exit, death, done] | null,
+Script ops: {"op": "expect", "done": bool | null, "available": [[actions of agent 0], ...] | null,
+             "derived_available": ...}  (LLE.done / LLE.available_actions as sets of Action values; `derived_` = computed by
+             the reference's code at that point but not asserted by its test)
+            {"op": "reset"} | {"op": "step", "actions": [...], "reward": r | [gem, exit, death, done] | null,
              "done": bool | null, "metrics": {"has-arrived": [...], "is-alive": [...]} | null}
             {"op": "set_state", "positions": [[i, j]...], "gems": [...], "alive": [...] | null}
             (set_state = LLE.set_state, python/lle/env/env.py:208-217: reward counters restart, World.set_state, the
@@ -61,6 +64,36 @@ case("multi_objective_rewards", "python/tests/test_env.py:258-284", "\n    S0 G 
      [reset, step([E], [1.0, 0, 0, 0]), step([E], [0, 0, 0, 0]), step([S], [0, EXIT, 0, DONE], True)], multi_objective=True)
 case("multi_objective_death", "python/tests/test_env.py:287-302", "\n    S0 L0S X\n    S1  G  X\n    ",
      [reset, step([STAY, E], [0, 0, DEATH, 0])], multi_objective=True)
+
+
+def expect(**kw):
+    return {"op": "expect", **kw}
+
+
+# ---- python/tests/test_core.py (round 2)
+MAP_CORE_AVAIL2 = """
+@   @ @  @  @ @ @
+@   . S0 S1 . . @
+@   . .  .  . . @
+L0E . .  .  . . @
+@   . .  .  . G @
+@   . X  X  . . @
+@   @ @  @  @ @ @"""
+# the reference asserts the mask after reset; inside its loop the check's result is dropped (test_core.py:63-70), so the
+# later masks are `derived_`: what LLE.available_actions returns there
+_mid = [[N, S, W, STAY], [N, S, E, STAY]]
+case("core_available_actions2", "python/tests/test_core.py:36-70", MAP_CORE_AVAIL2,
+     [reset, expect(available=[[S, W, STAY], [S, E, STAY]]),
+      step([S, S]), expect(derived_available=_mid), step([S, S]), expect(derived_available=_mid),
+      step([S, S]), expect(derived_available=_mid), step([S, S]), expect(derived_available=[[STAY], [STAY]])])
+case("core_move_end_game", "python/tests/test_core.py:144-161", "\n    S0 X .\n    .  . .\n    .  . .",
+     [reset, step([S], done=False), step([S], done=False), step([E], done=False), step([N], done=False), step([N], done=True)])
+case("core_force_end_state", "python/tests/test_core.py:164-175", "\n        S0 . G\n        X  . .\n    ",
+     [reset, {"op": "set_state", "positions": [[1, 0]], "gems": [True], "alive": None}, expect(done=True)])
+# the reference then expects ValueError from env.step: "Cannot step in a done environment" (env.py:166-167) -- agent 1
+# is revived by Agent::reset inside set_state, enters the lit beam of colour 0 and dies with an event (world.rs:571-579)
+case("core_force_state_agent_dies", "python/tests/test_core.py:178-192", "\n        S0 S1 G\n        X  . L0W\n        .  X  .\n    ",
+     [reset, {"op": "set_state", "positions": [[1, 0], [1, 1]], "gems": [False], "alive": [True, False]}, expect(done=True)])
 
 if __name__ == "__main__":
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kat_env.json")

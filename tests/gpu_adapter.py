@@ -81,3 +81,36 @@ class GpuWorld:
 
     def obs(self):
         return self.w.layered_observation()
+
+    # ---- binding-level operations: the product facade itself is under test here
+    def clone(self):
+        import copy
+        c = object.__new__(GpuWorld)
+        c.w = copy.deepcopy(self.w)  # PyWorld.__deepcopy__ = World::clone (pyworld.rs:557-559, world.rs:645-652)
+        assert c.w.agents_positions is not self.w.agents_positions
+        for name in ("height", "width", "n_agents", "n_gems", "n_sources", "start_pos", "exit_pos", "wall_pos", "void_pos", "gem_pos"):
+            setattr(c, name, getattr(self, name))
+        return c
+
+    def set_agent_position(self, agent, pos):
+        try:
+            ev = self.w.set_agent_position(agent, pos)
+        except IndexError:
+            raise KatError("OutOfWorldPosition") from None
+        except InvalidWorldStateError:
+            raise KatError("InvalidWorldState") from None
+        except ValueError as e:
+            assert "out of bounds" in str(e)
+            raise KatError("AgentIdOutOfBounds") from None
+        return [(e.event_type.value, e.agent_id) for e in ev]
+
+    def set_colour_checked(self, laser_id, colour):
+        src = self.w.laser_sources[laser_id]
+        before = src.agent_id
+        try:
+            src.set_colour(colour)
+        except OverflowError:
+            raise KatError("OverflowError") from None
+        except ValueError:
+            assert src.agent_id == before  # the caller's snapshot keeps the old id (pylaser_source.rs:141 is not reached)
+            raise KatError("ValueError") from None

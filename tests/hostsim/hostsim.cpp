@@ -250,11 +250,15 @@ void hs_set_sources(hs_batch* b, const uint8_t* colours, const uint32_t* enabled
     }
     for (int64_t env = 0; env < b->n; env++) {
         if (mask && !mask[env]) continue;
-        bool bad = false;
+        bool bad = false, crosses = false;
         if (colours)
-            for (int l = 0; l < L; l++) bad |= colours[env * L + l] >= A;
-        b->err[env] = bad ? ENV_INVALID_COLOUR : 0;
-        if (bad) continue;
+            for (int l = 0; l < L; l++) {
+                const int c = colours[env * L + l];
+                bad |= c >= A;
+                crosses |= c < A && !((h.colour_ok[l] >> c) & 1u);
+            }
+        b->err[env] = bad ? ENV_INVALID_COLOUR : (crosses ? ENV_COLOUR_CROSSES_START : 0);
+        if (bad || crosses) continue;
         const uint32_t lmask = L >= 32 ? 0xFFFFFFFFu : ((1u << L) - 1u);
         const uint32_t new_en = enabled ? (enabled[env] & lmask) : b->src_enabled[env];
         for (int l = 0; l < L; l++) {

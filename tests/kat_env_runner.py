@@ -1,7 +1,7 @@
 """Runs tests/golden/kat_env.json (the reference's LLE-level tests) against an adapter.
 
 Adapter protocol: reset(); step(actions) -> (reward float32 array [1] or [4], done bool); set_state(positions, gems, alive);
-metrics() -> {"has-arrived": [...], "is-alive": [...]}."""
+metrics() -> {"has-arrived": [...], "is-alive": [...]}; done() -> bool; available() -> bool array [A, 5]."""
 import json
 import os
 
@@ -33,5 +33,14 @@ def run_case(make_adapter, case):
                 assert bool(done) == op["done"], f"{name} op {k}: done {done}"
             if op["metrics"] is not None:
                 assert ad.metrics() == op["metrics"], f"{name} op {k}: {ad.metrics()}"
+        elif op["op"] == "expect":
+            if op.get("done") is not None:
+                assert bool(ad.done()) == op["done"], f"{name} op {k}: done {ad.done()}"
+            for key in ("available", "derived_available"):
+                if op.get(key) is not None:
+                    want = np.zeros((len(op[key]), 5), dtype=bool)
+                    for a, acts in enumerate(op[key]):
+                        want[a, acts] = True
+                    assert np.array_equal(np.asarray(ad.available(), dtype=bool), want), f"{name} op {k}: {key} {ad.available()}"
         else:
             raise ValueError(op)

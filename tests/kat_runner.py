@@ -171,7 +171,7 @@ def check_expect(w, ex, derived):
             for lid, bits in val.items():
                 assert w.beam_bits(int(lid)) == bits, (w.beam_bits(int(lid)), bits)
         elif k == "sources":
-            assert [(s[0], s[1], s[3]) for s in w.sources()] == _pairs(val)
+            assert [(s[0], s[1], s[3]) for s in w.sources()] == _pairs(val), (w.sources(), val)
         elif k == "sources_enabled":
             got = {(s[0], s[1]): bool(s[4]) for s in w.sources()}
             for (i, j, en) in val:
@@ -213,6 +213,46 @@ def check_events(ev, spec, derived):
         assert Counter(ev) == Counter(_pairs(spec["event_multiset"])), ev
     if derived and "derived_events" in spec:
         assert ev == _pairs(spec["derived_events"]), (ev, spec["derived_events"])
+
+
+class KatBindingError(Exception):
+    def __init__(self, kind):
+        super().__init__(kind)
+        self.kind = kind
+
+
+def _generic_clone(make, case, w):
+    c = make(map_str=case.get("map"), level=case.get("level"))
+    for k, s in enumerate(w.sources()):  # the config carries the sources' current colour / enabled flag
+        c.set_source(k, enabled=bool(s[4]), colour=s[3])
+    c.set_state(w.positions(), w.gems_collected(), w.alive())
+    return c
+
+
+def _binding_set_colour(w, laser_id, colour):
+    """PyLaserSource.set_agent_id (src/bindings/tiles/pylaser_source.rs:107-141) on the core surface: usize conversion,
+    colour < n_agents, the CORE colour is set (:114-119), and only then the beam (the tiles World::lasers() exposes for this
+    laser id) is checked against the possible starts of every OTHER agent (:121-139)."""
+    if colour < 0:
+        raise KatBindingError("OverflowError")
+    if colour >= w.n_agents:
+        raise KatBindingError("ValueError")
+    w.set_source(laser_id, colour=colour)
+    cells = {(l[0], l[1]) for l in w.lasers() if l[2] == laser_id}
+    for agent, start in enumerate(w.start_pos):
+        if agent != colour and tuple(start) in cells:
+            raise KatBindingError("ValueError")
+
+
+def _set_agent_position(w, agent, pos):
+    """PyWorld.set_agent_position (pyworld.rs:282-299): id check, then set_state(get_state() with one position replaced)."""
+    if hasattr(w, "set_agent_position"):
+        return w.set_agent_position(agent, pos)
+    if agent >= w.n_agents:
+        raise KatBindingError("AgentIdOutOfBounds")
+    positions = [tuple(p) for p in w.positions()]
+    positions[agent] = pos
+    return w.set_state(positions, w.gems_collected(), w.alive())
 
 
 def run_case(make, case, derived=True):
@@ -258,6 +298,32 @@ def run_case(make, case, derived=True):
                 check_events(w.set_state(op["positions"], op["gems"], op["alive"]), op, derived)
         elif kind == "source":
             w.set_source(op["laser_id"], enabled=op.get("enabled"), colour=op.get("colour"))
+        elif kind == "clone_check":
+            # World::clone (world.rs:645-652) = a new world from the config + set_state(get_state()); deepcopy is clone
+            c = w.clone() if hasattr(w, "clone") else _generic_clone(make, case, w)
+            assert _pairs(c.positions()) == _pairs(w.positions()) and c.n_gems_collected() == w.n_gems_collected()
+            assert (c.width, c.height) == (w.width, w.height)
+            assert [(s[0], s[1], s[2], s[3]) for s in c.sources()] == [(s[0], s[1], s[2], s[3]) for s in w.sources()]
+            if derived:
+                assert (c.alive(), c.gems_collected(), c.arrived()) == (w.alive(), w.gems_collected(), w.arrived())
+                before = (w.positions(), w.alive(), w.gems_collected())
+                c.step([a[-1] for a in c.available_actions()])  # the clone moves on; the original must not
+                assert (w.positions(), w.alive(), w.gems_collected()) == before
+        elif kind == "set_agent_position":
+            try:
+                _set_agent_position(w, op["agent"], tuple(op["pos"]))
+            except Exception as e:  # noqa: BLE001
+                assert "error" in op and _kind(e) in op["error"].split("|"), (_kind(e), op.get("error"))
+            else:
+                assert "error" not in op, f"expected {op.get('error')}"
+        elif kind == "colour":
+            try:
+                (w.set_colour_checked if hasattr(w, "set_colour_checked") else
+                 lambda lid, c: _binding_set_colour(w, lid, c))(op["laser_id"], op["colour"])
+            except Exception as e:  # noqa: BLE001
+                assert "error" in op and _kind(e) in op["error"].split("|"), (_kind(e), op.get("error"))
+            else:
+                assert "error" not in op, f"expected {op.get('error')}"
         elif kind == "expect":
             check_expect(w, op, derived)
         else:

@@ -108,3 +108,26 @@ def _add_generated():
 
 
 _add_generated()
+
+
+def legal_colours(maps, colours):
+    """Random per-env source colours made acceptable to lle_batch_set_sources: a colour that would put another agent's start
+    on the source's beam (refused with LLE_ENV_COLOUR_CROSSES_START, like the binding's LaserSource.set_colour,
+    pylaser_source.rs:121-139) is replaced by the colour the map gives that source.  `maps`: a Map / map text, or the list
+    of a multi-map batch (map m owns the m-th block of envs).  `colours`: numpy or torch [n, L]; same type comes back."""
+    import torch
+
+    from lle_amd import _capi
+    maps = maps if isinstance(maps, (list, tuple)) else [maps]
+    maps = [m if isinstance(m, _capi.Map) else _capi.Map(m) for m in maps]
+    is_torch = isinstance(colours, torch.Tensor)
+    arr = colours.cpu().numpy().copy() if is_torch else np.array(colours, copy=True)
+    n, L = arr.shape
+    per = n // len(maps)
+    for k, m in enumerate(maps):
+        block = arr[k * per:(k + 1) * per]
+        for s in m.sources():
+            for c in range(m.n_agents):
+                if not m.colour_allowed(s.laser_id, c):
+                    block[block[:, s.laser_id] == c, s.laser_id] = s.agent_id
+    return torch.from_numpy(arr).to(colours.device) if is_torch else arr

@@ -154,3 +154,22 @@ def test_row_alignment_is_validated_and_must_agree_inside_a_batch():
     assert b"row alignment" in L.lle_last_error()
     b.set_row_align(128)
     assert L.lle_batch_arena_bytes_multi((C.c_void_p * 2)(a.h, b.h), 2, 64) > 0
+
+
+def test_world_state_hash_eq_and_pickle():
+    """python/tests/test_world.py:393-407 (hash / eq of hand-built states, dead flag included) and
+    python/tests/test_serialization.py:9-16 (50 random WorldStates survive pickle)."""
+    import pickle
+    import random
+
+    from lle_amd import WorldState
+
+    s1, s2 = WorldState([(0, 0)], [False], [True]), WorldState([(0, 0)], [False], [False])
+    assert hash(s1) != hash(s2) and s1 != s2                      # test_world_state_hash_eq_dead
+    s1, s2 = WorldState([(0, 0)], [False]), WorldState([(0, 1)], [False])
+    assert hash(s1) != hash(s2) and s1 != s2                      # test_world_state_hash_neq
+    rng = random.Random(0)
+    for _ in range(50):                                           # test_pickle_world_state
+        s = WorldState(gems_collected=[rng.choice([True, False]) for _ in range(rng.randint(0, 10))],
+                       agents_positions=[(rng.randint(0, 50), rng.randint(0, 90)) for _ in range(rng.randint(0, 10))])
+        assert pickle.loads(pickle.dumps(s)) == s

@@ -5,7 +5,7 @@ import pytest
 
 from oracle.levels import LEVELS
 from tests.oracle_env import OracleLLE
-from tests.parity_util import EXTRA_MAPS
+from tests.parity_util import EXTRA_MAPS, legal_colours
 
 pytestmark = pytest.mark.gpu
 
@@ -54,7 +54,7 @@ def test_batched_lle_matches_per_env_restatement(oracle_mod, name, kw, randomize
             for e in range(n):
                 assert np.array_equal(r[e], rewards[e]), f"{where} reward env {e}: {r[e]} != {rewards[e]}"
 
-    colours = torch.from_numpy(rng.integers(0, A, size=(n, L), dtype=np.uint8)) if randomize else None
+    colours = torch.from_numpy(legal_colours(text, rng.integers(0, A, size=(n, L), dtype=np.uint8))) if randomize else None
     env.reset(colours=colours)
     for e in range(n):
         refs[e].reset(None if colours is None else colours[e].numpy())
@@ -63,7 +63,7 @@ def test_batched_lle_matches_per_env_restatement(oracle_mod, name, kw, randomize
         # finished envs are reset first (auto_reset), with fresh colours when lasers are randomised
         done = env.done.cpu().numpy()
         if randomize:
-            colours = torch.from_numpy(rng.integers(0, A, size=(n, L), dtype=np.uint8))
+            colours = torch.from_numpy(legal_colours(text, rng.integers(0, A, size=(n, L), dtype=np.uint8)))
             env.reset(env_mask=torch.from_numpy(done.astype(np.uint8)), colours=colours)
         for e in np.nonzero(done)[0]:
             refs[e].reset(None if not randomize else colours[e].numpy())
@@ -118,6 +118,16 @@ class _BatchedAdapter:
         return {"has-arrived": [bool(x) for x in self.env.agents_arrived()[-1].cpu().numpy()],
                 "is-alive": [bool(x) for x in self.env.agents_alive()[-1].cpu().numpy()]}
 
+    def done(self):
+        d = self.env.done.cpu().numpy()
+        assert d[0] == d[-1]
+        return bool(d[-1])
+
+    def available(self):
+        a = self.env.available_actions().cpu().numpy()
+        assert np.array_equal(a[0], a[-1])
+        return a[-1]
+
 
 @pytest.mark.parametrize("case", ENV_CASES, ids=[c["name"] for c in ENV_CASES])
 def test_batched_lle_env_kat(case):
@@ -139,7 +149,7 @@ def test_env_outputs_equals_separate_entry_points(name, per_env):
     A, G = w.map.n_agents, w.map.n_gems
     if per_env:
         g = torch.Generator(device="cuda").manual_seed(3)
-        w.set_sources(colours=torch.randint(0, A, (n, w.map.n_sources), generator=g, device="cuda").to(torch.uint8))
+        w.set_sources(colours=legal_colours(w.map, torch.randint(0, A, (n, w.map.n_sources), generator=g, device="cuda").to(torch.uint8)))
     for t in range(25):
         w.step(sample=True, auto_reset=(t % 5 == 4), seed=17, t=t)
         for normalize in (False, True):
@@ -163,3 +173,90 @@ def test_env_outputs_equals_separate_entry_points(name, per_env):
     only = torch.empty((n, 1), device="cuda")
     w.env_outputs(reward=only)
     assert torch.equal(only, w.reward_single_objective().unsqueeze(1))
+
+
+# ---- python/tests/test_env.py:381-430: randomize_lasers (the reference's only pins of per-env source colours)
+MAP_RANDOMIZED = "S0 S1 L0S\n.   . L1W\n.   . L0W\nX   X  ."
+
+
+def test_randomized_lasers_reach_every_colour_and_refresh_the_source_markers():
+    """test_randomized_lasers (:381-400): over repeated resets every source takes every colour.  
+    test_randomized_lasers_updates_static_observation_layer (:403-430): after EVERY reset the layered observation holds -1
+    at each source's cell on layer LASER_0 + the colour the source has now.  A batch draws a colour per env and source."""
+    import torch
+
+    from lle_amd import BatchedLLE
+
+    n = 1024
+    env = BatchedLLE(MAP_RANDOMIZED, n, obs_type="layered", randomize_lasers=True, seed=3)
+    A, sources = env.n_agents, env.world.map.sources()
+    L = len(sources)
+    seen = torch.zeros(L, A, dtype=torch.bool)
+    rows = torch.arange(n, device="cuda")
+    for _ in range(50):
+        obs, _state = env.reset()
+        colours = env.world.src_colour[:, :L].long()
+        assert int(colours.min()) >= 0 and int(colours.max()) < A
+        for l, s in enumerate(sources):
+            for c in range(A):
+                seen[l, c] |= bool((colours[:, l] == c).any())
+            assert bool((obs[rows, A + colours[:, l], s.i, s.j] == -1).all()), f"source {l}: marker missing"
+            # ... and on no other laser layer of that cell (a stale marker of the previous episode's colour)
+            others = obs[:, A:2 * A, s.i, s.j].clone()
+            others[rows, colours[:, l]] = 0
+            assert int(others.abs().sum()) == 0, f"source {l}: stale marker"
+    assert bool(seen.all()), seen
+    # the single-env restatement of the same loop through lle_amd.World (the facade the reference's LLE wraps)
+    from lle_amd import World
+    import random
+    rng = random.Random(0)
+    w = World(MAP_RANDOMIZED)
+    encountered = [[False] * w.n_agents for _ in w.laser_sources]
+    for _ in range(60):
+        w.reset()
+        for source in w.laser_sources:
+            source.set_colour(rng.randint(0, w.n_agents - 1))
+        for source in w.laser_sources:
+            encountered[source.laser_id][source.agent_id] = True
+    assert all(all(ce) for ce in encountered)
+
+
+def test_envs_of_a_batch_are_independent_copies():
+    """python/tests/test_core.py:127-141 (test_deep_copy): a copy of an env must not finish when the original does.
+    In a batch the copies are the environments: one walks onto the exit, its neighbour stays."""
+    import torch
+
+    from lle_amd import BatchedLLE
+
+    env = BatchedLLE("S0 X", 2)
+    env.reset()
+    out = env.step(torch.tensor([[2], [4]], dtype=torch.uint8))  # EAST | STAY
+    assert out["done"].tolist() == [True, False]
+    out = env.step(torch.tensor([[4], [2]], dtype=torch.uint8))
+    assert out["done"].tolist() == [True, True]
+
+
+def test_set_state_round_trip_along_a_rollout(oracle_mod):
+    """python/tests/test_env.py:144-180 (test_set_state): every state visited by a random rollout (resets at episode ends
+    included), handed back through LLE.set_state, is the state the world then reports.  The reference runs it on a
+    laser-free TOML map with random spawns (v2 maps: out of scope); same property on a laser-free v1 map, and on
+    level 6 for the states whose re-derivation is lossless (no agent dead: quirk Q6 covers the others)."""
+    import torch
+
+    from lle_amd import BatchedLLE
+
+    for text, only_alive in (("S0 . . G X\nS1 . @ . X\n.  G . . .\nS2 . . G X", False), (LEVELS[6], True)):
+        n = 128
+        env, probe = BatchedLLE(text, n, state_type="state"), BatchedLLE(text, n, state_type="state")
+        env.reset()
+        probe.reset()
+        A, G = env.n_agents, env.world.map.n_gems
+        for t in range(60):
+            env.world.step(sample=True, auto_reset=True, seed=4, t=t)
+            pos, gems, alive = env.world.pos.clone(), env.world.gems_collected(), env.world.agents_alive()
+            err = probe.set_state(pos, gems, alive)
+            ok = alive.all(dim=1) if only_alive else torch.ones(n, dtype=torch.bool, device="cuda")
+            assert int(err[ok].max()) == 0, f"t={t}"
+            assert torch.equal(probe.world.pos[ok], pos[ok]) and torch.equal(probe.world.gems_collected()[ok], gems[ok])
+            assert torch.equal(probe.world.agents_alive()[ok], alive[ok])
+            assert torch.equal(probe.get_state()[ok], env.get_state()[ok])

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle.levels import LEVELS
-from tests.parity_util import EXTRA_MAPS, assert_state_equal, assert_step_equal, unpack_engine
+from tests.parity_util import EXTRA_MAPS, assert_state_equal, assert_step_equal, legal_colours, unpack_engine
 
 pytestmark = pytest.mark.gpu
 
@@ -71,7 +71,7 @@ def test_random_colours_and_flags_per_env(oracle_mod, name):
             ostep = ob.step(None, auto_reset=auto, seed=21, t=t, env_offset=5)
             check(bw, ob, ostep, f"{name} episode {episode} t={t}")
             t += 1
-        colours = rng.integers(0, A, size=(n, L), dtype=np.uint8)
+        colours = legal_colours(bw.map, rng.integers(0, A, size=(n, L), dtype=np.uint8))
         enabled = rng.integers(0, 1 << L, size=n, dtype=np.int64).astype(np.int32) if episode != 2 else None
         mask = (rng.random(n) < 0.7).astype(np.uint8) if episode != 0 else None
         bw.set_sources(torch.from_numpy(colours), None if enabled is None else torch.from_numpy(enabled),
@@ -131,7 +131,7 @@ def test_other_builders_and_modes_with_per_env_sources(oracle_mod):
     A, L = ob.A, bw.map.n_sources
     mirror = Mirror(ob, n, L)
     rng = np.random.default_rng(3)
-    colours = rng.integers(0, A, size=(n, L), dtype=np.uint8)
+    colours = legal_colours(bw.map, rng.integers(0, A, size=(n, L), dtype=np.uint8))
     enabled = rng.integers(0, 1 << L, size=n).astype(np.int32)
     bw.set_sources(torch.from_numpy(colours), torch.from_numpy(enabled))
     mirror.apply(colours, enabled)
@@ -217,7 +217,7 @@ def test_reset_sources_equals_reset_then_set_sources(name):
         for t in range(4):
             for w in (a, b):
                 w.step(sample=True, auto_reset=False, seed=5, t=4 * rnd + t)
-        colours = torch.randint(0, A, (n, L), generator=g, device="cuda", dtype=torch.uint8)
+        colours = legal_colours(a.map, torch.randint(0, A, (n, L), generator=g, device="cuda", dtype=torch.uint8))
         if rnd % 3 == 1:
             colours[::7, 0] = A + 1  # refused envs: reset all the same, sources unchanged
         enabled = torch.randint(0, 1 << L, (n,), generator=g, device="cuda", dtype=torch.int32) if rnd % 2 else None
@@ -256,3 +256,28 @@ def test_reset_sources_without_observation_then_step():
             a.step(sample=True, seed=1, t=3 * rnd + t)
             b.step(sample=True, seed=1, t=3 * rnd + t)
             assert torch.equal(a.obs, b.obs), (rnd, t)
+
+
+def test_colour_that_crosses_a_start_is_refused_per_env(oracle_mod):
+    """The start check of the binding's LaserSource.set_colour (pylaser_source.rs:121-139; python/tests/test_world.py:537-545):
+    such an env keeps its sources and gets LLE_ENV_COLOUR_CROSSES_START; BatchedLLE(randomize_lasers=True) refuses the map."""
+    import torch
+
+    from lle_amd import BatchedLLE, BatchedWorld, _capi
+
+    text = "L0E X X . S0\n@ @ @ S1 ."       # S0 on the beam of source 0: only colour 0 is acceptable
+    n = 64
+    ob = oracle_mod.OracleBatch(text, n)
+    bw = BatchedWorld(text, n)
+    colours = np.zeros((n, 1), np.uint8)
+    colours[3::5, 0] = 1
+    bw.set_sources(torch.from_numpy(colours))
+    err = bw.err.cpu().numpy()
+    assert np.array_equal(err, np.where(colours[:, 0] == 1, _capi.LLE_ENV_COLOUR_CROSSES_START, 0))
+    check(bw, ob, None, "refused envs untouched, accepted ones keep colour 0")
+    for t in range(6):
+        bw.step(sample=True, seed=3, t=t)
+        check(bw, ob, ob.step(None, seed=3, t=t), f"t={t}")
+    with pytest.raises(ValueError, match="cross the start position"):
+        BatchedLLE(text, n, randomize_lasers=True)
+    BatchedLLE(LEVELS[6], n, randomize_lasers=True)  # no beam over a start: fine

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from tests.observer_checks import compare_all
-from tests.parity_util import assert_state_equal, assert_step_equal, unpack_engine
+from tests.parity_util import assert_state_equal, assert_step_equal, legal_colours, unpack_engine
 
 pytestmark = pytest.mark.gpu
 
@@ -102,7 +102,7 @@ def test_observers_and_per_env_sources_on_blocks_of_maps(oracle_mod):
     # per-environment sources on top: random colours / flags for every env of every map
     A, L = obs[0].A, bw.map.n_sources
     rng = np.random.default_rng(2)
-    colours = rng.integers(0, A, size=(n, L), dtype=np.uint8)
+    colours = legal_colours(bw.maps, rng.integers(0, A, size=(n, L), dtype=np.uint8))
     enabled = rng.integers(0, 1 << L, size=n).astype(np.int32)
     bw.set_sources(torch.from_numpy(colours), torch.from_numpy(enabled))
     for m, ob in enumerate(obs):
@@ -147,7 +147,7 @@ def test_env_outputs_on_blocks_of_maps():
     g = torch.Generator(device="cuda").manual_seed(1)
     for rnd in range(2):
         if rnd == 1:
-            w.set_sources(colours=torch.randint(0, A, (n, L), generator=g, device="cuda", dtype=torch.uint8))
+            w.set_sources(colours=legal_colours(w.maps, torch.randint(0, A, (n, L), generator=g, device="cuda", dtype=torch.uint8)))
         for t in range(12):
             w.step(sample=True, auto_reset=(t % 4 == 3), seed=8, t=12 * rnd + t)
             for walkable in (False, True):

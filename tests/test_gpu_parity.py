@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle.levels import LEVELS
-from tests.parity_util import EXTRA_MAPS, assert_state_equal, assert_step_equal, unpack_engine
+from tests.parity_util import EXTRA_MAPS, assert_state_equal, assert_step_equal, legal_colours, unpack_engine
 
 pytestmark = pytest.mark.gpu
 
@@ -437,7 +437,7 @@ def test_rollout_with_rings_equals_steps_in_every_general_mode(name, mode):
     L, A = a.map.n_sources, a.map.n_agents
     if mode.endswith("per_env_sources") and L > 0:
         g = torch.Generator(device="cuda").manual_seed(5)
-        colours = torch.randint(0, A, (n, L), generator=g, device="cuda", dtype=torch.uint8)
+        colours = legal_colours(a.maps, torch.randint(0, A, (n, L), generator=g, device="cuda", dtype=torch.uint8))
         enabled = torch.randint(0, 1 << min(L, 30), (n,), generator=g, device="cuda", dtype=torch.int32)
         for w in (a, b):
             w.set_sources(colours=colours, enabled=enabled)
