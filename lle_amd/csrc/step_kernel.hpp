@@ -3,6 +3,7 @@
 // in parallel; kernels.hip holds world_kernel and the host-side launch logic.
 #pragma once
 #include "kernel_common.hpp"
+#include "step_lanes.hpp"
 
 namespace lle {
 
@@ -24,36 +25,6 @@ namespace lle {
 //     independent; their events are ordered by agent id = lane order (prefix count inside the group);
 //   * the three loops stay in the reference's order, and passes repeat while any agent of the environment died.
 // Cross-lane traffic is DPP quad permutes (G <= 4) / ds_swizzle (G = 8, 16); nothing goes through memory.
-
-template <int J>
-__device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
-    static_assert(J >= 1 && J < 16, "group offsets only");
-    if (J == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
-    if (J == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
-    if (J == 3) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x1B, 0xF, 0xF, true);  // quad_perm [3,2,1,0]
-    return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (J << 10));                     // lane ^ J within 32 lanes
-}
-template <int G>
-__device__ __forceinline__ uint32_t grp_or(uint32_t v) {
-    if (G > 1) v |= lane_xor<1>(v);
-    if (G > 2) v |= lane_xor<2>(v);
-    if (G > 4) v |= lane_xor<4>(v);
-    if (G > 8) v |= lane_xor<8>(v);
-    return v;
-}
-template <int G>
-__device__ __forceinline__ uint64_t grp_or64(uint64_t v) {
-    return (uint64_t)grp_or<G>((uint32_t)v) | ((uint64_t)grp_or<G>((uint32_t)(v >> 32)) << 32);
-}
-
-// value of `v` in the group lane whose agent id is (a ^ J), for every J in 1..G-1, fed to f(other_agent_offset J, value)
-template <int G, int J = 1, typename F>
-__device__ __forceinline__ void for_each_other(uint32_t v, F&& f) {
-    if constexpr (J < G) {
-        f(J, lane_xor<J>(v));
-        for_each_other<G, J + 1>(v, f);
-    }
-}
 
 // GEN: the general instantiations -- environments with their own source colours / enabled flags (lle_batch_set_sources)
 // and/or batches of several maps (lle_batch_create_multi).  Separate instantiations, so that the default path (one
@@ -122,7 +93,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
 #pragma unroll
     for (int b = 0; b < LM; b++) h_init_beams[b] = (b < L) ? initp->beams[b] : 0u;
     const int64_t n_here = (K.env_limit - env0) < (int64_t)EPW ? (K.env_limit - env0) : (int64_t)EPW;
-    const uint32_t bit = 1u << a, amask = (1u << A) - 1u;
+    const uint32_t amask = (1u << A) - 1u;
     LLE_STAMP(0);
 
     // (split rows: the pristine static observation stays in global memory, every wavefront copies its slice from there)
@@ -271,123 +242,13 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         act = (uint32_t)P.actions[env * As + a];
     }
 
-    // ---- availability check (world.rs:444-453): lowest offending agent, before any mutation.  The cached list can
-    // only disagree with the static walk mask after a failed set_state left it stale; such an action is refused.
-    const uint32_t cur_cell = me ? cell_of(pos, W) : 0u;
-    uint64_t lay_cur = cell_lay[cur_cell];
-    if (PES) lay_cur = recolour_lay<CWM>(lay_cur, colw);
-    const uint32_t meta_cur = cell_meta[cur_cell];
-    const uint32_t walk_cur = ((meta_cur >> 8) & 15u) | 16u;
-    const bool bad = me && (act > 4u || !(((avail & walk_cur) >> (act & 7u)) & 1u));
-    const uint32_t badmask = grp_or<G>(bad ? bit : 0u);
-    const uint32_t err = badmask ? (uint32_t)__ffs((int)badmask) : 0u;
-
+    // ---- World.step for the lanes of this environment: availability check, vertex conflicts, move_agents passes
+    // (step_lanes.hpp: the same source runs on the host under sanitizers, tests/hostsim)
     uint64_t evw[NW];
-#pragma unroll
-    for (int k = 0; k < NW; k++) evw[k] = 0;
-    uint32_t n_ev = 0;
-    uint32_t meta_step = 0;   // cell meta of the agent's new cell, for the availability mask computed in post_step()
-    bool stepped = false;
-
-    if (env_ok && err == 0) {
-        // target cell (src/action.rs:18-26 on the packed i | j << 8 form); lanes without an agent keep a unique sentinel
-        uint32_t np = me ? apply_action(pos, act) : pos;
-        // solve_vertex_conflicts (world.rs:365-378): every agent whose target is shared goes back to its cell
-        bool again = true;
-        while (__any(again)) {
-            bool dup = false;
-            for_each_other<G>(np, [&](int, uint32_t other) { dup |= (other == np); });
-            np = dup ? pos : np;
-            again = grp_or<G>(dup ? 1u : 0u) != 0;
-        }
-        const uint32_t new_cell = me ? cell_of(np, W) : 0u;
-        uint64_t lay_new = cell_lay[new_cell];
-        if (PES) lay_new = recolour_lay<CWM>(lay_new, colw);
-        const uint32_t meta_new = cell_meta[new_cell];
-        const uint32_t kind = meta_new & 7u;
-        const uint32_t gbit = 1u << ((meta_new >> 3) & 31u);
-
-        // move_agents passes (world.rs:464-472)
-        bool go = true;
-        bool first_pass = true;
-        uint64_t lay_from = lay_cur;  // pass 1 leaves the old cells, later passes the new ones
-        while (__any(go)) {
-            // leave (laser.rs:199-202,157-162): what the alive agents of the env re-light, per beam
-            const uint32_t alive0 = alive;
-            const bool me_alive = go && me && (alive0 & bit);
-            uint32_t lit[LM], any_lit = 0;
-#pragma unroll
-            for (int b = 0; b < LM; b++) {
-                lit[b] = 0;
-                if (b < L) {
-                    uint32_t light = 0;
-                    for (uint32_t k = 0; k < max_layers; k++) {
-                        const uint32_t eo = (uint32_t)(lay_from >> (16 * k)) & 0xFFFFu;
-                        const bool lo = me_alive && (eo & LAY_VALID) && ((eo >> 1) & 31u) == (uint32_t)b &&
-                                        !((beams[b] >> ((eo >> 6) & 31u)) & 1u);
-                        light |= lo ? (0xFFFFFFFFu << ((eo >> 6) & 31u)) : 0u;
-                    }
-                    lit[b] = grp_or<G>(((enabled >> b) & 1u) ? light : 0u);
-                    any_lit |= lit[b];
-                }
-            }
-            // A pass after the first one leaves and re-enters the SAME cells.  If no alive agent re-lights anything, the
-            // beams cannot change (the owners' cuts are repeated as they are), so every enter repeats its outcome: alive
-            // agents stay alive, occupants / arrivals / gems are already recorded, the dead stay blocked or buried.
-            // The pass is then a no-op and `while agent_died` ends (world.rs:468-472).
-            if (!first_pass && any_lit == 0u) go = false;
-            if (go) {
-                occ &= ~alive0;  // Tile::leave: slot.take() for every alive agent
-#pragma unroll
-                for (int b = 0; b < LM; b++) {
-                    if (b < L) {
-                        uint32_t keep = 0xFFFFFFFFu;
-                        for (uint32_t k = 0; k < max_layers; k++) {
-                            const uint32_t en = (uint32_t)(lay_new >> (16 * k)) & 0xFFFFu;   // pre_enter (laser.rs:173-182)
-                            const bool pe = me_alive && (en & LAY_VALID) && ((en >> 1) & 31u) == (uint32_t)b && (en >> 11) == a;
-                            keep &= pe ? ((1u << ((en >> 6) & 31u)) - 1u) : 0xFFFFFFFFu;
-                        }
-                        const uint32_t cut = grp_or<G>(((enabled >> b) & 1u) ? ~keep : 0u);
-                        beams[b] = (beams[b] | lit[b]) & ~cut;
-                    }
-                }
-                // enter (tile.rs:29-50, laser.rs:184-197)
-                bool blocked = false;
-                for (uint32_t k = 0; k < max_layers; k++) {
-                    const uint32_t en = (uint32_t)(lay_new >> (16 * k)) & 0xFFFFu;
-                    const uint32_t m = beam_get<LM>(beams, (en >> 1) & 31u);
-                    blocked |= (en & LAY_VALID) && ((m >> ((en >> 6) & 31u)) & 1u) && ((en >> 11) != a);
-                }
-                const bool is_alive = (alive & bit) != 0;
-                const bool inner = me && !blocked;
-                const bool ev_exit = inner && kind == K_EXIT && !(arrived & bit);
-                const bool ev_gem = inner && kind == K_GEM && !(gems & gbit);
-                const bool died = me && is_alive && (blocked || kind == K_VOID);
-                const bool has_ev = died || ev_exit || ev_gem;
-                const uint32_t p1 = grp_or<G>((died ? bit : 0u) | (ev_exit ? bit << 16 : 0u));
-                const uint32_t p2 = grp_or<G>((inner ? bit : 0u) | (has_ev ? bit << 16 : 0u));
-                gems |= grp_or<G>(ev_gem ? gbit : 0u);
-                alive &= ~(p1 & 0xFFFFu);
-                arrived |= p1 >> 16;
-                occ |= p2 & 0xFFFFu;
-                const uint32_t evmask = p2 >> 16;  // agents with an event this pass: ordered by agent id
-                const uint32_t slot = n_ev + (uint32_t)__popc(evmask & (bit - 1u));
-                const uint64_t byte = has_ev ? (uint64_t)(((died ? EV_DIED : (ev_gem ? EV_GEM : EV_EXIT)) << 4) | a) : 0ull;
-#pragma unroll
-                for (int k = 0; k < NW; k++) evw[k] |= (NW == 1 || (slot >> 3) == (uint32_t)k) ? (byte << ((slot & 7u) * 8u)) : 0ull;
-                n_ev += (uint32_t)__popc(evmask);
-                go = (p1 & 0xFFFFu) != 0;  // while agent_died
-            }
-            lay_from = lay_new;
-            first_pass = false;
-        }
-        pos = np;
-#pragma unroll
-        for (int b = 0; b < LM; b++)
-            if (b < L) beams[b] &= h_beam_full[b];
-        meta_step = meta_new;
-        stepped = true;
-    }
+    uint32_t n_ev, meta_step, err;
+    bool stepped;
+    step_lanes<G, LM, ML1, PES, CWM>(cell_lay, cell_meta, A, L, W, max_layers, h_beam_full, a, me, env_ok, enabled, colw, act, pos, avail,
+                                     alive, arrived, occ, gems, beams, err, evw, n_ev, meta_step, stepped);
     LLE_STAMP(3);
 
     // ---- everything of the step that the observation does not need: availability masks (compute_available_actions,
@@ -396,19 +257,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     // the one whose first store ends the idle time of the memory system) does this after its stream, a younger one --
     // which waits for memory anyway and would otherwise add it to the end of the launch -- before.
     auto post_step = [&]() {
-    if (stepped) {
-        const bool can_move = me && (alive & bit) && !(arrived & bit);
-        uint32_t blocked_dirs = 0;
-        for_each_other<G>(pos, [&](int j, uint32_t other) {
-            const int d = (int)other - (int)pos;
-            uint32_t hit = (d == -1) ? 1u : 0u;
-            hit |= (d == 1) ? 2u : 0u;
-            hit |= (d == 256) ? 4u : 0u;
-            hit |= (d == -256) ? 8u : 0u;
-            blocked_dirs |= ((occ >> (a ^ (uint32_t)j)) & 1u) ? hit : 0u;
-        });
-        avail = 16u | (can_move ? (((meta_step >> 8) & 15u) & ~blocked_dirs) : 0u);
-    }
+    if (stepped) avail_lanes<G>(a, me, pos, occ, alive, arrived, meta_step, avail);
 #pragma unroll
     for (int k = 0; k < NW; k++) evw[k] = grp_or64<G>(evw[k]);
     if (env_ok && a == 0) {

@@ -11,7 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 _LIB = os.path.join(_HERE, "libhostsim.so")
 _SRCS = [os.path.join(_HERE, "hostsim.cpp"), os.path.join(_ROOT, "lle_amd", "csrc", "map_compile.cpp")]
-_DEPS = _SRCS + [os.path.join(_ROOT, "lle_amd", "csrc", f) for f in ("step_logic.hpp", "observers_logic.hpp", "tables.h", "map_compile.hpp")]
+_DEPS = _SRCS + [os.path.join(_ROOT, "lle_amd", "csrc", f) for f in ("step_logic.hpp", "step_lanes.hpp", "observers_logic.hpp", "tables.h", "map_compile.hpp")]
+ENGINES = {"env": 0, "lanes": 1, "lanes_no_shortcut": 2}
+DEFAULT_ENGINE = ["env"]  # tests/test_hostsim_lanes.py reruns the CPU suites with "lanes": the step_kernel restatement
 
 
 def build():
@@ -30,6 +32,9 @@ def lib():
         L.hs_create.restype = C.c_void_p
         L.hs_create.argtypes = [C.c_char_p, C.c_int64, C.POINTER(C.c_int)]
         L.hs_free.argtypes = [C.c_void_p]
+        L.hs_set_engine.argtypes = [C.c_void_p, C.c_int]
+        L.hs_lane_passes.restype = C.c_int64
+        L.hs_lane_passes.argtypes = [C.c_void_p]
         L.hs_reset.argtypes = [C.c_void_p, C.c_void_p]
         L.hs_step.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int64]
         L.hs_set_state.argtypes = [C.c_void_p]
@@ -66,6 +71,7 @@ class SimBatch:
         if not self.h:
             raise SimError(_capi.PARSE_ERROR_NAMES.get(err.value, str(err.value)))
         self.n = n
+        self.set_engine(DEFAULT_ENGINE[0])
         self.map = _capi.Map(text)  # static description through the product's host-only map functions
         m = self.map
         A, Ls = m.n_agents, max(m.n_sources, 1)
@@ -77,6 +83,15 @@ class SimBatch:
         if getattr(self, "h", None):
             self.L.hs_free(self.h)
             self.h = None
+
+    def set_engine(self, engine):
+        """"env": step_logic.hpp (one lane per environment, world_kernel); "lanes": step_lanes.hpp (one lane per agent, the
+        step_kernel restatement); "lanes_no_shortcut": the same with every move_agents pass executed."""
+        self.L.hs_set_engine(self.h, ENGINES[engine])
+
+    def lane_passes(self):
+        """move_agents passes the lane engines have executed so far (all envs, all steps)."""
+        return int(self.L.hs_lane_passes(self.h))
 
     def buf(self, name):
         which = _capi.BUFFER_NAMES.index(name)

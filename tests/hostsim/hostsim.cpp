@@ -6,12 +6,14 @@
 // It mirrors phase 1 / phase 2 of world_kernel (kernels.hip) one environment at a time, on buffers with exactly the
 // device layout (include/lle_hip.h LLE_BUF_*).
 #include <cstdint>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
 #include "../../include/lle_hip.h"
 #include "../../lle_amd/csrc/map_compile.hpp"
 #include "../../lle_amd/csrc/observers_logic.hpp"
+#include "../../lle_amd/csrc/step_lanes.hpp"
 #include "../../lle_amd/csrc/step_logic.hpp"
 
 using namespace lle;
@@ -29,7 +31,66 @@ struct hs_batch {
     bool per_env = false;
     std::vector<uint8_t> src_colour;
     std::vector<uint32_t> src_enabled;
+    // which restatement steps: 0 = one lane per ENV (step_logic.hpp step_env, the world_kernel path), 1 = one lane per
+    // AGENT (step_lanes.hpp, the step_kernel path: the product's hot path), 2 = the same without the no-op-pass shortcut
+    int engine = 0;
+    int64_t lane_passes = 0;  // (diagnostic of the lane engines: move_agents passes executed / skipped by the shortcut)
 };
+
+// ---- World.step through step_lanes.hpp: the G lanes of ONE environment, exactly what a group of lanes of step_kernel runs.
+// Replicated words must come back identical in every lane (uniform<> throws LaneDivergence otherwise).
+template <int AM, int LM, int G, bool ML1, bool PES, bool SHORTCUT>
+static uint32_t lanes_step_g(Env<AM, LM>& s, const uint32_t (&act)[AM], uint32_t (&avail)[AM], const MapView& mv, Events<AM>& ev, int64_t* passes) {
+    constexpr int NWG = (2 * G + 7) / 8, CWM = LM / 4;
+    static_assert(G <= AM || AM == 16, "the group is the power of two above the agent count");
+    const int A = mv.A, L = mv.L;
+    LV<G, uint32_t> a, pos, av, alive, arrived, occ, gems, beams[LM], err, n_ev, meta_step, actv, enabled, colw[CWM];
+    LV<G, bool> me, env_ok(true), stepped;
+    LV<G, uint64_t> evw[NWG];
+    uint32_t beam_full[LM];
+    for (int b = 0; b < LM; b++) beam_full[b] = b < L ? mv.hdr->beam_full[b] : 0u;
+    for (int i = 0; i < G; i++) {
+        a.v[i] = (uint32_t)i; me.v[i] = i < A;
+        pos.v[i] = i < A ? s.pos[i] : 0xFFFF0000u + (uint32_t)i;
+        av.v[i] = i < A ? avail[i] : 0u;
+        actv.v[i] = i < A ? act[i] : 4u;
+        alive.v[i] = s.alive; arrived.v[i] = s.arrived; occ.v[i] = s.occ; gems.v[i] = s.gems; enabled.v[i] = mv.enabled;
+        for (int b = 0; b < LM; b++) beams[b].v[i] = s.beams[b];
+        for (int q = 0; q < CWM; q++) colw[q].v[i] = mv.colw[q];
+    }
+    step_lanes<G, LM, ML1, PES, CWM, SHORTCUT>(mv.cell_lay, mv.cell_meta, A, L, mv.W, mv.max_layers, beam_full, a, me, env_ok, enabled, colw,
+                                               actv, pos, av, alive, arrived, occ, gems, beams, err, evw, n_ev, meta_step, stepped, passes);
+    const uint32_t e = uniform<G>(err);
+    if (!uniform<G>(stepped)) return e;
+    avail_lanes<G>(a, me, pos, occ, alive, arrived, meta_step, av);
+    for (int i = 0; i < AM; i++) {
+        if (i < A) { s.pos[i] = pos.v[i]; avail[i] = av.v[i]; }
+    }
+    s.alive = uniform<G>(alive); s.arrived = uniform<G>(arrived); s.occ = uniform<G>(occ); s.gems = uniform<G>(gems);
+    for (int b = 0; b < LM; b++) s.beams[b] = uniform<G>(beams[b]);
+    ev.clear();
+    ev.n = uniform<G>(n_ev);
+    for (int k = 0; k < NWG && k < Events<AM>::NW; k++) ev.w[k] = grp_or64<G>(evw[k]);
+    return 0;
+}
+template <int AM, int LM, int G>
+static uint32_t lanes_step(int engine, Env<AM, LM>& s, const uint32_t (&act)[AM], uint32_t (&avail)[AM], const MapView& mv, Events<AM>& ev, int64_t* passes) {
+    const bool ml1 = mv.max_layers <= 1, pes = mv.per_env, sc = engine == 1;
+#define HS_LANES(ML1, PES) (sc ? lanes_step_g<AM, LM, G, ML1, PES, true>(s, act, avail, mv, ev, passes) : lanes_step_g<AM, LM, G, ML1, PES, false>(s, act, avail, mv, ev, passes))
+    if (ml1) return pes ? HS_LANES(true, true) : HS_LANES(true, false);
+    return pes ? HS_LANES(false, true) : HS_LANES(false, false);
+#undef HS_LANES
+}
+template <int AM, int LM>
+static uint32_t lanes_step_any(int engine, Env<AM, LM>& s, const uint32_t (&act)[AM], uint32_t (&avail)[AM], const MapView& mv, Events<AM>& ev, int64_t* passes) {
+    const int A = mv.A;  // group size of the step kernel (kernels.hip step_group)
+    if (A <= 1) return lanes_step<AM, LM, 1>(engine, s, act, avail, mv, ev, passes);
+    if (A <= 2) return lanes_step<AM, LM, 2>(engine, s, act, avail, mv, ev, passes);
+    if (A <= 4) return lanes_step<AM, LM, 4>(engine, s, act, avail, mv, ev, passes);
+    if constexpr (AM >= 8) { if (A <= 8) return lanes_step<AM, LM, 8>(engine, s, act, avail, mv, ev, passes); }
+    if constexpr (AM >= 16) return lanes_step<AM, LM, 16>(engine, s, act, avail, mv, ev, passes);
+    return 0xFFu;
+}
 
 enum { M_STEP = 0, M_RESET = 1, M_SET_STATE = 2, M_OBSERVE = 3, M_SOURCES = 4 };
 
@@ -103,10 +164,17 @@ static void run(hs_batch* b, int mode, uint32_t flags, uint64_t seed, uint64_t t
                     if (act[a] > 4u || !((avail[a] >> act[a]) & 1u) || !((walk >> act[a]) & 1u)) err = (uint32_t)a + 1u;
                 }
             }
+            if (b->engine != 0) {
+                // the lane-per-agent restatement does its own availability check; it must agree with the one above
+                const uint32_t lane_err = lanes_step_any<AM, LM>(b->engine, s, act, avail, mv, ev, &b->lane_passes);
+                if (lane_err != err) throw LaneDivergence();
+            }
             if (err == 0) {
-                Cells<AM> fin;
-                step_env<AM, LM>(s, act, mv, ev, cur, fin);
-                compute_avail<AM, LM>(s, mv, fin, avail);
+                if (b->engine == 0) {
+                    Cells<AM> fin;
+                    step_env<AM, LM>(s, act, mv, ev, cur, fin);
+                    compute_avail<AM, LM>(s, mv, fin, avail);
+                }
                 store_avail = true;
             } else {
                 store_state = was_reset != 0;
@@ -224,9 +292,15 @@ hs_batch* hs_create(const char* text, int64_t n, int* parse_error) {
     return b;
 }
 void hs_free(hs_batch* b) { delete b; }
+void hs_set_engine(hs_batch* b, int engine) { b->engine = engine; }
+int64_t hs_lane_passes(hs_batch* b) { return b->lane_passes; }
 void hs_reset(hs_batch* b, const uint8_t* mask) { dispatch(b, M_RESET, 0, 0, 0, 0, nullptr, mask, 0); }
 void hs_step(hs_batch* b, const uint8_t* actions, uint32_t flags, uint64_t seed, uint64_t t, int64_t env_offset) {
-    dispatch(b, M_STEP, flags, seed, t, env_offset, actions, nullptr, 0);
+    try {
+        dispatch(b, M_STEP, flags, seed, t, env_offset, actions, nullptr, 0);
+    } catch (const LaneDivergence&) {  // lanes of one group disagree on a replicated word / on the error code: poison the batch
+        std::fill(b->err.begin(), b->err.end(), (uint8_t)0xEE);
+    }
 }
 void hs_set_state(hs_batch* b) { dispatch(b, M_SET_STATE, 0, 0, 0, 0, nullptr, nullptr, 0); }
 void hs_observe(hs_batch* b) { dispatch(b, M_OBSERVE, 0, 0, 0, 0, nullptr, nullptr, 0); }
