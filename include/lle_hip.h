@@ -209,8 +209,12 @@ enum {
 int lle_batch_step(lle_batch* b, const uint8_t* actions_dev, uint32_t flags, uint64_t seed, uint64_t t,
                    int64_t env_offset, void* stream);
 
-/* Fused rollout: `n_steps` consecutive steps in ONE launch, actions sampled on the device (flags must include
- * LLE_STEP_SAMPLE_ACTIONS; step j uses time index t0 + j).  Identical results to n_steps calls of lle_batch_step;
+/* Fused rollout: `n_steps` consecutive steps in ONE launch.  Actions: sampled on the device (LLE_STEP_SAMPLE_ACTIONS;
+ * step j uses time index t0 + j) and WRITTEN to the action ring, or -- without that flag -- READ from it: the caller
+ * fills slot (ring_pos + j) % ring_slots of `ring->actions` with the joint actions of step j beforehand (an open-loop
+ * plan, a replayed trajectory, an action repeated k times: with ring == NULL every step takes LLE_BUF_ACTIONS).  An env
+ * whose action is refused at some step keeps its state for that step, like lle_batch_step, and goes on with the next.
+ * Identical results to n_steps calls of lle_batch_step;
  * the state stays in registers between steps and the waves drift apart, so the integer work of one step overlaps
  * the observation stream of another.  Per-step outputs go to slot (ring_pos + j) % ring_slots of caller-provided
  * trajectory rings (device memory), or in place (LLE_BUF_OBS / ACTIONS / REWARD, each step overwriting the last)
@@ -220,7 +224,8 @@ typedef struct lle_rollout_ring {
     int32_t pad;
     uint64_t ring_pos;    /* slot of the first step */
     int8_t* obs;          /* [R][n_envs][obs_stride] */
-    uint8_t* actions;     /* [R][n_envs][agent pitch] (pitch: lle_buffer_desc.stride[0] of LLE_BUF_ACTIONS) */
+    uint8_t* actions;     /* [R][n_envs][agent pitch] (pitch: lle_buffer_desc.stride[0] of LLE_BUF_ACTIONS); output with
+                             LLE_STEP_SAMPLE_ACTIONS, input without */
     uint32_t* reward;     /* [R][n_envs]  gems | exits << 8 | deaths << 16 | all_arrived << 24 */
 } lle_rollout_ring;
 int lle_batch_rollout(lle_batch* b, uint32_t n_steps, uint32_t flags, uint64_t seed, uint64_t t0, int64_t env_offset,

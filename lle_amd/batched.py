@@ -182,10 +182,12 @@ class BatchedWorld:
         ring["actions"] = ring["actions_rows"][:, :, : m.n_agents]
         return ring
 
-    def rollout(self, n_steps, auto_reset=True, seed=0, t=None, env_offset=0, ring=None, ring_pos=0, write_obs=True):
-        """n_steps fused steps in one launch with on-device action sampling (lle_batch_rollout); identical results to
-        n_steps calls of step(sample=True).  With a ring (make_ring) step j lands in slot (ring_pos + j) % slots."""
-        flags = LLE_STEP_SAMPLE_ACTIONS | (LLE_STEP_AUTO_RESET if auto_reset else 0) | (0 if write_obs else LLE_STEP_NO_OBS)
+    def rollout(self, n_steps, auto_reset=True, seed=0, t=None, env_offset=0, ring=None, ring_pos=0, write_obs=True, sample=True):
+        """n_steps fused steps in one launch (lle_batch_rollout); identical results to n_steps calls of step().  With a ring
+        (make_ring) step j lands in slot (ring_pos + j) % slots.  sample=True: actions drawn on the device and written to
+        the action ring; sample=False: step j READS its joint actions from ring["actions"][(ring_pos + j) % slots] (fill
+        them first; without a ring every step takes `self.actions`)."""
+        flags = (LLE_STEP_SAMPLE_ACTIONS if sample else 0) | (LLE_STEP_AUTO_RESET if auto_reset else 0) | (0 if write_obs else LLE_STEP_NO_OBS)
         if t is None:
             t = self.t
         rp = None

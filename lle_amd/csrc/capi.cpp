@@ -542,7 +542,6 @@ int lle_batch_rollout(lle_batch* b, uint32_t n_steps, uint32_t flags, uint64_t s
                       const lle_rollout_ring* ring, void* stream) {
     if (!b) return fail(LLE_ERR_NULL, "NULL batch");
     if (n_steps == 0 || n_steps > 4096) return fail(LLE_ERR_ARG, "n_steps must be 1..4096");
-    if (!(flags & LLE_STEP_SAMPLE_ACTIONS)) return fail(LLE_ERR_ARG, "a fused rollout samples its actions on the device");
     if (b->lane_per_env_step) return fail(LLE_ERR_ARG, "the fused rollout runs on the default step kernel only");
     LaunchArgs K{};
     K.flags = flags; K.seed = seed; K.t = t0; K.env_offset = env_offset; K.n_steps = n_steps;

@@ -239,7 +239,9 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
             P.actions[env * As + a] = (uint8_t)act;
         }
     } else if (me) {
-        act = (uint32_t)P.actions[env * As + a];
+        // LLE_BUF_ACTIONS as filled by the caller -- or, in a fused rollout with rings, this step's slot of the ACTION ring:
+        // without on-device sampling the ring is the rollout's input (lle_batch_rollout)
+        act = (uint32_t)actions_out[env * As + a];
     }
 
     // ---- World.step for the lanes of this environment: availability check, vertex conflicts, move_agents passes

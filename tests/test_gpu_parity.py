@@ -459,3 +459,46 @@ def test_rollout_with_rings_equals_steps_in_every_general_mode(name, mode):
             assert torch.equal(ring["reward"][slot], per_step[j][2]), (name, mode, j, "ring reward")
         t0 += chunk
     assert a.stats() == b.stats()
+
+
+@pytest.mark.parametrize("name", ["level6", "nested", "many_agents", "config5_32x32"])
+def test_fused_rollout_with_a_caller_provided_action_ring(oracle_mod, name):
+    """lle_batch_rollout without on-device sampling: step j reads its joint actions from the action ring (an open-loop
+    plan).  The plan: what the sampler would have drawn, with every 7th env's plan corrupted at one step by an unavailable
+    action -- that env refuses the step (err of the last step only), keeps its state and goes on.  Against the oracle
+    stepped with the same actions, and against single steps."""
+    import torch
+
+    from lle_amd import BatchedWorld
+
+    text = MAPS[name]
+    n, T = 320, 8
+    ob = oracle_mod.OracleBatch(text, n)
+    planner, bw, single = BatchedWorld(text, n), BatchedWorld(text, n), BatchedWorld(text, n)
+    ring = bw.make_ring(T)
+    A = bw.map.n_agents
+    plan = []
+    for t in range(T):  # record the sampler's choices (no auto-reset: dead agents only ever STAY)
+        planner.step(sample=True, seed=3, t=t)
+        plan.append(planner.actions.clone())
+    plan[T // 2][::7, 0] = 5  # not an Action
+    for t in range(T):
+        ring["actions_rows"][t].copy_(plan[t].new_zeros(ring["actions_rows"][t].shape))
+        ring["actions"][t].copy_(plan[t][:, :A])
+    bw.rollout(T, auto_reset=False, ring=ring, ring_pos=0, sample=False)
+    for t in range(T):
+        acts = plan[t][:, :A].contiguous()
+        single.step(acts)
+        ostep = ob.step(acts.cpu().numpy())
+        assert torch.equal(ring["obs"][t], single.obs), (name, t)
+        assert np.array_equal(ring["obs"][t].cpu().numpy(), ostep["obs"]), (name, t)
+    check(bw, ob, None, f"{name} after the planned rollout")
+    for k in ("pos", "bits", "gems", "beams", "avail", "err", "evcount", "events", "done"):
+        assert torch.equal(getattr(bw, k), getattr(single, k)), (name, k)
+    # (an env thrown off its plan may refuse later steps as well: the counters say how many)
+    assert bw.stats() == single.stats() and bw.stats()["invalid"] >= len(range(0, n, 7))
+    # no ring: the same joint action at every step (LLE_BUF_ACTIONS), here STAY: nothing moves, nothing is refused
+    bw.actions.fill_(4)
+    before = bw.pos.clone()
+    bw.rollout(3, auto_reset=False, sample=False)
+    assert torch.equal(bw.pos, before) and int(bw.err.max()) == 0
