@@ -62,14 +62,11 @@ __global__ void __launch_bounds__(256) view_observe_kernel(BatchPtrs P, const ui
     const int CW = pes ? src_stride_of(L) / 4 : 0;
     const uint32_t obs_stride = vh0->obs_stride, n_chunks = vh0->n_chunks;
     const uint32_t scr_stride = (uint32_t)(L + A + 2 + CW) | 1u;
-    const uint32_t view_priv = obs_stride + OBS_ENVS_PER_WAVE * scr_stride * 4u;
-    uint8_t* priv = lds + blob_bytes * n_views + elem_bytes + wave_in_wg * n_views * view_priv;
-    for (uint32_t v = 0; v < n_views; v++) {
-        const ViewHeader* vh = reinterpret_cast<const ViewHeader*>(lds + v * blob_bytes);
-        const uint4* pristine = reinterpret_cast<const uint4*>(lds + v * blob_bytes + (pes ? vh->off_bare : vh->off_template));
-        uint4* mine = reinterpret_cast<uint4*>(priv + v * view_priv);
-        for (uint32_t c = lane; c < n_chunks; c += 64) mine[c] = pristine[c];
-    }
+    // private to a wavefront: ONE patchable row (re-initialised from the view's pristine template when the wave turns to
+    // the next view) and the hand-over records of its environments, one set per view (the agents' byte indices differ)
+    const uint32_t rec_bytes = OBS_ENVS_PER_WAVE * scr_stride * 4u;
+    uint8_t* priv = lds + blob_bytes * n_views + elem_bytes + wave_in_wg * (obs_stride + n_views * rec_bytes);
+    int8_t* tmpl = reinterpret_cast<int8_t*>(priv);
     const int64_t env0 = env_base + (int64_t)wave_id * OBS_ENVS_PER_WAVE;
     int64_t n_here = env_limit - env0;
     n_here = n_here < 0 ? 0 : (n_here > (int64_t)OBS_ENVS_PER_WAVE ? (int64_t)OBS_ENVS_PER_WAVE : n_here);
@@ -86,30 +83,36 @@ __global__ void __launch_bounds__(256) view_observe_kernel(BatchPtrs P, const ui
         else if (f >= (uint32_t)(L + 2 + A)) v = reinterpret_cast<const uint32_t*>(P.src_colour)[env * CW + (f - (uint32_t)(L + 2 + A))];
         for (uint32_t q = 0; q < n_views; q++) {
             const ViewHeader* vh = reinterpret_cast<const ViewHeader*>(lds + q * blob_bytes);
-            uint32_t* scratch = reinterpret_cast<uint32_t*>(priv + q * view_priv + obs_stride);
+            uint32_t* scratch = reinterpret_cast<uint32_t*>(priv + obs_stride + q * rec_bytes);
             scratch[k * scr_stride + f] = is_agent ? (uint32_t)vh->agent_layer[f - (uint32_t)L - 2u] * vh->HW + cell : v;
         }
     }
     wave_sync();
-    // one environment at a time, its views back to back (a single view: all environments in one call)
-    const int64_t outer = n_views == 1 ? (n_here > 0 ? 1 : 0) : n_here, inner_envs = n_views == 1 ? n_here : 1;
-    for (int64_t k = 0; k < outer; k++)
+    // one view at a time, all the wave's environments per view: the lane's dyn entry is decoded once per view and the
+    // patch / stream / unpatch of consecutive environments pipeline (env-major order -- the views of an environment back
+    // to back, one call per row -- measured 108.7 us for level 6 / 65 536 envs x 4 observers, this order 99.9)
+    if (n_here > 0)
         for (uint32_t q = 0; q < n_views; q++) {
             const ViewHeader* vh = reinterpret_cast<const ViewHeader*>(lds + q * blob_bytes);
-            int8_t* tmpl = reinterpret_cast<int8_t*>(priv + q * view_priv);
-            const uint32_t* scratch = reinterpret_cast<const uint32_t*>(tmpl + obs_stride) + (uint32_t)k * scr_stride;
+            const uint32_t* scratch = reinterpret_cast<const uint32_t*>(priv + obs_stride + q * rec_bytes);
+            {
+                const uint4* pristine = reinterpret_cast<const uint4*>(lds + q * blob_bytes + (pes ? vh->off_bare : vh->off_template));
+                uint4* mine = reinterpret_cast<uint4*>(tmpl);
+                for (uint32_t c = lane; c < n_chunks; c += 64) mine[c] = pristine[c];
+                wave_sync();
+            }
             if (pes) {
                 const int8_t* bare = reinterpret_cast<const int8_t*>(lds + q * blob_bytes + vh->off_bare);
                 if (wt) write_observations_env<true>(A, L, vh->HW, n_elems, n_chunks, (uint64_t)row_pitch, elems, bare, tmpl, scratch, scr_stride,
-                                                     out + (int64_t)q * view_pitch, env0 + k, inner_envs, lane, vh->laser_layer, vh->gem_layer);
+                                                     out + (int64_t)q * view_pitch, env0, n_here, lane, vh->laser_layer, vh->gem_layer);
                 else write_observations_env<false>(A, L, vh->HW, n_elems, n_chunks, (uint64_t)row_pitch, elems, bare, tmpl, scratch, scr_stride,
-                                                   out + (int64_t)q * view_pitch, env0 + k, inner_envs, lane, vh->laser_layer, vh->gem_layer);
+                                                   out + (int64_t)q * view_pitch, env0, n_here, lane, vh->laser_layer, vh->gem_layer);
             } else {
                 const uint64_t* dyn = reinterpret_cast<const uint64_t*>(lds + q * blob_bytes + vh->off_dyn);
                 if (wt) write_observations<true>(A, L, vh->D, n_chunks, (uint64_t)row_pitch, dyn, tmpl, scratch, scr_stride,
-                                                 out + (int64_t)q * view_pitch, env0 + k, inner_envs, lane);
+                                                 out + (int64_t)q * view_pitch, env0, n_here, lane);
                 else write_observations<false>(A, L, vh->D, n_chunks, (uint64_t)row_pitch, dyn, tmpl, scratch, scr_stride,
-                                               out + (int64_t)q * view_pitch, env0 + k, inner_envs, lane);
+                                               out + (int64_t)q * view_pitch, env0, n_here, lane);
             }
         }
 }
@@ -322,7 +325,7 @@ static hipError_t grant_lds(const void* fn, uint32_t lds, uint32_t& granted) {
 static uint32_t view_lds(const ViewHeader& v, uint32_t n_views, uint32_t wpw, bool pes, uint32_t n_elems) {
     const uint32_t scr_stride = (v.L + v.A + 2 + (pes ? (uint32_t)src_stride_of((int)v.L) / 4u : 0u)) | 1u;
     const uint32_t elem_bytes = pes ? ((n_elems * 4u + 15u) & ~15u) : 0u;
-    return n_views * v.blob_bytes + elem_bytes + wpw * n_views * (v.obs_stride + OBS_ENVS_PER_WAVE * scr_stride * 4u);
+    return n_views * v.blob_bytes + elem_bytes + wpw * (v.obs_stride + n_views * OBS_ENVS_PER_WAVE * scr_stride * 4u);
 }
 
 bool view_kernel_fits(const ViewHeader& v, uint32_t n_views, bool pes, uint32_t n_elems) {
