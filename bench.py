@@ -205,10 +205,10 @@ def preroll(torch, dev, fn, seconds=PREROLL_SECONDS):
     return n
 
 
-def measure_config(torch, timer, dev, map_or_text, n_envs, algo_bytes, steps, label, padded=False):
+def measure_config(torch, timer, dev, map_or_text, n_envs, algo_bytes, steps, label, traffic_key=None):
     """One secondary configuration (N = 1): K single-step launches after a warm-up, HIP-event timed."""
     from lle_amd import BatchedWorld
-    bw = BatchedWorld(map_or_text, n_envs, device=dev, **({"row_align": 128} if padded else {}))
+    bw = BatchedWorld(map_or_text, n_envs, device=dev)
     fn = stepper(bw)
     for _ in range(max(20, steps // 10)):
         fn()
@@ -224,6 +224,7 @@ def measure_config(torch, timer, dev, map_or_text, n_envs, algo_bytes, steps, la
         "row_bytes": m.obs_bytes, "row_stride": m.obs_stride, "rows_MB_per_launch": rows / 1e6,
         "bound": "hbm" if rows > INFINITY_CACHE_BYTES else "infinity-cache-absorbed",
         "kernel": info["kernel"], "envs_per_wave": info["envs_per_wave"], "lds_bytes_per_workgroup": info["lds_bytes"],
+        "traffic": load_traffic(traffic_key) if traffic_key else None,
         "rollout_stats": bw.stats(),
     }
     del bw
@@ -342,12 +343,14 @@ def main():
         from lle_amd import mapgen
         k = args.config_steps
         hbm = measure_config(torch, timer, dev, Map(level=LEVEL), HBM_REGIME_ENVS, ALGO_BYTES_PER_ENV_STEP, k,
-                             f"World.level({LEVEL}) x {HBM_REGIME_ENVS} envs: rows of one launch exceed the 256 MB Infinity Cache")
+                             f"World.level({LEVEL}) x {HBM_REGIME_ENVS} envs: rows of one launch exceed the 256 MB Infinity Cache",
+                             "hbm_regime_bytes_per_launch")
         cfgs = {
             "cfg2_level1_4096": measure_config(torch, timer, dev, Map(level=1), 4096, ALGO_BYTES_CFG2, max(k, 1000),
-                                               "BASELINE configs[1]: World.level(1), 1 agent, 4096 envs"),
+                                               "BASELINE configs[1]: World.level(1), 1 agent, 4096 envs", "cfg2_bytes_per_launch"),
             "cfg5_32x32_a8_l8_65536": measure_config(torch, timer, dev, mapgen.config5(0), 65536, ALGO_BYTES_CFG5, k,
-                                                     "BASELINE configs[4]: generated 32x32, 8 agents, 8 lasers (mapgen.config5(0)), 65536 envs"),
+                                                     "BASELINE configs[4]: generated 32x32, 8 agents, 8 lasers (mapgen.config5(0)), 65536 envs",
+                                                     "cfg5_bytes_per_launch"),
         }
 
     if rank == 0:
@@ -385,7 +388,7 @@ def main():
                                 "achieved_GBps_per_gpu": s_ach, "frac_of_hbm_peak": s_ach / HBM_PEAK_GBS}
         if hbm:
             out["roofline_hbm"] = {"bound": "hbm", "achieved": hbm["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": hbm["frac_of_hbm_peak"], "traffic": load_traffic("hbm_regime_bytes_per_launch"),
+                                   "frac": hbm["frac_of_hbm_peak"],
                                    "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * hbm["n_envs"], **hbm}
         if cfgs:
             out["configs"] = cfgs

@@ -1,0 +1,114 @@
+"""profile_round.py -- the round's measured evidence in one go (runs on the GPU box: `gpurun -- python3 tools/profile_round.py r02`).
+
+  1. `python3 bench.py`                                               -> gpurun_out/prof/bench.json
+  2. `rocprofv3 --kernel-trace --stats -- python3 bench.py ...`       -> per (kernel, grid) launch durations
+  3. `rocprofv3 --pmc WRITE_SIZE --kernel-trace -- python3 bench.py`  -> bytes written per launch (L2 -> fabric)
+  4. `rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 bench.py`  -> bytes fetched per launch (x2 on gfx950)
+     (counters in passes of their own, with --kernel-trace only: MI355X_MICROARCH.md, HBM / rocprofv3 section)
+and writes profiles/<tag>_summary.md, profiles/<tag>_kernel_stats.csv and profiles/traffic.json (read by bench.py).
+
+bench.py runs the headline workload (level 6 x 65 536), the same kernel at 262 144 envs (rows of one launch larger than the
+Infinity Cache), cfg2 (level 1 x 4 096), cfg5 (32x32, 8 agents x 65 536) and the fused rollouts, so one profiled run covers
+every number of the bench line; launches are told apart by (kernel name, grid size)."""
+import csv
+import glob
+import json
+import os
+import statistics
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out", "prof")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+ENV = dict(os.environ, TMPDIR="/tmp")
+BENCH = os.path.join(ROOT, "bench.py")
+# (label, kernel-name fragment, grid size in work-items = waves x 64): the single-step launches of the bench line
+WORKLOADS = [
+    ("cfg3 level 6 x 65 536 (headline)", "step_kernel<4, 4, 0, true, 3>", 65536 // 16 * 64, 1937 * 65536),
+    ("level 6 x 262 144 (rows > Infinity Cache)", "step_kernel<4, 4, 0, true, 3>", 262144 // 16 * 64, 1937 * 262144),
+    ("cfg2 level 1 x 4 096", "step_kernel<1, 4, 0, true, 0>", 4096 // 4 * 64, 953 * 4096),
+    ("cfg5 32x32 8 agents x 65 536", "step_kernel<8, 8, 0, false, -1>", 65536 // 8 * 64, 20617 * 65536),
+]
+
+
+def run(cmd, log):
+    print("+", " ".join(cmd), flush=True)
+    with open(os.path.join(OUT, log), "w") as f:
+        return subprocess.run(cmd, cwd="/tmp", env=ENV, stdout=subprocess.PIPE, stderr=f, text=True, timeout=1100)
+
+
+def latest(pattern):
+    files = sorted(glob.glob(os.path.join(OUT, pattern), recursive=True), key=os.path.getmtime)
+    return files[-1] if files else None
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    for d in ("stats", "pmc_write", "pmc_fetch"):
+        subprocess.run(["rm", "-rf", os.path.join(OUT, d)])
+    res = run([sys.executable, BENCH], "bench.err")
+    bench = json.loads(res.stdout.strip().splitlines()[-1])
+    json.dump(bench, open(os.path.join(OUT, "bench.json"), "w"))
+    light = ["--no-cpu-baseline", "--steps", "200", "--sustained-steps", "0", "--config-steps", "60"]
+    res = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", os.path.join(OUT, "stats"), "--", sys.executable, BENCH] + light,
+              "stats.err")
+    bench_prof = json.loads(res.stdout.strip().splitlines()[-1])
+    for kind, counter in (("write", "WRITE_SIZE"), ("fetch", "FETCH_SIZE")):
+        run(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(OUT, f"pmc_{kind}"), "--",
+             sys.executable, BENCH] + light + ["--no-fused", "--steps", "50"], f"pmc_{kind}.err")
+
+    trace = list(csv.DictReader(open(latest("stats/**/*_kernel_trace.csv"))))
+    stats = list(csv.DictReader(open(latest("stats/**/*_kernel_stats.csv"))))
+
+    def pmc(kind, frag, grid):
+        rows = [float(r["Counter_Value"]) for r in csv.DictReader(open(latest(f"pmc_{kind}/**/*_counter_collection.csv")))
+                if frag in r["Kernel_Name"] and int(r["Grid_Size"]) == grid]
+        return (statistics.median(rows), len(rows)) if rows else (None, 0)
+
+    lines = [f"# rocprofv3 summary ({tag}): `python3 bench.py` on one MI355X", "",
+             "Collected by `tools/profile_round.py` (one gpurun call): bench.py un-profiled; `rocprofv3 --kernel-trace --stats -- python3 bench.py "
+             + " ".join(light) + "`; `--pmc WRITE_SIZE` and `--pmc FETCH_SIZE` in passes of their own.", "",
+             "## Launches of the bench line, by (kernel, grid)", "",
+             "| workload | kernel | launches | avg us | median us | min us | algorithmic MB | algorithmic GB/s at avg | WRITE_SIZE MB | 2 x FETCH_SIZE MB | traffic / algorithmic |",
+             "|---|---|---|---|---|---|---|---|---|---|---|"]
+    traffic = {}
+    csv_rows = [["workload", "kernel", "grid", "launches", "avg_ns", "median_ns", "min_ns", "max_ns", "write_bytes", "fetch_bytes_corrected"]]
+    for label, frag, grid, algo in WORKLOADS:
+        d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in trace if frag in r["Kernel_Name"] and int(r["Grid_Size_X"]) == grid]
+        if not d:
+            lines.append(f"| {label} | `{frag}` | 0 | - | - | - | - | - | - | - | - |")
+            continue
+        w, _ = pmc("write", frag, grid)
+        fch, _ = pmc("fetch", frag, grid)
+        wb = w * 1024 if w is not None else None               # KiB -> bytes (exact for 16-B-per-lane streaming stores)
+        fb = 2 * fch * 1024 if fch is not None else None       # gfx950: FETCH_SIZE reports half of a wide coalesced read stream
+        tr = (wb + fb) if wb is not None and fb is not None else None
+        avg = statistics.mean(d)
+        lines.append(f"| {label} | `{frag}` | {len(d)} | {avg/1e3:.2f} | {statistics.median(d)/1e3:.2f} | {min(d)/1e3:.2f} | {algo/1e6:.1f} | {algo/avg:.0f} | "
+                     f"{(wb or 0)/1e6:.1f} | {(fb or 0)/1e6:.1f} | {(tr/algo if tr else float('nan')):.3f} |")
+        csv_rows.append([label, frag, grid, len(d), round(avg), statistics.median(d), min(d), max(d), wb, fb])
+        traffic[label] = tr
+    lines += ["", "## Kernel stats of the profiled run (`--stats`; a kernel name covers every grid it ran with)", "",
+              "| kernel | calls | avg ns | min ns | max ns | % |", "|---|---|---|---|---|---|"]
+    for r in stats:
+        if float(r["Percentage"]) >= 0.05:
+            lines.append(f"| `{r['Name'][:100]}` | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} | {float(r['Percentage']):.2f} |")
+    g = next(r for r in trace if WORKLOADS[0][1] in r["Kernel_Name"])
+    lines += ["", f"Headline kernel: workgroup {g['Workgroup_Size_X']}, LDS {g['LDS_Block_Size']} B (static; the dynamic size is in the bench line), VGPR {g['VGPR_Count']}, "
+              f"SGPR {g['SGPR_Count']}, scratch {g['Scratch_Size']}.", "",
+              "## bench.py lines of the same session", "", "Un-profiled:", "```json", json.dumps(bench), "```", "",
+              "Under rocprofv3 --kernel-trace --stats:", "```json", json.dumps(bench_prof), "```", ""]
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    open(os.path.join(ROOT, "gpurun_out", f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
+    with open(os.path.join(ROOT, "gpurun_out", f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+        csv.writer(f).writerows(csv_rows)
+    json.dump({"hbm_bytes_per_launch": traffic.get(WORKLOADS[0][0]), "hbm_regime_bytes_per_launch": traffic.get(WORKLOADS[1][0]),
+               "cfg2_bytes_per_launch": traffic.get(WORKLOADS[2][0]), "cfg5_bytes_per_launch": traffic.get(WORKLOADS[3][0]),
+               "fetch_correction": 2.0, "unit": "bytes (WRITE_SIZE + 2 x FETCH_SIZE, KiB counters x 1024)", "source": f"profiles/{tag}_summary.md"},
+              open(os.path.join(ROOT, "gpurun_out", f"{tag}_traffic.json"), "w"), indent=1)
+    print("\n".join(lines[:14]))
+
+
+if __name__ == "__main__":
+    main()
