@@ -14,6 +14,7 @@
   graph       HIP-graph replay of single-step launches vs plain launches
   pipe        state machine and observation as two kernels on two streams (timing prototype)
   streams     the batch split over k HIP streams
+  placement   several arenas of the same batch side by side: does the write rate depend on where a buffer lands?
   stamps      in-kernel s_memrealtime timeline of the step kernel (--fine: per-quarter view of a stamped MODE-0 build)
   target      a fixed workload for `rocprofv3 --pmc ... -- python3 tools/lle_prof.py target ...` (step / noobs / partial / cfg5 / hbm)
 
@@ -282,6 +283,19 @@ def cmd_streams(args):
         print(f"streams={k}: {dt:.2f} us per step of {n} envs ({algo_bytes(parts[0].map)*n/dt/1e3:.0f} GB/s)", flush=True)
 
 
+def cmd_placement(args):
+    """Four arenas of one batch shape, each timed twice: GB-sized buffers show a write rate that depends on where the
+    allocation landed (config 5: 222-225 us on some arenas, 252-257 on others, stable for the life of the buffer)."""
+    n = ints(args.sizes)[0]
+    m = the_map(args)
+    bws = [BatchedWorld(m, n) for _ in range(4)]
+    for rnd in range(2):
+        for i, bw in enumerate(bws):
+            us = timeit(stepper(bw), iters=60, warm=5)
+            print(f"round {rnd} arena {i}: base {bw._base.data_ptr():#x} obs {bw.obs_rows.data_ptr():#x}: {us:.1f} us/step "
+                  f"({algo_bytes(m)*n/us/1e3:.0f} GB/s)", flush=True)
+
+
 def cmd_stamps(args):
     """In-kernel timeline: per-wave s_memrealtime stamps (10 ns ticks) of lle_batch_step_stamped (MODE 1 build of the step
     kernel).  --fine expects the one-off diagnostic build that stamps in MODE 0 with 16 slots per wave."""
@@ -353,7 +367,7 @@ def main():
     sub = ap.add_subparsers(dest="cmd", required=True)
     cmds = {"step": cmd_step, "logic": cmd_logic, "configs": cmd_configs, "hbm": cmd_hbm, "rollout": cmd_rollout, "observers": cmd_observers,
             "env": cmd_env, "sources": cmd_sources, "multimap": cmd_multimap, "graph": cmd_graph, "pipe": cmd_pipe, "streams": cmd_streams,
-            "stamps": cmd_stamps, "target": cmd_target}
+            "placement": cmd_placement, "stamps": cmd_stamps, "target": cmd_target}
     for name, fn in cmds.items():
         p = sub.add_parser(name, help=(fn.__doc__ or "").strip().split("\n")[0])
         p.add_argument("--level", type=int, default=6)
