@@ -767,9 +767,14 @@ int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64
                                         b->n_envs, pes, h.n_elems, M, v->stride, st));
             break;
         }
-        case LLE_OBS_PARTIAL:
-            HIP_TRY(launch_partial_observe(h, b->ptrs, static_cast<int8_t*>(out_dev), param, b->n_envs, b->per_env_sources, M, st));
+        case LLE_OBS_PARTIAL: {
+            uint32_t n_entities = 0;  // what a k x k window can show besides agents (observers.hip partial_project_kernel)
+            for (const Map& mp : b->maps)
+                n_entities = std::max<uint32_t>(n_entities, (uint32_t)(mp.walls.size() + mp.exits.size() + mp.gems.size() + mp.n_laser_tiles() +
+                                                                    mp.sources.size()));
+            HIP_TRY(launch_partial_observe(h, b->ptrs, static_cast<int8_t*>(out_dev), param, b->n_envs, b->per_env_sources, M, n_entities, st));
             break;
+        }
         default:
             HIP_TRY(launch_state_observe(h, b->ptrs, static_cast<float*>(out_dev), kind == LLE_OBS_NORMALIZED_STATE, b->n_envs, st));
             break;

@@ -38,8 +38,9 @@ hipError_t launch_view_observe(const ViewHeader& v, const BatchPtrs& P, const ui
 // do n_views views fit the LDS of one workgroup together?
 bool view_kernel_fits(const ViewHeader& v, uint32_t n_views, bool pes, uint32_t n_elems);
 uint32_t partial_pitch(int A, int k);
+// n_entities: walls (sources included) + exits + gems + exposed laser tiles + sources of the map (the largest of a multi-map batch)
 hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t* out, int k, int64_t n_envs, bool per_env_sources,
-                                  MapSel M, hipStream_t stream);
+                                  MapSel M, uint32_t n_entities, hipStream_t stream);
 hipError_t launch_state_observe(const MapHeader& h, const BatchPtrs& P, float* out, int normalize, int64_t n_envs, hipStream_t stream);
 struct EnvOutputs {  // lle_env_outputs (include/lle_hip.h) as the kernel sees it
     float* state;

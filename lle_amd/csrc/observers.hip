@@ -225,6 +225,178 @@ __global__ void __launch_bounds__(256) partial_observe_kernel(BatchPtrs P, int8_
     }
 }
 
+// ---------------------------------------------------------------------------------------------- partial k x k, by projection
+// The window kernel above evaluates every cell of every agent's window against the cell tables: A * k * k units of ~75
+// vector instructions each, most of them on empty floor (7x7 on level 6: 2 394 VALU per wavefront of 8 envs, vector-issue
+// bound at 3.1 TB/s).  A row is almost all zeros, though: its non-zero bytes are the map's ENTITIES seen through the
+// windows -- walls (sources included), exits, uncollected gems, lit laser tiles (the two layers World.lasers() exposes),
+// -1 at sources, agents.  This kernel projects instead: one lane per (entity, observer) pair tests whether the entity's
+// cell lies in the observer's window and, if so, writes its one byte.  (n_entities + A) * A pairs of ~30 instructions
+// (level 6: 54 x 4 = 216 pairs against 196 window cells at 2.5 x the cost each).  All writes of one environment commute:
+// two entities share a byte only where a laser colour A / A + 1 aliases GEM / EXIT, and then both write 1 (a source, the
+// only -1, sits on a wall cell that holds nothing else) -- so any lane order reproduces the reference's write order
+// (observations.py:343-359).  The launcher picks the cheaper kernel per (map, k).
+//
+// The entity table is built once per workgroup, straight from the map's cell tables in global memory (nothing else of
+// them is needed afterwards, so they are not copied to LDS): u32 = i | j << 8 | type << 16 | index << 19 | offset << 24.
+// LDS: [count | entity table] then per wave [row (pitch bytes) | records of its envs: pos u16[As] | gems | beams[L] | colour words].
+enum : uint32_t { PE_WALL = 0, PE_EXIT = 1, PE_GEM = 2, PE_TILE = 3, PE_SOURCE = 4, PE_AGENT = 5 };
+__global__ void __launch_bounds__(256) partial_project_kernel(BatchPtrs P, int8_t* __restrict__ out, int k, uint32_t pitch,
+                                                              int64_t env_base, int64_t env_limit, int per_env_sources, MapSel M,
+                                                              uint32_t epw, uint32_t ent_cap) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t lane = threadIdx.x & 63u, wave_in_wg = threadIdx.x >> 6, waves_per_wg = blockDim.x >> 6;
+    const uint32_t blk = xcd_block(blockIdx.x, gridDim.x);
+    const uint32_t wave_id = blk * waves_per_wg + wave_in_wg;
+    const uint8_t* __restrict__ tables = tables_of(P, M, env_base + (int64_t)(blk * waves_per_wg) * epw);
+    const MapHeader* __restrict__ hdr = reinterpret_cast<const MapHeader*>(tables);
+    const int A = (int)hdr->A, L = (int)hdr->L, W = (int)hdr->W;
+    const int64_t As = agent_stride_of(A, L);
+    uint32_t* ent_count = reinterpret_cast<uint32_t*>(lds);
+    uint32_t* ents = reinterpret_cast<uint32_t*>(lds) + 4;
+    if (threadIdx.x == 0) *ent_count = 0u;
+    __syncthreads();
+    {
+        const uint64_t* __restrict__ glay = reinterpret_cast<const uint64_t*>(tables + hdr->off_cell_lay);
+        const uint32_t* __restrict__ gmeta = reinterpret_cast<const uint32_t*>(tables + hdr->off_cell_meta);
+        for (uint32_t c = threadIdx.x; c < hdr->HW; c += blockDim.x) {
+            const uint32_t meta = gmeta[c], kind = meta & 7u, idx = (meta >> 3) & 31u;
+            const uint64_t lay = glay[c];
+            const uint32_t i = c / (uint32_t)W, ij = i | ((c - i * (uint32_t)W) << 8);
+            uint32_t e[4], n = 0;
+            if (kind == K_WALL || kind == K_SOURCE) e[n++] = ij | (PE_WALL << 16);   // wall_pos holds the sources too
+            if (kind == K_SOURCE) e[n++] = ij | (PE_SOURCE << 16) | (idx << 19);      // idx = laser id of a source cell
+            if (kind == K_EXIT) e[n++] = ij | (PE_EXIT << 16);
+            if (kind == K_GEM) e[n++] = ij | (PE_GEM << 16) | (idx << 19);
+            for (int q = 0; q < 2; q++) {                                            // World.lasers(): two layers per cell
+                const uint32_t e2 = (uint32_t)(lay >> (16 * q)) & 0xFFFFu;
+                if (!(e2 & LAY_VALID)) break;
+                e[n++] = ij | (PE_TILE << 16) | (((e2 >> 1) & 31u) << 19) | (((e2 >> 6) & 31u) << 24);
+            }
+            if (n) {
+                const uint32_t at = atomicAdd(ent_count, n);
+                for (uint32_t q = 0; q < n; q++)
+                    if (at + q < ent_cap) ents[at + q] = e[q];
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t n_ent = *ent_count < ent_cap ? *ent_count : ent_cap;
+    const int CW = src_stride_of(L) / 4;
+    const uint32_t rec_dwords = (uint32_t)(As / 2 + 1 + L + CW);
+    const uint32_t ent_bytes = (16u + ent_cap * 4u + 15u) & ~15u;
+    const uint32_t priv_bytes = pitch + ((epw * rec_dwords * 4u + 15u) & ~15u);
+    int8_t* row = reinterpret_cast<int8_t*>(lds + ent_bytes + wave_in_wg * priv_bytes);
+    uint32_t* recs = reinterpret_cast<uint32_t*>(row + pitch);
+    const int64_t env0 = env_base + (int64_t)wave_id * epw;
+    int64_t n_here = env_limit - env0;
+    n_here = n_here < 0 ? 0 : (n_here > (int64_t)epw ? (int64_t)epw : n_here);
+    const uint32_t* __restrict__ map_colw = reinterpret_cast<const uint32_t*>(hdr->beam_colour);
+    for (uint32_t idx = lane; idx < (uint32_t)n_here * rec_dwords; idx += 64) {
+        const uint32_t e = idx / rec_dwords, f = idx - e * rec_dwords;
+        const int64_t env = env0 + e;
+        uint32_t v;
+        if (f < (uint32_t)(As / 2)) v = reinterpret_cast<const uint32_t*>(P.pos)[env * (As / 2) + f];
+        else if (f == (uint32_t)(As / 2)) v = P.gems[env];
+        else if (f < (uint32_t)(As / 2 + 1 + L)) v = P.beams[env * L + (f - (uint32_t)(As / 2) - 1u)];
+        else {
+            const uint32_t q = f - (uint32_t)(As / 2 + 1 + L);  // colours, 4 per word: the env's own or the map's
+            v = per_env_sources ? reinterpret_cast<const uint32_t*>(P.src_colour)[env * CW + q] : map_colw[q];
+        }
+        recs[idx] = v;
+    }
+    wave_sync();
+    const uint32_t n_chunks = pitch / 16, kk = (uint32_t)(k * k), layers = (uint32_t)(2 * A + 3);
+    const uint32_t logA = A <= 1 ? 0u : (A <= 2 ? 1u : (A <= 4 ? 2u : (A <= 8 ? 3u : 4u)));
+    const uint32_t n_pairs = (n_ent + (uint32_t)A) << logA;
+    const int centre = k / 2;
+    // A lane's pairs p = lane + 64 q are the same for every environment, and so is its observer a = lane mod 2^logA:
+    // what does not depend on the environment is decoded ONCE per wavefront -- the entity word, and for entities whose
+    // layer is static (everything but lasers under per-env colours) the byte offset of the layer in the observer's block.
+    constexpr int QM = 4;  // pairs per lane kept in registers (level 6: 216 pairs = 4 per lane); the rest take the loop below
+    const uint32_t a = lane & ((1u << logA) - 1u);
+    const bool a_ok = a < (uint32_t)A;
+    // per pair, static: packed cell of the entity, byte offset of (observer a, layer) in the row, the value to write, and
+    // how the dynamic parts are read -- LDS offsets inside an env record for the agent position / beam mask / colour byte
+    // (a harmless in-record offset when the pair needs none), bit to test, and masks that select among them arithmetically:
+    // the per-environment loop below has no data-dependent branch and issues its LDS reads together.
+    uint32_t q_cell[QM], q_base[QM], q_posoff[QM], q_beamoff[QM], q_coloff[QM], q_bit[QM], q_agent[QM], q_gem[QM], q_tile[QM], q_always[QM],
+        q_laser[QM];
+    int32_t q_val[QM];
+    const uint8_t* map_colour = hdr->beam_colour;
+    const uint32_t beams_at = (uint32_t)(As / 2 + 1) * 4u, colour_at = (uint32_t)(As / 2 + 1 + L) * 4u;  // byte offsets in a record
+#pragma unroll
+    for (int q = 0; q < QM; q++) {
+        const uint32_t p = lane + 64u * (uint32_t)q, en = p >> logA;
+        const bool valid = p < n_pairs && a_ok, is_agent = en >= n_ent;
+        const uint32_t ent = is_agent ? ((en - n_ent) << 19) | ((uint32_t)PE_AGENT << 16) : ents[valid ? en : 0u];
+        const uint32_t type = (ent >> 16) & 7u, idx = (ent >> 19) & 31u, off = (ent >> 24) & 31u;
+        const bool laser = type == PE_TILE || type == PE_SOURCE;
+        const uint32_t col = (laser && !per_env_sources) ? (uint32_t)map_colour[idx] : 0u;
+        const uint32_t layer = type == PE_WALL ? (uint32_t)A : type == PE_EXIT ? (uint32_t)(2 * A + 2) : type == PE_GEM ? (uint32_t)(2 * A + 1)
+                             : type == PE_AGENT ? idx : (uint32_t)(A + 1) + col;
+        q_cell[q] = ent & 0xFFFFu;
+        q_base[q] = (a * layers + layer) * kk;
+        q_val[q] = type == PE_SOURCE ? -1 : 1;
+        q_posoff[q] = (type == PE_AGENT ? idx : 0u) * 2u;
+        q_beamoff[q] = beams_at + (type == PE_TILE ? idx : 0u) * 4u;
+        q_coloff[q] = colour_at + (laser ? idx : 0u);
+        q_bit[q] = type == PE_GEM ? idx : off;
+        q_agent[q] = type == PE_AGENT ? 0xFFFFFFFFu : 0u;
+        q_gem[q] = (valid && type == PE_GEM) ? 1u : 0u;
+        q_tile[q] = (valid && type == PE_TILE) ? 1u : 0u;
+        q_always[q] = (valid && type != PE_GEM && type != PE_TILE) ? 1u : 0u;
+        q_laser[q] = (laser && per_env_sources) ? kk : 0u;   // colour -> byte offset multiplier (0: the layer is static)
+    }
+    uint4* row16 = reinterpret_cast<uint4*>(row);
+    for (int64_t e = 0; e < n_here; e++) {
+        const uint8_t* rec8 = reinterpret_cast<const uint8_t*>(recs + (uint32_t)e * rec_dwords);
+        const uint16_t* pos = reinterpret_cast<const uint16_t*>(rec8);
+        const uint32_t gems = reinterpret_cast<const uint32_t*>(rec8)[As / 2];
+        for (uint32_t c = lane; c < n_chunks; c += 64) row16[c] = make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t pa = pos[a_ok ? a : 0u];
+        uint32_t r_pos[QM], r_beam[QM], r_col[QM];
+#pragma unroll
+        for (int q = 0; q < QM; q++) {
+            r_pos[q] = *reinterpret_cast<const uint16_t*>(rec8 + q_posoff[q]);
+            r_beam[q] = *reinterpret_cast<const uint32_t*>(rec8 + q_beamoff[q]);
+            r_col[q] = rec8[q_coloff[q]];
+        }
+        const int oi = (int)(pa & 0xFFu) - centre, oj = (int)(pa >> 8) - centre;  // the window's origin
+        wave_sync();  // LDS operations of a wave execute in order: the writes below land after the clears
+#pragma unroll
+        for (int q = 0; q < QM; q++) {
+            const uint32_t pe = (r_pos[q] & q_agent[q]) | (q_cell[q] & ~q_agent[q]);
+            const int dy = (int)(pe & 0xFFu) - oi, dx = (int)(pe >> 8) - oj;
+            const uint32_t on = (q_gem[q] & ~(gems >> q_bit[q])) | (q_tile[q] & (r_beam[q] >> q_bit[q])) | q_always[q];
+            const uint32_t at = q_base[q] + r_col[q] * q_laser[q] + (uint32_t)(dy * k + dx);
+            const bool in = (on & 1u) && (uint32_t)dy < (uint32_t)k && (uint32_t)dx < (uint32_t)k;
+            if (in) row[at] = (int8_t)q_val[q];
+        }
+        const int8_t* colour = reinterpret_cast<const int8_t*>(rec8 + colour_at);
+        const uint32_t* beams = reinterpret_cast<const uint32_t*>(rec8 + beams_at);
+        for (uint32_t p = lane + 64u * QM; p < n_pairs; p += 64) {  // maps with more pairs than QM per lane
+            const uint32_t en = p >> logA;
+            const bool is_agent = en >= n_ent;
+            const uint32_t ent = is_agent ? ((en - n_ent) << 19) | ((uint32_t)PE_AGENT << 16) : ents[en];
+            const uint32_t type = (ent >> 16) & 7u, idx = (ent >> 19) & 31u, off = (ent >> 24) & 31u;
+            const uint32_t pe = type == PE_AGENT ? (uint32_t)pos[idx] : (ent & 0xFFFFu);
+            const int dy = (int)(pe & 0xFFu) - oi, dx = (int)(pe >> 8) - oj;
+            const uint32_t beam_bits = beams[type == PE_TILE ? idx : 0u];
+            const uint32_t col = (uint32_t)(uint8_t)colour[(type == PE_TILE || type == PE_SOURCE) ? idx : 0u];
+            const bool on = type == PE_GEM ? !((gems >> idx) & 1u) : (type == PE_TILE ? ((beam_bits >> off) & 1u) != 0 : true);
+            const uint32_t layer = type == PE_WALL ? (uint32_t)A : type == PE_EXIT ? (uint32_t)(2 * A + 2) : type == PE_GEM ? (uint32_t)(2 * A + 1)
+                                 : type == PE_AGENT ? idx : (uint32_t)(A + 1) + col;
+            const bool in = a_ok && (uint32_t)dy < (uint32_t)k && (uint32_t)dx < (uint32_t)k && on;
+            if (in) row[(a * layers + layer) * kk + (uint32_t)(dy * k + dx)] = type == PE_SOURCE ? (int8_t)-1 : (int8_t)1;
+        }
+        wave_sync();
+        uint4* __restrict__ dst = reinterpret_cast<uint4*>(out + (uint64_t)(env0 + e) * pitch);
+        stream_whole_row<false>(dst, row16, n_chunks, lane);
+        wave_sync();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- state vector
 __global__ void __launch_bounds__(256) state_observe_kernel(BatchPtrs P, float* __restrict__ out, int normalize, int64_t n_envs) {
     const MapHeader* __restrict__ hdr = reinterpret_cast<const MapHeader*>(P.tables);  // dimensions are common to all maps
@@ -357,10 +529,44 @@ hipError_t launch_view_observe(const ViewHeader& v, const BatchPtrs& P, const ui
 
 uint32_t partial_pitch(int A, int k) { return ((uint32_t)(A * (2 * A + 3) * k * k) + 15u) & ~15u; }
 
+// The cheaper of the two partial kernels for this (map, k).  Measured at 65 536 envs (us per launch, window / projection):
+// level 6 (216 pairs; 36 / 100 / 196 window cells) 3x3 19.0 / 23.6, 5x5 28.3 / 25.7, 7x7 44.8 / 28.7; config 5 (2 112 pairs;
+// 72 / 200 / 392 cells) 46 / 166, 102 / 170, 168 / 193: about 0.07 us per pair against 0.13-0.3 us per window cell, with
+// the projection's table build on top.  LLE_PARTIAL_PROJECT=0 / 1 forces it (tests, tuning).
+static bool partial_projects(const MapHeader& h, int k, uint32_t n_entities) {
+    if (const char* o = getenv("LLE_PARTIAL_PROJECT")) {
+        if ((o[0] == '0' || o[0] == '1') && !o[1]) return o[0] == '1';
+    }
+    const uint32_t a_pad = h.A <= 1 ? 1u : (h.A <= 2 ? 2u : (h.A <= 4 ? 4u : (h.A <= 8 ? 8u : 16u)));
+    const uint64_t pairs = (uint64_t)(n_entities + h.A) * a_pad, cells = (uint64_t)h.A * (uint32_t)(k * k);
+    return pairs <= cells * 3u / 2u + 80u;
+}
+
 hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t* out, int k, int64_t n_envs, bool per_env_sources,
-                                  MapSel M, hipStream_t stream) {
+                                  MapSel M, uint32_t n_entities, hipStream_t stream) {
     const uint32_t pitch = partial_pitch((int)h.A, k);
     const uint32_t As = (uint32_t)agent_stride_of((int)h.A, (int)h.L);
+    if (partial_projects(h, k, n_entities)) {
+        uint32_t epw = 16;  // level 6 7x7: 4 -> 36.8 us, 8 -> 30.2, 16 -> 28.7 (table build and static decode are per wavefront)
+        if (const char* o = getenv("LLE_PARTIAL_EPW")) {
+            const uint32_t v = (uint32_t)atoi(o);
+            if (v >= 1 && v <= OBS_ENVS_PER_WAVE && !(v & (v - 1))) epw = v;
+        }
+        const uint32_t ent_cap = n_entities;  // an upper bound computed by the host from the map(s)
+        const uint32_t rec_dwords = As / 2 + 1 + h.L + (uint32_t)src_stride_of((int)h.L) / 4u;
+        const uint32_t shared = (16u + ent_cap * 4u + 15u) & ~15u, priv = pitch + ((epw * rec_dwords * 4u + 15u) & ~15u);
+        uint32_t wpw = cap_wpw(4, M);
+        while (wpw > 1 && shared + wpw * priv > OBS_LDS_LIMIT) wpw >>= 1;
+        const uint32_t lds = shared + wpw * priv;
+        if (lds > OBS_LDS_LIMIT) return hipErrorInvalidValue;
+        static uint32_t granted_p = 0;
+        hipError_t e = grant_lds(reinterpret_cast<const void*>(&partial_project_kernel), lds, granted_p);
+        if (e != hipSuccess) return e;
+        const uint32_t n_waves = (uint32_t)((n_envs + epw - 1) / epw);
+        hipLaunchKernelGGL(partial_project_kernel, dim3((n_waves + wpw - 1) / wpw), dim3(64 * wpw), lds, stream, P, out, k, pitch,
+                           (int64_t)0, n_envs, per_env_sources ? 1 : 0, M, epw, ent_cap);
+        return hipGetLastError();
+    }
     // envs per wavefront: the chain of one env (clear, agents, cells, stream) is latency, so fewer envs per wave = more
     // waves in flight; measured at 65 536 envs, level 6 7x7: 16 -> 58 us, 8 -> 46, 4 -> 45, 2 -> 48; 32x32 maps (21 KB of
     // tables per workgroup) 7x7: 166 / 172 / 185 / 209 us, 3x3: 54 / 48 / 52 / 63.  LLE_PARTIAL_EPW: tuning override.

@@ -185,3 +185,40 @@ def test_unsupported_colour_raises_index_error():
         bw.observe_as(_capi.LLE_OBS_LAYERED)
     assert bw.observe_as(_capi.LLE_OBS_LAYERED_PADDED, 4).shape == (8, 14, 2, 3)  # 5 agent + 9 laser-and-fixed layers: colour 7 fits
     assert bw.observe_as(_capi.LLE_OBS_STATE).shape == (8, 3)
+
+
+@pytest.mark.parametrize("project", ["0", "1"])
+@pytest.mark.parametrize("name", ["level6", "nested", "colour_alias", "four_layers", "many_agents", "config5_32x32"])
+def test_partial_window_and_projection_kernels_agree_with_the_oracle(oracle_mod, monkeypatch, name, project):
+    """The partial k x k observation has two kernels -- per window cell (partial_observe_kernel) and per (entity, observer)
+    pair (partial_project_kernel) -- and the launcher picks by cost.  Force each (LLE_PARTIAL_PROJECT) on every map, every
+    window size, along a rollout with deaths, also with per-env source colours: both must match oracle/observers.py."""
+    import torch
+
+    from lle_amd import BatchedWorld, _capi
+    from oracle import observers as oo
+    from tests.parity_util import legal_colours
+
+    monkeypatch.setenv("LLE_PARTIAL_PROJECT", project)
+    text = MAPS[name]
+    n = 200
+    ob = oracle_mod.OracleBatch(text, n)
+    bw = BatchedWorld(text, n)
+    A, L = bw.map.n_agents, bw.map.n_sources
+    sizes = [k for k in (3, 5, 7) if bw.obs_desc(_capi.LLE_OBS_PARTIAL, k).supported]
+    rng = np.random.default_rng(5)
+    for t in range(12):
+        if t == 6 and L:  # per-environment colours from here on
+            colours = legal_colours(bw.map, rng.integers(0, A, size=(n, L), dtype=np.uint8))
+            bw.set_sources(torch.from_numpy(colours))
+            for e in range(n):
+                for l in range(L):
+                    ob.world(e).set_source(l, colour=int(colours[e, l]))
+            sizes = [k for k in (3, 5, 7) if bw.obs_desc(_capi.LLE_OBS_PARTIAL, k).supported]
+        bw.step(sample=True, auto_reset=(t % 4 == 3), seed=9, t=t)
+        ob.step(None, auto_reset=(t % 4 == 3), seed=9, t=t)
+        for k in sizes:
+            got = bw.observe_as(_capi.LLE_OBS_PARTIAL, k).cpu().numpy()
+            for e in range(0, n, 17):
+                want = oo.partial_observe(ob.world(e), k)
+                assert np.array_equal(got[e].astype(np.float32), want), (name, project, t, k, e)
