@@ -12,7 +12,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle as om  # noqa: E402  (test infrastructure: this tool is a checker, not product)
 from oracle.levels import LEVELS  # noqa: E402
-from tests.parity_util import EXTRA_MAPS, assert_state_equal, assert_step_equal, unpack_engine  # noqa: E402
+from tests.parity_util import EXTRA_MAPS, assert_state_equal, assert_step_equal, legal_colours, unpack_engine  # noqa: E402
 from lle_amd import BatchedWorld, mapgen  # noqa: E402
 
 import numpy as np  # noqa: E402
@@ -44,7 +44,7 @@ class Mirror:
 
 
 def redraw(bw, mirror, A, L, n):
-    colours = rng.integers(0, A, (n, L)).astype(np.uint8)
+    colours = legal_colours(bw.map, rng.integers(0, A, (n, L)).astype(np.uint8))  # (colours that cross a start are refused)
     enabled = (rng.integers(0, 1 << min(L, 30), n) | rng.integers(0, 2, n) * ((1 << L) - 1)).astype(np.int64) & ((1 << L) - 1)
     mask = (rng.random(n) < 0.5).astype(np.uint8)
     bw.set_sources(colours=torch.from_numpy(colours).cuda(), enabled=torch.from_numpy(enabled.astype(np.int32)).cuda(),
