@@ -205,7 +205,7 @@ def preroll(torch, dev, fn, seconds=PREROLL_SECONDS):
     return n
 
 
-def measure_config(torch, timer, dev, map_or_text, n_envs, algo_bytes, steps, label, traffic_key=None):
+def measure_config(torch, timer, dev, map_or_text, n_envs, algo_bytes, steps, label, traffic_key=None, fused=None):
     """One secondary configuration (N = 1): K single-step launches after a warm-up, HIP-event timed."""
     from lle_amd import BatchedWorld
     bw = BatchedWorld(map_or_text, n_envs, device=dev)
@@ -227,6 +227,21 @@ def measure_config(torch, timer, dev, map_or_text, n_envs, algo_bytes, steps, la
         "traffic": load_traffic(traffic_key) if traffic_key else None,
         "rollout_stats": bw.stats(),
     }
+    if fused:  # (T, R): the same rollout as lle_batch_rollout, T steps per launch into a ring of R slots
+        T, R = fused
+        ring = bw.make_ring(R)
+
+        def roll():
+            bw.rollout(T, auto_reset=True, seed=SEED, ring=ring, ring_pos=bw.t)
+        for _ in range(3):
+            roll()
+        launches = max(8, steps // T)
+        fw, _ = timer.run(roll, launches)
+        out["fused_rollout"] = {"steps_per_launch": T, "ring_slots": R, "ring_MB": R * rows / 1e6, "steps": launches * T,
+                                "ms_per_step": fw / (launches * T) * 1e3, "env_steps_per_s": n_envs * launches * T / fw,
+                                "agent_steps_per_s": m.n_agents * n_envs * launches * T / fw,
+                                "note": "a launch of 4 096 envs is launch-bound (min 4.7 us); several steps per launch are not"}
+        del ring
     del bw
     torch.cuda.empty_cache()
     return out
@@ -347,7 +362,8 @@ def main():
                              "hbm_regime_bytes_per_launch")
         cfgs = {
             "cfg2_level1_4096": measure_config(torch, timer, dev, Map(level=1), 4096, ALGO_BYTES_CFG2, max(k, 1000),
-                                               "BASELINE configs[1]: World.level(1), 1 agent, 4096 envs", "cfg2_bytes_per_launch"),
+                                               "BASELINE configs[1]: World.level(1), 1 agent, 4096 envs", "cfg2_bytes_per_launch",
+                                               fused=(64, 8)),
             "cfg5_32x32_a8_l8_65536": measure_config(torch, timer, dev, mapgen.config5(0), 65536, ALGO_BYTES_CFG5, k,
                                                      "BASELINE configs[4]: generated 32x32, 8 agents, 8 lasers (mapgen.config5(0)), 65536 envs",
                                                      "cfg5_bytes_per_launch"),
