@@ -73,6 +73,49 @@ class BatchedLLE:
         except KeyError:
             raise ValueError(f"Unknown observation type: {name}") from None
 
+    # ------------------------------------------------------------------ static description (env.py:72-143)
+    @property
+    def width(self):
+        return self.world.map.width
+
+    @property
+    def height(self):
+        return self.world.map.height
+
+    @property
+    def observation_shape(self):
+        """Per-env shape of `get_observation()` (the reference's `observation_shape`, without its tiled agent axis for the
+        kinds whose agents all see the same tensor)."""
+        return tuple(self._shape_of(self._obs_kind, self.obs_type, state=False))
+
+    @property
+    def state_shape(self):
+        """LLE.state_shape = get_state().shape (env.py:96): the state generator's observation of agent 0."""
+        return tuple(self._shape_of(self._state_kind, self.state_type, state=True))
+
+    def _shape_of(self, kind, name, state):
+        k, p = kind
+        m, A = self.world.map, self.n_agents
+        if k in (_capi.LLE_OBS_STATE, _capi.LLE_OBS_NORMALIZED_STATE):
+            return [3 * A + m.n_gems]
+        d = self.world.obs_desc(k, p)
+        shape = [int(d.shape[i]) for i in range(1, d.ndim)]
+        if state and k in (_capi.LLE_OBS_PARTIAL, _capi.LLE_OBS_PERSPECTIVE):
+            shape = shape[1:]  # agent 0's slice
+        if name == "flattened":
+            n = 1
+            for v in shape:
+                n *= v
+            return [n]
+        return shape
+
+    @property
+    def agent_state_size(self):
+        """StateGenerator.unit_size = 2 (i, j per agent; observations.py:174); other state types have none (env.py:135-140)."""
+        if self._state_kind[0] in (_capi.LLE_OBS_STATE, _capi.LLE_OBS_NORMALIZED_STATE):
+            return 2
+        raise NotImplementedError(f"State type {self.state_type} does not support `agent_state_size`.")
+
     # ------------------------------------------------------------------ LLE API, batched
     def seed(self, seed_value):
         """LLE.seed (env.py:245-247): seeds the colour randomisation (v1 maps have a single start per agent)."""

@@ -48,17 +48,30 @@ def _parse_error(e):
 
 
 # ------------------------------------------------------------------------------------------------ value types
-class Action(Enum):
-    """src/bindings/world/pyaction.rs:13-25"""
-    NORTH = 0
-    SOUTH = 1
-    EAST = 2
-    WEST = 3
-    STAY = 4
+class Action:
+    """src/bindings/world/pyaction.rs:13-88.  A value class like the PyO3 one, not a Python Enum: `Action(0) == Action.NORTH`,
+    equal hashes, but pickling / deep-copying gives a NEW equal object (`python/tests/test_actions.py:49-55` asserts
+    `a == b and a is not b`)."""
+    __slots__ = ("_value",)
+    _NAMES = ("NORTH", "SOUTH", "EAST", "WEST", "STAY")
 
-    @classmethod
-    def _missing_(cls, value):
-        raise ValueError(f"Invalid action value: {value}. Valid values for actions are between 0 and 4.")
+    def __init__(self, value):
+        if isinstance(value, Action):
+            value = value._value
+        if isinstance(value, bool) or not isinstance(value, (int, np.integer)) or not 0 <= int(value) <= 4:
+            raise ValueError(f"Invalid action value: {value}. Valid values for actions are between 0 and 4.")
+        object.__setattr__(self, "_value", int(value))
+
+    def __setattr__(self, key, val):
+        raise AttributeError("Action is immutable")
+
+    @property
+    def value(self):
+        return self._value
+
+    @property
+    def name(self):
+        return Action._NAMES[self._value]
 
     @staticmethod
     def variants():
@@ -70,10 +83,10 @@ class Action(Enum):
 
     @property
     def delta(self):
-        return {0: (-1, 0), 1: (1, 0), 2: (0, 1), 3: (0, -1), 4: (0, 0)}[self.value]  # src/action.rs:18-26
+        return {0: (-1, 0), 1: (1, 0), 2: (0, 1), 3: (0, -1), 4: (0, 0)}[self._value]  # src/action.rs:18-26
 
     def opposite(self):
-        return {0: Action.SOUTH, 1: Action.NORTH, 2: Action.WEST, 3: Action.EAST, 4: Action.STAY}[self.value]
+        return {0: Action.SOUTH, 1: Action.NORTH, 2: Action.WEST, 3: Action.EAST, 4: Action.STAY}[self._value]
 
     @staticmethod
     def from_delta(di, dj):
@@ -83,11 +96,34 @@ class Action(Enum):
             raise ValueError(f"Invalid delta: ({di}, {dj}). Valid deltas for actions are (-1, 0), (1, 0), (0, -1), or (0, 1).")
         return table[(di, dj)]
 
+    def __eq__(self, other):
+        return isinstance(other, Action) and self._value == other._value
+
+    def __ne__(self, other):
+        return not self == other
+
+    def __hash__(self):
+        return hash(("lle.Action", self._value))
+
+    def __int__(self):
+        return self._value
+
+    def __reduce__(self):
+        return (Action, (self._value,))
+
+    def __deepcopy__(self, memo):
+        return Action(self._value)
+
     def __repr__(self):
-        return _ACTION_DEBUG[self.value]
+        return _ACTION_DEBUG[self._value]
+
+    def __str__(self):
+        return self.name
 
 
 _ACTION_DEBUG = ["North", "South", "East", "West", "Stay"]
+for _v, _n in enumerate(Action._NAMES):
+    setattr(Action, _n, Action(_v))
 
 
 class EventType(Enum):

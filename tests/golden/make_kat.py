@@ -474,6 +474,16 @@ case("py_pickled_world_keeps_same_laser_ids", "python/tests/test_serialization.p
 # (SURVEY.md section 2 row 5).  Their v1 counterparts are py_laser_on_start_pos_error above and the get_state -> set_state
 # round trip of tests/test_gpu_env.py::test_set_state_round_trip_along_a_rollout.
 
+MAP_MULTI_DIGIT = " .   .   . . . .\n" + "".join(f"S{k} L{k}W . . . X\n" for k in range(14))
+case("parser_v1_multi_digit_agents_and_sources", "src/unit_tests/test_parser_v1.rs:22-57", map=MAP_MULTI_DIGIT,
+     static={"n_agents": 14, "n_sources": 14, "sources": [[k + 1, 1, k] for k in range(14)]},
+     script=[reset(), expect(sources=[[k + 1, 1, k] for k in range(14)])])
+# `S0` lies on the beam of colour 1 but BEHIND agent 1's only start, which blocks it: the start is kept and the world builds
+case("parser_v1_laser_blocked_on_spawn", "src/unit_tests/test_parser_v1.rs:80-98", map="\n    L1E . S1 S0 X\n    L0E .  .  . X\n    ",
+     static={"n_agents": 2, "start_pos": [[0, 3], [0, 2]]}, script=[reset(), expect(alive=[True, True])])
+# NOT transcribable as they stand: test_parser_v1.rs:5-20 parse `S10 X` / `L10E S0 ... S10 X` to a CONFIG only (they would not
+# survive into_world: ten agents without start / one exit for eleven agents); the map above covers multi-digit ids end to end.
+
 if __name__ == "__main__":
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kat_world.json")
     with open(out, "w") as f:

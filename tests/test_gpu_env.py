@@ -260,3 +260,32 @@ def test_set_state_round_trip_along_a_rollout(oracle_mod):
             assert torch.equal(probe.world.pos[ok], pos[ok]) and torch.equal(probe.world.gems_collected()[ok], gems[ok])
             assert torch.equal(probe.world.agents_alive()[ok], alive[ok])
             assert torch.equal(probe.get_state()[ok], env.get_state()[ok])
+
+
+def test_env_static_description():
+    """python/tests/test_core.py:71-114 (width / height, default and flattened state shapes), :195-201 (agent_state_size),
+    :238-241 (n_agents), :204-235 (observation types by string and by enum value)."""
+    from lle_amd import BatchedLLE
+    from lle_amd.observations import ObservationType
+
+    env = BatchedLLE("S0 X .\n.  . .\n.  . .", 4)
+    assert (env.width, env.height) == (3, 3)
+    assert BatchedLLE("S0 X . .\n.  . . .\nG  . . .", 4).width == 4
+    assert env.state_shape == (env.n_agents * 3 + env.world.map.n_gems,)
+    env.reset()
+    assert tuple(env.get_state().shape[1:]) == env.state_shape
+    flat = BatchedLLE("S0 X .\n.  . .\n.  . .", 4, state_type=ObservationType.FLATTENED.value)
+    assert flat.state_shape == (int(np.prod(flat.state_shape)),)
+    flat.reset()
+    assert tuple(flat.get_state().shape[1:]) == flat.state_shape == (6 * 3 * 3,)
+    assert BatchedLLE(LEVELS[1], 4).agent_state_size == 2
+    with pytest.raises((ValueError, NotImplementedError)):
+        BatchedLLE(LEVELS[1], 4, state_type="flattened").agent_state_size
+    assert BatchedLLE("S0 S1 X X", 4).n_agents == 2 and BatchedLLE(LEVELS[6], 4).n_agents == 4
+    for name, member in (("layered", ObservationType.LAYERED), ("flattened", ObservationType.FLATTENED), ("partial3x3", ObservationType.PARTIAL_3x3),
+                         ("partial5x5", ObservationType.PARTIAL_5x5), ("partial7x7", ObservationType.PARTIAL_7x7), ("state", ObservationType.STATE),
+                         ("perspective", ObservationType.AGENT0_PERSPECTIVE_LAYERED)):
+        a, b = BatchedLLE(LEVELS[1], 4, obs_type=name), BatchedLLE(LEVELS[1], 4, obs_type=member.value)
+        assert a.observation_shape == b.observation_shape and a.state_shape == b.state_shape
+        a.reset()
+        assert tuple(a.get_observation().shape[1:]) == a.observation_shape, name

@@ -1,0 +1,82 @@
+"""The reference's value-type tests replayed on the facade's types (no GPU needed): python/tests/test_actions.py (all of
+it), python/tests/test_world.py:606-640 (WorldState subclassing / constructor), python/tests/test_serialization.py:9-16.
+The types are API surface of the drop-in (`lle_amd.Action`, `lle_amd.WorldState`), not the hot path; the reference
+file:line of every assertion is given."""
+import copy
+import pickle
+
+import pytest
+
+from lle_amd import Action, WorldState
+
+
+def test_action_equality_count_names_hash():   # test_actions.py:4-38
+    assert Action.NORTH == Action.NORTH
+    assert Action(0) == Action(0)
+    values = [Action.NORTH, Action.SOUTH, Action.EAST, Action.WEST, Action.WEST]
+    assert [values.count(a) for a in (Action.NORTH, Action.SOUTH, Action.EAST, Action.WEST)] == [1, 1, 1, 2]
+    assert {a.name for a in Action.variants()} == {"NORTH", "SOUTH", "EAST", "WEST", "STAY"}
+    hashes, actions = set(), set()
+    for a in Action.variants():
+        assert hash(a) == hash(a)
+        hashes.add(hash(a))
+        actions.add(a)
+    assert len(hashes) == len(actions) == 5
+
+
+def test_action_deepcopy_and_pickle_give_new_equal_objects():   # test_actions.py:41-55
+    for a in Action.variants():
+        assert copy.deepcopy(a) == a
+        b = pickle.loads(pickle.dumps(a))
+        assert a == b
+        assert a is not b
+
+
+def test_action_from_delta_uses_dx_dy():   # test_actions.py:58-110 (quirk Q8: (dx, dy), not (di, dj))
+    assert Action.from_delta(0, 0) == Action.STAY
+    assert Action.from_delta(0, -1) == Action.NORTH
+    assert Action.from_delta(0, 1) == Action.SOUTH
+    assert Action.from_delta(1, 0) == Action.EAST
+    assert Action.from_delta(-1, 0) == Action.WEST
+    for delta in [(2, 0), (-2, 0), (0, 2), (0, -2), (1, 1), (-1, 1), (1, -1), (-1, -1), (5, 3)]:
+        with pytest.raises(ValueError):
+            Action.from_delta(*delta)
+    assert Action.NORTH.delta == (-1, 0) and Action.EAST.delta == (0, 1)   # Action.delta is (di, dj): src/action.rs:18-26
+
+
+def test_action_values_and_invalid_values():   # pyaction.rs:13-25,40-52
+    assert [a.value for a in Action.variants()] == [0, 1, 2, 3, 4] and Action.cardinality() == 5
+    for bad in (5, -1, 23):
+        with pytest.raises(ValueError):
+            Action(bad)
+    assert Action.NORTH.opposite() == Action.SOUTH and Action.STAY.opposite() == Action.STAY
+
+
+def test_subclass_world_state():   # test_world.py:606-623
+    class WS(WorldState):
+        def __init__(self, other, agents_positions, gems_collected, agents_alive=None):
+            super().__init__(agents_positions, gems_collected=gems_collected, agents_alive=agents_alive)
+            self.other = other
+
+    s1, s2 = WS(4, [(0, 0)], [False], [True]), WS(5, [(0, 0)], [False], [True])
+    assert s1 == s2
+
+
+def test_world_state_constructor():   # test_world.py:633-640
+    assert all(WorldState([(0, 0)], [False]).agents_alive)
+    assert all(WorldState([(0, 0)], [True], [True]).agents_alive)
+    assert WorldState([(0, 0), (1, 1)], [True], [False, True]).agents_alive == [False, True]
+
+
+def test_subclass_world_and_standard_levels_parse_without_a_gpu():   # test_world.py:626-630, :447-451; test_world.rs:438-453
+    from lle_amd import World
+
+    class W(World):
+        pass
+
+    assert W("S0 . X").width == 3
+    for i in range(1, 7):
+        a, b, c = World.level(i), World.from_file(f"lvl{i}"), World.from_file(f"level{i}")
+        assert a.world_string == b.world_string == c.world_string and a.n_agents == b.n_agents
+    with pytest.raises(FileNotFoundError):
+        World.from_file("no/such/file.toml")
