@@ -341,6 +341,14 @@ typedef struct lle_env_outputs {
 } lle_env_outputs;
 int lle_batch_env_outputs(lle_batch* b, const lle_env_outputs* out, void* stream);
 
+/* LLE.step in ONE launch (python/lle/env/env.py:165-187): lle_batch_step with the outputs of lle_batch_env_outputs written
+ * by the step kernel itself, from registers (the separate launch costs 4.9 us at 65 536 envs, all of it launch boundary).
+ * Same results as the two calls in a row.  `out->available` needs walkable_lasers != 0 (LLE_ERR_UNSUPPORTED otherwise: the
+ * mask without moves into foreign beams reads the neighbours' laser stacks -- use lle_batch_env_outputs for it).
+ * The struct is mirrored in device memory and re-uploaded only when it changes: keep the output buffers across steps. */
+int lle_batch_step_outputs(lle_batch* b, const uint8_t* actions_dev, uint32_t flags, uint64_t seed, uint64_t t, int64_t env_offset,
+                           const lle_env_outputs* out, void* stream);
+
 /* Sum the per-block counters (synchronises `stream`):
  * out[0] env_steps, [1] agent_steps, [2] gems, [3] exits, [4] deaths, [5] invalid, [6] auto_resets, [7] reward_sum */
 int lle_batch_stats(lle_batch* b, int64_t out[8], int reset_counters, void* stream);

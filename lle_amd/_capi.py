@@ -40,7 +40,7 @@ EXPORTS = [
     "lle_batch_arena_bytes", "lle_batch_create", "lle_batch_arena_bytes_multi", "lle_batch_create_multi", "lle_batch_n_maps", "lle_batch_free", "lle_batch_get_buffer", "lle_batch_n_envs",
     "lle_batch_reset", "lle_batch_step", "lle_batch_rollout", "lle_batch_set_state", "lle_batch_update_sources", "lle_batch_observe",
     "lle_batch_snapshot_bytes", "lle_batch_snapshot", "lle_batch_restore",
-    "lle_batch_set_sources", "lle_batch_reset_sources", "lle_batch_obs_desc", "lle_batch_observe_as", "lle_batch_available_actions", "lle_batch_env_outputs",
+    "lle_batch_set_sources", "lle_batch_reset_sources", "lle_batch_obs_desc", "lle_batch_observe_as", "lle_batch_available_actions", "lle_batch_env_outputs", "lle_batch_step_outputs",
     "lle_batch_stats", "lle_batch_kernel_info", "lle_batch_set_envs_per_wave", "lle_batch_step_stamped",
 ]
 
@@ -172,6 +172,8 @@ def lib():
     L.lle_batch_available_actions.argtypes = [vp, i32, vp, vp]
     L.lle_batch_env_outputs.restype = i32
     L.lle_batch_env_outputs.argtypes = [vp, C.POINTER(EnvOutputs), vp]
+    L.lle_batch_step_outputs.restype = i32
+    L.lle_batch_step_outputs.argtypes = [vp, vp, u32, u64, u64, i64, C.POINTER(EnvOutputs), vp]
     L.lle_batch_stats.restype = i32
     L.lle_batch_stats.argtypes = [vp, C.POINTER(C.c_int64), i32, vp]
     L.lle_batch_kernel_info.restype = i32

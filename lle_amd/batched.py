@@ -142,8 +142,9 @@ class BatchedWorld:
         self._check(_capi.lib().lle_batch_reset(self.h, mp, self._stream()))
         self.t = 0
 
-    def step(self, actions=None, sample=False, auto_reset=False, seed=0, t=None, env_offset=0, write_obs=True):
-        """World.step + Layered.observe for every env.
+    def step(self, actions=None, sample=False, auto_reset=False, seed=0, t=None, env_offset=0, write_obs=True, env_out=None):
+        """World.step + Layered.observe for every env.  env_out: an `_capi.EnvOutputs` (make_env_outputs) whose tensors the
+        step kernel fills in the same launch (lle_batch_step_outputs: LLE.step's state / reward / done / available / ...).
 
         actions: uint8 tensor [n, A] on the device (Action values), or None with sample=True to draw uniformly from the
         available actions with the counter-based sampler (seed, env_offset + env, t, agent)."""
@@ -165,7 +166,10 @@ class BatchedWorld:
             flags |= LLE_STEP_NO_OBS
         if t is None:
             t = self.t
-        self._check(_capi.lib().lle_batch_step(self.h, ap, flags, int(seed), int(t), int(env_offset), self._stream()))
+        if env_out is not None:
+            self._check(_capi.lib().lle_batch_step_outputs(self.h, ap, flags, int(seed), int(t), int(env_offset), C.byref(env_out), self._stream()))
+        else:
+            self._check(_capi.lib().lle_batch_step(self.h, ap, flags, int(seed), int(t), int(env_offset), self._stream()))
         self.t = t + 1
 
     def make_ring(self, slots):
@@ -273,6 +277,17 @@ class BatchedWorld:
             out = torch.empty((self.n_envs, self.map.n_agents, 5), dtype=torch.uint8, device=self.device)
         self._check(_capi.lib().lle_batch_available_actions(self.h, int(bool(walkable_lasers)), out.data_ptr(), self._stream()))
         return out.view(torch.bool)
+
+    def make_env_outputs(self, state=None, normalize_state=False, reward=None, multi_objective=False, done=None, available=None,
+                         walkable_lasers=True, alive=None, arrived=None):
+        """The lle_env_outputs struct over the given device tensors (None = not wanted); see env_outputs for the shapes."""
+        o = _capi.EnvOutputs()
+        for name, t in (("state", state), ("reward", reward), ("done", done), ("available", available), ("alive", alive), ("arrived", arrived)):
+            if t is not None:
+                assert t.is_contiguous() and t.device == self.device, name
+                setattr(o, name, t.data_ptr())
+        o.normalize_state, o.reward_kind, o.walkable_lasers = int(bool(normalize_state)), int(bool(multi_objective)), int(bool(walkable_lasers))
+        return o
 
     def env_outputs(self, state=None, normalize_state=False, reward=None, multi_objective=False, done=None, available=None,
                     walkable_lasers=True, alive=None, arrived=None):

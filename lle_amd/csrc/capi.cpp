@@ -48,6 +48,7 @@ struct Layout {
     int64_t off_init;
     int64_t table_stride;     // bytes between the table blobs of consecutive maps
     int64_t off_env_init[5];  // per-env reset state (pos, bits, gems, beams, avail), used with per-env sources
+    int64_t off_env_out;      // device copy of the EnvOutputs of lle_batch_step_outputs (64 B)
     int64_t total;
     int64_t n_stat_blocks;
 };
@@ -94,6 +95,8 @@ Layout make_layout(const MapHeader& h, int64_t n, int64_t n_maps = 1) {
         l.off_env_init[k] = off;
         off = align_up(off + init_sz[k]);
     }
+    l.off_env_out = off;
+    off = align_up(off + (int64_t)sizeof(EnvOutputs));
     l.total = off;
     return l;
 }
@@ -119,6 +122,9 @@ struct lle_batch {
     // (one per map, `stride` bytes apart), keyed by (kind, param); dropped when the sources change
     struct View { ViewHeader hdr; uint8_t* dev; uint32_t stride; };
     std::map<std::pair<int, int>, View> views;
+    // lle_batch_step_outputs: what the device copy of the EnvOutputs holds (re-uploaded only when the caller's struct changes)
+    EnvOutputs env_out_host{};
+    bool env_out_valid = false;
 };
 
 extern "C" {
@@ -535,6 +541,27 @@ int lle_batch_step(lle_batch* b, const uint8_t* actions_dev, uint32_t flags, uin
     if (!b) return fail(LLE_ERR_NULL, "NULL batch");
     LaunchArgs K{};
     K.flags = flags; K.seed = seed; K.t = t; K.env_offset = env_offset; K.actions_in = actions_dev;
+    return launch(b, KMODE_STEP, K, stream);
+}
+
+int lle_batch_step_outputs(lle_batch* b, const uint8_t* actions_dev, uint32_t flags, uint64_t seed, uint64_t t, int64_t env_offset,
+                           const lle_env_outputs* out, void* stream) {
+    if (!b || !out) return fail(LLE_ERR_NULL, "NULL argument");
+    if (out->reward_kind != 0 && out->reward_kind != 1) return fail(LLE_ERR_ARG, "reward_kind must be 0 (single objective) or 1 (multi objective)");
+    if (out->available && !out->walkable_lasers)
+        return fail(LLE_ERR_UNSUPPORTED, "the fused step writes LLE.available_actions with walkable_lasers only: use lle_batch_env_outputs");
+    if (b->lane_per_env_step) return fail(LLE_ERR_ARG, "the fused outputs are written by the default step kernel only");
+    HIP_TRY(hipSetDevice(b->device));
+    const EnvOutputs O{out->state, out->reward, out->done, out->available, out->alive, out->arrived,
+                       out->normalize_state, out->reward_kind, out->walkable_lasers, b->per_env_sources ? 1 : 0};
+    EnvOutputs* dev = reinterpret_cast<EnvOutputs*>(b->arena + b->layout.off_env_out);
+    if (!b->env_out_valid || std::memcmp(&O, &b->env_out_host, sizeof O) != 0) {
+        b->env_out_host = O;  // (the source of the copy must outlive it: a member, not the stack)
+        HIP_TRY(hipMemcpyAsync(dev, &b->env_out_host, sizeof O, hipMemcpyHostToDevice, (hipStream_t)stream));
+        b->env_out_valid = true;
+    }
+    LaunchArgs K{};
+    K.flags = flags; K.seed = seed; K.t = t; K.env_offset = env_offset; K.actions_in = actions_dev; K.env_out = dev;
     return launch(b, KMODE_STEP, K, stream);
 }
 

@@ -42,15 +42,6 @@ uint32_t partial_pitch(int A, int k);
 hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t* out, int k, int64_t n_envs, bool per_env_sources,
                                   MapSel M, uint32_t n_entities, hipStream_t stream);
 hipError_t launch_state_observe(const MapHeader& h, const BatchPtrs& P, float* out, int normalize, int64_t n_envs, hipStream_t stream);
-struct EnvOutputs {  // lle_env_outputs (include/lle_hip.h) as the kernel sees it
-    float* state;
-    float* reward;
-    uint8_t* done;
-    uint8_t* available;
-    uint8_t* alive;
-    uint8_t* arrived;
-    int32_t normalize_state, reward_kind, walkable_lasers, per_env_sources;
-};
 hipError_t launch_env_outputs(const MapHeader& h, const BatchPtrs& P, const EnvOutputs& O, int64_t n_envs, MapSel M, hipStream_t stream);
 hipError_t launch_avail(const MapHeader& h, const BatchPtrs& P, uint8_t* out, int walkable_lasers, int64_t n_envs, bool per_env_sources,
                         MapSel M, hipStream_t stream);

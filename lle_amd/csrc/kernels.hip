@@ -528,7 +528,8 @@ hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const Laun
         const uint64_t slots = K.ring_slots ? (K.n_steps < K.ring_slots ? (K.n_steps ? K.n_steps : 1u) : K.ring_slots) : 1u;
         if (write_through_pays((uint64_t)(K.env_limit - K.env_base) * h.obs_stride * slots, h.obs_stride)) K.flags |= LAUNCH_WRITE_THROUGH;
     }
-    if (pes || K.envs_per_map) K.flags |= LAUNCH_GENERAL;
+    if (pes || K.envs_per_map || K.env_out) K.flags |= LAUNCH_GENERAL;  // (fused LLE.step outputs: MODE 4 / 5 carry the epilogue)
+    if (K.env_out && (K.n_steps > 1 || K.ring_slots || K.stamps)) return hipErrorInvalidValue;  // single steps only
     if (K.n_steps > 1 || K.ring_slots || K.stamps) K.flags |= LAUNCH_ROLLOUT;
     if (h.max_layers <= 1) K.flags |= LAUNCH_SINGLE_LAYER;  // several maps: `h` carries the maximum over the maps
     uint32_t wpw = kernel_waves_per_wg(h, pes);

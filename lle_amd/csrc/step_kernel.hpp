@@ -288,6 +288,59 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         cnt.steps += 1u; cnt.gems += n_gem; cnt.exits += n_exit; cnt.died += n_died;
         cnt.invalid += err != 0 ? 1u : 0u; cnt.resets += was_reset; cnt.bonus += bonus;
     }
+    // ---- LLE.step's other outputs (python/lle/env/env.py:165-187), fused: what lle_batch_env_outputs writes in a launch
+    // of its own (4.9 us at 65 536 envs, all of it launch boundary), written here from registers.  walkable_lasers only
+    // (the availability without moves into foreign beams needs the neighbours' laser stacks: lle_batch_env_outputs).
+    // Only the general single-step instantiations (MODE 4 / 5) carry it -- the launcher routes a launch with outputs there --
+    // so that the default path keeps its registers (with the epilogue in MODE 0: 112 -> 127 VGPRs and 21.2 -> 21.6 us
+    // for launches that do not even use it).
+    if (MODE >= 4 && K.env_out) {
+        const EnvOutputs O = *K.env_out;  // uniform address: scalar loads
+        const int n_gems = (int)hdr->G, len = 3 * A + n_gems;
+        if (me) {
+            const int64_t ia = env * A + a;
+            if (O.alive) O.alive[ia] = (uint8_t)((alive >> a) & 1u);
+            if (O.arrived) O.arrived[ia] = (uint8_t)((arrived >> a) & 1u);
+            if (O.available) {
+                uint8_t* o = O.available + ia * 5;
+#pragma unroll
+                for (int k = 0; k < 5; k++) o[k] = (uint8_t)((avail >> k) & 1u);
+            }
+            if (O.state) {  // WorldState.as_array: [i0, j0, ..., gems..., alive...] (pyworld_state.rs:79-101)
+                float* st = O.state + env * len;
+                float fi = (float)(pos & 0xFFu), fj = (float)(pos >> 8);
+                if (O.normalize_state) {  // divided in float64, rounded to float32 on assignment (observations.py:145-175)
+                    fi = (float)((double)(pos & 0xFFu) / (double)hdr->H);
+                    fj = (float)((double)(pos >> 8) / (double)hdr->W);
+                }
+                st[2 * a] = fi;
+                st[2 * a + 1] = fj;
+                st[2 * A + n_gems + (int)a] = ((alive >> a) & 1u) ? 1.0f : 0.0f;
+            }
+        }
+        if (env_ok && O.state)
+            for (int g = (int)a; g < n_gems; g += G) O.state[env * len + 2 * A + g] = ((gems >> g) & 1u) ? 1.0f : 0.0f;
+        if (env_ok && a == 0) {
+            if (O.done) O.done[env] = (alive != amask || arrived == amask) ? 1 : 0;
+            if (O.reward) {
+                uint32_t n_died = 0, n_gem = 0;
+#pragma unroll
+                for (int k = 0; k < NW; k++) {
+                    n_died += (uint32_t)__popcll(evw[k] & 0x2020202020202020ull);
+                    n_gem += (uint32_t)__popcll(evw[k] & 0x1010101010101010ull);
+                }
+                const float gem = (float)n_gem, died = (float)n_died, ex = (float)(n_ev - n_died - n_gem);
+                const float bonus = (err == 0 && arrived == amask) ? 1.0f : 0.0f;
+                if (O.reward_kind == 0) {
+                    O.reward[env] = gem + ex - died + bonus;  // reward_strategy.py:58-75
+                } else {                                      // reward_strategy.py:90-109: a death zeroes the others
+                    const bool dead = n_died > 0;
+                    float* o = O.reward + env * 4;
+                    o[0] = dead ? 0.f : gem; o[1] = dead ? 0.f : ex; o[2] = -died; o[3] = dead ? 0.f : bonus;
+                }
+            }
+        }
+    }
     };  // post_step
 
     if (env_ok && a == 0) {

@@ -134,6 +134,17 @@ constexpr uint32_t ELEM_SOURCE = 0, ELEM_TILE = 1, ELEM_GEM = 2;
 // ---- event codes
 constexpr uint32_t EV_EXIT = 0, EV_GEM = 1, EV_DIED = 2;
 
+// lle_env_outputs (include/lle_hip.h) as the kernels see it: everything LLE.step returns besides the observation.
+struct EnvOutputs {
+    float* state;
+    float* reward;
+    uint8_t* done;
+    uint8_t* available;
+    uint8_t* alive;
+    uint8_t* arrived;
+    int32_t normalize_state, reward_kind, walkable_lasers, per_env_sources;
+};
+
 // Per-launch arguments.
 struct LaunchArgs {
     uint32_t flags;            // STEP_*
@@ -163,6 +174,9 @@ struct LaunchArgs {
     int64_t envs_per_map;
     uint32_t table_stride, map_override;
     uint32_t n_sources, pad3;  // host side only: MapHeader.L, for the launcher's choice of instantiation
+    // step_kernel only: write LLE.step's other outputs in the same launch (lle_batch_step_outputs).  A DEVICE copy of the
+    // struct, read with scalar loads where it is used: its six pointers never occupy registers during the state machine.
+    const EnvOutputs* env_out;
 };
 
 // State of a freshly reset environment (identical for every env of a map: v1 maps have one start per agent).

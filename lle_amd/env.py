@@ -61,6 +61,7 @@ class BatchedLLE:
         self._gen = torch.Generator(device=self.world.device)
         self._gen.manual_seed(int(seed))
         self._t = 0
+        self._fused = None  # output tensors + lle_env_outputs of the one-launch step (step(..., fused=True))
 
     @staticmethod
     def _kind(name, padding_size):
@@ -201,8 +202,25 @@ class BatchedLLE:
         self.world.env_outputs(reward=reward, multi_objective=self.multi_objective)
         return reward
 
-    def step(self, actions, auto_reset=False):
+    def _fused_outputs(self):
+        """Persistent output tensors of the one-launch step and the struct over them (lle_batch_step_outputs mirrors the
+        struct on the device and re-uploads it only when it changes)."""
+        if self._fused is None:
+            w, n, dev = self.world, self.n_envs, self.world.device
+            fused_state = self._state_kind[0] in (_capi.LLE_OBS_STATE, _capi.LLE_OBS_NORMALIZED_STATE)
+            t = {"state": torch.empty((n, 3 * self.n_agents + w.map.n_gems), dtype=torch.float32, device=dev) if fused_state else None,
+                 "reward": torch.empty((n, 4 if self.multi_objective else 1), dtype=torch.float32, device=dev),
+                 "available": torch.empty((n, self.n_agents, 5), dtype=torch.uint8, device=dev)}
+            o = w.make_env_outputs(state=t["state"], normalize_state=self._state_kind[0] == _capi.LLE_OBS_NORMALIZED_STATE, reward=t["reward"],
+                                   multi_objective=self.multi_objective, available=t["available"], walkable_lasers=True)
+            self._fused = (t, o)
+        return self._fused
+
+    def step(self, actions, auto_reset=False, fused=False):
         """LLE.step (env.py:165-187) for every env.  actions: integer tensor [n, n_agents] (Action values).
+        fused=True (needs walkable_lasers): state / reward / available_actions are written by the step kernel itself
+        (lle_batch_step_outputs) into PERSISTENT tensors that the next step overwrites -- one launch per step instead of
+        two (26.3 -> 21.6 us at 65 536 level-6 envs); the default returns fresh tensors every step.
         The reference refuses to step a finished environment (`Cannot step in a done environment`); here such an env
         is the caller's to reset -- or pass auto_reset=True: an env that is done when the step starts is reset first
         (with fresh colours under randomize_lasers), the usual vector-env convention.
@@ -211,16 +229,23 @@ class BatchedLLE:
         World.step: 0 or 1 + the agent whose action was not available, the env then being left untouched)."""
         w = self.world
         actions = actions.to(w.device, torch.uint8).contiguous()
+        if fused and not self.walkable_lasers:
+            raise ValueError("the one-launch step writes available_actions with walkable_lasers only")
+        env_out = self._fused_outputs()[1] if fused else None
         if auto_reset:
             if self.randomize_lasers:
                 # (the kernel reads an env's mask byte before it rewrites its `done`; the step rewrites the observation)
                 self._reset_world(w.done, write_obs=False)
-                w.step(actions, write_obs=self._needs_layered)
+                w.step(actions, write_obs=self._needs_layered, env_out=env_out)
             else:
-                w.step(actions, auto_reset=True, write_obs=self._needs_layered)
+                w.step(actions, auto_reset=True, write_obs=self._needs_layered, env_out=env_out)
         else:
-            w.step(actions, write_obs=self._needs_layered)
+            w.step(actions, write_obs=self._needs_layered, env_out=env_out)
         self._t += 1
+        if fused:
+            t = self._fused[0]
+            return {"obs": self.get_observation(), "state": t["state"] if t["state"] is not None else self.get_state(), "reward": t["reward"],
+                    "done": self.done, "available_actions": t["available"].view(torch.bool), "err": w.err}
         return self._outputs()
 
     def _outputs(self):

@@ -289,3 +289,67 @@ def test_env_static_description():
         assert a.observation_shape == b.observation_shape and a.state_shape == b.state_shape
         a.reset()
         assert tuple(a.get_observation().shape[1:]) == a.observation_shape, name
+
+
+@pytest.mark.parametrize("name", ["level1", "level6", "nested", "many_agents", "config5_32x32"])
+@pytest.mark.parametrize("variant", ["plain", "normalized_multi", "per_env_sources", "two_maps"])
+def test_one_launch_step_equals_step_plus_env_outputs(name, variant):
+    """lle_batch_step_outputs (the step kernel writes LLE.step's state / reward / done / available / alive / arrived itself)
+    against lle_batch_step followed by lle_batch_env_outputs, on twin batches: explicit actions with refused ones, sampled
+    actions with auto-reset, every output bit for bit (float32 bit patterns), in the default, rollout-free general modes."""
+    import torch
+
+    from lle_amd import BatchedWorld
+
+    text = LEVELS[int(name[-1])] if name.startswith("level") else EXTRA_MAPS[name]
+    n = 640
+    maps = [text, text] if variant == "two_maps" else text
+    a, b = BatchedWorld(maps, n), BatchedWorld(maps, n)
+    A, G, L = a.map.n_agents, a.map.n_gems, a.map.n_sources
+    if variant == "per_env_sources" and L:
+        g = torch.Generator(device="cuda").manual_seed(2)
+        colours = legal_colours(a.map, torch.randint(0, A, (n, L), generator=g, device="cuda", dtype=torch.uint8))
+        for w in (a, b):
+            w.set_sources(colours=colours)
+    norm, multi = variant == "normalized_multi", variant == "normalized_multi"
+
+    def outs():
+        return dict(state=torch.full((n, 3 * A + G), -7.0, device="cuda"), reward=torch.full((n, 4 if multi else 1), -7.0, device="cuda"),
+                    done=torch.full((n,), 9, dtype=torch.uint8, device="cuda"), available=torch.full((n, A, 5), 9, dtype=torch.uint8, device="cuda"),
+                    alive=torch.full((n, A), 9, dtype=torch.uint8, device="cuda"), arrived=torch.full((n, A), 9, dtype=torch.uint8, device="cuda"))
+    ta, tb = outs(), outs()
+    oa = a.make_env_outputs(normalize_state=norm, multi_objective=multi, **ta)
+    rng = np.random.default_rng(1)
+    for t in range(30):
+        if t % 3 == 0:
+            acts = torch.from_numpy(rng.integers(0, 6, size=(n, A), dtype=np.uint8)).cuda()  # unavailable and invalid ones included
+            a.step(acts, env_out=oa)
+            b.step(acts)
+        else:
+            a.step(sample=True, auto_reset=(t % 2 == 0), seed=3, t=t, env_out=oa)
+            b.step(sample=True, auto_reset=(t % 2 == 0), seed=3, t=t)
+        b.env_outputs(normalize_state=norm, multi_objective=multi, **tb)
+        for k in ta:
+            x, y = ta[k], tb[k]
+            same = torch.equal(x.view(torch.int32), y.view(torch.int32)) if x.dtype == torch.float32 else torch.equal(x, y)
+            assert same, (name, variant, t, k)
+        for k in ("pos", "bits", "gems", "beams", "avail", "err", "evcount", "events", "done", "obs", "reward"):
+            assert torch.equal(getattr(a, k), getattr(b, k)), (name, variant, t, k)
+
+
+def test_batched_lle_one_launch_step():
+    import torch
+
+    from lle_amd import BatchedLLE
+
+    n = 512
+    a, b = BatchedLLE(LEVELS[6], n, multi_objective=True), BatchedLLE(LEVELS[6], n, multi_objective=True)
+    a.reset()
+    b.reset()
+    for t in range(25):
+        acts = a.available_actions().to(torch.uint8).argmax(dim=2).to(torch.uint8)  # first available action of every agent
+        x, y = a.step(acts, auto_reset=True, fused=True), b.step(acts, auto_reset=True)
+        for k in ("obs", "state", "reward", "done", "available_actions", "err"):
+            assert torch.equal(x[k], y[k]), (t, k)
+    with pytest.raises(ValueError):
+        BatchedLLE(LEVELS[6], n, walkable_lasers=False).step(acts, fused=True)

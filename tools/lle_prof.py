@@ -185,7 +185,8 @@ def cmd_env(args):
         w = env.world
         acts = torch.full((n, env.n_agents), 4, dtype=torch.uint8, device=w.device)
         t = lambda f: timeit(f, iters=200, warm=20)  # noqa: E731
-        print(f"{kw}: step(auto_reset) {t(lambda: env.step(acts, auto_reset=True)):.1f} us | world.step {t(lambda: w.step(acts, auto_reset=True)):.1f}"
+        fused = f"{t(lambda: env.step(acts, auto_reset=True, fused=True)):.1f}" if env.walkable_lasers else "n/a"
+        print(f"{kw}: step(auto_reset) {t(lambda: env.step(acts, auto_reset=True)):.1f} us (one launch: {fused}) | world.step {t(lambda: w.step(acts, auto_reset=True)):.1f}"
               f" | get_state {t(env.get_state):.1f} | reward {t(env.reward):.1f} | done {t(lambda: env.done):.1f}"
               f" | available_actions {t(env.available_actions):.1f} | get_observation {t(env.get_observation):.1f}", flush=True)
 
