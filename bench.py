@@ -47,7 +47,7 @@ ALGO_BYTES_CFG5 = 20617    # 32x32, 8 agents, 8 sources: 20480 + 104 + 8 + 8 + 1
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 INFINITY_CACHE_BYTES = 256 << 20
 HBM_REGIME_ENVS = 262144   # rows of one launch: 491 MB > Infinity Cache
-PREROLL_SECONDS = 0.25     # untimed launches that bring the clocks up before the warm-up (reported as preroll_steps)
+PREROLL_SECONDS = 1.0      # untimed launches that bring the clocks up before the warm-up (reported as preroll_steps)
 
 
 def host_cores():
