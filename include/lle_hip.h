@@ -141,7 +141,8 @@ size_t lle_map_world_string(const lle_map* map, char* buf, size_t cap);
 
 enum {
     LLE_BUF_POS = 0,   /* u8  [n][A][2]   (i, j) of every agent               World.agents_positions */
-    LLE_BUF_BITS,      /* u64 [n]         alive bits 0-15 | arrived 16-31 | occupant 32-47 */
+    LLE_BUF_BITS,      /* u64 [n]         alive bits 0-15 | arrived 16-31 | occupant 32-47 | 48-63: dead by set_state without an
+                          AgentDied event (LLE.compute_done counts events: such an agent does not end the episode) */
     LLE_BUF_GEMS,      /* u32 [n]         bit g = gem g collected (parse order; World.gems) */
     LLE_BUF_BEAMS,     /* u32 [n][L]      bit k = beam of source l is on at offset k (LaserBeam, laser.rs:15-21) */
     LLE_BUF_AVAIL,     /* u8  [n][A]      bit a = Action a available (World.available_actions) */

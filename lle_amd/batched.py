@@ -29,7 +29,7 @@ class BatchedWorld:
     """n_envs independent `World`s of one map stepped by one kernel launch.
 
     Attributes (torch tensors on `device`, views into one arena):
-      pos [n,A,2] u8 (i,j) - bits [n] i64 (alive 0-15 | arrived 16-31 | occupant 32-47) - gems [n] i32 (bit g collected)
+      pos [n,A,2] u8 (i,j) - bits [n] i64 (alive 0-15 | arrived 16-31 | occupant 32-47 | 48-63 set_state bookkeeping) - gems [n] i32 (bit g collected)
       beams [n,L] i32 (bit k = on at offset k) - avail [n,A] u8 (bit a = Action a) - actions [n,A] u8
       err [n] u8 - evcount [n] u8 - events [n,2A] u8 (type<<4|agent) - done [n] u8 - obs [n,C,H,W] i8
     """

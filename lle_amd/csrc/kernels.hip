@@ -125,6 +125,7 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
         }
         s.alive = (uint32_t)raw_bits & 0xFFFFu; s.arrived = (uint32_t)(raw_bits >> 16) & 0xFFFFu; s.occ = (uint32_t)(raw_bits >> 32) & 0xFFFFu;
     }
+    uint32_t ghost = (uint32_t)(raw_bits >> GHOST_SHIFT);  // dead by set_state without an event (tables.h)
 
     MapView mv;
     mv.cell_lay = cell_lay; mv.cell_meta = cell_meta; mv.hdr = hdr;
@@ -147,7 +148,8 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
             if (K.flags & STEP_AUTO_RESET) {
                 // a finished env restarts from the reset state: identical for every env of the map, computed once on
                 // the device into P.init (uniform scalar loads + selects instead of re-running World::reset per lane)
-                const bool over = s.alive != amask || s.arrived == amask;
+                const bool over = (s.alive | ghost) != amask || s.arrived == amask;
+                ghost = over ? 0u : ghost;
                 const InitRecord* in0 = &init;
                 const uint64_t ib = in0->bits;
 #pragma unroll
@@ -217,6 +219,7 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
                 reset_env<AM, LM>(s, mv, at);
                 compute_avail<AM, LM>(s, mv, at, avail);
                 store_avail = true;
+                ghost = 0u;
             } else {
                 store_state = false;
                 touched = false;
@@ -232,6 +235,15 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
             Cells<AM> at;
             err = set_state_env<AM, LM>(s, rp, P.req_gems[env], (uint32_t)P.req_alive[env], mv, ev, dirty, at);
             if (err != 0) ev.clear();
+            {   // who is dead now without having died in this call (world.rs:571-579: agent.die() for `alive = false` emits nothing)
+                uint32_t died = 0;
+#pragma unroll
+                for (int q = 0; q < 2 * AM; q++) {
+                    const uint32_t byte = (uint32_t)(ev.w[q >> 3] >> ((q & 7) * 8)) & 0xFFu;
+                    died |= ((uint32_t)q < ev.n && (byte >> 4) == EV_DIED) ? (1u << (byte & 15u)) : 0u;
+                }
+                if (err == 0) ghost = ~s.alive & ~died & amask;  // (a refused request leaves the bookkeeping as it was)
+            }
             if (dirty) { load_cells<AM>(mv, s.pos, at); compute_avail<AM, LM>(s, mv, at, avail); store_avail = true; }
         } else if (MODE == MODE_SOURCES) {
             // LaserBeam::disable -> all off; LaserBeam::enable -> all on (laser.rs:69-77)
@@ -256,6 +268,7 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
                     compute_avail<AM, LM>(s, mv, at0, avail);
                     store_avail = true;
                     reset_first = true;
+                    ghost = 0u;
                 }
                 uint32_t new_en = fill ? hdr->enabled_mask : (K.enabled_in ? K.enabled_in[env] : mv.enabled);
                 new_en &= L >= 32 ? 0xFFFFFFFFu : ((1u << L) - 1u);
@@ -317,7 +330,7 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
         LLE_STAMP(3);
         if (store_state) {
             store_u16_record<AM>(P.pos, env, s.pos);
-            P.bits[env] = (uint64_t)s.alive | ((uint64_t)s.arrived << 16) | ((uint64_t)s.occ << 32);
+            P.bits[env] = (uint64_t)s.alive | ((uint64_t)s.arrived << 16) | ((uint64_t)s.occ << 32) | ((uint64_t)ghost << GHOST_SHIFT);
             P.gems[env] = s.gems;
 #pragma unroll
             for (int b = 0; b < LM; b++)
@@ -332,7 +345,7 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
 #pragma unroll
                 for (int k = 0; k < AM / 2; k++) w[k] = (uint32_t)(ev.w[k >> 1] >> ((k & 1) * 32));
             }
-            P.done[env] = (s.alive != amask || s.arrived == amask) ? 1 : 0;
+            P.done[env] = ((s.alive | ghost) != amask || s.arrived == amask) ? 1 : 0;
         }
 
         // hand the dynamic state to phase 2: [0 | beam masks | ~gem bits | byte index of each agent in the observation]

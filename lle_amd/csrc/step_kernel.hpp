@@ -188,6 +188,9 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     LLE_STAMP(1);
 
     uint32_t alive = (uint32_t)raw_bits & 0xFFFFu, arrived = (uint32_t)(raw_bits >> 16) & 0xFFFFu, occ = (uint32_t)(raw_bits >> 32) & 0xFFFFu;
+    // agents that set_state flagged dead WITHOUT a death event (tables.h GHOST_SHIFT): LLE.compute_done counts events, so
+    // they do not end the episode (python/lle/env/env.py:208-217,253-254).  Zero except after such a set_state.
+    uint32_t ghost = (uint32_t)(raw_bits >> GHOST_SHIFT);
     const uint32_t enabled = PES ? env_enabled : h_enabled, max_layers = ML1 ? 1u : hdr->max_layers;
     LLE_STAMP(2);
 
@@ -214,12 +217,13 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     // ---- auto-reset: a finished env restarts from the reset state (identical for every env, see InitRecord)
     uint32_t was_reset = 0;
     if (K.flags & STEP_AUTO_RESET) {
-        const bool over = env_ok && (alive != amask || arrived == amask);
+        const bool over = env_ok && ((alive | ghost) != amask || arrived == amask);
         pos = (over && me) ? init_pos_a : pos;
         avail = (over && me) ? init_avail_a : avail;
         alive = over ? ((uint32_t)init_bits & 0xFFFFu) : alive;
         arrived = over ? ((uint32_t)(init_bits >> 16) & 0xFFFFu) : arrived;
         occ = over ? ((uint32_t)(init_bits >> 32) & 0xFFFFu) : occ;
+        ghost = over ? 0u : ghost;
         gems = over ? init_gems : gems;
 #pragma unroll
         for (int b = 0; b < LM; b++)
@@ -275,7 +279,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
                 *reinterpret_cast<uint16_t*>(row) = (uint16_t)evw[0];
             }
         }
-        *LLE_LATE(done, env_c) = (alive != amask || arrived == amask) ? 1 : 0;
+        *LLE_LATE(done, env_c) = ((alive | ghost) != amask || arrived == amask) ? 1 : 0;
         uint32_t n_died = 0, n_gem = 0;
 #pragma unroll
         for (int k = 0; k < NW; k++) {
@@ -321,7 +325,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         if (env_ok && O.state)
             for (int g = (int)a; g < n_gems; g += G) O.state[env * len + 2 * A + g] = ((gems >> g) & 1u) ? 1.0f : 0.0f;
         if (env_ok && a == 0) {
-            if (O.done) O.done[env] = (alive != amask || arrived == amask) ? 1 : 0;
+            if (O.done) O.done[env] = ((alive | ghost) != amask || arrived == amask) ? 1 : 0;
             if (O.reward) {
                 uint32_t n_died = 0, n_gem = 0;
 #pragma unroll
@@ -407,7 +411,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         *LLE_LATE(avail, env_c * As + a) = (uint8_t)avail;
     }
     if (env_ok && a == 0) {
-        *LLE_LATE(bits, env_c) = (uint64_t)alive | ((uint64_t)arrived << 16) | ((uint64_t)occ << 32);
+        *LLE_LATE(bits, env_c) = (uint64_t)alive | ((uint64_t)arrived << 16) | ((uint64_t)occ << 32) | ((uint64_t)ghost << GHOST_SHIFT);
         *LLE_LATE(gems, env_c) = gems;
         uint32_t* const beams_out = LLE_LATE(beams, env_c * L);
 #pragma unroll

@@ -131,6 +131,12 @@ constexpr uint32_t LAUNCH_WRITE_THROUGH = 0x400000;    // internal: observation 
 constexpr uint64_t WRITE_THROUGH_MAX_BYTES = 256ull << 20;
 constexpr uint32_t ELEM_SOURCE = 0, ELEM_TILE = 1, ELEM_GEM = 2;
 
+// LLE_BUF_BITS: alive 0-15 | arrived 16-31 | occupant 32-47 | ghost 48-63.  "Ghost" = flagged dead by set_state without an
+// AgentDied event (a dead agent forced onto a tile that does not kill it): World state is `alive = false`, but LLE.compute_done
+// (python/lle/env/env.py:253-254) counts death EVENTS since the last reset / set_state, so such an agent does not end the
+// episode.  done = (alive | ghost) != all || arrived == all.  Cleared by reset; deaths by event never set it.
+constexpr uint32_t GHOST_SHIFT = 48;
+
 // ---- event codes
 constexpr uint32_t EV_EXIT = 0, EV_GEM = 1, EV_DIED = 2;
 

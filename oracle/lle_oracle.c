@@ -86,7 +86,9 @@ typedef struct tile {
 } tile_t;
 
 /* src/agent.rs:6-10 */
-typedef struct { int id; bool dead; bool arrived; } agent_t;
+/* `ghost`: harness bookkeeping, not reference state -- set_state flagged the agent dead without an AgentDied event, so
+ * LLE.compute_done (python/lle/env/env.py:208-217,253-254: it counts death EVENTS) does not see it */
+typedef struct { int id; bool dead; bool arrived; bool ghost; } agent_t;
 
 typedef struct { int type; int agent; } event_t;
 
@@ -521,7 +523,7 @@ static void compute_available_actions(ow_world* w) {
 /* world.rs:411-432 reset (single-start maps only: sample_different is deterministic, utils/mod.rs:63) */
 void ow_reset(ow_world* w) {
     for (int c = 0; c < w->width * w->height; c++) tile_reset(w->grid[c]);
-    for (int a = 0; a < w->n_agents; a++) { w->agents[a].dead = false; w->agents[a].arrived = false; }
+    for (int a = 0; a < w->n_agents; a++) { w->agents[a].dead = false; w->agents[a].arrived = false; w->agents[a].ghost = false; }
     for (int a = 0; a < w->n_agents; a++) {
         w->start_positions[a] = w->random_start_positions[a][0];
         w->agents_positions[a] = w->start_positions[a];
@@ -643,6 +645,8 @@ int ow_set_state(ow_world* w, const int32_t* pos, int n_pos, const uint8_t* gems
     for (int a = 0; a < A; a++) if (dup[a]) return OW_RT_INVALID_WORLD_STATE;
     for (int a = 0; a < A; a++)
         if (req[a].i < 0 || req[a].j < 0 || req[a].i >= w->height || req[a].j >= w->width) return OW_RT_OUT_OF_WORLD_POSITION;
+    bool ghost_before[OW_MAX_AGENTS];  /* harness bookkeeping: only a successful set_state changes it */
+    for (int a = 0; a < A; a++) ghost_before[a] = w->agents[a].ghost;
     /* current_state = self.get_state() */
     int32_t cur_pos[2 * OW_MAX_AGENTS]; uint8_t cur_alive[OW_MAX_AGENTS];
     uint8_t* cur_gems = (uint8_t*)malloc((size_t)w->n_gems + 1);
@@ -659,6 +663,7 @@ int ow_set_state(ow_world* w, const int32_t* pos, int n_pos, const uint8_t* gems
             int rc = ow_set_state(w, cur_pos, A, cur_gems, w->n_gems, cur_alive, NULL, 0, NULL);
             if (rc != OW_RT_OK) ow_panic(w, "set_state(current_state).unwrap() failed");
             free(cur_gems);
+            for (int q = 0; q < A; q++) w->agents[q].ghost = ghost_before[q];
             return OW_RT_INVALID_AGENT_POSITION;
         }
     }
@@ -668,7 +673,9 @@ int ow_set_state(ow_world* w, const int32_t* pos, int n_pos, const uint8_t* gems
         w->agents[a].dead = false; w->agents[a].arrived = false;
         event_t ev;
         if (tile_enter(w, at(w, req[a].i, req[a].j), &w->agents[a], &ev)) events[n_events++] = ev;
+        const bool died_here = w->agents[a].dead;
         if (!alive[a]) w->agents[a].dead = true;
+        w->agents[a].ghost = w->agents[a].dead && !died_here;
     }
     /* actual_state != *state -> Err(InvalidWorldState) WITHOUT rollback (world.rs:588-594) */
     int32_t act_pos[2 * OW_MAX_AGENTS]; uint8_t act_alive[OW_MAX_AGENTS];
@@ -677,7 +684,7 @@ int ow_set_state(ow_world* w, const int32_t* pos, int n_pos, const uint8_t* gems
     for (int a = 0; a < A; a++) if (act_pos[2 * a] != pos[2 * a] || act_pos[2 * a + 1] != pos[2 * a + 1] || (act_alive[a] != 0) != (alive[a] != 0)) same = false;
     for (int g = 0; g < w->n_gems; g++) if ((cur_gems[g] != 0) != (gems[g] != 0)) same = false;
     free(cur_gems);
-    if (!same) return OW_RT_INVALID_WORLD_STATE;
+    if (!same) { for (int q = 0; q < A; q++) w->agents[q].ghost = ghost_before[q]; return OW_RT_INVALID_WORLD_STATE; }
     compute_available_actions(w);
     if (events_out) for (int k = 0; k < n_events && k < cap; k++) { events_out[2 * k] = (uint8_t)events[k].type; events_out[2 * k + 1] = (uint8_t)events[k].agent; }
     if (n_events_out) *n_events_out = n_events;
@@ -837,9 +844,9 @@ int ow_sample_action(uint8_t mask, uint64_t seed, uint64_t env, uint64_t t, uint
     for (int b = 0; b < 5; b++) if (mask & (1u << b)) { if (k == 0) return b; k--; }
     return ACT_STAY;
 }
-static bool world_done(ow_world* w) { /* any agent dead, or all arrived */
+static bool world_done(ow_world* w) { /* LLE.compute_done: some agent died (by an event), or all arrived */
     bool all = true;
-    for (int a = 0; a < w->n_agents; a++) { if (w->agents[a].dead) return true; if (!w->agents[a].arrived) all = false; }
+    for (int a = 0; a < w->n_agents; a++) { if (w->agents[a].dead && !w->agents[a].ghost) return true; if (!w->agents[a].arrived) all = false; }
     return all;
 }
 

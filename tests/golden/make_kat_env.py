@@ -95,6 +95,15 @@ case("core_force_end_state", "python/tests/test_core.py:164-175", "\n        S0 
 case("core_force_state_agent_dies", "python/tests/test_core.py:178-192", "\n        S0 S1 G\n        X  . L0W\n        .  X  .\n    ",
      [reset, {"op": "set_state", "positions": [[1, 0], [1, 1]], "gems": [False], "alive": [True, False]}, expect(done=True)])
 
+# LLE.done counts EVENTS since the last reset / set_state (env.py:208-217,253-254; reward_strategy.py:58-75): an agent that a forced
+# state flags dead on a tile that does not kill it dies WITHOUT an AgentDied (world.rs:571-579), so the episode goes on -- derived
+# from the source, no reference test forces such a state; test_core.py:178-192 (above) is the case where the event does fire.
+case("derived_forced_dead_agent_without_event", "python/lle/env/env.py:208-217 + src/core/world.rs:571-579 (derived)",
+     "\n        S0 S1 G\n        X  . .\n        .  X  .\n    ",
+     [reset, {"op": "set_state", "positions": [[1, 1], [0, 1]], "gems": [False], "alive": [True, False]}, expect(done=False),
+      step([W, STAY], done=False, metrics={"has-arrived": [True, False], "is-alive": [True, False]}), expect(done=False),
+      step([STAY, STAY], done=False)])
+
 if __name__ == "__main__":
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kat_env.json")
     with open(out, "w") as f:

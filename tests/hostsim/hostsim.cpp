@@ -125,6 +125,7 @@ static void run(hs_batch* b, int mode, uint32_t flags, uint64_t seed, uint64_t t
         for (int a = 0; a < AM; a++) s.pos[a] = (a < A) ? (uint32_t)b->pos[env * A + a] : 0xFFFF0000u + (uint32_t)a;
         const uint64_t bits = b->bits[env];
         s.alive = (uint32_t)bits & 0xFFFFu; s.arrived = (uint32_t)(bits >> 16) & 0xFFFFu; s.occ = (uint32_t)(bits >> 32) & 0xFFFFu;
+        uint32_t ghost = (uint32_t)(bits >> GHOST_SHIFT);  // dead by set_state without an event (tables.h)
         s.gems = b->gems[env];
         for (int k = 0; k < LM; k++) s.beams[k] = (k < L) ? b->beams[env * L + k] : 0u;
         bool store_state = true, store_avail = false, touched = true;
@@ -134,11 +135,12 @@ static void run(hs_batch* b, int mode, uint32_t flags, uint64_t seed, uint64_t t
         uint32_t err = 0, was_reset = 0;
         if (mode == M_STEP) {
             for (int a = 0; a < AM; a++) avail[a] = (a < A) ? (uint32_t)b->avail[env * A + a] : 0u;
-            if ((flags & STEP_AUTO_RESET) && (s.alive != amask || s.arrived == amask)) {
+            if ((flags & STEP_AUTO_RESET) && ((s.alive | ghost) != amask || s.arrived == amask)) {
                 Cells<AM> at;
                 reset_env<AM, LM>(s, mv, at);
                 compute_avail<AM, LM>(s, mv, at, avail);
                 was_reset = 1;
+                ghost = 0;
             }
             Cells<AM> cur;
             load_cells<AM>(mv, s.pos, cur);
@@ -186,6 +188,7 @@ static void run(hs_batch* b, int mode, uint32_t flags, uint64_t seed, uint64_t t
                 reset_env<AM, LM>(s, mv, at);
                 compute_avail<AM, LM>(s, mv, at, avail);
                 store_avail = true;
+                ghost = 0;
             } else {
                 store_state = false;
                 touched = false;
@@ -197,6 +200,14 @@ static void run(hs_batch* b, int mode, uint32_t flags, uint64_t seed, uint64_t t
             Cells<AM> at;
             err = set_state_env<AM, LM>(s, rp, b->req_gems[env], (uint32_t)b->req_alive[env], mv, ev, dirty, at);
             if (err != 0) ev.clear();
+            {
+                uint32_t died = 0;
+                for (uint32_t q = 0; q < ev.n; q++) {
+                    const uint32_t byte = (uint32_t)(ev.w[q >> 3] >> ((q & 7) * 8)) & 0xFFu;
+                    if ((byte >> 4) == EV_DIED) died |= 1u << (byte & 15u);
+                }
+                if (err == 0) ghost = ~s.alive & ~died & amask;  // (a refused request leaves the bookkeeping as it was)
+            }
             if (dirty) { load_cells<AM>(mv, s.pos, at); compute_avail<AM, LM>(s, mv, at, avail); store_avail = true; }
         } else if (mode == M_SOURCES) {
             for (int k = 0; k < LM; k++) {
@@ -211,7 +222,7 @@ static void run(hs_batch* b, int mode, uint32_t flags, uint64_t seed, uint64_t t
         }
         if (store_state) {
             for (int a = 0; a < A; a++) b->pos[env * A + a] = (uint16_t)s.pos[a];
-            b->bits[env] = (uint64_t)s.alive | ((uint64_t)s.arrived << 16) | ((uint64_t)s.occ << 32);
+            b->bits[env] = (uint64_t)s.alive | ((uint64_t)s.arrived << 16) | ((uint64_t)s.occ << 32) | ((uint64_t)ghost << GHOST_SHIFT);
             b->gems[env] = s.gems;
             for (int k = 0; k < L; k++) b->beams[env * L + k] = s.beams[k];
         }
@@ -220,7 +231,7 @@ static void run(hs_batch* b, int mode, uint32_t flags, uint64_t seed, uint64_t t
             b->err[env] = (uint8_t)err;
             b->evcount[env] = (uint8_t)(ev.n | (was_reset << 7));
             for (int k = 0; k < 2 * A; k++) b->events[env * 2 * A + k] = (uint8_t)(ev.w[k >> 3] >> ((k & 7) * 8));
-            b->done[env] = (s.alive != amask || s.arrived == amask) ? 1 : 0;
+            b->done[env] = ((s.alive | ghost) != amask || s.arrived == amask) ? 1 : 0;
         }
         if (mode == M_STEP) {
             int64_t n_gem = 0, n_exit = 0, n_died = 0;
