@@ -1,7 +1,9 @@
 """Soak differential (GPU box): HIP path vs the CPU oracle on long random rollouts, every buffer of every env compared
 bit-for-bit after every step (state, ordered events, availability, error codes, the full int8 observation).
 Beyond the test suite's sizes; prints env-steps compared per map.
-Usage: python tools/soak_parity.py [seconds_per_map] [per-env-sources]
+Usage: python tools/soak_parity.py [seconds_per_map] [per-env-sources | full-size]
+With `full-size` only the BASELINE configurations at their full batch (and level 6 at 262 144 envs, the HBM-regime run of
+bench.py) are compared, a few steps each: the oracle side then dominates the time.
 With `per-env-sources` every env has its own source colours / enabled flags (lle_batch_set_sources; each oracle env is
 its own world object and receives the same set_colour / enable / disable calls), re-drawn every 48 steps for a random
 half of the envs: the general step-kernel modes.  Maps without sources are skipped."""
@@ -21,6 +23,7 @@ import torch  # noqa: E402
 om.build()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
 per_env = len(sys.argv) > 2 and sys.argv[2] == "per-env-sources"
+full_size = len(sys.argv) > 2 and sys.argv[2] == "full-size"
 rng = np.random.default_rng(7)
 
 
@@ -54,6 +57,9 @@ def redraw(bw, mirror, A, L, n):
 maps = {f"level{k}": (v, 32768) for k, v in LEVELS.items()}
 maps.update({k: (v, 8192) for k, v in EXTRA_MAPS.items()})
 maps["config5"] = (mapgen.config5(0), 4096)
+if full_size:
+    maps = {"cfg2 level1 x 4096": (LEVELS[1], 4096), "cfg3 level6 x 65536": (LEVELS[6], 65536), "level6 x 262144": (LEVELS[6], 262144),
+            "cfg5 32x32 x 65536": (mapgen.config5(0), 65536)}
 total = 0
 for name, (text, n) in maps.items():
     if per_env:
