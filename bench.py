@@ -315,8 +315,9 @@ def main():
     preroll_steps = preroll(torch, dev, step)
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize(dev)
-    bw.stats(reset=True)
+    # counters of the timed region only: zeroed by a fill on the launch stream (bw.stats(reset=True) would read them back
+    # first -- a host round trip right in front of a timed region that is 0.5 ms long at the driver's 20 steps)
+    bw.stats_blocks.zero_()
     elapsed, kernel_ms = timer.run(step, args.steps)
     elapsed = allreduce_max(elapsed, dev) if use_dist else elapsed
     stats = bw.stats()
