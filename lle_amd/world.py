@@ -134,11 +134,21 @@ class EventType(Enum):
 
 
 class Direction(Enum):
-    """src/core/tiles/direction.rs:8-18"""
+    """src/core/tiles/direction.rs:8-18, src/bindings/tiles/pydirection.rs: built from the map's letters too (`Direction("N")`)."""
     NORTH = 0
     EAST = 1
     SOUTH = 2
     WEST = 3
+
+    @classmethod
+    def _missing_(cls, value):
+        letters = {"N": cls.NORTH, "E": cls.EAST, "S": cls.SOUTH, "W": cls.WEST}
+        if value in letters:
+            return letters[value]
+        raise ValueError(f"Invalid direction string: {value}")
+
+    def opposite(self):
+        return Direction((self.value + 2) % 4)
 
     @property
     def delta(self):

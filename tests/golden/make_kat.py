@@ -484,6 +484,10 @@ case("parser_v1_laser_blocked_on_spawn", "src/unit_tests/test_parser_v1.rs:80-98
 # NOT transcribable as they stand: test_parser_v1.rs:5-20 parse `S10 X` / `L10E S0 ... S10 X` to a CONFIG only (they would not
 # survive into_world: ten agents without start / one exit for eleven agents); the map above covers multi-digit ids end to end.
 
+case("readme_world_example", "readme.md:56-67", map="S0 G X",
+     script=[reset(), expect(avail_sets=[[STAY, E]]), step([E], event_types=[GEM]), step([E], event_types=[EXIT])])
+case("doc_deepcopy", "python/lle/world/__init__.pyi:313-324", map="S0 X", script=[reset(), clone_check()])
+
 if __name__ == "__main__":
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kat_world.json")
     with open(out, "w") as f:

@@ -104,6 +104,25 @@ case("derived_forced_dead_agent_without_event", "python/lle/env/env.py:208-217 +
       step([W, STAY], done=False, metrics={"has-arrived": [True, False], "is-alive": [True, False]}), expect(done=False),
       step([STAY, STAY], done=False)])
 
+# ---- python/tests/test_death_strategy.py, python/tests/test_reward_strategy.py (round 2)
+case("death_strategy_end", "python/tests/test_death_strategy.py:4-18", "\nS0  G  X\nS1 L1N X\n", [reset, step([E, STAY], done=True)])
+# test_reward_strategy.py feeds hand-built event lists to the strategies; the same lists from real steps.  `free_running`: the
+# strategy is exercised past the end of the episode (the reference's LLE would refuse the step of a done env, its strategy
+# objects do not care), so adapters must not enforce "Cannot step in a done environment" on these cases.
+MAP_RS_ARRIVE = "S0 G X\nS1 . X"           # step 1: [GEM 0]; step 2: [EXIT 0, EXIT 1]
+MAP_RS_DEATHS = "S0 V X\nS1 . V\nX  . ."    # step 1: [DIED 0]; step 2: [DIED 1]
+case("reward_strategy_single_objective", "python/tests/test_reward_strategy.py:6-32", MAP_RS_ARRIVE,
+     [reset, step([E, E], GEM), step([E, E], 2 * EXIT + DONE, True, {"has-arrived": [True, True], "is-alive": [True, True]}),
+      reset, step([E, E]), step([E, E], 2 * EXIT + DONE)])
+case("reward_strategy_single_objective_deaths", "python/tests/test_reward_strategy.py:24-32", MAP_RS_DEATHS,
+     [reset, step([E, E], DEATH, True), reset, step([E, E], DEATH, True), step([STAY, E], DEATH, True, {"has-arrived": [False, False], "is-alive": [False, False]})])
+CASES[-1]["free_running"] = True
+case("reward_strategy_multi_objective", "python/tests/test_reward_strategy.py:35-62", MAP_RS_ARRIVE,
+     [reset, step([E, E], [GEM, 0, 0, 0]), step([E, E], [0, 2 * EXIT, 0, DONE], True)], multi_objective=True)
+case("reward_strategy_multi_objective_deaths", "python/tests/test_reward_strategy.py:54-62", MAP_RS_DEATHS,
+     [reset, step([E, E], [0, 0, DEATH, 0], True), reset, step([E, E], [0, 0, DEATH, 0]), step([STAY, E], [0, 0, DEATH, 0])], multi_objective=True)
+CASES[-1]["free_running"] = True
+
 if __name__ == "__main__":
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kat_env.json")
     with open(out, "w") as f:

@@ -85,7 +85,7 @@ class OracleLLE:
         return {"has-arrived": [bool(x) for x in self.w.arrived()], "is-alive": [bool(x) for x in self.w.alive()]}
 
     def step(self, actions):                        # env.py:165-187
-        assert not self.done, "Cannot step in a done environment"
+        assert not self.done or getattr(self, "free_running", False), "Cannot step in a done environment"
         events = self.w.step([int(a) for a in actions])
         reward = self.compute_reward(events)
         self.done = self.n_arrived == self.n_agents or self.n_deads > 0   # env.py:253-254

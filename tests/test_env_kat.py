@@ -12,6 +12,7 @@ CASES = load_cases()
 def test_oracle_env_kat(oracle_mod, case):
     def make(c):
         env = OracleLLE(oracle_mod.OracleWorld(c["map"]), multi_objective=c["multi_objective"])
+        env.free_running = bool(c.get("free_running"))  # strategy-level cases step past the end of the episode
         return _Adapter(env)
     run_case(make, case)
 

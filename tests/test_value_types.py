@@ -80,3 +80,19 @@ def test_subclass_world_and_standard_levels_parse_without_a_gpu():   # test_worl
         assert a.world_string == b.world_string == c.world_string and a.n_agents == b.n_agents
     with pytest.raises(FileNotFoundError):
         World.from_file("no/such/file.toml")
+
+
+def test_direction():   # python/tests/test_direction.py (all of it)
+    from lle_amd import Direction
+
+    ds = [Direction.NORTH, Direction.SOUTH, Direction.EAST, Direction.WEST]
+    for d in ds:
+        assert d == d
+        for d2 in ds:
+            if d is not d2:
+                assert d != d2
+    assert Direction("N") == Direction.NORTH and Direction("W") == Direction.WEST
+    with pytest.raises(ValueError):
+        Direction("z")
+    assert [d.delta for d in ds] == [(-1, 0), (1, 0), (0, 1), (0, -1)]
+    assert [d.opposite() for d in ds] == [Direction.SOUTH, Direction.NORTH, Direction.WEST, Direction.EAST]
