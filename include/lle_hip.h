@@ -128,6 +128,16 @@ int lle_map_colour_allowed(const lle_map* map, int laser_id, int agent_id);
  * pitch from lle_map_info.obs_stride / the buffer descriptors.  Call before lle_batch_create (a live batch keeps the
  * pitch it was created with). */
 int lle_map_set_row_align(lle_map* map, int align);
+/* The HEAD of a row: a run of whole 128-byte lines that hold no byte an agent, a beam or a gem can change -- behind
+ * the agent layers, no laser tile, no gem -- i.e. the same bytes in every environment after every step.  The step
+ * kernel stores these lines BEFORE its state machine runs (the memory system starts earlier; lle_amd/csrc/
+ * step_kernel.hpp; launches of about one to two rounds of workgroups only, where it pays).  `lines` = the most lines
+ * taken from the longest such run, 0..8 (0 = none), or -1 = automatic, the default: a fifth of the row.  The
+ * LLE_HEAD_LINES environment variable overrides the default.  Rows that are not line-aligned have no head.  Results do
+ * not depend on it. */
+int lle_map_set_head_lines(lle_map* map, int lines);
+/* The head chosen for the map's current sources: byte offset inside a row and length (0 = no head). */
+int lle_map_row_head(const lle_map* map, int32_t* first_byte, int32_t* n_bytes);
 
 /* static description of World.lasers (src/core/world.rs:159-172): per laser position the outer layer and, if
  * nested, the second one; `offset` indexes the beam mask of `laser_id`. */

@@ -225,6 +225,21 @@ int lle_map_set_row_align(lle_map* map, int align) {
     return LLE_OK;
 }
 
+int lle_map_set_head_lines(lle_map* map, int lines) {
+    if (!map) return fail(LLE_ERR_NULL, "NULL map");
+    if (lines < -1 || lines > 8) return fail(LLE_ERR_ARG, "head lines must be -1 (automatic) or 0..8");
+    map->m.head_lines = lines;
+    map->m.compile();
+    return LLE_OK;
+}
+
+int lle_map_row_head(const lle_map* map, int32_t* first_byte, int32_t* n_bytes) {
+    if (!map) return fail(LLE_ERR_NULL, "NULL map");
+    if (first_byte) *first_byte = (int32_t)(map->m.header.head_lo * 16u);
+    if (n_bytes) *n_bytes = (int32_t)(map->m.header.head_n * 16u);
+    return LLE_OK;
+}
+
 int lle_map_laser_tiles(const lle_map* map, lle_laser_tile* out, int cap) {
     if (!map) return fail(LLE_ERR_NULL, "NULL map");
     const Map& m = map->m;

@@ -496,6 +496,17 @@ bool write_through_pays(uint64_t bytes, uint32_t row_pitch) {
     return row_pitch % 128u == 0 || bytes <= WRITE_THROUGH_MAX_BYTES;
 }
 
+// Row heads ahead of the state machine (step_kernel.hpp HEAD; tables.h head_lo / head_n): pays when the launch is about
+// one or two rounds of workgroups -- every wavefront then runs its state machine at the same time with the memory system
+// idle.  Measured on level 6 with a 3-line head: 32 768 envs (2 048 wavefronts) 13.3 -> 12.4 us, 65 536 21.4 -> 19.8,
+// 131 072 36.7 -> 35.1; a small launch (16 384 envs: 9.4 -> 9.7) or many rounds (262 144: 98.9 -> 100.1) lose a little.
+// LLE_ROW_HEADS=0 / 1 forces it (read per launch: the parity tests run both in one process).
+static bool row_heads_pay(uint32_t n_waves) {
+    const char* o = getenv("LLE_ROW_HEADS");
+    if (o && (o[0] == '0' || o[0] == '1') && !o[1]) return o[0] == '1';
+    return n_waves >= 2048u && n_waves <= 8192u;
+}
+
 hipError_t launch_world_kernel(int mode, const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K_in, hipStream_t stream) {
     LaunchArgs K = K_in;
     if (write_through_pays((uint64_t)(K.env_limit - K.env_base) * h.obs_stride, h.obs_stride)) K.flags |= LAUNCH_WRITE_THROUGH;
@@ -569,7 +580,12 @@ hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const Laun
     if (pes) return roll ? launch_step_mode3(G, lm, P, K, n_waves, wpw, lds, stream) : launch_step_mode5(G, lm, P, K, n_waves, wpw, lds, stream);
     if (K.flags & LAUNCH_GENERAL)
         return roll ? launch_step_mode2(G, lm, P, K, n_waves, wpw, lds, stream) : launch_step_mode4(G, lm, P, K, n_waves, wpw, lds, stream);
-    return roll ? launch_step_mode1(G, lm, P, K, n_waves, wpw, lds, stream) : launch_step_mode0(G, lm, P, K, n_waves, wpw, lds, stream);
+    if (roll) return launch_step_mode1(G, lm, P, K, n_waves, wpw, lds, stream);
+    // one step in place, one map, the map's sources: with the rows' head lines ahead of the state machine (MODE 6) when the
+    // map has a head, the rows are not split and the launch is of the size where it pays
+    if (lm <= 8 && h.head_n != 0 && !(K.flags & (LAUNCH_SPLIT_ROWS | STEP_NO_OBS)) && row_heads_pay(n_waves))
+        return launch_step_mode6(G, lm, P, K, n_waves, wpw, lds, stream);
+    return launch_step_mode0(G, lm, P, K, n_waves, wpw, lds, stream);
 }
 
 }  // namespace lle

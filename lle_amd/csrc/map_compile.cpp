@@ -445,6 +445,26 @@ void Map::compile() {
         if (!build_obs_tables(lm, tmpl, dyn_tab)) h.obs_supported = 0;
     }
     h.D = (uint32_t)dyn_tab.size();
+    // ---- the head of a row (tables.h): the longest run of 128-byte lines without a dynamic byte -- behind the agent
+    // layers (an agent can stand on any walkable cell), no dyn entry -- cut to `head_lines` lines
+    if (h.obs_stride % 128u == 0 && h.obs_supported) {
+        const uint32_t n_lines = h.obs_stride / 128u;
+        std::vector<uint8_t> dynamic_line(n_lines, 0);
+        for (uint32_t l = 0; l < n_lines && l * 128u < (uint32_t)(A * HW); l++) dynamic_line[l] = 1;
+        for (uint64_t e : dyn_tab) dynamic_line[((uint32_t)e & 0xFFFFFu) / 128u] = 1;
+        uint32_t best_lo = 0, best_n = 0;
+        for (uint32_t l = 0; l < n_lines;) {
+            if (dynamic_line[l]) { l++; continue; }
+            uint32_t e = l;
+            while (e < n_lines && !dynamic_line[e]) e++;
+            if (e - l > best_n) { best_lo = l; best_n = e - l; }
+            l = e;
+        }
+        const uint32_t want = head_lines < 0 ? std::max(1u, (n_lines + 2u) / 5u) : (uint32_t)head_lines;
+        best_n = std::min(best_n, std::min(want, 8u));
+        h.head_lo = best_lo * 8u;
+        h.head_n = best_n * 8u;
+    }
 
     // ---- assemble blob
     auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };

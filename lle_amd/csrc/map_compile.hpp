@@ -7,6 +7,7 @@
 // Instead of a grid of boxed tiles it emits flat tables (tables.h).
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -53,6 +54,16 @@ struct Map {
         }
         return (bytes + row_align - 1u) / row_align * row_align;
     }
+
+    // Lines of a row that the default step kernel stores ahead of the state machine (tables.h head_lo / head_n), at most
+    // 8; -1 = automatic: a fifth of the row (measured best on levels 3, 5, 6 and generated 8- and 12-agent maps: with
+    // less the state machine is not covered, with more the head stores themselves hold the wavefront up);
+    // LLE_HEAD_LINES overrides the default.
+    static int default_head_lines() {
+        const char* e = std::getenv("LLE_HEAD_LINES");
+        return e && *e ? std::atoi(e) : -1;
+    }
+    int head_lines = default_head_lines();
 
     int n_agents() const { return (int)starts.size(); }
     int n_layers() const { return 2 * n_agents() + 4; }

@@ -100,14 +100,44 @@ __device__ __forceinline__ void stream_whole_row(uint4* __restrict__ dst, const 
     if (n_chunks > 128u) stream_row<WT>(dst, srcv, 128u, n_chunks, lane);
 }
 
+// The same without the row's HEAD (chunks [head_lo, head_lo + head_n), stored before the state machine, see
+// store_heads): tail chunk i is chunk i + (i >= head_lo ? head_n : 0).
+template <bool WT>
+__device__ __forceinline__ void stream_row_tail(uint4* __restrict__ dst, const uint4* srcv, uint32_t n_chunks, uint32_t head_lo, uint32_t head_n,
+                                                uint32_t lane) {
+    const uint32_t n_tail = n_chunks - head_n;
+    const uint32_t i0 = lane, i1 = lane + 64u;
+    const uint32_t c0 = i0 + (i0 >= head_lo ? head_n : 0u), c1 = i1 + (i1 >= head_lo ? head_n : 0u);
+    const uint4 v0 = srcv[i0 < n_tail ? c0 : 0u], v1 = srcv[i1 < n_tail ? c1 : 0u];
+    if (i0 < n_tail) stream_store<WT>(dst + c0, v0);
+    if (i1 < n_tail) stream_store<WT>(dst + c1, v1);
+    for (uint32_t i = lane + 128u; i < n_tail; i += 64u) {
+        const uint32_t c = i + (i >= head_lo ? head_n : 0u);
+        stream_store<WT>(dst + c, srcv[c]);
+    }
+}
+
+// The heads of the wave's rows: the same `head_n` (<= 64) chunks, straight from the map's pristine template in global
+// memory (`v`: this lane's chunk), into every row.  Issued BEFORE the state machine: a launch of the step kernel is
+// (ramp) + (state machine, every wavefront at the same time) + (stream), and the lines that no agent, beam or gem can
+// touch need not wait for the state machine -- the memory system starts ~2 us earlier (tools/ceiling/head_probe.hip).
+template <bool WT>
+__device__ __forceinline__ void store_heads(int8_t* __restrict__ obs, uint64_t obs_stride, int64_t env0, int64_t n_here, uint32_t head_lo,
+                                            uint32_t head_n, const uint4& v, uint32_t lane) {
+    if (lane < head_n)
+        for (int64_t k = 0; k < n_here; k++)
+            stream_store<WT>(reinterpret_cast<uint4*>(obs + (uint64_t)(env0 + k) * obs_stride) + head_lo + lane, v);
+}
+
 // ---- phase 2: layered observation of the wave's environments, one environment at a time.
 // `scratch` holds one hand-over record per environment: [0 | beam masks | ~gem bits | byte index of each agent].
 // `obs_stride` = bytes between the rows of consecutive environments in `obs`.
-template <bool WT>
+// HEAD: the rows' heads are already stored (store_heads); stream the rest.
+template <bool WT, bool HEAD = false>
 __device__ __forceinline__ void write_observations(int A, int L, uint32_t D, uint32_t n_chunks, uint64_t obs_stride,
                                                    const uint64_t* dyn, int8_t* tmpl, const uint32_t* scratch,
                                                    uint32_t scr_stride, int8_t* __restrict__ obs, int64_t env0,
-                                                   int64_t n_here, uint32_t lane) {
+                                                   int64_t n_here, uint32_t lane, uint32_t head_lo = 0, uint32_t head_n = 0) {
     // Each lane serves the same dyn entry for every environment: decode it once.
     // A laser / gem reference becomes (dword of the hand-over record, bit); an absent one points at the record's
     // zero word, so the per-environment evaluation is branch-free.
@@ -146,7 +176,8 @@ __device__ __forceinline__ void write_observations(int A, int L, uint32_t D, uin
         wave_sync();
         // (c) stream the patched copy as one contiguous row: 16 B per lane, 1 KiB per wave instruction
         uint4* __restrict__ dst = reinterpret_cast<uint4*>(obs + (uint64_t)(env0 + k) * obs_stride);
-        stream_whole_row<WT>(dst, srcv, n_chunks, lane);
+        if constexpr (HEAD) stream_row_tail<WT>(dst, srcv, n_chunks, head_lo, head_n, lane);
+        else stream_whole_row<WT>(dst, srcv, n_chunks, lane);
         wave_sync();
         // (d) agents off again (their layers are all-zero in the static copy); LDS is in order, so this lands after
         // the reads above and before the next environment's patches

@@ -36,17 +36,22 @@ namespace lle {
 // run-time flag of MODE 2, so that neither keeps the other's reset state and colour words in registers: both are short
 // of them).  MODE 4 / 5: MODE 2 / 3 without the rollout loop, rings and stamps -- the single-step launches of such
 // batches (the loop-carried state and the ring pointers are what pushes 2 / 3 into scratch).
+// MODE 6: MODE 0 for launches of one to two rounds of workgroups (kernels.hip: row_heads_pay): the rows' static head lines are
+// stored before the state machine, and every load of the kernel is issued up front (see HEAD below).  An instantiation
+// of its own: a launch without heads runs 0.2-0.4 us slower with that load order (level 1: 5.9 -> 6.1 us at 4 096 envs).
+// Maps with at most 8 sources only (with 16 / 32 beam registers the early state loads spill).
 // LX >= 0: the exact number of sources, known at compile time (instantiated for the default path of maps with at
 // most four sources: the per-beam loops lose their guards and the unused beam registers disappear; 0.4 us on level 6).
 template <int G, int LM, int MODE, bool ML1, int LX = -1>
 __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P, LaunchArgs K) {
-    constexpr bool GEN = MODE >= 2, ROLL = MODE >= 1 && MODE <= 3;
+    constexpr bool GEN = MODE >= 2 && MODE <= 5, ROLL = MODE >= 1 && MODE <= 3;
     constexpr bool PES = MODE == 3 || MODE == 5;  // (the launcher picks these exactly when LAUNCH_PER_ENV_SOURCES is set)
     // Big rows (LAUNCH_SPLIT_ROWS, set by the launcher when private whole-row copies would leave one workgroup per CU):
     // the row is split over the wavefronts of the workgroup, see write_observations_split (obs_stream.hpp).  Only the
     // instantiations of maps with more than four agents carry it (rows of 16 KB and more with at most four agents
     // would need maps beyond 36 x 36; those stay on whole-row copies), and not the per-env-sources modes.
     constexpr bool CAN_SPLIT = G >= 8 && !PES;
+    constexpr bool HEAD = MODE == 6;  // MODE 0 with the static lines of the rows ahead of the state machine (below)
     const bool split = CAN_SPLIT && (K.flags & LAUNCH_SPLIT_ROWS) != 0;
     // The default instantiation is one step in place and nothing else: the fused rollout (n_steps, trajectory rings)
     // and the timeline stamps run on the general one, so that their arguments do not occupy scalar registers here.
@@ -89,20 +94,16 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
 #pragma unroll
     for (int b = 0; b < LM; b++) h_beam_full[b] = (b < L) ? hdr->beam_full[b] : 0u;
     const uint32_t h_enabled = hdr->enabled_mask;
+    // (with head stores ahead of them, later header reads would be VECTOR loads -- the scalar cache is not coherent with
+    // the kernel's own stores, and the compiler cannot tell the header from the rows -- whose wait covers the stores too)
+    const uint32_t h_off_cell_meta = hdr->off_cell_meta, h_off_dyn = hdr->off_dyn, h_off_template = hdr->off_template;
+    const uint32_t h_max_layers = ML1 ? 1u : hdr->max_layers;
     uint32_t h_init_beams[LM];  // the reset state's beams (shared record; the per-env one is read where it is used)
 #pragma unroll
     for (int b = 0; b < LM; b++) h_init_beams[b] = (b < L) ? initp->beams[b] : 0u;
     const int64_t n_here = (K.env_limit - env0) < (int64_t)EPW ? (K.env_limit - env0) : (int64_t)EPW;
     const uint32_t amask = (1u << A) - 1u;
     LLE_STAMP(0);
-
-    // (split rows: the pristine static observation stays in global memory, every wavefront copies its slice from there)
-    const uint32_t tab_bytes = split ? hdr->lds_split_table_bytes : hdr->lds_table_bytes, tab_off = hdr->off_cell_lay;
-    copy_tables_to_lds(tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
-    const uint32_t ext_bytes = PES ? hdr->ext_bytes : 0u;
-    if (PES) copy_tables_to_lds(tables + hdr->off_bare, lds + tab_bytes, ext_bytes, lane, wave_in_wg, waves_per_wg);
-    LLE_STAMP(7);
-    __syncthreads();  // the only workgroup barrier
 
     // ---- packed state: own position / availability, and the env-wide words replicated in the group's lanes
     uint32_t pos = 0xFFFF0000u + a, avail = 0, beams[LM];
@@ -127,42 +128,91 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     // the state machine is a memory round trip): there the addresses of the late stores are rebuilt from the scalar
     // bases where they are used, and the per-lane copies above die after the loads.
 #define LLE_LATE(field, offset) (GEN ? P.field + (offset) : p_##field)
-    if (env_ok) {
-        raw_bits = *p_bits;
-        gems = *p_gems;
-#pragma unroll
-        for (int b = 0; b < LM; b++)
-            if (b < L) beams[b] = p_beams[b];
-    }
     uint32_t init_pos_a = 0xFFFF0000u + a, init_avail_a = 0;  // this agent's reset position / availability
-    if (me) {
-        pos = (uint32_t)*p_pos;
-        avail = (uint32_t)*p_avail;
-        init_pos_a = PES ? (uint32_t)P.init_pos[env * As + a] : (uint32_t)initp->pos[a];
-        init_avail_a = PES ? (uint32_t)P.init_avail[env * As + a] : (uint32_t)initp->avail[a];
-    }
-    uint64_t init_bits = initp->bits;
-    uint32_t init_gems = initp->gems;
+    uint64_t init_bits = 0;
+    uint32_t init_gems = 0;
     // per-environment sources: colours (4 per word), enabled mask, and the env's own reset state
     constexpr int CWM = LM / 4;
     const int CW = src_stride_of(L) / 4;
     uint32_t colw[CWM], env_enabled = h_enabled;
 #pragma unroll
     for (int q = 0; q < CWM; q++) colw[q] = 0;
-    if (PES && env_ok) {
-        env_enabled = P.src_enabled[env];
-#pragma unroll
-        for (int q = 0; q < CWM; q++)
-            if (q < CW) colw[q] = reinterpret_cast<const uint32_t*>(P.src_colour)[env * CW + q];
-        if (K.flags & STEP_AUTO_RESET) {
-            init_bits = P.init_bits[env];
-            init_gems = P.init_gems[env];
+    // The caller's action, read with the rest of the state in the single-step modes: a load inside the step would be
+    // waited for with a vmcnt(0) that every path executes -- the sampling path right behind its store of the sampled
+    // action, i.e. it would wait for that store's acknowledgement before the state machine starts.
+    uint32_t act_given = 4u;
+    // The wavefront's counters, likewise (kernel_common.hpp: flush_stats); the default single-step instantiations only --
+    // the general ones have no registers to spare, a rollout flushes once per launch.
+    constexpr bool PRE_STATS = (MODE == 0 || MODE == 6) && LM <= 8;  // (16 / 32 beam registers: already spilling)
+    int64_t stats_old = 0;
+    // (a macro, not a lambda: with the beam registers captured by reference the 32-source instantiations kept them in scratch)
+#define LLE_LOAD_STATE() \
+    do { \
+        if (env_ok) { \
+            raw_bits = *p_bits; \
+            gems = *p_gems; \
+        _Pragma("unroll") \
+            for (int b = 0; b < LM; b++) \
+                if (b < L) beams[b] = p_beams[b]; \
+        } \
+        if (me) { \
+            pos = (uint32_t)*p_pos; \
+            avail = (uint32_t)*p_avail; \
+            init_pos_a = PES ? (uint32_t)P.init_pos[env * As + a] : (uint32_t)initp->pos[a]; \
+            init_avail_a = PES ? (uint32_t)P.init_avail[env * As + a] : (uint32_t)initp->avail[a]; \
+            if (!ROLL && !(K.flags & STEP_SAMPLE_ACTIONS)) \
+                act_given = K.actions_in ? (uint32_t)K.actions_in[env * A + a] : (uint32_t)P.actions[env * As + a]; \
+        } \
+        init_bits = initp->bits; \
+        init_gems = initp->gems; \
+        if (PRE_STATS) stats_old = stats_preload(P.stats, wave_id, lane); \
+        if (PES && env_ok) { \
+            env_enabled = P.src_enabled[env]; \
+        _Pragma("unroll") \
+            for (int q = 0; q < CWM; q++) \
+                if (q < CW) colw[q] = reinterpret_cast<const uint32_t*>(P.src_colour)[env * CW + q]; \
+            if (K.flags & STEP_AUTO_RESET) { \
+                init_bits = P.init_bits[env]; \
+                init_gems = P.init_gems[env]; \
+            } \
+        } \
+    } while (0)
+
+    // HEAD (the default instantiation): the lines of every row that no agent, beam or gem can change (tables.h head_lo /
+    // head_n) are stored BEFORE the state machine, from the pristine template in global memory.  Every vector load of the
+    // kernel is therefore issued first -- the head chunk, the state, the caller's actions, the table rows -- and has
+    // returned before the first store: the vmcnt counter is in order, so a load waited for AFTER the head stores would
+    // wait for their acknowledgements (and the compiler does not see the `sc1` stores, which are inline asm).
+    const uint32_t head_lo = HEAD ? hdr->head_lo : 0u, head_n = (HEAD && write_obs && !split) ? hdr->head_n : 0u;
+    uint4 head_v = {0u, 0u, 0u, 0u};
+    if (HEAD) {
+        if (lane < head_n) head_v = reinterpret_cast<const uint4*>(tables + h_off_template)[head_lo + lane];
+        LLE_LOAD_STATE();
+    }
+    // (split rows: the pristine static observation stays in global memory, every wavefront copies its slice from there)
+    const uint32_t tab_bytes = split ? hdr->lds_split_table_bytes : hdr->lds_table_bytes, tab_off = hdr->off_cell_lay;
+    copy_tables_to_lds(tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
+    const uint32_t ext_bytes = PES ? hdr->ext_bytes : 0u;
+    if (PES) copy_tables_to_lds(tables + hdr->off_bare, lds + tab_bytes, ext_bytes, lane, wave_in_wg, waves_per_wg);
+    LLE_STAMP(7);
+    if (HEAD) {
+        // every load has returned (the table rows were the last ones, and they are in LDS): said with an s_waitcnt the
+        // compiler can see, or it puts its own vmcnt(0) where the loaded values are first used -- inside the loop of
+        // head stores and in the state machine -- where it would wait for the stores as well
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        if (head_n && n_here > 0) {
+            if (K.flags & LAUNCH_WRITE_THROUGH) store_heads<true>(P.obs, h_obs_stride, env0, n_here, head_lo, head_n, head_v, lane);
+            else store_heads<false>(P.obs, h_obs_stride, env0, n_here, head_lo, head_n, head_v, lane);
         }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS only: not the head stores' acknowledgements
+    } else {
+        __syncthreads();  // the only workgroup barrier
+        LLE_LOAD_STATE();
     }
 
     const uint64_t* cell_lay = reinterpret_cast<const uint64_t*>(lds);
-    const uint32_t* cell_meta = reinterpret_cast<const uint32_t*>(lds + (hdr->off_cell_meta - tab_off));
-    const uint64_t* dyn = reinterpret_cast<const uint64_t*>(lds + (hdr->off_dyn - tab_off));
+    const uint32_t* cell_meta = reinterpret_cast<const uint32_t*>(lds + (h_off_cell_meta - tab_off));
+    const uint64_t* dyn = reinterpret_cast<const uint64_t*>(lds + (h_off_dyn - tab_off));
     const uint32_t scr_stride = (uint32_t)(L + A + 2 + (PES ? CW : 0)) | 1u;
     const uint32_t priv_bytes = h_obs_stride + 64u * scr_stride * 4u;
     int8_t* tmpl = reinterpret_cast<int8_t*>(lds + tab_bytes + ext_bytes + wave_in_wg * priv_bytes);
@@ -176,22 +226,27 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     if (split) {
         tmpl = reinterpret_cast<int8_t*>(lds + tab_bytes + wave_in_wg * cpw * 16u);
         scratch = reinterpret_cast<uint32_t*>(lds + tab_bytes + waves_per_wg * cpw * 16u) + wave_in_wg * EPW * scr_stride;
-        const uint4* __restrict__ pristine = reinterpret_cast<const uint4*>(tables + hdr->off_template) + c_lo;
+        const uint4* __restrict__ pristine = reinterpret_cast<const uint4*>(tables + h_off_template) + c_lo;
         uint4* mine = reinterpret_cast<uint4*>(tmpl);
         for (uint32_t c = lane; c < c_hi - c_lo; c += 64) mine[c] = pristine[c];
     } else {
-        const uint4* pristine = PES ? reinterpret_cast<const uint4*>(bare) : reinterpret_cast<const uint4*>(lds + (hdr->off_template - tab_off));
+        const uint4* pristine = PES ? reinterpret_cast<const uint4*>(bare) : reinterpret_cast<const uint4*>(lds + (h_off_template - tab_off));
         uint4* mine = reinterpret_cast<uint4*>(tmpl);
         for (uint32_t c = lane; c < h_n_chunks; c += 64) mine[c] = pristine[c];
     }
     wave_sync();
+    // Every load of the prologue has to be back before the state machine starts anyway.  Saying so with an s_waitcnt the
+    // compiler sees keeps it from carrying the loads that only some paths consume (the reset record) as pending: it
+    // guards later reuses of their registers with vmcnt(0), and in hardware that also waits for every observation store
+    // in flight (the level-1 instantiation had two such waits behind its stream: 14.2 -> 14.8 us at 65 536 envs).
+    if (!HEAD) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); HEAD: said before the head stores
     LLE_STAMP(1);
 
     uint32_t alive = (uint32_t)raw_bits & 0xFFFFu, arrived = (uint32_t)(raw_bits >> 16) & 0xFFFFu, occ = (uint32_t)(raw_bits >> 32) & 0xFFFFu;
     // agents that set_state flagged dead WITHOUT a death event (tables.h GHOST_SHIFT): LLE.compute_done counts events, so
     // they do not end the episode (python/lle/env/env.py:208-217,253-254).  Zero except after such a set_state.
     uint32_t ghost = (uint32_t)(raw_bits >> GHOST_SHIFT);
-    const uint32_t enabled = PES ? env_enabled : h_enabled, max_layers = ML1 ? 1u : hdr->max_layers;
+    const uint32_t enabled = PES ? env_enabled : h_enabled, max_layers = h_max_layers;
     LLE_STAMP(2);
 
     // ---- n_steps consecutive steps of the wave's environments; the state stays in registers in between.
@@ -237,6 +292,9 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         const uint32_t hp = action_hash_pair(action_step_key(K.seed, t_now), (uint64_t)(K.env_offset + env), a >> 1);
         act = sample_action(avail, action_field(hp, a));
         if (me) actions_out[env * As + a] = (uint8_t)act;
+    } else if (!ROLL) {
+        act = act_given;
+        if (me && K.actions_in) P.actions[env * As + a] = (uint8_t)act;
     } else if (K.actions_in) {
         if (me) {
             act = (uint32_t)K.actions_in[env * A + a];  // caller's buffer: contiguous [n][A]
@@ -298,7 +356,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     // Only the general single-step instantiations (MODE 4 / 5) carry it -- the launcher routes a launch with outputs there --
     // so that the default path keeps its registers (with the epilogue in MODE 0: 112 -> 127 VGPRs and 21.2 -> 21.6 us
     // for launches that do not even use it).
-    if (MODE >= 4 && K.env_out) {
+    if ((MODE == 4 || MODE == 5) && K.env_out) {
         const EnvOutputs O = *K.env_out;  // uniform address: scalar loads
         const int n_gems = (int)hdr->G, len = 3 * A + n_gems;
         if (me) {
@@ -395,8 +453,8 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
             else write_observations_env<false>(A, L, h_HW, hdr->n_elems, h_n_chunks, h_obs_stride, elems, bare, tmpl, scratch, scr_stride,
                                                obs_out, env0, n_here, lane);
         } else {
-            if (wt) write_observations<true>(A, L, h_D, h_n_chunks, h_obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane);
-            else write_observations<false>(A, L, h_D, h_n_chunks, h_obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane);
+            if (wt) write_observations<true, HEAD>(A, L, h_D, h_n_chunks, h_obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane, head_lo, head_n);
+            else write_observations<false, HEAD>(A, L, h_D, h_n_chunks, h_obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane, head_lo, head_n);
         }
     }
     wave_sync();
@@ -418,8 +476,9 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         for (int b = 0; b < LM; b++)
             if (b < L) beams_out[b] = beams[b];
 #undef LLE_LATE
+#undef LLE_LOAD_STATE
     }
-    flush_stats(P.stats, wave_id, cnt, A, lane);
+    flush_stats(P.stats, wave_id, cnt, A, lane, PRE_STATS, stats_old);
     if (ROLL && stamps) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         LLE_STAMP(6);
@@ -457,6 +516,11 @@ static hipError_t launch_step_mode_gl(const BatchPtrs& P, const LaunchArgs& K, u
 }
 template <int MODE, int G>
 static hipError_t launch_step_mode_g(int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
+    if constexpr (MODE == 6) {  // (the launcher sends maps with more than 8 sources to MODE 0)
+        if (lm == 4) return launch_step_mode_gl<MODE, G, 4>(P, K, n_waves, wpw, lds, stream);
+        if (lm == 8) return launch_step_mode_gl<MODE, G, 8>(P, K, n_waves, wpw, lds, stream);
+        return hipErrorInvalidValue;
+    }
     switch (lm) {
         case 4: return launch_step_mode_gl<MODE, G, 4>(P, K, n_waves, wpw, lds, stream);
         case 8: return launch_step_mode_gl<MODE, G, 8>(P, K, n_waves, wpw, lds, stream);

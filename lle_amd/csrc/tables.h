@@ -65,8 +65,12 @@ struct MapHeader {
     // bit c: source s may take colour c -- no possible start of an agent other than c lies on the tiles World::lasers()
     // exposes for that source (the check of the binding's LaserSource.set_colour, src/bindings/tiles/pylaser_source.rs:121-139)
     uint16_t colour_ok[MAX_SOURCES];
+    // The "head" of a row: chunks [head_lo, head_lo + head_n) (whole 128-byte lines, at most 64 chunks) hold no byte that
+    // an agent, a beam or a gem can change -- identical in every environment at every step.  The default step kernel
+    // stores them BEFORE the state machine runs (step_kernel.hpp); head_n = 0: no such run of lines (or unaligned rows).
+    uint32_t head_lo, head_n, head_pad[10];  // (pads the header to 512 B: the table sections behind it start on a 128-byte line)
 };
-static_assert(sizeof(MapHeader) % 16 == 0, "sections must stay 16-byte aligned");
+static_assert(sizeof(MapHeader) % 128 == 0, "the sections start on a 128-byte line (the LDS copy loads 1 KiB per wave instruction)");
 
 constexpr uint32_t MAP_MAGIC = 0x31454C4Cu;
 

@@ -173,3 +173,35 @@ def test_world_state_hash_eq_and_pickle():
         s = WorldState(gems_collected=[rng.choice([True, False]) for _ in range(rng.randint(0, 10))],
                        agents_positions=[(rng.randint(0, 50), rng.randint(0, 90)) for _ in range(rng.randint(0, 10))])
         assert pickle.loads(pickle.dumps(s)) == s
+
+
+@pytest.mark.parametrize("name", sorted(dict({f"level{k}": v for k, v in LEVELS.items()}, **EXTRA_MAPS)))
+def test_row_head_bytes_never_change(oracle_mod, name):
+    """lle_map_row_head: whole 128-byte lines behind the agent layers whose bytes are the same in every environment after
+    every step (the step kernel stores them before its state machine).  Checked against oracle rollouts with deaths,
+    collected gems and beams switching, with and without resets."""
+    from lle_amd import Map
+
+    text = dict({f"level{k}": v for k, v in LEVELS.items()}, **EXTRA_MAPS)[name]
+    m = Map(text, row_align=128)
+    with pytest.raises(ValueError):
+        m.set_head_lines(9)
+    m.set_head_lines(8)
+    first, nbytes = m.row_head
+    assert first % 128 == 0 and nbytes % 128 == 0 and 0 <= nbytes <= 1024 and first + nbytes <= m.obs_stride
+    if m.obs_supported:
+        assert nbytes == 0 or first + 127 >= m.n_agents * m.height * m.width
+    lo, hi = min(first, m.obs_bytes), min(first + nbytes, m.obs_bytes)
+    n = 256
+    ob = oracle_mod.OracleBatch(text, n)
+    ref = None
+    for t in range(60):
+        rows = ob.step(None, auto_reset=(t // 20) % 2 == 0, seed=21, t=t)["obs"].reshape(n, -1)
+        ref = rows[0, lo:hi].copy() if ref is None else ref
+        assert (rows[:, lo:hi] == ref).all(), (name, t)
+    # unaligned rows have no head; 0 switches it off; -1 is the automatic size (a fifth of the row, at most 8 lines)
+    assert Map(text, row_align=16).row_head[1] == 0 or Map(text, row_align=16).obs_stride % 128 == 0
+    m.set_head_lines(0)
+    assert m.row_head[1] == 0
+    m.set_head_lines(-1)
+    assert m.row_head[1] <= max(128, min(1024, (m.obs_stride // 128 + 2) // 5 * 128))

@@ -1,0 +1,106 @@
+"""Row heads (lle_map_set_head_lines / lle_map_row_head): the default step kernel stores the lines of every row that no
+agent, beam or gem can change BEFORE its state machine, and streams the rest afterwards.  The launcher only does it for
+launches of one to two rounds of workgroups; LLE_ROW_HEADS=1 forces it so that the small batches here take that path.
+Every buffer must equal the oracle's whatever the head size, and equal the run without heads."""
+import numpy as np
+import pytest
+
+from oracle.levels import LEVELS
+from tests.parity_util import EXTRA_MAPS
+from tests.test_gpu_parity import check
+
+pytestmark = pytest.mark.gpu
+
+MAPS = dict({f"level{k}": v for k, v in LEVELS.items()}, **EXTRA_MAPS)
+
+
+@pytest.fixture
+def heads_forced(monkeypatch):
+    monkeypatch.setenv("LLE_ROW_HEADS", "1")
+
+
+@pytest.mark.parametrize("name", ["level2", "level3", "level5", "level6", "nested", "colour_alias", "gen_16x16_12agents"])
+@pytest.mark.parametrize("lines", [-1, 1, 4, 8])
+def test_heads_match_oracle(oracle_mod, heads_forced, name, lines):
+    from lle_amd import BatchedWorld, Map
+
+    m = Map(MAPS[name], row_align=128)
+    m.set_head_lines(lines)
+    first, nbytes = m.row_head
+    assert first % 128 == 0 and nbytes % 128 == 0 and nbytes <= (8 if lines < 0 else lines) * 128
+    assert first >= m.n_agents * m.height * m.width or nbytes == 0  # behind the agent layers
+    n = 1000
+    ob = oracle_mod.OracleBatch(MAPS[name], n)
+    bw = BatchedWorld(m, n)
+    bw.obs_rows.fill_(55)  # the launch must write every byte of every row itself, head included
+    for t in range(24):
+        auto = t % 8 != 7
+        bw.step(sample=True, auto_reset=auto, seed=99, t=t, env_offset=5)
+        check(bw, ob, ob.step(None, auto_reset=auto, seed=99, t=t, env_offset=5), f"{name} lines={lines} t={t}")
+        assert int(bw.obs_rows[:, m.obs_bytes:].abs().max()) == 0 if m.obs_stride > m.obs_bytes else True
+
+
+def test_heads_with_given_actions(oracle_mod, heads_forced):
+    """The caller's actions (lle_batch_step `actions` and the batch's own LLE_BUF_ACTIONS) are read up front on this path."""
+    import torch
+
+    from lle_amd import BatchedWorld, Map
+    from lle_amd._capi import lib
+
+    n = 640
+    m = Map(LEVELS[6])
+    assert m.row_head[1] > 0
+    ob = oracle_mod.OracleBatch(LEVELS[6], n)
+    bw = BatchedWorld(m, n)
+    rng = np.random.default_rng(3)
+    for t in range(30):
+        actions = rng.integers(0, 6, size=(n, ob.A), dtype=np.uint8)  # unavailable and out-of-range (5) included
+        if t % 2:
+            bw.step(torch.from_numpy(actions).cuda())
+        else:  # actions already in LLE_BUF_ACTIONS: NULL action pointer, no sampling
+            bw.actions.copy_(torch.from_numpy(actions).cuda())
+            assert lib().lle_batch_step(bw.h, None, 0, 0, t, 0, bw._stream()) == 0
+        check(bw, ob, ob.step(actions), f"t={t}")
+
+
+@pytest.mark.parametrize("name", ["level6", "level3"])
+def test_heads_on_and_off_agree_at_full_batch(name, monkeypatch):
+    """65 536 envs (the launcher's own choice is heads ON there): same buffers with LLE_ROW_HEADS=0."""
+    import torch
+
+    from lle_amd import BatchedWorld, Map
+
+    n = 65536
+    a, b = BatchedWorld(Map(MAPS[name]), n), BatchedWorld(Map(MAPS[name]), n)
+    assert a.map.row_head[1] > 0
+    for t in range(12):
+        monkeypatch.delenv("LLE_ROW_HEADS", raising=False)
+        a.step(sample=True, auto_reset=True, seed=4, t=t)
+        monkeypatch.setenv("LLE_ROW_HEADS", "0")
+        b.step(sample=True, auto_reset=True, seed=4, t=t)
+    for k in ("pos", "bits", "gems", "beams", "avail", "events", "evcount", "done", "obs"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+
+
+def test_source_update_moves_the_head(oracle_mod, heads_forced):
+    """lle_batch_update_sources recompiles the tables: a colour change moves beam bytes to another layer, and the head with them."""
+    from lle_amd import BatchedWorld, Map
+
+    n = 500
+    m = Map(LEVELS[6])
+    m.set_head_lines(8)
+    ob = oracle_mod.OracleBatch(LEVELS[6], n)
+    bw = BatchedWorld(m, n)
+    heads = {m.row_head}
+    for colour in (3, 0, 2, 1):
+        if not m.colour_allowed(0, colour):
+            continue
+        m.set_source(0, agent_id=colour)
+        bw.update_sources()
+        for e in range(n):
+            ob.world(e).set_source(0, colour=colour)
+        heads.add(m.row_head)
+        for t in range(6):
+            bw.step(sample=True, auto_reset=True, seed=8, t=t)
+            check(bw, ob, ob.step(None, auto_reset=True, seed=8, t=t), f"colour {colour} t={t}")
+    assert len(heads) >= 2, heads
