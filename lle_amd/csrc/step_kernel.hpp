@@ -520,12 +520,13 @@ static hipError_t launch_step_mode_g(int lm, const BatchPtrs& P, const LaunchArg
         if (lm == 4) return launch_step_mode_gl<MODE, G, 4>(P, K, n_waves, wpw, lds, stream);
         if (lm == 8) return launch_step_mode_gl<MODE, G, 8>(P, K, n_waves, wpw, lds, stream);
         return hipErrorInvalidValue;
-    }
-    switch (lm) {
-        case 4: return launch_step_mode_gl<MODE, G, 4>(P, K, n_waves, wpw, lds, stream);
-        case 8: return launch_step_mode_gl<MODE, G, 8>(P, K, n_waves, wpw, lds, stream);
-        case 16: return launch_step_mode_gl<MODE, G, 16>(P, K, n_waves, wpw, lds, stream);
-        default: return launch_step_mode_gl<MODE, G, 32>(P, K, n_waves, wpw, lds, stream);
+    } else {
+        switch (lm) {
+            case 4: return launch_step_mode_gl<MODE, G, 4>(P, K, n_waves, wpw, lds, stream);
+            case 8: return launch_step_mode_gl<MODE, G, 8>(P, K, n_waves, wpw, lds, stream);
+            case 16: return launch_step_mode_gl<MODE, G, 16>(P, K, n_waves, wpw, lds, stream);
+            default: return launch_step_mode_gl<MODE, G, 32>(P, K, n_waves, wpw, lds, stream);
+        }
     }
 }
 template <int MODE>

@@ -25,7 +25,7 @@ ENV = dict(os.environ, TMPDIR="/tmp")
 BENCH = os.path.join(ROOT, "bench.py")
 # (label, kernel-name fragment, grid size in work-items = waves x 64): the single-step launches of the bench line
 WORKLOADS = [
-    ("cfg3 level 6 x 65 536 (headline)", "step_kernel<4, 4, 0, true, 3>", 65536 // 16 * 64, 1937 * 65536),
+    ("cfg3 level 6 x 65 536 (headline)", "step_kernel<4, 4, 6, true, 3>", 65536 // 16 * 64, 1937 * 65536),  # MODE 6: row heads first
     ("level 6 x 262 144 (rows > Infinity Cache)", "step_kernel<4, 4, 0, true, 3>", 262144 // 16 * 64, 1937 * 262144),
     ("cfg2 level 1 x 4 096", "step_kernel<1, 4, 0, true, 0>", 4096 // 4 * 64, 953 * 4096),
     ("cfg5 32x32 8 agents x 65 536", "step_kernel<8, 8, 0, false, -1>", 65536 // 8 * 64, 20617 * 65536),
