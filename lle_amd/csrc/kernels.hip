@@ -578,13 +578,15 @@ hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const Laun
     // first of each pair with the rollout loop, rings and stamps, the second for single-step launches
     const bool roll = (K.flags & LAUNCH_ROLLOUT) != 0;
     if (pes) return roll ? launch_step_mode3(G, lm, P, K, n_waves, wpw, lds, stream) : launch_step_mode5(G, lm, P, K, n_waves, wpw, lds, stream);
-    if (K.flags & LAUNCH_GENERAL)
-        return roll ? launch_step_mode2(G, lm, P, K, n_waves, wpw, lds, stream) : launch_step_mode4(G, lm, P, K, n_waves, wpw, lds, stream);
+    // single-step launches with the map's sources: the rows' head lines go out ahead of the state machine (MODE 6 / 7) when
+    // the map has a head, the rows are not split and the launch is of the size where it pays
+    const bool heads = !roll && lm <= 8 && h.head_n != 0 && !(K.flags & (LAUNCH_SPLIT_ROWS | STEP_NO_OBS)) && row_heads_pay(n_waves);
+    if (K.flags & LAUNCH_GENERAL) {
+        if (roll) return launch_step_mode2(G, lm, P, K, n_waves, wpw, lds, stream);
+        return heads ? launch_step_mode7(G, lm, P, K, n_waves, wpw, lds, stream) : launch_step_mode4(G, lm, P, K, n_waves, wpw, lds, stream);
+    }
     if (roll) return launch_step_mode1(G, lm, P, K, n_waves, wpw, lds, stream);
-    // one step in place, one map, the map's sources: with the rows' head lines ahead of the state machine (MODE 6) when the
-    // map has a head, the rows are not split and the launch is of the size where it pays
-    if (lm <= 8 && h.head_n != 0 && !(K.flags & (LAUNCH_SPLIT_ROWS | STEP_NO_OBS)) && row_heads_pay(n_waves))
-        return launch_step_mode6(G, lm, P, K, n_waves, wpw, lds, stream);
+    if (heads) return launch_step_mode6(G, lm, P, K, n_waves, wpw, lds, stream);
     return launch_step_mode0(G, lm, P, K, n_waves, wpw, lds, stream);
 }
 

@@ -39,19 +39,20 @@ namespace lle {
 // MODE 6: MODE 0 for launches of one to two rounds of workgroups (kernels.hip: row_heads_pay): the rows' static head lines are
 // stored before the state machine, and every load of the kernel is issued up front (see HEAD below).  An instantiation
 // of its own: a launch without heads runs 0.2-0.4 us slower with that load order (level 1: 5.9 -> 6.1 us at 4 096 envs).
-// Maps with at most 8 sources only (with 16 / 32 beam registers the early state loads spill).
+// Maps with at most 8 sources only (with 16 / 32 beam registers the early state loads spill).  MODE 7: the same for MODE 4
+// (several maps / the fused LLE.step outputs).
 // LX >= 0: the exact number of sources, known at compile time (instantiated for the default path of maps with at
 // most four sources: the per-beam loops lose their guards and the unused beam registers disappear; 0.4 us on level 6).
 template <int G, int LM, int MODE, bool ML1, int LX = -1>
 __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P, LaunchArgs K) {
-    constexpr bool GEN = MODE >= 2 && MODE <= 5, ROLL = MODE >= 1 && MODE <= 3;
+    constexpr bool GEN = (MODE >= 2 && MODE <= 5) || MODE == 7, ROLL = MODE >= 1 && MODE <= 3;
     constexpr bool PES = MODE == 3 || MODE == 5;  // (the launcher picks these exactly when LAUNCH_PER_ENV_SOURCES is set)
     // Big rows (LAUNCH_SPLIT_ROWS, set by the launcher when private whole-row copies would leave one workgroup per CU):
     // the row is split over the wavefronts of the workgroup, see write_observations_split (obs_stream.hpp).  Only the
     // instantiations of maps with more than four agents carry it (rows of 16 KB and more with at most four agents
     // would need maps beyond 36 x 36; those stay on whole-row copies), and not the per-env-sources modes.
     constexpr bool CAN_SPLIT = G >= 8 && !PES;
-    constexpr bool HEAD = MODE == 6;  // MODE 0 with the static lines of the rows ahead of the state machine (below)
+    constexpr bool HEAD = MODE == 6 || MODE == 7;  // MODE 0 / 4 with the static lines of the rows ahead of the state machine (below)
     const bool split = CAN_SPLIT && (K.flags & LAUNCH_SPLIT_ROWS) != 0;
     // The default instantiation is one step in place and nothing else: the fused rollout (n_steps, trajectory rings)
     // and the timeline stamps run on the general one, so that their arguments do not occupy scalar registers here.
@@ -98,6 +99,15 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     // the kernel's own stores, and the compiler cannot tell the header from the rows -- whose wait covers the stores too)
     const uint32_t h_off_cell_meta = hdr->off_cell_meta, h_off_dyn = hdr->off_dyn, h_off_template = hdr->off_template;
     const uint32_t h_max_layers = ML1 ? 1u : hdr->max_layers;
+    // (MODE 7: so are the fused LLE.step outputs' descriptor and the header fields of that epilogue)
+    constexpr bool ENV_OUT = MODE == 4 || MODE == 5 || MODE == 7;
+    EnvOutputs O_early = {};
+    uint32_t h_G = 0, h_H = 0;
+    if (HEAD && ENV_OUT && K.env_out) {
+        O_early = *K.env_out;
+        h_G = hdr->G;
+        h_H = hdr->H;
+    }
     uint32_t h_init_beams[LM];  // the reset state's beams (shared record; the per-env one is read where it is used)
 #pragma unroll
     for (int b = 0; b < LM; b++) h_init_beams[b] = (b < L) ? initp->beams[b] : 0u;
@@ -143,7 +153,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     uint32_t act_given = 4u;
     // The wavefront's counters, likewise (kernel_common.hpp: flush_stats); the default single-step instantiations only --
     // the general ones have no registers to spare, a rollout flushes once per launch.
-    constexpr bool PRE_STATS = (MODE == 0 || MODE == 6) && LM <= 8;  // (16 / 32 beam registers: already spilling)
+    constexpr bool PRE_STATS = (MODE == 0 || MODE == 6 || MODE == 7) && LM <= 8;  // (16 / 32 beam registers: already spilling)
     int64_t stats_old = 0;
     // (a macro, not a lambda: with the beam registers captured by reference the 32-source instantiations kept them in scratch)
 #define LLE_LOAD_STATE() \
@@ -356,9 +366,9 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     // Only the general single-step instantiations (MODE 4 / 5) carry it -- the launcher routes a launch with outputs there --
     // so that the default path keeps its registers (with the epilogue in MODE 0: 112 -> 127 VGPRs and 21.2 -> 21.6 us
     // for launches that do not even use it).
-    if ((MODE == 4 || MODE == 5) && K.env_out) {
-        const EnvOutputs O = *K.env_out;  // uniform address: scalar loads
-        const int n_gems = (int)hdr->G, len = 3 * A + n_gems;
+    if (ENV_OUT && K.env_out) {
+        const EnvOutputs O = HEAD ? O_early : *K.env_out;  // uniform address: scalar loads
+        const int n_gems = HEAD ? (int)h_G : (int)hdr->G, len = 3 * A + n_gems;
         if (me) {
             const int64_t ia = env * A + a;
             if (O.alive) O.alive[ia] = (uint8_t)((alive >> a) & 1u);
@@ -372,8 +382,8 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
                 float* st = O.state + env * len;
                 float fi = (float)(pos & 0xFFu), fj = (float)(pos >> 8);
                 if (O.normalize_state) {  // divided in float64, rounded to float32 on assignment (observations.py:145-175)
-                    fi = (float)((double)(pos & 0xFFu) / (double)hdr->H);
-                    fj = (float)((double)(pos >> 8) / (double)hdr->W);
+                    fi = (float)((double)(pos & 0xFFu) / (double)(HEAD ? h_H : hdr->H));
+                    fj = (float)((double)(pos >> 8) / (double)W);
                 }
                 st[2 * a] = fi;
                 st[2 * a + 1] = fj;
@@ -516,7 +526,7 @@ static hipError_t launch_step_mode_gl(const BatchPtrs& P, const LaunchArgs& K, u
 }
 template <int MODE, int G>
 static hipError_t launch_step_mode_g(int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
-    if constexpr (MODE == 6) {  // (the launcher sends maps with more than 8 sources to MODE 0)
+    if constexpr (MODE == 6 || MODE == 7) {  // (the launcher sends maps with more than 8 sources to MODE 0 / 4)
         if (lm == 4) return launch_step_mode_gl<MODE, G, 4>(P, K, n_waves, wpw, lds, stream);
         if (lm == 8) return launch_step_mode_gl<MODE, G, 8>(P, K, n_waves, wpw, lds, stream);
         return hipErrorInvalidValue;

@@ -1,0 +1,45 @@
+"""The general single-step kernels with row heads (step_kernel MODE 7: several maps per batch, the fused LLE.step
+outputs): the existing tests of those paths, collected again with LLE_ROW_HEADS=1 so that their small batches take the
+head path (the launcher's own choice needs 2 048+ wavefronts), on 128-byte aligned rows (rows without a head otherwise)."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def heads_forced_on_aligned_rows(monkeypatch):
+    from lle_amd import BatchedWorld
+
+    monkeypatch.setenv("LLE_ROW_HEADS", "1")
+    orig = BatchedWorld.__init__
+
+    def init(self, map_or_text, n_envs, device=None, envs_per_wave=None, row_align=None):
+        orig(self, map_or_text, n_envs, device=device, envs_per_wave=envs_per_wave, row_align=128 if row_align is None else row_align)
+
+    monkeypatch.setattr(BatchedWorld, "__init__", init)
+
+
+from tests.test_gpu_env import (test_batched_lle_env_kat, test_batched_lle_matches_per_env_restatement,  # noqa: E402,F401
+                                test_batched_lle_one_launch_step, test_env_outputs_equals_separate_entry_points,
+                                test_one_launch_step_equals_step_plus_env_outputs)
+from tests.test_gpu_multi_map import test_blocks_of_maps_match_their_oracles  # noqa: E402,F401
+from tests.test_gpu_parity import test_explicit_and_invalid_actions, test_random_rollout, test_reward_counts_and_snapshot  # noqa: E402,F401
+
+
+def test_fused_step_outputs_with_heads_equal_two_launches():
+    """BatchedLLE.step(fused=True) (one launch, MODE 7 here) against the two-launch path, level 6, every output."""
+    import torch
+
+    from lle_amd import BatchedLLE
+    from oracle.levels import LEVELS
+
+    n = 3000
+    a, b = BatchedLLE(LEVELS[6], n), BatchedLLE(LEVELS[6], n)
+    a.reset(), b.reset()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for t in range(30):
+        avail = a.available_actions()
+        acts = torch.multinomial(avail.reshape(-1, 5).float(), 1, generator=g).reshape(n, -1).to(torch.uint8)
+        x, y = a.step(acts, auto_reset=True, fused=True), b.step(acts, auto_reset=True)
+        for k in ("obs", "state", "reward", "done", "available_actions", "err"):
+            assert torch.equal(x[k], y[k]), (k, t)
