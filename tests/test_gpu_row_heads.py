@@ -19,7 +19,7 @@ def heads_forced(monkeypatch):
     monkeypatch.setenv("LLE_ROW_HEADS", "1")
 
 
-@pytest.mark.parametrize("name", ["level2", "level3", "level5", "level6", "nested", "colour_alias", "gen_16x16_12agents"])
+@pytest.mark.parametrize("name", ["level1", "level2", "level3", "level5", "level6", "nested", "colour_alias", "gen_16x16_12agents"])
 @pytest.mark.parametrize("lines", [-1, 1, 4, 8])
 def test_heads_match_oracle(oracle_mod, heads_forced, name, lines):
     from lle_amd import BatchedWorld, Map

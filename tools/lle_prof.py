@@ -15,6 +15,7 @@
   pipe        state machine and observation as two kernels on two streams (timing prototype)
   streams     the batch split over k HIP streams
   placement   several arenas of the same batch side by side: does the write rate depend on where a buffer lands?
+  heads       row heads (lle_map_set_head_lines): us per launch by head size, over maps and batch sizes
   stamps      in-kernel s_memrealtime timeline of the step kernel (--fine: per-quarter view of a stamped MODE-0 build)
   target      a fixed workload for `rocprofv3 --pmc ... -- python3 tools/lle_prof.py target ...` (step / noobs / partial / cfg5 / hbm)
 
@@ -335,6 +336,31 @@ def cmd_stamps(args):
                   f"{np.percentile(s[sl, 3] - t0, 50):6.2f}; entry p50 {np.percentile(s[sl, 0] - t0, 50):6.2f}")
 
 
+def cmd_heads(args):
+    """Row heads (lle_map_set_head_lines): us per launch by head size, over maps and batch sizes (heads forced on)."""
+    os.environ["LLE_ROW_HEADS"] = "1"
+    cases = [("level 6", lambda: Map(level=6), [16384, 32768, 65536, 131072, 262144]), ("level 5", lambda: Map(level=5), [65536]),
+             ("level 3", lambda: Map(level=3), [65536, 131072]),
+             ("generated 16x16, 8 agents", lambda: Map(mapgen.generate(16, 16, 8, 4, 4, seed=1), row_align=128), [16384, 32768]),
+             ("generated 12x12, 12 agents", lambda: Map(mapgen.generate(12, 12, 12, 4, 4, seed=1), row_align=128), [8192, 16384])]
+    for name, mk, sizes in cases:
+        m0 = mk()
+        auto = m0.row_head[1] // 128
+        m0.set_head_lines(8)
+        print(f"{name}: {m0.n_agents} agents, rows of {m0.obs_stride} B, longest static run {m0.row_head}, automatic head {auto} lines", flush=True)
+        for n in sizes:
+            out = []
+            for h in (0, 1, 2, 3, 4, 6, 8):
+                m = mk()
+                m.set_head_lines(h)
+                if h and m.row_head[1] < h * 128:
+                    break
+                bw = BatchedWorld(m, n)
+                out.append(f"{h}:{timeit(stepper(bw), iters=200):.2f}")
+                del bw
+            print(f"  n={n}: " + "  ".join(out), flush=True)
+
+
 def cmd_target(args):
     """A fixed workload to put behind `rocprofv3 ... --` (kernel trace or one --pmc pass)."""
     what = args.what
@@ -368,7 +394,7 @@ def main():
     sub = ap.add_subparsers(dest="cmd", required=True)
     cmds = {"step": cmd_step, "logic": cmd_logic, "configs": cmd_configs, "hbm": cmd_hbm, "rollout": cmd_rollout, "observers": cmd_observers,
             "env": cmd_env, "sources": cmd_sources, "multimap": cmd_multimap, "graph": cmd_graph, "pipe": cmd_pipe, "streams": cmd_streams,
-            "placement": cmd_placement, "stamps": cmd_stamps, "target": cmd_target}
+            "placement": cmd_placement, "stamps": cmd_stamps, "heads": cmd_heads, "target": cmd_target}
     for name, fn in cmds.items():
         p = sub.add_parser(name, help=(fn.__doc__ or "").strip().split("\n")[0])
         p.add_argument("--level", type=int, default=6)
