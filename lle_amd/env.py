@@ -220,7 +220,7 @@ class BatchedLLE:
         """LLE.step (env.py:165-187) for every env.  actions: integer tensor [n, n_agents] (Action values).
         fused=True (needs walkable_lasers): state / reward / available_actions are written by the step kernel itself
         (lle_batch_step_outputs) into PERSISTENT tensors that the next step overwrites -- one launch per step instead of
-        two (26.3 -> 21.6 us at 65 536 level-6 envs); the default returns fresh tensors every step.
+        two (25.3 -> 21.6 us at 65 536 level-6 envs); the default returns fresh tensors every step.
         The reference refuses to step a finished environment (`Cannot step in a done environment`); here such an env
         is the caller's to reset -- or pass auto_reset=True: an env that is done when the step starts is reset first
         (with fresh colours under randomize_lasers), the usual vector-env convention.
