@@ -119,6 +119,11 @@ int lle_map_set_source(lle_map* map, int laser_id, int enabled, int agent_id);
 /* 1 if source `laser_id` may take colour `agent_id` without a possible start of another agent on its beam (the check of
  * the binding's LaserSource.set_colour, src/bindings/tiles/pylaser_source.rs:121-139), 0 if not, negative on bad arguments. */
 int lle_map_colour_allowed(const lle_map* map, int laser_id, int agent_id);
+/* The beam of source `laser_id` right after World.reset (src/core/world.rs:411-432) when the source is enabled and has
+ * colour `agent_id`: bit k = the tile at offset k is on (all on, cut from where that agent's start lies inside the beam:
+ * Laser::pre_enter, src/core/tiles/laser.rs:173-182).  What LLE_STEP_RECOLOUR_RESETS stores as the env's reset beams.
+ * Negative status on bad arguments. */
+int64_t lle_map_reset_beam(const lle_map* map, int laser_id, int agent_id);
 
 /* Pitch of an observation row (lle_map_info.obs_stride, the env stride of LLE_BUF_OBS and of every layered-style
  * lle_obs_desc): C*H*W rounded up to `align` bytes (16, 32, 64, 128 or 256).  The first C*H*W bytes of a row are the
@@ -214,7 +219,15 @@ enum {
     LLE_STEP_SAMPLE_ACTIONS = 1, /* ignore `actions`: draw uniformly from each agent's available actions with the
                                     counter-based sampler of DESIGN.md (seed, env, t, agent); writes LLE_BUF_ACTIONS */
     LLE_STEP_AUTO_RESET = 2,     /* reset an env at the start of the step when LLE_BUF_DONE says it is over */
-    LLE_STEP_NO_OBS = 4          /* skip the observation write */
+    LLE_STEP_NO_OBS = 4,         /* skip the observation write */
+    LLE_STEP_RECOLOUR_RESETS = 8 /* with LLE_STEP_AUTO_RESET, batches with per-environment sources: an env that is reset also draws a
+                                    fresh colour for each of its sources -- LLE.reset with randomize_lasers (python/lle/env/
+                                    env.py:189-203: world.reset() under the colours the env had, then the new colours on the live
+                                    world).  Uniform over the colours the source may take (lle_map_colour_allowed; all of
+                                    [0, n_agents) on the maps where the reference's own draw cannot fail), drawn with the action
+                                    sampler's hash keyed by (seed ^ 0xC01055EED, env_offset + env, t, laser_id); the new colours
+                                    are in LLE_BUF_SRC_COLOUR after the step.  Maps with a cell of more than two laser layers:
+                                    LLE_ERR_UNSUPPORTED (lle_batch_reset_sources serves those). */
 };
 /* actions_dev: device u8 [n][A], or NULL to use LLE_BUF_ACTIONS as already filled by the host. */
 int lle_batch_step(lle_batch* b, const uint8_t* actions_dev, uint32_t flags, uint64_t seed, uint64_t t,

@@ -18,7 +18,8 @@ LIB_PATH = os.environ.get("LLE_HIP_LIB") or os.path.join(_HERE, "liblle_hip.so")
 BUFFER_NAMES = ["pos", "bits", "gems", "beams", "avail", "actions", "err", "evcount", "events", "done", "obs", "stats",
                 "req_pos", "req_gems", "req_alive", "reward", "src_colour", "src_enabled"]
 LLE_POS_START, LLE_POS_EXIT, LLE_POS_WALL, LLE_POS_VOID, LLE_POS_GEM = range(5)
-LLE_STEP_SAMPLE_ACTIONS, LLE_STEP_AUTO_RESET, LLE_STEP_NO_OBS = 1, 2, 4
+LLE_STEP_SAMPLE_ACTIONS, LLE_STEP_AUTO_RESET, LLE_STEP_NO_OBS, LLE_STEP_RECOLOUR_RESETS = 1, 2, 4, 8
+RECOLOUR_SALT = 0xC01055EED  # the colour draws of LLE_STEP_RECOLOUR_RESETS hash (seed ^ RECOLOUR_SALT, env, t, laser_id)
 LLE_ENV_INVALID_WORLD_STATE, LLE_ENV_OUT_OF_WORLD_POSITION, LLE_ENV_INVALID_AGENT_POSITION = 0x40, 0x41, 0x42
 LLE_ENV_INVALID_COLOUR = 0x43
 LLE_ENV_COLOUR_CROSSES_START = 0x44
@@ -36,7 +37,7 @@ PARSE_ERROR_NAMES = {
 EXPORTS = [
     "lle_abi_version", "lle_last_status", "lle_last_error", "lle_action_hash",
     "lle_map_parse", "lle_map_level", "lle_map_free", "lle_map_get_info", "lle_map_positions", "lle_map_sources",
-    "lle_map_set_source", "lle_map_colour_allowed", "lle_map_set_row_align", "lle_map_set_head_lines", "lle_map_row_head", "lle_map_laser_tiles", "lle_map_world_string",
+    "lle_map_set_source", "lle_map_colour_allowed", "lle_map_reset_beam", "lle_map_set_row_align", "lle_map_set_head_lines", "lle_map_row_head", "lle_map_laser_tiles", "lle_map_world_string",
     "lle_batch_arena_bytes", "lle_batch_create", "lle_batch_arena_bytes_multi", "lle_batch_create_multi", "lle_batch_n_maps", "lle_batch_free", "lle_batch_get_buffer", "lle_batch_n_envs",
     "lle_batch_reset", "lle_batch_step", "lle_batch_rollout", "lle_batch_set_state", "lle_batch_update_sources", "lle_batch_observe",
     "lle_batch_snapshot_bytes", "lle_batch_snapshot", "lle_batch_restore",
@@ -123,6 +124,8 @@ def lib():
     L.lle_map_colour_allowed.argtypes = [vp, i32, i32]
     L.lle_map_set_row_align.restype = i32
     L.lle_map_set_row_align.argtypes = [vp, i32]
+    L.lle_map_reset_beam.restype = C.c_int64
+    L.lle_map_reset_beam.argtypes = [vp, i32, i32]
     L.lle_map_set_head_lines.restype = i32
     L.lle_map_set_head_lines.argtypes = [vp, i32]
     L.lle_map_row_head.restype = i32
@@ -256,6 +259,13 @@ class Map:
         if rc < 0:
             raise ValueError(lib().lle_last_error().decode())
         return bool(rc)
+
+    def reset_beam(self, laser_id, agent_id):
+        """Beam mask of source `laser_id` right after World.reset when it is enabled and has colour `agent_id` (lle_map_reset_beam)."""
+        v = lib().lle_map_reset_beam(self.h, int(laser_id), int(agent_id))
+        if v < 0:
+            raise ValueError(lib().lle_last_error().decode())
+        return int(v)
 
     def set_row_align(self, align):
         if lib().lle_map_set_row_align(self.h, int(align)) != 0:

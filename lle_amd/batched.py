@@ -9,7 +9,8 @@ import ctypes as C
 import torch
 
 from . import _capi
-from ._capi import (LLE_BUF_COUNT, BUFFER_NAMES, LLE_STEP_AUTO_RESET, LLE_STEP_NO_OBS, LLE_STEP_SAMPLE_ACTIONS, BufferDesc, Map)
+from ._capi import (LLE_BUF_COUNT, BUFFER_NAMES, LLE_STEP_AUTO_RESET, LLE_STEP_NO_OBS, LLE_STEP_RECOLOUR_RESETS, LLE_STEP_SAMPLE_ACTIONS,
+                    BufferDesc, Map)
 
 _TORCH_DTYPES = {
     "pos": torch.uint8, "bits": torch.int64, "gems": torch.int32, "beams": torch.int32, "avail": torch.uint8,
@@ -142,7 +143,8 @@ class BatchedWorld:
         self._check(_capi.lib().lle_batch_reset(self.h, mp, self._stream()))
         self.t = 0
 
-    def step(self, actions=None, sample=False, auto_reset=False, seed=0, t=None, env_offset=0, write_obs=True, env_out=None):
+    def step(self, actions=None, sample=False, auto_reset=False, seed=0, t=None, env_offset=0, write_obs=True, env_out=None,
+             recolour_resets=False):
         """World.step + Layered.observe for every env.  env_out: an `_capi.EnvOutputs` (make_env_outputs) whose tensors the
         step kernel fills in the same launch (lle_batch_step_outputs: LLE.step's state / reward / done / available / ...).
 
@@ -162,6 +164,8 @@ class BatchedWorld:
             ap = actions.data_ptr()
         if auto_reset:
             flags |= LLE_STEP_AUTO_RESET
+        if recolour_resets:  # (LLE.reset with randomize_lasers inside the step: per-env sources, see LLE_STEP_RECOLOUR_RESETS)
+            flags |= LLE_STEP_RECOLOUR_RESETS
         if not write_obs:
             flags |= LLE_STEP_NO_OBS
         if t is None:

@@ -240,6 +240,14 @@ int lle_map_row_head(const lle_map* map, int32_t* first_byte, int32_t* n_bytes) 
     return LLE_OK;
 }
 
+int64_t lle_map_reset_beam(const lle_map* map, int laser_id, int agent_id) {
+    if (!map) return fail(LLE_ERR_NULL, "NULL map");
+    const MapHeader& h = map->m.header;
+    if (laser_id < 0 || laser_id >= (int)h.L || agent_id < 0 || agent_id >= (int)h.A) return fail(LLE_ERR_ARG, "laser_id / agent_id out of range");
+    const uint32_t* tab = reinterpret_cast<const uint32_t*>(map->m.blob.data() + h.off_recolour);
+    return (int64_t)tab[(size_t)laser_id * (h.A + 1u) + 1u + (uint32_t)agent_id];
+}
+
 int lle_map_laser_tiles(const lle_map* map, lle_laser_tile* out, int cap) {
     if (!map) return fail(LLE_ERR_NULL, "NULL map");
     const Map& m = map->m;
@@ -310,6 +318,17 @@ static int launch(lle_batch* b, int mode, LaunchArgs K, void* stream) {
     if (b->per_env_sources) K.flags |= LAUNCH_PER_ENV_SOURCES;
     K.envs_per_map = b->envs_per_map;
     K.table_stride = (uint32_t)b->layout.table_stride;
+    if (mode == KMODE_STEP && (K.flags & STEP_RECOLOUR_RESETS)) {
+        if (!(K.flags & STEP_AUTO_RESET)) return fail(LLE_ERR_ARG, "LLE_STEP_RECOLOUR_RESETS re-colours the envs LLE_STEP_AUTO_RESET resets: pass both");
+        if (!b->per_env_sources)
+            return fail(LLE_ERR_ARG, "LLE_STEP_RECOLOUR_RESETS needs per-environment sources: call lle_batch_set_sources / lle_batch_reset_sources once first");
+        if (b->lane_per_env_step) return fail(LLE_ERR_ARG, "LLE_STEP_RECOLOUR_RESETS is served by the default step kernel only");
+        if (K.n_steps > 1 || K.ring_slots || K.stamps) return fail(LLE_ERR_UNSUPPORTED, "LLE_STEP_RECOLOUR_RESETS: single steps only (lle_batch_step, lle_batch_step_outputs)");
+        for (const Map& m : b->maps)
+            if (!m.header.recolour_exact)
+                return fail(LLE_ERR_UNSUPPORTED, "LLE_STEP_RECOLOUR_RESETS: a cell of the map carries more than two laser layers "
+                                                 "(use lle_batch_reset_sources, which resets such an env in full)");
+    }
     if (mode == KMODE_STEP && !b->lane_per_env_step) {
         K.envs_per_wave = step_envs_per_wave(b->n_envs, (int)b->hdr.A);
         HIP_TRY(launch_step_kernel(b->hdr, b->ptrs, K, (hipStream_t)stream));

@@ -504,11 +504,27 @@ void Map::compile() {
     h.off_bare = h.blob_capacity;
     h.off_elems = h.off_bare + h.obs_stride;
     h.n_elems = (uint32_t)elems.size();
-    h.ext_bytes = (h.obs_stride + h.n_elems * 4u + 1023u) & ~1023u;
+    // re-colouring table (tables.h off_recolour): World::reset turns every enabled beam fully on, then the agent standing on
+    // its start INSIDE a beam of its own colour cuts that beam from there (pre_enter, laser.rs:173-182)
+    std::vector<uint32_t> recolour((size_t)L * (A + 1), 0u);
+    for (int s = 0; s < L; s++) {
+        recolour[(size_t)s * (A + 1)] = h.colour_ok[s];
+        for (int c = 0; c < A; c++) {
+            uint32_t beam = h.beam_full[s];
+            const Pos st = starts[c][0];
+            for (const auto& lay : cell_layers[st.i * W + st.j])
+                if (lay.laser_id == s) beam &= (1u << lay.offset) - 1u;
+            recolour[(size_t)s * (A + 1) + 1 + c] = beam;
+        }
+    }
+    h.off_recolour = h.off_elems + h.n_elems * 4u;
+    h.recolour_exact = h.max_layers <= 2 ? 1u : 0u;
+    h.ext_bytes = (h.obs_stride + h.n_elems * 4u + (uint32_t)recolour.size() * 4u + 1023u) & ~1023u;
     off = (size_t)h.blob_capacity + h.ext_bytes;
     blob.assign(off, 0);
     std::memcpy(blob.data() + h.off_bare, bare.data(), bare.size());
     if (!elems.empty()) std::memcpy(blob.data() + h.off_elems, elems.data(), elems.size() * 4);
+    if (!recolour.empty()) std::memcpy(blob.data() + h.off_recolour, recolour.data(), recolour.size() * 4);
     std::memcpy(blob.data() + h.off_cell_lay, cell_lay.data(), cell_lay.size() * 8);
     std::memcpy(blob.data() + h.off_cell_meta, cell_meta.data(), cell_meta.size() * 4);
     if (!dyn_tab.empty()) std::memcpy(blob.data() + h.off_dyn, dyn_tab.data(), dyn_tab.size() * 8);

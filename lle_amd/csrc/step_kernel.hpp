@@ -99,6 +99,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     // the kernel's own stores, and the compiler cannot tell the header from the rows -- whose wait covers the stores too)
     const uint32_t h_off_cell_meta = hdr->off_cell_meta, h_off_dyn = hdr->off_dyn, h_off_template = hdr->off_template;
     const uint32_t h_max_layers = ML1 ? 1u : hdr->max_layers;
+    const uint32_t h_off_recolour = PES ? hdr->off_recolour : 0u, h_off_bare = PES ? hdr->off_bare : 0u;
     // (MODE 7: so are the fused LLE.step outputs' descriptor and the header fields of that epilogue)
     constexpr bool ENV_OUT = MODE == 4 || MODE == 5 || MODE == 7;
     EnvOutputs O_early = {};
@@ -294,6 +295,36 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         for (int b = 0; b < LM; b++)
             if (b < L) beams[b] = over ? (PES ? P.init_beams[env_ok ? env * L + b : 0] : h_init_beams[b]) : beams[b];
         was_reset = over ? 1u : 0u;
+        // LLE.reset with randomize_lasers (python/lle/env/env.py:189-203): world.reset() -- above, under the colours the env
+        // HAD: beams cut at reset stay as they are -- then a fresh colour for every source, uniform over the colours the
+        // source may take (MapHeader.colour_ok; every colour on the maps the reference's draw never fails on).  The draw is
+        // the action sampler's hash keyed with seed ^ RECOLOUR_SALT and the source id in place of the agent; lane a of
+        // the group decides colour a, a group OR hands the pick to all.  The env's reset record changes with the colours
+        // in its beams only (tables.h off_recolour).
+        if (PES && !ROLL && (K.flags & STEP_RECOLOUR_RESETS) && __ballot(over) != 0ull) {  // (single steps: the rollout modes have no registers for it)
+            const uint32_t* rtab = reinterpret_cast<const uint32_t*>(lds + tab_bytes + (h_off_recolour - h_off_bare));
+            const uint64_t rkey = action_step_key(K.seed ^ RECOLOUR_SALT, t_now);
+#pragma unroll
+            for (int b = 0; b < LM; b++) {
+                if (b < L) {
+                    const uint32_t* row = rtab + b * (A + 1);
+                    const uint32_t ok = row[0] & amask;
+                    const uint32_t field = action_field(action_hash_pair(rkey, (uint64_t)(K.env_offset + env), (uint32_t)b >> 1), (uint32_t)b);
+                    const uint32_t k = (field * (uint32_t)__popc(ok)) >> 16;
+                    const bool mine = ((ok >> a) & 1u) != 0u && (uint32_t)__popc(ok & ((1u << a) - 1u)) == k;
+                    const uint32_t pick = grp_or<G>(mine ? a + 1u : 0u);  // colour + 1; 0: no colour is allowed, keep
+                    const uint32_t sh = (uint32_t)(b & 3) * 8u, old_c = (colw[b >> 2] >> sh) & 0xFFu;
+                    const uint32_t c = (over && pick) ? pick - 1u : old_c;
+                    colw[b >> 2] = (colw[b >> 2] & ~(0xFFu << sh)) | (c << sh);
+                    if (over && a == 0) P.init_beams[env * L + b] = ((env_enabled >> b) & 1u) ? row[1u + (c < (uint32_t)A ? c : 0u)] : 0u;
+                }
+            }
+            if (over && a == 0) {
+#pragma unroll
+                for (int q = 0; q < CWM; q++)
+                    if (q < CW) reinterpret_cast<uint32_t*>(P.src_colour)[env * CW + q] = colw[q];
+            }
+        }
     }
 
     // ---- joint action: sampled on the device, or given

@@ -68,7 +68,13 @@ struct MapHeader {
     // The "head" of a row: chunks [head_lo, head_lo + head_n) (whole 128-byte lines, at most 64 chunks) hold no byte that
     // an agent, a beam or a gem can change -- identical in every environment at every step.  The default step kernel
     // stores them BEFORE the state machine runs (step_kernel.hpp); head_n = 0: no such run of lines (or unaligned rows).
-    uint32_t head_lo, head_n, head_pad[10];  // (pads the header to 512 B: the table sections behind it start on a 128-byte line)
+    uint32_t head_lo, head_n;
+    // Inside the per-env-sources section: per source, [colour_ok | beam mask after World::reset when the source has colour
+    // 0, 1, ..., A-1] (A + 1 words): what the step kernel needs to re-colour an environment that it resets
+    // (STEP_RECOLOUR_RESETS).  Exact for maps without a cell of more than two laser layers (`recolour_exact`): there the
+    // binding's colour check keeps every beam of another colour off every start, so nothing but the beams depends on the colours.
+    uint32_t off_recolour, recolour_exact;
+    uint32_t head_pad[8];  // (pads the header to 512 B: the table sections behind it start on a 128-byte line)
 };
 static_assert(sizeof(MapHeader) % 128 == 0, "the sections start on a 128-byte line (the LDS copy loads 1 KiB per wave instruction)");
 
@@ -120,7 +126,10 @@ constexpr uint8_t ENV_INVALID_COLOUR = 0x43;
 constexpr uint8_t ENV_COLOUR_CROSSES_START = 0x44;
 
 // ---- step flags (mirror include/lle_hip.h)
-constexpr uint32_t STEP_SAMPLE_ACTIONS = 1, STEP_AUTO_RESET = 2, STEP_NO_OBS = 4;
+// STEP_RECOLOUR_RESETS: an env that STEP_AUTO_RESET resets draws a fresh colour for each of its sources (LLE.reset with
+// randomize_lasers, python/lle/env/env.py:189-203); batches with per-env sources only.
+constexpr uint64_t RECOLOUR_SALT = 0xC01055EEDULL;  // seed ^ salt keys the colour draws (a stream of their own)
+constexpr uint32_t STEP_SAMPLE_ACTIONS = 1, STEP_AUTO_RESET = 2, STEP_NO_OBS = 4, STEP_RECOLOUR_RESETS = 8;
 constexpr uint32_t LAUNCH_PER_ENV_SOURCES = 0x10000;  // internal: the batch keeps colours / enabled flags per env
 constexpr uint32_t LAUNCH_FILL_DEFAULTS = 0x20000;    // internal (MODE_ENV_SOURCES): take them from the map header
 constexpr uint32_t LAUNCH_GENERAL = 0x80000;          // internal: the general step_kernel instantiation (per-env sources / several maps)

@@ -60,7 +60,11 @@ class BatchedLLE:
         self.multi_objective = bool(multi_objective)
         self._gen = torch.Generator(device=self.world.device)
         self._gen.manual_seed(int(seed))
+        self._seed_value = int(seed)
         self._t = 0
+        # auto-resets under randomize_lasers re-colour inside the step kernel (LLE_STEP_RECOLOUR_RESETS) unless a cell
+        # of the map carries more than two laser layers (then: a launch of lle_batch_reset_sources per step)
+        self._recolour_in_step = self.randomize_lasers and self.world.map.max_cell_layers <= 2
         self._fused = None  # output tensors + lle_env_outputs of the one-launch step (step(..., fused=True))
 
     @staticmethod
@@ -121,6 +125,7 @@ class BatchedLLE:
     def seed(self, seed_value):
         """LLE.seed (env.py:245-247): seeds the colour randomisation (v1 maps have a single start per agent)."""
         self._gen.manual_seed(int(seed_value))
+        self._seed_value = int(seed_value)
 
     @property
     def done(self):
@@ -233,7 +238,12 @@ class BatchedLLE:
             raise ValueError("the one-launch step writes available_actions with walkable_lasers only")
         env_out = self._fused_outputs()[1] if fused else None
         if auto_reset:
-            if self.randomize_lasers:
+            if self._recolour_in_step:
+                # world.reset() + a fresh colour per source for the envs that are over, inside the step kernel; the draws
+                # are keyed by (seed, env, step counter, source), not by the torch generator that reset() uses
+                w.step(actions, auto_reset=True, recolour_resets=True, seed=self._seed_value, t=self._t, write_obs=self._needs_layered,
+                       env_out=env_out)
+            elif self.randomize_lasers:
                 # (the kernel reads an env's mask byte before it rewrites its `done`; the step rewrites the observation)
                 self._reset_world(w.done, write_obs=False)
                 w.step(actions, write_obs=self._needs_layered, env_out=env_out)

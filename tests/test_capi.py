@@ -205,3 +205,25 @@ def test_row_head_bytes_never_change(oracle_mod, name):
     assert m.row_head[1] == 0
     m.set_head_lines(-1)
     assert m.row_head[1] <= max(128, min(1024, (m.obs_stride // 128 + 2) // 5 * 128))
+
+
+@pytest.mark.parametrize("name", sorted(dict({f"level{k}": v for k, v in LEVELS.items()}, **EXTRA_MAPS)))
+def test_reset_beam_table_matches_oracle_reset(oracle_mod, name):
+    """lle_map_reset_beam(s, c) -- what LLE_STEP_RECOLOUR_RESETS stores as an env's reset beams -- against the oracle:
+    colour c on source s, World.reset, read the beam (for every pair the binding's set_colour accepts)."""
+    from lle_amd import Map
+
+    text = dict({f"level{k}": v for k, v in LEVELS.items()}, **EXTRA_MAPS)[name]
+    m = Map(text)
+    for s in m.sources():
+        for c in range(m.n_agents):
+            with pytest.raises(ValueError):
+                m.reset_beam(len(m.sources()), c)
+            if not m.colour_allowed(s.laser_id, c):
+                continue
+            w = oracle_mod.OracleWorld(text)
+            w.set_source(s.laser_id, colour=c)
+            w.reset()
+            bits = w.beam_bits(s.laser_id)
+            want = sum(int(b) << k for k, b in enumerate(bits))
+            assert m.reset_beam(s.laser_id, c) == want, (name, s.laser_id, c)

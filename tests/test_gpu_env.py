@@ -221,6 +221,53 @@ def test_randomized_lasers_reach_every_colour_and_refresh_the_source_markers():
     assert all(all(ce) for ce in encountered)
 
 
+@pytest.mark.parametrize("map_name", ["randomized", "level6"])
+def test_randomized_lasers_through_auto_reset_steps(map_name):
+    """The same pins along ROLLOUTS: BatchedLLE.step(auto_reset=True) with randomize_lasers re-colours the envs it resets
+    inside the step kernel (LLE_STEP_RECOLOUR_RESETS).  After every step: colours in range, the -1 marker of every source on
+    the layer of its CURRENT colour and nowhere else, an env that was not reset keeps its colours, every colour is reached,
+    and the one-launch step (fused=True) returns what the two-launch step returns."""
+    import torch
+
+    from lle_amd import BatchedLLE
+
+    text = MAP_RANDOMIZED if map_name == "randomized" else LEVELS[6]
+    n = 2048
+    a = BatchedLLE(text, n, obs_type="layered", randomize_lasers=True, seed=11)
+    b = BatchedLLE(text, n, obs_type="layered", randomize_lasers=True, seed=11)
+    assert a._recolour_in_step
+    a.reset(), b.reset()
+    b.world.set_sources(colours=a.world.src_colour[:, : a.world.map.n_sources].clone())  # (reset() draws from the torch generator)
+    A, sources = a.n_agents, a.world.map.sources()
+    L = len(sources)
+    seen = torch.zeros(L, A, dtype=torch.bool)
+    rows = torch.arange(n, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(2)
+    n_resets = 0
+    for t in range(80):
+        before = a.world.src_colour[:, :L].clone()
+        over = a.done.clone()
+        avail = a.available_actions()
+        acts = torch.multinomial(avail.reshape(-1, 5).float(), 1, generator=g).reshape(n, -1).to(torch.uint8)
+        x, y = a.step(acts, auto_reset=True, fused=True), b.step(acts, auto_reset=True)
+        for k in ("obs", "state", "reward", "done", "available_actions", "err"):
+            assert torch.equal(x[k], y[k]), (k, t)
+        colours = a.world.src_colour[:, :L].long()
+        assert torch.equal(colours, b.world.src_colour[:, :L].long())
+        assert int(colours.min()) >= 0 and int(colours.max()) < A
+        assert torch.equal(colours[~over], before[~over].long()), "an env that was not reset changed colour"
+        n_resets += int(over.sum())
+        obs = x["obs"]
+        for l, s in enumerate(sources):
+            for c in range(A):
+                seen[l, c] |= bool((colours[over, l] == c).any())
+            assert bool((obs[rows, A + colours[:, l], s.i, s.j] == -1).all()), f"t={t} source {l}: marker missing"
+            others = obs[:, A:2 * A, s.i, s.j].clone()
+            others[rows, colours[:, l]] = 0
+            assert int(others.abs().sum()) == 0, f"t={t} source {l}: stale marker"
+    assert n_resets > n and bool(seen.all()), (n_resets, seen)
+
+
 def test_envs_of_a_batch_are_independent_copies():
     """python/tests/test_core.py:127-141 (test_deep_copy): a copy of an env must not finish when the original does.
     In a batch the copies are the environments: one walks onto the exit, its neighbour stays."""

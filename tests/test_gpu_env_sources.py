@@ -281,3 +281,81 @@ def test_colour_that_crosses_a_start_is_refused_per_env(oracle_mod):
     with pytest.raises(ValueError, match="cross the start position"):
         BatchedLLE(text, n, randomize_lasers=True)
     BatchedLLE(LEVELS[6], n, randomize_lasers=True)  # no beam over a start: fine
+
+
+# ---- LLE_STEP_RECOLOUR_RESETS: LLE.reset with randomize_lasers inside the step kernel
+@pytest.mark.parametrize("name", ["level6", "level5", "three_beams", "q1", "many_agents", "gen_20_lasers", "config5_32x32"])
+@pytest.mark.parametrize("with_flags", [False, True])
+def test_recolour_resets_inside_the_step(oracle_mod, name, with_flags):
+    """An env that the step auto-resets also draws a fresh colour per source (python/lle/env/env.py:189-203: world.reset()
+    under the colours it had, then set_colour on the live world).  The oracle side does exactly that per env -- reset(),
+    then the colours from the documented hash -- and every buffer is compared after every step; with_flags: some sources
+    disabled per env (their reset beams stay off)."""
+    import torch
+
+    from lle_amd import BatchedWorld
+    from lle_amd._capi import RECOLOUR_SALT
+
+    text = dict(MAPS, config5_32x32=EXTRA_MAPS["config5_32x32"])[name]
+    n, seed, off = 1200, 4242, 17
+    bw = BatchedWorld(text, n)
+    m = bw.map
+    A, L = m.n_agents, m.n_sources
+    assert m.max_cell_layers <= 2
+    allowed = [[c for c in range(A) if m.colour_allowed(s, c)] for s in range(L)]
+    ob = oracle_mod.OracleBatch(text, n)
+    mirror = Mirror(ob, n, L)
+    rng = np.random.default_rng(1)
+    enabled = (rng.integers(0, 1 << min(L, 30), n) | (rng.integers(0, 3, n) > 0) * ((1 << L) - 1)).astype(np.int64) & ((1 << L) - 1) if with_flags else None
+    start_colours = legal_colours(m, rng.integers(0, A, (n, L)).astype(np.uint8))
+    bw.set_sources(colours=torch.from_numpy(start_colours).cuda(), enabled=None if enabled is None else torch.from_numpy(enabled.astype(np.int32)).cuda())
+    mirror.apply(start_colours, enabled)
+    colours = start_colours.copy()
+    check(bw, ob, None, f"{name} after set_sources")
+    seen = [set() for _ in range(L)]
+    for t in range(70):
+        over = bw.done.cpu().numpy().astype(bool)
+        for e in np.nonzero(over)[0]:
+            w = ob.world(int(e))
+            w.reset()
+            for s in range(L):
+                if allowed[s]:
+                    h = oracle_mod.action_hash(seed ^ RECOLOUR_SALT, off + int(e), t, s)
+                    colours[e, s] = allowed[s][(h * len(allowed[s])) >> 16]
+                    w.set_source(s, colour=int(colours[e, s]))
+                    seen[s].add(int(colours[e, s]))
+        bw.step(sample=True, auto_reset=True, recolour_resets=True, seed=seed, t=t, env_offset=off)
+        ostep = ob.step(None, auto_reset=False, seed=seed, t=t, env_offset=off)
+        eng = unpack_engine(bw.host_buffers(), *dims_of(ob))
+        assert np.array_equal(eng["ev_count"] >> 7, over.astype(np.uint8)), f"{name} t={t}: which envs were reset"
+        eng["ev_count"] = eng["ev_count"] & 0x7F
+        assert_step_equal(eng, ostep, f"{name} t={t}")
+        assert_state_equal(eng, ob.dump(), f"{name} t={t}")
+        assert np.array_equal(bw.src_colour.cpu().numpy()[:, :L], colours), f"{name} t={t}: LLE_BUF_SRC_COLOUR"
+    if name in ("level6", "three_beams"):
+        assert all(seen[s] == set(allowed[s]) for s in range(L)), seen  # every allowed colour is reached (test_env.py:381-400)
+    # the reset record the kernel keeps per env follows the colours: a plain masked reset afterwards equals the oracle's
+    mask = (rng.random(n) < 0.5).astype(np.uint8)
+    bw.reset(torch.from_numpy(mask).cuda())
+    for e in np.nonzero(mask)[0]:
+        ob.world(int(e)).reset()
+    check(bw, ob, None, f"{name} masked reset after recoloured resets")
+
+
+def test_recolour_resets_argument_checks():
+    import torch
+
+    from lle_amd import BatchedWorld
+
+    bw = BatchedWorld(LEVELS[6], 256)
+    with pytest.raises(Exception, match="per-environment sources"):
+        bw.step(sample=True, auto_reset=True, recolour_resets=True)
+    bw.set_sources(colours=torch.zeros((256, 3), dtype=torch.uint8, device="cuda") + torch.tensor([2, 0, 1], dtype=torch.uint8, device="cuda"))
+    with pytest.raises(Exception, match="pass both"):
+        bw.step(sample=True, recolour_resets=True)
+    deep = BatchedWorld(EXTRA_MAPS["four_layers"], 256)
+    A, L = deep.map.n_agents, deep.map.n_sources
+    deep.set_sources(colours=torch.from_numpy(legal_colours(deep.map, np.zeros((256, L), np.uint8))).cuda())
+    if deep.map.max_cell_layers > 2:
+        with pytest.raises(Exception, match="more than two laser layers"):
+            deep.step(sample=True, auto_reset=True, recolour_resets=True)
