@@ -1,7 +1,11 @@
 """Soak differential (GPU box): HIP path vs the CPU oracle on long random rollouts, every buffer of every env compared
 bit-for-bit after every step (state, ordered events, availability, error codes, the full int8 observation).
 Beyond the test suite's sizes; prints env-steps compared per map.
-Usage: python tools/soak_parity.py [seconds_per_map] [per-env-sources | full-size]
+Usage: python tools/soak_parity.py [seconds_per_map] [per-env-sources | full-size | recolour-resets]
+With `recolour-resets` every finished env is reset AND re-coloured inside the step kernel (LLE_STEP_AUTO_RESET |
+LLE_STEP_RECOLOUR_RESETS: LLE.reset with randomize_lasers); the oracle side resets such an env, sets the colours of the
+documented draws (hash of seed ^ RECOLOUR_SALT, env, t, source; uniform over the colours the source may take) and steps.
+Maps without sources or with a cell of more than two laser layers are skipped.
 With `full-size` only the BASELINE configurations at their full batch (and level 6 at 262 144 envs, the HBM-regime run of
 bench.py) are compared, a few steps each: the oracle side then dominates the time.
 With `per-env-sources` every env has its own source colours / enabled flags (lle_batch_set_sources; each oracle env is
@@ -24,6 +28,7 @@ om.build()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
 per_env = len(sys.argv) > 2 and sys.argv[2] == "per-env-sources"
 full_size = len(sys.argv) > 2 and sys.argv[2] == "full-size"
+recolour = len(sys.argv) > 2 and sys.argv[2] == "recolour-resets"
 rng = np.random.default_rng(7)
 
 
@@ -62,16 +67,45 @@ if full_size:
             "cfg5 32x32 x 65536": (mapgen.config5(0), 65536)}
 total = 0
 for name, (text, n) in maps.items():
-    if per_env:
+    if per_env or recolour:
         n = min(n, 2048)  # (the per-env source calls on the oracle side are Python loops)
     ob, bw = om.OracleBatch(text, n), BatchedWorld(text, n)
     dims = (ob.A, ob.G, ob.Ls, ob.beam_stride, ob.C, ob.H, ob.W)
     L = bw.map.n_sources
-    if per_env and L == 0:
+    if (per_env or recolour) and L == 0:
+        continue
+    if recolour and bw.map.max_cell_layers > 2:
         continue
     mirror = Mirror(ob, n, L) if per_env else None
     t, t0 = 0, time.time()
-    while time.time() - t0 < budget:
+    if recolour:
+        from lle_amd._capi import RECOLOUR_SALT
+        allowed = [[c for c in range(ob.A) if bw.map.colour_allowed(s, c)] for s in range(L)]
+        start = legal_colours(bw.map, rng.integers(0, ob.A, (n, L)).astype(np.uint8))
+        bw.set_sources(colours=torch.from_numpy(start).cuda())
+        for e in range(n):
+            for s in range(L):
+                ob.world(e).set_source(s, colour=int(start[e, s]))
+        colours = start.copy()
+    while recolour and time.time() - t0 < budget:
+        over = bw.done.cpu().numpy().astype(bool)
+        for e in np.nonzero(over)[0]:
+            w = ob.world(int(e))
+            w.reset()
+            for s in range(L):
+                if allowed[s]:
+                    colours[e, s] = allowed[s][(om.action_hash(2026 ^ RECOLOUR_SALT, 11 + int(e), t, s) * len(allowed[s])) >> 16]
+                    w.set_source(s, colour=int(colours[e, s]))
+        bw.step(sample=True, auto_reset=True, recolour_resets=True, seed=2026, t=t, env_offset=11)
+        ostep = ob.step(None, auto_reset=False, seed=2026, t=t, env_offset=11)
+        eng = unpack_engine(bw.host_buffers(), *dims)
+        assert np.array_equal(eng["ev_count"] >> 7, over.astype(np.uint8)), f"{name} t={t}: which envs were reset"
+        eng["ev_count"] = eng["ev_count"] & 0x7F
+        assert_step_equal(eng, ostep, f"{name} t={t}")
+        assert_state_equal(eng, ob.dump(), f"{name} t={t}")
+        assert np.array_equal(bw.src_colour.cpu().numpy()[:, :L], colours), f"{name} t={t}: colours"
+        t += 1
+    while not recolour and time.time() - t0 < budget:
         if per_env and t % 48 == 0:
             redraw(bw, mirror, ob.A, L, n)
             eng = unpack_engine(bw.host_buffers(), *dims)
