@@ -21,6 +21,7 @@ env-steps/s is reported next to it.  Objects of the line:
   roofline_hbm   the same kernel on a batch whose rows (491 MB per launch) do not fit the Infinity Cache: true HBM writes.
   sustained      the same launches as the --steps region, >= 1000 of them.
   configs        BASELINE.json configs[1] (level 1 x 4 096) and configs[4] (32x32, 8 agents, 8 lasers x 65 536).
+  lle_step       BatchedLLE.step (the reference's LLE host class, batched) on the headline workload: us per step.
   fused_rollout  lle_batch_rollout, 16 steps per launch into a trajectory ring larger than the caches.
   cpu_baseline   the C restatement of the reference algorithm (oracle/) on the host cores, N = 1 only.
 """
@@ -251,6 +252,41 @@ def measure_config(torch, timer, dev, map_or_text, n_envs, algo_bytes, steps, la
     return out
 
 
+def measure_lle_step(torch, timer, dev, n, steps):
+    """The reference's host class around the path, batched (lle_amd.BatchedLLE): LLE.step =
+    World.step + observation + state + reward + done + available_actions, with auto-reset, on level 6 x n envs.  The joint
+    actions are a recorded random rollout of the same world (valid along the same trajectory); with randomize_lasers the
+    trajectories part at the first re-coloured reset and a recorded action may be refused (the kernels do the same work)."""
+    from lle_amd import BatchedLLE, BatchedWorld, Map
+    W = 32                      # untimed steps per variant
+    K = W + steps               # every step of a variant replays its own slot: on the recorded trajectory throughout
+    rec = BatchedWorld(Map(level=LEVEL), n, device=dev)
+    ring = rec.make_ring(K)
+    rec.rollout(K, auto_reset=True, seed=SEED, ring=ring, ring_pos=0)
+    actions = ring["actions"].clone()  # [K, n, A]
+    del ring, rec
+    out = {"what": f"lle_amd.BatchedLLE.step(actions, auto_reset=True) on World.level({LEVEL}) x {n} envs: obs (layered) + state + reward + "
+                   "done + available_actions per step; us per step, launch-to-launch", "steps": steps}
+    for key, kw, fused in (("two_launches_us", {}, False), ("one_launch_us", {}, True),
+                           ("randomize_lasers_two_launches_us", {"randomize_lasers": True}, False),
+                           ("randomize_lasers_one_launch_us", {"randomize_lasers": True}, True)):
+        env = BatchedLLE(Map(level=LEVEL), n, device=dev, seed=SEED, **kw)
+        env.reset()
+        state = {"t": 0}
+
+        def step():
+            env.step(actions[state["t"] % K], auto_reset=True, fused=fused)
+            state["t"] += 1
+        for _ in range(W):
+            step()
+        wall, _ = timer.run(step, steps)
+        assert state["t"] == K
+        out[key] = wall / steps * 1e6
+        del env
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -374,6 +410,10 @@ def main():
                                                      "cfg5_bytes_per_launch"),
         }
 
+    lle_step = None
+    if world == 1 and not args.no_configs:
+        lle_step = measure_lle_step(torch, timer, dev, n, max(args.config_steps, 200))
+
     if rank == 0:
         total_envs = n * world
         env_steps_s = total_envs * args.steps / elapsed
@@ -413,6 +453,8 @@ def main():
                                    "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * hbm["n_envs"], **hbm}
         if cfgs:
             out["configs"] = cfgs
+        if lle_step:
+            out["lle_step"] = lle_step
         for key, (T, R, launches, fe) in zip(("fused_rollout", "fused_rollout_double_buffer"), fused):
             # per env-step: obs 1872 + actions 4 + reward 4 + err/evcount/done 3 + events 8, state r/w (48 B) once per launch
             fused_bytes = 1891 + 48.0 / T
