@@ -43,6 +43,17 @@ namespace lle {
 // (several maps / the fused LLE.step outputs).
 // LX >= 0: the exact number of sources, known at compile time (instantiated for the default path of maps with at
 // most four sources: the per-beam loops lose their guards and the unused beam registers disappear; 0.4 us on level 6).
+// A 64-byte struct at a wave-uniform address that only the host writes, through the scalar cache.
+__device__ __forceinline__ EnvOutputs load_uniform(const EnvOutputs* p) {
+    static_assert(sizeof(EnvOutputs) == 64, "one s_load_dwordx16");
+    typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+    u32x16 w;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(p) : "memory");
+    EnvOutputs o;
+    __builtin_memcpy(&o, &w, sizeof o);
+    return o;
+}
+
 template <int G, int LM, int MODE, bool ML1, int LX = -1>
 __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P, LaunchArgs K) {
     constexpr bool GEN = (MODE >= 2 && MODE <= 5) || MODE == 7, ROLL = MODE >= 1 && MODE <= 3;
@@ -100,15 +111,14 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     const uint32_t h_off_cell_meta = hdr->off_cell_meta, h_off_dyn = hdr->off_dyn, h_off_template = hdr->off_template;
     const uint32_t h_max_layers = ML1 ? 1u : hdr->max_layers;
     const uint32_t h_off_recolour = PES ? hdr->off_recolour : 0u, h_off_bare = PES ? hdr->off_bare : 0u;
+    const uint32_t h_off_elems = PES ? hdr->off_elems : 0u, h_n_elems = PES ? hdr->n_elems : 0u;
     // (MODE 7: so are the fused LLE.step outputs' descriptor and the header fields of that epilogue)
     constexpr bool ENV_OUT = MODE == 4 || MODE == 5 || MODE == 7;
     EnvOutputs O_early = {};
     uint32_t h_G = 0, h_H = 0;
-    if (HEAD && ENV_OUT && K.env_out) {
-        O_early = *K.env_out;
-        h_G = hdr->G;
-        h_H = hdr->H;
-    }
+    constexpr bool EARLY_OUT = HEAD && ENV_OUT;  // (MODE 4 / 5 have no scalar registers to park the descriptor in: they spill vector registers for it)
+    if (EARLY_OUT && K.env_out) O_early = *K.env_out;
+    if (ENV_OUT) { h_G = hdr->G; h_H = hdr->H; }
     uint32_t h_init_beams[LM];  // the reset state's beams (shared record; the per-env one is read where it is used)
 #pragma unroll
     for (int b = 0; b < LM; b++) h_init_beams[b] = (b < L) ? initp->beams[b] : 0u;
@@ -204,7 +214,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     const uint32_t tab_bytes = split ? hdr->lds_split_table_bytes : hdr->lds_table_bytes, tab_off = hdr->off_cell_lay;
     copy_tables_to_lds(tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
     const uint32_t ext_bytes = PES ? hdr->ext_bytes : 0u;
-    if (PES) copy_tables_to_lds(tables + hdr->off_bare, lds + tab_bytes, ext_bytes, lane, wave_in_wg, waves_per_wg);
+    if (PES) copy_tables_to_lds(tables + h_off_bare, lds + tab_bytes, ext_bytes, lane, wave_in_wg, waves_per_wg);
     LLE_STAMP(7);
     if (HEAD) {
         // every load has returned (the table rows were the last ones, and they are in LDS): said with an s_waitcnt the
@@ -229,7 +239,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     int8_t* tmpl = reinterpret_cast<int8_t*>(lds + tab_bytes + ext_bytes + wave_in_wg * priv_bytes);
     uint32_t* scratch = reinterpret_cast<uint32_t*>(tmpl + h_obs_stride);
     const int8_t* bare = reinterpret_cast<const int8_t*>(lds + tab_bytes);
-    const uint32_t* elems = reinterpret_cast<const uint32_t*>(lds + tab_bytes + (hdr->off_elems - hdr->off_bare));
+    const uint32_t* elems = reinterpret_cast<const uint32_t*>(lds + tab_bytes + (h_off_elems - h_off_bare));
     // split rows: [tables | one slice per wavefront | the hand-over records of all the workgroup's environments]
     const uint32_t cpw = (h_n_chunks + waves_per_wg - 1u) / waves_per_wg;  // chunks per slice
     const uint32_t c_lo = wave_in_wg * cpw < h_n_chunks ? wave_in_wg * cpw : h_n_chunks;
@@ -398,8 +408,10 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     // so that the default path keeps its registers (with the epilogue in MODE 0: 112 -> 127 VGPRs and 21.2 -> 21.6 us
     // for launches that do not even use it).
     if (ENV_OUT && K.env_out) {
-        const EnvOutputs O = HEAD ? O_early : *K.env_out;  // uniform address: scalar loads
-        const int n_gems = HEAD ? (int)h_G : (int)hdr->G, len = 3 * A + n_gems;
+        // (read where it is used; through the SCALAR cache by hand: behind the kernel's own stores the compiler would fetch it
+        // with vector loads, whose wait also covers every store in flight -- the descriptor is written by the host only)
+        const EnvOutputs O = EARLY_OUT ? O_early : load_uniform(K.env_out);
+        const int n_gems = (int)h_G, len = 3 * A + n_gems;
         if (me) {
             const int64_t ia = env * A + a;
             if (O.alive) O.alive[ia] = (uint8_t)((alive >> a) & 1u);
@@ -413,7 +425,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
                 float* st = O.state + env * len;
                 float fi = (float)(pos & 0xFFu), fj = (float)(pos >> 8);
                 if (O.normalize_state) {  // divided in float64, rounded to float32 on assignment (observations.py:145-175)
-                    fi = (float)((double)(pos & 0xFFu) / (double)(HEAD ? h_H : hdr->H));
+                    fi = (float)((double)(pos & 0xFFu) / (double)h_H);
                     fj = (float)((double)(pos >> 8) / (double)W);
                 }
                 st[2 * a] = fi;
@@ -489,9 +501,9 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     } else if (write_obs && n_here > 0) {
         const bool wt = (K.flags & LAUNCH_WRITE_THROUGH) != 0;  // see stream_store (obs_stream.hpp)
         if (PES) {
-            if (wt) write_observations_env<true>(A, L, h_HW, hdr->n_elems, h_n_chunks, h_obs_stride, elems, bare, tmpl, scratch, scr_stride,
+            if (wt) write_observations_env<true>(A, L, h_HW, h_n_elems, h_n_chunks, h_obs_stride, elems, bare, tmpl, scratch, scr_stride,
                                                  obs_out, env0, n_here, lane);
-            else write_observations_env<false>(A, L, h_HW, hdr->n_elems, h_n_chunks, h_obs_stride, elems, bare, tmpl, scratch, scr_stride,
+            else write_observations_env<false>(A, L, h_HW, h_n_elems, h_n_chunks, h_obs_stride, elems, bare, tmpl, scratch, scr_stride,
                                                obs_out, env0, n_here, lane);
         } else {
             if (wt) write_observations<true, HEAD>(A, L, h_D, h_n_chunks, h_obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane, head_lo, head_n);
