@@ -156,6 +156,12 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     constexpr int CWM = LM / 4;
     const int CW = src_stride_of(L) / 4;
     uint32_t colw[CWM], env_enabled = h_enabled;
+    // the env's reset beams, read with the rest of its state in the single-step mode: read where the reset needs them they
+    // are a memory round trip between the decision to reset and the state machine, in every wavefront that resets anything
+    constexpr bool PRE_BEAMS = PES && !ROLL && LM <= 8;
+    uint32_t env_init_beams[LM];
+#pragma unroll
+    for (int b = 0; b < LM; b++) env_init_beams[b] = 0u;
 #pragma unroll
     for (int q = 0; q < CWM; q++) colw[q] = 0;
     // The caller's action, read with the rest of the state in the single-step modes: a load inside the step would be
@@ -164,7 +170,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     uint32_t act_given = 4u;
     // The wavefront's counters, likewise (kernel_common.hpp: flush_stats); the default single-step instantiations only --
     // the general ones have no registers to spare, a rollout flushes once per launch.
-    constexpr bool PRE_STATS = (MODE == 0 || MODE == 6 || MODE == 7) && LM <= 8;  // (16 / 32 beam registers: already spilling)
+    constexpr bool PRE_STATS = (MODE == 0 || MODE == 6 || MODE == 7) && LM <= 8;  // (16 / 32 beam registers: already spilling; MODE 4 / 5: they spill more with it)
     int64_t stats_old = 0;
     // (a macro, not a lambda: with the beam registers captured by reference the 32-source instantiations kept them in scratch)
 #define LLE_LOAD_STATE() \
@@ -195,6 +201,9 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
             if (K.flags & STEP_AUTO_RESET) { \
                 init_bits = P.init_bits[env]; \
                 init_gems = P.init_gems[env]; \
+        _Pragma("unroll") \
+                for (int b = 0; b < LM; b++) \
+                    if (PRE_BEAMS && b < L) env_init_beams[b] = P.init_beams[env * L + b]; \
             } \
         } \
     } while (0)
@@ -303,7 +312,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         gems = over ? init_gems : gems;
 #pragma unroll
         for (int b = 0; b < LM; b++)
-            if (b < L) beams[b] = over ? (PES ? P.init_beams[env_ok ? env * L + b : 0] : h_init_beams[b]) : beams[b];
+            if (b < L) beams[b] = over ? (PES ? (PRE_BEAMS ? env_init_beams[b] : P.init_beams[env_ok ? env * L + b : 0]) : h_init_beams[b]) : beams[b];
         was_reset = over ? 1u : 0u;
         // LLE.reset with randomize_lasers (python/lle/env/env.py:189-203): world.reset() -- above, under the colours the env
         // HAD: beams cut at reset stay as they are -- then a fresh colour for every source, uniform over the colours the
