@@ -452,7 +452,8 @@ const char* kernel_variant_name(int variant) {
 // `pes`: per-environment sources (the second table section in LDS, colour words in the hand-over records)
 uint32_t kernel_lds_bytes(const MapHeader& h, uint32_t waves_per_wg, bool pes) {
     const uint32_t scr_stride = (h.L + h.A + 2 + (pes ? (uint32_t)src_stride_of((int)h.L) / 4u : 0u)) | 1u;
-    return h.lds_table_bytes + (pes ? h.ext_bytes : 0u) + waves_per_wg * (h.obs_stride + 64 * scr_stride * 4) + 64;
+    // (+ 256 B: step_kernel's beam tables of maps with more than 8 sources, step_kernel.hpp BM)
+    return h.lds_table_bytes + (pes ? h.ext_bytes : 0u) + (h.L > 8 ? 256u : 0u) + waves_per_wg * (h.obs_stride + 64 * scr_stride * 4) + 64;
 }
 
 // wavefronts per workgroup: as many (4, 2, 1) as fit the 160 KiB of a CU.  More wavefronts per table copy beat more
@@ -481,7 +482,7 @@ bool step_splits_rows(const MapHeader& h, bool pes) {
 }
 uint32_t split_lds_bytes(const MapHeader& h, uint32_t wpw, uint32_t epw) {
     const uint32_t scr_stride = (h.L + h.A + 2) | 1u, cpw = (h.n_chunks + wpw - 1) / wpw;
-    return h.lds_split_table_bytes + wpw * cpw * 16u + wpw * epw * scr_stride * 4u + 64u;
+    return h.lds_split_table_bytes + (h.L > 8 ? 256u : 0u) + wpw * cpw * 16u + wpw * epw * scr_stride * 4u + 64u;
 }
 
 // Store policy of a launch that writes `bytes` of observation rows (WRITE_THROUGH_MAX_BYTES, tables.h).

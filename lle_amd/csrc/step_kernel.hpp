@@ -62,6 +62,9 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     // the row is split over the wavefronts of the workgroup, see write_observations_split (obs_stream.hpp).  Only the
     // instantiations of maps with more than four agents carry it (rows of 16 KB and more with at most four agents
     // would need maps beyond 36 x 36; those stay on whole-row copies), and not the per-env-sources modes.
+    // More than 8 sources: the beam masks live in the env's LDS record instead of LM registers of every lane (step_lanes.hpp BM)
+    constexpr bool BM = LM >= 16 && !(PES && ROLL);  // (per-env-sources rollouts keep the registers: see DESIGN)
+    constexpr int LR = BM ? 1 : LM;  // beam REGISTERS of a lane
     constexpr bool CAN_SPLIT = G >= 8 && !PES;
     constexpr bool HEAD = MODE == 6 || MODE == 7;  // MODE 0 / 4 with the static lines of the rows ahead of the state machine (below)
     const bool split = CAN_SPLIT && (K.flags & LAUNCH_SPLIT_ROWS) != 0;
@@ -102,9 +105,9 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     // arguments: read where they are used they become vector loads from global memory with a full wait each, three of
     // them in a row between the state machine and the first observation store.
     const uint32_t h_HW = hdr->HW, h_obs_stride = hdr->obs_stride, h_n_chunks = hdr->n_chunks, h_D = hdr->D;
-    uint32_t h_beam_full[LM];
+    uint32_t h_beam_full[LR];
 #pragma unroll
-    for (int b = 0; b < LM; b++) h_beam_full[b] = (b < L) ? hdr->beam_full[b] : 0u;
+    for (int b = 0; b < LR; b++) h_beam_full[b] = (!BM && b < L) ? hdr->beam_full[b] : 0u;
     const uint32_t h_enabled = hdr->enabled_mask;
     // (with head stores ahead of them, later header reads would be VECTOR loads -- the scalar cache is not coherent with
     // the kernel's own stores, and the compiler cannot tell the header from the rows -- whose wait covers the stores too)
@@ -119,19 +122,19 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     constexpr bool EARLY_OUT = HEAD && ENV_OUT;  // (MODE 4 / 5 have no scalar registers to park the descriptor in: they spill vector registers for it)
     if (EARLY_OUT && K.env_out) O_early = *K.env_out;
     if (ENV_OUT) { h_G = hdr->G; h_H = hdr->H; }
-    uint32_t h_init_beams[LM];  // the reset state's beams (shared record; the per-env one is read where it is used)
+    uint32_t h_init_beams[LR];  // the reset state's beams (shared record; the per-env one is read where it is used)
 #pragma unroll
-    for (int b = 0; b < LM; b++) h_init_beams[b] = (b < L) ? initp->beams[b] : 0u;
+    for (int b = 0; b < LR; b++) h_init_beams[b] = (!BM && b < L) ? initp->beams[b] : 0u;
     const int64_t n_here = (K.env_limit - env0) < (int64_t)EPW ? (K.env_limit - env0) : (int64_t)EPW;
     const uint32_t amask = (1u << A) - 1u;
     LLE_STAMP(0);
 
     // ---- packed state: own position / availability, and the env-wide words replicated in the group's lanes
-    uint32_t pos = 0xFFFF0000u + a, avail = 0, beams[LM];
+    uint32_t pos = 0xFFFF0000u + a, avail = 0, beams[LR];
     uint64_t raw_bits = 0;
     uint32_t gems = 0;
 #pragma unroll
-    for (int b = 0; b < LM; b++) beams[b] = 0;
+    for (int b = 0; b < LR; b++) beams[b] = 0;
     // Per-lane addresses of this env's / agent's records, computed once and kept in vector registers for the stores at
     // the end: the scalar base pointers are then dead during the state machine (scalar registers are the scarce
     // resource of this kernel, vector registers are not).
@@ -159,9 +162,9 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     // the env's reset beams, read with the rest of its state in the single-step mode: read where the reset needs them they
     // are a memory round trip between the decision to reset and the state machine, in every wavefront that resets anything
     constexpr bool PRE_BEAMS = PES && !ROLL && LM <= 8;
-    uint32_t env_init_beams[LM];
+    uint32_t env_init_beams[LR];
 #pragma unroll
-    for (int b = 0; b < LM; b++) env_init_beams[b] = 0u;
+    for (int b = 0; b < LR; b++) env_init_beams[b] = 0u;
 #pragma unroll
     for (int q = 0; q < CWM; q++) colw[q] = 0;
     // The caller's action, read with the rest of the state in the single-step modes: a load inside the step would be
@@ -179,8 +182,8 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
             raw_bits = *p_bits; \
             gems = *p_gems; \
         _Pragma("unroll") \
-            for (int b = 0; b < LM; b++) \
-                if (b < L) beams[b] = p_beams[b]; \
+            for (int b = 0; b < LR; b++) \
+                if (!BM && b < L) beams[b] = p_beams[b]; \
         } \
         if (me) { \
             pos = (uint32_t)*p_pos; \
@@ -202,7 +205,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
                 init_bits = P.init_bits[env]; \
                 init_gems = P.init_gems[env]; \
         _Pragma("unroll") \
-                for (int b = 0; b < LM; b++) \
+                for (int b = 0; b < LR; b++) \
                     if (PRE_BEAMS && b < L) env_init_beams[b] = P.init_beams[env * L + b]; \
             } \
         } \
@@ -224,6 +227,13 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     copy_tables_to_lds(tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
     const uint32_t ext_bytes = PES ? hdr->ext_bytes : 0u;
     if (PES) copy_tables_to_lds(tables + h_off_bare, lds + tab_bytes, ext_bytes, lane, wave_in_wg, waves_per_wg);
+    // BM: [length masks | beams of the reset state], one copy per workgroup behind the tables
+    constexpr uint32_t bt_bytes = BM ? 2u * LM * 4u : 0u;
+    uint32_t* beam_tab = reinterpret_cast<uint32_t*>(lds + tab_bytes + ext_bytes);
+    if (BM && (int)threadIdx.x < L) {
+        beam_tab[threadIdx.x] = hdr->beam_full[threadIdx.x];
+        beam_tab[LM + threadIdx.x] = initp->beams[threadIdx.x];
+    }
     LLE_STAMP(7);
     if (HEAD) {
         // every load has returned (the table rows were the last ones, and they are in LDS): said with an s_waitcnt the
@@ -245,7 +255,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     const uint64_t* dyn = reinterpret_cast<const uint64_t*>(lds + (h_off_dyn - tab_off));
     const uint32_t scr_stride = (uint32_t)(L + A + 2 + (PES ? CW : 0)) | 1u;
     const uint32_t priv_bytes = h_obs_stride + 64u * scr_stride * 4u;
-    int8_t* tmpl = reinterpret_cast<int8_t*>(lds + tab_bytes + ext_bytes + wave_in_wg * priv_bytes);
+    int8_t* tmpl = reinterpret_cast<int8_t*>(lds + tab_bytes + ext_bytes + bt_bytes + wave_in_wg * priv_bytes);
     uint32_t* scratch = reinterpret_cast<uint32_t*>(tmpl + h_obs_stride);
     const int8_t* bare = reinterpret_cast<const int8_t*>(lds + tab_bytes);
     const uint32_t* elems = reinterpret_cast<const uint32_t*>(lds + tab_bytes + (h_off_elems - h_off_bare));
@@ -254,8 +264,8 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     const uint32_t c_lo = wave_in_wg * cpw < h_n_chunks ? wave_in_wg * cpw : h_n_chunks;
     const uint32_t c_hi = c_lo + cpw < h_n_chunks ? c_lo + cpw : h_n_chunks;
     if (split) {
-        tmpl = reinterpret_cast<int8_t*>(lds + tab_bytes + wave_in_wg * cpw * 16u);
-        scratch = reinterpret_cast<uint32_t*>(lds + tab_bytes + waves_per_wg * cpw * 16u) + wave_in_wg * EPW * scr_stride;
+        tmpl = reinterpret_cast<int8_t*>(lds + tab_bytes + bt_bytes + wave_in_wg * cpw * 16u);
+        scratch = reinterpret_cast<uint32_t*>(lds + tab_bytes + bt_bytes + waves_per_wg * cpw * 16u) + wave_in_wg * EPW * scr_stride;
         const uint4* __restrict__ pristine = reinterpret_cast<const uint4*>(tables + h_off_template) + c_lo;
         uint4* mine = reinterpret_cast<uint4*>(tmpl);
         for (uint32_t c = lane; c < c_hi - c_lo; c += 64) mine[c] = pristine[c];
@@ -264,6 +274,10 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         uint4* mine = reinterpret_cast<uint4*>(tmpl);
         for (uint32_t c = lane; c < h_n_chunks; c += 64) mine[c] = pristine[c];
     }
+    // BM: the env's beam masks go straight into its hand-over record, which phase 2 reads and the state machine updates in place
+    uint32_t* const bm = scratch + grp * scr_stride + 1;
+    if (BM && env_ok)
+        for (int b = (int)a; b < L; b += G) bm[b] = p_beams[b];
     wave_sync();
     // Every load of the prologue has to be back before the state machine starts anyway.  Saying so with an s_waitcnt the
     // compiler sees keeps it from carrying the loads that only some paths consume (the reset record) as pending: it
@@ -311,8 +325,10 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         ghost = over ? 0u : ghost;
         gems = over ? init_gems : gems;
 #pragma unroll
-        for (int b = 0; b < LM; b++)
-            if (b < L) beams[b] = over ? (PES ? (PRE_BEAMS ? env_init_beams[b] : P.init_beams[env_ok ? env * L + b : 0]) : h_init_beams[b]) : beams[b];
+        for (int b = 0; b < LR; b++)
+            if (!BM && b < L) beams[b] = over ? (PES ? (PRE_BEAMS ? env_init_beams[b] : P.init_beams[env_ok ? env * L + b : 0]) : h_init_beams[b]) : beams[b];
+        if (BM && over)  // the group's lanes share the copy of the record
+            for (int b = (int)a; b < L; b += G) bm[b] = PES ? P.init_beams[env * L + b] : beam_tab[LM + b];
         was_reset = over ? 1u : 0u;
         // LLE.reset with randomize_lasers (python/lle/env/env.py:189-203): world.reset() -- above, under the colours the env
         // HAD: beams cut at reset stay as they are -- then a fresh colour for every source, uniform over the colours the
@@ -371,8 +387,8 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     uint64_t evw[NW];
     uint32_t n_ev, meta_step, err;
     bool stepped;
-    step_lanes<G, LM, ML1, PES, CWM>(cell_lay, cell_meta, A, L, W, max_layers, h_beam_full, a, me, env_ok, enabled, colw, act, pos, avail,
-                                     alive, arrived, occ, gems, beams, err, evw, n_ev, meta_step, stepped);
+    step_lanes<G, LR, ML1, PES, CWM, true, BM>(cell_lay, cell_meta, A, L, W, max_layers, h_beam_full, a, me, env_ok, enabled, colw, act, pos, avail,
+                                               alive, arrived, occ, gems, beams, err, evw, n_ev, meta_step, stepped, nullptr, bm, beam_tab);
     LLE_STAMP(3);
 
     // ---- everything of the step that the observation does not need: availability masks (compute_available_actions,
@@ -472,8 +488,8 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         uint32_t* sc = scratch + grp * scr_stride;
         sc[0] = 0u;
 #pragma unroll
-        for (int b = 0; b < LM; b++)
-            if (b < L) sc[1 + b] = beams[b];
+        for (int b = 0; b < LR; b++)
+            if (!BM && b < L) sc[1 + b] = beams[b];  // (BM: the masks are there already)
         sc[L + 1] = ~gems;
         if (PES) {
 #pragma unroll
@@ -501,7 +517,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
             const int64_t wg_env0 = K.env_base + (int64_t)(blk * waves_per_wg) * EPW;
             int64_t n_wg = K.env_limit - wg_env0;
             n_wg = n_wg < 0 ? 0 : (n_wg > (int64_t)(waves_per_wg * EPW) ? (int64_t)(waves_per_wg * EPW) : n_wg);
-            const uint32_t* records = reinterpret_cast<const uint32_t*>(lds + tab_bytes + waves_per_wg * cpw * 16u);
+            const uint32_t* records = reinterpret_cast<const uint32_t*>(lds + tab_bytes + bt_bytes + waves_per_wg * cpw * 16u);
             if (K.flags & LAUNCH_WRITE_THROUGH) write_observations_split<true>(A, L, h_D, c_lo, c_hi, h_obs_stride, dyn, tmpl, records, scr_stride, obs_out, wg_env0, n_wg, lane);
             else write_observations_split<false>(A, L, h_D, c_lo, c_hi, h_obs_stride, dyn, tmpl, records, scr_stride, obs_out, wg_env0, n_wg, lane);
         }
@@ -535,8 +551,12 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         *LLE_LATE(gems, env_c) = gems;
         uint32_t* const beams_out = LLE_LATE(beams, env_c * L);
 #pragma unroll
-        for (int b = 0; b < LM; b++)
-            if (b < L) beams_out[b] = beams[b];
+        for (int b = 0; b < LR; b++)
+            if (!BM && b < L) beams_out[b] = beams[b];
+    }
+    if (BM && env_ok) {
+        uint32_t* const beams_out = LLE_LATE(beams, env_c * L);
+        for (int b = (int)a; b < L; b += G) beams_out[b] = bm[b];
 #undef LLE_LATE
 #undef LLE_LOAD_STATE
     }

@@ -58,6 +58,9 @@ template <int G>
 __device__ __forceinline__ bool any_lane(bool v) { return __any(v); }
 template <int G>
 __device__ __forceinline__ bool uniform(bool v) { return v; }
+// beam words kept in the environment's LDS record (BM below): OR / AND without return (ds_or_b32 / ds_and_b32)
+__device__ __forceinline__ void mem_or(uint32_t* p, uint32_t m) { (void)__hip_atomic_fetch_or(p, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void mem_and(uint32_t* p, uint32_t m) { (void)__hip_atomic_fetch_and(p, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 #else
 // ------------------------------------------------------------------------------------------------ host (test builds only)
@@ -93,6 +96,8 @@ inline bool any_lane(const LV<G, bool>& x) { bool r = false; for (int i = 0; i <
 struct LaneDivergence {};
 template <int G, typename T>
 inline T uniform(const LV<G, T>& x) { for (int i = 1; i < G; i++) if (!(x.v[i] == x.v[0])) throw LaneDivergence(); return x.v[0]; }
+inline void mem_or(uint32_t* p, uint32_t m) { *p |= m; }
+inline void mem_and(uint32_t* p, uint32_t m) { *p &= m; }
 #endif
 
 // value of `v` in the group lane whose agent id is (a ^ J), for every J in 1..G-1, fed to f(J, value)
@@ -119,14 +124,25 @@ LLE_LANE_FN uint32_t beam_get_lv(const E (&b)[LM], uint32_t idx) {
 // Out: err (0, or 1 + lowest agent whose action was not available: nothing else is then touched), evw[] / n_ev (the ordered
 // event bytes, this lane's share: OR them over the group), meta_step (cell meta of the agent's final cell), stepped.
 // SHORTCUT: skip a pass that cannot change anything (see below); always on in the product, switchable in test builds.
-template <int G, int LM, bool ML1, bool PES, int CWM, bool SHORTCUT = true>
+// BM ("beams in memory", maps with more than 8 sources): the beam masks are not registers of every lane but the L words
+// `bm[0..L)` of the environment -- its hand-over record in LDS on the device -- and `full_tab[b]` = (1 << length) - 1.
+// With the masks in registers a pass walks ALL LM of them against the layers of the lane's cell, twice, with a group
+// reduction per beam each: O(LM x layers) instructions per pass, most of them for beams the lane has nothing to do
+// with.  A cell carries at most four beams, so here a lane asks for its <= 4 re-lights (mem_or) and cuts (mem_and) by beam
+// index and reads back the <= 4 masks its enter needs.  Legal for the reason the register form is (leaves commute,
+// pre-enters commute, all leaves precede all pre-enters): the conditions of every leave are read in one LLE_LANES
+// block, the ORs happen in the next, the ANDs in the one after -- on the device the LDS operations of a wavefront
+// execute in order and the lanes of an environment share a wavefront.  `beams` / `h_beam_full` are then unused
+// (instantiate with LM = 1).
+template <int G, int LM, bool ML1, bool PES, int CWM, bool SHORTCUT = true, bool BM = false>
 LLE_LANE_FN void step_lanes(const uint64_t* cell_lay, const uint32_t* cell_meta, int A, int L, int W, uint32_t table_max_layers,
                        const uint32_t (&h_beam_full)[LM], const LV<G, uint32_t>& a, const LV<G, bool>& me, const LV<G, bool>& env_ok,
                        const LV<G, uint32_t>& enabled, const LV<G, uint32_t> (&colw)[CWM > 0 ? CWM : 1], const LV<G, uint32_t>& act,
                        LV<G, uint32_t>& pos, const LV<G, uint32_t>& avail, LV<G, uint32_t>& alive, LV<G, uint32_t>& arrived,
                        LV<G, uint32_t>& occ, LV<G, uint32_t>& gems, LV<G, uint32_t> (&beams)[LM], LV<G, uint32_t>& err,
                        LV<G, uint64_t> (&evw)[(2 * G + 7) / 8], LV<G, uint32_t>& n_ev, LV<G, uint32_t>& meta_step, LV<G, bool>& stepped,
-                       int64_t* passes_executed = nullptr /* test builds: counts the move_agents passes that ran */) {
+                       int64_t* passes_executed = nullptr /* test builds: counts the move_agents passes that ran */,
+                       uint32_t* bm = nullptr, const uint32_t* full_tab = nullptr /* BM only */) {
     constexpr int NW = (2 * G + 7) / 8;
     const uint32_t max_layers = ML1 ? 1u : table_max_layers;
 
@@ -204,32 +220,58 @@ LLE_LANE_FN void step_lanes(const uint64_t* cell_lay, const uint32_t* cell_meta,
     LV<G, bool> go(true), me_alive, first_pass(true);
     LV<G, uint32_t> light[LM], lit[LM], cutv[LM], alive0, p1v, p2v, gemv;
     LV<G, bool> died, ev_exit, ev_gem, has_ev, inner;
+    LV<G, uint32_t> rq_b[4], rq_m[4], rq_any;  // BM: this lane's re-light requests (beam, suffix), one per layer of its cell
     while (any_lane<G>(go)) {
         // leave (laser.rs:199-202,157-162): what the alive agents of the env re-light, per beam
         LLE_LANES(G) {
             alive0 = (uint32_t)alive;
             me_alive = go && me && (alive0 & bit);
+            if constexpr (BM) {
+                uint32_t any = 0;
 #pragma unroll
-            for (int b = 0; b < LM; b++) {
-                uint32_t lt = 0;
-                if (b < L) {
-                    for (uint32_t k = 0; k < max_layers; k++) {
+                for (int k = 0; k < 4; k++) {
+                    uint32_t rb = 0, rm = 0;
+                    if ((uint32_t)k < max_layers) {
                         const uint32_t eo = (uint32_t)((uint64_t)lay_from >> (16 * k)) & 0xFFFFu;
-                        const bool lo = me_alive && (eo & LAY_VALID) && ((eo >> 1) & 31u) == (uint32_t)b &&
-                                        !(((uint32_t)beams[b] >> ((eo >> 6) & 31u)) & 1u);
-                        lt |= lo ? (0xFFFFFFFFu << ((eo >> 6) & 31u)) : 0u;
+                        const uint32_t b = (eo >> 1) & 31u, off = (eo >> 6) & 31u;
+                        const bool valid = (eo & LAY_VALID) != 0;  // (an empty layer slot names no beam: nothing is read for it)
+                        const uint32_t cur = valid ? bm[b] : 0xFFFFFFFFu, full = valid ? full_tab[b] : 0u;
+                        const bool lo = me_alive && valid && ((enabled >> b) & 1u) && !((cur >> off) & 1u);
+                        rb = valid ? b : 0u;
+                        rm = lo ? ((0xFFFFFFFFu << off) & full) : 0u;
                     }
-                    lt = ((enabled >> b) & 1u) ? lt : 0u;
+                    rq_b[k] = rb;
+                    rq_m[k] = rm;
+                    any |= rm;
                 }
-                light[b] = lt;
+                rq_any = any;
+            } else {
+#pragma unroll
+                for (int b = 0; b < LM; b++) {
+                    uint32_t lt = 0;
+                    if (b < L) {
+                        for (uint32_t k = 0; k < max_layers; k++) {
+                            const uint32_t eo = (uint32_t)((uint64_t)lay_from >> (16 * k)) & 0xFFFFu;
+                            const bool lo = me_alive && (eo & LAY_VALID) && ((eo >> 1) & 31u) == (uint32_t)b &&
+                                            !(((uint32_t)beams[b] >> ((eo >> 6) & 31u)) & 1u);
+                            lt |= lo ? (0xFFFFFFFFu << ((eo >> 6) & 31u)) : 0u;
+                        }
+                        lt = ((enabled >> b) & 1u) ? lt : 0u;
+                    }
+                    light[b] = lt;
+                }
             }
         }
         LLE_LANES(G) {
             uint32_t al = 0;
+            if constexpr (BM) {
+                al = grp_or<G>(rq_any);
+            } else {
 #pragma unroll
-            for (int b = 0; b < LM; b++) {
-                lit[b] = (b < L) ? grp_or<G>(light[b]) : 0u;
-                al |= lit[b];
+                for (int b = 0; b < LM; b++) {
+                    lit[b] = (b < L) ? grp_or<G>(light[b]) : 0u;
+                    al |= lit[b];
+                }
             }
             // A pass after the first one leaves and re-enters the SAME cells.  If no alive agent re-lights anything, the
             // beams cannot change (the owners' cuts are repeated as they are), so every enter repeats its outcome: alive
@@ -237,28 +279,52 @@ LLE_LANE_FN void step_lanes(const uint64_t* cell_lay, const uint32_t* cell_meta,
             // The pass is then a no-op and `while agent_died` ends (world.rs:468-472).
             if (SHORTCUT && !first_pass && al == 0u) go = false;
         }
+        if constexpr (BM) {
+            LLE_LANES(G) {  // every leave's condition has been read: re-light
+                if (go) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if ((uint32_t)rq_m[k]) mem_or(bm + (uint32_t)rq_b[k], (uint32_t)rq_m[k]);
+                }
+            }
+        }
         // pre_enter (laser.rs:173-182): what the alive agents of the beam's colour cut
         LLE_LANES(G) {
+            if constexpr (BM) {
+                if (go && me_alive) {
 #pragma unroll
-            for (int b = 0; b < LM; b++) {
-                uint32_t keep = 0xFFFFFFFFu;
-                if (b < L) {
-                    for (uint32_t k = 0; k < max_layers; k++) {
-                        const uint32_t en = (uint32_t)((uint64_t)lay_new >> (16 * k)) & 0xFFFFu;
-                        const bool pe = go && me_alive && (en & LAY_VALID) && ((en >> 1) & 31u) == (uint32_t)b && (en >> 11) == a;
-                        keep &= pe ? ((1u << ((en >> 6) & 31u)) - 1u) : 0xFFFFFFFFu;
+                    for (int k = 0; k < 4; k++) {
+                        if ((uint32_t)k < max_layers) {
+                            const uint32_t en = (uint32_t)((uint64_t)lay_new >> (16 * k)) & 0xFFFFu;
+                            const uint32_t b = (en >> 1) & 31u;
+                            if ((en & LAY_VALID) && (en >> 11) == a && ((enabled >> b) & 1u)) mem_and(bm + b, (1u << ((en >> 6) & 31u)) - 1u);
+                        }
                     }
                 }
-                cutv[b] = ((b < L) && ((enabled >> b) & 1u)) ? ~keep : 0u;
+            } else {
+#pragma unroll
+                for (int b = 0; b < LM; b++) {
+                    uint32_t keep = 0xFFFFFFFFu;
+                    if (b < L) {
+                        for (uint32_t k = 0; k < max_layers; k++) {
+                            const uint32_t en = (uint32_t)((uint64_t)lay_new >> (16 * k)) & 0xFFFFu;
+                            const bool pe = go && me_alive && (en & LAY_VALID) && ((en >> 1) & 31u) == (uint32_t)b && (en >> 11) == a;
+                            keep &= pe ? ((1u << ((en >> 6) & 31u)) - 1u) : 0xFFFFFFFFu;
+                        }
+                    }
+                    cutv[b] = ((b < L) && ((enabled >> b) & 1u)) ? ~keep : 0u;
+                }
             }
         }
         LLE_LANES(G) {
             if (go) {
                 if (passes_executed && LLE_LANE_INDEX == 0) ++*passes_executed;
                 occ &= ~(uint32_t)alive0;  // Tile::leave: slot.take() for every alive agent
+                if constexpr (!BM) {
 #pragma unroll
-                for (int b = 0; b < LM; b++)
-                    if (b < L) beams[b] = ((uint32_t)beams[b] | lit[b]) & ~grp_or<G>(cutv[b]);
+                    for (int b = 0; b < LM; b++)
+                        if (b < L) beams[b] = ((uint32_t)beams[b] | lit[b]) & ~grp_or<G>(cutv[b]);
+                }
             }
         }
         // enter (tile.rs:29-50, laser.rs:184-197)
@@ -266,7 +332,9 @@ LLE_LANE_FN void step_lanes(const uint64_t* cell_lay, const uint32_t* cell_meta,
             bool blocked = false;
             for (uint32_t k = 0; k < max_layers; k++) {
                 const uint32_t en = (uint32_t)((uint64_t)lay_new >> (16 * k)) & 0xFFFFu;
-                const uint32_t m = beam_get_lv<LM>(beams, (en >> 1) & 31u);
+                uint32_t m;
+                if constexpr (BM) m = (en & LAY_VALID) ? bm[(en >> 1) & 31u] : 0u;
+                else m = beam_get_lv<LM>(beams, (en >> 1) & 31u);
                 blocked |= (en & LAY_VALID) && ((m >> ((en >> 6) & 31u)) & 1u) && ((en >> 11) != a);
             }
             const bool is_alive = (alive & bit) != 0;
@@ -306,9 +374,11 @@ LLE_LANE_FN void step_lanes(const uint64_t* cell_lay, const uint32_t* cell_meta,
     }
     LLE_LANES(G) {
         pos = (uint32_t)np;
+        if constexpr (!BM) {
 #pragma unroll
-        for (int b = 0; b < LM; b++)
-            if (b < L) beams[b] &= h_beam_full[b];
+            for (int b = 0; b < LM; b++)
+                if (b < L) beams[b] &= h_beam_full[b];
+        }
         meta_step = (uint32_t)meta_new;
         stepped = true;
     }

@@ -42,24 +42,31 @@ struct hs_batch {
 template <int AM, int LM, int G, bool ML1, bool PES, bool SHORTCUT>
 static uint32_t lanes_step_g(Env<AM, LM>& s, const uint32_t (&act)[AM], uint32_t (&avail)[AM], const MapView& mv, Events<AM>& ev, int64_t* passes) {
     constexpr int NWG = (2 * G + 7) / 8, CWM = LM / 4;
+    // like step_kernel: more than 8 sources -> the beam masks live in the env's record (here: `bm`), not in lane registers
+    constexpr bool BM = LM >= 16;
+    constexpr int LR = BM ? 1 : LM;
     static_assert(G <= AM || AM == 16, "the group is the power of two above the agent count");
     const int A = mv.A, L = mv.L;
-    LV<G, uint32_t> a, pos, av, alive, arrived, occ, gems, beams[LM], err, n_ev, meta_step, actv, enabled, colw[CWM];
+    LV<G, uint32_t> a, pos, av, alive, arrived, occ, gems, beams[LR], err, n_ev, meta_step, actv, enabled, colw[CWM];
     LV<G, bool> me, env_ok(true), stepped;
     LV<G, uint64_t> evw[NWG];
-    uint32_t beam_full[LM];
-    for (int b = 0; b < LM; b++) beam_full[b] = b < L ? mv.hdr->beam_full[b] : 0u;
+    uint32_t beam_full[LM], beam_full_r[LR], bm[LM];
+    for (int b = 0; b < LM; b++) { beam_full[b] = b < L ? mv.hdr->beam_full[b] : 0u; bm[b] = s.beams[b]; }
+    for (int b = 0; b < LR; b++) beam_full_r[b] = beam_full[b];
     for (int i = 0; i < G; i++) {
         a.v[i] = (uint32_t)i; me.v[i] = i < A;
         pos.v[i] = i < A ? s.pos[i] : 0xFFFF0000u + (uint32_t)i;
         av.v[i] = i < A ? avail[i] : 0u;
         actv.v[i] = i < A ? act[i] : 4u;
         alive.v[i] = s.alive; arrived.v[i] = s.arrived; occ.v[i] = s.occ; gems.v[i] = s.gems; enabled.v[i] = mv.enabled;
-        for (int b = 0; b < LM; b++) beams[b].v[i] = s.beams[b];
+        for (int b = 0; b < LR; b++) beams[b].v[i] = s.beams[b];
         for (int q = 0; q < CWM; q++) colw[q].v[i] = mv.colw[q];
     }
-    step_lanes<G, LM, ML1, PES, CWM, SHORTCUT>(mv.cell_lay, mv.cell_meta, A, L, mv.W, mv.max_layers, beam_full, a, me, env_ok, enabled, colw,
-                                               actv, pos, av, alive, arrived, occ, gems, beams, err, evw, n_ev, meta_step, stepped, passes);
+    // (bm is sized L on the device; here LM words, so that an out-of-range beam index would still be caught by ASan via `bm + L` below)
+    std::vector<uint32_t> bm_exact(bm, bm + (L > 0 ? L : 1)), full_exact(beam_full, beam_full + (L > 0 ? L : 1));
+    step_lanes<G, LR, ML1, PES, CWM, SHORTCUT, BM>(mv.cell_lay, mv.cell_meta, A, L, mv.W, mv.max_layers, beam_full_r, a, me, env_ok, enabled, colw,
+                                                   actv, pos, av, alive, arrived, occ, gems, beams, err, evw, n_ev, meta_step, stepped, passes,
+                                                   BM ? bm_exact.data() : nullptr, BM ? full_exact.data() : nullptr);
     const uint32_t e = uniform<G>(err);
     if (!uniform<G>(stepped)) return e;
     avail_lanes<G>(a, me, pos, occ, alive, arrived, meta_step, av);
@@ -67,7 +74,8 @@ static uint32_t lanes_step_g(Env<AM, LM>& s, const uint32_t (&act)[AM], uint32_t
         if (i < A) { s.pos[i] = pos.v[i]; avail[i] = av.v[i]; }
     }
     s.alive = uniform<G>(alive); s.arrived = uniform<G>(arrived); s.occ = uniform<G>(occ); s.gems = uniform<G>(gems);
-    for (int b = 0; b < LM; b++) s.beams[b] = uniform<G>(beams[b]);
+    if (BM) { for (int b = 0; b < L; b++) s.beams[b] = bm_exact[b]; }
+    else { for (int b = 0; b < LR; b++) s.beams[b] = uniform<G>(beams[b]); }
     ev.clear();
     ev.n = uniform<G>(n_ev);
     for (int k = 0; k < NWG && k < Events<AM>::NW; k++) ev.w[k] = grp_or64<G>(evw[k]);
