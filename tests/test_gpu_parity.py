@@ -301,7 +301,7 @@ def test_reward_counts_and_snapshot(oracle_mod):
         assert np.array_equal(now[k], ref[k]), k
 
 
-@pytest.mark.parametrize("name", ["level6", "nested", "many_agents"])
+@pytest.mark.parametrize("name", ["level6", "nested", "many_agents", "gen_20_lasers", "gen_16x16_12agents"])
 def test_fused_rollout_equals_single_steps(oracle_mod, name):
     """lle_batch_rollout: T steps in one launch == T single steps of the oracle, per-step outputs in the rings."""
     from lle_amd import BatchedWorld
