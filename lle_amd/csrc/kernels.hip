@@ -449,11 +449,15 @@ const char* kernel_variant_name(int variant) {
     return names[variant & 3];
 }
 
+// step_kernel keeps the beam masks of these maps in the env's LDS record (step_kernel.hpp BM): more than 8 sources, or 5-8
+// sources with more than four agents
+static bool beams_in_lds(const MapHeader& h) { return h.L > 8 || (h.L > 4 && h.A > 4); }
+
 // `pes`: per-environment sources (the second table section in LDS, colour words in the hand-over records)
 uint32_t kernel_lds_bytes(const MapHeader& h, uint32_t waves_per_wg, bool pes) {
     const uint32_t scr_stride = (h.L + h.A + 2 + (pes ? (uint32_t)src_stride_of((int)h.L) / 4u : 0u)) | 1u;
     // (+ 256 B: step_kernel's beam tables of maps with more than 8 sources, step_kernel.hpp BM)
-    return h.lds_table_bytes + (pes ? h.ext_bytes : 0u) + (h.L > 8 ? 256u : 0u) + waves_per_wg * (h.obs_stride + 64 * scr_stride * 4) + 64;
+    return h.lds_table_bytes + (pes ? h.ext_bytes : 0u) + (beams_in_lds(h) ? 256u : 0u) + waves_per_wg * (h.obs_stride + 64 * scr_stride * 4) + 64;
 }
 
 // wavefronts per workgroup: as many (4, 2, 1) as fit the 160 KiB of a CU.  More wavefronts per table copy beat more
@@ -482,7 +486,7 @@ bool step_splits_rows(const MapHeader& h, bool pes) {
 }
 uint32_t split_lds_bytes(const MapHeader& h, uint32_t wpw, uint32_t epw) {
     const uint32_t scr_stride = (h.L + h.A + 2) | 1u, cpw = (h.n_chunks + wpw - 1) / wpw;
-    return h.lds_split_table_bytes + (h.L > 8 ? 256u : 0u) + wpw * cpw * 16u + wpw * epw * scr_stride * 4u + 64u;
+    return h.lds_split_table_bytes + (beams_in_lds(h) ? 256u : 0u) + wpw * cpw * 16u + wpw * epw * scr_stride * 4u + 64u;
 }
 
 // Store policy of a launch that writes `bytes` of observation rows (WRITE_THROUGH_MAX_BYTES, tables.h).
@@ -581,7 +585,7 @@ hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const Laun
     if (pes) return roll ? launch_step_mode3(G, lm, P, K, n_waves, wpw, lds, stream) : launch_step_mode5(G, lm, P, K, n_waves, wpw, lds, stream);
     // single-step launches with the map's sources: the rows' head lines go out ahead of the state machine (MODE 6 / 7) when
     // the map has a head, the rows are not split and the launch is of the size where it pays
-    const bool heads = !roll && lm <= 8 && h.head_n != 0 && !(K.flags & (LAUNCH_SPLIT_ROWS | STEP_NO_OBS)) && row_heads_pay(n_waves);
+    const bool heads = !roll && lm <= 8 && !beams_in_lds(h) && h.head_n != 0 && !(K.flags & (LAUNCH_SPLIT_ROWS | STEP_NO_OBS)) && row_heads_pay(n_waves);
     if (K.flags & LAUNCH_GENERAL) {
         if (roll) return launch_step_mode2(G, lm, P, K, n_waves, wpw, lds, stream);
         return heads ? launch_step_mode7(G, lm, P, K, n_waves, wpw, lds, stream) : launch_step_mode4(G, lm, P, K, n_waves, wpw, lds, stream);

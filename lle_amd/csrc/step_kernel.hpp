@@ -63,7 +63,9 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     // instantiations of maps with more than four agents carry it (rows of 16 KB and more with at most four agents
     // would need maps beyond 36 x 36; those stay on whole-row copies), and not the per-env-sources modes.
     // More than 8 sources: the beam masks live in the env's LDS record instead of LM registers of every lane (step_lanes.hpp BM)
-    constexpr bool BM = LM >= 16 && !(PES && ROLL);  // (per-env-sources rollouts keep the registers: see DESIGN)
+    // (also 5-8 sources with more than four agents -- config 5 --: groups of 8 / 16 lanes pay the most per group reduction;
+    //  per-env-sources rollouts keep the registers: see DESIGN)
+    constexpr bool BM = (LM >= 16 || (LM == 8 && G >= 8)) && !(PES && ROLL);
     constexpr int LR = BM ? 1 : LM;  // beam REGISTERS of a lane
     constexpr bool CAN_SPLIT = G >= 8 && !PES;
     constexpr bool HEAD = MODE == 6 || MODE == 7;  // MODE 0 / 4 with the static lines of the rows ahead of the state machine (below)
@@ -598,9 +600,9 @@ static hipError_t launch_step_mode_gl(const BatchPtrs& P, const LaunchArgs& K, u
 }
 template <int MODE, int G>
 static hipError_t launch_step_mode_g(int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
-    if constexpr (MODE == 6 || MODE == 7) {  // (the launcher sends maps with more than 8 sources to MODE 0 / 4)
+    if constexpr (MODE == 6 || MODE == 7) {  // (the launcher sends maps whose beam masks live in LDS to MODE 0 / 4: row_heads_fit)
         if (lm == 4) return launch_step_mode_gl<MODE, G, 4>(P, K, n_waves, wpw, lds, stream);
-        if (lm == 8) return launch_step_mode_gl<MODE, G, 8>(P, K, n_waves, wpw, lds, stream);
+        if constexpr (G < 8) { if (lm == 8) return launch_step_mode_gl<MODE, G, 8>(P, K, n_waves, wpw, lds, stream); }
         return hipErrorInvalidValue;
     } else {
         switch (lm) {
