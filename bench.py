@@ -355,6 +355,10 @@ def main():
     preroll_steps = preroll(torch, dev, step)
     for _ in range(args.warmup):
         step()
+    # A dress rehearsal of the timed region, untimed: the first pass through Timer.run in a process pays one-off host costs
+    # (first timing events, first elapsed_time, cold Python / ctypes paths: ~100 us, a fifth of the driver's 20-step region;
+    # measured 26.0 us per step for the first region of a process against 21.1-21.2 for every later one).
+    timer.run(step, max(1, min(args.steps, 32)))
     # counters of the timed region only: zeroed by a fill on the launch stream (bw.stats(reset=True) would read them back
     # first -- a host round trip right in front of a timed region that is 0.5 ms long at the driver's 20 steps)
     bw.stats_blocks.zero_()
