@@ -352,11 +352,12 @@ def main():
     offset = shard_offset(n, rank)
     step = stepper(bw, offset)
 
+    bw.stats_blocks.zero_()  # (the first torch fill of the process loads a code object: not right in front of the timed region)
     preroll_steps = preroll(torch, dev, step)
     for _ in range(args.warmup):
         step()
     # A dress rehearsal of the timed region, untimed: the first pass through Timer.run in a process pays one-off host costs
-    # (first timing events, first elapsed_time, cold Python / ctypes paths: ~100 us, a fifth of the driver's 20-step region;
+    # (first timing events, first elapsed_time, cold Python / ctypes paths, and the first torch fill kernel above: ~100 us, a fifth of the driver's 20-step region;
     # measured 26.0 us per step for the first region of a process against 21.1-21.2 for every later one).
     timer.run(step, max(1, min(args.steps, 32)))
     # counters of the timed region only: zeroed by a fill on the launch stream (bw.stats(reset=True) would read them back
