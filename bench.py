@@ -193,9 +193,8 @@ class Timer:
 
 
 def stepper(bw, offset=0):
-    def fn():
-        bw.step(sample=True, auto_reset=True, seed=SEED, env_offset=offset)
-    return fn
+    """One step per call, arguments and stream bound once (BatchedWorld.sampled_stepper): the host side of a step is the C-ABI call."""
+    return bw.sampled_stepper(auto_reset=True, seed=SEED, env_offset=offset)
 
 
 def preroll(torch, dev, fn, seconds=PREROLL_SECONDS):

@@ -176,6 +176,22 @@ class BatchedWorld:
             self._check(_capi.lib().lle_batch_step(self.h, ap, flags, int(seed), int(t), int(env_offset), self._stream()))
         self.t = t + 1
 
+    def sampled_stepper(self, auto_reset=True, seed=0, env_offset=0, write_obs=True):
+        """A zero-argument callable for hot loops: one `step(sample=True, ...)` per call with the arguments and the
+        stream bound once (the stream that is current NOW), the time index advancing by one per call -- the C-ABI call
+        and nothing else per step (`step()` itself spends a few microseconds in Python per launch)."""
+        fn, h, st = _capi.lib().lle_batch_step, self.h, self._stream()
+        flags = LLE_STEP_SAMPLE_ACTIONS | (LLE_STEP_AUTO_RESET if auto_reset else 0) | (0 if write_obs else LLE_STEP_NO_OBS)
+        seed, env_offset = int(seed), int(env_offset)
+
+        def one_step():
+            t = self.t
+            rc = fn(h, None, flags, seed, t, env_offset, st)
+            if rc != 0:
+                self._check(rc)
+            self.t = t + 1
+        return one_step
+
     def make_ring(self, slots):
         """Trajectory rings for `rollout`: obs [R,n,C,H,W] int8, actions [R,n,A] uint8, reward [R,n,4] uint8."""
         m = self.map
