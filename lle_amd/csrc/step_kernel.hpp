@@ -39,8 +39,8 @@ namespace lle {
 // MODE 6: MODE 0 for launches of one to two rounds of workgroups (kernels.hip: row_heads_pay): the rows' static head lines are
 // stored before the state machine, and every load of the kernel is issued up front (see HEAD below).  An instantiation
 // of its own: a launch without heads runs 0.2-0.4 us slower with that load order (level 1: 5.9 -> 6.1 us at 4 096 envs).
-// Maps with at most 8 sources only (with 16 / 32 beam registers the early state loads spill).  MODE 7: the same for MODE 4
-// (several maps / the fused LLE.step outputs).
+// Only for maps whose beam masks are registers (BM below: the fill of the LDS record would be a load behind the head stores).
+// MODE 7: the same for MODE 4 (several maps / the fused LLE.step outputs).
 // LX >= 0: the exact number of sources, known at compile time (instantiated for the default path of maps with at
 // most four sources: the per-beam loops lose their guards and the unused beam registers disappear; 0.4 us on level 6).
 // A 64-byte struct at a wave-uniform address that only the host writes, through the scalar cache.
@@ -58,15 +58,15 @@ template <int G, int LM, int MODE, bool ML1, int LX = -1>
 __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P, LaunchArgs K) {
     constexpr bool GEN = (MODE >= 2 && MODE <= 5) || MODE == 7, ROLL = MODE >= 1 && MODE <= 3;
     constexpr bool PES = MODE == 3 || MODE == 5;  // (the launcher picks these exactly when LAUNCH_PER_ENV_SOURCES is set)
-    // Big rows (LAUNCH_SPLIT_ROWS, set by the launcher when private whole-row copies would leave one workgroup per CU):
-    // the row is split over the wavefronts of the workgroup, see write_observations_split (obs_stream.hpp).  Only the
-    // instantiations of maps with more than four agents carry it (rows of 16 KB and more with at most four agents
-    // would need maps beyond 36 x 36; those stay on whole-row copies), and not the per-env-sources modes.
     // More than 8 sources: the beam masks live in the env's LDS record instead of LM registers of every lane (step_lanes.hpp BM)
     // (also 5-8 sources with more than four agents -- config 5 --: groups of 8 / 16 lanes pay the most per group reduction;
     //  per-env-sources rollouts keep the registers: see DESIGN)
     constexpr bool BM = (LM >= 16 || (LM == 8 && G >= 8)) && !(PES && ROLL);
     constexpr int LR = BM ? 1 : LM;  // beam REGISTERS of a lane
+    // Big rows (LAUNCH_SPLIT_ROWS, set by the launcher when private whole-row copies would leave one workgroup per CU):
+    // the row is split over the wavefronts of the workgroup, see write_observations_split (obs_stream.hpp).  Only the
+    // instantiations of maps with more than four agents carry it (rows of 16 KB and more with at most four agents
+    // would need maps beyond 36 x 36; those stay on whole-row copies), and not the per-env-sources modes.
     constexpr bool CAN_SPLIT = G >= 8 && !PES;
     constexpr bool HEAD = MODE == 6 || MODE == 7;  // MODE 0 / 4 with the static lines of the rows ahead of the state machine (below)
     const bool split = CAN_SPLIT && (K.flags & LAUNCH_SPLIT_ROWS) != 0;
