@@ -1,7 +1,10 @@
 """Soak differential (GPU box): HIP path vs the CPU oracle on long random rollouts, every buffer of every env compared
 bit-for-bit after every step (state, ordered events, availability, error codes, the full int8 observation).
 Beyond the test suite's sizes; prints env-steps compared per map.
-Usage: python tools/soak_parity.py [seconds_per_map] [per-env-sources | full-size | recolour-resets]
+Usage: python tools/soak_parity.py [seconds_per_map] [per-env-sources | full-size | recolour-resets | rollouts]
+With `rollouts` the GPU side runs lle_batch_rollout (8 steps per launch into a trajectory ring of 8 slots: the fused
+kernels, MODE 1) and the oracle the same 8 steps one by one: every slot of the observation / action / reward rings and
+the final state of every launch are compared.
 With `recolour-resets` every finished env is reset AND re-coloured inside the step kernel (LLE_STEP_AUTO_RESET |
 LLE_STEP_RECOLOUR_RESETS: LLE.reset with randomize_lasers); the oracle side resets such an env, sets the colours of the
 documented draws (hash of seed ^ RECOLOUR_SALT, env, t, source; uniform over the colours the source may take) and steps.
@@ -29,6 +32,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
 per_env = len(sys.argv) > 2 and sys.argv[2] == "per-env-sources"
 full_size = len(sys.argv) > 2 and sys.argv[2] == "full-size"
 recolour = len(sys.argv) > 2 and sys.argv[2] == "recolour-resets"
+rollouts = len(sys.argv) > 2 and sys.argv[2] == "rollouts"
 rng = np.random.default_rng(7)
 
 
@@ -69,6 +73,8 @@ total = 0
 for name, (text, n) in maps.items():
     if per_env or recolour:
         n = min(n, 2048)  # (the per-env source calls on the oracle side are Python loops)
+    if rollouts:
+        n = min(n, 8192)
     ob, bw = om.OracleBatch(text, n), BatchedWorld(text, n)
     dims = (ob.A, ob.G, ob.Ls, ob.beam_stride, ob.C, ob.H, ob.W)
     L = bw.map.n_sources
@@ -87,6 +93,25 @@ for name, (text, n) in maps.items():
             for s in range(L):
                 ob.world(e).set_source(s, colour=int(start[e, s]))
         colours = start.copy()
+    if rollouts:
+        T = 8
+        ring = bw.make_ring(T)
+    while rollouts and time.time() - t0 < budget:
+        bw.rollout(T, auto_reset=True, seed=2026, t=t, env_offset=11, ring=ring, ring_pos=0)
+        robs, ract, rrew = ring["obs"].cpu().numpy(), ring["actions"].cpu().numpy(), ring["reward"].cpu().numpy()
+        for j in range(T):
+            ostep = ob.step(None, auto_reset=True, seed=2026, t=t + j, env_offset=11)
+            assert np.array_equal(robs[j], ostep["obs"]), f"{name} t={t + j}: ring obs"
+            assert np.array_equal(ract[j], ostep["actions"]), f"{name} t={t + j}: ring actions"
+            cnt = (ostep["ev_count"] & 0x7F).astype(np.int64)
+            ev = np.where((np.arange(ostep["events"].shape[1])[None, :] < cnt[:, None]), ostep["events"][:, :, 0], 255)
+            want = np.stack([(ev == 1).sum(1), (ev == 0).sum(1), (ev == 2).sum(1)], 1)  # gems, exits, deaths of the step
+            assert np.array_equal(rrew[j][:, :3].astype(np.int64), want), f"{name} t={t + j}: ring reward counts"
+        eng = unpack_engine(bw.host_buffers(), *dims)
+        eng["actions"] = ostep["actions"]  # (with a ring the actions of a step are in its ring slot, compared above)
+        assert_step_equal(eng, ostep, f"{name} t={t + T - 1} (last step of the launch)", check_obs=False)  # (obs: the ring)
+        assert_state_equal(eng, ob.dump(), f"{name} t={t + T - 1}")
+        t += T
     while recolour and time.time() - t0 < budget:
         over = bw.done.cpu().numpy().astype(bool)
         for e in np.nonzero(over)[0]:
@@ -105,7 +130,7 @@ for name, (text, n) in maps.items():
         assert_state_equal(eng, ob.dump(), f"{name} t={t}")
         assert np.array_equal(bw.src_colour.cpu().numpy()[:, :L], colours), f"{name} t={t}: colours"
         t += 1
-    while not recolour and time.time() - t0 < budget:
+    while not recolour and not rollouts and time.time() - t0 < budget:
         if per_env and t % 48 == 0:
             redraw(bw, mirror, ob.A, L, n)
             eng = unpack_engine(bw.host_buffers(), *dims)
