@@ -449,9 +449,8 @@ const char* kernel_variant_name(int variant) {
     return names[variant & 3];
 }
 
-// step_kernel keeps the beam masks of these maps in the env's LDS record (step_kernel.hpp BM): more than 8 sources, or 5-8
-// sources with more than four agents
-static bool beams_in_lds(const MapHeader& h) { return h.L > 8 || (h.L > 4 && h.A > 4); }
+// step_kernel keeps the beam masks of these maps in the env's LDS record (step_kernel.hpp BM): more than 4 sources
+static bool beams_in_lds(const MapHeader& h) { return h.L > 4; }
 
 // `pes`: per-environment sources (the second table section in LDS, colour words in the hand-over records)
 uint32_t kernel_lds_bytes(const MapHeader& h, uint32_t waves_per_wg, bool pes) {

@@ -58,10 +58,10 @@ template <int G, int LM, int MODE, bool ML1, int LX = -1>
 __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P, LaunchArgs K) {
     constexpr bool GEN = (MODE >= 2 && MODE <= 5) || MODE == 7, ROLL = MODE >= 1 && MODE <= 3;
     constexpr bool PES = MODE == 3 || MODE == 5;  // (the launcher picks these exactly when LAUNCH_PER_ENV_SOURCES is set)
-    // More than 8 sources: the beam masks live in the env's LDS record instead of LM registers of every lane (step_lanes.hpp BM)
-    // (also 5-8 sources with more than four agents -- config 5 --: groups of 8 / 16 lanes pay the most per group reduction;
-    //  per-env-sources rollouts keep the registers: see DESIGN)
-    constexpr bool BM = (LM >= 16 || (LM == 8 && G >= 8)) && !(PES && ROLL);
+    // More than 4 sources: the beam masks live in the env's LDS record instead of LM registers of every lane (step_lanes.hpp BM;
+    // per-env-sources rollouts keep the registers: see DESIGN).  4 agents and 8 sources: state machine 11.5 -> 8.9 us, config 5
+    // (8 agents, 8 sources) 41.6 -> 20.1, 20 sources 121 -> 15.
+    constexpr bool BM = (LM >= 8) && !(PES && ROLL);
     constexpr int LR = BM ? 1 : LM;  // beam REGISTERS of a lane
     // Big rows (LAUNCH_SPLIT_ROWS, set by the launcher when private whole-row copies would leave one workgroup per CU):
     // the row is split over the wavefronts of the workgroup, see write_observations_split (obs_stream.hpp).  Only the
@@ -600,9 +600,8 @@ static hipError_t launch_step_mode_gl(const BatchPtrs& P, const LaunchArgs& K, u
 }
 template <int MODE, int G>
 static hipError_t launch_step_mode_g(int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
-    if constexpr (MODE == 6 || MODE == 7) {  // (the launcher sends maps whose beam masks live in LDS to MODE 0 / 4: row_heads_fit)
+    if constexpr (MODE == 6 || MODE == 7) {  // (the launcher sends maps whose beam masks live in LDS -- more than 4 sources -- to MODE 0 / 4)
         if (lm == 4) return launch_step_mode_gl<MODE, G, 4>(P, K, n_waves, wpw, lds, stream);
-        if constexpr (G < 8) { if (lm == 8) return launch_step_mode_gl<MODE, G, 8>(P, K, n_waves, wpw, lds, stream); }
         return hipErrorInvalidValue;
     } else {
         switch (lm) {

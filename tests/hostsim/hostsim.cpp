@@ -42,9 +42,9 @@ struct hs_batch {
 template <int AM, int LM, int G, bool ML1, bool PES, bool SHORTCUT>
 static uint32_t lanes_step_g(Env<AM, LM>& s, const uint32_t (&act)[AM], uint32_t (&avail)[AM], const MapView& mv, Events<AM>& ev, int64_t* passes) {
     constexpr int NWG = (2 * G + 7) / 8, CWM = LM / 4;
-    // like step_kernel: more than 8 sources, or 5-8 with more than four agents -> the beam masks live in the env's record
+    // like step_kernel: more than 4 sources -> the beam masks live in the env's record
     // (here: `bm`), not in lane registers
-    constexpr bool BM = LM >= 16 || (LM == 8 && G >= 8);
+    constexpr bool BM = LM >= 8;
     constexpr int LR = BM ? 1 : LM;
     static_assert(G <= AM || AM == 16, "the group is the power of two above the agent count");
     const int A = mv.A, L = mv.L;
