@@ -39,7 +39,7 @@ namespace lle {
 // MODE 6: MODE 0 for launches of one to two rounds of workgroups (kernels.hip: row_heads_pay): the rows' static head lines are
 // stored before the state machine, and every load of the kernel is issued up front (see HEAD below).  An instantiation
 // of its own: a launch without heads runs 0.2-0.4 us slower with that load order (level 1: 5.9 -> 6.1 us at 4 096 envs).
-// Only for maps whose beam masks are registers (BM below: the fill of the LDS record would be a load behind the head stores).
+// Maps with at most 8 sources (with the beam masks in LDS, BM below, this lane's share of them is read up front into registers).
 // MODE 7: the same for MODE 4 (several maps / the fused LLE.step outputs).
 // LX >= 0: the exact number of sources, known at compile time (instantiated for the default path of maps with at
 // most four sources: the per-beam loops lose their guards and the unused beam registers disappear; 0.4 us on level 6).
@@ -173,6 +173,11 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     // waited for with a vmcnt(0) that every path executes -- the sampling path right behind its store of the sampled
     // action, i.e. it would wait for that store's acknowledgement before the state machine starts.
     uint32_t act_given = 4u;
+    // HEAD && BM: the env's beam masks on their way to its LDS record (a + k * G is this lane's share), read with the rest
+    constexpr int BPL = (HEAD && BM) ? (LM + G - 1) / G : 1;
+    uint32_t bm_pre[BPL];
+#pragma unroll
+    for (int k = 0; k < BPL; k++) bm_pre[k] = 0u;
     // The wavefront's counters, likewise (kernel_common.hpp: flush_stats); the default single-step instantiations only --
     // the general ones have no registers to spare, a rollout flushes once per launch.
     constexpr bool PRE_STATS = (MODE == 0 || MODE == 6 || MODE == 7) && LM <= 8;  // (16 / 32 beam registers: already spilling; MODE 4 / 5: they spill more with it)
@@ -194,6 +199,11 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
             init_avail_a = PES ? (uint32_t)P.init_avail[env * As + a] : (uint32_t)initp->avail[a]; \
             if (!ROLL && !(K.flags & STEP_SAMPLE_ACTIONS)) \
                 act_given = K.actions_in ? (uint32_t)K.actions_in[env * A + a] : (uint32_t)P.actions[env * As + a]; \
+        } \
+        if (HEAD && BM && env_ok) { \
+        _Pragma("unroll") \
+            for (int k = 0; k < BPL; k++) \
+                if ((int)a + k * G < L) bm_pre[k] = p_beams[(int)a + k * G]; \
         } \
         init_bits = initp->bits; \
         init_gems = initp->gems; \
@@ -224,17 +234,22 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         if (lane < head_n) head_v = reinterpret_cast<const uint4*>(tables + h_off_template)[head_lo + lane];
         LLE_LOAD_STATE();
     }
+    // BM: [length masks | beams of the reset state], one copy per workgroup behind the tables; read here, ahead of the table rows
+    uint32_t bt_full = 0u, bt_init = 0u;
+    if (BM && (int)threadIdx.x < L) {
+        bt_full = hdr->beam_full[threadIdx.x];
+        bt_init = initp->beams[threadIdx.x];
+    }
     // (split rows: the pristine static observation stays in global memory, every wavefront copies its slice from there)
     const uint32_t tab_bytes = split ? hdr->lds_split_table_bytes : hdr->lds_table_bytes, tab_off = hdr->off_cell_lay;
     copy_tables_to_lds(tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
     const uint32_t ext_bytes = PES ? hdr->ext_bytes : 0u;
     if (PES) copy_tables_to_lds(tables + h_off_bare, lds + tab_bytes, ext_bytes, lane, wave_in_wg, waves_per_wg);
-    // BM: [length masks | beams of the reset state], one copy per workgroup behind the tables
     constexpr uint32_t bt_bytes = BM ? 2u * LM * 4u : 0u;
     uint32_t* beam_tab = reinterpret_cast<uint32_t*>(lds + tab_bytes + ext_bytes);
     if (BM && (int)threadIdx.x < L) {
-        beam_tab[threadIdx.x] = hdr->beam_full[threadIdx.x];
-        beam_tab[LM + threadIdx.x] = initp->beams[threadIdx.x];
+        beam_tab[threadIdx.x] = bt_full;
+        beam_tab[LM + threadIdx.x] = bt_init;
     }
     LLE_STAMP(7);
     if (HEAD) {
@@ -278,8 +293,15 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     }
     // BM: the env's beam masks go straight into its hand-over record, which phase 2 reads and the state machine updates in place
     uint32_t* const bm = scratch + grp * scr_stride + 1;
-    if (BM && env_ok)
+    if (HEAD && BM) {  // (read up front; only the LDS writes are left here, behind the head stores)
+        if (env_ok) {
+#pragma unroll
+            for (int k = 0; k < BPL; k++)
+                if ((int)a + k * G < L) bm[(int)a + k * G] = bm_pre[k];
+        }
+    } else if (BM && env_ok) {
         for (int b = (int)a; b < L; b += G) bm[b] = p_beams[b];
+    }
     wave_sync();
     // Every load of the prologue has to be back before the state machine starts anyway.  Saying so with an s_waitcnt the
     // compiler sees keeps it from carrying the loads that only some paths consume (the reset record) as pending: it
@@ -600,8 +622,9 @@ static hipError_t launch_step_mode_gl(const BatchPtrs& P, const LaunchArgs& K, u
 }
 template <int MODE, int G>
 static hipError_t launch_step_mode_g(int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
-    if constexpr (MODE == 6 || MODE == 7) {  // (the launcher sends maps whose beam masks live in LDS -- more than 4 sources -- to MODE 0 / 4)
+    if constexpr (MODE == 6 || MODE == 7) {  // (the launcher sends maps with more than 8 sources to MODE 0 / 4)
         if (lm == 4) return launch_step_mode_gl<MODE, G, 4>(P, K, n_waves, wpw, lds, stream);
+        if (lm == 8) return launch_step_mode_gl<MODE, G, 8>(P, K, n_waves, wpw, lds, stream);
         return hipErrorInvalidValue;
     } else {
         switch (lm) {

@@ -14,12 +14,24 @@ pytestmark = pytest.mark.gpu
 MAPS = dict({f"level{k}": v for k, v in LEVELS.items()}, **EXTRA_MAPS)
 
 
+def _generated():
+    """Maps with 5-8 sources: their beam masks live in the LDS record AND they have row heads (the lane's share of the masks is
+    read up front, ahead of the head stores)."""
+    from lle_amd import mapgen
+    return {"gen_12x13_4agents_8lasers": mapgen.generate(12, 13, 4, 8, 4, seed=2), "gen_12x13_2agents_8lasers": mapgen.generate(12, 13, 2, 8, 4, seed=2),
+            "gen_12x13_1agent_6lasers": mapgen.generate(12, 13, 1, 6, 2, seed=5)}
+
+
+MAPS.update(_generated())
+
+
 @pytest.fixture
 def heads_forced(monkeypatch):
     monkeypatch.setenv("LLE_ROW_HEADS", "1")
 
 
-@pytest.mark.parametrize("name", ["level1", "level2", "level3", "level5", "level6", "nested", "colour_alias", "gen_16x16_12agents"])
+@pytest.mark.parametrize("name", ["level1", "level2", "level3", "level5", "level6", "nested", "colour_alias", "gen_16x16_12agents",
+                                  "gen_12x13_4agents_8lasers", "gen_12x13_2agents_8lasers", "gen_12x13_1agent_6lasers"])
 @pytest.mark.parametrize("lines", [-1, 1, 4, 8])
 def test_heads_match_oracle(oracle_mod, heads_forced, name, lines):
     from lle_amd import BatchedWorld, Map

@@ -26,15 +26,18 @@ from tests.test_gpu_multi_map import test_blocks_of_maps_match_their_oracles  # 
 from tests.test_gpu_parity import test_explicit_and_invalid_actions, test_random_rollout, test_reward_counts_and_snapshot  # noqa: E402,F401
 
 
-def test_fused_step_outputs_with_heads_equal_two_launches():
-    """BatchedLLE.step(fused=True) (one launch, MODE 7 here) against the two-launch path, level 6, every output."""
+@pytest.mark.parametrize("name", ["level6", "gen_12x13_4agents_8lasers"])
+def test_fused_step_outputs_with_heads_equal_two_launches(name):
+    """BatchedLLE.step(fused=True) (one launch, MODE 7 here) against the two-launch path, every output; the generated map
+    has 8 sources: beam masks in the LDS record, this lane's share read ahead of the head stores."""
     import torch
 
-    from lle_amd import BatchedLLE
+    from lle_amd import BatchedLLE, mapgen
     from oracle.levels import LEVELS
 
+    text = LEVELS[6] if name == "level6" else mapgen.generate(12, 13, 4, 8, 4, seed=2)
     n = 3000
-    a, b = BatchedLLE(LEVELS[6], n), BatchedLLE(LEVELS[6], n)
+    a, b = BatchedLLE(text, n), BatchedLLE(text, n)
     a.reset(), b.reset()
     g = torch.Generator(device="cuda").manual_seed(5)
     for t in range(30):
