@@ -66,6 +66,9 @@ def redraw(bw, mirror, A, L, n):
 maps = {f"level{k}": (v, 32768) for k, v in LEVELS.items()}
 maps.update({k: (v, 8192) for k, v in EXTRA_MAPS.items()})
 maps["config5"] = (mapgen.config5(0), 4096)
+# 5-8 sources with few agents: beam masks in the LDS record AND row heads (32 768 envs = 2 048 wavefronts: heads on)
+maps["gen_12x13_4agents_8lasers"] = (mapgen.generate(12, 13, 4, 8, 4, seed=2), 32768)
+maps["gen_12x13_2agents_8lasers"] = (mapgen.generate(12, 13, 2, 8, 4, seed=2), 65536)
 if full_size:
     maps = {"cfg2 level1 x 4096": (LEVELS[1], 4096), "cfg3 level6 x 65536": (LEVELS[6], 65536), "level6 x 262144": (LEVELS[6], 262144),
             "cfg5 32x32 x 65536": (mapgen.config5(0), 65536)}
