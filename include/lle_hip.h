@@ -116,6 +116,19 @@ int lle_map_sources(const lle_map* map, lle_source_info* out, int cap);
 /* LaserSource.enable/disable/set_agent_id (src/core/tiles/laser_source.rs:37-47).  -1 = leave unchanged.
  * Only changes the host object: call lle_batch_update_sources() to push it to a live batch. */
 int lle_map_set_source(lle_map* map, int laser_id, int enabled, int agent_id);
+/* World.exit_pos = [...] (setter: src/bindings/world/pyworld.rs:203-209 -> World::set_exit_positions,
+ * src/core/world.rs:195-234): the current exits become Floor tiles and the `n_exits` given (i, j) cells Exit tiles -- under a
+ * beam the innermost tile of the Laser stack is swapped (Laser::set_tile, src/core/tiles/laser.rs:109-115).  The occupant of
+ * a swapped tile stays, agents keep their `arrived` flags: no dynamic state changes.  The list is kept as given (order,
+ * duplicates under a beam) and is what lle_map_positions(LLE_POS_EXIT) returns from now on.
+ *   fewer exits than agents  -> LLE_ERR_ARG, *parse_error = LLE_PARSE_NOT_ENOUGH_EXIT_TILES (ParseError::NotEnoughExitTiles)
+ *   a cell that is not a Floor (wall, source, gem, void, the same direct cell twice), a gem under a beam, a position out of the
+ *   world -> LLE_ERR_ARG with *parse_error = 0 and the reason in lle_last_error().  The reference PANICS there, half way
+ *   through the swap, which poisons the world's mutex for good (pyworld.rs:205 `lock().unwrap()`); here the map is untouched.
+ * Only changes the host object: call lle_batch_update_map() to push it to a live batch. */
+int lle_map_set_exits(lle_map* map, const int32_t* exits_ij, int n_exits, int* parse_error);
+/* An independent copy of a map (sources, exits, row alignment and head lines included). */
+lle_map* lle_map_clone(const lle_map* map);
 /* 1 if source `laser_id` may take colour `agent_id` without a possible start of another agent on its beam (the check of
  * the binding's LaserSource.set_colour, src/bindings/tiles/pylaser_source.rs:121-139), 0 if not, negative on bad arguments. */
 int lle_map_colour_allowed(const lle_map* map, int laser_id, int agent_id);
@@ -262,6 +275,15 @@ int lle_batch_set_state(lle_batch* b, void* stream);
 /* Push the map's current source colours / enabled flags to the device tables and apply
  * LaserBeam::enable/disable (laser.rs:69-77) to the beam masks of every env; rewrites the observation. */
 int lle_batch_update_sources(lle_batch* b, const lle_map* map, void* stream);
+
+/* Push another compilation of map `map_index` of the batch (0 for a one-map batch) to the device: the same map after
+ * lle_map_set_exits and / or lle_map_set_source.  The tables (cell kinds, static observation with its EXIT plane, row head)
+ * and the reset state of the map's envs follow -- an agent whose start is an exit now arrives at reset, world.rs:411-432 --,
+ * the dynamic state of live envs does not (world.rs:195-234 keeps occupants and flags), LLE_BUF_OBS is rewritten.  With
+ * per-environment sources every env keeps ITS colours / flags and gets its reset state recomputed; the map's own source
+ * colours / flags must then be unchanged (likewise in a batch of several maps), else LLE_ERR_ARG.  LLE_ERR_ARG too when the
+ * map is not a recompilation of the batch's map (other tiles, other row pitch). */
+int lle_batch_update_map(lle_batch* b, int map_index, const lle_map* map, void* stream);
 
 /* Per-ENVIRONMENT sources: what LLE.reset does with randomize_lasers (python/lle/env/env.py:198-200:
  * `source.set_colour(random.randint(0, n_agents - 1))`) and LaserSource.enable / disable, for every env at once.

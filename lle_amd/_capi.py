@@ -37,9 +37,9 @@ PARSE_ERROR_NAMES = {
 EXPORTS = [
     "lle_abi_version", "lle_last_status", "lle_last_error", "lle_action_hash",
     "lle_map_parse", "lle_map_level", "lle_map_free", "lle_map_get_info", "lle_map_positions", "lle_map_sources",
-    "lle_map_set_source", "lle_map_colour_allowed", "lle_map_reset_beam", "lle_map_set_row_align", "lle_map_set_head_lines", "lle_map_row_head", "lle_map_laser_tiles", "lle_map_world_string",
+    "lle_map_set_source", "lle_map_set_exits", "lle_map_clone", "lle_map_colour_allowed", "lle_map_reset_beam", "lle_map_set_row_align", "lle_map_set_head_lines", "lle_map_row_head", "lle_map_laser_tiles", "lle_map_world_string",
     "lle_batch_arena_bytes", "lle_batch_create", "lle_batch_arena_bytes_multi", "lle_batch_create_multi", "lle_batch_n_maps", "lle_batch_free", "lle_batch_get_buffer", "lle_batch_n_envs",
-    "lle_batch_reset", "lle_batch_step", "lle_batch_rollout", "lle_batch_set_state", "lle_batch_update_sources", "lle_batch_observe",
+    "lle_batch_reset", "lle_batch_step", "lle_batch_rollout", "lle_batch_set_state", "lle_batch_update_sources", "lle_batch_update_map", "lle_batch_observe",
     "lle_batch_snapshot_bytes", "lle_batch_snapshot", "lle_batch_restore",
     "lle_batch_set_sources", "lle_batch_reset_sources", "lle_batch_obs_desc", "lle_batch_observe_as", "lle_batch_available_actions", "lle_batch_env_outputs", "lle_batch_step_outputs",
     "lle_batch_stats", "lle_batch_kernel_info", "lle_batch_set_envs_per_wave", "lle_batch_step_stamped",
@@ -120,6 +120,10 @@ def lib():
     L.lle_map_sources.argtypes = [vp, C.POINTER(SourceInfo), i32]
     L.lle_map_set_source.restype = i32
     L.lle_map_set_source.argtypes = [vp, i32, i32, i32]
+    L.lle_map_set_exits.restype = i32
+    L.lle_map_set_exits.argtypes = [vp, C.POINTER(C.c_int32), i32, C.POINTER(C.c_int)]
+    L.lle_map_clone.restype = vp
+    L.lle_map_clone.argtypes = [vp]
     L.lle_map_colour_allowed.restype = i32
     L.lle_map_colour_allowed.argtypes = [vp, i32, i32]
     L.lle_map_set_row_align.restype = i32
@@ -165,6 +169,8 @@ def lib():
     L.lle_batch_set_state.argtypes = [vp, vp]
     L.lle_batch_update_sources.restype = i32
     L.lle_batch_update_sources.argtypes = [vp, vp, vp]
+    L.lle_batch_update_map.restype = i32
+    L.lle_batch_update_map.argtypes = [vp, i32, vp, vp]
     L.lle_batch_observe.restype = i32
     L.lle_batch_observe.argtypes = [vp, vp]
     L.lle_batch_set_sources.restype = i32
@@ -205,11 +211,14 @@ class MapParseError(ValueError):
 class Map:
     """Host-side compiled map (lle_map*).  Needs no GPU."""
 
-    def __init__(self, text=None, level=None, row_align=None):
-        """`row_align`: pitch of an observation row in bytes (lle_map_set_row_align; default 16, 128 = one cache line)."""
+    def __init__(self, text=None, level=None, row_align=None, _handle=None):
+        """`row_align`: pitch of an observation row in bytes (lle_map_set_row_align; default 0 = automatic: whole 128-byte
+        lines when that pads the row by at most 1/32 -- level 6: 1 872 -> 1 920 B --, 16 otherwise)."""
         L = lib()
         err = C.c_int(0)
-        if level is not None:
+        if _handle is not None:
+            self.h = _handle
+        elif level is not None:
             self.h = L.lle_map_level(int(level), C.byref(err))
         else:
             data = text.encode()
@@ -234,6 +243,28 @@ class Map:
             except Exception:  # noqa: BLE001  (interpreter shutdown)
                 pass
             self.h = None
+
+    def clone(self):
+        """An independent copy (lle_map_clone): sources, exits, row alignment and head lines included."""
+        h = lib().lle_map_clone(self.h)
+        if not h:
+            raise MemoryError("lle_map_clone failed")
+        return Map(_handle=h)
+
+    def set_exits(self, exits):
+        """World::set_exit_positions on the host object (lle_map_set_exits).  Raises MapParseError("NotEnoughExitTiles") or
+        ValueError (a cell where the reference panics); the map is untouched then."""
+        flat = [int(v) for p in exits for v in p]
+        if len(flat) != 2 * len(exits):
+            raise ValueError("exit positions are (i, j) pairs")
+        buf = (C.c_int32 * max(len(flat), 1))(*flat)
+        err = C.c_int(0)
+        rc = lib().lle_map_set_exits(self.h, buf, len(exits), C.byref(err))
+        if rc != 0:
+            if err.value:
+                raise MapParseError(err.value)
+            raise ValueError(lib().lle_last_error().decode())
+        self.refresh()
 
     def positions(self, which):
         n = lib().lle_map_positions(self.h, which, None, 0)

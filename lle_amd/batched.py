@@ -43,7 +43,8 @@ class BatchedWorld:
         _require_gpu()
         many = isinstance(map_or_text, (list, tuple))
         self.maps = [m if isinstance(m, Map) else Map(m) for m in (map_or_text if many else [map_or_text])]
-        if row_align is not None:
+        if row_align is not None:  # on copies: the caller's Map objects keep their pitch (a live batch elsewhere may hold them)
+            self.maps = [m.clone() for m in self.maps]
             for m in self.maps:
                 m.set_row_align(row_align)
         self.map = self.maps[0]  # common dimensions
@@ -236,6 +237,16 @@ class BatchedWorld:
     def update_sources(self):
         """Push self.map's current source colours / enabled flags to the device (LaserSource.enable/disable/set_colour)."""
         self._check(_capi.lib().lle_batch_update_sources(self.h, self.map.h, self._stream()))
+
+    def update_map(self, map_index=0):
+        """Push self.maps[map_index] to the device after Map.set_exits (World.exit_pos = ...) or Map.set_source: tables,
+        reset states and the observation follow, the dynamic state of live envs stays (lle_batch_update_map)."""
+        self._check(_capi.lib().lle_batch_update_map(self.h, int(map_index), self.maps[map_index].h, self._stream()))
+
+    def set_exits(self, exits, map_index=0):
+        """World.exit_pos = exits for every env of map `map_index` (src/core/world.rs:195-234)."""
+        self.maps[map_index].set_exits(exits)
+        self.update_map(map_index)
 
     def set_sources(self, colours=None, enabled=None, env_mask=None, reset_first=False, write_obs=True):
         """Per-environment laser sources (LLE.reset with randomize_lasers, python/lle/env/env.py:198-200; LaserSource

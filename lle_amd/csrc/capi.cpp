@@ -208,6 +208,30 @@ int lle_map_set_source(lle_map* map, int laser_id, int enabled, int agent_id) {
     return LLE_OK;
 }
 
+int lle_map_set_exits(lle_map* map, const int32_t* exits_ij, int n_exits, int* parse_error) {
+    if (parse_error) *parse_error = LLE_PARSE_OK;
+    if (!map || (!exits_ij && n_exits > 0)) return fail(LLE_ERR_NULL, "NULL argument");
+    if (n_exits < 0) return fail(LLE_ERR_ARG, "n_exits is negative");
+    std::vector<Pos> ex((size_t)n_exits);
+    for (int k = 0; k < n_exits; k++) ex[(size_t)k] = Pos{exits_ij[2 * k], exits_ij[2 * k + 1]};
+    std::string why;
+    const int rc = map->m.set_exits(ex, why);
+    if (rc == LLE_PARSE_NOT_ENOUGH_EXIT_TILES) {
+        if (parse_error) *parse_error = rc;
+        return fail(LLE_ERR_ARG, "Not enough exit tiles: " + std::to_string(map->m.n_agents()) + " starts, " + std::to_string(n_exits) + " exits");
+    }
+    if (rc != LLE_PARSE_OK) return fail(LLE_ERR_ARG, why);
+    g_status = LLE_OK;
+    return LLE_OK;
+}
+
+lle_map* lle_map_clone(const lle_map* map) {
+    if (!map) { fail(LLE_ERR_NULL, "NULL map"); return nullptr; }
+    lle_map* m = new (std::nothrow) lle_map(*map);
+    if (m) g_status = LLE_OK;
+    return m;
+}
+
 int lle_map_colour_allowed(const lle_map* map, int laser_id, int agent_id) {
     if (!map) return fail(LLE_ERR_NULL, "NULL map");
     const Map& m = map->m;
@@ -528,7 +552,8 @@ int lle_batch_get_buffer(const lle_batch* b, int which, lle_buffer_desc* out) {
 // the dynamic state is the contiguous arena range [pos, actions): pos, bits, gems, beams, avail; followed in a snapshot
 // by the per-env sources and reset states (meaningful once lle_batch_set_sources has been called)
 static int64_t state_bytes(const lle_batch* b) { return b->layout.off[LLE_BUF_ACTIONS] - b->layout.off[LLE_BUF_POS]; }
-static int64_t sources_bytes(const lle_batch* b) { return b->layout.total - b->layout.off[LLE_BUF_SRC_COLOUR]; }
+// (up to, not including, the device mirror of the EnvOutputs descriptor of lle_batch_step_outputs: pointers are not state)
+static int64_t sources_bytes(const lle_batch* b) { return b->layout.off_env_out - b->layout.off[LLE_BUF_SRC_COLOUR]; }
 int64_t lle_batch_snapshot_bytes(const lle_batch* b) {
     if (!b) return fail(LLE_ERR_NULL, "NULL batch");
     return state_bytes(b) + sources_bytes(b) + 256;
@@ -559,6 +584,7 @@ int lle_batch_restore(lle_batch* b, const void* src_dev, void* stream) {
     if (b->per_env_sources)
         HIP_TRY(hipMemcpyAsync(b->arena + b->layout.off[LLE_BUF_SRC_COLOUR], src + 256 + state_bytes(b), (size_t)sources_bytes(b),
                                hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    b->env_out_valid = false;  // (belt and braces: the next lle_batch_step_outputs uploads its descriptor again)
     LaunchArgs K{};
     return launch(b, KMODE_OBSERVE, K, stream);  // bring the observation in line with the restored state
 }
@@ -865,30 +891,80 @@ int lle_batch_env_outputs(lle_batch* b, const lle_env_outputs* out, void* stream
     return LLE_OK;
 }
 
+// A live batch takes another compilation of one of its maps: the sources' colours / flags (lle_map_set_source) and the
+// exits (lle_map_set_exits) may differ, nothing else.  `broadcast`: with per-environment sources every env takes the map's
+// sources (lle_batch_update_sources); otherwise every env keeps its own and only its reset state is recomputed.
+static int push_map(lle_batch* b, int map_index, const lle_map* map, bool broadcast, void* stream) {
+    if (!b || !map) return fail(LLE_ERR_NULL, "NULL argument");
+    if (map_index < 0 || map_index >= (int)b->maps.size()) return fail(LLE_ERR_ARG, "map_index out of range");
+    const MapHeader& nh = map->m.header;
+    const MapHeader& oh = b->maps[(size_t)map_index].header;
+    if (nh.H != oh.H || nh.W != oh.W || nh.A != oh.A || nh.L != oh.L || nh.G != oh.G || nh.blob_capacity != oh.blob_capacity ||
+        nh.blob_bytes > nh.blob_capacity || nh.ext_bytes != oh.ext_bytes)
+        return fail(LLE_ERR_ARG, "map does not match the batch");
+    // the rows of LLE_BUF_OBS keep the pitch the batch was created with (lle_map_set_row_align after lle_batch_create)
+    if (nh.obs_stride != oh.obs_stride || nh.n_chunks != oh.n_chunks)
+        return fail(LLE_ERR_ARG, "the map's row alignment differs from the batch's (lle_map_set_row_align: a live batch keeps the pitch it was created with)");
+    for (size_t s = 0; s < map->m.sources.size(); s++) {
+        const Source &a = map->m.sources[s], &o = b->maps[(size_t)map_index].sources[s];
+        if (!(a.pos == o.pos) || a.direction != o.direction || a.beam.size() != o.beam.size()) return fail(LLE_ERR_ARG, "map does not match the batch (another map's sources)");
+    }
+    if (map->m.kind.size() != b->maps[(size_t)map_index].kind.size()) return fail(LLE_ERR_ARG, "map does not match the batch");
+    for (size_t c = 0; c < map->m.kind.size(); c++) {  // walls, voids, gems and sources stay where they are; floor <-> exit may swap
+        const uint8_t a = map->m.kind[c], o = b->maps[(size_t)map_index].kind[c];
+        const bool swap_ok = (a == K_FLOOR || a == K_EXIT || a == K_VOID) && (o == K_FLOOR || o == K_EXIT || o == K_VOID);
+        if (a != o && !swap_ok) return fail(LLE_ERR_ARG, "map does not match the batch (another map's tiles)");
+    }
+    HIP_TRY(hipSetDevice(b->device));
+    LaunchArgs K{};
+    K.old_enabled = oh.enabled_mask;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(b->arena + b->layout.off_tables + (int64_t)map_index * b->layout.table_stride, map->m.blob.data(),
+                           map->m.blob.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    b->maps[(size_t)map_index] = map->m;
+    if (b->maps.size() == 1) {
+        b->hdr = nh;
+    } else {  // the common header carries the largest table sizes of the batch's maps
+        std::vector<lle_map> tmp(b->maps.size());
+        std::vector<const lle_map*> ptrs;
+        for (size_t m = 0; m < b->maps.size(); m++) { tmp[m].m = b->maps[m]; ptrs.push_back(&tmp[m]); }
+        int rc = common_header(ptrs.data(), (int)ptrs.size(), &b->hdr, &b->worst_table_bytes);
+        if (rc != LLE_OK) return rc;
+    }
+    drop_views(b);  // their tables depend on the colours and the exits (the stream is idle: synchronised above)
+    int rc = refresh_init_record(b, stream);
+    if (rc != LLE_OK) return rc;
+    if (b->per_env_sources) {
+        // every env's own reset state follows the new tables; broadcast: and every env takes the map's sources
+        // (enable / disable applied per env, where the flag changes)
+        if (broadcast) K.flags = LAUNCH_FILL_DEFAULTS;
+        return launch(b, KMODE_ENV_SOURCES, K, stream);
+    }
+    // one map: applies enable / disable where a flag changed; both rewrite the observation
+    return launch(b, b->maps.size() == 1 ? KMODE_SOURCES : KMODE_OBSERVE, K, stream);
+}
+
 int lle_batch_update_sources(lle_batch* b, const lle_map* map, void* stream) {
     if (!b || !map) return fail(LLE_ERR_NULL, "NULL argument");
     if (b->maps.size() != 1)
         return fail(LLE_ERR_UNSUPPORTED, "lle_batch_update_sources serves one-map batches; use lle_batch_set_sources per environment");
-    const MapHeader& nh = map->m.header;
-    if (nh.H != b->hdr.H || nh.W != b->hdr.W || nh.A != b->hdr.A || nh.L != b->hdr.L || nh.G != b->hdr.G ||
-        nh.blob_capacity != b->hdr.blob_capacity || nh.blob_bytes > nh.blob_capacity)
-        return fail(LLE_ERR_ARG, "map does not match the batch");
-    HIP_TRY(hipSetDevice(b->device));
-    LaunchArgs K{};
-    K.old_enabled = b->hdr.enabled_mask;
-    hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipMemcpyAsync(b->arena + b->layout.off_tables, map->m.blob.data(), map->m.blob.size(), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    b->hdr = nh;
-    b->maps[0] = map->m;
-    drop_views(b);  // their channel tables depend on the colours (the stream is idle: synchronised above)
-    int rc = refresh_init_record(b, stream);
-    if (rc != LLE_OK) return rc;
-    if (b->per_env_sources) {  // broadcast the map's sources to every env (enable / disable applied per env)
-        K.flags = LAUNCH_FILL_DEFAULTS;
-        return launch(b, KMODE_ENV_SOURCES, K, stream);
+    return push_map(b, 0, map, true, stream);
+}
+
+int lle_batch_update_map(lle_batch* b, int map_index, const lle_map* map, void* stream) {
+    if (!b || !map) return fail(LLE_ERR_NULL, "NULL argument");
+    if (map_index < 0 || map_index >= (int)b->maps.size()) return fail(LLE_ERR_ARG, "map_index out of range");
+    // per-environment sources are kept: the map's source colours / flags must then be the ones the batch was last told about;
+    // likewise in a batch of several maps (the enable / disable pass below compares ONE pair of masks for every env)
+    if (b->per_env_sources || b->maps.size() > 1) {
+        const Map& cur = b->maps[(size_t)map_index];
+        for (size_t s = 0; s < cur.sources.size() && s < map->m.sources.size(); s++)
+            if (cur.sources[s].agent_id != map->m.sources[s].agent_id || cur.sources[s].enabled != map->m.sources[s].enabled)
+                return fail(LLE_ERR_ARG, "lle_batch_update_map: with per-environment sources or several maps the map's source colours / flags must be "
+                                         "unchanged (use lle_batch_update_sources to broadcast, lle_batch_set_sources per environment)");
     }
-    return launch(b, KMODE_SOURCES, K, stream);
+    return push_map(b, map_index, map, false, stream);
 }
 
 int lle_batch_stats(lle_batch* b, int64_t out[8], int reset_counters, void* stream) {

@@ -325,6 +325,8 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
             }
         } else {
             store_state = false;
+            // (MODE_OBSERVE: `done` is a function of the state; lle_batch_restore rebuilds it here together with the observation)
+            if (MODE == MODE_OBSERVE) P.done[env] = ((s.alive | ghost) != amask || s.arrived == amask) ? 1 : 0;
         }
 
         LLE_STAMP(3);

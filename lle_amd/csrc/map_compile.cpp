@@ -533,6 +533,42 @@ void Map::compile() {
     header = h;
 }
 
+// World::set_exit_positions, src/core/world.rs:195-234.  The reference swaps tile objects: `Exit{agent}` -> `Floor{agent}`
+// for every current exit, then `Floor{agent}` -> `Exit{agent}` for every new one; under a beam `Laser::set_tile`
+// (laser.rs:109-115) replaces the INNERMOST tile whatever it is.  Here the innermost tile is `kind[cell]` and the
+// occupant is dynamic state (one bit per agent), so the swap is a change of `kind` and nothing else.
+int Map::set_exits(const std::vector<Pos>& new_exits, std::string& why) {
+    if ((int)new_exits.size() < n_agents()) return LLE_PARSE_NOT_ENOUGH_EXIT_TILES;  // :196-201
+    std::vector<uint8_t> k = kind;
+    // :203-216 -- a current exit is `Tile::Exit` or a `Tile::Laser` (whose innermost tile becomes Floor); anything else
+    // panics, which the parser and this function never leave behind
+    for (const Pos& q : exits) k[q.i * W + q.j] = K_FLOOR;
+    // :219-232
+    for (const Pos& q : new_exits) {
+        if (q.i < 0 || q.j < 0 || q.i >= H || q.j >= W) {
+            why = "exit position (" + std::to_string(q.i) + ", " + std::to_string(q.j) + ") is out of the world (the reference panics)";
+            return -1;
+        }
+        const int c = q.i * W + q.j;
+        if (cell_layers[c].empty()) {
+            if (k[c] != K_FLOOR) {  // `other => panic!("Tile is not a floor")`: wall, source, gem, void, or an exit given twice
+                why = "tile (" + std::to_string(q.i) + ", " + std::to_string(q.j) + ") is not a floor (the reference panics)";
+                return -1;
+            }
+        } else if (k[c] == K_GEM) {
+            // Laser::set_tile would replace the gem by the exit without a word; World::gems() (world.rs:128-139) then
+            // unwraps None on its next call.  Refused here.
+            why = "tile (" + std::to_string(q.i) + ", " + std::to_string(q.j) + ") holds a gem under a laser (the reference drops the gem and panics later)";
+            return -1;
+        }
+        k[c] = K_EXIT;  // (under a beam: whatever was innermost -- floor, a void -- is replaced, laser.rs:109-115)
+    }
+    kind = std::move(k);
+    exits = new_exits;
+    compile();
+    return LLE_PARSE_OK;
+}
+
 std::string Map::world_string() const {
     // parser_v1.rs:100-130
     std::vector<std::vector<std::string>> res(H, std::vector<std::string>(W, " . "));

@@ -86,6 +86,13 @@ struct Map {
     void compile();             // (re)builds header + blob from the fields above
 
     std::string world_string() const;  // parser_v1.rs:100-130 to_v1_string
+
+    // World::set_exit_positions (src/core/world.rs:195-234): the current exits become Floor, the given cells Exit; the
+    // occupant of a tile survives the swap, so nothing dynamic changes.  Returns LLE_PARSE_OK,
+    // LLE_PARSE_NOT_ENOUGH_EXIT_TILES (fewer exits than agents, :196-201), or -1 with `why` set where the reference
+    // PANICS half way through the swap (`other => panic!`, :213,230; an index out of the grid): there the map is left
+    // untouched instead.  Recompiles the tables.
+    int set_exits(const std::vector<Pos>& new_exits, std::string& why);
 };
 
 // Returns LLE_PARSE_* (0 = ok).

@@ -357,7 +357,7 @@ class World:
         self._batch_obj = None
         m = _map
         self.height, self.width, self.n_agents, self.n_gems = m.height, m.width, m.n_agents, m.n_gems
-        self.exit_pos = m.positions(LLE_POS_EXIT)
+        self._exit_pos = m.positions(LLE_POS_EXIT)
         self.wall_pos = m.positions(LLE_POS_WALL)
         self.void_pos = m.positions(LLE_POS_VOID)
         self.start_pos = m.positions(LLE_POS_START)
@@ -386,12 +386,47 @@ class World:
         with open(filename) as f:
             return World(f.read())
 
+    def save(self, filename):
+        """Save the world configuration to the given file (pyworld.rs:183-193: `world_string` written as is)."""
+        try:
+            with open(filename, "w") as f:
+                f.write(self.world_string)
+        except OSError as e:
+            raise ValueError(f"Could not write to file: {filename}: {e}") from None
+
+    @property
+    def exit_pos(self):
+        """The (i, j) position of each exit (pyworld.rs:46-56)."""
+        return self._exit_pos
+
+    @exit_pos.setter
+    def exit_pos(self, exit_pos):
+        """World::set_exit_positions (src/core/world.rs:195-234) through the setter of the binding (pyworld.rs:203-209): the
+        current exits become floor tiles, the given cells exits -- also under a laser --, whoever stands on a swapped tile stays
+        there and nobody's `has_arrived` changes.  Fewer exits than agents: ParsingError (NotEnoughExitTiles), world untouched.
+        A cell that is not a floor (wall, laser source, gem, void, the same cell twice) or out of the world: the reference
+        PANICS half way through the swap and leaves a poisoned world behind; here it is a ValueError and the world is untouched."""
+        pos = [tuple(int(v) for v in p) for p in exit_pos]
+        if any(v < 0 for p in pos for v in p):
+            raise OverflowError("can't convert negative int to unsigned")
+        try:
+            self._map.set_exits(pos)
+        except MapParseError as e:
+            err = ParsingError(f"Not enough exit tiles: {self.n_agents} starts, {len(pos)} exits" if e.kind == "NotEnoughExitTiles"
+                               else _PARSE_MESSAGES.get(e.kind, e.kind))
+            err.kind = e.kind
+            raise err from None
+        self._exit_pos = pos
+        if self._batch_obj is not None:
+            self._batch_obj.update_map()
+
     # ---- device batch (lazy: parsing needs no GPU, dynamics do)
     @property
     def _batch(self):
         if self._batch_obj is None:
             from .batched import BatchedWorld
             self._batch_obj = BatchedWorld(self._map, 1, device=self._device)  # creation resets (World::new, world.rs:82)
+            self._map = self._batch_obj.map  # (the batch may hold a copy: mutators go through the object it pushes from)
         return self._batch_obj
 
     def _state(self):

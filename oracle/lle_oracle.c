@@ -777,6 +777,61 @@ int ow_tile_agent(ow_world* w, int i, int j) {
 void ow_source_set_enabled(ow_world* w, int laser_id, int enabled) { if (enabled) beam_enable(w->beams[laser_id]); else beam_disable(w->beams[laser_id]); }
 void ow_source_set_agent_id(ow_world* w, int laser_id, int agent_id) { w->beams[laser_id]->agent_id = agent_id; }
 
+/* ---------------------------------------------------------------- World::set_exit_positions (world.rs:195-234)
+ * laser.rs:109-115 Laser::set_tile: replaces the INNERMOST wrapped tile, whatever it is */
+static void laser_set_tile(tile_t* l, tile_kind kind, int agent) {
+    if (l->wrapped->kind == T_LASER) { laser_set_tile(l->wrapped, kind, agent); return; }
+    free(l->wrapped);
+    l->wrapped = new_tile(kind);
+    l->wrapped->agent = agent;
+}
+/* Returns OW_OK, OW_ERR_NOT_ENOUGH_EXITS (:196-201), or -1 where the reference panics (`other => panic!`, an index out
+ * of the grid).  The reference panics HALF WAY through the swap; the checks are made up front here so that the world
+ * stays usable, which is also what the product does (include/lle_hip.h lle_map_set_exits). */
+int ow_set_exits(ow_world* w, const int32_t* exits_ij, int n_exits) {
+    if (n_exits < w->n_agents) return OW_ERR_NOT_ENOUGH_EXITS;
+    int W = w->width, H = w->height;
+    /* dry run of the two loops on a copy of the innermost kinds: does a `panic!` arm fire? */
+    tile_kind* inner = (tile_kind*)malloc(sizeof *inner * (size_t)(H * W));
+    for (int c = 0; c < H * W; c++) { tile_t* t = w->grid[c]; while (t->kind == T_LASER) t = t->wrapped; inner[c] = t->kind; }
+    int bad = 0;
+    for (int k = 0; k < w->n_exits; k++) {
+        int c = w->exits[k].i * W + w->exits[k].j;
+        if (w->grid[c]->kind != T_LASER && inner[c] != T_EXIT) bad = 1;   /* "Tile is not an exit" */
+        inner[c] = T_FLOOR;
+    }
+    for (int k = 0; k < n_exits && !bad; k++) {
+        int i = exits_ij[2 * k], j = exits_ij[2 * k + 1];
+        if (i < 0 || j < 0 || i >= H || j >= W) { bad = 1; break; }       /* Vec index out of bounds */
+        int c = i * W + j;
+        if (w->grid[c]->kind != T_LASER) { if (inner[c] != T_FLOOR) bad = 1; }  /* "Tile is not a floor" */
+        else if (inner[c] == T_GEM) bad = 1;  /* the gem would be dropped: World::gems() unwraps None afterwards (world.rs:128-139) */
+        inner[c] = T_EXIT;
+    }
+    free(inner);
+    if (bad) return -1;
+    /* :203-216 Replace current exits by floor tiles */
+    for (int k = 0; k < w->n_exits; k++) {
+        tile_t** slot = &w->grid[w->exits[k].i * W + w->exits[k].j];
+        tile_t* t = *slot;
+        if (t->kind == T_EXIT) { int agent = t->agent; free(t); *slot = new_tile(T_FLOOR); (*slot)->agent = agent; }
+        else if (t->kind == T_LASER) laser_set_tile(t, T_FLOOR, tile_agent(t));   /* Floor { agent: laser.agent() } */
+    }
+    /* :218 self.exits = exits */
+    free(w->exits);
+    w->exits = (pos_t*)malloc(sizeof(pos_t) * (size_t)(n_exits + 1));
+    w->n_exits = n_exits;
+    for (int k = 0; k < n_exits; k++) { w->exits[k].i = exits_ij[2 * k]; w->exits[k].j = exits_ij[2 * k + 1]; }
+    /* :219-232 Set new exits */
+    for (int k = 0; k < n_exits; k++) {
+        tile_t** slot = &w->grid[w->exits[k].i * W + w->exits[k].j];
+        tile_t* t = *slot;
+        if (t->kind == T_FLOOR) { int agent = t->agent; free(t); *slot = new_tile(T_EXIT); (*slot)->agent = agent; }
+        else if (t->kind == T_LASER) laser_set_tile(t, T_EXIT, tile_agent(t));    /* Exit { agent: laser.agent() } */
+    }
+    return OW_OK;
+}
+
 /* ---------------------------------------------------------------- layered observation
  * python/lle/observations.py:200-214 (channel layout), :216-237 (_setup, static), :254-266 (observe).
  * Values are {-1,0,1}; stored as int8.  One (C,H,W) slice (the reference tiles it A times).

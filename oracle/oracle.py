@@ -78,6 +78,8 @@ def lib():
         L.ow_lasers.argtypes = [vp, pi32, i32]
         L.ow_tile_agent.restype = i32
         L.ow_tile_agent.argtypes = [vp, i32, i32]
+        L.ow_set_exits.restype = i32
+        L.ow_set_exits.argtypes = [vp, pi32, i32]
         L.ow_source_set_enabled.argtypes = [vp, i32, i32]
         L.ow_source_set_agent_id.argtypes = [vp, i32, i32]
         L.ow_layered_obs.restype = i32
@@ -255,6 +257,15 @@ class OracleWorld:
             self.L.ow_source_set_enabled(self.h, laser_id, int(enabled))
         if colour is not None:
             self.L.ow_source_set_agent_id(self.h, laser_id, int(colour))
+
+    def set_exits(self, exits):
+        """World::set_exit_positions (world.rs:195-234)."""
+        flat = [int(v) for p in exits for v in p]
+        rc = self.L.ow_set_exits(self.h, (C.c_int32 * max(len(flat), 1))(*flat), len(exits))
+        if rc > 0:
+            raise OracleError(PARSE_ERRORS[rc])
+        if rc < 0:
+            raise OracleError("Panic")
 
     def tile_agent(self, i, j):
         return self.L.ow_tile_agent(self.h, i, j)

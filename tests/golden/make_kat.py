@@ -488,6 +488,67 @@ case("readme_world_example", "readme.md:56-67", map="S0 G X",
      script=[reset(), expect(avail_sets=[[STAY, E]]), step([E], event_types=[GEM]), step([E], event_types=[EXIT])])
 case("doc_deepcopy", "python/lle/world/__init__.pyi:313-324", map="S0 X", script=[reset(), clone_check()])
 
+
+# --------------------------------------------------------------------------- World.exit_pos = [...] (world.rs:195-234)
+def set_exits(exits, **kw):
+    return {"op": "set_exits", "exits": [list(p) for p in exits], **kw}
+
+
+MAP_SET_EXITS = "\n        S0 . G\n        X  . .\n    "
+case("set_exits", "src/unit_tests/test_world.rs:583-602", map=MAP_SET_EXITS,
+     script=[reset(), expect(n_exits=1, exit_pos_contains=[[1, 0]]), set_exits([(0, 1), (1, 1)]),
+             expect(n_exits=2, exit_pos_contains=[[0, 1], [1, 1]])])
+case("set_exits_events", "src/unit_tests/test_world.rs:604-641", map=MAP_SET_EXITS,
+     script=[reset(), set_exits([(0, 1), (1, 1)]), step([E], n_events=1, event_multiset=[[EXIT, 0]])])
+case("set_exits_old_exit_inactive", "src/unit_tests/test_world.rs:643-660", map=MAP_SET_EXITS,
+     script=[reset(), set_exits([(0, 1), (1, 1)]), step([S], n_events=0)])
+case("py_set_exit_positions", "python/tests/test_world.py:764-781", map="S0 . X",
+     script=[reset(), expect(exit_pos=[[0, 2]]), set_exits([(0, 1)]), reset(), expect(exit_pos=[[0, 1]]),
+             step([E], event_types=[EXIT]),
+             set_exits([(0, 2)]), reset(), expect(exit_pos=[[0, 2]]), step([E], n_events=0), step([E], event_types=[EXIT])])
+# (A = 1: EXIT is layer 2A+3 = 5.  The reference's generator caches its static layers until `observer.reset()`; the test calls it.)
+case("py_observe_layered_change_exits", "python/tests/test_observations.py:76-92", map="S0 X . .",
+     static={"exit_pos": [[0, 1]]},
+     script=[set_exits([(0, 2), (0, 3)]), reset(), expect(obs_cells=[[5, 0, 2, 1], [5, 0, 3, 1]], derived_obs_layer_exact={"5": [[0, 2], [0, 3]]})])
+# ---- derived from the source (world.rs:195-234, laser.rs:109-115); not asserted by any reference test
+case("derived_set_exits_not_enough", "src/core/world.rs:196-201", map="S0 S1 X X",
+     script=[reset(), set_exits([(0, 2)], error="NotEnoughExitTiles"), expect(exit_pos=[[0, 2], [0, 3]]),
+             set_exits([], error="NotEnoughExitTiles"), expect(exit_pos=[[0, 2], [0, 3]])])
+# `other => panic!("Tile is not a floor")` (:230) / Vec index out of bounds: refused up front, world untouched (lle_hip.h)
+case("derived_set_exits_where_the_reference_panics", "src/core/world.rs:219-232", map="S0 . @ G V\n . . . . .\nL0E . X . .",
+     script=[reset()] + [x for bad in ([(0, 2)], [(0, 3)], [(0, 4)], [(2, 0)], [(7, 0)], [(0, 9)], [(1, 3), (1, 3)])
+                         for x in (set_exits(bad, error="Panic"), expect(exit_pos=[[2, 2]]))] +
+            [step([S], n_events=0), step([E], n_events=0), step([E], n_events=0), step([S], event_types=[EXIT])])
+# ... but under a beam the same cell twice is fine: the second Laser::set_tile finds a Laser again, not an Exit (:221-227)
+case("derived_set_exits_twice_the_same_cell_under_a_laser", "src/core/world.rs:221-227", map="S0 . @ G V\n . . . . .\nL0E . X . .",
+     script=[reset(), set_exits([(2, 3), (2, 3)]), expect(exit_pos=[[2, 3], [2, 3]], obs_cells=[[5, 2, 2, 0], [5, 2, 3, 1]])])
+# the exit under a beam: Laser::set_tile swaps the innermost tile (laser.rs:109-115); the old exit is a plain floor afterwards
+case("derived_set_exits_under_a_laser", "src/core/world.rs:204-228", map="L0E . . .\n S0 . X .",
+     script=[reset(), set_exits([(0, 2)]), expect(exit_pos=[[0, 2]], obs_cells=[[5, 0, 2, 1], [5, 1, 2, 0]], n_lasers=3),
+             step([E], n_events=0), step([E], n_events=0), expect(positions=[[1, 2]], arrived=[False]),
+             step([N], events=[[EXIT, 0]]), expect(positions=[[0, 2]], arrived=[True], beam_bits={"0": [True, False, False]}),
+             set_exits([(1, 2)]), expect(arrived=[True], tile_agent=[[0, 2, 0]], obs_cells=[[5, 0, 2, 0], [5, 1, 2, 1]]),
+             reset(), expect(arrived=[False], all_lasers="on"), step([E], n_events=0), step([E], events=[[EXIT, 0]])])
+# whoever stands on a swapped tile stays its occupant, and `has_arrived` is the agent's, not the tile's (:207,224)
+case("derived_set_exits_keeps_occupant_and_arrival", "src/core/world.rs:204-228", map="S0 X . S1\n . . . X",
+     script=[reset(), step([E, STAY], events=[[EXIT, 0]]), set_exits([(0, 2), (1, 0)]),
+             expect(positions=[[0, 1], [0, 3]], arrived=[True, False], tile_agent=[[0, 1, 0], [0, 3, 1], [0, 2, -1]],
+                    avail_sets=[[STAY], [STAY, S, W]]),
+             step([STAY, W], events=[[EXIT, 1]]), expect(arrived=[True, True]),
+             reset(), expect(arrived=[False, False]), step([E, STAY], n_events=0), step([E, STAY], events=[[EXIT, 0]])])
+# an agent whose START becomes an exit arrives at the next reset (world.rs:411-432 enters every agent; events dropped)
+case("derived_set_exits_on_a_start", "src/core/world.rs:411-432", map="S0 . X",
+     script=[reset(), set_exits([(0, 0)]), expect(arrived=[False], avail_sets=[[STAY, E]]),
+             reset(), expect(arrived=[True], avail_sets=[[STAY]]), step([E], error="InvalidAction", error_agent=0)])
+# a void under a beam turned exit: Laser::set_tile replaces the innermost tile whatever it is (laser.rs:109-115) -- the agent
+# survives where it would have died; `void_pos` still lists the cell (world.rs:218 only replaces `exits`): A = 1, VOID = 3, EXIT = 5
+case("derived_set_exits_replaces_a_void_under_a_laser", "src/core/tiles/laser.rs:109-115", map="L0S . X\n V S0 .\n . . .",
+     script=[reset(), set_exits([(1, 0)]), expect(obs_cells=[[3, 1, 0, 1], [5, 1, 0, 1], [5, 0, 2, 0]]),
+             step([W], events=[[EXIT, 0]]), expect(alive=[True], arrived=[True], beam_bits={"0": [False, False]}),
+             set_exits([(0, 2)]), reset(), step([W], n_events=0), expect(alive=[True], positions=[[1, 0]], obs_cells=[[3, 1, 0, 1], [5, 1, 0, 0]])])
+case("derived_set_exits_then_clone", "src/core/world.rs:645-652", map=MAP_SET_EXITS,
+     script=[reset(), set_exits([(0, 1), (1, 1)]), step([E], events=[[EXIT, 0]]), clone_check()])
+
 if __name__ == "__main__":
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kat_world.json")
     with open(out, "w") as f:

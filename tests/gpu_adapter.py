@@ -82,6 +82,19 @@ class GpuWorld:
     def obs(self):
         return self.w.layered_observation()
 
+    def set_exits(self, exits):
+        try:
+            self.w.exit_pos = exits  # the property setter of the facade (pyworld.rs:203-209)
+        except ParsingError as e:
+            raise KatError(e.kind) from None
+        except ValueError:
+            raise KatError("Panic") from None
+        self.exit_pos = self.w.exit_pos
+
+    def tile_agent(self, i, j):
+        a = self.w._occupant_at(self.w._state(), (i, j))
+        return -1 if a is None else a
+
     # ---- binding-level operations: the product facade itself is under test here
     def clone(self):
         import copy

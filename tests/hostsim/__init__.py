@@ -40,6 +40,8 @@ def lib():
         L.hs_set_state.argtypes = [C.c_void_p]
         L.hs_observe.argtypes = [C.c_void_p]
         L.hs_set_source.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.hs_set_exits.restype = C.c_int
+        L.hs_set_exits.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
         L.hs_set_sources.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hs_observe_as.restype = C.c_int
         L.hs_observe_as.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
@@ -154,6 +156,16 @@ class SimBatch:
         self.map.set_source(laser_id, enabled=enabled, agent_id=colour)
 
 
+    def set_exits(self, exits):
+        flat = [int(v) for p in exits for v in p]
+        rc = self.L.hs_set_exits(self.h, (C.c_int32 * max(len(flat), 1))(*flat), len(exits))
+        if rc > 0:
+            raise SimError(_capi.PARSE_ERROR_NAMES[rc])
+        if rc < 0:
+            raise SimError("Panic")
+        self.map.set_exits(exits)
+
+
 class SimWorld:
     """KAT surface over a 1-env SimBatch (mirrors oracle.OracleWorld)."""
 
@@ -233,6 +245,18 @@ class SimWorld:
 
     def set_source(self, laser_id, enabled=None, colour=None):
         self.b.set_source(laser_id, enabled, colour)
+
+    def set_exits(self, exits):
+        self.b.set_exits(exits)
+        self.exit_pos = self.b.map.positions(_capi.LLE_POS_EXIT)
+
+    def tile_agent(self, i, j):
+        """Tile::agent (tile.rs:86-95): the occupant of cell (i, j), -1 = none."""
+        occ = self._bits()[2]
+        for a, p in enumerate(self.positions()):
+            if occ[a] and tuple(p) == (i, j):
+                return a
+        return -1
 
     def obs(self):
         m = self.b.map

@@ -331,6 +331,16 @@ void hs_set_source(hs_batch* b, int laser_id, int enabled, int agent_id) {
     b->map.compile();
     dispatch(b, M_SOURCES, 0, 0, 0, 0, nullptr, nullptr, old);
 }
+// World.exit_pos = [...] (lle_map_set_exits + lle_batch_update_map): new tables, same dynamic state, observation rewritten
+int hs_set_exits(hs_batch* b, const int32_t* exits_ij, int n_exits) {
+    std::vector<Pos> ex((size_t)n_exits);
+    for (int k = 0; k < n_exits; k++) ex[(size_t)k] = Pos{exits_ij[2 * k], exits_ij[2 * k + 1]};
+    std::string why;
+    const int rc = b->map.set_exits(ex, why);
+    if (rc != 0) return rc;
+    dispatch(b, M_OBSERVE, 0, 0, 0, 0, nullptr, nullptr, 0);
+    return 0;
+}
 // LaserSource.set_colour / enable / disable per environment (lle_batch_set_sources; kernels.hip MODE_ENV_SOURCES)
 void hs_set_sources(hs_batch* b, const uint8_t* colours, const uint32_t* enabled, const uint8_t* mask) {
     const MapHeader& h = b->map.header;

@@ -48,6 +48,8 @@ def check_static(w, st):
             assert _pairs(w.start_pos) == _pairs(val)
         elif key == "exit_pos":
             assert _pairs(w.exit_pos) == _pairs(val)
+        elif key == "n_exits":
+            assert len(w.exit_pos) == val
         elif key == "gem_pos_contains":
             assert set(_pairs(val)) <= set(_pairs(w.gem_pos))
         elif key == "exit_pos_contains":
@@ -176,6 +178,15 @@ def check_expect(w, ex, derived):
             got = {(s[0], s[1]): bool(s[4]) for s in w.sources()}
             for (i, j, en) in val:
                 assert got[(i, j)] == en
+        elif k == "exit_pos":
+            assert _pairs(w.exit_pos) == _pairs(val), (w.exit_pos, val)
+        elif k == "n_exits":
+            assert len(w.exit_pos) == val
+        elif k == "exit_pos_contains":
+            assert set(_pairs(val)) <= set(_pairs(w.exit_pos))
+        elif k == "tile_agent":
+            for (i, j, a) in val:
+                assert w.tile_agent(i, j) == a, ((i, j), w.tile_agent(i, j), a)
         elif k == "obs_shape":
             assert list(w.obs().shape) == val
         elif k == "obs_shape_formula":
@@ -223,6 +234,8 @@ class KatBindingError(Exception):
 
 def _generic_clone(make, case, w):
     c = make(map_str=case.get("map"), level=case.get("level"))
+    if _pairs(c.exit_pos) != _pairs(w.exit_pos):  # (the config the reference clones from carries the current exits)
+        c.set_exits(_pairs(w.exit_pos))
     for k, s in enumerate(w.sources()):  # the config carries the sources' current colour / enabled flag
         c.set_source(k, enabled=bool(s[4]), colour=s[3])
     c.set_state(w.positions(), w.gems_collected(), w.alive())
@@ -298,6 +311,14 @@ def run_case(make, case, derived=True):
                 check_events(w.set_state(op["positions"], op["gems"], op["alive"]), op, derived)
         elif kind == "source":
             w.set_source(op["laser_id"], enabled=op.get("enabled"), colour=op.get("colour"))
+        elif kind == "set_exits":
+            # World.exit_pos = [...] (pyworld.rs:203-209 -> world.rs:195-234); "Panic": a cell where the reference panics
+            try:
+                w.set_exits([tuple(p) for p in op["exits"]])
+            except Exception as e:  # noqa: BLE001
+                assert "error" in op and _kind(e) in op["error"].split("|"), (_kind(e), op.get("error"))
+            else:
+                assert "error" not in op, f"expected {op.get('error')}"
         elif kind == "clone_check":
             # World::clone (world.rs:645-652) = a new world from the config + set_state(get_state()); deepcopy is clone
             c = w.clone() if hasattr(w, "clone") else _generic_clone(make, case, w)

@@ -227,3 +227,39 @@ def test_reset_beam_table_matches_oracle_reset(oracle_mod, name):
             bits = w.beam_bits(s.laser_id)
             want = sum(int(b) << k for k, b in enumerate(bits))
             assert m.reset_beam(s.laser_id, c) == want, (name, s.laser_id, c)
+
+
+def test_map_set_exits_and_clone(oracle_mod, tmp_path):
+    """lle_map_set_exits (World::set_exit_positions, world.rs:195-234) on the host object: the exit list, the world string and
+    the row head's bytes follow; the refusals leave the map untouched; lle_map_clone is independent.  No GPU involved."""
+    from lle_amd import World, _capi
+    from lle_amd.world import ParsingError
+
+    m = _capi.Map(LEVELS[6])
+    o = oracle_mod.OracleWorld(LEVELS[6])
+    old = m.positions(_capi.LLE_POS_EXIT)
+    new = [(0, 2), (4, 3), (11, 0), (5, 5)]  # (4, 3) lies under the beam of L0E
+    copy = m.clone()
+    m.set_exits(new)
+    o.set_exits(new)
+    assert m.positions(_capi.LLE_POS_EXIT) == new == o.exit_pos and m.n_exits == 4
+    assert copy.positions(_capi.LLE_POS_EXIT) == old and copy.world_string() != m.world_string()
+    rows = [r.split() for r in m.world_string().split("\n")]
+    assert all(rows[i][j] == "X" for i, j in new) and all(rows[i][j] == "." for i, j in old)
+    assert _capi.Map(m.world_string()).positions(_capi.LLE_POS_EXIT) == sorted(new)  # (a re-parse lists them in row-major order)
+    with pytest.raises(_capi.MapParseError) as e:
+        m.set_exits(new[:3])
+    assert e.value.kind == "NotEnoughExitTiles"
+    for bad in ([(3, 0)] + new[1:], [(0, 0)] + new[1:], [(4, 0)] + new[1:], [(12, 0)] + new[1:], [(0, 2), (0, 2)] + new[2:]):
+        with pytest.raises(ValueError):  # wall, gem, source, out of the world, the same floor twice
+            m.set_exits(bad)
+        assert m.positions(_capi.LLE_POS_EXIT) == new
+    # the facade without a device: the property, the error classes, save
+    w = World.level(6)
+    w.exit_pos = new
+    assert w.exit_pos == new and w.world_string == m.world_string()
+    with pytest.raises(ParsingError) as pe:
+        w.exit_pos = new[:2]
+    assert pe.value.kind == "NotEnoughExitTiles" and w.exit_pos == new
+    w.save(str(tmp_path / "lvl.txt"))
+    assert World.from_file(str(tmp_path / "lvl.txt")).exit_pos == sorted(new)

@@ -400,3 +400,42 @@ def test_batched_lle_one_launch_step():
             assert torch.equal(x[k], y[k]), (t, k)
     with pytest.raises(ValueError):
         BatchedLLE(LEVELS[6], n, walkable_lasers=False).step(acts, fused=True)
+
+
+def test_restore_does_not_bring_back_an_old_output_descriptor():
+    """with per-env sources a snapshot used to include the device mirror of the lle_env_outputs descriptor,
+    so restore() put back the pointers bound at snapshot time while the host still believed its copy current: the next
+    fused step wrote into whatever those were.  snapshot -> fused step into NEW tensors -> restore -> fused step must equal
+    the two-launch path on a twin."""
+    import torch
+
+    from lle_amd import BatchedLLE
+
+    n = 1024
+    a = BatchedLLE(LEVELS[6], n, obs_type="layered", randomize_lasers=True, seed=4)
+    b = BatchedLLE(LEVELS[6], n, obs_type="layered", randomize_lasers=True, seed=4)
+    a.reset(), b.reset()
+    b.world.set_sources(colours=a.world.src_colour[:, : a.world.map.n_sources].clone())
+    g = torch.Generator(device="cuda").manual_seed(9)
+
+    def acts_of(env):
+        return torch.multinomial(env.available_actions().reshape(-1, 5).float(), 1, generator=g).reshape(n, -1).to(torch.uint8)
+
+    for _ in range(3):
+        acts = acts_of(a)
+        a.step(acts, auto_reset=True, fused=True), b.step(acts, auto_reset=True)
+    snap_a, snap_b = a.world.snapshot(), b.world.snapshot()
+    old_fused = a._fused
+    a._fused = None  # the next fused step binds fresh output tensors: the device descriptor changes after the snapshot
+    acts = acts_of(a)
+    x, y = a.step(acts, auto_reset=True, fused=True), b.step(acts, auto_reset=True)
+    assert all(torch.equal(x[k], y[k]) for k in ("obs", "state", "reward", "done", "available_actions"))
+    del old_fused  # the tensors the snapshot-time descriptor pointed at are gone
+    torch.cuda.empty_cache()
+    a.world.restore(snap_a), b.world.restore(snap_b)
+    a._t = b._t = 3
+    for t in range(6):
+        acts = acts_of(b)
+        x, y = a.step(acts, auto_reset=True, fused=True), b.step(acts, auto_reset=True)
+        for k in ("obs", "state", "reward", "done", "available_actions", "err"):
+            assert torch.equal(x[k], y[k]), (k, t)
