@@ -899,12 +899,12 @@ static int push_map(lle_batch* b, int map_index, const lle_map* map, bool broadc
     if (map_index < 0 || map_index >= (int)b->maps.size()) return fail(LLE_ERR_ARG, "map_index out of range");
     const MapHeader& nh = map->m.header;
     const MapHeader& oh = b->maps[(size_t)map_index].header;
-    if (nh.H != oh.H || nh.W != oh.W || nh.A != oh.A || nh.L != oh.L || nh.G != oh.G || nh.blob_capacity != oh.blob_capacity ||
-        nh.blob_bytes > nh.blob_capacity || nh.ext_bytes != oh.ext_bytes)
-        return fail(LLE_ERR_ARG, "map does not match the batch");
+    if (nh.H != oh.H || nh.W != oh.W || nh.A != oh.A || nh.L != oh.L || nh.G != oh.G) return fail(LLE_ERR_ARG, "map does not match the batch");
     // the rows of LLE_BUF_OBS keep the pitch the batch was created with (lle_map_set_row_align after lle_batch_create)
     if (nh.obs_stride != oh.obs_stride || nh.n_chunks != oh.n_chunks)
         return fail(LLE_ERR_ARG, "the map's row alignment differs from the batch's (lle_map_set_row_align: a live batch keeps the pitch it was created with)");
+    if (nh.blob_capacity != oh.blob_capacity || nh.blob_bytes > nh.blob_capacity || nh.ext_bytes != oh.ext_bytes)
+        return fail(LLE_ERR_ARG, "map does not match the batch");
     for (size_t s = 0; s < map->m.sources.size(); s++) {
         const Source &a = map->m.sources[s], &o = b->maps[(size_t)map_index].sources[s];
         if (!(a.pos == o.pos) || a.direction != o.direction || a.beam.size() != o.beam.size()) return fail(LLE_ERR_ARG, "map does not match the batch (another map's sources)");
