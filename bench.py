@@ -60,8 +60,10 @@ def host_cores():
 
 def cpu_baseline(n_envs, seconds_target=12.0):
     """The CPU oracle (C restatement of the reference algorithm, kind "port") on a bounded sample of the same workload:
-    the same n_envs level-6 environments, sampled actions + auto-reset + int8 layered observation, for about
-    `seconds_target` seconds on the host cores this process may use (one thread per core over disjoint env ranges)."""
+    the same n_envs level-6 environments, sampled actions + auto-reset + int8 layered observation.  The thread count is
+    SWEPT -- 64, 128 and every core this process may run on (deduplicated, capped at the visible cores), threads pinned to
+    distinct cores over disjoint env ranges -- for about `seconds_target` seconds in total; every point is reported and the
+    best one is quoted as `value`."""
     import numpy as np
 
     from oracle import oracle
@@ -69,29 +71,39 @@ def cpu_baseline(n_envs, seconds_target=12.0):
 
     level_text = LEVELS[LEVEL]
     cores = host_cores()
-    threads = max(1, min(cores, 64))  # the GPU box gives one GPU a share of the host cores; more threads only thrash
+    counts = sorted({max(1, min(c, cores)) for c in (64, 128, cores)})
     ob = oracle.OracleBatch(level_text, n_envs)
     obs = np.zeros((n_envs, ob.C * ob.H * ob.W), np.int8)
-    ob.rollout(4, SEED, threads, obs)  # warm-up
-    cal = 16
-    t0 = time.perf_counter()
-    ob.rollout(cal, SEED, threads, obs)
-    rate = n_envs * cal / (time.perf_counter() - t0)
-    steps = max(8, int(seconds_target * rate / n_envs))
-    t0 = time.perf_counter()
-    ob.rollout(steps, SEED, threads, obs)
-    dt = time.perf_counter() - t0
-    steps1 = max(2, steps // (4 * threads))
+    oracle.set_thread_pinning(True)
+    ob.rollout(2, SEED, counts[-1], obs)  # warm-up: pages of `obs` touched, worlds in cache
+    per_point = seconds_target / (len(counts) + 0.25)
+    sweep = []
+    for threads in counts:
+        cal = 4
+        t0 = time.perf_counter()
+        ob.rollout(cal, SEED, threads, obs)
+        rate = n_envs * cal / (time.perf_counter() - t0)
+        steps = max(4, int(per_point * rate / n_envs))
+        t0 = time.perf_counter()
+        ob.rollout(steps, SEED, threads, obs)
+        dt = time.perf_counter() - t0
+        sweep.append({"threads": threads, "steps": steps, "seconds": dt, "env_steps_per_s": n_envs * steps / dt,
+                      "agent_steps_per_s": ob.A * n_envs * steps / dt})
+    best = max(sweep, key=lambda p: p["env_steps_per_s"])
+    steps1 = max(2, int(0.25 * per_point * best["env_steps_per_s"] / best["threads"] / n_envs))
     t1 = time.perf_counter()
     ob.rollout(steps1, SEED, 1, obs)
     dt1 = time.perf_counter() - t1
+    oracle.set_thread_pinning(False)
     return {
-        "value": ob.A * n_envs * steps / dt, "unit": "agent-steps/s", "cores": threads, "kind": "port",
-        "threads_used": threads, "host_cores_visible": cores, "host_cores_total": os.cpu_count(),
-        "env_steps_per_s": n_envs * steps / dt, "seconds": dt,
+        "value": best["agent_steps_per_s"], "unit": "agent-steps/s", "cores": best["threads"], "kind": "port",
+        "threads_used": best["threads"], "threads_pinned": True, "host_cores_visible": cores, "host_cores_total": os.cpu_count(),
+        "env_steps_per_s": best["env_steps_per_s"], "seconds": sum(p["seconds"] for p in sweep), "thread_sweep": sweep,
         "single_thread_env_steps_per_s": n_envs * steps1 / dt1,
-        "sample": f"level {LEVEL}, {n_envs} envs x {steps} steps ({dt:.1f} s), sampled actions + auto-reset + int8 layered obs, "
-                  f"C restatement of the Rust reference algorithm (oracle/lle_oracle.c), {threads} threads on {cores} visible host cores",
+        "sample": f"level {LEVEL}, {n_envs} envs, sampled actions + auto-reset + int8 layered obs, C restatement of the Rust reference "
+                  f"algorithm (oracle/lle_oracle.c); thread sweep {counts} (pinned) on {cores} visible host cores, "
+                  f"{'/'.join(str(p['steps']) for p in sweep)} steps per point; best: {best['threads']} threads, "
+                  f"{best['steps']} steps in {best['seconds']:.1f} s",
     }
 
 
@@ -111,12 +123,44 @@ def free_port():
         return s.getsockname()[1]
 
 
+def visible_gpus():
+    """GPUs this process would see, WITHOUT loading HIP: the parent of an N-rank run must stay off the GPU (on ROCm,
+    torch.cuda.device_count() may run hsa_init and keep /dev/kfd open for the whole run).  KFD topology nodes with SIMDs are
+    GPUs -- those whose DRM render node this process can open --; HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES narrow them.  Falls back to a short-lived child
+    process that asks torch when sysfs is not there."""
+    nodes = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        count = 0
+        for d in sorted(os.listdir(nodes)):
+            with open(os.path.join(nodes, d, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                # a container may be given some of the host's GPUs only: the render node must be there and usable
+                minor = props.get("drm_render_minor")
+                if minor is None or os.access(f"/dev/dri/renderD{minor}", os.R_OK | os.W_OK):
+                    count += 1
+    except OSError:
+        count = None
+    if count is None:
+        try:
+            res = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], stdout=subprocess.PIPE,
+                                 stderr=subprocess.DEVNULL, text=True, timeout=300)
+            return int(res.stdout.strip().splitlines()[-1])
+        except Exception:  # noqa: BLE001
+            return 0
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            count = min(count, len([x for x in v.split(",") if x.strip() != ""]))
+    return count
+
+
 def spawn_ranks(args, argv):
-    """Parent of an N-rank run.  Never initialises a GPU (device_count() does not) and never execs: the ranks are child
-    processes of torch.distributed.run, and this process exits with their code."""
+    """Parent of an N-rank run.  Never touches a GPU (visible_gpus() reads sysfs) and never execs: the ranks are child
+    processes of torch.distributed.run, and this process exits with their code.  The ranks check their own device again."""
     if not args.plumbing_only:
-        import torch
-        visible = torch.cuda.device_count()
+        visible = visible_gpus()
         if visible < args.gpus:
             print(f"bench.py: --gpus {args.gpus} but only {visible} GPU(s) visible; refusing to measure fewer GPUs than asked for",
                   file=sys.stderr)
@@ -138,25 +182,82 @@ def plumbing_only(args, real_stdout):
     import torch
     import torch.distributed as dist
 
-    from lle_amd.distributed import STAT_KEYS, allreduce_max, allreduce_stats
+    from lle_amd.distributed import STAT_KEYS, allreduce_max, allreduce_stats, gather_rows
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     if "RANK" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
     stats = {k: (rank + 1) * (i + 1) for i, k in enumerate(STAT_KEYS)}
     dev = torch.device("cpu")
+    # (the same region record every rank of a real run contributes: wall s, kernel ms per launch, env-steps, sustained wall s, kernel ms)
+    mine = [float(rank + 1), 0.02 * (rank + 1), 65536.0 * 20, 2.0 * (rank + 1), 0.019 * (rank + 1)]
     if dist.is_initialized():
         stats = allreduce_stats(stats, dev)
         elapsed = allreduce_max(float(rank + 1), dev)
     else:
         elapsed = 1.0
+    rows = gather_rows(mine, dev)
     if rank == 0:
         line = {"plumbing_only": True, "n_gpus": world, "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
-                "backend": "gloo", "rollout_stats": stats, "elapsed_max": elapsed}
+                "backend": "gloo", "rollout_stats": stats, "elapsed_max": elapsed,
+                **scaling_block(rows, steps=20, sustained_steps=2000, n_envs=65536, agents=4)}
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
     return 0
+
+
+def scaling_block(rows, steps, sustained_steps, n_envs, agents, n1_reference=None):
+    """What a reader needs to diagnose an N-rank line: every rank's own numbers and the region both ways.
+    rows[r] = [wall seconds of the --steps region, HIP-event ms per launch in it, env-steps stepped in it,
+               wall seconds of the sustained region (0 = none), HIP-event ms per launch in it].
+    `value` of the line follows the contract (wall clock around barrier + synchronize, max over ranks); the HIP-event figures
+    say what the GPUs did inside it: at --steps 20 the region is 0.4 ms long and the closing one-element all-reduce, the rank
+    skew and the host's wake-up are a visible share of it."""
+    world = len(rows)
+    per_rank = [{"rank": r, "wall_ms_per_step": row[0] / steps * 1e3, "kernel_ms": row[1], "env_steps": int(row[2]),
+                 "agent_steps_per_s_by_events": agents * n_envs / (row[1] * 1e-3) if row[1] > 0 else None,
+                 "sustained_wall_ms_per_step": row[3] / sustained_steps * 1e3 if sustained_steps and row[3] > 0 else None,
+                 "sustained_kernel_ms": row[4] if sustained_steps and row[4] > 0 else None} for r, row in enumerate(rows)]
+    k_max, k_min = max(row[1] for row in rows), min(row[1] for row in rows)
+    wall_max = max(row[0] for row in rows)
+    out = {"per_rank": per_rank,
+           "region": {"wall_ms_per_step_max_over_ranks": wall_max / steps * 1e3, "kernel_ms_max_over_ranks": k_max,
+                      "kernel_ms_min_over_ranks": k_min,
+                      "agent_steps_per_s_by_slowest_rank_events": agents * n_envs * world / (k_max * 1e-3) if k_max > 0 else None,
+                      "host_share_of_wall": 1.0 - k_max * steps * 1e-3 / wall_max if wall_max > 0 else None,
+                      "note": "wall = the contract's clock (barrier + synchronize on both sides, closing all-reduce inside); kernel = HIP "
+                              "events on each rank's launch stream around the same launches"}}
+    if sustained_steps and all(row[4] > 0 for row in rows):
+        s_k = max(row[4] for row in rows)
+        out["region"]["sustained_kernel_ms_max_over_ranks"] = s_k
+        if n1_reference:
+            # weak scaling: every rank steps the same n_envs; N ranks at the speed of one alone would take the same time per launch
+            out["weak_scaling_vs_n1"] = {"n1_sustained_kernel_ms": n1_reference, "sustained_kernel_ms_max_over_ranks": s_k,
+                                         "ratio": n1_reference / s_k,
+                                         "note": "the slowest rank's sustained launch time against the N = 1 sustained launch time recorded "
+                                                 "on this host by an earlier `bench.py --gpus 1` (a diagnostic; the driver computes efficiency "
+                                                 "from the per-N `value`s itself)"}
+    return out
+
+
+N1_CACHE = os.path.join(os.environ.get("TMPDIR", "/tmp"), "lle_amd_bench_n1.json")
+
+
+def n1_reference(write=None):
+    """The N = 1 sustained launch time (ms) of an earlier run on this host, for the diagnostic of N > 1 runs; `write`: record it."""
+    try:
+        if write is not None:
+            with open(N1_CACHE, "w") as f:
+                json.dump({"sustained_kernel_ms": write, "host": socket.gethostname(), "time": time.time()}, f)
+            return write
+        with open(N1_CACHE) as f:
+            d = json.load(f)
+        if d.get("host") == socket.gethostname() and time.time() - d.get("time", 0) < 6 * 3600:
+            return float(d["sustained_kernel_ms"])
+    except Exception:  # noqa: BLE001
+        pass
+    return None
 
 
 class Timer:
@@ -209,7 +310,7 @@ def preroll(torch, dev, fn, seconds=PREROLL_SECONDS):
     return n
 
 
-def measure_config(torch, timer, dev, map_or_text, n_envs, algo_bytes, steps, label, traffic_key=None, fused=None):
+def measure_config(torch, timer, dev, map_or_text, n_envs, algo_bytes, steps, label, traffic_key=None, fused=None, fill_ceiling=False):
     """One secondary configuration (N = 1): K single-step launches after a warm-up, HIP-event timed."""
     from lle_amd import BatchedWorld
     bw = BatchedWorld(map_or_text, n_envs, device=dev)
@@ -231,6 +332,28 @@ def measure_config(torch, timer, dev, map_or_text, n_envs, algo_bytes, steps, la
         "traffic": load_traffic(traffic_key) if traffic_key else None,
         "rollout_stats": bw.stats(),
     }
+    if fill_ceiling:
+        # what THIS box gives a writer of the same shape: (a) the step kernel's own store pattern without a state machine
+        # (lle_batch_probe_row_fill), (b) a memset-class fill of the same bytes (a narrow write front); ~10 ms each.  Boxes
+        # differ by up to 15 % past the Infinity Cache (DESIGN.md section 4 "Two kinds of box"): read `frac_of_fill`.
+        probe = bw.row_fill_prober()
+        launches = max(20, min(400, int(10e-3 / (ms * 1e-3))))
+        for _ in range(5):
+            probe()
+        _, p_ms = timer.run(probe, launches)
+        rows_t = bw.obs_rows
+
+        def memset():
+            rows_t.zero_()
+        for _ in range(5):
+            memset()
+        _, m_ms = timer.run(memset, launches)
+        bw.observe()
+        out["fill_ceiling"] = {"row_fill_us": p_ms * 1e3, "row_fill_GBps": rows / (p_ms * 1e-3) / 1e9,
+                               "memset_us": m_ms * 1e3, "memset_GBps": rows / (m_ms * 1e-3) / 1e9, "launches": launches,
+                               "frac_of_fill": p_ms / ms, "frac_of_memset": m_ms / ms,
+                               "note": "row_fill = the step kernel's stores, rows per wavefront and block mapping with no state machine "
+                                       "(lle_batch_probe_row_fill); memset = torch fill of the same bytes; frac = that time / the step kernel's"}
     if fused:  # (T, R): the same rollout as lle_batch_rollout, T steps per launch into a ring of R slots
         T, R = fused
         ring = bw.make_ring(R)
@@ -321,7 +444,7 @@ def main():
     import torch.distributed as dist
 
     from lle_amd import BatchedWorld, Map
-    from lle_amd.distributed import allreduce_max, allreduce_stats, shard_offset
+    from lle_amd.distributed import allreduce_max, allreduce_stats, gather_rows, shard_offset
 
     world = int(os.environ.get("WORLD_SIZE", "1")) if under_launcher else 1
     rank = int(os.environ.get("RANK", "0")) if under_launcher else 0
@@ -362,16 +485,19 @@ def main():
     # counters of the timed region only: zeroed by a fill on the launch stream (bw.stats(reset=True) would read them back
     # first -- a host round trip right in front of a timed region that is 0.5 ms long at the driver's 20 steps)
     bw.stats_blocks.zero_()
-    elapsed, kernel_ms = timer.run(step, args.steps)
-    elapsed = allreduce_max(elapsed, dev) if use_dist else elapsed
-    stats = bw.stats()
-    stats = allreduce_stats(stats, dev) if use_dist else stats
+    my_wall, kernel_ms = timer.run(step, args.steps)
+    elapsed = allreduce_max(my_wall, dev) if use_dist else my_wall
+    local_stats = bw.stats()
+    stats = allreduce_stats(local_stats, dev) if use_dist else local_stats
 
     sustained = None
+    my_s_wall = s_ms = 0.0
     if args.sustained_steps > 0:
-        s_wall, s_ms = timer.run(step, args.sustained_steps)
-        s_wall = allreduce_max(s_wall, dev) if use_dist else s_wall
+        my_s_wall, s_ms = timer.run(step, args.sustained_steps)
+        s_wall = allreduce_max(my_s_wall, dev) if use_dist else my_s_wall
         sustained = (args.sustained_steps, s_wall, s_ms)
+    # every rank's own numbers (rank order): a poor aggregate can then be traced to the rank, or to the host side, that caused it
+    rank_rows = gather_rows([my_wall, kernel_ms, local_stats["env_steps"], my_s_wall, s_ms], dev)
 
     # ---- secondary measurement: the same random rollout with lle_batch_rollout (several steps per launch, every
     # step's observation / actions / reward counts written to a trajectory ring larger than the caches)
@@ -404,14 +530,14 @@ def main():
         k = args.config_steps
         hbm = measure_config(torch, timer, dev, Map(level=LEVEL), HBM_REGIME_ENVS, ALGO_BYTES_PER_ENV_STEP, k,
                              f"World.level({LEVEL}) x {HBM_REGIME_ENVS} envs: rows of one launch exceed the 256 MB Infinity Cache",
-                             "hbm_regime_bytes_per_launch")
+                             "hbm_regime_bytes_per_launch", fill_ceiling=True)
         cfgs = {
             "cfg2_level1_4096": measure_config(torch, timer, dev, Map(level=1), 4096, ALGO_BYTES_CFG2, max(k, 1000),
                                                "BASELINE configs[1]: World.level(1), 1 agent, 4096 envs", "cfg2_bytes_per_launch",
                                                fused=(64, 8)),
             "cfg5_32x32_a8_l8_65536": measure_config(torch, timer, dev, mapgen.config5(0), 65536, ALGO_BYTES_CFG5, k,
                                                      "BASELINE configs[4]: generated 32x32, 8 agents, 8 lasers (mapgen.config5(0)), 65536 envs",
-                                                     "cfg5_bytes_per_launch"),
+                                                     "cfg5_bytes_per_launch", fill_ceiling=True),
         }
 
     lle_step = None
@@ -445,6 +571,9 @@ def main():
                          "rows_MB_per_launch": rows_bytes / 1e6},
             "rollout_stats": stats,
         }
+        if world == 1 and sustained:
+            n1_reference(write=sustained[2])
+        out.update(scaling_block(rank_rows, args.steps, args.sustained_steps, n, A, n1_reference() if world > 1 else None))
         if sustained:
             k, s_wall, s_ms = sustained
             s_ach = ALGO_BYTES_PER_ENV_STEP * n / (s_ms * 1e-3) / 1e9

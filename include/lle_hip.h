@@ -8,7 +8,8 @@
  * plain pointers and sizes, no torch types.  Each entry point cites the reference interface it replaces.
  *
  * Threading: a batch handle is NOT thread-safe (the reference serialises through a Mutex, pyworld.rs:69-82);
- * distinct handles are independent.  All device work of a call is enqueued on the `stream` argument
+ * distinct handles are independent -- one per GPU of a node, from one thread or several.  Every call on a batch runs with
+ * the batch's device current and puts the caller's current device back before it returns.  All device work of a call is enqueued on the `stream` argument
  * (a hipStream_t passed as void*; NULL = the default stream) and is asynchronous unless stated otherwise.
  *
  * Value codes (identical to the reference):
@@ -399,6 +400,37 @@ int lle_batch_step_outputs(lle_batch* b, const uint8_t* actions_dev, uint32_t fl
  * out[0] env_steps, [1] agent_steps, [2] gems, [3] exits, [4] deaths, [5] invalid, [6] auto_resets, [7] reward_sum */
 int lle_batch_stats(lle_batch* b, int64_t out[8], int reset_counters, void* stream);
 
+/* ================================================================== multi-GPU: the end-of-batch reduction
+ * Environments are independent (no cross-env state anywhere in `World`, src/core/world.rs:21-44), so a batch shards over the
+ * GPUs of a node by env range with NO data-path exchange: rank r owns the envs [r*n, (r+1)*n) and samples with
+ * env_offset = r*n.  The one collective is the sum of the eight rollout counters at the end of a batch -- 64 bytes over
+ * RCCL / xGMI, latency-bound (the reference itself has no collective: a single-process library).
+ * librccl is dlopen'ed on first use (LLE_RCCL_LIB overrides the search); without it these calls return LLE_ERR_UNSUPPORTED.
+ *
+ * One process per GPU:   rank 0 calls lle_comm_unique_id() and ships the 128 bytes to the other ranks by any side channel
+ *                        (a file, a pipe, MPI, the launcher's store); every rank then calls lle_comm_create().
+ * One process, N GPUs:   lle_comm_create_all() (ncclCommInitAll) gives one communicator per device; reduce with
+ *                        lle_batch_stats_allreduce_group(), which posts every rank's call inside one RCCL group. */
+typedef struct lle_comm lle_comm;
+#define LLE_COMM_ID_BYTES 128
+enum { LLE_COMM_SUM = 0, LLE_COMM_MAX = 1 };
+int lle_comm_unique_id(uint8_t id[LLE_COMM_ID_BYTES]);
+lle_comm* lle_comm_create(const uint8_t id[LLE_COMM_ID_BYTES], int n_ranks, int rank, int device_id);
+/* out[k] = the communicator of device_ids[k] (NULL: devices 0..n_devices-1), rank k of n_devices. */
+int lle_comm_create_all(lle_comm** out, int n_devices, const int* device_ids);
+void lle_comm_free(lle_comm* c);
+int lle_comm_rank(const lle_comm* c, int* rank, int* n_ranks);
+/* lle_batch_stats summed over every rank of the communicator; every rank gets the total.  Collective: all ranks call it.
+ * Enqueued on `stream` behind the batch's launches; synchronises `stream`. */
+int lle_batch_stats_allreduce(lle_batch* b, lle_comm* c, int64_t out[8], int reset_counters, void* stream);
+/* The same for ONE process that owns all n ranks (batches[k] and comms[k] on the same device, streams[k] the stream of
+ * handle k or streams == NULL for the default streams). */
+int lle_batch_stats_allreduce_group(lle_batch* const* batches, lle_comm* const* comms, void* const* streams, int n, int64_t out[8],
+                                    int reset_counters);
+/* In-place all-reduce of `count` int64 values in device memory (op: LLE_COMM_SUM / LLE_COMM_MAX), asynchronous on `stream`:
+ * for a host's own end-of-batch numbers (e.g. the slowest rank's elapsed nanoseconds). */
+int lle_comm_allreduce_i64(lle_comm* c, int64_t* buf_dev, int count, int op, void* stream);
+
 /* The sampler used by LLE_STEP_SAMPLE_ACTIONS (host copy, for harnesses): the 16-bit field f of (seed, env, t, agent);
  * the action taken is the k-th available one in enum order with k = (f * popcount(avail)) >> 16.  See DESIGN.md. */
 uint64_t lle_action_hash(uint64_t seed, uint64_t env, uint64_t t, uint64_t agent);
@@ -412,6 +444,11 @@ int lle_batch_kernel_info(const lle_batch* b, char* name_buf, size_t cap, int32_
  * (10 ns ticks: entry, tables in LDS, state requested, logic done, state stored, observation stores issued, drained)
  * to stamps_dev [n_waves][8] u64. */
 int lle_batch_step_stamped(lle_batch* b, uint32_t flags, uint64_t seed, uint64_t t, uint64_t* stamps_dev, void* stream);
+/* Profiling aid: overwrite LLE_BUF_OBS with the step kernel's store pattern and nothing else -- the same rows per wavefront,
+ * store instructions, store policy and workgroup -> block mapping, every 32-bit word = `value`, no state machine.  Its
+ * duration is the write ceiling of THIS box for this batch shape (bench.py `fill_ceiling`): boxes differ by up to 15 % once
+ * the rows of a launch exceed the Infinity Cache.  Call lle_batch_observe() afterwards to get the observation back. */
+int lle_batch_probe_row_fill(lle_batch* b, uint32_t value, void* stream);
 /* Diagnostic knob: step with the one-environment-per-lane kernel at 8, 16, 32 or 64 environments per wavefront
  * instead of the default one-lane-per-agent step kernel (64 / G environments per wavefront). */
 int lle_batch_set_envs_per_wave(lle_batch* b, int envs_per_wave);

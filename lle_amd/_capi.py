@@ -42,7 +42,9 @@ EXPORTS = [
     "lle_batch_reset", "lle_batch_step", "lle_batch_rollout", "lle_batch_set_state", "lle_batch_update_sources", "lle_batch_update_map", "lle_batch_observe",
     "lle_batch_snapshot_bytes", "lle_batch_snapshot", "lle_batch_restore",
     "lle_batch_set_sources", "lle_batch_reset_sources", "lle_batch_obs_desc", "lle_batch_observe_as", "lle_batch_available_actions", "lle_batch_env_outputs", "lle_batch_step_outputs",
-    "lle_batch_stats", "lle_batch_kernel_info", "lle_batch_set_envs_per_wave", "lle_batch_step_stamped",
+    "lle_comm_unique_id", "lle_comm_create", "lle_comm_create_all", "lle_comm_free", "lle_comm_rank", "lle_batch_stats_allreduce",
+    "lle_batch_stats_allreduce_group", "lle_comm_allreduce_i64",
+    "lle_batch_stats", "lle_batch_kernel_info", "lle_batch_set_envs_per_wave", "lle_batch_step_stamped", "lle_batch_probe_row_fill",
 ]
 
 
@@ -189,10 +191,27 @@ def lib():
     L.lle_batch_step_outputs.argtypes = [vp, vp, u32, u64, u64, i64, C.POINTER(EnvOutputs), vp]
     L.lle_batch_stats.restype = i32
     L.lle_batch_stats.argtypes = [vp, C.POINTER(C.c_int64), i32, vp]
+    L.lle_comm_unique_id.restype = i32
+    L.lle_comm_unique_id.argtypes = [C.POINTER(C.c_uint8)]
+    L.lle_comm_create.restype = vp
+    L.lle_comm_create.argtypes = [C.POINTER(C.c_uint8), i32, i32, i32]
+    L.lle_comm_create_all.restype = i32
+    L.lle_comm_create_all.argtypes = [C.POINTER(vp), i32, C.POINTER(C.c_int)]
+    L.lle_comm_free.argtypes = [vp]
+    L.lle_comm_rank.restype = i32
+    L.lle_comm_rank.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.lle_batch_stats_allreduce.restype = i32
+    L.lle_batch_stats_allreduce.argtypes = [vp, vp, C.POINTER(C.c_int64), i32, vp]
+    L.lle_batch_stats_allreduce_group.restype = i32
+    L.lle_batch_stats_allreduce_group.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, C.POINTER(C.c_int64), i32]
+    L.lle_comm_allreduce_i64.restype = i32
+    L.lle_comm_allreduce_i64.argtypes = [vp, vp, i32, i32, vp]
     L.lle_batch_kernel_info.restype = i32
     L.lle_batch_kernel_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.lle_batch_step_stamped.restype = i32
     L.lle_batch_step_stamped.argtypes = [vp, u32, u64, u64, vp, vp]
+    L.lle_batch_probe_row_fill.restype = i32
+    L.lle_batch_probe_row_fill.argtypes = [vp, u32, vp]
     L.lle_batch_set_envs_per_wave.restype = i32
     L.lle_batch_set_envs_per_wave.argtypes = [vp, i32]
     _lib = L

@@ -333,6 +333,17 @@ class BatchedWorld:
         o.normalize_state, o.reward_kind, o.walkable_lasers = int(bool(normalize_state)), int(bool(multi_objective)), int(bool(walkable_lasers))
         self._check(_capi.lib().lle_batch_env_outputs(self.h, C.byref(o), self._stream()))
 
+    def row_fill_prober(self, value=0):
+        """A zero-argument callable: one launch that overwrites `obs` with the step kernel's store pattern and nothing else
+        (lle_batch_probe_row_fill): the write ceiling of this box for this batch shape.  Call observe() afterwards."""
+        fn, h, st, v = _capi.lib().lle_batch_probe_row_fill, self.h, self._stream(), int(value)
+
+        def probe():
+            rc = fn(h, v, st)
+            if rc != 0:
+                self._check(rc)
+        return probe
+
     def _noop_launch(self):
         """Profiling aid: a launch that loads the tables and the state and does nothing else (step with every
         action invalid and no observation write is the closest public equivalent)."""

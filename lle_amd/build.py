@@ -16,10 +16,11 @@ def build_native(force=False, verbose=False):
     return os.path.join(_HERE, "liblle_hip.so")
 
 
-def build_c_example(verbose=False):
-    """examples/c_abi_rollout.c: a plain-C host over include/lle_hip.h and the HIP runtime (gcc, no torch, no Python)."""
+def build_c_example(verbose=False, name="c_abi_rollout"):
+    """examples/c_abi_rollout.c, examples/c_abi_multi_gpu.c: plain-C hosts over include/lle_hip.h and the HIP runtime (gcc, no
+    torch, no Python)."""
     root = os.path.dirname(_HERE)
-    src, out = os.path.join(root, "examples", "c_abi_rollout.c"), os.path.join(root, "examples", "c_abi_rollout")
+    src, out = os.path.join(root, "examples", name + ".c"), os.path.join(root, "examples", name)
     cmd = ["gcc", "-std=c11", "-O2", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(root, "include"), "-I/opt/rocm/include",
            src, "-o", out, "-L" + _HERE, "-llle_hip", "-L/opt/rocm/lib", "-lamdhip64",
            "-Wl,-rpath,$ORIGIN/../lle_amd", "-Wl,-rpath,/opt/rocm/lib"]
@@ -27,5 +28,5 @@ def build_c_example(verbose=False):
     if verbose or res.returncode != 0:
         print(res.stdout)
     if res.returncode != 0:
-        raise RuntimeError("building examples/c_abi_rollout failed")
+        raise RuntimeError(f"building examples/{name} failed")
     return out

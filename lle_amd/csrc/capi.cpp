@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/lle_hip.h"
+#include "capi_internal.hpp"
 #include "kernels.h"
 #include "map_compile.hpp"
 #include "step_logic.hpp"
@@ -38,6 +39,28 @@ int fail(int status, const std::string& msg) {
         if (e_ != hipSuccess) return fail(LLE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// Every entry point of a batch runs with the batch's device current and puts the caller's device back afterwards: a host
+// that owns one handle per GPU of the node (BASELINE north_star; lle_hip.h "distinct handles are independent") calls them
+// with whatever device happens to be current, and a Python host's torch must not find its current device changed.
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err;
+    explicit DeviceScope(int dev) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) {
+            err = hipSetDevice(dev);
+            switched = err == hipSuccess;
+        }
+    }
+    ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
+#define ON_DEVICE_OF(b)                                                                                              \
+    DeviceScope device_scope_((b)->device);                                                                          \
+    if (device_scope_.err != hipSuccess) return fail(LLE_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(device_scope_.err))
+
 constexpr int64_t ALIGN = 256;
 int64_t align_up(int64_t x) { return (x + ALIGN - 1) / ALIGN * ALIGN; }
 
@@ -49,6 +72,7 @@ struct Layout {
     int64_t table_stride;     // bytes between the table blobs of consecutive maps
     int64_t off_env_init[5];  // per-env reset state (pos, bits, gems, beams, avail), used with per-env sources
     int64_t off_env_out;      // device copy of the EnvOutputs of lle_batch_step_outputs (64 B)
+    int64_t off_stats_sum;    // the eight counters summed over the per-wavefront slots (lle_batch_stats: 64 B come back, not the slots)
     int64_t total;
     int64_t n_stat_blocks;
 };
@@ -97,6 +121,8 @@ Layout make_layout(const MapHeader& h, int64_t n, int64_t n_maps = 1) {
     }
     l.off_env_out = off;
     off = align_up(off + (int64_t)sizeof(EnvOutputs));
+    l.off_stats_sum = off;
+    off = align_up(off + 64);
     l.total = off;
     return l;
 }
@@ -126,6 +152,19 @@ struct lle_batch {
     EnvOutputs env_out_host{};
     bool env_out_valid = false;
 };
+
+namespace lle {
+int capi_fail(int status, const std::string& msg) { return fail(status, msg); }
+int capi_ok() { g_status = LLE_OK; return LLE_OK; }
+int capi_batch_device(const lle_batch* b) { return b->device; }
+int capi_batch_stats_to_device(lle_batch* b, int64_t* out8_dev, int reset_counters, void* stream) {
+    ON_DEVICE_OF(b);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(launch_stats_sum(b->ptrs.stats, b->layout.n_stat_blocks, out8_dev, st));
+    if (reset_counters) HIP_TRY(hipMemsetAsync(b->ptrs.stats, 0, (size_t)b->layout.n_stat_blocks * 64, st));
+    return LLE_OK;
+}
+}  // namespace lle
 
 extern "C" {
 
@@ -393,7 +432,7 @@ static int create_impl(lle_batch* b, void* arena, int64_t arena_bytes, void* str
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
         return fail(LLE_ERR_NO_DEVICE, "no HIP device: lle_amd has no CPU execution path");
     if (b->device < 0 || b->device >= n_dev) return fail(LLE_ERR_ARG, "device_id out of range");
-    HIP_TRY(hipSetDevice(b->device));
+    ON_DEVICE_OF(b);
     MapHeader worst = b->hdr;
     worst.lds_table_bytes = b->worst_table_bytes;
     const uint32_t lds = kernel_lds_bytes(worst, 1);
@@ -560,6 +599,7 @@ int64_t lle_batch_snapshot_bytes(const lle_batch* b) {
 }
 int lle_batch_snapshot(lle_batch* b, void* dst_dev, void* stream) {
     if (!b || !dst_dev) return fail(LLE_ERR_NULL, "NULL argument");
+    ON_DEVICE_OF(b);
     uint8_t* dst = static_cast<uint8_t*>(dst_dev);
     const uint64_t mode = b->per_env_sources ? 1 : 0;
     HIP_TRY(hipMemcpyAsync(dst, &mode, 8, hipMemcpyHostToDevice, (hipStream_t)stream));
@@ -573,6 +613,7 @@ int lle_batch_snapshot(lle_batch* b, void* dst_dev, void* stream) {
 }
 int lle_batch_restore(lle_batch* b, const void* src_dev, void* stream) {
     if (!b || !src_dev) return fail(LLE_ERR_NULL, "NULL argument");
+    ON_DEVICE_OF(b);
     const uint8_t* src = static_cast<const uint8_t*>(src_dev);
     uint64_t mode = 0;
     HIP_TRY(hipMemcpyAsync(&mode, src, 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -591,6 +632,7 @@ int lle_batch_restore(lle_batch* b, const void* src_dev, void* stream) {
 
 int lle_batch_reset(lle_batch* b, const uint8_t* env_mask_dev, void* stream) {
     if (!b) return fail(LLE_ERR_NULL, "NULL batch");
+    ON_DEVICE_OF(b);
     LaunchArgs K{};
     K.env_mask = env_mask_dev;
     return launch(b, KMODE_RESET, K, stream);
@@ -599,6 +641,7 @@ int lle_batch_reset(lle_batch* b, const uint8_t* env_mask_dev, void* stream) {
 int lle_batch_step(lle_batch* b, const uint8_t* actions_dev, uint32_t flags, uint64_t seed, uint64_t t, int64_t env_offset,
                    void* stream) {
     if (!b) return fail(LLE_ERR_NULL, "NULL batch");
+    ON_DEVICE_OF(b);
     LaunchArgs K{};
     K.flags = flags; K.seed = seed; K.t = t; K.env_offset = env_offset; K.actions_in = actions_dev;
     return launch(b, KMODE_STEP, K, stream);
@@ -611,7 +654,7 @@ int lle_batch_step_outputs(lle_batch* b, const uint8_t* actions_dev, uint32_t fl
     if (out->available && !out->walkable_lasers)
         return fail(LLE_ERR_UNSUPPORTED, "the fused step writes LLE.available_actions with walkable_lasers only: use lle_batch_env_outputs");
     if (b->lane_per_env_step) return fail(LLE_ERR_ARG, "the fused outputs are written by the default step kernel only");
-    HIP_TRY(hipSetDevice(b->device));
+    ON_DEVICE_OF(b);
     const EnvOutputs O{out->state, out->reward, out->done, out->available, out->alive, out->arrived,
                        out->normalize_state, out->reward_kind, out->walkable_lasers, b->per_env_sources ? 1 : 0};
     EnvOutputs* dev = reinterpret_cast<EnvOutputs*>(b->arena + b->layout.off_env_out);
@@ -628,6 +671,7 @@ int lle_batch_step_outputs(lle_batch* b, const uint8_t* actions_dev, uint32_t fl
 int lle_batch_rollout(lle_batch* b, uint32_t n_steps, uint32_t flags, uint64_t seed, uint64_t t0, int64_t env_offset,
                       const lle_rollout_ring* ring, void* stream) {
     if (!b) return fail(LLE_ERR_NULL, "NULL batch");
+    ON_DEVICE_OF(b);
     if (n_steps == 0 || n_steps > 4096) return fail(LLE_ERR_ARG, "n_steps must be 1..4096");
     if (b->lane_per_env_step) return fail(LLE_ERR_ARG, "the fused rollout runs on the default step kernel only");
     LaunchArgs K{};
@@ -642,6 +686,7 @@ int lle_batch_rollout(lle_batch* b, uint32_t n_steps, uint32_t flags, uint64_t s
 
 int lle_batch_set_state(lle_batch* b, void* stream) {
     if (!b) return fail(LLE_ERR_NULL, "NULL batch");
+    ON_DEVICE_OF(b);
     LaunchArgs K{};
     return launch(b, KMODE_SET_STATE, K, stream);
 }
@@ -649,7 +694,7 @@ int lle_batch_set_state(lle_batch* b, void* stream) {
 static int set_sources(lle_batch* b, const uint8_t* colours_dev, const uint32_t* enabled_dev, const uint8_t* env_mask_dev,
                        uint32_t flags, void* stream) {
     if (!b) return fail(LLE_ERR_NULL, "NULL batch");
-    HIP_TRY(hipSetDevice(b->device));
+    ON_DEVICE_OF(b);
     if (kernel_lds_bytes(b->hdr, 1, true) > 160 * 1024)
         return fail(LLE_ERR_UNSUPPORTED, "map tables with per-environment sources exceed the LDS of a workgroup");
     if (!b->per_env_sources) {
@@ -681,6 +726,7 @@ int lle_batch_reset_sources(lle_batch* b, const uint8_t* colours_dev, const uint
 
 int lle_batch_observe(lle_batch* b, void* stream) {
     if (!b) return fail(LLE_ERR_NULL, "NULL batch");
+    ON_DEVICE_OF(b);
     LaunchArgs K{};
     return launch(b, KMODE_OBSERVE, K, stream);
 }
@@ -802,7 +848,7 @@ int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64
     if (rc != LLE_OK) return rc;
     if (!d.supported) return fail(LLE_ERR_UNSUPPORTED, "a laser colour has no layer in this observation (the reference raises IndexError)");
     if (b->per_env_sources && kind == LLE_OBS_LAYERED) {  // the env-coloured layered writer of the world kernel, into `out_dev`
-        HIP_TRY(hipSetDevice(b->device));
+        ON_DEVICE_OF(b);
         BatchPtrs P = b->ptrs;
         P.obs = static_cast<int8_t*>(out_dev);
         LaunchArgs K{};
@@ -817,7 +863,7 @@ int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64
     }
     if (out_bytes < d.bytes || (reinterpret_cast<uintptr_t>(out_dev) % 16) != 0)
         return fail(LLE_ERR_ARENA, "output buffer too small or not 16-byte aligned");
-    HIP_TRY(hipSetDevice(b->device));
+    ON_DEVICE_OF(b);
     hipStream_t st = (hipStream_t)stream;
     const MapHeader& h = b->hdr;
     const bool pes = b->per_env_sources;
@@ -872,7 +918,7 @@ int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64
 
 int lle_batch_available_actions(lle_batch* b, int walkable_lasers, uint8_t* out_dev, void* stream) {
     if (!b || !out_dev) return fail(LLE_ERR_NULL, "NULL argument");
-    HIP_TRY(hipSetDevice(b->device));
+    ON_DEVICE_OF(b);
     const MapSel M{b->envs_per_map, (uint32_t)b->layout.table_stride, 0u};
     HIP_TRY(launch_avail(b->hdr, b->ptrs, out_dev, walkable_lasers, b->n_envs, b->per_env_sources, M, (hipStream_t)stream));
     g_status = LLE_OK;
@@ -882,7 +928,7 @@ int lle_batch_available_actions(lle_batch* b, int walkable_lasers, uint8_t* out_
 int lle_batch_env_outputs(lle_batch* b, const lle_env_outputs* out, void* stream) {
     if (!b || !out) return fail(LLE_ERR_NULL, "NULL argument");
     if (out->reward_kind != 0 && out->reward_kind != 1) return fail(LLE_ERR_ARG, "reward_kind must be 0 (single objective) or 1 (multi objective)");
-    HIP_TRY(hipSetDevice(b->device));
+    ON_DEVICE_OF(b);
     const MapSel M{b->envs_per_map, (uint32_t)b->layout.table_stride, 0u};
     EnvOutputs O{out->state, out->reward, out->done, out->available, out->alive, out->arrived,
                  out->normalize_state, out->reward_kind, out->walkable_lasers, b->per_env_sources ? 1 : 0};
@@ -915,7 +961,7 @@ static int push_map(lle_batch* b, int map_index, const lle_map* map, bool broadc
         const bool swap_ok = (a == K_FLOOR || a == K_EXIT || a == K_VOID) && (o == K_FLOOR || o == K_EXIT || o == K_VOID);
         if (a != o && !swap_ok) return fail(LLE_ERR_ARG, "map does not match the batch (another map's tiles)");
     }
-    HIP_TRY(hipSetDevice(b->device));
+    ON_DEVICE_OF(b);
     LaunchArgs K{};
     K.old_enabled = oh.enabled_mask;
     hipStream_t st = (hipStream_t)stream;
@@ -969,13 +1015,14 @@ int lle_batch_update_map(lle_batch* b, int map_index, const lle_map* map, void* 
 
 int lle_batch_stats(lle_batch* b, int64_t out[8], int reset_counters, void* stream) {
     if (!b || !out) return fail(LLE_ERR_NULL, "NULL argument");
+    ON_DEVICE_OF(b);
     hipStream_t st = (hipStream_t)stream;
-    std::vector<int64_t> host((size_t)b->layout.n_stat_blocks * 8);
-    HIP_TRY(hipMemcpyAsync(host.data(), b->ptrs.stats, host.size() * 8, hipMemcpyDeviceToHost, st));
-    if (reset_counters) HIP_TRY(hipMemsetAsync(b->ptrs.stats, 0, host.size() * 8, st));
+    int64_t* sum = reinterpret_cast<int64_t*>(b->arena + b->layout.off_stats_sum);
+    int rc = capi_batch_stats_to_device(b, sum, reset_counters, stream);
+    if (rc != LLE_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(out, sum, 8 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    for (int k = 0; k < 8; k++) out[k] = 0;
-    for (size_t i = 0; i < host.size(); i++) out[i & 7] += host[i];
+    g_status = LLE_OK;
     return LLE_OK;
 }
 
@@ -1002,9 +1049,19 @@ int lle_batch_kernel_info(const lle_batch* b, char* name_buf, size_t cap, int32_
 // per-wave s_memrealtime stamps written to `stamps_dev` ([n_blocks][8] u64).
 int lle_batch_step_stamped(lle_batch* b, uint32_t flags, uint64_t seed, uint64_t t, uint64_t* stamps_dev, void* stream) {
     if (!b || !stamps_dev) return fail(LLE_ERR_NULL, "NULL argument");
+    ON_DEVICE_OF(b);
     LaunchArgs K{};
     K.flags = flags; K.seed = seed; K.t = t; K.stamps = stamps_dev;
     return launch(b, KMODE_STEP, K, stream);
+}
+
+int lle_batch_probe_row_fill(lle_batch* b, uint32_t value, void* stream) {
+    if (!b) return fail(LLE_ERR_NULL, "NULL batch");
+    ON_DEVICE_OF(b);
+    const uint32_t epw = b->lane_per_env_step ? b->envs_per_wave : step_envs_per_wave(b->n_envs, (int)b->hdr.A);
+    HIP_TRY(launch_row_fill_probe(b->ptrs.obs, b->n_envs, b->hdr.obs_stride, epw, value, (hipStream_t)stream));
+    g_status = LLE_OK;
+    return LLE_OK;
 }
 
 int lle_batch_set_envs_per_wave(lle_batch* b, int epw) {

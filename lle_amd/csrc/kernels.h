@@ -4,7 +4,30 @@
 
 #include "tables.h"
 
+#include <atomic>
+
 namespace lle {
+
+// More than 64 KiB of dynamic LDS per workgroup is an opt-in per (kernel, DEVICE): a code object is loaded once per
+// device, and hipFuncSetAttribute acts on the current one.  One of these per kernel instantiation remembers what each
+// device has been granted (a process may own a handle on every GPU of the node; lle_hip.h: distinct handles are independent,
+// also across threads -- hence the atomics; a lost race costs one redundant hipFuncSetAttribute).
+struct LdsGrant {
+    static constexpr int MAX_DEVICES = 32;
+    std::atomic<uint32_t> bytes[MAX_DEVICES];
+    LdsGrant() { for (auto& b : bytes) b.store(0, std::memory_order_relaxed); }
+    hipError_t ensure(const void* fn, uint32_t lds) {
+        if (lds <= 64u * 1024u) return hipSuccess;
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        const bool cached = dev >= 0 && dev < MAX_DEVICES;
+        if (cached && lds <= bytes[dev].load(std::memory_order_relaxed)) return hipSuccess;
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess && cached) bytes[dev].store(lds, std::memory_order_relaxed);
+        return e;
+    }
+};
 
 enum { KMODE_STEP = 0, KMODE_RESET = 1, KMODE_SET_STATE = 2, KMODE_OBSERVE = 3, KMODE_SOURCES = 4, KMODE_ENV_SOURCES = 5 };
 constexpr uint32_t MIN_ENVS_PER_WAVE = 4;  // step_kernel<16, .>: 4 environments per wavefront
@@ -45,6 +68,10 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
                                   MapSel M, uint32_t n_entities, hipStream_t stream);
 hipError_t launch_state_observe(const MapHeader& h, const BatchPtrs& P, float* out, int normalize, int64_t n_envs, hipStream_t stream);
 hipError_t launch_env_outputs(const MapHeader& h, const BatchPtrs& P, const EnvOutputs& O, int64_t n_envs, MapSel M, hipStream_t stream);
+// ceiling probe: n_rows rows of row_bytes (a multiple of 16) filled with the step kernel's store pattern (observers.hip)
+hipError_t launch_row_fill_probe(int8_t* out, int64_t n_rows, uint32_t row_bytes, uint32_t rows_per_wave, uint32_t value, hipStream_t stream);
+// out8[k] = sum over the n_blocks per-wavefront slots of stats[slot][k] (one workgroup; lle_batch_stats, lle_batch_stats_allreduce)
+hipError_t launch_stats_sum(const int64_t* stats, int64_t n_blocks, int64_t* out8, hipStream_t stream);
 hipError_t launch_avail(const MapHeader& h, const BatchPtrs& P, uint8_t* out, int walkable_lasers, int64_t n_envs, bool per_env_sources,
                         MapSel M, hipStream_t stream);
 

@@ -412,17 +412,16 @@ static hipError_t launch_mode(int mode, const BatchPtrs& P, const LaunchArgs& K,
                               uint32_t waves_per_wg, uint32_t lds_bytes, hipStream_t stream) {
     dim3 grid((n_waves + waves_per_wg - 1) / waves_per_wg), block(64 * waves_per_wg);
     if (lds_bytes > 64 * 1024) {
-        static uint32_t granted[6] = {0, 0, 0, 0, 0, 0};
-        if (mode >= 0 && mode < 6 && lds_bytes > granted[mode]) {
+        static LdsGrant granted[6];  // per mode, per device (kernels.h)
+        if (mode >= 0 && mode < 6) {
             const void* fn = mode == MODE_STEP ? reinterpret_cast<const void*>(&world_kernel<AM, LM, MODE_STEP>)
                            : mode == MODE_RESET ? reinterpret_cast<const void*>(&world_kernel<AM, LM, MODE_RESET>)
                            : mode == MODE_SET_STATE ? reinterpret_cast<const void*>(&world_kernel<AM, LM, MODE_SET_STATE>)
                            : mode == MODE_OBSERVE ? reinterpret_cast<const void*>(&world_kernel<AM, LM, MODE_OBSERVE>)
                            : mode == MODE_SOURCES ? reinterpret_cast<const void*>(&world_kernel<AM, LM, MODE_SOURCES>)
                                                   : reinterpret_cast<const void*>(&world_kernel<AM, LM, MODE_ENV_SOURCES>);
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            hipError_t e = granted[mode].ensure(fn, lds_bytes);
             if (e != hipSuccess) return e;
-            granted[mode] = lds_bytes;
         }
     }
     switch (mode) {

@@ -483,14 +483,62 @@ __global__ void __launch_bounds__(256) env_outputs_kernel(BatchPtrs P, EnvOutput
     }
 }
 
-// ---------------------------------------------------------------------------------------------- launchers
-static hipError_t grant_lds(const void* fn, uint32_t lds, uint32_t& granted) {
-    if (lds > 64 * 1024 && lds > granted) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        granted = lds;
+// ---- ceiling probe (lle_probe_row_fill; bench.py `fill_ceiling`): the write pattern of the step kernel's observation stream
+// and nothing else -- wavefront w owns rows [w * rows_per_wave, (w + 1) * rows_per_wave), 16 B per lane and instruction, the
+// same stores (stream_store) and the same workgroup -> block mapping (xcd_block).  What this reaches on a box is what a
+// row-owning writer can reach there; the step kernel is read against it (DESIGN.md section 4 "Two kinds of box").
+template <bool WT>
+__global__ void __launch_bounds__(256) row_fill_probe_kernel(int8_t* __restrict__ out, int64_t n_rows, uint32_t n_chunks, uint32_t rows_per_wave,
+                                                             uint32_t value) {
+    const uint32_t blk = xcd_block(blockIdx.x, gridDim.x);
+    const uint32_t lane = threadIdx.x & 63u, wave = blk * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t r0 = (int64_t)wave * rows_per_wave;
+    const uint4 v = {value, value, value, value};
+    for (uint32_t r = 0; r < rows_per_wave && r0 + r < n_rows; r++) {
+        uint4* dst = reinterpret_cast<uint4*>(out + (r0 + r) * (int64_t)n_chunks * 16);
+        for (uint32_t c = lane; c < n_chunks; c += 64u) stream_store<WT>(dst + c, v);
     }
-    return hipSuccess;
+}
+
+// The eight rollout counters: every wavefront of a step launch owns a slot of 8 x i64 (no atomics on the hot path); this sums
+// the slots.  One workgroup of 1 024 threads, thread t takes counter t & 7 of the slots t >> 3, t >> 3 + 128, ...: 64-byte
+// rows read whole by 8 neighbouring lanes.  8 192 slots = 512 KB, L2-resident right after a rollout.
+__global__ void __launch_bounds__(1024) stats_sum_kernel(const int64_t* __restrict__ stats, int64_t n_blocks, int64_t* __restrict__ out8) {
+    __shared__ int64_t part[16][8];
+    const uint32_t k = threadIdx.x & 7u, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    int64_t acc = 0;
+    for (int64_t slot = threadIdx.x >> 3; slot < n_blocks; slot += 128) acc += stats[slot * 8 + k];
+    // lanes with the same k inside the wavefront: strides of 8
+#pragma unroll
+    for (int o = 32; o >= 8; o >>= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t)acc, o, 64), hi = __shfl_xor((uint32_t)((uint64_t)acc >> 32), o, 64);
+        acc += (int64_t)(((uint64_t)hi << 32) | lo);
+    }
+    if (lane < 8) part[wave][lane] = acc;
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        int64_t v = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) v += part[w][threadIdx.x];
+        out8[threadIdx.x] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- launchers
+hipError_t launch_row_fill_probe(int8_t* out, int64_t n_rows, uint32_t row_bytes, uint32_t rows_per_wave, uint32_t value, hipStream_t stream) {
+    const uint32_t n_chunks = row_bytes / 16u, wpw = 4;
+    const int64_t n_waves = (n_rows + rows_per_wave - 1) / rows_per_wave;
+    const dim3 grid((uint32_t)((n_waves + wpw - 1) / wpw)), block(64 * wpw);
+    if (write_through_pays((uint64_t)n_rows * row_bytes, row_bytes))
+        hipLaunchKernelGGL(row_fill_probe_kernel<true>, grid, block, 0, stream, out, n_rows, n_chunks, rows_per_wave, value);
+    else
+        hipLaunchKernelGGL(row_fill_probe_kernel<false>, grid, block, 0, stream, out, n_rows, n_chunks, rows_per_wave, value);
+    return hipGetLastError();
+}
+
+hipError_t launch_stats_sum(const int64_t* stats, int64_t n_blocks, int64_t* out8, hipStream_t stream) {
+    hipLaunchKernelGGL(stats_sum_kernel, dim3(1), dim3(1024), 0, stream, stats, n_blocks, out8);
+    return hipGetLastError();
 }
 
 // LDS bytes of the view kernel for n_views views per launch and wpw wavefronts per workgroup
@@ -517,8 +565,8 @@ hipError_t launch_view_observe(const ViewHeader& v, const BatchPtrs& P, const ui
     while (wpw > 1 && view_lds(v, n_views, wpw, pes, n_elems) > OBS_LDS_LIMIT) wpw >>= 1;
     const uint32_t lds = view_lds(v, n_views, wpw, pes, n_elems);
     if (lds > OBS_LDS_LIMIT) return hipErrorInvalidValue;
-    static uint32_t granted = 0;
-    hipError_t e = grant_lds(reinterpret_cast<const void*>(&view_observe_kernel), lds, granted);
+    static LdsGrant granted;  // per device (kernels.h)
+    hipError_t e = granted.ensure(reinterpret_cast<const void*>(&view_observe_kernel), lds);
     if (e != hipSuccess) return e;
     const uint32_t n_waves = (uint32_t)((n_envs + OBS_ENVS_PER_WAVE - 1) / OBS_ENVS_PER_WAVE);
     hipLaunchKernelGGL(view_observe_kernel, dim3((n_waves + wpw - 1) / wpw), dim3(64 * wpw), lds, stream, P, views_dev, n_views, out,
@@ -559,8 +607,8 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
         while (wpw > 1 && shared + wpw * priv > OBS_LDS_LIMIT) wpw >>= 1;
         const uint32_t lds = shared + wpw * priv;
         if (lds > OBS_LDS_LIMIT) return hipErrorInvalidValue;
-        static uint32_t granted_p = 0;
-        hipError_t e = grant_lds(reinterpret_cast<const void*>(&partial_project_kernel), lds, granted_p);
+        static LdsGrant granted_p;
+        hipError_t e = granted_p.ensure(reinterpret_cast<const void*>(&partial_project_kernel), lds);
         if (e != hipSuccess) return e;
         const uint32_t n_waves = (uint32_t)((n_envs + epw - 1) / epw);
         hipLaunchKernelGGL(partial_project_kernel, dim3((n_waves + wpw - 1) / wpw), dim3(64 * wpw), lds, stream, P, out, k, pitch,
@@ -581,8 +629,8 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
     while (wpw > 1 && shared + wpw * priv > OBS_LDS_LIMIT) wpw >>= 1;
     const uint32_t lds = shared + wpw * priv;
     if (lds > OBS_LDS_LIMIT) return hipErrorInvalidValue;
-    static uint32_t granted = 0;
-    hipError_t e = grant_lds(reinterpret_cast<const void*>(&partial_observe_kernel), lds, granted);
+    static LdsGrant granted;
+    hipError_t e = granted.ensure(reinterpret_cast<const void*>(&partial_observe_kernel), lds);
     if (e != hipSuccess) return e;
     const uint32_t n_waves = (uint32_t)((n_envs + epw - 1) / epw);
     hipLaunchKernelGGL(partial_observe_kernel, dim3((n_waves + wpw - 1) / wpw), dim3(64 * wpw), lds, stream, P, out, k, pitch,

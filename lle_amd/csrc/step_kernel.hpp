@@ -596,13 +596,10 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
 template <int G, int LM, int MODE, bool ML1, int LX = -1>
 static hipError_t launch_step_glp(const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
     dim3 grid((n_waves + wpw - 1) / wpw), block(64 * wpw);
-    if (lds > 64 * 1024) {  // gfx950 has 160 KiB of LDS per CU; more than 64 KiB per workgroup is opt-in
-        static uint32_t granted = 0;
-        if (lds > granted) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<G, LM, MODE, ML1, LX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            granted = lds;
-        }
+    if (lds > 64 * 1024) {  // gfx950 has 160 KiB of LDS per CU; more than 64 KiB per workgroup is opt-in, per device (kernels.h)
+        static LdsGrant granted;
+        hipError_t e = granted.ensure(reinterpret_cast<const void*>(&step_kernel<G, LM, MODE, ML1, LX>), lds);
+        if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL((step_kernel<G, LM, MODE, ML1, LX>), grid, block, lds, stream, P, K);
     return hipGetLastError();

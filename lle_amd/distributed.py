@@ -33,3 +33,14 @@ def allreduce_max(value, device):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_rows(row, device):
+    """Every rank's list of floats, in rank order, on every rank (one all_gather of a small float64 tensor): the per-rank
+    timings of a benchmark region, so that a poor aggregate can be traced to the rank that caused it."""
+    t = torch.tensor([float(v) for v in row], dtype=torch.float64, device=device)
+    if not (dist.is_available() and dist.is_initialized()):
+        return [t.tolist()]
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [o.tolist() for o in out]

@@ -19,6 +19,9 @@
  * Every function cites the reference file:line (relative to the reference repository root) that
  * it restates.
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE /* pthread_setaffinity_np, CPU_SET (cpu_baseline thread pinning) */
+#endif
 #include <stdbool.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -990,9 +993,19 @@ void ow_batch_dump(ow_batch* b, int64_t e0, int64_t e1, int beam_stride,
  * Each thread owns a contiguous env range and runs `steps` sampled-action steps with auto-reset,
  * writing the layered observation of every env-step into obs[n][C*H*W] (same bytes the GPU path emits). */
 #include <pthread.h>
-typedef struct { ow_batch* b; int64_t e0, e1; int steps; uint64_t seed; int8_t* obs; int64_t stats[8]; } rollout_job;
+#include <sched.h>
+typedef struct { ow_batch* b; int64_t e0, e1; int steps; uint64_t seed; int8_t* obs; int64_t stats[8]; int cpu; } rollout_job;
+static int g_pin_threads = 0;
+/* bench.py cpu_baseline: pin thread k of a rollout to the k-th CPU this process may run on (0 = leave it to the scheduler) */
+void ow_set_thread_pinning(int on) { g_pin_threads = on; }
 static void* rollout_thread(void* arg) {
     rollout_job* j = (rollout_job*)arg;
+    if (j->cpu >= 0) {
+        cpu_set_t one;
+        CPU_ZERO(&one);
+        CPU_SET(j->cpu, &one);
+        (void)pthread_setaffinity_np(pthread_self(), sizeof one, &one);
+    }
     int64_t stats[8] = {0};  /* thread-local: the job structs of neighbouring threads share cache lines */
     for (int t = 0; t < j->steps; t++)
         ow_batch_step_range(j->b, j->e0, j->e1, NULL, 1, j->seed, (uint64_t)t, 0, NULL, NULL, NULL, NULL, j->obs, stats);
@@ -1003,7 +1016,12 @@ void ow_batch_rollout(ow_batch* b, int steps, uint64_t seed, int n_threads, int8
     if (n_threads < 1) n_threads = 1;
     pthread_t* th = (pthread_t*)calloc((size_t)n_threads, sizeof *th);
     rollout_job* jobs = (rollout_job*)calloc((size_t)n_threads, sizeof *jobs);
+    cpu_set_t allowed;
+    int n_allowed = 0, cpus[CPU_SETSIZE];
+    if (g_pin_threads && n_threads > 1 && sched_getaffinity(0, sizeof allowed, &allowed) == 0)
+        for (int c = 0; c < CPU_SETSIZE; c++) if (CPU_ISSET(c, &allowed)) cpus[n_allowed++] = c;
     for (int k = 0; k < n_threads; k++) {
+        jobs[k].cpu = n_allowed > 0 ? cpus[k % n_allowed] : -1;
         jobs[k].b = b; jobs[k].e0 = b->n * k / n_threads; jobs[k].e1 = b->n * (k + 1) / n_threads;
         jobs[k].steps = steps; jobs[k].seed = seed; jobs[k].obs = obs;
         if (n_threads == 1) rollout_thread(&jobs[k]);

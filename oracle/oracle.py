@@ -97,6 +97,7 @@ def lib():
         L.ow_batch_step_range.argtypes = [vp, i64, i64, vp, i32, u64, u64, i64, vp, vp, vp, vp, vp, vp]
         L.ow_batch_dump.argtypes = [vp, i64, i64, i32, vp, vp, vp, vp, vp, vp, vp]
         L.ow_batch_rollout.argtypes = [vp, i32, u64, i32, vp, pi64]
+        L.ow_set_thread_pinning.argtypes = [i32]
         _lib = L
     return _lib
 
@@ -350,6 +351,11 @@ class OracleBatch:
         self.L.ow_batch_rollout(self.h, steps, seed, n_threads, obs.ctypes.data if obs is not None else None,
                                 stats.ctypes.data_as(C.POINTER(C.c_int64)))
         return stats
+
+
+def set_thread_pinning(on):
+    """Pin thread k of OracleBatch.rollout to the k-th CPU this process may run on (bench.py cpu_baseline)."""
+    lib().ow_set_thread_pinning(int(bool(on)))
 
 
 def action_hash(seed, env, t, agent):

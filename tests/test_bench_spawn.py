@@ -38,6 +38,34 @@ def test_parent_spawns_n_ranks_and_prints_one_line(world):
     tri = world * (world + 1) // 2  # rank r contributes (r + 1) * (i + 1) to counter i
     assert out["rollout_stats"] == {k: tri * (i + 1) for i, k in enumerate(STAT_KEYS)}
     assert out["elapsed_max"] == float(world)
+    # the per-rank record of a real N-rank line (gathered over the same collective helpers), in rank order
+    assert [r["rank"] for r in out["per_rank"]] == list(range(world))
+    assert [round(r["kernel_ms"], 6) for r in out["per_rank"]] == [round(0.02 * (k + 1), 6) for k in range(world)]
+    assert all(r["env_steps"] == 65536 * 20 for r in out["per_rank"])
+    reg = out["region"]
+    assert abs(reg["kernel_ms_max_over_ranks"] - 0.02 * world) < 1e-9 and abs(reg["kernel_ms_min_over_ranks"] - 0.02) < 1e-9
+    assert abs(reg["wall_ms_per_step_max_over_ranks"] - world / 20 * 1e3) < 1e-6
+    assert abs(reg["agent_steps_per_s_by_slowest_rank_events"] - 4 * 65536 * world / (0.02e-3 * world)) < 1.0
+    assert abs(reg["sustained_kernel_ms_max_over_ranks"] - 0.019 * world) < 1e-9
+
+
+def test_scaling_block_and_gpu_count_helpers():
+    """scaling_block on made-up rows (one slow rank must show), the N = 1 reference round trip, visible_gpus without HIP."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rows = [[0.0005, 0.0200, 65536 * 20, 0.04, 0.0195], [0.0009, 0.0400, 65536 * 20, 0.08, 0.0390]]  # rank 1 twice as slow
+    blk = bench.scaling_block(rows, steps=20, sustained_steps=2000, n_envs=65536, agents=4, n1_reference=0.0195)
+    assert blk["region"]["kernel_ms_max_over_ranks"] == 0.04 and blk["per_rank"][1]["kernel_ms"] == 0.04
+    assert abs(blk["weak_scaling_vs_n1"]["ratio"] - 0.5) < 1e-12
+    assert abs(blk["region"]["host_share_of_wall"] - (1 - 0.04e-3 * 20 / 0.0009)) < 1e-12
+    assert "weak_scaling_vs_n1" not in bench.scaling_block(rows, 20, 2000, 65536, 4)
+    import torch
+    n = bench.visible_gpus()
+    assert isinstance(n, int) and n >= 0
+    if not torch.cuda.is_available():
+        assert n == 0
 
 
 def test_refuses_to_measure_fewer_gpus_than_asked_for():

@@ -33,3 +33,64 @@ def test_c_example_builds_and_fails_loudly_without_a_device():
         pytest.skip("a device is present")
     res = subprocess.run([exe, "64", "2"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=60)
     assert res.returncode != 0 and "failed" in res.stdout
+
+
+@pytest.mark.gpu
+def test_c_host_owning_one_handle_per_gpu_reduces_over_rccl():
+    """examples/c_abi_multi_gpu.c: ONE process, a batch + stream + RCCL communicator per visible GPU (lle_comm_create_all), the
+    current device deliberately wrong for every handle but the last, counters reduced by lle_batch_stats_allreduce_group."""
+    exe = os.path.join(ROOT, "examples", "c_abi_multi_gpu")
+    if not os.path.exists(exe):
+        from lle_amd.build import build_c_example
+        build_c_example(name="c_abi_multi_gpu")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([exe, "8192", "40"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, env=env)
+    assert res.returncode == 0, res.stdout
+    lines = res.stdout.strip().splitlines()
+    assert lines[-1] == "ok", res.stdout
+    n_gpus = sum(1 for ln in lines if ln.startswith("gpu "))
+    row = next(ln for ln in lines if ln.startswith("env_steps"))
+    stats = dict(zip(row.split()[0::2], map(int, row.split()[1::2])))
+    assert n_gpus >= 1 and stats["env_steps"] == n_gpus * 8192 * 40 and stats["invalid"] == 0
+    # more GPUs than visible: refused, never a smaller run under the same name
+    res = subprocess.run([exe, "64", "2", "99"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=60, env=env)
+    assert res.returncode == 2 and "refusing" in res.stdout
+
+
+@pytest.mark.gpu
+def test_comm_api_with_one_rank_matches_the_local_counters():
+    """lle_comm_unique_id / lle_comm_create (one process per GPU) and lle_comm_create_all with a world of one: the reduced
+    counters are the batch's own; the calls leave the current device alone."""
+    import ctypes as C
+
+    import torch
+
+    from lle_amd import BatchedWorld, Map, _capi
+
+    L = _capi.lib()
+    bw = BatchedWorld(Map(level=6), 4096)
+    for t in range(12):
+        bw.step(sample=True, auto_reset=True, seed=3, t=t)
+    local = bw.stats()
+    ident = (C.c_uint8 * 128)()
+    assert L.lle_comm_unique_id(ident) == 0, L.lle_last_error()
+    comm = L.lle_comm_create(ident, 1, 0, bw.device.index or 0)
+    assert comm, L.lle_last_error()
+    rank, world = C.c_int(-1), C.c_int(-1)
+    assert L.lle_comm_rank(comm, C.byref(rank), C.byref(world)) == 0 and (rank.value, world.value) == (0, 1)
+    out = (C.c_int64 * 8)()
+    assert L.lle_batch_stats_allreduce(bw.h, comm, out, 0, bw._stream()) == 0, L.lle_last_error()
+    assert list(out) == list(local.values()) and out[0] == 4096 * 12
+    buf = torch.tensor([5, 7], dtype=torch.int64, device=bw.device)
+    assert L.lle_comm_allreduce_i64(comm, buf.data_ptr(), 2, 1, bw._stream()) == 0
+    torch.cuda.synchronize()
+    assert buf.tolist() == [5, 7]
+    L.lle_comm_free(comm)
+    comms = (C.c_void_p * 1)()
+    assert L.lle_comm_create_all(comms, 1, None) == 0, L.lle_last_error()
+    batches, streams = (C.c_void_p * 1)(bw.h), (C.c_void_p * 1)(bw._stream())
+    assert L.lle_batch_stats_allreduce_group(batches, comms, streams, 1, out, 1) == 0, L.lle_last_error()
+    assert list(out) == list(local.values())
+    assert bw.stats()["env_steps"] == 0  # reset_counters
+    L.lle_comm_free(comms[0])
+    assert L.lle_comm_create(ident, 2, 5, 0) is None and L.lle_last_status() == -2
