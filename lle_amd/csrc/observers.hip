@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "kernels.h"
 #include "obs_stream.hpp"
@@ -397,6 +398,175 @@ __global__ void __launch_bounds__(256) partial_project_kernel(BatchPtrs P, int8_
     }
 }
 
+// ---------------------------------------------------------------------------------------------- partial k x k, one lane per (env, observer)
+// Both kernels above spend the whole wavefront on ONE environment at a time: 36 window cells (3x3, four agents) leave half
+// of the lanes idle, every environment pays its own clear -> patch -> stream chain, and the instruction count per
+// environment (150-300 vector instructions) is what bounds small maps (~20 us at 65 536 envs whatever the window).
+// Here a wavefront takes a BATCH of E environments and a lane is one (environment, observer) pair -- or, when E x observers
+// is below 64, one share of that observer's window rows (S lanes per observer).  What makes a lane cheap:
+//   * a non-empty bitmap of the map, one bit per cell (wall, source, exit, gem, laser tile), built once per workgroup with
+//     8 empty cells of margin on every side: a window row is k bits of it at (i0 + wi, j0), no bounds test anywhere;
+//   * the lane walks only the SET bits of its rows (level 6: 1-2 of the 9 cells of a 3x3 window, ~8 of 49 at 7x7) and
+//     evaluates those cells against the cell tables like the window kernel -- reference order observations.py:343-359:
+//     agents, gems, exits, walls, lasers that are on, -1 at sources; all writes of an environment commute (see above);
+//   * agents are pairs (observer, other agent): A tests per lane instead of an occupancy map.
+// The E rows are contiguous in the output, so the wavefront clears, patches and streams them as ONE block of E x pitch
+// bytes: 1 KiB per store instruction whatever the row size (a 400-byte row alone fills 25 lanes of 64).
+// LDS: [cell_lay | cell_meta (whole KiB rows)] [bitmap] then per wave [E rows] [E records: pos u16[As] | gems | beams[L] | colour words].
+struct PartialDims { int32_t A, L, H, W; uint32_t off_cell_meta; };  // common to the maps of a batch; off_cell_meta relative to off_cell_lay
+__global__ void __launch_bounds__(256) partial_lanes_kernel(BatchPtrs P, int8_t* __restrict__ out, int k, uint32_t pitch, int64_t env_base,
+                                                            int64_t env_limit, int per_env_sources, MapSel M, uint32_t E, uint32_t batches,
+                                                            uint32_t tab_bytes, int wt, PartialDims D, uint32_t tab_off) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t lane = threadIdx.x & 63u, wave_in_wg = threadIdx.x >> 6, waves_per_wg = blockDim.x >> 6;
+    const uint32_t blk = xcd_block(blockIdx.x, gridDim.x);
+    const uint32_t wave_id = blk * waves_per_wg + wave_in_wg;
+    const uint32_t epw = E * batches;  // environments per wavefront
+    const uint8_t* __restrict__ tables = tables_of(P, M, env_base + (int64_t)(blk * waves_per_wg) * epw);
+    const MapHeader* __restrict__ hdr = reinterpret_cast<const MapHeader*>(tables);
+    // the dimensions come with the kernel arguments (the maps of a batch agree on them): no header read stands in front of
+    // the first loads -- the wavefront's records and the workgroup's tables are requested together, one round trip in all
+    const int A = D.A, L = D.L, H = D.H, W = D.W;
+    const int64_t As = agent_stride_of(A, L);
+    const int CW = src_stride_of(L) / 4;
+    const uint32_t rec_dwords = (uint32_t)(As / 2 + 1 + L + CW);
+    const int64_t envw = env_base + (int64_t)wave_id * epw;
+    int64_t n_all = env_limit - envw;
+    n_all = n_all < 0 ? 0 : (n_all > (int64_t)epw ? (int64_t)epw : n_all);
+    const uint32_t* __restrict__ map_colw = reinterpret_cast<const uint32_t*>(hdr->beam_colour);
+    // Record dword (e, f) of the wavefront -- pos u16[As] | gems | beams[L] | colour words -- is requested by lane idx = f * epw + e
+    // (epw is a power of two: no division; neighbouring lanes read neighbouring environments of one array) and lands at
+    // recs_all[e * rec_dwords + f].  The four arrays are told apart with selects, not branches.
+    const uint32_t lg_epw = 31u - (uint32_t)__builtin_clz(epw);
+    const uint32_t rec_total = rec_dwords << lg_epw;
+    auto rec_word = [&](uint32_t idx, uint32_t& at) -> uint32_t {
+        const uint32_t f = idx >> lg_epw, e = idx & (epw - 1u);
+        const bool ok = idx < rec_total && e < (uint32_t)n_all;
+        const int64_t env = envw + (ok ? e : 0u);
+        const uint32_t fp = (uint32_t)(As / 2), fb = fp + 1u, fc = fb + (uint32_t)L;
+        const uint32_t* base = f < fp ? reinterpret_cast<const uint32_t*>(P.pos) : (f == fp ? P.gems : (f < fc ? P.beams
+                             : (per_env_sources ? reinterpret_cast<const uint32_t*>(P.src_colour) : map_colw)));
+        const int64_t off = f < fp ? env * (As / 2) + f : (f == fp ? env : (f < fc ? env * L + (f - fb)
+                          : (per_env_sources ? env * CW + (f - fc) : (int64_t)(f - fc))));
+        at = ok ? e * rec_dwords + f : 0xFFFFFFFFu;
+        return ok ? base[off] : 0u;
+    };
+    constexpr int RV = 4;  // record dwords per lane requested ahead of the table copy (the rest, if any, behind it)
+    uint32_t rv[RV], rat[RV];
+#pragma unroll
+    for (int q = 0; q < RV; q++) rv[q] = rec_word(lane + 64u * (uint32_t)q, rat[q]);
+    copy_tables_to_lds(tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
+    // ---- the non-empty bitmap: (H + 16) rows of RW words, cell (i, j) at row i + 8, bit j + 8
+    const uint32_t RW = ((uint32_t)W + 16u + 31u) / 32u + 1u, bm_words = (uint32_t)(H + 16) * RW, bm_bytes = (bm_words * 4u + 15u) & ~15u;
+    uint32_t* bm = reinterpret_cast<uint32_t*>(lds + tab_bytes);
+    for (uint32_t w = threadIdx.x; w < bm_words; w += blockDim.x) bm[w] = 0u;
+    __syncthreads();  // (also: the table copy has landed)
+    const uint64_t* cell_lay = reinterpret_cast<const uint64_t*>(lds);
+    const uint32_t* cell_meta = reinterpret_cast<const uint32_t*>(lds + D.off_cell_meta);
+    for (uint32_t c = threadIdx.x; c < (uint32_t)(H * W); c += blockDim.x) {
+        if ((cell_meta[c] & 7u) != K_FLOOR || cell_lay[c] != 0ull) {
+            const uint32_t i = c / (uint32_t)W, j = c - i * (uint32_t)W;
+            atomicOr(&bm[(i + 8u) * RW + ((j + 8u) >> 5)], 1u << ((j + 8u) & 31u));
+        }
+    }
+    __syncthreads();
+    // ---- who this lane is: environment slot e of the batch, observer a, share s of S of the window rows
+    const uint32_t logA = A <= 1 ? 0u : (A <= 2 ? 1u : (A <= 4 ? 2u : (A <= 8 ? 3u : 4u)));
+    const uint32_t S = 64u / (E << logA);                 // lanes per (env, observer); the launcher keeps E << logA <= 64
+    const uint32_t e_slot = lane / (S << logA), a = (lane / S) & ((1u << logA) - 1u), s = lane % S;
+    const uint32_t SBL = k <= 8 ? 3u : 4u;                // a window row takes 8 (k <= 8) or 16 bits of the lane's 64-bit set
+    const int centre = k / 2;
+    const uint32_t kk = (uint32_t)(k * k), layers = (uint32_t)(2 * A + 3), n_chunks = pitch / 16u;
+    const uint32_t rec_bytes = (epw * rec_dwords * 4u + 15u) & ~15u;
+    const uint32_t priv_bytes = E * pitch + rec_bytes + 16u;
+    int8_t* rows = reinterpret_cast<int8_t*>(lds + tab_bytes + bm_bytes + wave_in_wg * priv_bytes);
+    uint32_t* recs_all = reinterpret_cast<uint32_t*>(rows + E * pitch);
+    uint4* rows16 = reinterpret_cast<uint4*>(rows);
+    const uint32_t colour_at = (uint32_t)(As / 2 + 1 + L) * 4u;  // byte offset of the colour bytes in a record
+    const int WALL = A, LASER_0 = A + 1, GEM = 2 * A + 1, EXIT = 2 * A + 2;   // observations.py:318-323
+#pragma unroll
+    for (int q = 0; q < RV; q++)
+        if (rat[q] != 0xFFFFFFFFu) recs_all[rat[q]] = rv[q];
+    for (uint32_t idx = lane + 64u * RV; idx < rec_total; idx += 64) {
+        uint32_t at;
+        const uint32_t v = rec_word(idx, at);
+        if (at != 0xFFFFFFFFu) recs_all[at] = v;
+    }
+    // layer of the one static byte of a cell, by kind (0xFF: none): FLOOR, WALL, VOID, EXIT | GEM, SOURCE (wall_pos holds the sources too)
+    const uint32_t lt_lo = 0xFFu | ((uint32_t)WALL << 8) | (0xFFu << 16) | ((uint32_t)EXIT << 24), lt_hi = (uint32_t)GEM | ((uint32_t)WALL << 8) | 0xFFFF0000u;
+    int8_t* dummy = rows + E * pitch + rec_bytes;   // 16 bytes nobody reads: where the writes of a cell that do not apply go
+
+    for (uint32_t batch = 0; batch < batches; batch++) {
+        const int64_t env0 = env_base + (int64_t)wave_id * epw + (int64_t)batch * E;
+        int64_t n_here = env_limit - env0;
+        n_here = n_here < 0 ? 0 : (n_here > (int64_t)E ? (int64_t)E : n_here);
+        if (n_here == 0) break;
+        const uint32_t* recs = recs_all + batch * E * rec_dwords;
+        for (uint32_t c = lane; c < (uint32_t)n_here * n_chunks; c += 64) rows16[c] = make_uint4(0u, 0u, 0u, 0u);
+        wave_sync();  // LDS operations of a wavefront execute in order: everything below lands after the clears
+        const bool live = e_slot < (uint32_t)n_here && a < (uint32_t)A;
+        const uint8_t* rec8 = reinterpret_cast<const uint8_t*>(recs + (live ? e_slot : 0u) * rec_dwords);
+        const uint16_t* pos = reinterpret_cast<const uint16_t*>(rec8);
+        const uint32_t pa = pos[live ? a : 0u];
+        const int i0 = (int)(pa & 0xFFu) - centre, j0 = (int)(pa >> 8) - centre;   // the window's origin on the map
+        int8_t* mine = rows + __umul24(live ? e_slot : 0u, pitch) + __umul24(a, layers * kk);   // observer a's block of this env's row
+        // ---- other agents (dead ones included: agents_positions): lane s takes agents s, s + S, ...
+        if (live)
+            for (uint32_t a2 = s; a2 < (uint32_t)A; a2 += S) {
+                const uint32_t p2 = pos[a2];
+                const uint32_t dy = (uint32_t)((int)(p2 & 0xFFu) - i0), dx = (uint32_t)((int)(p2 >> 8) - j0);
+                if (dy < (uint32_t)k && dx < (uint32_t)k) mine[__umul24(a2, kk) + __umul24(dy, (uint32_t)k) + dx] = 1;
+            }
+        // ---- the non-empty cells of this lane's window rows wi = s, s + S, ...: bit (r << SBL) + wj of `todo`
+        uint64_t todo = 0;
+        if (live) {
+            const uint32_t off = (uint32_t)(j0 + 8);   // >= 1: bit of the window's first column in a bitmap row
+            uint32_t r = 0;
+            for (uint32_t wi = s; wi < (uint32_t)k; wi += S, r++) {
+                const uint32_t* rowp = bm + __umul24((uint32_t)(i0 + (int)wi + 8), RW) + (off >> 5);
+                const uint64_t two = (uint64_t)rowp[0] | ((uint64_t)rowp[1] << 32);
+                const uint64_t bits = (two >> (off & 31u)) & ((1ull << k) - 1ull);
+                todo |= bits << (r << SBL);
+            }
+        }
+        // One non-empty cell per pass, no branch inside: a cell has at most four bytes to give -- its static one (wall / exit /
+        // uncollected gem), the two laser layers World.lasers() exposes when lit, the -1 of a source -- and each is a store
+        // whose address is the byte, or `dummy` when it does not apply.  Every LDS read of a pass is issued before the first
+        // is needed.  (Write order = the reference's, observations.py:347-359; all four commute, see the kernel's header.)
+        const uint32_t* rec32 = reinterpret_cast<const uint32_t*>(rec8);
+        const int cell0 = i0 * W + j0;
+        while (todo) {
+            const uint32_t b = (uint32_t)__builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            // (24-bit multiplies run at the full vector rate, 32-bit ones at a quarter; every factor here is tiny)
+            const uint32_t r = b >> SBL, wj = b & ((1u << SBL) - 1u), wi = s + __umul24(r, S);
+            const uint32_t cell = (uint32_t)(cell0 + (int)(__umul24(wi, (uint32_t)W) + wj));
+            const uint32_t meta = cell_meta[cell];
+            const uint64_t lay = cell_lay[cell];
+            const uint32_t gems = rec32[As / 2];
+            const uint32_t kind = meta & 7u, idx = (meta >> 3) & 31u;
+            const uint32_t l0 = (uint32_t)lay & 0xFFFFu, l1 = (uint32_t)(lay >> 16) & 0xFFFFu;   // World.lasers(): two layers per cell
+            const uint32_t b0 = (l0 >> 1) & 31u, o0 = (l0 >> 6) & 31u, b1 = (l1 >> 1) & 31u, o1 = (l1 >> 6) & 31u;
+            const uint32_t src = kind == K_SOURCE ? idx : 0u;   // idx = laser id of a source cell (gem index otherwise)
+            const uint32_t m0 = rec32[As / 2 + 1 + b0], m1 = rec32[As / 2 + 1 + b1];
+            const uint32_t c0 = rec8[colour_at + b0], c1 = rec8[colour_at + b1], cs = rec8[colour_at + src];
+            const uint32_t lt = ((kind < 4u ? lt_lo : lt_hi) >> ((kind & 3u) * 8u)) & 0xFFu;
+            const bool en0 = lt != 0xFFu && !(kind == K_GEM && ((gems >> idx) & 1u));
+            const bool en1 = (l0 & LAY_VALID) && ((m0 >> o0) & 1u), en2 = (l1 & LAY_VALID) && ((m1 >> o1) & 1u);
+            int8_t* cp = mine + __umul24(wi, (uint32_t)k) + wj;
+            *(en0 ? cp + __umul24(lt, kk) : dummy) = 1;
+            *(en1 ? cp + __umul24((uint32_t)LASER_0 + c0, kk) : dummy) = 1;
+            *(en2 ? cp + __umul24((uint32_t)LASER_0 + c1, kk) : dummy) = 1;
+            *(kind == K_SOURCE ? cp + __umul24((uint32_t)LASER_0 + cs, kk) : dummy) = -1;
+        }
+        wave_sync();
+        uint4* __restrict__ dst = reinterpret_cast<uint4*>(out + (uint64_t)env0 * pitch);
+        if (wt) stream_row<true>(dst, rows16, 0u, (uint32_t)n_here * n_chunks, lane);
+        else stream_row<false>(dst, rows16, 0u, (uint32_t)n_here * n_chunks, lane);
+        wave_sync();  // the next batch clears the rows: after these reads (in order, same wavefront)
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- state vector
 __global__ void __launch_bounds__(256) state_observe_kernel(BatchPtrs P, float* __restrict__ out, int normalize, int64_t n_envs) {
     const MapHeader* __restrict__ hdr = reinterpret_cast<const MapHeader*>(P.tables);  // dimensions are common to all maps
@@ -592,9 +762,75 @@ static bool partial_projects(const MapHeader& h, int k, uint32_t n_entities) {
 
 hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t* out, int k, int64_t n_envs, bool per_env_sources,
                                   MapSel M, uint32_t n_entities, hipStream_t stream) {
+    const uint32_t pitch_l = partial_pitch((int)h.A, k);
+    int force_old = -1;  // LLE_PARTIAL_KERNEL=window / project: one of the two round-1/2 kernels (kept as cross-checks)
+    {   // ---- the lane-per-(env, observer) kernel (partial_lanes_kernel): every map and window size
+        const char* which = getenv("LLE_PARTIAL_KERNEL");  // "lanes" (default) | "window" | "project" | "auto" (the round-2 choice)
+        const bool old_forced = getenv("LLE_PARTIAL_PROJECT") != nullptr;
+        if (!old_forced && (!which || !strcmp(which, "lanes"))) {
+            const uint32_t a_pad = h.A <= 1 ? 1u : (h.A <= 2 ? 2u : (h.A <= 4 ? 4u : (h.A <= 8 ? 8u : 16u)));
+            // S = 64 / (E * a_pad) lanes share an observer's rows; a lane's rows must fit its 64-bit set: 8 rows (k <= 8), else 4
+            const uint32_t s_min = k <= 8 ? 1u : ((uint32_t)k + 3u) / 4u;
+            uint32_t e_max = 64u / a_pad;
+            while (e_max > 1 && 64u / (e_max * a_pad) < s_min) e_max >>= 1;
+            // E, the environments per batch (S = 64 / (E * a_pad) lanes then share an observer's window rows).  Measured at 65 536
+            // envs (tools/lle_prof.py partial --sweep, profiles/r03_partial.md): the best E keeps the batch's block of rows at
+            // 6-16 KiB per wavefront -- level 6 (4 observers) 3x3 / 5x5 / 7x7: E = 16 / 8 / 4; 32x32 with 8 observers: 4 / 4 / 2.
+            // Rule: the largest E whose rows stay within 16 KiB; above 9 KiB half of that when the lanes stay busy (S <= k and
+            // at least 3/4 of the lanes of an observer have a row in every pass).  LLE_PARTIAL_E: tuning override.
+            uint32_t E = e_max;
+            while (E > 1 && E * pitch_l > 16384u) E >>= 1;
+            if (E > 1 && E * pitch_l > 9216u) {
+                const uint32_t S2 = 64u / ((E / 2u) * a_pad), rl = ((uint32_t)k + S2 - 1u) / S2;
+                if (S2 <= (uint32_t)k && 4u * (uint32_t)k >= 3u * S2 * rl) E >>= 1;
+            }
+            if (const char* o = getenv("LLE_PARTIAL_E")) {
+                const uint32_t v = (uint32_t)atoi(o);
+                if (v >= 1 && v <= e_max && !(v & (v - 1))) E = v;
+            }
+            const uint32_t As_l = (uint32_t)agent_stride_of((int)h.A, (int)h.L);
+            const uint32_t rec_dwords = As_l / 2 + 1 + h.L + (uint32_t)src_stride_of((int)h.L) / 4u;
+            uint32_t tab = (h.off_dyn - h.off_cell_lay + 1023u) & ~1023u;
+            if (tab > h.lds_table_bytes) tab = h.lds_table_bytes;
+            const uint32_t RW = (h.W + 16u + 31u) / 32u + 1u, bm_bytes = ((h.H + 16u) * RW * 4u + 15u) & ~15u;
+            // batches per wavefront: a workgroup copies the tables and builds the bitmap before its first row, so a launch should
+            // be ONE round of workgroups (about four per CU): 65 536 envs -> 16 environments per wavefront, i.e. batches = 16 / E
+            uint32_t batches = 1;
+            while (batches < 16 && (int64_t)E * batches * 2 * 4096 <= n_envs) batches *= 2;
+            if (const char* o = getenv("LLE_PARTIAL_BATCHES")) {
+                const uint32_t v = (uint32_t)atoi(o);
+                if (v >= 1 && v <= 64) batches = v;
+            }
+            uint32_t wpw = 4;
+            while (wpw > 1 && M.envs_per_map && M.envs_per_map % (int64_t)(wpw * E * batches) != 0) wpw >>= 1;
+            while (batches > 1 && M.envs_per_map && M.envs_per_map % (int64_t)(wpw * E * batches) != 0) batches >>= 1;
+            uint32_t priv = E * pitch_l + ((E * batches * rec_dwords * 4u + 15u) & ~15u) + 16u;
+            while (wpw > 1 && tab + bm_bytes + wpw * priv > OBS_LDS_LIMIT) wpw >>= 1;
+            const uint32_t lds = tab + bm_bytes + wpw * priv;
+            const bool fits = lds <= OBS_LDS_LIMIT && (!M.envs_per_map || M.envs_per_map % (int64_t)(wpw * E * batches) == 0);
+            if (fits) {
+                static LdsGrant granted_l;
+                hipError_t e = granted_l.ensure(reinterpret_cast<const void*>(&partial_lanes_kernel), lds);
+                if (e != hipSuccess) return e;
+                const uint32_t epw = E * batches;
+                const uint32_t n_waves = (uint32_t)((n_envs + epw - 1) / epw);
+                // written through (`sc1`): the batch's rows are one contiguous block, so lines are shared only at its two ends;
+                // measured better at every size incl. 489 MB (32x32 7x7: 114 -> 99 us).  LLE_PARTIAL_WT=0 / 1: tuning override
+                int wt = 1;
+                if (const char* o = getenv("LLE_PARTIAL_WT")) wt = o[0] == '1';
+                const PartialDims D{(int32_t)h.A, (int32_t)h.L, (int32_t)h.H, (int32_t)h.W, h.off_cell_meta - h.off_cell_lay};
+                hipLaunchKernelGGL(partial_lanes_kernel, dim3((n_waves + wpw - 1) / wpw), dim3(64 * wpw), lds, stream, P, out, k, pitch_l,
+                                   (int64_t)0, n_envs, per_env_sources ? 1 : 0, M, E, batches, tab, wt, D, h.off_cell_lay);
+                return hipGetLastError();
+            }
+        }
+        if (which && !strcmp(which, "window")) force_old = 0;
+        if (which && !strcmp(which, "project")) force_old = 1;
+    }
+
     const uint32_t pitch = partial_pitch((int)h.A, k);
     const uint32_t As = (uint32_t)agent_stride_of((int)h.A, (int)h.L);
-    if (partial_projects(h, k, n_entities)) {
+    if (force_old == 1 || (force_old < 0 && partial_projects(h, k, n_entities))) {
         uint32_t epw = 16;  // level 6 7x7: 4 -> 36.8 us, 8 -> 30.2, 16 -> 28.7 (table build and static decode are per wavefront)
         if (const char* o = getenv("LLE_PARTIAL_EPW")) {
             const uint32_t v = (uint32_t)atoi(o);

@@ -187,25 +187,34 @@ def test_unsupported_colour_raises_index_error():
     assert bw.observe_as(_capi.LLE_OBS_STATE).shape == (8, 3)
 
 
-@pytest.mark.parametrize("project", ["0", "1"])
+@pytest.mark.parametrize("project", ["0", "1", "lanes", "lanes:E=1", "lanes:E=2", "lanes:E=4,B=2", "lanes:WT"])
 @pytest.mark.parametrize("name", ["level6", "nested", "colour_alias", "four_layers", "many_agents", "config5_32x32"])
 def test_partial_window_and_projection_kernels_agree_with_the_oracle(oracle_mod, monkeypatch, name, project):
-    """The partial k x k observation has two kernels -- per window cell (partial_observe_kernel) and per (entity, observer)
-    pair (partial_project_kernel) -- and the launcher picks by cost.  Force each (LLE_PARTIAL_PROJECT) on every map, every
-    window size, along a rollout with deaths, also with per-env source colours: both must match oracle/observers.py."""
+    """The partial k x k observation has three kernels -- one lane per (env, observer) over the non-empty cells of its window
+    (partial_lanes_kernel, the default), per window cell (partial_observe_kernel) and per (entity, observer) pair
+    (partial_project_kernel).  Force each (LLE_PARTIAL_PROJECT for the last two; the lane kernel also with few environments
+    per batch, i.e. several lanes per observer, several batches per wavefront and written-through stores) on every map,
+    window sizes 3 to 15, along a rollout with deaths, also with per-env source colours: all must match oracle/observers.py."""
     import torch
 
     from lle_amd import BatchedWorld, _capi
     from oracle import observers as oo
     from tests.parity_util import legal_colours
 
-    monkeypatch.setenv("LLE_PARTIAL_PROJECT", project)
+    if project in ("0", "1"):
+        monkeypatch.setenv("LLE_PARTIAL_PROJECT", project)
+    else:
+        monkeypatch.delenv("LLE_PARTIAL_PROJECT", raising=False)
+        for opt in project.split(":")[1].split(",") if ":" in project else []:
+            key, _, val = opt.partition("=")
+            monkeypatch.setenv({"E": "LLE_PARTIAL_E", "B": "LLE_PARTIAL_BATCHES", "WT": "LLE_PARTIAL_WT"}[key], val or "1")
+    all_sizes = (3, 5, 7) if project in ("0", "1") else (3, 5, 7, 9, 15)
     text = MAPS[name]
     n = 200
     ob = oracle_mod.OracleBatch(text, n)
     bw = BatchedWorld(text, n)
     A, L = bw.map.n_agents, bw.map.n_sources
-    sizes = [k for k in (3, 5, 7) if bw.obs_desc(_capi.LLE_OBS_PARTIAL, k).supported]
+    sizes = [k for k in all_sizes if bw.obs_desc(_capi.LLE_OBS_PARTIAL, k).supported]
     rng = np.random.default_rng(5)
     for t in range(12):
         if t == 6 and L:  # per-environment colours from here on
@@ -214,7 +223,7 @@ def test_partial_window_and_projection_kernels_agree_with_the_oracle(oracle_mod,
             for e in range(n):
                 for l in range(L):
                     ob.world(e).set_source(l, colour=int(colours[e, l]))
-            sizes = [k for k in (3, 5, 7) if bw.obs_desc(_capi.LLE_OBS_PARTIAL, k).supported]
+            sizes = [k for k in all_sizes if bw.obs_desc(_capi.LLE_OBS_PARTIAL, k).supported]
         bw.step(sample=True, auto_reset=(t % 4 == 3), seed=9, t=t)
         ob.step(None, auto_reset=(t % 4 == 3), seed=9, t=t)
         for k in sizes:

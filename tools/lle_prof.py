@@ -178,6 +178,41 @@ def cmd_observers(args):
         torch.cuda.empty_cache()
 
 
+def cmd_partial(args):
+    """partial k x k: the three kernels (LLE_PARTIAL_KERNEL) and, for the lane kernel, envs per batch / batches per wavefront / store policy"""
+    n = ints(args.sizes)[0]
+    for label, m in (("level 6", Map(level=6)), ("config5 32x32", Map(mapgen.config5(0)))):
+        bw = BatchedWorld(m, n)
+        for t in range(8):
+            bw.step(sample=True, auto_reset=True, seed=1, t=t)
+        for k in (3, 5, 7):
+            d = bw.obs_desc(_capi.LLE_OBS_PARTIAL, k)
+            buf = torch.empty(int(d.bytes) + 256, dtype=torch.uint8, device="cuda")
+            buf = buf[(-buf.data_ptr()) % 256:][: int(d.bytes)]
+            ref = None
+            variants = [dict(LLE_PARTIAL_KERNEL="window"), dict(LLE_PARTIAL_KERNEL="project"), dict()]
+            if args.sweep:
+                variants += [dict(LLE_PARTIAL_E=str(e)) for e in (1, 2, 4, 8, 16)] + [dict(LLE_PARTIAL_BATCHES=str(b)) for b in (1, 2, 4)]
+                variants += [dict(LLE_PARTIAL_WT="1")]
+            for env in variants:
+                for key in ("LLE_PARTIAL_KERNEL", "LLE_PARTIAL_E", "LLE_PARTIAL_BATCHES", "LLE_PARTIAL_WT"):
+                    os.environ.pop(key, None)
+                os.environ.update(env)
+                try:
+                    us = timeit(lambda: bw.observe_as(_capi.LLE_OBS_PARTIAL, k, out=buf), iters=50, warm=5)
+                except RuntimeError as e:  # (a forced E the launcher cannot use falls back silently; a hard failure is reported)
+                    print(f"{label:14s} {k}x{k} {env}: {e}", flush=True)
+                    continue
+                got = buf.clone()
+                same = "" if ref is None else ("  == window" if torch.equal(got, ref) else "  DIFFERS from the window kernel")
+                if ref is None:
+                    ref = got
+                print(f"{label:14s} {k}x{k} {str(env or 'lanes (default)'):44s} {d.bytes/1e6:7.1f} MB {us:8.2f} us {d.bytes/us/1e3:6.0f} GB/s{same}", flush=True)
+            del buf
+        del bw
+        torch.cuda.empty_cache()
+
+
 def cmd_env(args):
     n = ints(args.sizes)[0]
     for kw in (dict(), dict(walkable_lasers=False), dict(multi_objective=True), dict(obs_type="partial7x7"), dict(randomize_lasers=True)):
@@ -393,7 +428,7 @@ def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     sub = ap.add_subparsers(dest="cmd", required=True)
     cmds = {"step": cmd_step, "logic": cmd_logic, "configs": cmd_configs, "hbm": cmd_hbm, "rollout": cmd_rollout, "observers": cmd_observers,
-            "env": cmd_env, "sources": cmd_sources, "multimap": cmd_multimap, "graph": cmd_graph, "pipe": cmd_pipe, "streams": cmd_streams,
+            "partial": cmd_partial, "env": cmd_env, "sources": cmd_sources, "multimap": cmd_multimap, "graph": cmd_graph, "pipe": cmd_pipe, "streams": cmd_streams,
             "placement": cmd_placement, "stamps": cmd_stamps, "heads": cmd_heads, "target": cmd_target}
     for name, fn in cmds.items():
         p = sub.add_parser(name, help=(fn.__doc__ or "").strip().split("\n")[0])
@@ -406,6 +441,8 @@ def main():
         if name == "hbm":
             p.add_argument("--aligns", default="16,128")
             p.add_argument("--policies", default="auto,0,1", help="LLE_WRITE_THROUGH settings: auto, 0 (plain), 1 (sc1)")
+        if name == "partial":
+            p.add_argument("--sweep", action="store_true", help="also envs per batch, batches per wavefront and the store policy of the lane kernel")
         if name == "stamps":
             p.add_argument("--fine", action="store_true")
         if name == "target":

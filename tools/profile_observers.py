@@ -13,7 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out", "prof_obs")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 PROF = os.path.join(ROOT, "tools", "lle_prof.py")
 COUNTERS = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_WR", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"]
 
@@ -41,25 +41,29 @@ def main():
         if float(r["Percentage"]) >= 0.05:
             lines.append(f"| `{r['Name'][:110]}` | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} | {float(r['Percentage']):.2f} |")
     lines += ["", "Program output (launch-to-launch event timing; a kernel name covers level 6 and config 5):", "```", res.stdout.strip(), "```", "",
-              "## SQ counters of partial 7x7 on level 6: window kernel vs projection kernel", "",
-              "`rocprofv3 --pmc " + " ".join(COUNTERS) + " --kernel-trace -- python3 tools/lle_prof.py target partial -k 7` with `LLE_PARTIAL_PROJECT=0` / `1`; "
-              "medians over the dispatches, per wavefront (the window kernel runs 8 envs per wavefront, the projection 16).", "",
-              "| kernel | waves | " + " | ".join(c.replace("SQ_", "") for c in COUNTERS[1:]) + " | VALU per env |", "|---|---|" + "---|" * len(COUNTERS)]
-    for proj, name, epw in (("0", "partial_observe_kernel", 8), ("1", "partial_project_kernel", 16)):
-        d = os.path.join(OUT, f"pmc{proj}")
-        run(["rocprofv3", "--pmc"] + COUNTERS + ["--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, PROF, "target", "partial", "-k", "7", "--iters", "20"],
-            f"pmc{proj}.err", env={"LLE_PARTIAL_PROJECT": proj})
-        acc = {}
-        for r in csv.DictReader(open(latest(f"pmc{proj}/**/*_counter_collection.csv"))):
-            if name in r["Kernel_Name"]:
-                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-        if not acc:
-            lines.append(f"| `{name}` | (no dispatches found) |")
-            continue
-        med = {k: statistics.median(v) for k, v in acc.items()}
-        waves = med.get("SQ_WAVES", 1.0) or 1.0
-        per = [med.get(c, float("nan")) / waves for c in COUNTERS[1:]]
-        lines.append(f"| `{name}` | {waves:.0f} | " + " | ".join(f"{v:.0f}" for v in per) + f" | {per[0] / epw:.0f} |")
+              "## SQ counters of the partial k x k kernels", "",
+              "`rocprofv3 --pmc " + " ".join(COUNTERS) + " --kernel-trace -- python3 tools/lle_prof.py target partial -k K [--cfg5]` with "
+              "`LLE_PARTIAL_KERNEL=window` / `project` / unset (the lane-per-(env, observer) kernel, round 3); medians over the dispatches, "
+              "per ENVIRONMENT (counter / 65 536) -- the kernels differ in environments per wavefront.", "",
+              "| map | k | kernel | waves | " + " | ".join(c.replace("SQ_", "") + " / env" for c in COUNTERS[1:]) + " |", "|---|---|---|---|" + "---|" * (len(COUNTERS) - 1)]
+    n_envs = 65536
+    for label, extra in (("level 6", []), ("config 5", ["--cfg5"])):
+        for k in ("3", "7"):
+            for which, name in (("window", "partial_observe_kernel"), ("project", "partial_project_kernel"), ("", "partial_lanes_kernel")):
+                d = os.path.join(OUT, f"pmc_{label.replace(' ', '')}_{k}_{which or 'lanes'}")
+                run(["rocprofv3", "--pmc"] + COUNTERS + ["--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, PROF, "target", "partial",
+                     "-k", k, "--iters", "20"] + extra, os.path.basename(d) + ".err", env={"LLE_PARTIAL_KERNEL": which} if which else {})
+                acc = {}
+                f = latest(os.path.basename(d) + "/**/*_counter_collection.csv")
+                for r in (csv.DictReader(open(f)) if f else []):
+                    if name in r["Kernel_Name"]:
+                        acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+                if not acc:
+                    lines.append(f"| {label} | {k} | `{name}` | (no dispatches found) |")
+                    continue
+                med = {kk: statistics.median(v) for kk, v in acc.items()}
+                lines.append(f"| {label} | {k}x{k} | `{name}` | {med.get('SQ_WAVES', 0):.0f} | " +
+                             " | ".join(f"{med.get(c, float('nan')) / n_envs:.1f}" for c in COUNTERS[1:]) + " |")
     text = "\n".join(lines) + "\n"
     open(os.path.join(ROOT, "gpurun_out", f"{tag}_observers_summary.md"), "w").write(text)
     print(text[-2500:])
