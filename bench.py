@@ -22,6 +22,7 @@ env-steps/s is reported next to it.  Objects of the line:
   sustained      the same launches as the --steps region, >= 1000 of them.
   configs        BASELINE.json configs[1] (level 1 x 4 096) and configs[4] (32x32, 8 agents, 8 lasers x 65 536).
   lle_step       BatchedLLE.step (the reference's LLE host class, batched) on the headline workload: us per step.
+  observers      the other observation builders (partial k x k, state, availability) through bound calls: us per launch, GB/s.
   fused_rollout  lle_batch_rollout, 16 steps per launch into a trajectory ring larger than the caches.
   cpu_baseline   the C restatement of the reference algorithm (oracle/) on the host cores, N = 1 only.
 """
@@ -389,15 +390,15 @@ def measure_lle_step(torch, timer, dev, n, steps):
     del ring, rec
     out = {"what": f"lle_amd.BatchedLLE.step(actions, auto_reset=True) on World.level({LEVEL}) x {n} envs: obs (layered) + state + reward + "
                    "done + available_actions per step; us per step, launch-to-launch", "steps": steps}
-    for key, kw, fused in (("two_launches_us", {}, False), ("one_launch_us", {}, True),
-                           ("randomize_lasers_two_launches_us", {"randomize_lasers": True}, False),
-                           ("randomize_lasers_one_launch_us", {"randomize_lasers": True}, True)):
+    for key, kw, mode in (("two_launches_us", {}, {}), ("two_launches_persistent_us", {}, {"persistent": True}), ("one_launch_us", {}, {"fused": True}),
+                          ("randomize_lasers_two_launches_us", {"randomize_lasers": True}, {}),
+                          ("randomize_lasers_one_launch_us", {"randomize_lasers": True}, {"fused": True})):
         env = BatchedLLE(Map(level=LEVEL), n, device=dev, seed=SEED, **kw)
         env.reset()
         state = {"t": 0}
 
         def step():
-            env.step(actions[state["t"] % K], auto_reset=True, fused=fused)
+            env.step(actions[state["t"] % K], auto_reset=True, **mode)
             state["t"] += 1
         for _ in range(W):
             step()
@@ -406,6 +407,33 @@ def measure_lle_step(torch, timer, dev, n, steps):
         out[key] = wall / steps * 1e6
         del env
     torch.cuda.empty_cache()
+    return out
+
+
+def measure_observers(torch, timer, dev, n, steps):
+    """The other observation builders on the headline batch and on config 5: launch-to-launch time of the
+    bound calls (BatchedWorld.bound_*: the C-ABI call and nothing else per launch) and bytes written / time."""
+    from lle_amd import BatchedWorld, Map, _capi, mapgen
+    out = {"what": "observers.hip builders through bound calls, us per launch (HIP events) and GB/s of the bytes they write", "steps": steps}
+    for label, m in (("level6", Map(level=LEVEL)), ("cfg5", Map(mapgen.config5(0)))):
+        bw = BatchedWorld(m, n, device=dev)
+        fn = stepper(bw)
+        for _ in range(16):
+            fn()
+        calls = {f"partial{k}x{k}": bw.bound_observer(_capi.LLE_OBS_PARTIAL, k) for k in (3, 5, 7)}
+        calls["state"] = bw.bound_observer(_capi.LLE_OBS_STATE)
+        calls["available_actions"] = bw.bound_available_actions(True)
+        calls["available_actions_no_walkable_lasers"] = bw.bound_available_actions(False)
+        blk = {}
+        for name, call in calls.items():
+            for _ in range(10):
+                call()
+            _, ms = timer.run(call, steps)
+            nbytes = call.buffer.numel() * call.buffer.element_size()
+            blk[name] = {"us": ms * 1e3, "MB": nbytes / 1e6, "GBps": nbytes / (ms * 1e-3) / 1e9}
+        out[label] = blk
+        del calls, bw
+        torch.cuda.empty_cache()
     return out
 
 
@@ -540,9 +568,10 @@ def main():
                                                      "cfg5_bytes_per_launch", fill_ceiling=True),
         }
 
-    lle_step = None
+    lle_step = observers = None
     if world == 1 and not args.no_configs:
         lle_step = measure_lle_step(torch, timer, dev, n, max(args.config_steps, 200))
+        observers = measure_observers(torch, timer, dev, n, max(args.config_steps, 200))
 
     if rank == 0:
         total_envs = n * world
@@ -588,6 +617,8 @@ def main():
             out["configs"] = cfgs
         if lle_step:
             out["lle_step"] = lle_step
+        if observers:
+            out["observers"] = observers
         for key, (T, R, launches, fe) in zip(("fused_rollout", "fused_rollout_double_buffer"), fused):
             # per env-step: obs 1872 + actions 4 + reward 4 + err/evcount/done 3 + events 8, state r/w (48 B) once per launch
             fused_bytes = 1891 + 48.0 / T

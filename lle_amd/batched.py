@@ -302,6 +302,78 @@ class BatchedWorld:
         flat = out[: int(d.bytes)].view(dt)
         return torch.as_strided(flat, [int(d.shape[k]) for k in range(d.ndim)], [int(d.stride[k]) for k in range(d.ndim)])
 
+    # ---- bound calls: arguments, output buffer and stream fixed ONCE (the stream that is current now); per call the C-ABI call
+    # and nothing else.  observe_as() / available_actions() / env_outputs() spend 10-15 us per call in Python (descriptor query,
+    # allocation, view construction, argument conversion) around kernels of 4-6 us: a host that steps in a loop uses these.
+    def bound_observer(self, kind, param=0, out=None):
+        """A zero-argument callable that writes observation `kind` into ONE persistent buffer (`call.out`: the strided view
+        observe_as() returns; overwritten by every call)."""
+        d = self.obs_desc(kind, param)
+        if not d.supported:
+            raise IndexError("a laser colour has no layer in this observation (the reference raises IndexError too)")
+        if out is None:
+            out = torch.empty(int(d.bytes) + 256, dtype=torch.uint8, device=self.device)
+            out = out[(-out.data_ptr()) % 256:][: int(d.bytes)]
+        assert out.dtype == torch.uint8 and out.is_contiguous() and out.numel() >= d.bytes and out.data_ptr() % 16 == 0
+        dt = torch.int8 if d.elem_bytes == 1 else torch.float32
+        view = torch.as_strided(out[: int(d.bytes)].view(dt), [int(d.shape[k]) for k in range(d.ndim)], [int(d.stride[k]) for k in range(d.ndim)])
+        fn = _capi.lib().lle_batch_observe_as
+        args = (C.c_void_p(self.h), C.c_int(int(kind)), C.c_int(int(param)), C.c_void_p(out.data_ptr()), C.c_int64(out.numel()), self._stream())
+
+        def call():
+            rc = fn(*args)
+            if rc != 0:
+                self._check(rc)
+            return view
+        call.out, call.buffer = view, out
+        return call
+
+    def bound_available_actions(self, walkable_lasers=True, out=None):
+        """Zero-argument callable for available_actions(): bool [n, A, 5] in `call.out`, overwritten by every call."""
+        if out is None:
+            out = torch.empty((self.n_envs, self.map.n_agents, 5), dtype=torch.uint8, device=self.device)
+        fn = _capi.lib().lle_batch_available_actions
+        args = (C.c_void_p(self.h), C.c_int(int(bool(walkable_lasers))), C.c_void_p(out.data_ptr()), self._stream())
+        view = out.view(torch.bool)
+
+        def call():
+            rc = fn(*args)
+            if rc != 0:
+                self._check(rc)
+            return view
+        call.out, call.buffer = view, out
+        return call
+
+    def bound_env_outputs(self, **tensors):
+        """Zero-argument callable for env_outputs() over fixed tensors (same keyword arguments)."""
+        o = self.make_env_outputs(**tensors)
+        fn = _capi.lib().lle_batch_env_outputs
+        args = (C.c_void_p(self.h), C.byref(o), self._stream())
+
+        def call():
+            rc = fn(*args)
+            if rc != 0:
+                self._check(rc)
+        call.struct, call.tensors = o, tensors  # (kept alive with the callable)
+        return call
+
+    def bound_step(self, auto_reset=False, recolour_resets=False, write_obs=True, seed=0, env_offset=0, env_out=None):
+        """`fn(actions)` = step(actions, ...) with the flags, the stream and the output struct fixed; `actions` must already be a
+        contiguous uint8 [n, A] tensor on this device (no conversion, no checks).  The time index advances by one per call."""
+        flags = ((LLE_STEP_AUTO_RESET if auto_reset else 0) | (LLE_STEP_RECOLOUR_RESETS if recolour_resets else 0) |
+                 (0 if write_obs else LLE_STEP_NO_OBS))
+        L, h, st, seed, env_offset = _capi.lib(), C.c_void_p(self.h), self._stream(), int(seed), int(env_offset)
+        fn = L.lle_batch_step_outputs if env_out is not None else L.lle_batch_step
+        tail = (C.byref(env_out), st) if env_out is not None else (st,)
+
+        def call(actions):
+            t = self.t
+            rc = fn(h, actions.data_ptr(), flags, seed, t, env_offset, *tail)
+            if rc != 0:
+                self._check(rc)
+            self.t = t + 1
+        return call
+
     def available_actions(self, walkable_lasers=True, out=None):
         """LLE.available_actions (python/lle/env/env.py:146-163) for every env: bool [n, A, 5] in Action value order."""
         if out is None:

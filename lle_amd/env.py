@@ -66,6 +66,7 @@ class BatchedLLE:
         # of the map carries more than two laser layers (then: a launch of lle_batch_reset_sources per step)
         self._recolour_in_step = self.randomize_lasers and all(m.max_cell_layers <= 2 for m in self.world.maps)
         self._fused = None  # output tensors + lle_env_outputs of the one-launch step (step(..., fused=True))
+        self._bound = {}    # bound calls over persistent buffers (step(..., persistent=True)): BatchedWorld.bound_*
 
     @staticmethod
     def _kind(name, padding_size):
@@ -221,11 +222,14 @@ class BatchedLLE:
             self._fused = (t, o)
         return self._fused
 
-    def step(self, actions, auto_reset=False, fused=False):
+    def step(self, actions, auto_reset=False, fused=False, persistent=False):
         """LLE.step (env.py:165-187) for every env.  actions: integer tensor [n, n_agents] (Action values).
         fused=True (needs walkable_lasers): state / reward / available_actions are written by the step kernel itself
         (lle_batch_step_outputs) into PERSISTENT tensors that the next step overwrites -- one launch per step instead of
         two (25.3 -> 21.6 us at 65 536 level-6 envs); the default returns fresh tensors every step.
+        persistent=True: the two-launch step (any walkable_lasers, any observation / state type) through calls bound once
+        (BatchedWorld.bound_*) into persistent tensors that the next step overwrites: the host side of a step is two C-ABI
+        calls (three with an observation type other than layered) instead of allocations, descriptor queries and views.
         The reference refuses to step a finished environment (`Cannot step in a done environment`); here such an env
         is the caller's to reset -- or pass auto_reset=True: an env that is done when the step starts is reset first
         (with fresh colours under randomize_lasers), the usual vector-env convention.
@@ -233,9 +237,12 @@ class BatchedLLE:
         Returns a dict of device tensors: obs, state, reward, done, available_actions, err (per-env error code of
         World.step: 0 or 1 + the agent whose action was not available, the env then being left untouched)."""
         w = self.world
-        actions = actions.to(w.device, torch.uint8).contiguous()
+        if actions.dtype is not torch.uint8 or actions.device != w.device or not actions.is_contiguous():
+            actions = actions.to(w.device, torch.uint8).contiguous()
         if fused and not self.walkable_lasers:
             raise ValueError("the one-launch step writes available_actions with walkable_lasers only")
+        if persistent and not fused:
+            return self._step_persistent(actions, auto_reset)
         env_out = self._fused_outputs()[1] if fused else None
         if auto_reset:
             if self._recolour_in_step:
@@ -257,6 +264,49 @@ class BatchedLLE:
             return {"obs": self.get_observation(), "state": t["state"] if t["state"] is not None else self.get_state(), "reward": t["reward"],
                     "done": self.done, "available_actions": t["available"].view(torch.bool), "err": w.err}
         return self._outputs()
+
+    def _step_persistent(self, actions, auto_reset):
+        """step(persistent=True): see step()."""
+        w, b = self.world, self._bound
+        key = ("step", bool(auto_reset))
+        if key not in b:
+            n, dev = self.n_envs, w.device
+            plain_state = self._state_kind[0] in (_capi.LLE_OBS_STATE, _capi.LLE_OBS_NORMALIZED_STATE)
+            if "outs" not in b:
+                t = {"state": torch.empty((n, 3 * self.n_agents + w.map.n_gems), dtype=torch.float32, device=dev) if plain_state else None,
+                     "reward": torch.empty((n, 4 if self.multi_objective else 1), dtype=torch.float32, device=dev),
+                     "available": torch.empty((n, self.n_agents, 5), dtype=torch.uint8, device=dev)}
+                b["outs"] = (t, w.bound_env_outputs(state=t["state"], normalize_state=self._state_kind[0] == _capi.LLE_OBS_NORMALIZED_STATE,
+                                                    reward=t["reward"], multi_objective=self.multi_objective, available=t["available"],
+                                                    walkable_lasers=self.walkable_lasers))
+                b["obs"] = None if self._obs_kind[0] == _capi.LLE_OBS_LAYERED else w.bound_observer(*self._obs_kind)
+                b["state"] = None if plain_state or self._state_kind[0] == _capi.LLE_OBS_LAYERED else (
+                    b["obs"] if self._state_kind == self._obs_kind and b["obs"] is not None else w.bound_observer(*self._state_kind))
+            recolour = auto_reset and self._recolour_in_step
+            in_kernel_reset = auto_reset and (recolour or not self.randomize_lasers)
+            b[key] = w.bound_step(auto_reset=in_kernel_reset, recolour_resets=recolour, write_obs=self._needs_layered, seed=self._seed_value)
+        if auto_reset and self.randomize_lasers and not self._recolour_in_step:
+            self._reset_world(w.done, write_obs=False)
+        w.t = self._t
+        b[key](actions)
+        self._t += 1
+        t, outs = b["outs"]
+        outs()
+        obs = w.obs if b["obs"] is None else b["obs"]()
+        if self.obs_type == "flattened":
+            obs = obs.flatten(1)
+        if t["state"] is not None:
+            state = t["state"]
+        elif b["state"] is None:
+            state = w.obs
+        else:
+            state = b["state"].out if b["state"] is b["obs"] else b["state"]()
+            if self._state_kind[0] in (_capi.LLE_OBS_PARTIAL, _capi.LLE_OBS_PERSPECTIVE):
+                state = state[:, 0]
+        if t["state"] is None and self.state_type == "flattened":
+            state = state.flatten(1)
+        return {"obs": obs, "state": state, "reward": t["reward"], "done": self.done, "available_actions": t["available"].view(torch.bool),
+                "err": w.err}
 
     def _outputs(self):
         """obs / state / reward / done / available_actions / err after a step: one launch of lle_batch_env_outputs for

@@ -439,3 +439,34 @@ def test_restore_does_not_bring_back_an_old_output_descriptor():
         x, y = a.step(acts, auto_reset=True, fused=True), b.step(acts, auto_reset=True)
         for k in ("obs", "state", "reward", "done", "available_actions", "err"):
             assert torch.equal(x[k], y[k]), (k, t)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(walkable_lasers=False, multi_objective=True), dict(obs_type="partial5x5", state_type="normalized-state"),
+                                dict(obs_type="flattened", state_type="layered"), dict(obs_type="perspective", state_type="perspective"),
+                                dict(randomize_lasers=True), dict(obs_type="layered-padded-2", state_type="partial3x3")])
+def test_persistent_step_equals_the_allocating_step(kw):
+    """BatchedLLE.step(persistent=True) -- bound C-ABI calls into persistent tensors (BatchedWorld.bound_step / bound_env_outputs /
+    bound_observer) -- returns what the default step returns, for every observation / state pairing and option."""
+    import torch
+
+    from lle_amd import BatchedLLE
+
+    n = 768
+    a, b = BatchedLLE(LEVELS[6], n, seed=5, **kw), BatchedLLE(LEVELS[6], n, seed=5, **kw)
+    a.reset(), b.reset()
+    if kw.get("randomize_lasers"):
+        b.world.set_sources(colours=a.world.src_colour[:, : a.world.map.n_sources].clone())
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for t in range(20):
+        avail = a.available_actions()
+        acts = torch.multinomial(avail.reshape(-1, 5).float() + 1e-6, 1, generator=g).reshape(n, -1).to(torch.uint8)  # (now and then a refused one)
+        x, y = a.step(acts, auto_reset=True, persistent=True), b.step(acts, auto_reset=True)
+        for k in ("obs", "state", "reward", "done", "available_actions", "err"):
+            assert x[k].shape == y[k].shape and torch.equal(x[k], y[k]), (kw, t, k)
+    # the bound calls on their own
+    w = a.world
+    from lle_amd import _capi
+    f = w.bound_observer(_capi.LLE_OBS_PARTIAL, 3)
+    assert torch.equal(f(), w.observe_as(_capi.LLE_OBS_PARTIAL, 3)) and f() is f.out
+    h = w.bound_available_actions(False)
+    assert torch.equal(h(), w.available_actions(False))

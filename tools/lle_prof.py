@@ -171,7 +171,16 @@ def cmd_observers(args):
         out = torch.empty((n, A, 5), dtype=torch.uint8, device="cuda")
         for wl in (True, False):
             us = timeit(lambda: bw.available_actions(wl, out=out), iters=50, warm=5)
-            print(f"{label:14s} available_actions(walkable_lasers={wl})  {us:8.2f} us", flush=True)
+            bound = bw.bound_available_actions(wl)
+            print(f"{label:14s} available_actions(walkable_lasers={wl})  {us:8.2f} us   bound call {timeit(bound, iters=200, warm=20):8.2f} us", flush=True)
+        for name, kind in (("state", _capi.LLE_OBS_STATE), ("partial3x3", _capi.LLE_OBS_PARTIAL)):
+            bound = bw.bound_observer(kind, 3 if kind == _capi.LLE_OBS_PARTIAL else 0)
+            print(f"{label:14s} bound_observer({name})  {timeit(bound, iters=200, warm=20):8.2f} us", flush=True)
+        st, rw, av = (torch.empty((n, 3 * A + bw.map.n_gems), device="cuda"), torch.empty((n, 1), device="cuda"),
+                      torch.empty((n, A, 5), dtype=torch.uint8, device="cuda"))
+        us = timeit(lambda: bw.env_outputs(state=st, reward=rw, available=av), iters=200, warm=20)
+        bound = bw.bound_env_outputs(state=st, reward=rw, available=av)
+        print(f"{label:14s} env_outputs(state, reward, available)  {us:8.2f} us   bound call {timeit(bound, iters=200, warm=20):8.2f} us", flush=True)
         us = timeit(bw.observe, iters=50, warm=5)
         print(f"{label:14s} observe() (layered, world_kernel)  {us:8.2f} us  {bw.map.obs_bytes*n/us/1e3:6.0f} GB/s", flush=True)
         del bw
