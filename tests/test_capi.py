@@ -263,3 +263,32 @@ def test_map_set_exits_and_clone(oracle_mod, tmp_path):
     assert pe.value.kind == "NotEnoughExitTiles" and w.exit_pos == new
     w.save(str(tmp_path / "lvl.txt"))
     assert World.from_file(str(tmp_path / "lvl.txt")).exit_pos == sorted(new)
+
+
+def test_limits_are_refused_loudly(oracle_mod):
+    """include/lle_hip.h LLE_MAX_*: a map beyond a static limit is refused with LLE_PARSE_LIMIT -- never
+    clamped, never a silent wrong answer; the same map at the limit is accepted and matches the oracle's parser."""
+    from lle_amd import World, _capi
+    from lle_amd.world import ParsingError
+
+    def corridor(n):  # a source followed by n free cells: a beam of n cells (agent 0's own colour, so its start may lie on it)
+        return "L0E " + ". " * (n - 2) + "S0 X"
+    ok = _capi.Map(corridor(32))
+    assert ok.max_beam_len == 32 and ok.width == 33
+    o = oracle_mod.OracleWorld(corridor(32))
+    assert [s.length for s in ok.sources()] == [s[5] for s in o.sources()] == [32]
+    with pytest.raises(_capi.MapParseError) as e:
+        _capi.Map(corridor(33))
+    assert e.value.kind == "Limit"
+    assert oracle_mod.OracleWorld(corridor(33)).sources()[0][5] == 33  # (legal in the reference: laser.rs:15-21 has no bound)
+    with pytest.raises(ParsingError, match="static limit"):
+        World(corridor(40))
+    with pytest.raises(_capi.MapParseError) as e:  # 17 agents
+        _capi.Map(" ".join(f"S{k}" for k in range(17)) + "\n" + " ".join("X" for _ in range(17)))
+    assert e.value.kind == "Limit"
+    with pytest.raises(_capi.MapParseError) as e:  # 33 gems
+        _capi.Map("S0 X " + "G " * 33)
+    assert e.value.kind == "Limit"
+    with pytest.raises(_capi.MapParseError) as e:  # a side of 256
+        _capi.Map("S0 X " + ". " * 254)
+    assert e.value.kind == "Limit"
