@@ -158,6 +158,11 @@ int lle_map_set_head_lines(lle_map* map, int lines);
 /* The head chosen for the map's current sources: byte offset inside a row and length (0 = no head). */
 int lle_map_row_head(const lle_map* map, int32_t* first_byte, int32_t* n_bytes);
 
+/* The same for batches with per-environment sources (lle_batch_set_sources): the lines that hold no byte an agent, a gem or a
+ * laser of ANY colour below n_agents can change (WALL / VOID / EXIT planes).  0 bytes when a source of the map itself has a
+ * colour >= n_agents (quirk Q5: its layer aliases those planes). */
+int lle_map_row_head_env_sources(const lle_map* map, int32_t* first_byte, int32_t* n_bytes);
+
 /* static description of World.lasers (src/core/world.rs:159-172): per laser position the outer layer and, if
  * nested, the second one; `offset` indexes the beam mask of `laser_id`. */
 typedef struct lle_laser_tile { int32_t i, j, laser_id, offset, layer; } lle_laser_tile;

@@ -48,6 +48,7 @@ hipError_t launch_step_mode4(int G, int lm, const BatchPtrs& P, const LaunchArgs
 hipError_t launch_step_mode5(int G, int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream);
 hipError_t launch_step_mode6(int G, int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream);
 hipError_t launch_step_mode7(int G, int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream);
+hipError_t launch_step_mode8(int G, int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream);
 bool write_through_pays(uint64_t bytes, uint32_t row_pitch);  // store policy of an observation stream (obs_stream.hpp: stream_store)
 hipError_t launch_world_kernel(int mode, const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K, hipStream_t stream);
 // World.step with one lane per agent (the default step path)

@@ -48,11 +48,10 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
     } while (0)
     LLE_STAMP(0);
     const uint32_t tab_bytes = hdr->lds_table_bytes, tab_off = hdr->off_cell_lay;
-    copy_tables_to_lds(tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
     // per-environment sources (lle_batch_set_sources): the bare static observation + element list follow in LDS
     const bool pes = (K.flags & LAUNCH_PER_ENV_SOURCES) != 0;
     const uint32_t ext_bytes = pes ? hdr->ext_bytes : 0u;
-    if (pes) copy_tables_to_lds(tables + hdr->off_bare, lds + tab_bytes, ext_bytes, lane, wave_in_wg, waves_per_wg);
+    copy_tables2_to_lds(tables + tab_off, tab_bytes, tables + hdr->off_bare, ext_bytes, lds, lane, wave_in_wg, waves_per_wg);
     LLE_STAMP(7);
     __syncthreads();  // the only workgroup barrier: nothing is in flight yet but the loads above
     // ---- the env's packed state and (for auto-reset) the reset-state record, requested raw and together.  (Issued
@@ -582,7 +581,12 @@ hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const Laun
     // MODE of the instantiation (step_kernel.hpp): per-env sources 3 / 5, several maps 2 / 4, one map 1 / 0 -- the
     // first of each pair with the rollout loop, rings and stamps, the second for single-step launches
     const bool roll = (K.flags & LAUNCH_ROLLOUT) != 0;
-    if (pes) return roll ? launch_step_mode3(G, lm, P, K, n_waves, wpw, lds, stream) : launch_step_mode5(G, lm, P, K, n_waves, wpw, lds, stream);
+    if (pes) {
+        if (roll) return launch_step_mode3(G, lm, P, K, n_waves, wpw, lds, stream);
+        // single steps: the colour-independent head lines ahead of the state machine (MODE 8) under the same conditions as below
+        const bool heads_pes = lm <= 8 && h.pes_head_n != 0 && !(K.flags & (LAUNCH_SPLIT_ROWS | STEP_NO_OBS)) && row_heads_pay(n_waves);
+        return heads_pes ? launch_step_mode8(G, lm, P, K, n_waves, wpw, lds, stream) : launch_step_mode5(G, lm, P, K, n_waves, wpw, lds, stream);
+    }
     // single-step launches with the map's sources: the rows' head lines go out ahead of the state machine (MODE 6 / 7) when
     // the map has a head, the rows are not split and the launch is of the size where it pays
     const bool heads = !roll && lm <= 8 && h.head_n != 0 && !(K.flags & (LAUNCH_SPLIT_ROWS | STEP_NO_OBS)) && row_heads_pay(n_waves);

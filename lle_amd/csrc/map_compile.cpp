@@ -466,6 +466,29 @@ void Map::compile() {
         h.head_n = best_n * 8u;
     }
 
+    // the same for environments with their own source colours (tables.h pes_head_*): a laser byte may then sit on any of the
+    // A laser layers, so the whole of [0, 2A * HW) is dynamic; behind it only the gem bytes are
+    if (h.obs_stride % 128u == 0 && h.obs_supported) {
+        bool plain_colours = true;
+        for (auto& src : sources) plain_colours = plain_colours && src.agent_id < A;
+        const uint32_t n_lines = h.obs_stride / 128u;
+        std::vector<uint8_t> dynamic_line(n_lines, 0);
+        for (uint32_t l = 0; l < n_lines && l * 128u < (uint32_t)(2 * A * HW); l++) dynamic_line[l] = 1;
+        for (int g = 0; g < G; g++) dynamic_line[(uint32_t)((2 * A + 2) * HW + gems[g].i * W + gems[g].j) / 128u] = 1;
+        uint32_t best_lo = 0, best_n = 0;
+        for (uint32_t l = 0; l < n_lines && plain_colours;) {
+            if (dynamic_line[l]) { l++; continue; }
+            uint32_t e = l;
+            while (e < n_lines && !dynamic_line[e]) e++;
+            if (e - l > best_n) { best_lo = l; best_n = e - l; }
+            l = e;
+        }
+        const uint32_t want = head_lines < 0 ? std::max(1u, (n_lines + 2u) / 5u) : (uint32_t)head_lines;
+        best_n = std::min(best_n, std::min(want, 8u));
+        h.pes_head_lo = best_lo * 8u;
+        h.pes_head_n = best_n * 8u;
+    }
+
     // ---- assemble blob
     auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     size_t off = sizeof(MapHeader);

@@ -54,6 +54,30 @@ __device__ __forceinline__ void copy_tables_to_lds(const uint8_t* __restrict__ t
     }
 }
 
+// Two sections into consecutive LDS ranges (the map tables and, behind them, the per-env-sources section), with the rows of BOTH
+// requested before the first LDS write: called one after the other, the second copy's loads would only be issued once the
+// first copy's have returned -- a second global round trip in front of every workgroup's first instruction of real work.
+__device__ __forceinline__ void copy_tables2_to_lds(const uint8_t* __restrict__ t1, uint32_t bytes1, const uint8_t* __restrict__ t2, uint32_t bytes2,
+                                                    uint8_t* lds, uint32_t lane, uint32_t wave_in_wg, uint32_t waves_per_wg) {
+    const u32x4* __restrict__ s1 = reinterpret_cast<const u32x4*>(t1) + lane;
+    const u32x4* __restrict__ s2 = reinterpret_cast<const u32x4*>(t2) + lane;
+    u32x4* dst = reinterpret_cast<u32x4*>(lds) + lane;
+    const uint32_t rows1 = bytes1 / 1024, rows = rows1 + bytes2 / 1024;
+    auto src = [&](uint32_t r) -> const u32x4* { return r < rows1 ? s1 + r * 64 : s2 + (r - rows1) * 64; };
+    for (uint32_t r0 = wave_in_wg; r0 < rows; r0 += 4 * waves_per_wg) {
+        const uint32_t r1 = r0 + waves_per_wg, r2 = r1 + waves_per_wg, r3 = r2 + waves_per_wg;
+        u32x4 v0 = *src(r0), v1 = {0, 0, 0, 0}, v2 = {0, 0, 0, 0}, v3 = {0, 0, 0, 0};
+        if (r1 < rows) v1 = *src(r1);
+        if (r2 < rows) v2 = *src(r2);
+        if (r3 < rows) v3 = *src(r3);
+        __builtin_amdgcn_sched_barrier(0);  // keep the loads together, ahead of the LDS writes
+        dst[r0 * 64] = v0;
+        if (r1 < rows) dst[r1 * 64] = v1;
+        if (r2 < rows) dst[r2 * 64] = v2;
+        if (r3 < rows) dst[r3 * 64] = v3;
+    }
+}
+
 // ---- the stores of an observation stream.
 // WT = write-through (`sc1`: agent scope, so the line leaves the XCD's L2 for the Infinity Cache as it is written).
 // A plain store leaves the row dirty in L2 and the end of the kernel writes all of it back before the next launch can
@@ -266,23 +290,36 @@ __device__ __forceinline__ void elem_eval(uint32_t e, const uint32_t* sc, int A,
     val = type == ELEM_SOURCE ? -1 : 1;
     on = type == ELEM_SOURCE ? true : (is_gem ? ((sc[L + 1] >> i5) & 1u) != 0 : ((sc[1 + i5] >> off) & 1u) != 0);
 }
-template <bool WT>
+template <bool WT, bool HEAD = false>
 __device__ __forceinline__ void write_observations_env(int A, int L, uint32_t HW, uint32_t n_elems, uint32_t n_chunks,
                                                        uint64_t obs_stride, const uint32_t* elems, const int8_t* bare,
                                                        int8_t* tmpl, const uint32_t* scratch, uint32_t scr_stride,
                                                        int8_t* __restrict__ obs, int64_t env0, int64_t n_here, uint32_t lane,
-                                                       const uint8_t* laser_layer = nullptr, uint32_t gem_layer_in = 0xFFFFFFFFu) {
+                                                       const uint8_t* laser_layer = nullptr, uint32_t gem_layer_in = 0xFFFFFFFFu,
+                                                       uint32_t head_lo = 0, uint32_t head_n = 0) {
     const uint32_t gem_layer = gem_layer_in == 0xFFFFFFFFu ? (uint32_t)(2 * A + 2) : gem_layer_in;
     const bool has_e0 = lane < n_elems;
     const uint32_t e0 = has_e0 ? elems[lane] : 0u;
+    // the lane serves the same element for every environment: what does not depend on the environment is decoded once --
+    // the cell, the record word and shift that hold its colour, the record word and bit that say whether it shows
+    const uint32_t e0_cell = e0 & 0xFFFFu, e0_i5 = (e0 >> 16) & 31u, e0_off = (e0 >> 21) & 31u, e0_type = (e0 >> 26) & 3u;
+    const bool e0_gem = e0_type == ELEM_GEM, e0_src = e0_type == ELEM_SOURCE;
+    const uint32_t e0_colw = (uint32_t)(L + 2 + A) + (e0_i5 >> 2), e0_colsh = (e0_i5 & 3u) * 8u;
+    const uint32_t e0_onw = e0_gem ? (uint32_t)L + 1u : (e0_src ? 0u : 1u + e0_i5);   // gem: ~collected bits; tile: the beam mask; source: always
+    const uint32_t e0_onsh = e0_gem ? e0_i5 : e0_off;
+    const int8_t e0_val = e0_src ? (int8_t)-1 : (int8_t)1;
+    // byte index = e0_base + colour * e0_mul (Layered: layer LASER_0 + colour; a gem: its own layer, whatever the colour word says)
+    const uint32_t e0_base = (e0_gem ? gem_layer : (uint32_t)A) * HW + e0_cell, e0_mul = (e0_gem || laser_layer) ? 0u : HW;
+    const uint32_t e0_always = (has_e0 && e0_src) ? 1u : 0u, e0_dyn = (has_e0 && !e0_src) ? 1u : 0u;
     const bool is_agent_lane = (int)lane < A;
     const uint4* srcv = reinterpret_cast<const uint4*>(tmpl);
     for (int64_t k = 0; k < n_here; k++) {
         const uint32_t* sc = scratch + (uint32_t)k * scr_stride;
-        uint32_t idx0; int32_t val0; bool on0;
-        elem_eval(e0, sc, A, L, HW, laser_layer, gem_layer, idx0, val0, on0);
-        on0 = on0 && has_e0;
-        if (on0) tmpl[idx0] = (int8_t)val0;
+        const uint32_t colour = (sc[e0_colw] >> e0_colsh) & 0xFFu, onw = sc[e0_onw];
+        uint32_t idx0 = e0_base + __umul24(colour, e0_mul);
+        if (laser_layer && !e0_gem) idx0 = (uint32_t)laser_layer[colour] * HW + e0_cell;   // views: the layer of colour c is a table
+        const bool on0 = ((e0_always | (e0_dyn & (onw >> e0_onsh))) & 1u) != 0u;
+        if (on0) tmpl[idx0] = e0_val;
         for (uint32_t d = lane + 64u; d < n_elems; d += 64) {
             uint32_t idx; int32_t val; bool on;
             elem_eval(elems[d], sc, A, L, HW, laser_layer, gem_layer, idx, val, on);
@@ -292,10 +329,17 @@ __device__ __forceinline__ void write_observations_env(int A, int L, uint32_t HW
         if (is_agent_lane) tmpl[agent_idx] = 1;
         wave_sync();
         uint4* __restrict__ dst = reinterpret_cast<uint4*>(obs + (uint64_t)(env0 + k) * obs_stride);
-        stream_whole_row<WT>(dst, srcv, n_chunks, lane);
+        if constexpr (HEAD) stream_row_tail<WT>(dst, srcv, n_chunks, head_lo, head_n, lane);  // (the head is stored already: store_heads)
+        else stream_whole_row<WT>(dst, srcv, n_chunks, lane);
         wave_sync();
-        // bare bytes back (LDS is in order: after the reads above, before the next environment's writes)
-        if (on0) tmpl[idx0] = bare[idx0];
+        // bare bytes back (LDS is in order: after the reads above, before the next environment's writes).  On the agent / laser
+        // planes and at a gem the bare byte is zero; only a colour >= n_agents, whose layer aliases WALL / VOID / GEM / EXIT
+        // (quirk Q5), has one to read back -- a round trip of the wavefront's per-environment chain that the rest skips
+        if (on0) {
+            int8_t back = 0;
+            if (!e0_gem && colour >= (uint32_t)A) back = bare[idx0];
+            tmpl[idx0] = back;
+        }
         for (uint32_t d = lane + 64u; d < n_elems; d += 64) {
             uint32_t idx; int32_t val; bool on;
             elem_eval(elems[d], sc, A, L, HW, laser_layer, gem_layer, idx, val, on);

@@ -41,6 +41,9 @@ namespace lle {
 // of its own: a launch without heads runs 0.2-0.4 us slower with that load order (level 1: 5.9 -> 6.1 us at 4 096 envs).
 // Maps with at most 8 sources (with the beam masks in LDS, BM below, this lane's share of them is read up front into registers).
 // MODE 7: the same for MODE 4 (several maps / the fused LLE.step outputs).
+// MODE 8: the same for MODE 5 (per-environment sources: LLE.step with randomize_lasers): the head is the part of the row that no
+// colouring can touch (tables.h pes_head_*: WALL / VOID / EXIT lines), stored from the BARE template; every load of the
+// prologue -- the env's colours, enabled mask and own reset record among them -- is in flight before the table copy.
 // LX >= 0: the exact number of sources, known at compile time (instantiated for the default path of maps with at
 // most four sources: the per-beam loops lose their guards and the unused beam registers disappear; 0.4 us on level 6).
 // A 64-byte struct at a wave-uniform address that only the host writes, through the scalar cache.
@@ -56,8 +59,8 @@ __device__ __forceinline__ EnvOutputs load_uniform(const EnvOutputs* p) {
 
 template <int G, int LM, int MODE, bool ML1, int LX = -1>
 __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P, LaunchArgs K) {
-    constexpr bool GEN = (MODE >= 2 && MODE <= 5) || MODE == 7, ROLL = MODE >= 1 && MODE <= 3;
-    constexpr bool PES = MODE == 3 || MODE == 5;  // (the launcher picks these exactly when LAUNCH_PER_ENV_SOURCES is set)
+    constexpr bool GEN = (MODE >= 2 && MODE <= 5) || MODE == 7 || MODE == 8, ROLL = MODE >= 1 && MODE <= 3;
+    constexpr bool PES = MODE == 3 || MODE == 5 || MODE == 8;  // (the launcher picks these exactly when LAUNCH_PER_ENV_SOURCES is set)
     // More than 4 sources: the beam masks live in the env's LDS record instead of LM registers of every lane (step_lanes.hpp BM;
     // per-env-sources rollouts keep the registers: see DESIGN).  4 agents and 8 sources: state machine 11.5 -> 8.9 us, config 5
     // (8 agents, 8 sources) 41.6 -> 20.1, 20 sources 121 -> 15.
@@ -68,7 +71,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     // instantiations of maps with more than four agents carry it (rows of 16 KB and more with at most four agents
     // would need maps beyond 36 x 36; those stay on whole-row copies), and not the per-env-sources modes.
     constexpr bool CAN_SPLIT = G >= 8 && !PES;
-    constexpr bool HEAD = MODE == 6 || MODE == 7;  // MODE 0 / 4 with the static lines of the rows ahead of the state machine (below)
+    constexpr bool HEAD = MODE == 6 || MODE == 7 || MODE == 8;  // MODE 0 / 4 / 5 with the static lines of the rows ahead of the state machine (below)
     const bool split = CAN_SPLIT && (K.flags & LAUNCH_SPLIT_ROWS) != 0;
     // The default instantiation is one step in place and nothing else: the fused rollout (n_steps, trajectory rings)
     // and the timeline stamps run on the general one, so that their arguments do not occupy scalar registers here.
@@ -118,10 +121,11 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     const uint32_t h_off_recolour = PES ? hdr->off_recolour : 0u, h_off_bare = PES ? hdr->off_bare : 0u;
     const uint32_t h_off_elems = PES ? hdr->off_elems : 0u, h_n_elems = PES ? hdr->n_elems : 0u;
     // (MODE 7: so are the fused LLE.step outputs' descriptor and the header fields of that epilogue)
-    constexpr bool ENV_OUT = MODE == 4 || MODE == 5 || MODE == 7;
+    constexpr bool ENV_OUT = MODE == 4 || MODE == 5 || MODE == 7 || MODE == 8;
     EnvOutputs O_early = {};
     uint32_t h_G = 0, h_H = 0;
-    constexpr bool EARLY_OUT = HEAD && ENV_OUT;  // (MODE 4 / 5 have no scalar registers to park the descriptor in: they spill vector registers for it)
+    constexpr bool EARLY_OUT = MODE == 7;  // (MODE 4 / 5 / 8 have no scalar registers to park the descriptor in: they spill vector registers for it;
+                                           //  they fetch it where it is used through the scalar cache, load_uniform: no vmcnt wait behind the head stores)
     if (EARLY_OUT && K.env_out) O_early = *K.env_out;
     if (ENV_OUT) { h_G = hdr->G; h_H = hdr->H; }
     uint32_t h_init_beams[LR];  // the reset state's beams (shared record; the per-env one is read where it is used)
@@ -180,7 +184,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     for (int k = 0; k < BPL; k++) bm_pre[k] = 0u;
     // The wavefront's counters, likewise (kernel_common.hpp: flush_stats); the default single-step instantiations only --
     // the general ones have no registers to spare, a rollout flushes once per launch.
-    constexpr bool PRE_STATS = (MODE == 0 || MODE == 6 || MODE == 7) && LM <= 8;  // (16 / 32 beam registers: already spilling; MODE 4 / 5: they spill more with it)
+    constexpr bool PRE_STATS = (MODE == 0 || MODE == 6 || MODE == 7 || MODE == 8) && LM <= 8;  // (16 / 32 beam registers: already spilling; MODE 4 / 5: they spill more with it)
     int64_t stats_old = 0;
     // (a macro, not a lambda: with the beam registers captured by reference the 32-source instantiations kept them in scratch)
 #define LLE_LOAD_STATE() \
@@ -228,10 +232,11 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     // kernel is therefore issued first -- the head chunk, the state, the caller's actions, the table rows -- and has
     // returned before the first store: the vmcnt counter is in order, so a load waited for AFTER the head stores would
     // wait for their acknowledgements (and the compiler does not see the `sc1` stores, which are inline asm).
-    const uint32_t head_lo = HEAD ? hdr->head_lo : 0u, head_n = (HEAD && write_obs && !split) ? hdr->head_n : 0u;
+    const uint32_t head_lo = HEAD ? (PES ? hdr->pes_head_lo : hdr->head_lo) : 0u;
+    const uint32_t head_n = (HEAD && write_obs && !split) ? (PES ? hdr->pes_head_n : hdr->head_n) : 0u;
     uint4 head_v = {0u, 0u, 0u, 0u};
     if (HEAD) {
-        if (lane < head_n) head_v = reinterpret_cast<const uint4*>(tables + h_off_template)[head_lo + lane];
+        if (lane < head_n) head_v = reinterpret_cast<const uint4*>(tables + (PES ? h_off_bare : h_off_template))[head_lo + lane];
         LLE_LOAD_STATE();
     }
     // BM: [length masks | beams of the reset state], one copy per workgroup behind the tables; read here, ahead of the table rows
@@ -242,9 +247,9 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     }
     // (split rows: the pristine static observation stays in global memory, every wavefront copies its slice from there)
     const uint32_t tab_bytes = split ? hdr->lds_split_table_bytes : hdr->lds_table_bytes, tab_off = hdr->off_cell_lay;
-    copy_tables_to_lds(tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
     const uint32_t ext_bytes = PES ? hdr->ext_bytes : 0u;
-    if (PES) copy_tables_to_lds(tables + h_off_bare, lds + tab_bytes, ext_bytes, lane, wave_in_wg, waves_per_wg);
+    if (PES) copy_tables2_to_lds(tables + tab_off, tab_bytes, tables + h_off_bare, ext_bytes, lds, lane, wave_in_wg, waves_per_wg);
+    else copy_tables_to_lds(tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
     constexpr uint32_t bt_bytes = BM ? 2u * LM * 4u : 0u;
     uint32_t* beam_tab = reinterpret_cast<uint32_t*>(lds + tab_bytes + ext_bytes);
     if (BM && (int)threadIdx.x < L) {
@@ -550,10 +555,10 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     } else if (write_obs && n_here > 0) {
         const bool wt = (K.flags & LAUNCH_WRITE_THROUGH) != 0;  // see stream_store (obs_stream.hpp)
         if (PES) {
-            if (wt) write_observations_env<true>(A, L, h_HW, h_n_elems, h_n_chunks, h_obs_stride, elems, bare, tmpl, scratch, scr_stride,
-                                                 obs_out, env0, n_here, lane);
-            else write_observations_env<false>(A, L, h_HW, h_n_elems, h_n_chunks, h_obs_stride, elems, bare, tmpl, scratch, scr_stride,
-                                               obs_out, env0, n_here, lane);
+            if (wt) write_observations_env<true, HEAD>(A, L, h_HW, h_n_elems, h_n_chunks, h_obs_stride, elems, bare, tmpl, scratch, scr_stride,
+                                                       obs_out, env0, n_here, lane, nullptr, 0xFFFFFFFFu, head_lo, head_n);
+            else write_observations_env<false, HEAD>(A, L, h_HW, h_n_elems, h_n_chunks, h_obs_stride, elems, bare, tmpl, scratch, scr_stride,
+                                                     obs_out, env0, n_here, lane, nullptr, 0xFFFFFFFFu, head_lo, head_n);
         } else {
             if (wt) write_observations<true, HEAD>(A, L, h_D, h_n_chunks, h_obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane, head_lo, head_n);
             else write_observations<false, HEAD>(A, L, h_D, h_n_chunks, h_obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane, head_lo, head_n);
@@ -619,7 +624,7 @@ static hipError_t launch_step_mode_gl(const BatchPtrs& P, const LaunchArgs& K, u
 }
 template <int MODE, int G>
 static hipError_t launch_step_mode_g(int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
-    if constexpr (MODE == 6 || MODE == 7) {  // (the launcher sends maps with more than 8 sources to MODE 0 / 4)
+    if constexpr (MODE == 6 || MODE == 7 || MODE == 8) {  // (the launcher sends maps with more than 8 sources to MODE 0 / 4 / 5)
         if (lm == 4) return launch_step_mode_gl<MODE, G, 4>(P, K, n_waves, wpw, lds, stream);
         if (lm == 8) return launch_step_mode_gl<MODE, G, 8>(P, K, n_waves, wpw, lds, stream);
         return hipErrorInvalidValue;

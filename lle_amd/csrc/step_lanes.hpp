@@ -158,7 +158,7 @@ LLE_LANE_FN void step_lanes(const uint64_t* cell_lay, const uint32_t* cell_meta,
             uint32_t cw[CWM > 0 ? CWM : 1];
 #pragma unroll
             for (int q = 0; q < (CWM > 0 ? CWM : 1); q++) cw[q] = colw[q];
-            lc = recolour_lay<(CWM > 0 ? CWM : 1)>(lc, cw);
+            lc = recolour_lay<(CWM > 0 ? CWM : 1), (ML1 ? 1 : MAX_CELL_LAYERS)>(lc, cw);
         }
         lay_cur = lc;
         const uint32_t walk_cur = ((cell_meta[cur_cell] >> 8) & 15u) | 16u;
@@ -206,7 +206,7 @@ LLE_LANE_FN void step_lanes(const uint64_t* cell_lay, const uint32_t* cell_meta,
             uint32_t cw[CWM > 0 ? CWM : 1];
 #pragma unroll
             for (int q = 0; q < (CWM > 0 ? CWM : 1); q++) cw[q] = colw[q];
-            ln = recolour_lay<(CWM > 0 ? CWM : 1)>(ln, cw);
+            ln = recolour_lay<(CWM > 0 ? CWM : 1), (ML1 ? 1 : MAX_CELL_LAYERS)>(ln, cw);
         }
         lay_new = ln;
         const uint32_t mn = cell_meta[new_cell];

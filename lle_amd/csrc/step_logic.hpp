@@ -98,11 +98,12 @@ LLE_HD uint32_t colour_get(const uint32_t (&colw)[NWORDS], uint32_t b) {
     return (w >> ((b & 3u) * 8u)) & 0xFFu;
 }
 // cell_lay entry with the colour field of every valid layer replaced by the env's colour of that layer's beam
-template <int NWORDS>
+// NL: layers that can be valid (1 on maps without crossing beams: the other three slots are empty and stay as they are)
+template <int NWORDS, int NL = MAX_CELL_LAYERS>
 LLE_HD uint64_t recolour_lay(uint64_t lay, const uint32_t (&colw)[NWORDS]) {
-    uint64_t out = 0;
+    uint64_t out = NL < MAX_CELL_LAYERS ? (lay & ~((1ull << (16 * NL)) - 1ull)) : 0ull;
 #pragma unroll
-    for (int q = 0; q < MAX_CELL_LAYERS; q++) {
+    for (int q = 0; q < NL; q++) {
         uint32_t e = (uint32_t)(lay >> (16 * q)) & 0xFFFFu;
         const uint32_t c = colour_get<NWORDS>(colw, (e >> 1) & 31u);
         e = (e & LAY_VALID) ? ((e & 0x7FFu) | (c << 11)) : e;

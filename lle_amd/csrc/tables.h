@@ -74,7 +74,12 @@ struct MapHeader {
     // (STEP_RECOLOUR_RESETS).  Exact for maps without a cell of more than two laser layers (`recolour_exact`): there the
     // binding's colour check keeps every beam of another colour off every start, so nothing but the beams depends on the colours.
     uint32_t off_recolour, recolour_exact;
-    uint32_t head_pad[8];  // (pads the header to 512 B: the table sections behind it start on a 128-byte line)
+    // The head of a row when every environment has its own source colours (step_kernel MODE 8): lines that stay the same
+    // under ANY colouring with colours below n_agents -- behind the agent AND laser layers, no gem byte (WALL / VOID / EXIT
+    // planes); chunks [pes_head_lo, pes_head_lo + pes_head_n) of the BARE template.  0 when a source of the map itself has
+    // a colour >= n_agents (its layer then aliases those planes, quirk Q5).
+    uint32_t pes_head_lo, pes_head_n;
+    uint32_t head_pad[6];  // (pads the header to 512 B: the table sections behind it start on a 128-byte line)
 };
 static_assert(sizeof(MapHeader) % 128 == 0, "the sections start on a 128-byte line (the LDS copy loads 1 KiB per wave instruction)");
 

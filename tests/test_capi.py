@@ -292,3 +292,39 @@ def test_limits_are_refused_loudly(oracle_mod):
     with pytest.raises(_capi.MapParseError) as e:  # a side of 256
         _capi.Map("S0 X " + ". " * 254)
     assert e.value.kind == "Limit"
+
+
+@pytest.mark.parametrize("name", ["level3", "level5", "level6", "nested", "exit_under_beam", "three_beams", "many_agents", "colour_alias"])
+def test_row_head_under_per_env_colours_never_changes(oracle_mod, name):
+    """lle_map_row_head_env_sources: lines that no agent, gem or laser of ANY colour below n_agents can change -- what the
+    per-env-sources step kernel (MODE 8) stores ahead of its state machine.  Oracle worlds re-coloured at random (legal
+    colours only) and switched on / off along rollouts: the head's bytes are the same in every env at every step, and equal
+    the bare template's.  A map whose own sources have a colour >= n_agents has no such head."""
+    from lle_amd import Map
+    from tests.parity_util import legal_colours
+
+    text = dict({f"level{k}": v for k, v in LEVELS.items()}, **EXTRA_MAPS)[name]
+    m = Map(text, row_align=128)
+    m.set_head_lines(8)
+    first, nbytes = m.row_head_env_sources
+    A, L = m.n_agents, m.n_sources
+    if any(s.agent_id >= A for s in m.sources()):
+        assert nbytes == 0
+        return
+    assert first % 128 == 0 and nbytes % 128 == 0 and first + nbytes <= m.obs_stride
+    assert nbytes == 0 or first + 127 >= 2 * A * m.height * m.width  # behind the agent and laser layers
+    lo, hi = min(first, m.obs_bytes), min(first + nbytes, m.obs_bytes)
+    n = 96
+    ob = oracle_mod.OracleBatch(text, n)
+    rng = np.random.default_rng(4)
+    ref = None
+    for t in range(45):
+        if t % 9 == 0 and L:
+            colours = legal_colours(m, rng.integers(0, A, size=(n, L), dtype=np.uint8))
+            for e in range(n):
+                w = ob.world(e)
+                for l in range(L):
+                    w.set_source(l, colour=int(colours[e, l]), enabled=bool(rng.integers(0, 2)))
+        rows = ob.step(None, auto_reset=(t // 15) % 2 == 0, seed=8, t=t)["obs"].reshape(n, -1)
+        ref = rows[0, lo:hi].copy() if ref is None else ref
+        assert (rows[:, lo:hi] == ref).all(), (name, t)

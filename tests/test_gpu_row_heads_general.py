@@ -1,6 +1,7 @@
 """The general single-step kernels with row heads (step_kernel MODE 7: several maps per batch, the fused LLE.step
-outputs): the existing tests of those paths, collected again with LLE_ROW_HEADS=1 so that their small batches take the
-head path (the launcher's own choice needs 2 048+ wavefronts), on 128-byte aligned rows (rows without a head otherwise)."""
+outputs; MODE 8: per-environment sources, LLE.step with randomize_lasers): the existing tests of those paths, collected again
+with LLE_ROW_HEADS=1 so that their small batches take the head path (the launcher's own choice needs 2 048+ wavefronts), on
+128-byte aligned rows (rows without a head otherwise)."""
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -22,7 +23,11 @@ def heads_forced_on_aligned_rows(monkeypatch):
 from tests.test_gpu_env import (test_batched_lle_env_kat, test_batched_lle_matches_per_env_restatement,  # noqa: E402,F401
                                 test_batched_lle_one_launch_step, test_env_outputs_equals_separate_entry_points,
                                 test_one_launch_step_equals_step_plus_env_outputs)
-from tests.test_gpu_multi_map import test_blocks_of_maps_match_their_oracles  # noqa: E402,F401
+from tests.test_gpu_env import (test_persistent_step_equals_the_allocating_step, test_randomized_lasers_through_auto_reset_steps,  # noqa: E402,F401
+                                test_restore_does_not_bring_back_an_old_output_descriptor)
+from tests.test_gpu_env_sources import *  # noqa: E402,F401,F403  (every per-env-sources parity test: MODE 8 where the map has a head)
+from tests.test_gpu_exits import test_exits_with_per_env_sources  # noqa: E402,F401
+from tests.test_gpu_multi_map import test_blocks_of_maps_match_their_oracles, test_observers_and_per_env_sources_on_blocks_of_maps  # noqa: E402,F401
 from tests.test_gpu_parity import test_explicit_and_invalid_actions, test_random_rollout, test_reward_counts_and_snapshot  # noqa: E402,F401
 
 

@@ -424,6 +424,12 @@ def cmd_target(args):
         buf = buf[(-buf.data_ptr()) % 256:][: int(d.bytes)]
         for _ in range(args.iters):
             bw.observe_as(_capi.LLE_OBS_PERSPECTIVE, 0, out=buf)
+    elif what == "pes":  # per-environment sources (LLE.step with randomize_lasers): step_kernel MODE 8 / 5
+        bw = BatchedWorld(the_map(args), n)
+        g = torch.Generator().manual_seed(0)
+        bw.set_sources(torch.randint(0, bw.map.n_agents, (n, bw.map.n_sources), generator=g, dtype=torch.uint8))
+        for t in range(args.iters):
+            bw.step(sample=True, auto_reset=True, seed=1, t=t, recolour_resets=True)
     else:  # step | noobs | cfg5 | hbm
         m = Map(mapgen.config5(0), row_align=args.row_align) if what == "cfg5" else the_map(args)
         bw = BatchedWorld(m, 262144 if what == "hbm" and n == 65536 else n)
@@ -455,7 +461,7 @@ def main():
         if name == "stamps":
             p.add_argument("--fine", action="store_true")
         if name == "target":
-            p.add_argument("what", choices=["step", "noobs", "partial", "perspective", "cfg5", "hbm"])
+            p.add_argument("what", choices=["step", "noobs", "partial", "perspective", "cfg5", "hbm", "pes"])
             p.add_argument("-k", type=int, default=7, help="window of the partial observer")
     args = ap.parse_args()
     assert torch.cuda.is_available(), "lle_prof.py needs an MI355X"
