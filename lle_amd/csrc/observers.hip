@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(256) partial_project_kernel(BatchPtrs P, int8_
 // The E rows are contiguous in the output, so the wavefront clears, patches and streams them as ONE block of E x pitch
 // bytes: 1 KiB per store instruction whatever the row size (a 400-byte row alone fills 25 lanes of 64).
 // LDS: [cell_lay | cell_meta (whole KiB rows)] [bitmap] then per wave [E rows] [E records: pos u16[As] | gems | beams[L] | colour words].
-struct PartialDims { int32_t A, L, H, W; uint32_t off_cell_meta; };  // common to the maps of a batch; off_cell_meta relative to off_cell_lay
+struct PartialDims { int32_t A, L, H, W; uint32_t off_cell_meta, max_layers; };  // common to the maps of a batch; off_cell_meta relative to off_cell_lay
 __global__ void __launch_bounds__(256) partial_lanes_kernel(BatchPtrs P, int8_t* __restrict__ out, int k, uint32_t pitch, int64_t env_base,
                                                             int64_t env_limit, int per_env_sources, MapSel M, uint32_t E, uint32_t batches,
                                                             uint32_t tab_bytes, int wt, PartialDims D, uint32_t tab_off) {
@@ -522,19 +522,23 @@ __global__ void __launch_bounds__(256) partial_lanes_kernel(BatchPtrs P, int8_t*
         // cells with (wi + wj) mod S == s -- so that a row of walls or a beam, the runs maps are made of, is spread over all of
         // them (split by rows, the lane that holds the wall row decides the trip count of the whole wavefront: level 6 7x7
         // 27.7 -> 25.x us).  Larger windows are split by rows (a lane's rows must fit its set: at most four of 16 bits).
-        uint64_t todo = 0;
+        // The set is kept as two dwords (rows [0, RH) and [RH, 2 RH) of the lane's rows, RH = 32 >> SBL): 32-bit find-first-set,
+        // shifts and clears instead of 64-bit ones, which cost two to four instructions each.
+        uint32_t todo2[2] = {0u, 0u};
         const bool diag = k <= 8;
-        const uint32_t wi_base = diag ? 0u : s, wi_step = diag ? 1u : S;
+        const uint32_t wi_base = diag ? 0u : s, wi_step = diag ? 1u : S, RH = 32u >> SBL;
         if (live) {
             const uint32_t off = (uint32_t)(j0 + 8);   // >= 1: bit of the window's first column in a bitmap row
             const uint32_t rep = S >= 8 ? 0x01u : (S == 4 ? 0x11u : (S == 2 ? 0x55u : 0xFFu));   // every S-th bit of a row
+            const uint32_t kmask = (1u << k) - 1u;
             uint32_t r = 0;
             for (uint32_t wi = wi_base; wi < (uint32_t)k; wi += wi_step, r++) {
                 const uint32_t* rowp = bm + __umul24((uint32_t)(i0 + (int)wi + 8), RW) + (off >> 5);
-                const uint64_t two = (uint64_t)rowp[0] | ((uint64_t)rowp[1] << 32);
-                uint32_t bits = (uint32_t)(two >> (off & 31u)) & ((1u << k) - 1u);
+                uint32_t bits = __funnelshift_r(rowp[0], rowp[1], off & 31u) & kmask;   // v_alignbit_b32
                 if (diag) bits &= rep << ((s - wi) & (S - 1u));
-                todo |= (uint64_t)bits << (r << SBL);
+                const uint32_t sh = (r & (RH - 1u)) << SBL;
+                if (r < RH) todo2[0] |= bits << sh;
+                else todo2[1] |= bits << sh;
             }
         }
         // One non-empty cell per pass, no branch inside: a cell has at most four bytes to give -- its static one (wall / exit /
@@ -543,29 +547,39 @@ __global__ void __launch_bounds__(256) partial_lanes_kernel(BatchPtrs P, int8_t*
         // is needed.  (Write order = the reference's, observations.py:347-359; all four commute, see the kernel's header.)
         const uint32_t* rec32 = reinterpret_cast<const uint32_t*>(rec8);
         const int cell0 = i0 * W + j0;
-        while (todo) {
-            const uint32_t b = (uint32_t)__builtin_ctzll(todo);
-            todo &= todo - 1ull;
-            // (24-bit multiplies run at the full vector rate, 32-bit ones at a quarter; every factor here is tiny)
-            const uint32_t r = b >> SBL, wj = b & ((1u << SBL) - 1u), wi = wi_base + __umul24(r, wi_step);
-            const uint32_t cell = (uint32_t)(cell0 + (int)(__umul24(wi, (uint32_t)W) + wj));
-            const uint32_t meta = cell_meta[cell];
-            const uint64_t lay = cell_lay[cell];
-            const uint32_t gems = rec32[As / 2];
-            const uint32_t kind = meta & 7u, idx = (meta >> 3) & 31u;
-            const uint32_t l0 = (uint32_t)lay & 0xFFFFu, l1 = (uint32_t)(lay >> 16) & 0xFFFFu;   // World.lasers(): two layers per cell
-            const uint32_t b0 = (l0 >> 1) & 31u, o0 = (l0 >> 6) & 31u, b1 = (l1 >> 1) & 31u, o1 = (l1 >> 6) & 31u;
-            const uint32_t src = kind == K_SOURCE ? idx : 0u;   // idx = laser id of a source cell (gem index otherwise)
-            const uint32_t m0 = rec32[As / 2 + 1 + b0], m1 = rec32[As / 2 + 1 + b1];
-            const uint32_t c0 = rec8[colour_at + b0], c1 = rec8[colour_at + b1], cs = rec8[colour_at + src];
-            const uint32_t lt = ((kind < 4u ? lt_lo : lt_hi) >> ((kind & 3u) * 8u)) & 0xFFu;
-            const bool en0 = lt != 0xFFu && !(kind == K_GEM && ((gems >> idx) & 1u));
-            const bool en1 = (l0 & LAY_VALID) && ((m0 >> o0) & 1u), en2 = (l1 & LAY_VALID) && ((m1 >> o1) & 1u);
-            int8_t* cp = mine + __umul24(wi, (uint32_t)k) + wj;
-            *(en0 ? cp + __umul24(lt, kk) : dummy) = 1;
-            *(en1 ? cp + __umul24((uint32_t)LASER_0 + c0, kk) : dummy) = 1;
-            *(en2 ? cp + __umul24((uint32_t)LASER_0 + c1, kk) : dummy) = 1;
-            *(kind == K_SOURCE ? cp + __umul24((uint32_t)LASER_0 + cs, kk) : dummy) = -1;
+        const bool two_layers = D.max_layers > 1u;   // (uniform: maps without crossing beams never look at a second layer)
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            uint32_t todo = todo2[half];
+            while (todo) {
+                const uint32_t b = (uint32_t)__builtin_ctz(todo);
+                todo &= todo - 1u;
+                // (24-bit multiplies run at the full vector rate, 32-bit ones at a quarter; every factor here is tiny)
+                const uint32_t r = (b >> SBL) + (half ? RH : 0u), wj = b & ((1u << SBL) - 1u), wi = wi_base + __umul24(r, wi_step);
+                const uint32_t cell = (uint32_t)(cell0 + (int)(__umul24(wi, (uint32_t)W) + wj));
+                const uint32_t meta = cell_meta[cell];
+                const uint64_t lay = cell_lay[cell];
+                const uint32_t gems = rec32[As / 2];
+                const uint32_t kind = meta & 7u, idx = (meta >> 3) & 31u;
+                const uint32_t l0 = (uint32_t)lay & 0xFFFFu;   // World.lasers(): the two outer layers of a cell
+                const uint32_t b0 = (l0 >> 1) & 31u, o0 = (l0 >> 6) & 31u;
+                const uint32_t src = kind == K_SOURCE ? idx : 0u;   // idx = laser id of a source cell (gem index otherwise)
+                const uint32_t m0 = rec32[As / 2 + 1 + b0];
+                const uint32_t c0 = rec8[colour_at + b0], cs = rec8[colour_at + src];
+                const uint32_t lt = ((kind < 4u ? lt_lo : lt_hi) >> ((kind & 3u) * 8u)) & 0xFFu;
+                const bool en0 = lt != 0xFFu && !(kind == K_GEM && ((gems >> idx) & 1u));
+                const bool en1 = (l0 & LAY_VALID) && ((m0 >> o0) & 1u);
+                int8_t* cp = mine + __umul24(wi, (uint32_t)k) + wj;
+                if (two_layers) {
+                    const uint32_t l1 = (uint32_t)(lay >> 16) & 0xFFFFu, b1 = (l1 >> 1) & 31u, o1 = (l1 >> 6) & 31u;
+                    const uint32_t m1 = rec32[As / 2 + 1 + b1], c1 = rec8[colour_at + b1];
+                    const bool en2 = (l1 & LAY_VALID) && ((m1 >> o1) & 1u);
+                    *(en2 ? cp + __umul24((uint32_t)LASER_0 + c1, kk) : dummy) = 1;
+                }
+                *(en0 ? cp + __umul24(lt, kk) : dummy) = 1;
+                *(en1 ? cp + __umul24((uint32_t)LASER_0 + c0, kk) : dummy) = 1;
+                *(kind == K_SOURCE ? cp + __umul24((uint32_t)LASER_0 + cs, kk) : dummy) = -1;
+            }
         }
         wave_sync();
         uint4* __restrict__ dst = reinterpret_cast<uint4*>(out + (uint64_t)env0 * pitch);
@@ -826,7 +840,7 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
                 // measured better at every size incl. 489 MB (32x32 7x7: 114 -> 99 us).  LLE_PARTIAL_WT=0 / 1: tuning override
                 int wt = 1;
                 if (const char* o = getenv("LLE_PARTIAL_WT")) wt = o[0] == '1';
-                const PartialDims D{(int32_t)h.A, (int32_t)h.L, (int32_t)h.H, (int32_t)h.W, h.off_cell_meta - h.off_cell_lay};
+                const PartialDims D{(int32_t)h.A, (int32_t)h.L, (int32_t)h.H, (int32_t)h.W, h.off_cell_meta - h.off_cell_lay, h.max_layers};
                 hipLaunchKernelGGL(partial_lanes_kernel, dim3((n_waves + wpw - 1) / wpw), dim3(64 * wpw), lds, stream, P, out, k, pitch_l,
                                    (int64_t)0, n_envs, per_env_sources ? 1 : 0, M, E, batches, tab, wt, D, h.off_cell_lay);
                 return hipGetLastError();

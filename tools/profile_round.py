@@ -20,7 +20,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out", "prof")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 ENV = dict(os.environ, TMPDIR="/tmp")
 BENCH = os.path.join(ROOT, "bench.py")
 # (label, kernel-name fragment, grid size in work-items = waves x 64): the single-step launches of the bench line
@@ -29,6 +29,8 @@ WORKLOADS = [
     ("level 6 x 262 144 (rows > Infinity Cache)", "step_kernel<4, 4, 0, true, 3>", 262144 // 16 * 64, 1937 * 262144),
     ("cfg2 level 1 x 4 096", "step_kernel<1, 4, 0, true, 0>", 4096 // 4 * 64, 953 * 4096),
     ("cfg5 32x32 8 agents x 65 536", "step_kernel<8, 8, 0, false, -1>", 65536 // 8 * 64, 20617 * 65536),
+    # BatchedLLE.step with randomize_lasers (bench `lle_step`): per-env sources, row heads first (MODE 8), the fused outputs on top
+    ("LLE.step + randomize_lasers, level 6 x 65 536 (MODE 8)", "step_kernel<4, 4, 8, true, 3>", 65536 // 16 * 64, (1937 + 16 * 4 + 4 + 20 + 1) * 65536),
 ]
 
 

@@ -1,7 +1,9 @@
 """Soak differential (GPU box): HIP path vs the CPU oracle on long random rollouts, every buffer of every env compared
 bit-for-bit after every step (state, ordered events, availability, error codes, the full int8 observation).
 Beyond the test suite's sizes; prints env-steps compared per map.
-Usage: python tools/soak_parity.py [seconds_per_map] [per-env-sources | full-size | recolour-resets | rollouts]
+Usage: python tools/soak_parity.py [seconds_per_map] [per-env-sources | full-size | recolour-resets | rollouts | exits]
+With `exits` the exits MOVE every 40 steps (World.exit_pos = [...], world.rs:195-234: lle_map_set_exits + lle_batch_update_map on
+the GPU side, set_exit_positions on every oracle world): random legal cells, one of them under a beam where the map has one.
 With `rollouts` the GPU side runs lle_batch_rollout (8 steps per launch into a trajectory ring of 8 slots: the fused
 kernels, MODE 1) and the oracle the same 8 steps one by one: every slot of the observation / action / reward rings and
 the final state of every launch are compared.
@@ -33,6 +35,7 @@ per_env = len(sys.argv) > 2 and sys.argv[2] == "per-env-sources"
 full_size = len(sys.argv) > 2 and sys.argv[2] == "full-size"
 recolour = len(sys.argv) > 2 and sys.argv[2] == "recolour-resets"
 rollouts = len(sys.argv) > 2 and sys.argv[2] == "rollouts"
+exits_mode = len(sys.argv) > 2 and sys.argv[2] == "exits"
 rng = np.random.default_rng(7)
 
 
@@ -78,6 +81,8 @@ for name, (text, n) in maps.items():
         n = min(n, 2048)  # (the per-env source calls on the oracle side are Python loops)
     if rollouts:
         n = min(n, 8192)
+    if exits_mode:
+        n = min(n, 4096)  # (set_exit_positions on the oracle side is one call per world)
     ob, bw = om.OracleBatch(text, n), BatchedWorld(text, n)
     dims = (ob.A, ob.G, ob.Ls, ob.beam_stride, ob.C, ob.H, ob.W)
     L = bw.map.n_sources
@@ -138,6 +143,15 @@ for name, (text, n) in maps.items():
             redraw(bw, mirror, ob.A, L, n)
             eng = unpack_engine(bw.host_buffers(), *dims)
             assert_state_equal(eng, ob.dump(), f"{name} t={t} after set_sources")
+        if exits_mode and t % 40 == 39:
+            from tests.test_gpu_exits import legal_exits
+            new_exits = legal_exits(bw.map, rng, ob.A + int(rng.integers(0, 3)))
+            bw.set_exits(new_exits)
+            for e in range(n):
+                ob.world(e).set_exits(new_exits)
+            eng = unpack_engine(bw.host_buffers(), *dims)
+            assert_state_equal(eng, ob.dump(), f"{name} t={t} after set_exits")
+            assert np.array_equal(eng["obs"][:64], np.stack([ob.world(e).obs() for e in range(64)])), f"{name} t={t}: observation after set_exits"
         auto = (t // 64) % 2 == 0  # alternate: auto-reset regime / episodes running into all-dead, all-STAY states (Q1, Q2)
         bw.step(sample=True, auto_reset=auto, seed=2026, t=t, env_offset=11)
         ostep = ob.step(None, auto_reset=auto, seed=2026, t=t, env_offset=11)
