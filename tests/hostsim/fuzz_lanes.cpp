@@ -41,6 +41,8 @@ int ow_n_sources(ow_world* w);
 int ow_height(ow_world* w);
 int ow_width(ow_world* w);
 int ow_panics(ow_world* w);
+int hs_set_exits(hs_batch* b, const int32_t* exits_ij, int n_exits);
+int ow_set_exits(ow_world* w, const int32_t* exits_ij, int n_exits);
 }
 
 static int fail(const char* what, size_t map_idx, uint64_t t, int64_t env, const std::string& text) {
@@ -60,7 +62,7 @@ int main(int argc, char** argv) {
         else maps.back() += line + "\n";
     }
     if (maps.back().empty()) maps.pop_back();
-    int64_t env_steps = 0, deaths = 0, passes = 0;
+    int64_t env_steps = 0, deaths = 0, passes = 0, exits_taken = 0, exits_refused = 0;
     for (size_t m = 0; m < maps.size(); m++) {
         const std::string& text = maps[m];
         int perr = 0, oerr = 0;
@@ -82,9 +84,28 @@ int main(int argc, char** argv) {
             o_gems(n * (G ? G : 1)), o_beams(n * Ls * bs), o_avail(n * A);
         std::vector<int32_t> o_err(n);
         std::vector<int8_t> o_obs(n * row);
+        uint64_t lcg = 0x9E3779B97F4A7C15ull * (m + 1);
         for (uint64_t t = 0; t < steps; t++) {
             const int auto_reset = t >= steps / 2;
             const uint64_t seed = 1000 + m;
+            if (t % 16 == 15) {
+                // World.exit_pos = [...] (world.rs:195-234) with RANDOM cells, legal or not: both sides must take or refuse the same
+                // lists (a refusal leaves either untouched), and go on identically afterwards
+                int32_t ij[2 * 20];
+                lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+                const int cnt = A - 1 + (int)((lcg >> 60) & 3u) < 0 ? 0 : A - 1 + (int)((lcg >> 60) & 3u);
+                for (int k = 0; k < cnt && k < 20; k++) {
+                    lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+                    ij[2 * k] = (int32_t)((lcg >> 33) % (uint64_t)(H + 1));      // (H, W themselves: out of the world)
+                    ij[2 * k + 1] = (int32_t)((lcg >> 13) % (uint64_t)(W + 1));
+                }
+                const int r_hs = hs_set_exits(hb, ij, cnt < 20 ? cnt : 20);
+                int r_ow = 0;
+                for (int64_t e = 0; e < n; e++) r_ow = ow_set_exits(ow_batch_world(ob, e), ij, cnt < 20 ? cnt : 20);
+                if ((r_hs == 0) != (r_ow == 0) || (r_hs > 0) != (r_ow > 0)) return fail("set_exits: one side took the list, the other refused it", m, t, 0, text);
+                exits_taken += r_hs == 0;
+                exits_refused += r_hs != 0;
+            }
             ow_batch_step_range(ob, 0, n, nullptr, auto_reset, seed, t, 3, o_act.data(), o_err.data(), o_evc.data(), o_ev.data(), o_obs.data(), nullptr);
             ow_batch_dump(ob, 0, n, bs, o_pos.data(), o_alive.data(), o_arr.data(), o_occ.data(), G ? o_gems.data() : nullptr,
                           L ? o_beams.data() : nullptr, o_avail.data());
@@ -131,7 +152,8 @@ int main(int argc, char** argv) {
         hs_free(hb);
         ow_batch_free(ob);
     }
-    std::printf("OK maps=%zu env_steps=%lld deaths=%lld lane_passes=%lld engine=%d\n", maps.size(), (long long)env_steps, (long long)deaths,
+    std::printf("OK maps=%zu env_steps=%lld deaths=%lld exits_taken=%lld exits_refused=%lld lane_passes=%lld engine=%d\n", maps.size(), (long long)env_steps, (long long)deaths,
+                (long long)exits_taken, (long long)exits_refused,
                 (long long)passes, engine);
     return 0;
 }

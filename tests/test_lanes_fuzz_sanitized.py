@@ -87,6 +87,8 @@ def test_generated_small_maps(fuzzer, tmp_path, engine):
     maps = generated_maps(1000, seed=engine)
     out = run(fuzzer, maps, tmp_path / "generated.txt", envs=12, steps=40, engine=engine)
     assert int(out["maps"]) == 1000 and int(out["deaths"]) > 10000
+    # World.exit_pos = [...] with random cells every 16 steps (world.rs:195-234): lists taken AND lists refused, on both sides alike
+    assert int(out["exits_taken"]) > 50 and int(out["exits_refused"]) > 50, out
 
 
 def test_shortcut_saves_passes_and_nothing_else(fuzzer, tmp_path):
