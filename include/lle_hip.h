@@ -223,9 +223,11 @@ void lle_batch_free(lle_batch* b);
 int lle_batch_get_buffer(const lle_batch* b, int which, lle_buffer_desc* out);
 int64_t lle_batch_n_envs(const lle_batch* b);
 
-/* Exact checkpoint of the dynamic state (positions, alive/arrived/occupant bits, gems, beam masks, availability):
- * unlike World.get_state/set_state (world_state.rs:5-9) nothing is re-derived, so it is valid mid-episode, corpses
- * included.  `dst_dev` / `src_dev`: device memory of lle_batch_snapshot_bytes() bytes. */
+/* Exact checkpoint of the dynamic state (positions, alive/arrived/occupant bits, gems, beam masks, availability; with
+ * per-environment sources also every env's colours and flags): unlike World.get_state/set_state (world_state.rs:5-9)
+ * nothing is re-derived, so it is valid mid-episode, corpses included.  The MAP is not part of it: a snapshot restored
+ * after lle_batch_update_map (exits moved) comes back under the current exits, LLE_BUF_OBS / LLE_BUF_DONE are rebuilt and
+ * the per-env reset records recomputed.  `dst_dev` / `src_dev`: device memory of lle_batch_snapshot_bytes() bytes. */
 int64_t lle_batch_snapshot_bytes(const lle_batch* b);
 int lle_batch_snapshot(lle_batch* b, void* dst_dev, void* stream);
 int lle_batch_restore(lle_batch* b, const void* src_dev, void* stream);

@@ -634,7 +634,10 @@ int lle_batch_restore(lle_batch* b, const void* src_dev, void* stream) {
                                hipMemcpyDeviceToDevice, (hipStream_t)stream));
     b->env_out_valid = false;  // (belt and braces: the next lle_batch_step_outputs uploads its descriptor again)
     LaunchArgs K{};
-    return launch(b, KMODE_OBSERVE, K, stream);  // bring the observation in line with the restored state
+    // bring the observation (and `done`) in line with the restored state.  With per-environment sources also every env's own
+    // reset record, from its restored colours / flags under the CURRENT tables: the snapshot may predate an exit change
+    // (lle_batch_update_map), and an agent whose start is an exit now arrives at reset
+    return launch(b, b->per_env_sources ? KMODE_ENV_SOURCES : KMODE_OBSERVE, K, stream);
 }
 
 int lle_batch_reset(lle_batch* b, const uint8_t* env_mask_dev, void* stream) {

@@ -319,6 +319,7 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
                     store_state = reset_first;
                 }
                 P.err[env] = (uint8_t)err;
+                P.done[env] = ((s.alive | ghost) != amask || s.arrived == amask) ? 1 : 0;  // (a function of the state: lle_batch_restore relies on it)
             } else {
                 store_state = false;
             }

@@ -244,3 +244,46 @@ def test_world_facade_exit_pos_save_copy_pickle(tmp_path):
     g.reset()
     o = g.observe()
     assert np.all(o[:, g.EXIT, 0, 2] == 1) and np.all(o[:, g.EXIT, 0, 3] == 1) and np.all(o[:, g.EXIT, 0, 1] == 0)
+
+
+def test_restore_after_an_exit_change_recomputes_the_reset_records(oracle_mod):
+    """A snapshot taken BEFORE World.exit_pos changes, restored AFTER: the dynamic state comes back as it was, but with
+    per-environment sources the snapshot also carries every env's own reset record -- computed under the old exits.  restore
+    recomputes them under the current tables (an agent whose start is an exit now arrives at reset)."""
+    import torch
+
+    from lle_amd import BatchedWorld
+
+    text = "S0 . S1 .\nL0E . . X\n X . . ."
+    n = 128
+    ob = oracle_mod.OracleBatch(text, n)
+    bw = BatchedWorld(text, n)
+    colours = torch.zeros((n, 1), dtype=torch.uint8)
+    bw.set_sources(colours=colours)  # per-environment sources on (the map's own colour)
+    for t in range(5):
+        bw.step(sample=True, seed=3, t=t)
+        ob.step(None, seed=3, t=t)
+    snap = bw.snapshot()
+    saved = [(ob.world(e).positions(), ob.world(e).gems_collected(), ob.world(e).alive(), ob.world(e).arrived()) for e in range(n)]
+    exits = [(0, 0), (2, 3)]
+    bw.set_exits(exits)
+    for e in range(n):
+        ob.world(e).set_exits(exits)
+    for t in range(5, 9):
+        bw.step(sample=True, auto_reset=True, seed=3, t=t)
+        check(bw, ob, ob.step(None, auto_reset=True, seed=3, t=t), f"t={t}")
+    bw.restore(snap)
+    assert bw.map.positions(1) == exits  # the map is not part of a snapshot
+    got = unpack_engine(bw.host_buffers(), *dims_of(ob))
+    assert [tuple(map(tuple, got["pos"][e].tolist())) for e in range(n)] == [tuple(s[0]) for s in saved]
+    # every env over -> auto-reset copies its own reset record: agent 0's start is an exit now
+    bw.bits.zero_()  # everybody dead: the next auto-reset step restarts every env
+    bw.step(sample=True, auto_reset=True, seed=3, t=20)
+    assert bool((bw.evcount >> 7).all())
+    ob.reset()
+    ostep = ob.step(None, seed=3, t=20)
+    eng = unpack_engine(bw.host_buffers(), *dims_of(ob))
+    eng["ev_count"] = eng["ev_count"] & 0x7F  # (bit 7: the env was auto-reset first; the oracle side was reset by hand)
+    assert_step_equal(eng, ostep, "after restore + reset")
+    assert_state_equal(eng, ob.dump(), "after restore + reset")
+    assert bool(bw.agents_arrived()[:, 0].all())
