@@ -144,12 +144,7 @@ def visible_gpus():
     except OSError:
         count = None
     if count is None:
-        try:
-            res = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], stdout=subprocess.PIPE,
-                                 stderr=subprocess.DEVNULL, text=True, timeout=300)
-            return int(res.stdout.strip().splitlines()[-1])
-        except Exception:  # noqa: BLE001
-            return 0
+        return gpus_seen_by_a_child()
     for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:
@@ -157,11 +152,23 @@ def visible_gpus():
     return count
 
 
+def gpus_seen_by_a_child():
+    """torch.cuda.device_count() asked in a short-lived child process (the parent stays off the GPU)."""
+    try:
+        res = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], stdout=subprocess.PIPE,
+                             stderr=subprocess.DEVNULL, text=True, timeout=300)
+        return int(res.stdout.strip().splitlines()[-1])
+    except Exception:  # noqa: BLE001
+        return 0
+
+
 def spawn_ranks(args, argv):
     """Parent of an N-rank run.  Never touches a GPU (visible_gpus() reads sysfs) and never execs: the ranks are child
     processes of torch.distributed.run, and this process exits with their code.  The ranks check their own device again."""
     if not args.plumbing_only:
         visible = visible_gpus()
+        if visible < args.gpus:  # (sysfs says too few: before refusing, ask the runtime itself -- in a child)
+            visible = max(visible, gpus_seen_by_a_child())
         if visible < args.gpus:
             print(f"bench.py: --gpus {args.gpus} but only {visible} GPU(s) visible; refusing to measure fewer GPUs than asked for",
                   file=sys.stderr)
