@@ -165,7 +165,7 @@ def gpus_seen_by_a_child():
 def spawn_ranks(args, argv):
     """Parent of an N-rank run.  Never touches a GPU (visible_gpus() reads sysfs) and never execs: the ranks are child
     processes of torch.distributed.run, and this process exits with their code.  The ranks check their own device again."""
-    if not args.plumbing_only:
+    if not args.plumbing_only and not args.rehearse_on_one_gpu:
         visible = visible_gpus()
         if visible < args.gpus:  # (sysfs says too few: before refusing, ask the runtime itself -- in a child)
             visible = max(visible, gpus_seen_by_a_child())
@@ -275,9 +275,10 @@ class Timer:
     synchronize that follows: no rank's clock stops before every rank's launches are done, and the region does not pay a
     second host wake-up plus an idle gap in front of a separate barrier call (that is 10 % of a 20-step region)."""
 
-    def __init__(self, torch, dist, dev, use_dist):
-        self.torch, self.dist, self.dev, self.use_dist = torch, dist, dev, use_dist
-        self.flag = torch.zeros(1, dtype=torch.int32, device=dev) if use_dist else None
+    def __init__(self, torch, dist, dev, use_dist, sync_dev=None):
+        self.torch, self.dist, self.use_dist = torch, dist, use_dist
+        self.flag = torch.zeros(1, dtype=torch.int32, device=dev) if use_dist else None  # (`dev`: where the barrier's element lives)
+        self.dev = sync_dev if sync_dev is not None else dev                             # the GPU this rank launches on
 
     def sync(self):
         self.torch.cuda.synchronize(self.dev)
@@ -461,6 +462,8 @@ def main():
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of a self-spawned N-rank run (0 = pick a free one)")
     ap.add_argument("--force-spawn", action="store_true", help="go through torch.distributed.run (and RCCL) even for --gpus 1")
     ap.add_argument("--plumbing-only", action="store_true", help="spawn / rendezvous / one-line check over gloo, no GPU, no measurement")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N ranks that SHARE cuda:0, collectives over gloo: every line of the N > 1 path but RCCL, on a one-GPU box (not a measurement)")
     args = ap.parse_args()
 
     under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
@@ -489,6 +492,9 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; refusing to report a rank count that was not asked for", file=sys.stderr)
         sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU execution path)"
+    rehearsal = args.rehearse_on_one_gpu and under_launcher
+    if rehearsal:
+        local_rank = 0  # every rank on the one card; RCCL refuses two ranks on a device, so the collectives run over gloo
     if torch.cuda.device_count() <= local_rank:
         print(f"bench.py: rank {rank} has no GPU {local_rank} ({torch.cuda.device_count()} visible)", file=sys.stderr)
         sys.exit(2)
@@ -500,9 +506,14 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         rccl_ranks = dist.get_world_size()
-    timer = Timer(torch, dist, dev, use_dist)
+    # the small tensors of the collectives live where the backend can reduce them: on the GPU for RCCL, on the host for gloo
+    cdev = torch.device("cpu") if rehearsal else dev
+    timer = Timer(torch, dist, cdev if rehearsal else dev, use_dist, sync_dev=dev)
 
     n = args.envs_per_gpu
     bw = BatchedWorld(Map(level=LEVEL), n, device=dev, envs_per_wave=args.envs_per_wave or None)
@@ -521,18 +532,18 @@ def main():
     # first -- a host round trip right in front of a timed region that is 0.5 ms long at the driver's 20 steps)
     bw.stats_blocks.zero_()
     my_wall, kernel_ms = timer.run(step, args.steps)
-    elapsed = allreduce_max(my_wall, dev) if use_dist else my_wall
+    elapsed = allreduce_max(my_wall, cdev) if use_dist else my_wall
     local_stats = bw.stats()
-    stats = allreduce_stats(local_stats, dev) if use_dist else local_stats
+    stats = allreduce_stats(local_stats, cdev) if use_dist else local_stats
 
     sustained = None
     my_s_wall = s_ms = 0.0
     if args.sustained_steps > 0:
         my_s_wall, s_ms = timer.run(step, args.sustained_steps)
-        s_wall = allreduce_max(my_s_wall, dev) if use_dist else my_s_wall
+        s_wall = allreduce_max(my_s_wall, cdev) if use_dist else my_s_wall
         sustained = (args.sustained_steps, s_wall, s_ms)
     # every rank's own numbers (rank order): a poor aggregate can then be traced to the rank, or to the host side, that caused it
-    rank_rows = gather_rows([my_wall, kernel_ms, local_stats["env_steps"], my_s_wall, s_ms], dev)
+    rank_rows = gather_rows([my_wall, kernel_ms, local_stats["env_steps"], my_s_wall, s_ms], cdev)
 
     # ---- secondary measurement: the same random rollout with lle_batch_rollout (several steps per launch, every
     # step's observation / actions / reward counts written to a trajectory ring larger than the caches)
@@ -549,7 +560,7 @@ def main():
             for _ in range(2):
                 roll()
             fe, _ = timer.run(roll, launches)
-            fe = allreduce_max(fe, dev) if use_dist else fe
+            fe = allreduce_max(fe, cdev) if use_dist else fe
             fused.append((T, R, launches, fe))
             del ring
 
@@ -589,7 +600,8 @@ def main():
             "metric": "env-steps/s (agents x envs x steps/s), level-6 batch 65536",
             "value": A * env_steps_s, "unit": "agent-steps/s",
             "env_steps_per_s": env_steps_s,
-            "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup, "preroll_steps": preroll_steps,
+            "n_gpus": world, "rccl_ranks": rccl_ranks, **({"rehearsal": "N ranks SHARING one GPU, collectives over gloo: the N > 1 code path, NOT a measurement"} if rehearsal else {}),
+            "steps": args.steps, "warmup": args.warmup, "preroll_steps": preroll_steps,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",

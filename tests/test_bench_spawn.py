@@ -124,3 +124,24 @@ def test_allreduce_of_batched_world_counters_over_rccl():
         assert allreduce_max(1.5, dev) == 1.5
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_code_path_rehearsed_on_one_gpu():
+    """`bench.py --gpus 2 --rehearse-on-one-gpu`: the parent spawns two ranks through torch.distributed.run, both step their own
+    env range on cuda:0, the collectives run over gloo -- every line of the N > 1 path (sharding, barrier-bracketed timed
+    region, max over ranks, counter all-reduce, per-rank gather, the one JSON line) except RCCL itself, which refuses two
+    ranks on one device.  Not a measurement, and the line says so."""
+    steps = 20
+    res = _run("--gpus", "2", "--rehearse-on-one-gpu", "--steps", str(steps), "--warmup", "5", "--no-cpu-baseline", "--no-configs",
+               "--fused-steps", "4", "--sustained-steps", "40")
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = _one_line(res)
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and "NOT a measurement" in out["rehearsal"]
+    assert out["rollout_stats"]["env_steps"] == 2 * 65536 * steps and out["rollout_stats"]["agent_steps"] == 4 * 2 * 65536 * steps
+    assert out["config"]["global_batch"] == 2 * 65536 and out["config"]["parallelism"] == "env-shard x2"
+    assert [r["rank"] for r in out["per_rank"]] == [0, 1] and all(r["env_steps"] == 65536 * steps for r in out["per_rank"])
+    assert all(r["kernel_ms"] > 0 and r["sustained_kernel_ms"] > 0 for r in out["per_rank"])
+    assert out["region"]["kernel_ms_max_over_ranks"] >= out["region"]["kernel_ms_min_over_ranks"] > 0
+    assert out["sustained"]["steps"] == 40 and out["fused_rollout"]["steps_per_launch"] == 4
+    assert "cpu_baseline" not in out and "configs" not in out  # N = 1 only
