@@ -220,8 +220,8 @@ def scaling_block(rows, steps, sustained_steps, n_envs, agents, n1_reference=Non
     rows[r] = [wall seconds of the --steps region, HIP-event ms per launch in it, env-steps stepped in it,
                wall seconds of the sustained region (0 = none), HIP-event ms per launch in it].
     `value` of the line follows the contract (wall clock around barrier + synchronize, max over ranks); the HIP-event figures
-    say what the GPUs did inside it: at --steps 20 the region is 0.4 ms long and the closing one-element all-reduce, the rank
-    skew and the host's wake-up are a visible share of it."""
+    say what the GPUs did inside it: at --steps 20 the region is 0.4 ms long and the rank skew and the host's wake-up are a
+    visible share of it."""
     world = len(rows)
     per_rank = [{"rank": r, "wall_ms_per_step": row[0] / steps * 1e3, "kernel_ms": row[1], "env_steps": int(row[2]),
                  "agent_steps_per_s_by_events": agents * n_envs / (row[1] * 1e-3) if row[1] > 0 else None,
@@ -234,7 +234,7 @@ def scaling_block(rows, steps, sustained_steps, n_envs, agents, n1_reference=Non
                       "kernel_ms_min_over_ranks": k_min,
                       "agent_steps_per_s_by_slowest_rank_events": agents * n_envs * world / (k_max * 1e-3) if k_max > 0 else None,
                       "host_share_of_wall": 1.0 - k_max * steps * 1e-3 / wall_max if wall_max > 0 else None,
-                      "note": "wall = the contract's clock (barrier + synchronize on both sides, closing all-reduce inside); kernel = HIP "
+                      "note": "wall = the contract's clock (barrier + synchronize on both sides; each rank's clock stops at its own synchronize, the max over ranks is taken); kernel = HIP "
                               "events on each rank's launch stream around the same launches"}}
     if sustained_steps and all(row[4] > 0 for row in rows):
         s_k = max(row[4] for row in rows)
@@ -269,16 +269,17 @@ def n1_reference(write=None):
 
 
 class Timer:
-    """K launches bracketed the way the contract asks: barrier + synchronize on both sides, wall clock (max over ranks
-    taken by the caller) and HIP events on the launch stream (torch's current stream is the one every launch uses).
-    The closing barrier is a one-element RCCL all-reduce ENQUEUED behind the last launch and waited for by the one
-    synchronize that follows: no rank's clock stops before every rank's launches are done, and the region does not pay a
-    second host wake-up plus an idle gap in front of a separate barrier call (that is 10 % of a 20-step region)."""
+    """K launches bracketed the way the contract asks: barrier + synchronize on both sides, every rank's own wall clock
+    (the caller takes the MAX over ranks) and HIP events on the launch stream (torch's current stream is the one every
+    launch uses).  Opening: synchronize, barrier, synchronize, clock starts -- the ranks start together.  Closing: synchronize,
+    clock stops, barrier.  The MAX over ranks of those clocks is the time from the common start until the slowest rank's last
+    launch has finished, i.e. the job's time; the closing barrier itself is not work of the K steps, and at N = 1 there is
+    none to pay, so keeping it outside the clock makes the per-N values comparable (a one-element all-reduce is tens of
+    microseconds: 5-10 % of the driver's 0.4-ms region of 20 steps).  Until round 2 it sat inside the clock."""
 
     def __init__(self, torch, dist, dev, use_dist, sync_dev=None):
         self.torch, self.dist, self.use_dist = torch, dist, use_dist
-        self.flag = torch.zeros(1, dtype=torch.int32, device=dev) if use_dist else None  # (`dev`: where the barrier's element lives)
-        self.dev = sync_dev if sync_dev is not None else dev                             # the GPU this rank launches on
+        self.dev = sync_dev if sync_dev is not None else dev  # the GPU this rank launches on
 
     def sync(self):
         self.torch.cuda.synchronize(self.dev)
@@ -295,10 +296,10 @@ class Timer:
         for _ in range(k):
             fn()
         ev1.record()
-        if self.use_dist:
-            self.dist.all_reduce(self.flag)  # the barrier: completes on a rank only when every rank has got here
         torch.cuda.synchronize(self.dev)
         wall = time.perf_counter() - t0
+        if self.use_dist:
+            self.dist.barrier()  # every rank's launches are done before anybody goes on (outside the clock, see above)
         return wall, ev0.elapsed_time(ev1) / k  # seconds, ms per launch
 
 
