@@ -61,10 +61,12 @@ template <int G, int LM, int MODE, bool ML1, int LX = -1>
 __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P, LaunchArgs K) {
     constexpr bool GEN = (MODE >= 2 && MODE <= 5) || MODE == 7 || MODE == 8, ROLL = MODE >= 1 && MODE <= 3;
     constexpr bool PES = MODE == 3 || MODE == 5 || MODE == 8;  // (the launcher picks these exactly when LAUNCH_PER_ENV_SOURCES is set)
-    // More than 4 sources: the beam masks live in the env's LDS record instead of LM registers of every lane (step_lanes.hpp BM;
-    // per-env-sources rollouts keep the registers: see DESIGN).  4 agents and 8 sources: state machine 11.5 -> 8.9 us, config 5
-    // (8 agents, 8 sources) 41.6 -> 20.1, 20 sources 121 -> 15.
-    constexpr bool BM = (LM >= 8) && !(PES && ROLL);
+    // More than 4 sources: the beam masks live in the env's LDS record instead of LM registers of every lane (step_lanes.hpp BM).
+    // 4 agents and 8 sources: state machine 11.5 -> 8.9 us, config 5 (8 agents, 8 sources) 41.6 -> 20.1, 20 sources 121 -> 15.
+    // (Round 2 kept the registers in the per-env-sources ROLLOUT mode, MODE 3, where the record form had faulted on the
+    // 20-source map; on the round-3 kernels it does not: 8e8 env-steps of fused rollouts against single steps on five
+    // many-source maps, tools/soak_mode3.py -- and those instantiations lose 100-700 B of scratch per lane.)
+    constexpr bool BM = LM >= 8;
     constexpr int LR = BM ? 1 : LM;  // beam REGISTERS of a lane
     // Big rows (LAUNCH_SPLIT_ROWS, set by the launcher when private whole-row copies would leave one workgroup per CU):
     // the row is split over the wavefronts of the workgroup, see write_observations_split (obs_stream.hpp).  Only the

@@ -359,3 +359,39 @@ def test_recolour_resets_argument_checks():
     if deep.map.max_cell_layers > 2:
         with pytest.raises(Exception, match="more than two laser layers"):
             deep.step(sample=True, auto_reset=True, recolour_resets=True)
+
+
+@pytest.mark.parametrize("name", ["gen_12x13_4agents_8lasers", "many_agents", "gen_20_lasers", "config5_32x32"])
+def test_fused_rollout_with_per_env_sources_on_many_source_maps(name):
+    """lle_batch_rollout on batches with per-environment sources (step_kernel MODE 3) on maps with 8, 14, 20 and 8 sources
+    (LM = 8 / 16 / 32 beam words): the fused rollout -- in place and into a ring -- must leave what the same number of single
+    steps leaves (MODE 5 / 8, compared with the oracle above), state and every ring slot."""
+    import torch
+
+    from lle_amd import BatchedWorld, mapgen
+
+    text = mapgen.generate(12, 13, 4, 8, 4, seed=2) if name.startswith("gen_12x13") else EXTRA_MAPS[name]
+    n = 384
+    a, b, c = BatchedWorld(text, n), BatchedWorld(text, n), BatchedWorld(text, n)
+    A, L = a.map.n_agents, a.map.n_sources
+    rng = np.random.default_rng(12)
+    colours = torch.from_numpy(legal_colours(a.map, rng.integers(0, A, size=(n, L), dtype=np.uint8)))
+    enabled = torch.from_numpy((rng.integers(0, 1 << min(L, 30), size=n) | (rng.integers(0, 2, size=n) * ((1 << L) - 1))).astype(np.int64).astype(np.int32))
+    for w in (a, b, c):
+        w.set_sources(colours, enabled)
+    T = 12
+    ring = c.make_ring(4)
+    a.rollout(T, auto_reset=True, seed=31, t=0)
+    c.rollout(T, auto_reset=True, seed=31, t=0, ring=ring, ring_pos=0)
+    obs_of_step = {}
+    for t in range(T):
+        b.step(sample=True, auto_reset=True, seed=31, t=t)
+        if t >= T - 4:
+            obs_of_step[t % 4] = (b.obs.clone(), b.actions.clone())
+    for k in ("pos", "bits", "gems", "beams", "avail", "obs", "err", "evcount", "events", "done"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), (name, k)
+        if k != "obs":
+            assert torch.equal(getattr(c, k), getattr(b, k)), (name, "ring", k)
+    for slot, (obs, acts) in obs_of_step.items():
+        assert torch.equal(ring["obs"][slot], obs) and torch.equal(ring["actions"][slot], acts), (name, "ring slot", slot)
+    assert a.stats()["env_steps"] == b.stats()["env_steps"] == n * T
