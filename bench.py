@@ -63,8 +63,9 @@ def cpu_baseline(n_envs, seconds_target=12.0):
     """The CPU oracle (C restatement of the reference algorithm, kind "port") on a bounded sample of the same workload:
     the same n_envs level-6 environments, sampled actions + auto-reset + int8 layered observation.  The thread count is
     SWEPT -- 64, 128 and every core this process may run on (deduplicated, capped at the visible cores), threads pinned to
-    distinct cores over disjoint env ranges -- for about `seconds_target` seconds in total; every point is reported and the
-    best one is quoted as `value`."""
+    distinct CPUs spread evenly over the allowed set, disjoint env ranges; then the best count once more with placement left
+    to the scheduler -- for about `seconds_target` seconds in total; every point is reported and the best one is quoted as
+    `value`."""
     import numpy as np
 
     from oracle import oracle
@@ -77,9 +78,12 @@ def cpu_baseline(n_envs, seconds_target=12.0):
     obs = np.zeros((n_envs, ob.C * ob.H * ob.W), np.int8)
     oracle.set_thread_pinning(True)
     ob.rollout(2, SEED, counts[-1], obs)  # warm-up: pages of `obs` touched, worlds in cache
-    per_point = seconds_target / (len(counts) + 0.25)
+    per_point = seconds_target / (len(counts) + 1.25)
     sweep = []
-    for threads in counts:
+    for threads, pinned in [(c, True) for c in counts] + [(None, False)]:
+        if threads is None:  # one more point: the best pinned thread count again, placement left to the scheduler
+            threads = max(sweep, key=lambda p: p["env_steps_per_s"])["threads"]
+        oracle.set_thread_pinning(pinned)
         cal = 4
         t0 = time.perf_counter()
         ob.rollout(cal, SEED, threads, obs)
@@ -88,7 +92,7 @@ def cpu_baseline(n_envs, seconds_target=12.0):
         t0 = time.perf_counter()
         ob.rollout(steps, SEED, threads, obs)
         dt = time.perf_counter() - t0
-        sweep.append({"threads": threads, "steps": steps, "seconds": dt, "env_steps_per_s": n_envs * steps / dt,
+        sweep.append({"threads": threads, "pinned": pinned, "steps": steps, "seconds": dt, "env_steps_per_s": n_envs * steps / dt,
                       "agent_steps_per_s": ob.A * n_envs * steps / dt})
     best = max(sweep, key=lambda p: p["env_steps_per_s"])
     steps1 = max(2, int(0.25 * per_point * best["env_steps_per_s"] / best["threads"] / n_envs))
@@ -98,12 +102,12 @@ def cpu_baseline(n_envs, seconds_target=12.0):
     oracle.set_thread_pinning(False)
     return {
         "value": best["agent_steps_per_s"], "unit": "agent-steps/s", "cores": best["threads"], "kind": "port",
-        "threads_used": best["threads"], "threads_pinned": True, "host_cores_visible": cores, "host_cores_total": os.cpu_count(),
+        "threads_used": best["threads"], "threads_pinned": best["pinned"], "host_cores_visible": cores, "host_cores_total": os.cpu_count(),
         "env_steps_per_s": best["env_steps_per_s"], "seconds": sum(p["seconds"] for p in sweep), "thread_sweep": sweep,
         "single_thread_env_steps_per_s": n_envs * steps1 / dt1,
         "sample": f"level {LEVEL}, {n_envs} envs, sampled actions + auto-reset + int8 layered obs, C restatement of the Rust reference "
-                  f"algorithm (oracle/lle_oracle.c); thread sweep {counts} (pinned) on {cores} visible host cores, "
-                  f"{'/'.join(str(p['steps']) for p in sweep)} steps per point; best: {best['threads']} threads, "
+                  f"algorithm (oracle/lle_oracle.c); thread sweep {counts} (pinned, spread evenly over the allowed CPUs) + the best count unpinned, on {cores} visible host cores, "
+                  f"{'/'.join(str(p['steps']) for p in sweep)} steps per point; best: {best['threads']} threads{' pinned' if best['pinned'] else ' unpinned'}, "
                   f"{best['steps']} steps in {best['seconds']:.1f} s",
     }
 

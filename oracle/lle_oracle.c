@@ -996,7 +996,9 @@ void ow_batch_dump(ow_batch* b, int64_t e0, int64_t e1, int beam_stride,
 #include <sched.h>
 typedef struct { ow_batch* b; int64_t e0, e1; int steps; uint64_t seed; int8_t* obs; int64_t stats[8]; int cpu; } rollout_job;
 static int g_pin_threads = 0;
-/* bench.py cpu_baseline: pin thread k of a rollout to the k-th CPU this process may run on (0 = leave it to the scheduler) */
+/* bench.py cpu_baseline: pin the threads of a rollout to CPUs this process may run on, spread evenly over the allowed set
+ * (thread k of n on the (k * allowed / n)-th allowed CPU: distinct cores and both sockets also when n < allowed);
+ * 0 = leave it to the scheduler */
 void ow_set_thread_pinning(int on) { g_pin_threads = on; }
 static void* rollout_thread(void* arg) {
     rollout_job* j = (rollout_job*)arg;
@@ -1021,7 +1023,7 @@ void ow_batch_rollout(ow_batch* b, int steps, uint64_t seed, int n_threads, int8
     if (g_pin_threads && n_threads > 1 && sched_getaffinity(0, sizeof allowed, &allowed) == 0)
         for (int c = 0; c < CPU_SETSIZE; c++) if (CPU_ISSET(c, &allowed)) cpus[n_allowed++] = c;
     for (int k = 0; k < n_threads; k++) {
-        jobs[k].cpu = n_allowed > 0 ? cpus[k % n_allowed] : -1;
+        jobs[k].cpu = n_allowed <= 0 ? -1 : n_threads <= n_allowed ? cpus[(int64_t)k * n_allowed / n_threads] : cpus[k % n_allowed];
         jobs[k].b = b; jobs[k].e0 = b->n * k / n_threads; jobs[k].e1 = b->n * (k + 1) / n_threads;
         jobs[k].steps = steps; jobs[k].seed = seed; jobs[k].obs = obs;
         if (n_threads == 1) rollout_thread(&jobs[k]);

@@ -48,8 +48,9 @@ def main():
     with concurrent.futures.ThreadPoolExecutor(args.jobs) as ex:
         results = list(ex.map(analyse, files))
     lines = ["# Kernel resource usage (hipcc -Rpass-analysis=kernel-resource-usage, gfx950)", "",
-             "`step_kernel<G, LM, MODE, ML1, LX>`: G lanes per env, LM beam registers, MODE 0 single step (6: with the row heads ahead of the state machine) / 1 fused rollout / 2-3 general "
-             "rollout (several maps / per-env sources) / 4-5 general single step, ML1 = at most one laser layer per cell, LX = exact source count.", ""]
+             "`step_kernel<G, LM, MODE, ML1, LX>`: G lanes per env, LM beam masks per lane (LM >= 8: kept in the LDS record, not in registers), MODE 0 single step (6: with the row heads ahead of "
+             "the state machine) / 1 fused rollout / 2-3 general rollout (several maps / per-env sources) / 4-5 general single step (7 / 8: 4 / 5 with the row heads), ML1 = at most one laser "
+             "layer per cell, LX = exact source count.", ""]
     total = spilled = 0
     for fname, rows in results:
         if not rows:
