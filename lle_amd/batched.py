@@ -35,11 +35,15 @@ class BatchedWorld:
       err [n] u8 - evcount [n] u8 - events [n,2A] u8 (type<<4|agent) - done [n] u8 - obs [n,C,H,W] i8
     """
 
-    def __init__(self, map_or_text, n_envs, device=None, envs_per_wave=None, row_align=None):
+    def __init__(self, map_or_text, n_envs, device=None, envs_per_wave=None, row_align=None, placement_candidates=None):
         """`map_or_text`: a Map / map text, or a LIST of them for a batch of several maps -- map m then owns the envs
         [m * n_envs / len(maps), (m + 1) * n_envs / len(maps)); the maps must agree on height, width and the numbers of
         agents, sources and gems, and each must own a multiple of 64 envs.
-        `row_align`: pitch of the observation rows in bytes (Map.set_row_align: applied to the maps given)."""
+        `row_align`: pitch of the observation rows in bytes (Map.set_row_align: applied to the maps given).
+        `placement_candidates`: k > 1 allocates k arenas, times the step kernel's store pattern on each
+        (lle_batch_probe_row_fill) and keeps the fastest; the others are released (torch.cuda.empty_cache()).  Worth it only
+        when the rows of a step exceed the 256 MB Infinity Cache: there the write rate depends on where the allocation landed
+        (profiles/r03_hbm_fronts.md: 5.8 ... 6.8 TB/s over twelve buffers of one process).  `self.placement` records the timings."""
         _require_gpu()
         many = isinstance(map_or_text, (list, tuple))
         self.maps = [m if isinstance(m, Map) else Map(m) for m in (map_or_text if many else [map_or_text])]
@@ -64,22 +68,63 @@ class BatchedWorld:
             nbytes = L.lle_batch_arena_bytes(self.map.h, self.n_envs)
         if nbytes <= 0:
             raise RuntimeError(L.lle_last_error().decode())
-        with torch.cuda.device(self.device):
-            self.arena = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
-            skew = (-self.arena.data_ptr()) % 256
-            self._base = self.arena[skew:skew + nbytes]
+        def create():
+            arena = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+            base = arena[(-arena.data_ptr()) % 256:][:nbytes]
             if many:
-                self.h = L.lle_batch_create_multi(handles, len(self.maps), self.envs_per_map, self.device.index or 0,
-                                                  self._base.data_ptr(), nbytes, self._stream())
+                h = L.lle_batch_create_multi(handles, len(self.maps), self.envs_per_map, self.device.index or 0, base.data_ptr(), nbytes,
+                                             self._stream())
             else:
-                self.h = L.lle_batch_create(self.map.h, self.n_envs, self.device.index or 0, self._base.data_ptr(), nbytes,
-                                            self._stream())
-        if not self.h:
-            raise RuntimeError(f"lle_batch_create failed: {L.lle_last_error().decode()}")
+                h = L.lle_batch_create(self.map.h, self.n_envs, self.device.index or 0, base.data_ptr(), nbytes, self._stream())
+            if not h:
+                raise RuntimeError(f"lle_batch_create failed: {L.lle_last_error().decode()}")
+            return arena, base, h
+
+        self.placement = None
+        with torch.cuda.device(self.device):
+            k = max(1, int(placement_candidates or 1))
+            if k == 1:
+                self.arena, self._base, self.h = create()
+            else:
+                self.arena, self._base, self.h = self._place(create, k)
         if envs_per_wave is not None:
             self.set_envs_per_wave(envs_per_wave)
         self._bind()
         self.t = 0
+
+    def _place(self, create, k):
+        """k candidate arenas side by side (all alive until every one is timed: distinct physical memory), the row-fill
+        probe on each, the fastest kept."""
+        L = _capi.lib()
+        cands, times = [], []
+        try:
+            for _ in range(k):
+                cands.append(create())
+            st = self._stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _, _, h in cands:
+                for _ in range(3):
+                    self._check(L.lle_batch_probe_row_fill(h, 0, st))
+                e0.record()
+                for _ in range(10):
+                    self._check(L.lle_batch_probe_row_fill(h, 0, st))
+                e1.record()
+                e1.synchronize()
+                times.append(e0.elapsed_time(e1) * 100.0)  # us per launch
+            best = min(range(k), key=times.__getitem__)
+        except Exception:
+            for _, _, h in cands:
+                L.lle_batch_free(h)
+            raise
+        for i, (_, _, h) in enumerate(cands):
+            if i != best:
+                L.lle_batch_free(h)
+        arena, base, h = cands[best]
+        del cands
+        torch.cuda.empty_cache()
+        self._check(L.lle_batch_reset(h, None, self._stream()))  # the probe overwrote the rows: back to the start state's observation
+        self.placement = {"candidates": k, "row_fill_us": [round(t, 2) for t in times], "chosen": best}
+        return arena, base, h
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):

@@ -65,3 +65,28 @@ def test_handles_on_two_devices_with_the_wrong_device_current(oracle_mod):
             assert_step_equal(eng, ostep, f"device {d} t={t}")
             assert_state_equal(eng, ob.dump(), f"device {d} t={t}")
     assert bws[0].stats()["env_steps"] == bws[1].stats()["env_steps"] == 8 * n
+
+
+def test_placement_candidates_keep_one_arena_and_change_nothing(oracle_mod):
+    """BatchedWorld(placement_candidates=k): k arenas timed with the row-fill probe, the fastest kept, back in the start
+    state -- then the batch is the batch it would have been (steps against the oracle)."""
+    import torch
+
+    from lle_amd import BatchedWorld
+    from tests.parity_util import assert_state_equal, assert_step_equal, unpack_engine
+    n = 1024
+    bw = BatchedWorld(LEVELS[6], n, placement_candidates=3)
+    p = bw.placement
+    assert p["candidates"] == 3 and len(p["row_fill_us"]) == 3 and 0 <= p["chosen"] < 3 and min(p["row_fill_us"]) > 0
+    assert p["row_fill_us"][p["chosen"]] == min(p["row_fill_us"])
+    plain = BatchedWorld(LEVELS[6], n)
+    assert plain.placement is None
+    torch.cuda.synchronize()
+    assert torch.equal(bw.obs, plain.obs) and torch.equal(bw.pos, plain.pos) and torch.equal(bw.avail, plain.avail)
+    ob = oracle_mod.OracleBatch(LEVELS[6], n)
+    for t in range(6):
+        bw.step(sample=True, auto_reset=True, seed=11, t=t)
+        ostep = ob.step(None, auto_reset=True, seed=11, t=t)
+        eng = unpack_engine(bw.host_buffers(), ob.A, ob.G, ob.Ls, ob.beam_stride, ob.C, ob.H, ob.W)
+        assert_step_equal(eng, ostep, f"placed t={t}")
+        assert_state_equal(eng, ob.dump(), f"placed t={t}")
