@@ -76,6 +76,24 @@ def test_config3_level6_batch65536(oracle_mod):
         check(bw, ob, ob.step(None, auto_reset=True, seed=1234, t=t), f"t={t}")
 
 
+@pytest.mark.parametrize("rank", [3, 7])
+def test_config4_one_shard_of_the_524288_env_job(oracle_mod, rank):
+    """BASELINE.json configs[3]: level 6 x 524 288 envs sharded over 8 GPUs = 65 536 envs per rank, rank r sampling for the
+    global env ids [r * 65 536, (r + 1) * 65 536) (lle_amd/distributed.py shard_range -> env_offset).  No 8-GPU box here:
+    the shard of one rank on the one GPU, every buffer against the oracle stepping the same global ids."""
+    from lle_amd import BatchedWorld
+    from lle_amd.distributed import shard_range
+
+    lo, hi = shard_range(524288, rank, 8)
+    assert (lo, hi) == (rank * 65536, (rank + 1) * 65536)
+    n = hi - lo
+    ob = oracle_mod.OracleBatch(LEVELS[6], n)
+    bw = BatchedWorld(LEVELS[6], n)
+    for t in range(8):
+        bw.step(sample=True, auto_reset=True, seed=77, t=t, env_offset=lo)
+        check(bw, ob, ob.step(None, auto_reset=True, seed=77, t=t, env_offset=lo), f"rank {rank} t={t}")
+
+
 def test_explicit_and_invalid_actions(oracle_mod):
     import torch
 
@@ -417,6 +435,20 @@ def test_config5_plain_store_path(oracle_mod):
         bw.step(sample=True, auto_reset=True, seed=21, t=t)
         check(bw, ob, ob.step(None, auto_reset=True, seed=21, t=t), f"t={t}")
 
+
+def test_config5_full_batch_against_the_oracle(oracle_mod):
+    """BASELINE configs[4] at its full batch of 65 536 envs (1.34 GB of rows per launch), every buffer against the oracle
+    (until round 3 only the soak runs did this; two steps keep it to seconds)."""
+    from lle_amd import BatchedWorld, mapgen
+
+    text = mapgen.config5(0)
+    n = 65536
+    ob = oracle_mod.OracleBatch(text, n)
+    bw = BatchedWorld(text, n)
+    assert bw.kernel_info()["kernel"] == "step_kernel<8,8>"
+    for t in range(2):
+        bw.step(sample=True, auto_reset=True, seed=33, t=t)
+        check(bw, ob, ob.step(None, auto_reset=True, seed=33, t=t), f"t={t}")
 
 
 @pytest.mark.parametrize("name", ["level6", "corridor", "nested", "many_agents", "gen_20_lasers", "config5_32x32"])
