@@ -147,12 +147,39 @@ class Direction(Enum):
             return letters[value]
         raise ValueError(f"Invalid direction string: {value}")
 
+    @staticmethod
+    def from_str(direction):
+        """pydirection.rs:82-90: one of "N", "E", "S", "W"; ValueError otherwise."""
+        letters = {"N": Direction.NORTH, "E": Direction.EAST, "S": Direction.SOUTH, "W": Direction.WEST}
+        if direction not in letters:
+            raise ValueError("Invalid direction string.")
+        return letters[direction]
+
     def opposite(self):
         return Direction((self.value + 2) % 4)
 
     @property
     def delta(self):
         return {0: (-1, 0), 1: (0, 1), 2: (1, 0), 3: (0, -1)}[self.value]
+
+    @property
+    def is_horizontal(self):
+        return self in (Direction.EAST, Direction.WEST)  # pydirection.rs:112-117
+
+    @property
+    def is_vertical(self):
+        return not self.is_horizontal
+
+    @property
+    def name(self):
+        """The map's letter, as in the reference (pydirection.rs:129-138) -- not the enum member's identifier."""
+        return "NESW"[self.value]
+
+    def __repr__(self):
+        return self.name
+
+    def __hash__(self):
+        return self.value  # pydirection.rs:158-165
 
 
 class WorldEvent:
@@ -230,18 +257,39 @@ class Laser:
         return not self.is_enabled
 
     def __repr__(self):
-        return (f"Laser(laser_id={self.laser_id}, is_on={self.is_on}, direction={self.direction.name}, "
-                f"agent_id={self.agent_id}, agent={self.agent})")
+        return (f"Laser(laser_id={self.laser_id}, is_on={_rust_bool(self.is_on)}, direction={self.direction.name}, "
+                f"agent_id={self.agent_id}, agent={self.agent})")  # pylaser.rs:83-96
+
+
+def _rust_bool(b):
+    return "true" if b else "false"
 
 
 class Gem:
-    """Snapshot of one gem (src/bindings/tiles/pygem.rs:13-66)."""
+    """One gem (src/bindings/tiles/pygem.rs:13-88): `pos` and `is_collected` are a snapshot taken when the list was built,
+    `agent` reads the world, `collect()` marks the gem collected IN the world (no event, no reward: tiles/gem.rs:17-19)."""
 
-    def __init__(self, pos, is_collected, occupant):
-        self.pos, self.is_collected, self.agent = pos, bool(is_collected), occupant
+    def __init__(self, world, index, pos, is_collected):
+        self._world, self._index = world, index
+        self.pos, self.is_collected = pos, bool(is_collected)
+
+    @property
+    def agent(self):
+        if self.pos in self._world._laser_cells:  # the tile there is a Laser, not a Gem (pygem.rs:69-76)
+            return None
+        return self._world._occupant_at(self._world._state(), self.pos)
+
+    def collect(self):
+        if self.pos in self._world._laser_cells:  # `inner` is World::at_mut: a gem under a beam is a Laser tile (pygem.rs:52-62)
+            raise ValueError(f"Tile at {self.pos} is not a gem")
+        self._world._collect_gem(self._index)
+        self.is_collected = True
 
     def __repr__(self):
-        return f"Gem(pos={self.pos}, is_collected={self.is_collected}, agent={self.agent})"
+        a = self.agent
+        return f"Gem(pos={self.pos}, is_collected={_rust_bool(self.is_collected)}, agent={'None' if a is None else f'Some({a})'})"
+
+    __str__ = __repr__
 
 
 class Agent:
@@ -329,8 +377,8 @@ class LaserSource:
         return self.laser_id
 
     def __repr__(self):
-        return (f"LaserSource(laser_id={self.laser_id}, is_enabled={self.is_enabled}, direction={self.direction.name}, "
-                f"agent_id={self.agent_id})")
+        return (f"LaserSource(laser_id={self.laser_id}, is_enabled={_rust_bool(self.is_enabled)}, direction={self.direction.name}, "
+                f"agent_id={self.agent_id})")  # pylaser_source.rs:167-175
 
 
 # ------------------------------------------------------------------------------------------------ World
@@ -554,7 +602,14 @@ class World:
     def gems(self):
         st = self._state()
         col = _decode.gem_bits(st["gems"], self.n_gems)
-        return [Gem(p, c, self._occupant_at(st, p)) for p, c in zip(self._gem_pos, col)]
+        return [Gem(self, g, p, c) for g, (p, c) in enumerate(zip(self._gem_pos, col))]
+
+    def _collect_gem(self, index):
+        """Gem.collect (pygem.rs:52-66): bit `index` of the env's gem word, then the observation rebuilt from the state."""
+        bw = self._batch
+        bit = 1 << int(index)
+        bw.gems[0] |= bit - (1 << 32) if bit >= 1 << 31 else bit  # (an int32 word)
+        bw.observe()
 
     @property
     def gems_collected(self):

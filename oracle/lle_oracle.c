@@ -776,6 +776,15 @@ int ow_tile_agent(ow_world* w, int i, int j) {
     if (i < 0 || j < 0 || i >= w->height || j >= w->width) return -2;
     return tile_agent(at(w, i, j));
 }
+/* Gem.collect() of the bindings (src/bindings/tiles/pygem.rs:52-66 -> tiles/gem.rs:17-19): `collected = true` on the tile AT the
+ * position -- World::at_mut, so a gem lying under a beam is a Laser tile there and the call fails (-1; ValueError in Python) */
+int ow_gem_collect(ow_world* w, int i, int j) {
+    if (i < 0 || j < 0 || i >= w->height || j >= w->width) return -1;
+    tile_t* t = at(w, i, j);
+    if (t->kind != T_GEM) return -1;
+    t->collected = true;
+    return 0;
+}
 /* source mutators (laser_source.rs:37-47; pylaser_source.rs:55-75,107-142 without its start check) */
 void ow_source_set_enabled(ow_world* w, int laser_id, int enabled) { if (enabled) beam_enable(w->beams[laser_id]); else beam_disable(w->beams[laser_id]); }
 void ow_source_set_agent_id(ow_world* w, int laser_id, int agent_id) { w->beams[laser_id]->agent_id = agent_id; }

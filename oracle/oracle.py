@@ -78,6 +78,8 @@ def lib():
         L.ow_lasers.argtypes = [vp, pi32, i32]
         L.ow_tile_agent.restype = i32
         L.ow_tile_agent.argtypes = [vp, i32, i32]
+        L.ow_gem_collect.restype = i32
+        L.ow_gem_collect.argtypes = [vp, i32, i32]
         L.ow_set_exits.restype = i32
         L.ow_set_exits.argtypes = [vp, pi32, i32]
         L.ow_source_set_enabled.argtypes = [vp, i32, i32]
@@ -270,6 +272,11 @@ class OracleWorld:
 
     def tile_agent(self, i, j):
         return self.L.ow_tile_agent(self.h, i, j)
+
+    def collect_gem(self, i, j):
+        """Gem.collect() (pygem.rs:52-66)."""
+        if self.L.ow_gem_collect(self.h, int(i), int(j)) != 0:
+            raise OracleError("ValueError")
 
     def obs(self):
         c = 2 * self.n_agents + 4

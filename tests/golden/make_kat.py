@@ -549,6 +549,29 @@ case("derived_set_exits_replaces_a_void_under_a_laser", "src/core/tiles/laser.rs
 case("derived_set_exits_then_clone", "src/core/world.rs:645-652", map=MAP_SET_EXITS,
      script=[reset(), set_exits([(0, 1), (1, 1)]), step([E], events=[[EXIT, 0]]), clone_check()])
 
+
+
+# ---- Gem.collect() of the bindings (src/bindings/tiles/pygem.rs:52-66 -> tiles/gem.rs:17-19): the reference has no test for it
+# (python/tests/test_tiles.py:6 lists it as to do); derived from the two functions.  Layers for A = 1: gem = 4.
+def collect_gem(pos, **kw):
+    return {"op": "collect_gem", "pos": list(pos), **kw}
+
+
+# collected without an event; entering it later collects nothing (gem.rs:26-33); reset puts it back (gem.rs:21-24)
+case("derived_gem_collect", "src/bindings/tiles/pygem.rs:52-66", map="S0 G . X",
+     script=[reset(), expect(gems=[False], obs_cells=[[4, 0, 1, 1]]), collect_gem((0, 1)),
+             expect(gems=[True], n_gems_collected=1, obs_cells=[[4, 0, 1, 0]], positions=[[0, 0]]),
+             step([E], n_events=0), expect(tile_agent=[[0, 1, 0]]), step([E], n_events=0), step([E], events=[[EXIT, 0]]),
+             reset(), expect(gems=[False], obs_cells=[[4, 0, 1, 1]]), step([E], events=[[GEM, 0]])])
+# `inner` is World::at_mut: a gem under a beam is a Laser tile there, and so is any other cell -> ValueError, nothing changes
+case("derived_gem_collect_refused", "src/bindings/tiles/pygem.rs:52-62", map="S0 . X\nL0E G .",
+     script=[reset(), collect_gem((1, 1), error="ValueError"), collect_gem((0, 1), error="ValueError"),
+             expect(gems=[False], n_gems_collected=0, obs_cells=[[4, 1, 1, 1]])])
+# with the collector standing on ANOTHER gem: only the addressed bit moves
+case("derived_gem_collect_one_of_two", "src/bindings/tiles/pygem.rs:52-66", map="S0 G G X",
+     script=[reset(), step([E], events=[[GEM, 0]]), collect_gem((0, 2)), expect(gems=[True, True], n_gems_collected=2),
+             step([E], n_events=0), step([E], events=[[EXIT, 0]])])
+
 if __name__ == "__main__":
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kat_world.json")
     with open(out, "w") as f:

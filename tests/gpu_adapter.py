@@ -91,6 +91,12 @@ class GpuWorld:
             raise KatError("Panic") from None
         self.exit_pos = self.w.exit_pos
 
+    def collect_gem(self, i, j):
+        try:
+            self.w.gem_at((i, j)).collect()  # the facade's Gem.collect (pygem.rs:52-66)
+        except ValueError:
+            raise KatError("ValueError") from None
+
     def tile_agent(self, i, j):
         a = self.w._occupant_at(self.w._state(), (i, j))
         return -1 if a is None else a

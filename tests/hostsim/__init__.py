@@ -250,6 +250,15 @@ class SimWorld:
         self.b.set_exits(exits)
         self.exit_pos = self.b.map.positions(_capi.LLE_POS_EXIT)
 
+    def collect_gem(self, i, j):
+        """Gem.collect() (pygem.rs:52-66) the way the facade does it: the gem's bit in the env's word, observation rebuilt."""
+        gems = self.b.map.positions(_capi.LLE_POS_GEM)
+        under_beam = {(t.i, t.j) for t in self.b.map.laser_tiles()}
+        if (i, j) not in gems or (i, j) in under_beam:
+            raise SimError("ValueError")
+        self.b.buf("gems")[0] |= np.uint32(1 << gems.index((i, j)))
+        self.b.L.hs_observe(self.b.h)
+
     def tile_agent(self, i, j):
         """Tile::agent (tile.rs:86-95): the occupant of cell (i, j), -1 = none."""
         occ = self._bits()[2]

@@ -319,6 +319,14 @@ def run_case(make, case, derived=True):
                 assert "error" in op and _kind(e) in op["error"].split("|"), (_kind(e), op.get("error"))
             else:
                 assert "error" not in op, f"expected {op.get('error')}"
+        elif kind == "collect_gem":
+            # Gem.collect() (pygem.rs:52-66): no event, the gem simply counts as collected from now on
+            try:
+                w.collect_gem(*op["pos"])
+            except Exception as e:  # noqa: BLE001
+                assert "error" in op and _kind(e) in op["error"].split("|"), (_kind(e), op.get("error"))
+            else:
+                assert "error" not in op, f"expected {op.get('error')}"
         elif kind == "clone_check":
             # World::clone (world.rs:645-652) = a new world from the config + set_state(get_state()); deepcopy is clone
             c = w.clone() if hasattr(w, "clone") else _generic_clone(make, case, w)

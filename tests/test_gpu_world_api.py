@@ -25,6 +25,31 @@ def test_world_step_tuple_and_invalid_sequence_action():   # test_world.py:92-10
     assert world.step(Action.SOUTH) == [] and world.agents_positions == [(2, 0)]   # a bare Action for a single agent (:52-62)
 
 
+def test_gem_collect_and_the_tile_reprs():
+    """Gem.collect() / Gem.agent (src/bindings/tiles/pygem.rs:52-88) and the strings the bindings print
+    (pygem.rs:78-88, pylaser.rs:83-96, pylaser_source.rs:167-175: Rust's `true` / `false`, `Some(0)` / `None`, the direction's letter)."""
+    from lle_amd import Action, World
+
+    world = World("S0 G . X\nL0E G . .")
+    world.reset()
+    free, under = world.gems
+    assert (free.pos, under.pos) == ((0, 1), (1, 1)) and not free.is_collected
+    assert repr(free) == str(free) == "Gem(pos=(0, 1), is_collected=false, agent=None)"
+    free.collect()
+    assert free.is_collected and world.gems[0].is_collected and world.gems_collected == 1
+    assert world.get_state().gems_collected == [True, False]
+    assert int(world.layered_observation()[4, 0, 1]) == 0 and int(world.layered_observation()[4, 1, 1]) == 1
+    assert world.step(Action.EAST) == []   # nothing left to collect there (gem.rs:26-33)
+    assert free.agent == 0 and repr(world.gems[0]) == "Gem(pos=(0, 1), is_collected=true, agent=Some(0))"
+    with pytest.raises(ValueError, match="is not a gem"):
+        under.collect()   # a Laser tile wraps it (World::at_mut)
+    assert under.agent is None and not world.gems[1].is_collected
+    assert repr(world.laser_sources[0]) == "LaserSource(laser_id=0, is_enabled=true, direction=E, agent_id=0)"
+    assert repr(world.lasers[0]).startswith("Laser(laser_id=0, is_on=true, direction=E, agent_id=0, agent=None")
+    world.reset()
+    assert [g.is_collected for g in world.gems] == [False, False]
+
+
 def test_sampled_stepper_equals_step():
     """BatchedWorld.sampled_stepper(): the bound hot-loop callable takes the same steps as step(sample=True, ...)."""
     import pytest

@@ -96,3 +96,13 @@ def test_direction():   # python/tests/test_direction.py (all of it)
         Direction("z")
     assert [d.delta for d in ds] == [(-1, 0), (1, 0), (0, 1), (0, -1)]
     assert [d.opposite() for d in ds] == [Direction.SOUTH, Direction.NORTH, Direction.WEST, Direction.EAST]
+    # the rest of the stub (python/lle/tiles/__init__.pyi:150-200, src/bindings/tiles/pydirection.rs:82-165)
+    assert [d.name for d in ds] == ["N", "S", "E", "W"] and [repr(d) for d in ds] == ["N", "S", "E", "W"]
+    assert [d.is_horizontal for d in ds] == [False, False, True, True] and [d.is_vertical for d in ds] == [True, True, False, False]
+    assert [Direction.from_str(c) for c in "NSEW"] == ds
+    with pytest.raises(ValueError, match="Invalid direction string."):
+        Direction.from_str("north")
+    assert [hash(d) for d in (Direction.NORTH, Direction.EAST, Direction.SOUTH, Direction.WEST)] == [0, 1, 2, 3]
+    import copy
+    import pickle
+    assert all(pickle.loads(pickle.dumps(d)) is d and copy.deepcopy(d) is d for d in ds)
