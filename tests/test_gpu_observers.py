@@ -174,6 +174,32 @@ def test_full_size_properties():
     assert torch.all(walk | ~strict)                          # the laser filter only removes actions
 
 
+def test_perspective_output_beyond_4_GiB():
+    """Maximum sizes: the perspective tensor of config 5 at 65 536 envs is 10.7 GB -- (env, agent) row offsets pass 2^32 in
+    the kernel.  The relation to the layered tensor (agent k's view = layers 0 <-> k and A <-> A + k swapped) on every env."""
+    import torch
+
+    from lle_amd import BatchedWorld, _capi, mapgen
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 24 << 30:
+        pytest.skip("needs 24 GB of free device memory")
+    n = 65536
+    bw = BatchedWorld(mapgen.config5(0), n)
+    for t in range(4):
+        bw.step(sample=True, auto_reset=True, seed=8, t=t)
+    A, H, W = bw.map.n_agents, bw.map.height, bw.map.width
+    persp = bw.observe_as(_capi.LLE_OBS_PERSPECTIVE)
+    assert persp.shape == (n, A, 2 * A + 4, H, W) and persp.numel() > 1 << 33
+    layered = bw.obs
+    for k in range(A):
+        perm = list(range(2 * A + 4))
+        perm[0], perm[k] = perm[k], perm[0]
+        perm[A], perm[A + k] = perm[A + k], perm[A]
+        for lo in range(0, n, 16384):
+            assert torch.equal(persp[lo:lo + 16384, k], layered[lo:lo + 16384][:, perm]), (k, lo)
+
+
 def test_unsupported_colour_raises_index_error():
     """A laser colour without a layer: IndexError like the reference (python/lle/observations.py:229, 259, 356)."""
     from lle_amd import BatchedWorld, _capi

@@ -76,6 +76,48 @@ def test_config3_level6_batch65536(oracle_mod):
         check(bw, ob, ob.step(None, auto_reset=True, seed=1234, t=t), f"t={t}")
 
 
+def test_rows_beyond_4_GiB(oracle_mod):
+    """Maximum sizes: config 5's map at 262 144 envs = 5.4 GB of observation rows in one launch, so row offsets pass 2^32
+    (and 2^31) inside the kernel.  Windows of 64 envs -- the first, the ones astride the 2 GiB and 4 GiB offsets, the last --
+    against oracle batches stepping the same global env ids; the rest by the size-independent properties."""
+    import torch
+
+    from lle_amd import BatchedWorld, mapgen
+    from tests.parity_util import assert_state_equal, assert_step_equal, unpack_engine
+
+    text = mapgen.config5(0)
+    n = 262144
+    free, _ = torch.cuda.mem_get_info()
+    if free < 8 << 30:
+        pytest.skip("needs 8 GB of free device memory")
+    bw = BatchedWorld(text, n)
+    pitch = bw.map.obs_stride
+    assert n * pitch > 1 << 32
+    starts = sorted({0, (1 << 31) // pitch - 32, (1 << 32) // pitch - 32, n - 64})
+    obs = [oracle_mod.OracleBatch(text, 64) for _ in starts]
+    names = ("pos", "bits", "gems", "beams", "avail", "actions", "err", "evcount", "events", "done")
+    for t in range(3):
+        bw.step(sample=True, auto_reset=True, seed=41, t=t)
+        torch.cuda.synchronize()
+        for lo, ob in zip(starts, obs):
+            ostep = ob.step(None, auto_reset=True, seed=41, t=t, env_offset=lo)
+            bufs = {k: getattr(bw, k)[lo:lo + 64].cpu().numpy() for k in names}
+            bufs["obs"] = bw.obs_rows[lo:lo + 64].cpu().numpy()
+            for k, dt in (("bits", np.uint64), ("gems", np.uint32), ("beams", np.uint32)):
+                bufs[k] = np.ascontiguousarray(bufs[k]).view(dt)
+            eng = unpack_engine(bufs, ob.A, ob.G, ob.Ls, ob.beam_stride, ob.C, ob.H, ob.W)
+            assert_step_equal(eng, ostep, f"envs {lo}.. t={t}")
+            assert_state_equal(eng, ob.dump(), f"envs {lo}.. t={t}")
+    A, H, W = bw.map.n_agents, bw.map.height, bw.map.width
+    for lo in range(0, n, 32768):  # every env: one cell per agent layer, and it is the agent's cell
+        sl = slice(lo, lo + 32768)
+        layers = bw.obs[sl, :A].reshape(32768, A, H * W)
+        cell = bw.pos[sl].to(torch.int64)
+        cell = cell[..., 0] * W + cell[..., 1]
+        assert torch.equal(layers.sum(-1).to(torch.int64), torch.ones(32768, A, dtype=torch.int64, device="cuda")), lo
+        assert torch.all(layers.gather(2, cell.unsqueeze(-1)) == 1), lo
+
+
 @pytest.mark.parametrize("rank", [3, 7])
 def test_config4_one_shard_of_the_524288_env_job(oracle_mod, rank):
     """BASELINE.json configs[3]: level 6 x 524 288 envs sharded over 8 GPUs = 65 536 envs per rank, rank r sampling for the
