@@ -99,7 +99,13 @@ class BatchedWorld:
         cands, times = [], []
         try:
             for _ in range(k):
-                cands.append(create())
+                try:
+                    cands.append(create())
+                except torch.cuda.OutOfMemoryError:  # fewer candidates than asked for: place among those that fit
+                    if not cands:
+                        raise
+                    break
+            k = len(cands)
             st = self._stream()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             for _, _, h in cands:
