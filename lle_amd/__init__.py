@@ -4,9 +4,12 @@ Drop-in for the hot path of yamoling/lle: `World` (single environment, reference
 (tens of thousands of lock-stepped environments per kernel launch, torch tensors over device buffers).
 The compute path is hand-written HIP for gfx950 behind the C ABI of include/lle_hip.h; there is no CPU fallback.
 """
+from . import exceptions, tiles, types, world  # the reference's submodule paths: lle.tiles, lle.exceptions, lle.types, lle.world
 from ._capi import Map, MapParseError
 from .world import (Action, Agent, Direction, EventType, Gem, InvalidActionError, InvalidLevelError, InvalidWorldStateError,
                     Laser, LaserSource, ParsingError, World, WorldEvent, WorldState)
+
+__version__ = "0.3.0"  # (round 3 of this build; the reference exposes lle.__version__: python/tests/test_imports.py:35-39)
 
 
 def __getattr__(name):
@@ -26,4 +29,4 @@ def __getattr__(name):
 
 __all__ = ["Action", "Agent", "AgentZeroPerspective", "BatchedLLE", "BatchedWorld", "Direction", "EventType", "FlattenedLayered", "Gem", "InvalidActionError", "InvalidLevelError",
            "InvalidWorldStateError", "Laser", "LaserSource", "Layered", "LayeredPadded", "Map", "MapParseError",
-           "ObservationType", "ParsingError", "PartialGenerator", "StateGenerator", "World", "WorldEvent", "WorldState"]
+           "ObservationType", "ParsingError", "PartialGenerator", "StateGenerator", "World", "WorldEvent", "WorldState", "__version__", "exceptions", "tiles", "types", "world"]

@@ -8,11 +8,17 @@ reference's protocol -- class names, the channel attributes (`A0`, `LASER_0`, `W
 (SURVEY.md section 2 row 11).
 """
 from enum import Enum
+from typing import Literal
 
 import numpy as np
 
 from . import _capi
 from .world import WorldState
+
+
+# the preset names as a typing Literal (python/lle/observations.py:21-35; pinned by python/tests/test_observations.py:8-17)
+ObservationTypeLiteral = Literal["layered", "flattened", "partial3x3", "partial5x5", "partial7x7", "state", "rgb-image", "perspective",
+                                 "normalized-state", "layered-padded-1", "layered-padded-2", "layered-padded-3", "layered-padded"]
 
 
 class ObservationType(str, Enum):

@@ -328,3 +328,18 @@ def test_row_head_under_per_env_colours_never_changes(oracle_mod, name):
         rows = ob.step(None, auto_reset=(t // 15) % 2 == 0, seed=8, t=t)["obs"].reshape(n, -1)
         ref = rows[0, lo:hi].copy() if ref is None else ref
         assert (rows[:, lo:hi] == ref).all(), (name, t)
+
+
+def test_laser_tokens():
+    """src/unit_tests/test_laser_config.rs:6-26: `L<agent><direction>` tokens -- the colour digit, the four letters, ids in parse order."""
+    from lle_amd import Map
+
+    m = Map("L0E .   .  S0\n"
+            ".   .   .  L1W\n"
+            ".   .   X  .\n"
+            ".   L2N .  .\n"
+            "L3S .   .  .\n"
+            ".   .   .  .")
+    srcs = m.sources()
+    assert [(s.laser_id, s.agent_id, s.direction) for s in srcs] == [(0, 0, 1), (1, 1, 3), (2, 2, 0), (3, 3, 2)]   # N=0 E=1 S=2 W=3
+    assert [(s.i, s.j) for s in srcs] == [(0, 0), (1, 3), (3, 1), (4, 0)]

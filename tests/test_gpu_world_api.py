@@ -50,6 +50,54 @@ def test_gem_collect_and_the_tile_reprs():
     assert [g.is_collected for g in world.gems] == [False, False]
 
 
+def test_perspective_generator_reports_its_observation_type():   # python/tests/test_observations.py:404-407
+    from lle_amd import World
+    from lle_amd.observations import AgentZeroPerspective, ObservationType
+
+    assert AgentZeroPerspective(World("S0 X")).obs_type is ObservationType.AGENT0_PERSPECTIVE_LAYERED
+
+
+def test_world_and_action_cross_a_thread_boundary():   # python/tests/test_world.py:262-288 (the binding declares World Send + Sync)
+    import threading
+
+    from lle_amd import Action, World
+
+    class Holder(threading.Thread):
+        def __init__(self, item):
+            super().__init__()
+            self.item, self.result = item, None
+
+        def run(self):
+            w = self.item
+            self.result = w.step(Action.EAST) if isinstance(w, World) else w.delta
+
+    world = World("S0 . X")
+    world.reset()
+    threads = [Holder(Action.NORTH), Holder(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert threads[0].result == (-1, 0) and threads[1].result == [] and world.agents_positions == [(0, 1)]
+
+
+def test_standard_level_names_and_setstate_onto_another_world():
+    """python/tests/test_world.py:447-451 (`lvl3` / `level3` are level names for from_file, src/core/levels.rs:10-19) and
+    src/unit_tests/test_pyworld.rs:4-9 (__setstate__ turns an existing world into the pickled one)."""
+    from lle_amd import World
+
+    for i in range(1, 7):
+        a, b, c = World.level(i), World.from_file(f"lvl{i}"), World.from_file(f"level{i}")
+        assert a.world_string == b.world_string == c.world_string
+    world = World.level(1)
+    other = World("S0 X")
+    other.__setstate__(world.__getstate__())
+    assert (other.width, other.height, other.n_agents) == (world.width, world.height, 1) and other.get_state() == world.get_state()
+    other.reset()
+    world.reset()
+    assert other.agents_positions == world.agents_positions
+
+
 def test_sampled_stepper_equals_step():
     """BatchedWorld.sampled_stepper(): the bound hot-loop callable takes the same steps as step(sample=True, ...)."""
     import pytest

@@ -106,3 +106,29 @@ def test_direction():   # python/tests/test_direction.py (all of it)
     import copy
     import pickle
     assert all(pickle.loads(pickle.dumps(d)) is d and copy.deepcopy(d) is d for d in ds)
+
+
+def test_import_paths():   # python/tests/test_imports.py:1-27,35-39 (solver / rendering / characterization paths: out of scope)
+    import lle_amd
+    from lle_amd import __version__, exceptions, tiles, world  # noqa: F401
+    from lle_amd.exceptions import InvalidActionError, InvalidLevelError, InvalidWorldStateError, ParsingError
+    from lle_amd.tiles import Direction, Gem, Laser, LaserSource
+    from lle_amd.types import AgentId, LaserId, Position
+    from lle_amd.world import Action, EventType, World, WorldEvent, WorldState  # noqa: F401
+
+    assert isinstance(__version__, str) and lle_amd.__version__ == __version__
+    assert (tiles.Gem, tiles.Laser, tiles.LaserSource, tiles.Direction) == (Gem, Laser, LaserSource, Direction)
+    assert all(issubclass(e, ValueError) for e in (InvalidActionError, InvalidLevelError, InvalidWorldStateError, ParsingError))
+    assert (AgentId, LaserId) == (int, int) and Position == tuple[int, int]
+    assert lle_amd.Gem is Gem and lle_amd.ParsingError is ParsingError
+
+
+def test_typing_observation_type_literal():   # python/tests/test_observations.py:8-17
+    from typing import get_args
+
+    from lle_amd.observations import ObservationType, ObservationTypeLiteral
+
+    for name in get_args(ObservationTypeLiteral):
+        assert any(name == o for o in ObservationType), f"{name} is not a valid ObservationType"
+    for o in ObservationType:
+        assert o in get_args(ObservationTypeLiteral)
