@@ -22,6 +22,24 @@ def test_c_host_runs_a_rollout_through_the_c_abi():
     assert stats["env_steps"] == 8192 * 50 and stats["agent_steps"] == 4 * 8192 * 50 and stats["invalid"] == 0
 
 
+@pytest.mark.gpu
+def test_c_host_places_its_arena():
+    """The same host with three candidate arenas: the row-fill probe times each, the rollout runs on the one kept
+    and takes the same steps (the counters are a function of seed and step numbers only)."""
+    exe = os.path.join(ROOT, "examples", "c_abi_rollout")
+    if not os.path.exists(exe):
+        from lle_amd.build import build_c_example
+        build_c_example()
+    outs = []
+    for extra in ([], ["3"]):
+        res = subprocess.run([exe, "8192", "50"] + extra, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+        assert res.returncode == 0 and res.stdout.strip().splitlines()[-1] == "ok", res.stdout
+        outs.append(res.stdout)
+    assert sum(line.startswith("arena ") and "row fill" in line for line in outs[1].splitlines()) == 3
+    stats = [next(line for line in o.splitlines() if line.startswith("env_steps")) for o in outs]
+    assert stats[0] == stats[1]
+
+
 def test_c_example_builds_and_fails_loudly_without_a_device():
     """CPU side: the example compiles against include/lle_hip.h with gcc and links liblle_hip.so; without a GPU it stops
     at the first HIP call with a message (there is no CPU path to fall back to)."""
