@@ -17,9 +17,9 @@ def __getattr__(name):
     if name == "BatchedWorld":
         from .batched import BatchedWorld
         return BatchedWorld
-    if name == "BatchedLLE":
-        from .env import BatchedLLE
-        return BatchedLLE
+    if name in ("BatchedLLE", "Builder", "DeathStrategy", "level", "from_str", "from_file"):  # (lle.level(6).obs_type(...).build())
+        from . import env
+        return getattr(env, name)
     if name in ("Layered", "LayeredPadded", "ObservationType", "StateGenerator", "FlattenedLayered", "PartialGenerator",
                 "AgentZeroPerspective"):
         from . import observations

@@ -11,10 +11,27 @@ device tensors with a leading env axis.  No marlenv dependency, no extras genera
     obs, state = env.reset()
     step = env.step(actions)            # dict: obs, state, reward, done, available_actions
 """
+import os
+from enum import IntEnum
+
 import torch
 
 from . import _capi
 from .batched import BatchedWorld
+
+
+class DeathStrategy(IntEnum):
+    """python/lle/env/env.py:23-37."""
+    END = 0      # the episode ends when an agent dies
+    RESPAWN = 1  # (not implemented by the reference either: env.py:106-107)
+
+    @staticmethod
+    def from_str(value):
+        if value == "end":
+            return DeathStrategy.END
+        if value == "respawn":
+            return DeathStrategy.RESPAWN
+        raise ValueError(f"Unknown death strategy: {value}")
 
 _OBS_KINDS = {
     "layered": (_capi.LLE_OBS_LAYERED, 0), "flattened": (_capi.LLE_OBS_LAYERED, 0),
@@ -33,11 +50,14 @@ class BatchedLLE:
     multi_objective (MultiObjective instead of SingleObjective); death_strategy "end" only, like the reference."""
 
     def __init__(self, maps, n_envs, obs_type="layered", state_type="state", walkable_lasers=True, randomize_lasers=False,
-                 multi_objective=False, death_strategy="end", padding_size=0, device=None, seed=0):
+                 multi_objective=False, death_strategy="end", padding_size=0, device=None, seed=0, name=None):
         if death_strategy == "respawn":
             raise NotImplementedError("Respawn strategy is not implemented yet")  # env.py:106-107
         if death_strategy != "end":
             raise ValueError(f"Unknown death strategy: {death_strategy}")
+        self.death_strategy = DeathStrategy.END
+        self._name = name
+        obs_type, state_type = getattr(obs_type, "value", obs_type), getattr(state_type, "value", state_type)  # ObservationType or its string
         self.world = BatchedWorld(maps, n_envs, device=device)
         self.n_envs, self.n_agents, self.n_actions = self.world.n_envs, self.world.map.n_agents, 5
         self.obs_type, self.state_type = str(obs_type), str(state_type)
@@ -78,6 +98,32 @@ class BatchedLLE:
             return _OBS_KINDS[name]
         except KeyError:
             raise ValueError(f"Unknown observation type: {name}") from None
+
+    # ------------------------------------------------------------------ construction the reference's way (env.py:222-243, builder.py)
+    @staticmethod
+    def from_str(world_string):
+        """`LLE.from_str(...)`: a Builder; `.build(n_envs)` makes the batch."""
+        return Builder(world_string)
+
+    @staticmethod
+    def from_file(path):
+        from .world import _LEVEL_NAMES
+        name = str(path).lower()
+        if name in _LEVEL_NAMES:  # (World.from_file takes the standard levels' names: src/core/levels.rs:10-19)
+            return Builder(_capi.Map(level=_LEVEL_NAMES[name])).name(f"LLE-{os.path.basename(str(path))}")
+        if not os.path.exists(path):
+            raise FileNotFoundError(str(path))
+        with open(path) as f:
+            return Builder(f.read()).name(f"LLE-{os.path.basename(str(path))}")
+
+    @staticmethod
+    def level(level):
+        """Load a predefined level between 1 and 6 (env.py:238-243)."""
+        return Builder(_capi.Map(level=int(level))).name(f"LLE-lvl{level}")
+
+    @property
+    def name(self):
+        return self._name if self._name is not None else "LLE"  # (marlenv's default is the class name, env.py:116-120)
 
     # ------------------------------------------------------------------ static description (env.py:72-143)
     @property
@@ -132,6 +178,15 @@ class BatchedLLE:
     def done(self):
         """bool [n]: LLE.compute_done (env.py:253-254) -- every agent arrived, or somebody died."""
         return self.world.done.view(torch.bool)  # the kernel writes 0 / 1: a view, no launch
+
+    def compute_done(self):
+        return self.done
+
+    @property
+    def n_arrived(self):
+        """int64 [n]: RewardStrategy.n_arrived (reward_strategy.py:22-25,33-39) = agents that have reached an exit this episode."""
+        arrived = (self.world.bits >> 16) & 0xFFFF
+        return sum((arrived >> a) & 1 for a in range(self.n_agents))
 
     def reset(self, env_mask=None, seed=None, colours=None):
         """LLE.reset (env.py:189-203) for every env, or those with env_mask != 0: world.reset(), then -- with
@@ -322,3 +377,74 @@ class BatchedLLE:
                       multi_objective=self.multi_objective, available=avail, walkable_lasers=self.walkable_lasers)
         return {"obs": self.get_observation(), "state": state if fused_state else self.get_state(), "reward": reward,
                 "done": self.done, "available_actions": avail.view(torch.bool), "err": w.err}
+
+
+class Builder:
+    """`lle.level(6).obs_type("layered").randomize_lasers().build()` of the reference (python/lle/env/builder.py:12-166), for the
+    batch: the same chain, and `build(n_envs)` returns a BatchedLLE.  `pbrs` and `add_extras` belong to the parts of `LLE` that are
+    outside this package (reward shaping and extras generators) and say so."""
+
+    def __init__(self, map_or_text):
+        self._map = map_or_text
+        self._obs_type, self._state_type = "layered", "state"
+        self._death_strategy, self._walkable_lasers = "end", True
+        self._env_name, self._multi_objective, self._randomize_lasers = "LLE", False, False
+        self._padding_size = 0
+
+    def obs_type(self, obs_type):
+        from .observations import ObservationType
+        self._obs_type = ObservationType.from_str(obs_type).value if isinstance(obs_type, str) else obs_type.value
+        return self
+
+    def state_type(self, state_type):
+        from .observations import ObservationType
+        self._state_type = ObservationType.from_str(state_type).value if isinstance(state_type, str) else state_type.value
+        return self
+
+    def walkable_lasers(self, walkable_lasers):
+        self._walkable_lasers = bool(walkable_lasers)
+        return self
+
+    def death_strategy(self, death_strategy):
+        self._death_strategy = death_strategy
+        return self
+
+    def name(self, name):
+        self._env_name = name
+        return self
+
+    def multi_objective(self):
+        if not self._multi_objective:
+            self._multi_objective = True
+            self._env_name = f"{self._env_name}-MO"  # builder.py:74-76
+        return self
+
+    def randomize_lasers(self):
+        self._randomize_lasers = True
+        return self
+
+    def pbrs(self, *args, **kwargs):
+        raise NotImplementedError("potential-based reward shaping is outside the scope of lle_amd (SURVEY.md section 2, row 9)")
+
+    def add_extras(self, *extras):
+        if not extras:
+            return self
+        raise NotImplementedError("extras generators are outside the scope of lle_amd (SURVEY.md section 2, row 9)")
+
+    def build(self, n_envs=1, device=None, seed=0):
+        return BatchedLLE(self._map, n_envs, obs_type=self._obs_type, state_type=self._state_type, walkable_lasers=self._walkable_lasers,
+                          randomize_lasers=self._randomize_lasers, multi_objective=self._multi_objective, death_strategy=self._death_strategy,
+                          padding_size=self._padding_size, device=device, seed=seed, name=self._env_name)
+
+
+def level(level):
+    """`lle.level(n)` (python/lle/__init__.py)."""
+    return BatchedLLE.level(level)
+
+
+def from_str(world_string):
+    return BatchedLLE.from_str(world_string)
+
+
+def from_file(path):
+    return BatchedLLE.from_file(path)

@@ -338,6 +338,65 @@ def test_env_static_description():
         assert tuple(a.get_observation().shape[1:]) == a.observation_shape, name
 
 
+def test_builder_chain_names_and_the_small_members():
+    """`lle.level(6).obs_type(...).build()` (python/lle/env/builder.py:12-166; env.py:222-243) for the batch; names as
+    python/tests/test_env.py:310-331; `n_arrived` / `compute_done` (env.py:142-144,253-254) against the oracle-side env; the
+    reference's own other pieces of the builder (pbrs, extras) refuse loudly."""
+    import os
+    import tempfile
+
+    import torch
+
+    import lle_amd
+    from lle_amd import BatchedLLE, Builder, DeathStrategy
+    from lle_amd.observations import ObservationType
+
+    for lvl in range(1, 7):
+        assert lle_amd.level(lvl).build(4).name == f"LLE-lvl{lvl}"
+        assert BatchedLLE.level(lvl).multi_objective().build(4).name == f"LLE-lvl{lvl}-MO"
+    assert lle_amd.from_str("S0 X").build(4).name == "LLE" and BatchedLLE.from_str("S0 X").multi_objective().multi_objective().build(4).name == "LLE-MO"
+    with tempfile.NamedTemporaryFile(mode="w+") as f:
+        f.write("S0 X")
+        f.flush()
+        assert lle_amd.from_file(f.name).build(4).name == f"LLE-{os.path.basename(f.name)}"
+    with pytest.raises(FileNotFoundError):
+        lle_amd.from_file("/no/such/map")
+    assert BatchedLLE("S0 X", 4).name == "LLE" and BatchedLLE("S0 X", 4).death_strategy is DeathStrategy.END
+    with pytest.raises(NotImplementedError):
+        lle_amd.level(1).death_strategy("respawn").build(4)      # env.py:106-107
+    with pytest.raises(ValueError):
+        lle_amd.level(1).death_strategy("sleep").build(4)
+    with pytest.raises(NotImplementedError):
+        lle_amd.level(1).pbrs()
+    with pytest.raises(NotImplementedError):
+        lle_amd.level(1).add_extras("laser_subgoal")
+    assert isinstance(lle_amd.level(1).add_extras(), Builder)
+    a = lle_amd.level(1).obs_type("partial5x5").state_type(ObservationType.NORMALIZED_STATE).walkable_lasers(False).build(8)
+    b = BatchedLLE(LEVELS[1], 8, obs_type=ObservationType.PARTIAL_5x5, state_type="normalized-state", walkable_lasers=False)
+    assert (a.obs_type, a.state_type, a.walkable_lasers) == (b.obs_type, b.state_type, b.walkable_lasers) == ("partial5x5", "normalized-state", False)
+    assert a.observation_shape == b.observation_shape
+    # n_arrived / compute_done along a rollout, against one OracleLLE per env
+    n = 64
+    assert lle_amd.level(3).randomize_lasers().build(n, seed=3).randomize_lasers
+    env = lle_amd.from_str("S0 . X\nS1 . X\n.  V .").build(n)   # exits two steps away, a void to die in
+    env.reset()
+    assert int(env.n_arrived.sum()) == 0 and not bool(env.compute_done().any())
+    rng = np.random.default_rng(5)
+    seen = 0
+    for t in range(60):
+        avail = env.available_actions().cpu().numpy()
+        actions = np.array([[rng.choice(np.nonzero(avail[e, a])[0]) for a in range(env.n_agents)] for e in range(n)], dtype=np.uint8)
+        env.step(torch.from_numpy(actions).cuda(), auto_reset=False)
+        arrived = ((env.world.bits.cpu().numpy().view(np.uint64)[:, None] >> (np.arange(env.n_agents, dtype=np.uint64) + np.uint64(16))) & np.uint64(1)).sum(1)
+        assert np.array_equal(env.n_arrived.cpu().numpy(), arrived.astype(np.int64))
+        done = env.compute_done().cpu().numpy()
+        alive = ((env.world.bits.cpu().numpy().view(np.uint64)[:, None] >> np.arange(env.n_agents, dtype=np.uint64)) & np.uint64(1)).sum(1)
+        assert np.array_equal(done, (arrived == env.n_agents) | (alive < env.n_agents))
+        seen += int(arrived.sum())
+        env.reset(torch.from_numpy(done.astype(np.uint8)).cuda()) if done.any() else None
+    assert seen > 0
+
+
 @pytest.mark.parametrize("name", ["level1", "level6", "nested", "many_agents", "config5_32x32"])
 @pytest.mark.parametrize("variant", ["plain", "normalized_multi", "per_env_sources", "two_maps"])
 def test_one_launch_step_equals_step_plus_env_outputs(name, variant):
