@@ -151,7 +151,27 @@ struct lle_batch {
     // lle_batch_step_outputs: what the device copy of the EnvOutputs holds (re-uploaded only when the caller's struct changes)
     EnvOutputs env_out_host{};
     bool env_out_valid = false;
+    // outputs larger than the Infinity Cache: the launches that rewrite one walk the environments alternately up and down
+    // (obs_stream.hpp xcd_block_dir); per output buffer, the direction of its next launch
+    std::map<const void*, bool> walk_dir;
 };
+
+// Whether alternating the walk can pay: the rows of one launch must exceed what the 256 MB Infinity Cache keeps of them
+// (LLE_PINGPONG=0 / 1 forces it either way; read per launch, the parity tests run both in one process).
+static bool pingpong_pays(uint64_t row_bytes_per_launch) {
+    const char* o = getenv("LLE_PINGPONG");
+    if (o && (o[0] == '0' || o[0] == '1') && !o[1]) return o[0] == '1';
+    return row_bytes_per_launch > (256ull << 20);
+}
+// the direction of the launch that is about to rewrite `out` (bytes of it), and the flip for the next one
+static bool next_walk_reversed(lle_batch* b, const void* out, uint64_t bytes) {
+    if (!pingpong_pays(bytes)) return false;
+    if (b->walk_dir.size() > 64) b->walk_dir.clear();  // (callers that hand a fresh buffer every time)
+    bool& d = b->walk_dir[out];
+    const bool r = d;
+    d = !d;
+    return r;
+}
 
 namespace lle {
 int capi_fail(int status, const std::string& msg) { return fail(status, msg); }
@@ -401,10 +421,16 @@ static int launch(lle_batch* b, int mode, LaunchArgs K, void* stream) {
     }
     if (mode == KMODE_STEP && !b->lane_per_env_step) {
         K.envs_per_wave = step_envs_per_wave(b->n_envs, (int)b->hdr.A);
+        // single steps that rewrite the rows in place (a fused rollout rewrites them inside one launch, a ring never revisits a slot in time)
+        if (K.n_steps <= 1 && !K.ring_slots && !K.stamps && !(K.flags & STEP_NO_OBS) &&
+            next_walk_reversed(b, b->ptrs.obs, (uint64_t)b->n_envs * b->hdr.obs_stride))
+            K.flags |= LAUNCH_REVERSE;
         HIP_TRY(launch_step_kernel(b->hdr, b->ptrs, K, (hipStream_t)stream));
     }
-    else
+    else {
+        if (mode != KMODE_SET_STATE && next_walk_reversed(b, b->ptrs.obs, (uint64_t)b->n_envs * b->hdr.obs_stride)) K.flags |= LAUNCH_REVERSE;
         HIP_TRY(launch_world_kernel(mode, b->hdr, b->ptrs, K, (hipStream_t)stream));
+    }
     g_status = LLE_OK;
     return LLE_OK;
 }
@@ -865,6 +891,7 @@ int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64
         K.envs_per_wave = b->envs_per_wave;
         K.env_limit = b->n_envs;
         K.flags = LAUNCH_PER_ENV_SOURCES;
+        if (next_walk_reversed(b, out_dev, (uint64_t)d.bytes)) K.flags |= LAUNCH_REVERSE;
         K.envs_per_map = b->envs_per_map;
         K.table_stride = (uint32_t)b->layout.table_stride;
         HIP_TRY(launch_world_kernel(KMODE_OBSERVE, b->hdr, P, K, (hipStream_t)stream));
@@ -878,6 +905,7 @@ int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64
     const MapHeader& h = b->hdr;
     const bool pes = b->per_env_sources;
     const MapSel M{b->envs_per_map, (uint32_t)b->layout.table_stride, 0u};
+    const bool reverse = next_walk_reversed(b, out_dev, (uint64_t)d.bytes);  // (every launch of this call in the same direction)
     switch (kind) {
         case LLE_OBS_LAYERED:
         case LLE_OBS_PERSPECTIVE: {
@@ -891,14 +919,14 @@ int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64
                 rc = get_view(b, LLE_OBS_PERSPECTIVE, -1, st, &v);
                 if (rc != LLE_OK) return rc;
                 HIP_TRY(launch_view_observe(v->hdr, b->ptrs, v->dev, (uint32_t)n_views, static_cast<int8_t*>(out_dev),
-                                            (int64_t)n_views * h.obs_stride, (int64_t)h.obs_stride, b->n_envs, pes, h.n_elems, M, v->stride, st));
+                                            (int64_t)n_views * h.obs_stride, (int64_t)h.obs_stride, b->n_envs, pes, h.n_elems, M, v->stride, reverse, st));
                 break;
             }
             for (int k = 0; k < n_views; k++) {  // big rows: one launch per observer, rows strided by A * obs_stride
                 rc = get_view(b, LLE_OBS_PERSPECTIVE, k, st, &v);
                 if (rc != LLE_OK) return rc;
                 HIP_TRY(launch_view_observe(v->hdr, b->ptrs, v->dev, 1u, static_cast<int8_t*>(out_dev) + (int64_t)k * h.obs_stride,
-                                            (int64_t)n_views * h.obs_stride, 0, b->n_envs, pes, h.n_elems, M, v->stride, st));
+                                            (int64_t)n_views * h.obs_stride, 0, b->n_envs, pes, h.n_elems, M, v->stride, reverse, st));
             }
             break;
         }
@@ -907,7 +935,7 @@ int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64
             rc = get_view(b, kind, param, st, &v);
             if (rc != LLE_OK) return rc;
             HIP_TRY(launch_view_observe(v->hdr, b->ptrs, v->dev, 1u, static_cast<int8_t*>(out_dev), (int64_t)v->hdr.obs_stride, 0,
-                                        b->n_envs, pes, h.n_elems, M, v->stride, st));
+                                        b->n_envs, pes, h.n_elems, M, v->stride, reverse, st));
             break;
         }
         case LLE_OBS_PARTIAL: {
@@ -915,7 +943,7 @@ int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64
             for (const Map& mp : b->maps)
                 n_entities = std::max<uint32_t>(n_entities, (uint32_t)(mp.walls.size() + mp.exits.size() + mp.gems.size() + mp.n_laser_tiles() +
                                                                     mp.sources.size()));
-            HIP_TRY(launch_partial_observe(h, b->ptrs, static_cast<int8_t*>(out_dev), param, b->n_envs, b->per_env_sources, M, n_entities, st));
+            HIP_TRY(launch_partial_observe(h, b->ptrs, static_cast<int8_t*>(out_dev), param, b->n_envs, b->per_env_sources, M, n_entities, reverse, st));
             break;
         }
         default:
@@ -1069,7 +1097,9 @@ int lle_batch_probe_row_fill(lle_batch* b, uint32_t value, void* stream) {
     if (!b) return fail(LLE_ERR_NULL, "NULL batch");
     ON_DEVICE_OF(b);
     const uint32_t epw = b->lane_per_env_step ? b->envs_per_wave : step_envs_per_wave(b->n_envs, (int)b->hdr.A);
-    HIP_TRY(launch_row_fill_probe(b->ptrs.obs, b->n_envs, b->hdr.obs_stride, epw, value, (hipStream_t)stream));
+    // the same alternation as the step launches it stands in for
+    const bool reverse = next_walk_reversed(b, b->ptrs.obs, (uint64_t)b->n_envs * b->hdr.obs_stride);
+    HIP_TRY(launch_row_fill_probe(b->ptrs.obs, b->n_envs, b->hdr.obs_stride, epw, value, reverse, (hipStream_t)stream));
     g_status = LLE_OK;
     return LLE_OK;
 }

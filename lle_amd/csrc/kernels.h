@@ -60,17 +60,17 @@ int step_lm(int L);
 // observers.hip
 hipError_t launch_view_observe(const ViewHeader& v, const BatchPtrs& P, const uint8_t* views_dev, uint32_t n_views, int8_t* out,
                                int64_t row_pitch, int64_t view_pitch, int64_t n_envs, bool pes, uint32_t n_elems, MapSel M,
-                               uint32_t views_stride, hipStream_t stream);
+                               uint32_t views_stride, bool reverse, hipStream_t stream);
 // do n_views views fit the LDS of one workgroup together?
 bool view_kernel_fits(const ViewHeader& v, uint32_t n_views, bool pes, uint32_t n_elems);
 uint32_t partial_pitch(int A, int k);
 // n_entities: walls (sources included) + exits + gems + exposed laser tiles + sources of the map (the largest of a multi-map batch)
 hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t* out, int k, int64_t n_envs, bool per_env_sources,
-                                  MapSel M, uint32_t n_entities, hipStream_t stream);
+                                  MapSel M, uint32_t n_entities, bool reverse, hipStream_t stream);
 hipError_t launch_state_observe(const MapHeader& h, const BatchPtrs& P, float* out, int normalize, int64_t n_envs, hipStream_t stream);
 hipError_t launch_env_outputs(const MapHeader& h, const BatchPtrs& P, const EnvOutputs& O, int64_t n_envs, MapSel M, hipStream_t stream);
 // ceiling probe: n_rows rows of row_bytes (a multiple of 16) filled with the step kernel's store pattern (observers.hip)
-hipError_t launch_row_fill_probe(int8_t* out, int64_t n_rows, uint32_t row_bytes, uint32_t rows_per_wave, uint32_t value, hipStream_t stream);
+hipError_t launch_row_fill_probe(int8_t* out, int64_t n_rows, uint32_t row_bytes, uint32_t rows_per_wave, uint32_t value, bool reverse, hipStream_t stream);
 // out8[k] = sum over the n_blocks per-wavefront slots of stats[slot][k] (one workgroup; lle_batch_stats, lle_batch_stats_allreduce)
 hipError_t launch_stats_sum(const int64_t* stats, int64_t n_blocks, int64_t* out8, hipStream_t stream);
 hipError_t launch_avail(const MapHeader& h, const BatchPtrs& P, uint8_t* out, int walkable_lasers, int64_t n_envs, bool per_env_sources,

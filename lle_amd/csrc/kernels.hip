@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
     // 400-byte header by value in the kernel-argument segment measured ~2.4 us SLOWER per launch: the kernarg
     // segment is fetched with a much longer latency than device memory.
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const uint32_t blk = xcd_block(blockIdx.x, gridDim.x);  // the block of environments this workgroup serves (obs_stream.hpp)
+    const uint32_t blk = xcd_block_dir(blockIdx.x, gridDim.x, K.flags);  // the block of environments this workgroup serves (obs_stream.hpp)
     const uint32_t map_idx = map_index_of(K, K.env_base + (int64_t)(blk * (blockDim.x >> 6)) * K.envs_per_wave);
     const uint8_t* __restrict__ tables = P.tables + (uint64_t)map_idx * K.table_stride;  // this workgroup's map
     const InitRecord* __restrict__ initp = P.init + map_idx;

@@ -38,10 +38,10 @@ constexpr uint32_t OBS_LDS_LIMIT = 160 * 1024;
 // every env writes its laser / gem bytes through the view's colour -> layer table (write_observations_env).
 __global__ void __launch_bounds__(256) view_observe_kernel(BatchPtrs P, const uint8_t* __restrict__ views, uint32_t n_views,
                                                            int8_t* __restrict__ out, int64_t row_pitch, int64_t view_pitch,
-                                                           int64_t env_base, int64_t env_limit, int pes, MapSel M, uint32_t views_stride, int wt) {
+                                                           int64_t env_base, int64_t env_limit, int pes, MapSel M, uint32_t views_stride, int wt, uint32_t walk) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t lane = threadIdx.x & 63u, wave_in_wg = threadIdx.x >> 6, waves_per_wg = blockDim.x >> 6;
-    const uint32_t blk = xcd_block(blockIdx.x, gridDim.x);  // the block of environments this workgroup serves (obs_stream.hpp)
+    const uint32_t blk = xcd_block_dir(blockIdx.x, gridDim.x, walk);  // the block of environments this workgroup serves, and the launch's direction (obs_stream.hpp)
     const uint32_t wave_id = blk * waves_per_wg + wave_in_wg;
     const int64_t wg_env0 = env_base + (int64_t)(blk * waves_per_wg) * OBS_ENVS_PER_WAVE;
     const uint8_t* __restrict__ map_tables = tables_of(P, M, wg_env0);   // this workgroup's map and its views
@@ -125,10 +125,10 @@ __global__ void __launch_bounds__(256) view_observe_kernel(BatchPtrs P, const ui
 // non-zero bytes are written), and the row is streamed as 16 B per lane.
 __global__ void __launch_bounds__(256) partial_observe_kernel(BatchPtrs P, int8_t* __restrict__ out, int k, uint32_t pitch,
                                                               int64_t env_base, int64_t env_limit, int per_env_sources, MapSel M,
-                                                              uint32_t epw) {
+                                                              uint32_t epw, uint32_t walk) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t lane = threadIdx.x & 63u, wave_in_wg = threadIdx.x >> 6, waves_per_wg = blockDim.x >> 6;
-    const uint32_t blk = xcd_block(blockIdx.x, gridDim.x);
+    const uint32_t blk = xcd_block_dir(blockIdx.x, gridDim.x, walk);
     const uint32_t wave_id = blk * waves_per_wg + wave_in_wg;
     const uint8_t* __restrict__ tables = tables_of(P, M, env_base + (int64_t)(blk * waves_per_wg) * epw);
     const MapHeader* __restrict__ hdr = reinterpret_cast<const MapHeader*>(tables);
@@ -244,10 +244,10 @@ __global__ void __launch_bounds__(256) partial_observe_kernel(BatchPtrs P, int8_
 enum : uint32_t { PE_WALL = 0, PE_EXIT = 1, PE_GEM = 2, PE_TILE = 3, PE_SOURCE = 4, PE_AGENT = 5 };
 __global__ void __launch_bounds__(256) partial_project_kernel(BatchPtrs P, int8_t* __restrict__ out, int k, uint32_t pitch,
                                                               int64_t env_base, int64_t env_limit, int per_env_sources, MapSel M,
-                                                              uint32_t epw, uint32_t ent_cap) {
+                                                              uint32_t epw, uint32_t ent_cap, uint32_t walk) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t lane = threadIdx.x & 63u, wave_in_wg = threadIdx.x >> 6, waves_per_wg = blockDim.x >> 6;
-    const uint32_t blk = xcd_block(blockIdx.x, gridDim.x);
+    const uint32_t blk = xcd_block_dir(blockIdx.x, gridDim.x, walk);
     const uint32_t wave_id = blk * waves_per_wg + wave_in_wg;
     const uint8_t* __restrict__ tables = tables_of(P, M, env_base + (int64_t)(blk * waves_per_wg) * epw);
     const MapHeader* __restrict__ hdr = reinterpret_cast<const MapHeader*>(tables);
@@ -416,10 +416,10 @@ __global__ void __launch_bounds__(256) partial_project_kernel(BatchPtrs P, int8_
 struct PartialDims { int32_t A, L, H, W; uint32_t off_cell_meta, max_layers; };  // common to the maps of a batch; off_cell_meta relative to off_cell_lay
 __global__ void __launch_bounds__(256) partial_lanes_kernel(BatchPtrs P, int8_t* __restrict__ out, int k, uint32_t pitch, int64_t env_base,
                                                             int64_t env_limit, int per_env_sources, MapSel M, uint32_t E, uint32_t batches,
-                                                            uint32_t tab_bytes, int wt, PartialDims D, uint32_t tab_off) {
+                                                            uint32_t tab_bytes, int wt, PartialDims D, uint32_t tab_off, uint32_t walk) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t lane = threadIdx.x & 63u, wave_in_wg = threadIdx.x >> 6, waves_per_wg = blockDim.x >> 6;
-    const uint32_t blk = xcd_block(blockIdx.x, gridDim.x);
+    const uint32_t blk = xcd_block_dir(blockIdx.x, gridDim.x, walk);
     const uint32_t wave_id = blk * waves_per_wg + wave_in_wg;
     const uint32_t epw = E * batches;  // environments per wavefront
     const uint8_t* __restrict__ tables = tables_of(P, M, env_base + (int64_t)(blk * waves_per_wg) * epw);
@@ -681,8 +681,8 @@ __global__ void __launch_bounds__(256) env_outputs_kernel(BatchPtrs P, EnvOutput
 // row-owning writer can reach there; the step kernel is read against it (DESIGN.md section 4 "Two kinds of box").
 template <bool WT>
 __global__ void __launch_bounds__(256) row_fill_probe_kernel(int8_t* __restrict__ out, int64_t n_rows, uint32_t n_chunks, uint32_t rows_per_wave,
-                                                             uint32_t value) {
-    const uint32_t blk = xcd_block(blockIdx.x, gridDim.x);
+                                                             uint32_t value, uint32_t flags) {
+    const uint32_t blk = xcd_block_dir(blockIdx.x, gridDim.x, flags);
     const uint32_t lane = threadIdx.x & 63u, wave = blk * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t r0 = (int64_t)wave * rows_per_wave;
     const uint4 v = {value, value, value, value};
@@ -717,14 +717,15 @@ __global__ void __launch_bounds__(1024) stats_sum_kernel(const int64_t* __restri
 }
 
 // ---------------------------------------------------------------------------------------------- launchers
-hipError_t launch_row_fill_probe(int8_t* out, int64_t n_rows, uint32_t row_bytes, uint32_t rows_per_wave, uint32_t value, hipStream_t stream) {
+hipError_t launch_row_fill_probe(int8_t* out, int64_t n_rows, uint32_t row_bytes, uint32_t rows_per_wave, uint32_t value, bool reverse, hipStream_t stream) {
+    const uint32_t flags = reverse ? LAUNCH_REVERSE : 0u;
     const uint32_t n_chunks = row_bytes / 16u, wpw = 4;
     const int64_t n_waves = (n_rows + rows_per_wave - 1) / rows_per_wave;
     const dim3 grid((uint32_t)((n_waves + wpw - 1) / wpw)), block(64 * wpw);
     if (write_through_pays((uint64_t)n_rows * row_bytes, row_bytes))
-        hipLaunchKernelGGL(row_fill_probe_kernel<true>, grid, block, 0, stream, out, n_rows, n_chunks, rows_per_wave, value);
+        hipLaunchKernelGGL(row_fill_probe_kernel<true>, grid, block, 0, stream, out, n_rows, n_chunks, rows_per_wave, value, flags);
     else
-        hipLaunchKernelGGL(row_fill_probe_kernel<false>, grid, block, 0, stream, out, n_rows, n_chunks, rows_per_wave, value);
+        hipLaunchKernelGGL(row_fill_probe_kernel<false>, grid, block, 0, stream, out, n_rows, n_chunks, rows_per_wave, value, flags);
     return hipGetLastError();
 }
 
@@ -752,7 +753,7 @@ static uint32_t cap_wpw(uint32_t wpw, const MapSel& M) {
 
 hipError_t launch_view_observe(const ViewHeader& v, const BatchPtrs& P, const uint8_t* views_dev, uint32_t n_views, int8_t* out,
                                int64_t row_pitch, int64_t view_pitch, int64_t n_envs, bool pes, uint32_t n_elems, MapSel M,
-                               uint32_t views_stride, hipStream_t stream) {
+                               uint32_t views_stride, bool reverse, hipStream_t stream) {
     uint32_t wpw = cap_wpw(4, M);
     while (wpw > 1 && view_lds(v, n_views, wpw, pes, n_elems) > OBS_LDS_LIMIT) wpw >>= 1;
     const uint32_t lds = view_lds(v, n_views, wpw, pes, n_elems);
@@ -763,7 +764,8 @@ hipError_t launch_view_observe(const ViewHeader& v, const BatchPtrs& P, const ui
     const uint32_t n_waves = (uint32_t)((n_envs + OBS_ENVS_PER_WAVE - 1) / OBS_ENVS_PER_WAVE);
     hipLaunchKernelGGL(view_observe_kernel, dim3((n_waves + wpw - 1) / wpw), dim3(64 * wpw), lds, stream, P, views_dev, n_views, out,
                        row_pitch, view_pitch, (int64_t)0, n_envs, pes ? 1 : 0, M, views_stride,
-                       write_through_pays((uint64_t)n_envs * (uint64_t)(n_views > 1 ? view_pitch * n_views : row_pitch), (uint32_t)v.obs_stride) ? 1 : 0);
+                       write_through_pays((uint64_t)n_envs * (uint64_t)(n_views > 1 ? view_pitch * n_views : row_pitch), (uint32_t)v.obs_stride) ? 1 : 0,
+                       reverse ? LAUNCH_REVERSE : 0u);
     return hipGetLastError();
 }
 
@@ -783,7 +785,8 @@ static bool partial_projects(const MapHeader& h, int k, uint32_t n_entities) {
 }
 
 hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t* out, int k, int64_t n_envs, bool per_env_sources,
-                                  MapSel M, uint32_t n_entities, hipStream_t stream) {
+                                  MapSel M, uint32_t n_entities, bool reverse, hipStream_t stream) {
+    const uint32_t walk = reverse ? LAUNCH_REVERSE : 0u;
     const uint32_t pitch_l = partial_pitch((int)h.A, k);
     int force_old = -1;  // LLE_PARTIAL_KERNEL=window / project: one of the two round-1/2 kernels (kept as cross-checks)
     {   // ---- the lane-per-(env, observer) kernel (partial_lanes_kernel): every map and window size
@@ -842,7 +845,7 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
                 if (const char* o = getenv("LLE_PARTIAL_WT")) wt = o[0] == '1';
                 const PartialDims D{(int32_t)h.A, (int32_t)h.L, (int32_t)h.H, (int32_t)h.W, h.off_cell_meta - h.off_cell_lay, h.max_layers};
                 hipLaunchKernelGGL(partial_lanes_kernel, dim3((n_waves + wpw - 1) / wpw), dim3(64 * wpw), lds, stream, P, out, k, pitch_l,
-                                   (int64_t)0, n_envs, per_env_sources ? 1 : 0, M, E, batches, tab, wt, D, h.off_cell_lay);
+                                   (int64_t)0, n_envs, per_env_sources ? 1 : 0, M, E, batches, tab, wt, D, h.off_cell_lay, walk);
                 return hipGetLastError();
             }
         }
@@ -870,7 +873,7 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
         if (e != hipSuccess) return e;
         const uint32_t n_waves = (uint32_t)((n_envs + epw - 1) / epw);
         hipLaunchKernelGGL(partial_project_kernel, dim3((n_waves + wpw - 1) / wpw), dim3(64 * wpw), lds, stream, P, out, k, pitch,
-                           (int64_t)0, n_envs, per_env_sources ? 1 : 0, M, epw, ent_cap);
+                           (int64_t)0, n_envs, per_env_sources ? 1 : 0, M, epw, ent_cap, walk);
         return hipGetLastError();
     }
     // envs per wavefront: the chain of one env (clear, agents, cells, stream) is latency, so fewer envs per wave = more
@@ -892,7 +895,7 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
     if (e != hipSuccess) return e;
     const uint32_t n_waves = (uint32_t)((n_envs + epw - 1) / epw);
     hipLaunchKernelGGL(partial_observe_kernel, dim3((n_waves + wpw - 1) / wpw), dim3(64 * wpw), lds, stream, P, out, k, pitch,
-                       (int64_t)0, n_envs, per_env_sources ? 1 : 0, M, epw);
+                       (int64_t)0, n_envs, per_env_sources ? 1 : 0, M, epw, walk);
     return hipGetLastError();
 }
 

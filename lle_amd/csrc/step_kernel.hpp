@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     constexpr int NW = (2 * G + 7) / 8;             // 64-bit words of the event list (2 events per agent at most)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t lane = threadIdx.x & 63u, wave_in_wg = threadIdx.x >> 6, waves_per_wg = blockDim.x >> 6;
-    const uint32_t blk = xcd_block(blockIdx.x, gridDim.x);  // the block of environments this workgroup serves
+    const uint32_t blk = xcd_block_dir(blockIdx.x, gridDim.x, K.flags);  // the block of environments this workgroup serves
     const uint32_t wave_id = blk * waves_per_wg + wave_in_wg;
     const uint8_t* __restrict__ tables = P.tables;
     const InitRecord* __restrict__ initp = P.init;
