@@ -18,7 +18,9 @@ Prints ONE JSON line (rank 0).  value = agent-steps/s over the whole job (agents
 env-steps/s is reported next to it.  Objects of the line:
   roofline       the dominant kernel of the --steps region (HIP events on the launch stream).  Each step rewrites the
                  same 122.7 MB of rows, which the 256 MB Infinity Cache absorbs: bound = "infinity-cache-absorbed".
-  roofline_hbm   the same kernel on a batch whose rows (491 MB per launch) do not fit the Infinity Cache: true HBM writes.
+  roofline_hbm   the same kernel on a batch whose rows (503 MB per launch) do not fit the Infinity Cache.  Since round 3 such launches
+                 walk the environments alternately up and down, so each one finds the last cache-full of its predecessor's rows
+                 in the Infinity Cache (`infinity_cache_share`); the rest are HBM writes.
   sustained      the same launches as the --steps region, >= 1000 of them.
   configs        BASELINE.json configs[1] (level 1 x 4 096) and configs[4] (32x32, 8 agents, 8 lasers x 65 536).
   lle_step       BatchedLLE.step (the reference's LLE host class, batched) on the headline workload: us per step.
@@ -344,7 +346,12 @@ def measure_config(torch, timer, dev, map_or_text, n_envs, algo_bytes, steps, la
         "env_steps_per_s": n_envs * steps / wall, "agent_steps_per_s": m.n_agents * n_envs * steps / wall,
         "algorithmic_bytes_per_env_step": algo_bytes, "achieved_GBps": achieved, "frac_of_hbm_peak": achieved / HBM_PEAK_GBS,
         "row_bytes": m.obs_bytes, "row_stride": m.obs_stride, "rows_MB_per_launch": rows / 1e6,
-        "bound": "hbm" if rows > INFINITY_CACHE_BYTES else "infinity-cache-absorbed",
+        "bound": ("hbm" if os.environ.get("LLE_PINGPONG", "1") == "0" else "hbm + infinity cache (alternating walk)")
+                 if rows > INFINITY_CACHE_BYTES else "infinity-cache-absorbed",
+        # rows > cache: launches walk the envs alternately up and down (LLE_PINGPONG, obs_stream.hpp xcd_block_dir): at most this
+        # share of a launch's rows is still in the 256 MB Infinity Cache from the launch before and is rewritten there
+        "walk": "alternating" if rows > INFINITY_CACHE_BYTES and os.environ.get("LLE_PINGPONG", "1") != "0" else "ascending",
+        "infinity_cache_share": min(1.0, INFINITY_CACHE_BYTES / rows),
         "kernel": info["kernel"], "envs_per_wave": info["envs_per_wave"], "lds_bytes_per_workgroup": info["lds_bytes"],
         "traffic": load_traffic(traffic_key) if traffic_key else None,
         "rollout_stats": bw.stats(),
@@ -640,7 +647,7 @@ def main():
                                 "env_steps_per_s": total_envs * k / s_wall, "agent_steps_per_s": A * total_envs * k / s_wall,
                                 "achieved_GBps_per_gpu": s_ach, "frac_of_hbm_peak": s_ach / HBM_PEAK_GBS}
         if hbm:
-            out["roofline_hbm"] = {"bound": "hbm", "achieved": hbm["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            out["roofline_hbm"] = {"bound": hbm["bound"], "achieved": hbm["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": hbm["frac_of_hbm_peak"],
                                    "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * hbm["n_envs"], **hbm}
         if cfgs:

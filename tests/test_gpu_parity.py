@@ -76,6 +76,41 @@ def test_config3_level6_batch65536(oracle_mod):
         check(bw, ob, ob.step(None, auto_reset=True, seed=1234, t=t), f"t={t}")
 
 
+@pytest.mark.parametrize("name", ["level6", "many_agents", "config5_32x32"])
+def test_alternating_walk_changes_nothing(oracle_mod, monkeypatch, name):
+    """Launches that rewrite an output larger than the Infinity Cache walk the environments alternately up and down
+    (obs_stream.hpp xcd_block_dir; LLE_PINGPONG=1 forces it at any size, =0 switches it off): the order in which a launch serves
+    its environments is not observable.  A ragged batch (the last wavefront partly empty, served FIRST on the way down),
+    every buffer against the oracle along a rollout, and every observation builder against the one-directional run."""
+    import torch
+
+    from lle_amd import BatchedWorld, _capi
+
+    text = MAPS[name] if name in MAPS else EXTRA_MAPS[name]
+    n = 1000
+    ob = oracle_mod.OracleBatch(text, n)
+    monkeypatch.setenv("LLE_PINGPONG", "1")
+    bw = BatchedWorld(text, n)
+    monkeypatch.setenv("LLE_PINGPONG", "0")
+    ref = BatchedWorld(text, n)
+    kinds = [(_capi.LLE_OBS_LAYERED, 0), (_capi.LLE_OBS_LAYERED_PADDED, 2), (_capi.LLE_OBS_PERSPECTIVE, 0), (_capi.LLE_OBS_PARTIAL, 3),
+             (_capi.LLE_OBS_PARTIAL, 7), (_capi.LLE_OBS_STATE, 0)]
+    for t in range(9):
+        monkeypatch.setenv("LLE_PINGPONG", "1")
+        bw.step(sample=True, auto_reset=(t % 3 != 2), seed=19, t=t)
+        check(bw, ob, ob.step(None, auto_reset=(t % 3 != 2), seed=19, t=t), f"{name} t={t}")
+        got = [bw.observe_as(k, p).clone() for k, p in kinds for _ in (0, 1)]   # twice each: once up, once down
+        bw.observe()
+        rows_down = bw.obs_rows.clone()
+        bw.observe()
+        assert torch.equal(bw.obs_rows, rows_down)
+        monkeypatch.setenv("LLE_PINGPONG", "0")
+        ref.step(sample=True, auto_reset=(t % 3 != 2), seed=19, t=t)
+        want = [ref.observe_as(k, p) for k, p in kinds for _ in (0, 1)]
+        assert all(torch.equal(a, b) for a, b in zip(got, want)), t
+        assert torch.equal(ref.obs_rows, rows_down)
+
+
 def test_rows_beyond_4_GiB(oracle_mod):
     """Maximum sizes: config 5's map at 262 144 envs = 5.4 GB of observation rows in one launch, so row offsets pass 2^32
     (and 2^31) inside the kernel.  Windows of 64 envs -- the first, the ones astride the 2 GiB and 4 GiB offsets, the last --
