@@ -447,6 +447,9 @@ def measure_observers(torch, timer, dev, n, steps):
         for _ in range(16):
             fn()
         calls = {f"partial{k}x{k}": bw.bound_observer(_capi.LLE_OBS_PARTIAL, k) for k in (3, 5, 7)}
+        if label == "level6":  # (config 5's perspective tensor is 10.7 GB: left to tools/lle_prof.py observers)
+            calls["perspective"] = bw.bound_observer(_capi.LLE_OBS_PERSPECTIVE)
+        calls["layered_padded2"] = bw.bound_observer(_capi.LLE_OBS_LAYERED_PADDED, 2)
         calls["state"] = bw.bound_observer(_capi.LLE_OBS_STATE)
         calls["available_actions"] = bw.bound_available_actions(True)
         calls["available_actions_no_walkable_lasers"] = bw.bound_available_actions(False)
