@@ -506,10 +506,18 @@ bool write_through_pays(uint64_t bytes, uint32_t row_pitch) {
 // idle.  Measured on level 6 with a 3-line head: 32 768 envs (2 048 wavefronts) 13.3 -> 12.4 us, 65 536 21.4 -> 19.8,
 // 131 072 36.7 -> 35.1; a small launch (16 384 envs: 9.4 -> 9.7) or many rounds (262 144: 98.9 -> 100.1) lose a little.
 // LLE_ROW_HEADS=0 / 1 forces it (read per launch: the parity tests run both in one process).
-static bool row_heads_pay(uint32_t n_waves) {
+static bool row_heads_pay(uint32_t n_waves, bool general) {
     const char* o = getenv("LLE_ROW_HEADS");
     if (o && (o[0] == '0' || o[0] == '1') && !o[1]) return o[0] == '1';
-    return n_waves >= 2048u && n_waves <= 8192u;
+    // The general instantiations (several maps / fused LLE.step outputs: MODE 7 against 4; per-env sources: MODE 8 against 5) win
+    // with the heads at every size from 2 048 wavefronts up -- they are also the ones with every load up front and, for MODE 8,
+    // without the spills of MODE 5.  Level 6, us per step without / with (round 3, one box): per-env sources 8 192 envs 9.7 / 8.8,
+    // 65 536 24.3 / 21.8, 262 144 102.2 / 87.5, 524 288 202.5 / 190.4; fused outputs 8 192 9.2 / 8.9, 65 536 23.2 / 21.1,
+    // 262 144 87.5 / 80.6; five other maps: profiles/r03_heads_rule.md (below 2 048 wavefronts it is a wash: -0.5 ... +0.6 us).
+    if (general) return n_waves >= 2048u;
+    // The default instantiation (MODE 6 against 0): 16 384 envs 9.1 / 9.5, 32 768 13.0 / 12.3, 65 536 21.2 / 19.5, 131 072 37.3 / 35.2,
+    // 196 608 59.9 / 58.8, 262 144 74.3 / 74.4, 524 288 170.0 / 173.4.
+    return n_waves >= 2048u && n_waves <= 12288u;
 }
 
 hipError_t launch_world_kernel(int mode, const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K_in, hipStream_t stream) {
@@ -585,12 +593,13 @@ hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const Laun
     if (pes) {
         if (roll) return launch_step_mode3(G, lm, P, K, n_waves, wpw, lds, stream);
         // single steps: the colour-independent head lines ahead of the state machine (MODE 8) under the same conditions as below
-        const bool heads_pes = lm <= 8 && h.pes_head_n != 0 && !(K.flags & (LAUNCH_SPLIT_ROWS | STEP_NO_OBS)) && row_heads_pay(n_waves);
+        const bool heads_pes = lm <= 8 && h.pes_head_n != 0 && !(K.flags & (LAUNCH_SPLIT_ROWS | STEP_NO_OBS)) && row_heads_pay(n_waves, true);
         return heads_pes ? launch_step_mode8(G, lm, P, K, n_waves, wpw, lds, stream) : launch_step_mode5(G, lm, P, K, n_waves, wpw, lds, stream);
     }
     // single-step launches with the map's sources: the rows' head lines go out ahead of the state machine (MODE 6 / 7) when
     // the map has a head, the rows are not split and the launch is of the size where it pays
-    const bool heads = !roll && lm <= 8 && h.head_n != 0 && !(K.flags & (LAUNCH_SPLIT_ROWS | STEP_NO_OBS)) && row_heads_pay(n_waves);
+    const bool heads = !roll && lm <= 8 && h.head_n != 0 && !(K.flags & (LAUNCH_SPLIT_ROWS | STEP_NO_OBS)) &&
+                       row_heads_pay(n_waves, (K.flags & LAUNCH_GENERAL) != 0);
     if (K.flags & LAUNCH_GENERAL) {
         if (roll) return launch_step_mode2(G, lm, P, K, n_waves, wpw, lds, stream);
         return heads ? launch_step_mode7(G, lm, P, K, n_waves, wpw, lds, stream) : launch_step_mode4(G, lm, P, K, n_waves, wpw, lds, stream);

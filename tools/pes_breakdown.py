@@ -5,7 +5,7 @@ sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "t
 import torch
 from lle_prof import timeit
 from lle_amd import BatchedWorld, Map, _capi
-n = 65536
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 def mk(pes):
     bw = BatchedWorld(Map(level=6), n)
     if pes:
