@@ -94,6 +94,39 @@ def test_heads_on_and_off_agree_at_full_batch(name, monkeypatch):
         assert torch.equal(getattr(a, k), getattr(b, k)), k
 
 
+@pytest.mark.parametrize("variant", ["per_env_sources", "fused_outputs"])
+def test_general_modes_with_heads_in_a_many_round_launch(variant, monkeypatch):
+    """262 144 level-6 envs = 16 384 wavefronts, four rounds of workgroups: since round 3 the launcher takes the head kernels there
+    too in the general modes (MODE 8 for per-env sources, MODE 7 for the fused LLE.step outputs; kernels.hip row_heads_pay).  Same
+    buffers, same outputs as the kernels without heads (MODE 5 / 4), which the small-batch suites hold against the oracle."""
+    import torch
+
+    from lle_amd import BatchedWorld, Map
+    from tests.parity_util import legal_colours
+
+    n = 262144
+    worlds = [BatchedWorld(Map(LEVELS[6]), n) for _ in (0, 1)]
+    outs = []
+    for bw in worlds:
+        A, G = bw.map.n_agents, bw.map.n_gems
+        st, rw, av = (torch.zeros((n, 3 * A + G), device="cuda"), torch.zeros((n, 1), device="cuda"),
+                      torch.zeros((n, A, 5), dtype=torch.uint8, device="cuda"))
+        outs.append((st, rw, av, bw.make_env_outputs(state=st, reward=rw, available=av)))
+        if variant == "per_env_sources":
+            rng = np.random.default_rng(3)
+            bw.set_sources(torch.from_numpy(legal_colours(bw.map, rng.integers(0, A, size=(n, bw.map.n_sources), dtype=np.uint8))))
+    for t in range(6):
+        for bw, (st, rw, av, eo), heads in zip(worlds, outs, ("1", "0")):
+            monkeypatch.setenv("LLE_ROW_HEADS", heads)
+            kw = dict(env_out=eo) if variant == "fused_outputs" else dict(recolour_resets=(t % 2 == 1))
+            bw.step(sample=True, auto_reset=True, seed=8, t=t, **kw)
+    a, b = worlds
+    for k in ("pos", "bits", "gems", "beams", "avail", "events", "evcount", "done", "obs"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    if variant == "fused_outputs":
+        assert all(torch.equal(x, y) for x, y in zip(outs[0][:3], outs[1][:3]))
+
+
 def test_source_update_moves_the_head(oracle_mod, heads_forced):
     """lle_batch_update_sources recompiles the tables: a colour change moves beam bytes to another layer, and the head with them."""
     from lle_amd import BatchedWorld, Map
