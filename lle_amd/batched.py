@@ -20,6 +20,18 @@ _TORCH_DTYPES = {
 }
 
 
+# The raw handle of torch's CURRENT stream on a device: the bound calls below read it on every call (an integer from the C
+# extension, ~0.1 us) instead of freezing the stream that was current when they were bound -- a caller that enters another
+# `torch.cuda.stream(...)` later gets its launches there, ordered with its own tensors.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _current_stream_handle(device):
+    if _raw_stream is not None:
+        return _raw_stream(device.index or 0)
+    return torch.cuda.current_stream(device).cuda_stream
+
+
 def _require_gpu():
     if not torch.cuda.is_available():
         raise RuntimeError("lle_amd: no HIP device is visible. The batched World runs only on the GPU "
@@ -230,15 +242,15 @@ class BatchedWorld:
 
     def sampled_stepper(self, auto_reset=True, seed=0, env_offset=0, write_obs=True):
         """A zero-argument callable for hot loops: one `step(sample=True, ...)` per call with the arguments and the
-        stream bound once (the stream that is current NOW), the time index advancing by one per call -- the C-ABI call
+        flags bound once, the time index advancing by one per call -- the C-ABI call
         and nothing else per step (`step()` itself spends a few microseconds in Python per launch)."""
-        fn, h, st = _capi.lib().lle_batch_step, self.h, self._stream()
+        fn, h, dev = _capi.lib().lle_batch_step, self.h, self.device
         flags = LLE_STEP_SAMPLE_ACTIONS | (LLE_STEP_AUTO_RESET if auto_reset else 0) | (0 if write_obs else LLE_STEP_NO_OBS)
         seed, env_offset = int(seed), int(env_offset)
 
         def one_step():
             t = self.t
-            rc = fn(h, None, flags, seed, t, env_offset, st)
+            rc = fn(h, None, flags, seed, t, env_offset, _current_stream_handle(dev))
             if rc != 0:
                 self._check(rc)
             self.t = t + 1
@@ -353,8 +365,7 @@ class BatchedWorld:
         flat = out[: int(d.bytes)].view(dt)
         return torch.as_strided(flat, [int(d.shape[k]) for k in range(d.ndim)], [int(d.stride[k]) for k in range(d.ndim)])
 
-    # ---- bound calls: arguments, output buffer and stream fixed ONCE (the stream that is current now); per call the C-ABI call
-    # and nothing else.  observe_as() / available_actions() / env_outputs() spend 10-15 us per call in Python (descriptor query,
+    # ---- bound calls: arguments and output buffer fixed ONCE; per call the C-ABI call on torch's current stream and nothing else.  observe_as() / available_actions() / env_outputs() spend 10-15 us per call in Python (descriptor query,
     # allocation, view construction, argument conversion) around kernels of 4-6 us: a host that steps in a loop uses these.
     def bound_observer(self, kind, param=0, out=None):
         """A zero-argument callable that writes observation `kind` into ONE persistent buffer (`call.out`: the strided view
@@ -369,10 +380,10 @@ class BatchedWorld:
         dt = torch.int8 if d.elem_bytes == 1 else torch.float32
         view = torch.as_strided(out[: int(d.bytes)].view(dt), [int(d.shape[k]) for k in range(d.ndim)], [int(d.stride[k]) for k in range(d.ndim)])
         fn = _capi.lib().lle_batch_observe_as
-        args = (C.c_void_p(self.h), C.c_int(int(kind)), C.c_int(int(param)), C.c_void_p(out.data_ptr()), C.c_int64(out.numel()), self._stream())
+        args, dev = (C.c_void_p(self.h), C.c_int(int(kind)), C.c_int(int(param)), C.c_void_p(out.data_ptr()), C.c_int64(out.numel())), self.device
 
         def call():
-            rc = fn(*args)
+            rc = fn(*args, _current_stream_handle(dev))
             if rc != 0:
                 self._check(rc)
             return view
@@ -384,11 +395,11 @@ class BatchedWorld:
         if out is None:
             out = torch.empty((self.n_envs, self.map.n_agents, 5), dtype=torch.uint8, device=self.device)
         fn = _capi.lib().lle_batch_available_actions
-        args = (C.c_void_p(self.h), C.c_int(int(bool(walkable_lasers))), C.c_void_p(out.data_ptr()), self._stream())
+        args, dev = (C.c_void_p(self.h), C.c_int(int(bool(walkable_lasers))), C.c_void_p(out.data_ptr())), self.device
         view = out.view(torch.bool)
 
         def call():
-            rc = fn(*args)
+            rc = fn(*args, _current_stream_handle(dev))
             if rc != 0:
                 self._check(rc)
             return view
@@ -399,10 +410,10 @@ class BatchedWorld:
         """Zero-argument callable for env_outputs() over fixed tensors (same keyword arguments)."""
         o = self.make_env_outputs(**tensors)
         fn = _capi.lib().lle_batch_env_outputs
-        args = (C.c_void_p(self.h), C.byref(o), self._stream())
+        args, dev = (C.c_void_p(self.h), C.byref(o)), self.device
 
         def call():
-            rc = fn(*args)
+            rc = fn(*args, _current_stream_handle(dev))
             if rc != 0:
                 self._check(rc)
         call.struct, call.tensors = o, tensors  # (kept alive with the callable)
@@ -413,13 +424,13 @@ class BatchedWorld:
         contiguous uint8 [n, A] tensor on this device (no conversion, no checks).  The time index advances by one per call."""
         flags = ((LLE_STEP_AUTO_RESET if auto_reset else 0) | (LLE_STEP_RECOLOUR_RESETS if recolour_resets else 0) |
                  (0 if write_obs else LLE_STEP_NO_OBS))
-        L, h, st, seed, env_offset = _capi.lib(), C.c_void_p(self.h), self._stream(), int(seed), int(env_offset)
+        L, h, dev, seed, env_offset = _capi.lib(), C.c_void_p(self.h), self.device, int(seed), int(env_offset)
         fn = L.lle_batch_step_outputs if env_out is not None else L.lle_batch_step
-        tail = (C.byref(env_out), st) if env_out is not None else (st,)
+        tail = (C.byref(env_out),) if env_out is not None else ()
 
         def call(actions):
             t = self.t
-            rc = fn(h, actions.data_ptr(), flags, seed, t, env_offset, *tail)
+            rc = fn(h, actions.data_ptr(), flags, seed, t, env_offset, *tail, _current_stream_handle(dev))
             if rc != 0:
                 self._check(rc)
             self.t = t + 1
@@ -459,10 +470,10 @@ class BatchedWorld:
     def row_fill_prober(self, value=0):
         """A zero-argument callable: one launch that overwrites `obs` with the step kernel's store pattern and nothing else
         (lle_batch_probe_row_fill): the write ceiling of this box for this batch shape.  Call observe() afterwards."""
-        fn, h, st, v = _capi.lib().lle_batch_probe_row_fill, self.h, self._stream(), int(value)
+        fn, h, dev, v = _capi.lib().lle_batch_probe_row_fill, self.h, self.device, int(value)
 
         def probe():
-            rc = fn(h, v, st)
+            rc = fn(h, v, _current_stream_handle(dev))
             if rc != 0:
                 self._check(rc)
         return probe

@@ -173,6 +173,9 @@ class BatchedLLE:
         """LLE.seed (env.py:245-247): seeds the colour randomisation (v1 maps have a single start per agent)."""
         self._gen.manual_seed(int(seed_value))
         self._seed_value = int(seed_value)
+        # the persistent step's bound calls carry the seed of the in-kernel colour draws: bind them again with the new one
+        for key in [k for k in self._bound if isinstance(k, tuple) and k[0] == "step"]:
+            del self._bound[key]
 
     @property
     def done(self):

@@ -529,3 +529,42 @@ def test_persistent_step_equals_the_allocating_step(kw):
     assert torch.equal(f(), w.observe_as(_capi.LLE_OBS_PARTIAL, 3)) and f() is f.out
     h = w.bound_available_actions(False)
     assert torch.equal(h(), w.available_actions(False))
+
+
+def test_seed_after_a_persistent_step_and_another_stream():
+    """the bound calls of step(persistent=True) must not freeze the seed of the in-kernel colour draws nor the stream
+    that was current when they were bound.  env.seed(x) after a persistent step gives the draws of the allocating path with the
+    same seed; a persistent step issued inside `torch.cuda.stream(s)` lands on s (ordered with the caller's tensors there)."""
+    import torch
+
+    from lle_amd import BatchedLLE
+
+    n = 640
+    a, b = BatchedLLE(LEVELS[6], n, seed=5, randomize_lasers=True), BatchedLLE(LEVELS[6], n, seed=5, randomize_lasers=True)
+    a.reset(), b.reset()
+    b.world.set_sources(colours=a.world.src_colour[:, : a.world.map.n_sources].clone())
+    g = torch.Generator(device="cuda").manual_seed(2)
+
+    def acts_of(env):
+        avail = env.available_actions()
+        return torch.multinomial(avail.reshape(-1, 5).float(), 1, generator=g).reshape(n, -1).to(torch.uint8)
+
+    for t in range(12):
+        if t == 4:
+            a.seed(77), b.seed(77)  # (after the step calls were bound with seed 5)
+        acts = acts_of(b)
+        x, y = a.step(acts, auto_reset=True, persistent=True), b.step(acts, auto_reset=True)
+        for k in ("obs", "state", "reward", "done", "available_actions", "err"):
+            assert torch.equal(x[k], y[k]), (t, k)
+        assert torch.equal(a.world.src_colour, b.world.src_colour), t
+    assert a.world.stats()["auto_resets"] > 0
+    # another stream: the producer of `acts` and the step are ordered on `side` alone
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for t in range(6):
+            acts = acts_of(b)
+            x, y = a.step(acts, auto_reset=True, persistent=True), b.step(acts, auto_reset=True)
+            for k in ("obs", "state", "reward", "done", "err"):
+                assert torch.equal(x[k], y[k]), (t, k)
+    side.synchronize()
