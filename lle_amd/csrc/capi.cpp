@@ -184,6 +184,11 @@ int capi_batch_stats_to_device(lle_batch* b, int64_t* out8_dev, int reset_counte
     if (reset_counters) HIP_TRY(hipMemsetAsync(b->ptrs.stats, 0, (size_t)b->layout.n_stat_blocks * 64, st));
     return LLE_OK;
 }
+int capi_batch_reset_counters(lle_batch* b, void* stream) {
+    ON_DEVICE_OF(b);
+    HIP_TRY(hipMemsetAsync(b->ptrs.stats, 0, (size_t)b->layout.n_stat_blocks * 64, (hipStream_t)stream));
+    return LLE_OK;
+}
 }  // namespace lle
 
 extern "C" {
@@ -994,10 +999,27 @@ static int push_map(lle_batch* b, int map_index, const lle_map* map, bool broadc
         if (!(a.pos == o.pos) || a.direction != o.direction || a.beam.size() != o.beam.size()) return fail(LLE_ERR_ARG, "map does not match the batch (another map's sources)");
     }
     if (map->m.kind.size() != b->maps[(size_t)map_index].kind.size()) return fail(LLE_ERR_ARG, "map does not match the batch");
-    for (size_t c = 0; c < map->m.kind.size(); c++) {  // walls, voids, gems and sources stay where they are; floor <-> exit may swap
+    for (size_t c = 0; c < map->m.kind.size(); c++) {
+        // walls, gems and sources stay where they are; floor <-> exit may swap anywhere (World::set_exit_positions, world.rs:195-234);
+        // a void takes part only UNDER A BEAM, where Laser::set_tile (laser.rs:109-115) replaces the innermost tile whatever it is --
+        // a plain void that turned into floor (or the reverse) is another map: live agents would stand on a void without a death event
         const uint8_t a = map->m.kind[c], o = b->maps[(size_t)map_index].kind[c];
-        const bool swap_ok = (a == K_FLOOR || a == K_EXIT || a == K_VOID) && (o == K_FLOOR || o == K_EXIT || o == K_VOID);
-        if (a != o && !swap_ok) return fail(LLE_ERR_ARG, "map does not match the batch (another map's tiles)");
+        if (a == o) continue;
+        const bool fe = (a == K_FLOOR || a == K_EXIT) && (o == K_FLOOR || o == K_EXIT);
+        const bool under_beam = !map->m.cell_layers[c].empty() && !b->maps[(size_t)map_index].cell_layers[c].empty();
+        const bool with_void = under_beam && (a == K_FLOOR || a == K_EXIT || a == K_VOID) && (o == K_FLOOR || o == K_EXIT || o == K_VOID);
+        if (!fe && !with_void) return fail(LLE_ERR_ARG, "map does not match the batch (another map's tiles)");
+    }
+    // several maps: the common header (largest table sizes) is worked out BEFORE anything is uploaded or replaced, so that a
+    // refusal leaves host and device as they were
+    MapHeader new_common = nh;
+    uint32_t new_worst = b->worst_table_bytes;
+    if (b->maps.size() > 1) {
+        std::vector<lle_map> tmp(b->maps.size());
+        std::vector<const lle_map*> ptrs;
+        for (size_t m = 0; m < b->maps.size(); m++) { tmp[m].m = (int)m == map_index ? map->m : b->maps[m]; ptrs.push_back(&tmp[m]); }
+        int rc = common_header(ptrs.data(), (int)ptrs.size(), &new_common, &new_worst);
+        if (rc != LLE_OK) return rc;
     }
     ON_DEVICE_OF(b);
     LaunchArgs K{};
@@ -1007,15 +1029,8 @@ static int push_map(lle_batch* b, int map_index, const lle_map* map, bool broadc
                            map->m.blob.size(), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
     b->maps[(size_t)map_index] = map->m;
-    if (b->maps.size() == 1) {
-        b->hdr = nh;
-    } else {  // the common header carries the largest table sizes of the batch's maps
-        std::vector<lle_map> tmp(b->maps.size());
-        std::vector<const lle_map*> ptrs;
-        for (size_t m = 0; m < b->maps.size(); m++) { tmp[m].m = b->maps[m]; ptrs.push_back(&tmp[m]); }
-        int rc = common_header(ptrs.data(), (int)ptrs.size(), &b->hdr, &b->worst_table_bytes);
-        if (rc != LLE_OK) return rc;
-    }
+    b->hdr = new_common;
+    b->worst_table_bytes = new_worst;
     drop_views(b);  // their tables depend on the colours and the exits (the stream is idle: synchronised above)
     int rc = refresh_init_record(b, stream);
     if (rc != LLE_OK) return rc;

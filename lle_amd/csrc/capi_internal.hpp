@@ -12,4 +12,5 @@ int capi_batch_device(const lle_batch* b);
 // this batch's eight counters (lle_batch_stats) summed over its per-wavefront slots INTO device memory `out8_dev`, enqueued
 // on `stream`; reset_counters: the slots are zeroed behind the sum
 int capi_batch_stats_to_device(lle_batch* b, int64_t* out8_dev, int reset_counters, void* stream);
+int capi_batch_reset_counters(lle_batch* b, void* stream);  // the slots back to zero, enqueued on `stream`
 }  // namespace lle

@@ -133,7 +133,7 @@ lle_comm* lle_comm_create(const uint8_t id[LLE_COMM_ID_BYTES], int n_ranks, int 
         return nullptr;
     }
     lle_comm* c = new (std::nothrow) lle_comm();
-    if (!c) return nullptr;
+    if (!c) { lle::capi_fail(LLE_ERR_HIP, "out of memory"); return nullptr; }
     c->n_ranks = n_ranks; c->rank = rank; c->device = device_id;
     {
         DeviceScopeC scope(device_id);  // ncclCommInitRank binds the communicator to the CURRENT device
@@ -171,13 +171,23 @@ int lle_comm_create_all(lle_comm** out, int n_devices, const int* device_ids) {
         RCCL_TRY(R, R->CommInitAll(comms, n_devices, devs));
     }
     for (int k = 0; k < n_devices; k++) out[k] = nullptr;
+    // On any failure nothing is left behind: the handles built so far are freed (each destroys its communicator), the
+    // communicators that never got a handle are destroyed here, and out[] is all NULL again.
+    auto undo = [&](int built, int rc) {
+        for (int q = 0; q < built; q++) { lle_comm_free(out[q]); out[q] = nullptr; }
+        for (int q = built; q < n_devices; q++) {
+            DeviceScopeC scope(devs[q]);
+            (void)R->CommDestroy(comms[q]);
+        }
+        return rc;
+    };
     for (int k = 0; k < n_devices; k++) {
         lle_comm* c = new (std::nothrow) lle_comm();
-        if (!c) return lle::capi_fail(LLE_ERR_HIP, "out of memory");
+        if (!c) return undo(k, lle::capi_fail(LLE_ERR_HIP, "out of memory"));
         c->comm = comms[k]; c->n_ranks = n_devices; c->rank = k; c->device = devs[k];
         out[k] = c;
         int rc = finish_comm(c);
-        if (rc != LLE_OK) return rc;
+        if (rc != LLE_OK) return undo(k + 1, rc);
     }
     return lle::capi_ok();
 }
@@ -215,11 +225,13 @@ int lle_batch_stats_allreduce(lle_batch* b, lle_comm* c, int64_t out[8], int res
     if (!R) return no_rccl();
     DeviceScopeC scope(c->device);
     hipStream_t st = (hipStream_t)stream;
-    int rc = lle::capi_batch_stats_to_device(b, c->scratch, reset_counters, stream);  // this rank's eight sums, on the device
+    int rc = lle::capi_batch_stats_to_device(b, c->scratch, 0, stream);  // this rank's eight sums, on the device
     if (rc != LLE_OK) return rc;
     RCCL_TRY(R, R->AllReduce(c->scratch, c->scratch, 8, NCCL_INT64, NCCL_SUM, c->comm, st));
     HIP_TRY_C(hipMemcpyAsync(out, c->scratch, 8 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
     HIP_TRY_C(hipStreamSynchronize(st));
+    // the counters go back to zero only once the reduced values are in the caller's hands: a failed collective loses nothing
+    if (reset_counters && (rc = lle::capi_batch_reset_counters(b, stream)) != LLE_OK) return rc;
     return lle::capi_ok();
 }
 
@@ -235,7 +247,7 @@ int lle_batch_stats_allreduce_group(lle_batch* const* batches, lle_comm* const* 
         if (comms[k]->n_ranks != n) return lle::capi_fail(LLE_ERR_ARG, "the group must hold every rank of the communicator");
     }
     for (int k = 0; k < n; k++) {
-        int rc = lle::capi_batch_stats_to_device(batches[k], comms[k]->scratch, reset_counters, streams ? streams[k] : nullptr);
+        int rc = lle::capi_batch_stats_to_device(batches[k], comms[k]->scratch, 0, streams ? streams[k] : nullptr);
         if (rc != LLE_OK) return rc;
     }
     // one process drives every rank: the calls of all ranks must be posted inside one group or the first would block
@@ -256,6 +268,11 @@ int lle_batch_stats_allreduce_group(lle_batch* const* batches, lle_comm* const* 
         if (k == 0) std::memcpy(out, got, sizeof got);
         else if (std::memcmp(out, got, sizeof got) != 0) return lle::capi_fail(LLE_ERR_HIP, "ranks disagree on the reduced counters");
     }
+    if (reset_counters)  // (after the reduction succeeded on every rank)
+        for (int k = 0; k < n; k++) {
+            int rc = lle::capi_batch_reset_counters(batches[k], streams ? streams[k] : nullptr);
+            if (rc != LLE_OK) return rc;
+        }
     return lle::capi_ok();
 }
 

@@ -45,6 +45,7 @@ def test_parent_spawns_n_ranks_and_prints_one_line(world):
     reg = out["region"]
     assert abs(reg["kernel_ms_max_over_ranks"] - 0.02 * world) < 1e-9 and abs(reg["kernel_ms_min_over_ranks"] - 0.02) < 1e-9
     assert abs(reg["wall_ms_per_step_max_over_ranks"] - world / 20 * 1e3) < 1e-6
+    assert abs(reg["wall_ms_per_step_without_closing_barrier_max_over_ranks"] - 0.9 * world / 20 * 1e3) < 1e-6
     assert abs(reg["agent_steps_per_s_by_slowest_rank_events"] - 4 * 65536 * world / (0.02e-3 * world)) < 1.0
     assert abs(reg["sustained_kernel_ms_max_over_ranks"] - 0.019 * world) < 1e-9
 
@@ -55,12 +56,20 @@ def test_scaling_block_and_gpu_count_helpers():
     spec = importlib.util.spec_from_file_location("bench_module", BENCH)
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    rows = [[0.0005, 0.0200, 65536 * 20, 0.04, 0.0195], [0.0009, 0.0400, 65536 * 20, 0.08, 0.0390]]  # rank 1 twice as slow
+    rows = [[0.0005, 0.0200, 65536 * 20, 0.04, 0.0195, 0.00045], [0.0009, 0.0400, 65536 * 20, 0.08, 0.0390, 0.00085]]  # rank 1 twice as slow
     blk = bench.scaling_block(rows, steps=20, sustained_steps=2000, n_envs=65536, agents=4, n1_reference=0.0195)
     assert blk["region"]["kernel_ms_max_over_ranks"] == 0.04 and blk["per_rank"][1]["kernel_ms"] == 0.04
     assert abs(blk["weak_scaling_vs_n1"]["ratio"] - 0.5) < 1e-12
     assert abs(blk["region"]["host_share_of_wall"] - (1 - 0.04e-3 * 20 / 0.0009)) < 1e-12
     assert "weak_scaling_vs_n1" not in bench.scaling_block(rows, 20, 2000, 65536, 4)
+    # both clocks of the region: the contract's (closing barrier inside) and each rank's own
+    assert abs(blk["region"]["wall_ms_per_step_without_closing_barrier_max_over_ranks"] - 0.00085 / 20 * 1e3) < 1e-12
+    assert abs(blk["per_rank"][0]["wall_ms_per_step_without_closing_barrier"] - 0.00045 / 20 * 1e3) < 1e-12
+    # the N = 1 reference is keyed on (user, envs per GPU, sustained launches): another workload's figure is never picked up
+    assert bench.n1_reference(4321, 77, write=0.5) == 0.5 and bench.n1_reference(4321, 77) == 0.5
+    assert bench.n1_reference(4321, 78) is None and bench.n1_reference(4322, 77) is None
+    import os
+    os.unlink(bench.n1_cache_path(4321, 77))
     import torch
     n = bench.visible_gpus()
     assert isinstance(n, int) and n >= 0

@@ -179,6 +179,8 @@ def test_exits_of_one_map_of_several(oracle_mod):
 def test_update_map_refuses_what_is_not_a_recompilation():
     """a map with another row pitch (lle_map_set_row_align after lle_batch_create) or other tiles is LLE_ERR_ARG,
     for lle_batch_update_sources too; BatchedWorld(row_align=...) leaves the caller's Map alone."""
+    import torch
+
     from lle_amd import BatchedWorld, _capi
 
     m = _capi.Map(LEVELS[6])
@@ -195,6 +197,17 @@ def test_update_map_refuses_what_is_not_a_recompilation():
     small.maps[0] = small.map = _capi.Map("S0 @ . X\nL0E . . .")  # same shape and counts, a wall moved
     with pytest.raises(RuntimeError, match="does not match"):
         small.update_map()
+    # a plain void that became floor (or the reverse) is another map -- only under a beam may a void change
+    # (Laser::set_tile, laser.rs:109-115), and the batch is left as it was
+    voids = BatchedWorld("S0 . V X\nL0E . . .", 64)
+    before = voids.obs.clone()
+    voids.maps[0] = voids.map = _capi.Map("S0 . . X\nL0E . . .")
+    with pytest.raises(RuntimeError, match="does not match"):
+        voids.update_map()
+    assert torch.equal(voids.obs, before)
+    under = BatchedWorld("S0 . . X\nL0E . V .", 64)  # the void sits under the beam: it may become an exit
+    under.set_exits([(1, 2)])
+    assert under.map.positions(_capi.LLE_POS_EXIT) == [(1, 2)]
     # row_align on a batch is applied to a COPY of the caller's map
     mine = _capi.Map(LEVELS[6])
     bw2 = BatchedWorld(mine, 64, row_align=16)
