@@ -197,7 +197,8 @@ def plumbing_only(args, real_stdout):
     import torch
     import torch.distributed as dist
 
-    from lle_amd.distributed import STAT_KEYS, allreduce_max, allreduce_stats, gather_rows
+    from lle_amd import _capi
+    from lle_amd.distributed import STAT_KEYS, allreduce_max, allreduce_stats, gather_rows, shard_check
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     if "RANK" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -212,8 +213,12 @@ def plumbing_only(args, real_stdout):
     else:
         elapsed = 1.0
     rows = gather_rows(mine, dev)
+    # the shard check's plumbing (all-gather of 64-bit hashes, rank 0's recomputation): the "window" is the host-side action hash
+    # of the shard's first environment -- a function of env_offset alone, like the real window's checksum
+    check = shard_check(lambda off: int(_capi.lib().lle_action_hash(SEED, off, 8, 0)) ^ (off * 0x9E3779B97F4A7C15 & (2**64 - 1)),
+                        65536, rank, world, dev)
     if rank == 0:
-        line = {"plumbing_only": True, "n_gpus": world, "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+        line = {"plumbing_only": True, "shard_check": check, "n_gpus": world, "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
                 "backend": "gloo", "rollout_stats": stats, "elapsed_max": elapsed,
                 **scaling_block(rows, steps=20, sustained_steps=2000, n_envs=65536, agents=4)}
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
@@ -301,6 +306,7 @@ class Timer:
         self.torch, self.dist, self.use_dist = torch, dist, use_dist
         self.dev = sync_dev if sync_dev is not None else dev  # the GPU this rank launches on
         self.wall_open = 0.0  # the last region's clock without the closing barrier
+        self.issue = 0.0      # ... and the host time its K calls took to issue
 
     def sync(self):
         self.torch.cuda.synchronize(self.dev)
@@ -316,6 +322,7 @@ class Timer:
         ev0.record()
         for _ in range(k):
             fn()
+        self.issue = time.perf_counter() - t0  # the host's own time: K calls issued, nothing waited for
         ev1.record()
         torch.cuda.synchronize(self.dev)
         wall = self.wall_open = time.perf_counter() - t0
@@ -372,6 +379,26 @@ def measure_config(torch, timer, dev, map_or_text, n_envs, algo_bytes, steps, la
         "traffic": load_traffic(traffic_key) if traffic_key else None,
         "rollout_stats": bw.stats(),
     }
+    if rows > INFINITY_CACHE_BYTES:
+        # the same launches walked one way only (LLE_PINGPONG=0): nothing of a launch's rows is found in the Infinity Cache, every
+        # row goes to DRAM -- the only figure of this block that may be quoted against the HBM peak
+        from lle_amd import _capi
+        old = os.environ.get("LLE_PINGPONG")
+        os.environ["LLE_PINGPONG"] = "0"
+        _capi.refresh_tuning()
+        for _ in range(6):
+            fn()
+        _, d_ms = timer.run(fn, max(20, steps // 2))
+        if old is None:
+            os.environ.pop("LLE_PINGPONG")
+        else:
+            os.environ["LLE_PINGPONG"] = old
+        _capi.refresh_tuning()
+        for _ in range(4):
+            fn()
+        d_ach = algo_bytes * n_envs / (d_ms * 1e-3) / 1e9
+        out["dram_only"] = {"walk": "ascending (LLE_PINGPONG=0)", "kernel_ms": d_ms, "achieved_GBps": d_ach, "frac_of_hbm_peak": d_ach / HBM_PEAK_GBS,
+                            "note": "every row of every launch is written to DRAM: the figure to read against the 8 TB/s HBM peak"}
     if bw.placement:
         out["placement"] = dict(bw.placement, note="BatchedWorld(placement_candidates=k): k arenas allocated side by side, the step kernel's store "
                                                    "pattern timed on each (us per launch), the fastest kept, the rest released before the timed region")
@@ -413,6 +440,68 @@ def measure_config(torch, timer, dev, map_or_text, n_envs, algo_bytes, steps, la
                                 "note": "a launch of 4 096 envs is launch-bound (min 4.7 us); several steps per launch are not"}
         del ring
     del bw
+    torch.cuda.empty_cache()
+    return out
+
+
+def measure_consumer_loop(torch, timer, dev, steps):
+    """step -> reader -> step on the launch stream: what a policy does between two steps is READ the observation (its first layer),
+    which changes what the Infinity Cache holds when the next step rewrites the rows.  Reader = an int8 -> fp16 cast of the whole
+    observation into a separate buffer (python/lle/env/env.py:165-189: the caller of LLE.step consumes `obs` before it steps again).
+    Per workload: step alone, reader alone, the pair -- with the alternating walk on and off where the rows exceed the cache.
+    The walk's default (capi.cpp pingpong_pays) is read off the `pair_us` columns of this block."""
+    from lle_amd import BatchedWorld, Map, _capi, mapgen
+    out = {"what": "us per launch (HIP events): World.step alone, an int8->fp16 cast of the whole observation alone, and step + cast alternating on one stream",
+           "steps": steps}
+    for label, m, n in (("level6_65536", Map(level=LEVEL), 65536), ("level6_262144", Map(level=LEVEL), 262144),
+                        ("cfg5_65536", Map(mapgen.config5(0)), 65536)):
+        bw = BatchedWorld(m, n, device=dev)
+        rows = bw.obs_rows
+        big = rows.numel() > INFINITY_CACHE_BYTES
+        half = torch.empty(rows.shape, dtype=torch.float16, device=dev)
+        step = stepper(bw)
+
+        def reader():
+            half.copy_(rows)
+
+        def pair():
+            step()
+            reader()
+        blk = {"rows_MB": rows.numel() / 1e6, "reader_out_MB": half.numel() * 2 / 1e6}
+        k = max(20, steps if not big else steps // 2)
+        for walk in (("on", "off") if big else ("default",)):
+            if walk != "default":
+                os.environ["LLE_PINGPONG"] = "1" if walk == "on" else "0"
+                _capi.refresh_tuning()
+            for _ in range(8):
+                pair()
+            _, s_ms = timer.run(step, k)
+            _, r_ms = timer.run(reader, k)
+            _, p_ms = timer.run(pair, k)
+            blk["walk_" + walk] = {"step_us": s_ms * 1e3, "reader_us": r_ms * 1e3, "pair_us": p_ms * 1e3, "step_in_pair_us": (p_ms - r_ms) * 1e3}
+        if big:
+            os.environ.pop("LLE_PINGPONG", None)
+            _capi.refresh_tuning()
+            blk["walk_that_wins_the_pair"] = "on" if blk["walk_on"]["pair_us"] <= blk["walk_off"]["pair_us"] else "off"
+        out[label] = blk
+        del bw, rows, half
+        torch.cuda.empty_cache()
+    # the fused rollout into a two-slot ring with the reader trailing one slot (a double buffer: slot t is cast while t + 1 is written)
+    bw = BatchedWorld(Map(level=LEVEL), 65536, device=dev)
+    ring = bw.make_ring(2)
+    half = torch.empty(ring["obs_rows"][0].shape, dtype=torch.float16, device=dev)
+    state = {"t": 0}
+
+    def ring_pair():
+        t = state["t"]
+        bw.rollout(1, auto_reset=True, seed=SEED, ring=ring, ring_pos=t)
+        half.copy_(ring["obs_rows"][(t + 1) % 2])  # the slot written by the launch before this one
+        state["t"] = t + 1
+    for _ in range(8):
+        ring_pair()
+    _, rp_ms = timer.run(ring_pair, max(20, steps))
+    out["level6_65536"]["ring2_reader_trailing_one_slot_pair_us"] = rp_ms * 1e3
+    del bw, ring, half
     torch.cuda.empty_cache()
     return out
 
@@ -492,6 +581,8 @@ def main():
     ap.add_argument("--sustained-steps", type=int, default=2000, help="launches of the `sustained` block (0 = skip)")
     ap.add_argument("--config-steps", type=int, default=200, help="launches per secondary configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--autotune-ms", type=float, default=30.0,
+                    help="GPU time lle_batch_autotune may spend per batch choosing its launch rules (0 = the library's default rules)")
     ap.add_argument("--no-fused", action="store_true", help="skip the secondary fused-rollout measurement")
     ap.add_argument("--no-configs", action="store_true", help="skip roofline_hbm and the cfg2 / cfg5 blocks")
     ap.add_argument("--fused-steps", type=int, default=16, help="steps per launch of the fused rollout")
@@ -519,7 +610,7 @@ def main():
     import torch.distributed as dist
 
     from lle_amd import BatchedWorld, Map
-    from lle_amd.distributed import allreduce_max, allreduce_stats, gather_rows, shard_offset
+    from lle_amd.distributed import allreduce_max, allreduce_stats, gather_rows, shard_check, shard_offset, world_hash
 
     world = int(os.environ.get("WORLD_SIZE", "1")) if under_launcher else 1
     rank = int(os.environ.get("RANK", "0")) if under_launcher else 0
@@ -553,8 +644,21 @@ def main():
     timer = Timer(torch, dist, cdev if rehearsal else dev, use_dist, sync_dev=dev)
 
     n = args.envs_per_gpu
+    # ---- shard invariance over the real collective, before anything is timed: every rank steps the 64
+    # environments at the head of its shard for 8 steps, the ranks all-gather a 64-bit checksum of (pos, bits, beams, obs), rank 0
+    # recomputes all N windows with the matching env_offset.  No oracle involved: the product against itself, across ranks.
+    def window_hash(env_offset, envs=64, steps=8):
+        w = BatchedWorld(Map(level=LEVEL), envs, device=dev)
+        for t in range(steps):
+            w.step(sample=True, auto_reset=True, seed=SEED, t=t, env_offset=env_offset)
+        return world_hash(w)
+    check = shard_check(window_hash, n, rank, world, cdev)
+    if rank == 0 and check["status"] != "ok":
+        print(f"bench.py: shard check FAILED: {check}", file=sys.stderr)
+
     bw = BatchedWorld(Map(level=LEVEL), n, device=dev, envs_per_wave=args.envs_per_wave or None)
     offset = shard_offset(n, rank)
+    tuning = bw.autotune(args.autotune_ms) if args.autotune_ms > 0 and not args.envs_per_wave else bw.tuning()
     step = stepper(bw, offset)
 
     bw.stats_blocks.zero_()  # (the first torch fill of the process loads a code object: not right in front of the timed region)
@@ -569,7 +673,7 @@ def main():
     # first -- a host round trip right in front of a timed region that is 0.5 ms long at the driver's 20 steps)
     bw.stats_blocks.zero_()
     my_wall, kernel_ms = timer.run(step, args.steps)
-    my_wall_open = timer.wall_open
+    my_wall_open, my_issue = timer.wall_open, timer.issue
     elapsed = allreduce_max(my_wall, cdev) if use_dist else my_wall
     local_stats = bw.stats()
     stats = allreduce_stats(local_stats, cdev) if use_dist else local_stats
@@ -578,8 +682,9 @@ def main():
     my_s_wall = s_ms = 0.0
     if args.sustained_steps > 0:
         my_s_wall, s_ms = timer.run(step, args.sustained_steps)
+        s_issue = timer.issue
         s_wall = allreduce_max(my_s_wall, cdev) if use_dist else my_s_wall
-        sustained = (args.sustained_steps, s_wall, s_ms)
+        sustained = (args.sustained_steps, s_wall, s_ms, s_issue)
     # every rank's own numbers (rank order): a poor aggregate can then be traced to the rank, or to the host side, that caused it
     rank_rows = gather_rows([my_wall, kernel_ms, local_stats["env_steps"], my_s_wall, s_ms, my_wall_open], cdev)
 
@@ -624,10 +729,11 @@ def main():
                                                      "cfg5_bytes_per_launch", fill_ceiling=True),
         }
 
-    lle_step = observers = None
+    lle_step = observers = consumer = None
     if world == 1 and not args.no_configs:
         lle_step = measure_lle_step(torch, timer, dev, n, max(args.config_steps, 200))
         observers = measure_observers(torch, timer, dev, n, max(args.config_steps, 200))
+        consumer = measure_consumer_loop(torch, timer, dev, max(args.config_steps, 200))
 
     if rank == 0:
         total_envs = n * world
@@ -656,20 +762,30 @@ def main():
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n, "kernel_ms": kernel_ms,
                          "rows_MB_per_launch": rows_bytes / 1e6},
             "rollout_stats": stats,
+            "shard_check": dict(check, what="every rank steps the 64 envs at the head of its shard for 8 steps; the ranks all-gather a 64-bit checksum of (pos, bits, "
+                                             "beams, obs) over the run's collective backend; rank 0 recomputes the N windows with the matching env_offset"),
+            # the launch rules of the headline batch (lle_batch_tuning): chosen by lle_batch_autotune on this batch's own arena when
+            # `autotuned`, the library's default rules otherwise; `log` = the trials (us per launch)
+            "tuning": tuning,
+            # host side of the timed region: the K C-ABI calls took this long to ISSUE (nothing waited for); the rest of
+            # (ms_per_step - kernel_ms) is the closing synchronize's wake-up spread over K steps
+            "host_issue_us_per_step": my_issue / args.steps * 1e6,
         }
         if world == 1 and sustained:
             n1_reference(n, args.sustained_steps, write=sustained[2])
         out.update(scaling_block(rank_rows, args.steps, args.sustained_steps, n, A,
                                  n1_reference(n, args.sustained_steps) if world > 1 else None))
         if sustained:
-            k, s_wall, s_ms = sustained
+            k, s_wall, s_ms, s_issue = sustained
             s_ach = ALGO_BYTES_PER_ENV_STEP * n / (s_ms * 1e-3) / 1e9
-            out["sustained"] = {"steps": k, "ms_per_step": s_wall / k * 1e3, "kernel_ms": s_ms,
+            out["sustained"] = {"steps": k, "ms_per_step": s_wall / k * 1e3, "kernel_ms": s_ms, "host_issue_us_per_step": s_issue / k * 1e6,
                                 "env_steps_per_s": total_envs * k / s_wall, "agent_steps_per_s": A * total_envs * k / s_wall,
                                 "achieved_GBps_per_gpu": s_ach, "frac_of_hbm_peak": s_ach / HBM_PEAK_GBS}
         if hbm:
             out["roofline_hbm"] = {"bound": hbm["bound"], "achieved": hbm["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": hbm["frac_of_hbm_peak"],
+                                   "frac_note": "with the alternating walk part of every launch's rows is rewritten inside the Infinity Cache: NOT a fraction of "
+                                                "the HBM peak -- `dram_only` (same kernel, one-directional walk) is",
                                    "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * hbm["n_envs"], **hbm}
         if cfgs:
             out["configs"] = cfgs
@@ -677,6 +793,8 @@ def main():
             out["lle_step"] = lle_step
         if observers:
             out["observers"] = observers
+        if consumer:
+            out["consumer_loop"] = consumer
         for key, (T, R, launches, fe) in zip(("fused_rollout", "fused_rollout_double_buffer"), fused):
             # per env-step: obs 1872 + actions 4 + reward 4 + err/evcount/done 3 + events 8, state r/w (48 B) once per launch
             fused_bytes = 1891 + 48.0 / T

@@ -456,6 +456,29 @@ int lle_batch_step_stamped(lle_batch* b, uint32_t flags, uint64_t seed, uint64_t
  * duration is the write ceiling of THIS box for this batch shape (bench.py `fill_ceiling`): boxes differ by up to 15 % once
  * the rows of a launch exceed the Infinity Cache.  Call lle_batch_observe() afterwards to get the observation back. */
 int lle_batch_probe_row_fill(lle_batch* b, uint32_t value, void* stream);
+/* ---- launch rules measured on the batch itself (no reference counterpart: the reference has no launch to tune).
+ * The step launcher's rules -- environments per wavefront, row heads ahead of the state machine, `sc1` or plain stores,
+ * split rows, the alternating walk of outputs larger than the Infinity Cache -- have defaults fitted on the builder's
+ * boxes.  lle_batch_autotune times the alternatives that exist for THIS batch on ITS OWN arena
+ * (its plain single step with sampled actions and auto-reset, HIP events on `stream`, about budget_ms of GPU time in total;
+ * <= 0: 20 ms) and keeps the fastest of each in the handle; later launches of the batch follow them.  The trials are real
+ * steps: the call ends with World.reset of every environment and the counters at zero -- call it right after
+ * lle_batch_create (or lle_batch_set_sources), not in the middle of an episode.  Results never depend on these choices.
+ * The LLE_* environment overrides still win; they are read ONCE per process, never on the launch
+ * path -- lle_tuning_refresh() reads them again (tests and tuning tools change them mid-process). */
+typedef struct lle_tuning_info {
+    int32_t envs_per_wave;    /* environments per wavefront of the step kernel */
+    int32_t row_heads;        /* 1: a plain single step stores the rows' static head lines ahead of the state machine */
+    int32_t write_through;    /* 1: `sc1` stores of the observation rows */
+    int32_t split_rows;       /* 1: every row split over the wavefronts of a workgroup (big observations) */
+    int32_t alternating_walk; /* 1: successive launches walk the environments alternately up and down */
+    int32_t autotuned;        /* 1: lle_batch_autotune has run on this handle (else: the default rules) */
+} lle_tuning_info;
+int lle_batch_autotune(lle_batch* b, double budget_ms, void* stream);
+/* The rules a plain single step of this batch is launched with, and (log_buf, optional) the trial log of lle_batch_autotune. */
+int lle_batch_tuning(const lle_batch* b, lle_tuning_info* out, char* log_buf, size_t cap);
+void lle_tuning_refresh(void);
+
 /* Diagnostic knob: step with the one-environment-per-lane kernel at 8, 16, 32 or 64 environments per wavefront
  * instead of the default one-lane-per-agent step kernel (64 / G environments per wavefront). */
 int lle_batch_set_envs_per_wave(lle_batch* b, int envs_per_wave);

@@ -45,6 +45,7 @@ EXPORTS = [
     "lle_comm_unique_id", "lle_comm_create", "lle_comm_create_all", "lle_comm_free", "lle_comm_rank", "lle_batch_stats_allreduce",
     "lle_batch_stats_allreduce_group", "lle_comm_allreduce_i64",
     "lle_batch_stats", "lle_batch_kernel_info", "lle_batch_set_envs_per_wave", "lle_batch_step_stamped", "lle_batch_probe_row_fill",
+    "lle_batch_autotune", "lle_batch_tuning", "lle_tuning_refresh",
 ]
 
 
@@ -67,6 +68,11 @@ class EnvOutputs(C.Structure):
     _fields_ = [("state", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p), ("available", C.c_void_p),
                 ("alive", C.c_void_p), ("arrived", C.c_void_p), ("normalize_state", C.c_int32), ("reward_kind", C.c_int32),
                 ("walkable_lasers", C.c_int32), ("pad", C.c_int32)]
+
+
+class TuningInfo(C.Structure):
+    """lle_tuning_info (include/lle_hip.h)."""
+    _fields_ = [(n, C.c_int32) for n in ("envs_per_wave", "row_heads", "write_through", "split_rows", "alternating_walk", "autotuned")]
 
 
 class RolloutRing(C.Structure):
@@ -216,8 +222,19 @@ def lib():
     L.lle_batch_probe_row_fill.argtypes = [vp, u32, vp]
     L.lle_batch_set_envs_per_wave.restype = i32
     L.lle_batch_set_envs_per_wave.argtypes = [vp, i32]
+    L.lle_batch_autotune.restype = i32
+    L.lle_batch_autotune.argtypes = [vp, C.c_double, vp]
+    L.lle_batch_tuning.restype = i32
+    L.lle_batch_tuning.argtypes = [vp, C.POINTER(TuningInfo), C.c_char_p, C.c_size_t]
+    L.lle_tuning_refresh.restype = None
+    L.lle_tuning_refresh.argtypes = []
     _lib = L
     return L
+
+
+def refresh_tuning():
+    """Read the LLE_* tuning overrides from the environment again (lle_tuning_refresh): the library reads them once per process."""
+    lib().lle_tuning_refresh()
 
 
 class MapParseError(ValueError):

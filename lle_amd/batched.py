@@ -184,6 +184,22 @@ class BatchedWorld:
                 pass
             self.h = None
 
+    def autotune(self, budget_ms=20.0):
+        """Time the step launcher's alternatives on this batch's own arena and keep the fastest (lle_batch_autotune): environments
+        per wavefront, row heads, store policy, split rows, alternating walk.  The trials are real steps: the batch ends reset, with
+        its counters at zero -- call it right after construction.  Returns tuning()."""
+        self._check(_capi.lib().lle_batch_autotune(self.h, float(budget_ms), self._stream()))
+        self.t = 0
+        return self.tuning()
+
+    def tuning(self):
+        """The rules a plain single step of this batch is launched with (lle_batch_tuning) and the autotune log."""
+        info, log = _capi.TuningInfo(), C.create_string_buffer(2048)
+        self._check(_capi.lib().lle_batch_tuning(self.h, C.byref(info), log, 2048))
+        out = {n: int(getattr(info, n)) for n, _ in _capi.TuningInfo._fields_}
+        out["log"] = log.value.decode()
+        return out
+
     def set_envs_per_wave(self, epw):
         self._check(_capi.lib().lle_batch_set_envs_per_wave(self.h, int(epw)))
 

@@ -152,20 +152,29 @@ struct lle_batch {
     EnvOutputs env_out_host{};
     bool env_out_valid = false;
     // outputs larger than the Infinity Cache: the launches that rewrite one walk the environments alternately up and down
-    // (obs_stream.hpp xcd_block_dir); per output buffer, the direction of its next launch
+    // (obs_stream.hpp xcd_block_dir); per output buffer, the direction of its next launch (the batch's own rows: a member, no lookup)
     std::map<const void*, bool> walk_dir;
+    bool obs_walk_dir = false;
+    // what lle_batch_autotune chose for this batch's step launches (kernels.h StepTune) and the log of its trials
+    StepTune tune{};
+    std::string tune_log;
 };
 
 // Whether alternating the walk can pay: the rows of one launch must exceed what the 256 MB Infinity Cache keeps of them
 // (LLE_PINGPONG=0 / 1 forces it either way; read per launch, the parity tests run both in one process).
-static bool pingpong_pays(uint64_t row_bytes_per_launch) {
-    const char* o = getenv("LLE_PINGPONG");
-    if (o && (o[0] == '0' || o[0] == '1') && !o[1]) return o[0] == '1';
+static bool pingpong_pays(const lle_batch* b, uint64_t row_bytes_per_launch) {
+    if (tuning().pingpong >= 0) return tuning().pingpong == 1;  // LLE_PINGPONG (read once: kernels.h Tuning)
+    if (b->tune.walk >= 0) return b->tune.walk == 1 && row_bytes_per_launch > (256ull << 20);  // (the batch's own A/B: lle_batch_autotune)
     return row_bytes_per_launch > (256ull << 20);
 }
 // the direction of the launch that is about to rewrite `out` (bytes of it), and the flip for the next one
 static bool next_walk_reversed(lle_batch* b, const void* out, uint64_t bytes) {
-    if (!pingpong_pays(bytes)) return false;
+    if (!pingpong_pays(b, bytes)) return false;
+    if (out == b->ptrs.obs) {  // the step path
+        const bool r = b->obs_walk_dir;
+        b->obs_walk_dir = !r;
+        return r;
+    }
     if (b->walk_dir.size() > 64) b->walk_dir.clear();  // (callers that hand a fresh buffer every time)
     bool& d = b->walk_dir[out];
     const bool r = d;
@@ -425,12 +434,12 @@ static int launch(lle_batch* b, int mode, LaunchArgs K, void* stream) {
                                                  "(use lle_batch_reset_sources, which resets such an env in full)");
     }
     if (mode == KMODE_STEP && !b->lane_per_env_step) {
-        K.envs_per_wave = step_envs_per_wave(b->n_envs, (int)b->hdr.A);
+        K.envs_per_wave = step_envs_per_wave(b->n_envs, (int)b->hdr.A, b->tune);
         // single steps that rewrite the rows in place (a fused rollout rewrites them inside one launch, a ring never revisits a slot in time)
         if (K.n_steps <= 1 && !K.ring_slots && !K.stamps && !(K.flags & STEP_NO_OBS) &&
             next_walk_reversed(b, b->ptrs.obs, (uint64_t)b->n_envs * b->hdr.obs_stride))
             K.flags |= LAUNCH_REVERSE;
-        HIP_TRY(launch_step_kernel(b->hdr, b->ptrs, K, (hipStream_t)stream));
+        HIP_TRY(launch_step_kernel(b->hdr, b->ptrs, K, (hipStream_t)stream, b->tune));
     }
     else {
         if (mode != KMODE_SET_STATE && next_walk_reversed(b, b->ptrs.obs, (uint64_t)b->n_envs * b->hdr.obs_stride)) K.flags |= LAUNCH_REVERSE;
@@ -1087,14 +1096,14 @@ int lle_batch_kernel_info(const lle_batch* b, char* name_buf, size_t cap, int32_
     }
     if (lds_bytes) {
         const bool pes = b->per_env_sources;
-        if (!b->lane_per_env_step && step_splits_rows(b->hdr, pes)) {
-            const uint32_t cap = 64u / (uint32_t)step_group((int)b->hdr.A), e = step_envs_per_wave(b->n_envs, (int)b->hdr.A);
+        if (!b->lane_per_env_step && step_splits_rows(b->hdr, pes, b->tune)) {
+            const uint32_t cap = 64u / (uint32_t)step_group((int)b->hdr.A), e = step_envs_per_wave(b->n_envs, (int)b->hdr.A, b->tune);
             *lds_bytes = (int32_t)split_lds_bytes(b->hdr, 4, e < cap ? e : cap);
         } else {
             *lds_bytes = (int32_t)kernel_lds_bytes(b->hdr, kernel_waves_per_wg(b->hdr, pes), pes);
         }
     }
-    if (envs_per_wave) *envs_per_wave = b->lane_per_env_step ? (int32_t)b->envs_per_wave : (int32_t)step_envs_per_wave(b->n_envs, (int)b->hdr.A);
+    if (envs_per_wave) *envs_per_wave = b->lane_per_env_step ? (int32_t)b->envs_per_wave : (int32_t)step_envs_per_wave(b->n_envs, (int)b->hdr.A, b->tune);
     return LLE_OK;
 }
 
@@ -1111,10 +1120,124 @@ int lle_batch_step_stamped(lle_batch* b, uint32_t flags, uint64_t seed, uint64_t
 int lle_batch_probe_row_fill(lle_batch* b, uint32_t value, void* stream) {
     if (!b) return fail(LLE_ERR_NULL, "NULL batch");
     ON_DEVICE_OF(b);
-    const uint32_t epw = b->lane_per_env_step ? b->envs_per_wave : step_envs_per_wave(b->n_envs, (int)b->hdr.A);
+    const uint32_t epw = b->lane_per_env_step ? b->envs_per_wave : step_envs_per_wave(b->n_envs, (int)b->hdr.A, b->tune);
     // the same alternation as the step launches it stands in for
     const bool reverse = next_walk_reversed(b, b->ptrs.obs, (uint64_t)b->n_envs * b->hdr.obs_stride);
     HIP_TRY(launch_row_fill_probe(b->ptrs.obs, b->n_envs, b->hdr.obs_stride, epw, value, reverse, (hipStream_t)stream));
+    g_status = LLE_OK;
+    return LLE_OK;
+}
+
+void lle_tuning_refresh(void) { tuning_refresh(); }
+
+// One timed trial of the batch's plain single step (sampled actions + auto-reset) under `t`: us per launch by HIP events.
+static int time_step_trial(lle_batch* b, const StepTune& t, int launches, hipStream_t st, hipEvent_t e0, hipEvent_t e1, uint64_t* t_idx, double* us) {
+    const StepTune keep = b->tune;
+    b->tune = t;
+    int rc = LLE_OK;
+    auto one = [&]() {
+        LaunchArgs K{};
+        K.flags = STEP_SAMPLE_ACTIONS | STEP_AUTO_RESET; K.seed = 0x7E57ull; K.t = (*t_idx)++;
+        return launch(b, KMODE_STEP, K, st);
+    };
+    for (int i = 0; i < 4 && rc == LLE_OK; i++) rc = one();  // (an even count: the alternating walk keeps its phase)
+    if (rc == LLE_OK && hipEventRecord(e0, st) != hipSuccess) rc = fail(LLE_ERR_HIP, "hipEventRecord");
+    for (int i = 0; i < launches && rc == LLE_OK; i++) rc = one();
+    if (rc == LLE_OK && (hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)) rc = fail(LLE_ERR_HIP, "hipEventSynchronize");
+    float ms = 0.f;
+    if (rc == LLE_OK && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = fail(LLE_ERR_HIP, "hipEventElapsedTime");
+    *us = (double)ms * 1e3 / launches;
+    b->tune = keep;
+    return rc;
+}
+
+int lle_batch_autotune(lle_batch* b, double budget_ms, void* stream) {
+    if (!b) return fail(LLE_ERR_NULL, "NULL batch");
+    if (b->lane_per_env_step) return fail(LLE_ERR_ARG, "lle_batch_autotune tunes the default step kernel (lle_batch_set_envs_per_wave selected the diagnostic one)");
+    if (!(budget_ms > 0.0)) budget_ms = 20.0;
+    ON_DEVICE_OF(b);
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return fail(LLE_ERR_HIP, "hipEventCreate"); }
+    const bool pes = b->per_env_sources;
+    const MapHeader& h = b->hdr;
+    const uint64_t row_bytes = (uint64_t)b->n_envs * h.obs_stride;
+    // the alternatives, one coordinate at a time (each keeps the best of the ones before it): environments per wavefront, row
+    // heads, store policy, split rows, the alternating walk -- only those that exist for this batch
+    const uint32_t cap = 64u / (uint32_t)step_group((int)h.A);
+    std::vector<uint32_t> epws;
+    for (uint32_t e = cap; e >= 1 && epws.size() < 3; e >>= 1) epws.push_back(e);
+    const bool can_heads = step_has_row_heads(h, pes), can_split = step_can_split_rows(h, pes), can_walk = row_bytes > (256ull << 20);
+    const int n_trials = (int)epws.size() + (can_heads ? 2 : 0) + 2 + (can_split ? 2 : 0) + (can_walk ? 2 : 0);
+    uint64_t t_idx = 1u << 20;
+    StepTune best = b->tune;
+    double probe_us = 0.0;
+    int rc = time_step_trial(b, best, 4, st, e0, e1, &t_idx, &probe_us);  // how long a launch is: sizes the trials
+    const double per_trial_us = budget_ms * 1e3 / n_trials;
+    int launches = probe_us > 0 ? (int)(per_trial_us / probe_us) : 16;
+    launches = launches < 6 ? 6 : (launches > 400 ? 400 : launches);
+    launches &= ~1;
+    char line[256];
+    std::string log;
+    auto sweep = [&](const char* what, std::vector<int> values, auto&& set) {
+        if (rc != LLE_OK || values.size() < 2) return;
+        double best_us = 0.0;
+        int best_v = values[0];
+        std::snprintf(line, sizeof line, "%s:", what);
+        log += line;
+        for (size_t i = 0; i < values.size() && rc == LLE_OK; i++) {
+            StepTune t = best;
+            set(t, values[i]);
+            double us = 0.0;
+            rc = time_step_trial(b, t, launches, st, e0, e1, &t_idx, &us);
+            std::snprintf(line, sizeof line, " %d=%.2fus", values[i], us);
+            log += line;
+            if (i == 0 || us < best_us) { best_us = us; best_v = values[i]; }
+        }
+        set(best, best_v);
+        std::snprintf(line, sizeof line, " -> %d; ", best_v);
+        log += line;
+    };
+    sweep("envs_per_wave", std::vector<int>(epws.begin(), epws.end()), [](StepTune& t, int v) { t.epw = (uint8_t)v; });
+    if (can_heads) sweep("row_heads", {0, 1}, [](StepTune& t, int v) { t.heads = (int8_t)v; });
+    sweep("write_through", {0, 1}, [](StepTune& t, int v) { t.write_through = (int8_t)v; });
+    if (can_split) sweep("split_rows", {0, 1}, [](StepTune& t, int v) { t.split = (int8_t)v; });
+    if (can_walk) sweep("alternating_walk", {0, 1}, [](StepTune& t, int v) { t.walk = (int8_t)v; });
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != LLE_OK) return rc;
+    b->tune = best;
+    std::snprintf(line, sizeof line, "%d launches per trial, %d trials", launches, n_trials);
+    b->tune_log = log + line;
+    // the trials were real steps: back to World.reset of every env, counters at zero
+    HIP_TRY(hipMemsetAsync(b->ptrs.stats, 0, (size_t)b->layout.n_stat_blocks * 64, st));
+    LaunchArgs K{};
+    return launch(b, KMODE_RESET, K, stream);
+}
+
+int lle_batch_tuning(const lle_batch* b, lle_tuning_info* out, char* log_buf, size_t cap) {
+    if (!b || !out) return fail(LLE_ERR_NULL, "NULL argument");
+    const bool pes = b->per_env_sources;
+    const MapHeader& h = b->hdr;
+    const uint64_t row_bytes = (uint64_t)b->n_envs * h.obs_stride;
+    const uint32_t epw = step_envs_per_wave(b->n_envs, (int)h.A, b->tune);
+    const uint32_t n_waves = (uint32_t)((b->n_envs + epw - 1) / epw);
+    out->envs_per_wave = (int32_t)epw;
+    out->split_rows = step_splits_rows(h, pes, b->tune) ? 1 : 0;
+    out->write_through = write_through_pays(row_bytes, h.obs_stride, b->tune.write_through) ? 1 : 0;
+    out->alternating_walk = pingpong_pays(b, row_bytes) ? 1 : 0;
+    // (what a plain single step of this batch gets: the same conditions as launch_step_kernel)
+    const bool general = pes || b->envs_per_map != 0;
+    StepTune t = b->tune;
+    int heads = 0;
+    if (step_has_row_heads(h, pes) && !out->split_rows) {
+        const int forced = tuning().row_heads >= 0 ? tuning().row_heads : (int)t.heads;
+        heads = forced >= 0 ? forced : ((general ? n_waves >= 2048u : (n_waves >= 2048u && n_waves <= 12288u)) ? 1 : 0);
+    }
+    out->row_heads = heads;
+    out->autotuned = b->tune_log.empty() ? 0 : 1;
+    if (log_buf && cap) std::snprintf(log_buf, cap, "%s", b->tune_log.c_str());
     g_status = LLE_OK;
     return LLE_OK;
 }

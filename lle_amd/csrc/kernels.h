@@ -29,6 +29,33 @@ struct LdsGrant {
     }
 };
 
+// ---- tuning overrides.  The LLE_* environment variables of DESIGN.md section 7 are read ONCE per process into this snapshot
+// (first use) -- never on the launch path; lle_tuning_refresh() reads them again (the parity tests and the tuning tools change
+// them mid-process).  -1 / 0 = not set.
+struct Tuning {
+    int step_wpw = 0;          // LLE_STEP_WPW = 1 / 2 / 4
+    int step_split = -1;       // LLE_STEP_SPLIT = 0 / 1
+    int write_through = -1;    // LLE_WRITE_THROUGH = 0 / 1
+    int row_heads = -1;        // LLE_ROW_HEADS = 0 / 1
+    int step_epw = 0;          // LLE_STEP_EPW = power of two
+    int pingpong = -1;         // LLE_PINGPONG = 0 / 1
+    int partial_project = -1;  // LLE_PARTIAL_PROJECT = 0 / 1
+    int partial_kernel = 0;    // LLE_PARTIAL_KERNEL: 0 unset, 1 "lanes", 2 "window", 3 "project", 4 anything else ("auto")
+    int partial_e = 0, partial_batches = 0, partial_wt = -1, partial_epw = 0;  // LLE_PARTIAL_E / _BATCHES / _WT / _EPW
+};
+const Tuning& tuning();
+void tuning_refresh();
+
+// What a batch has chosen for its own step launches (lle_batch_autotune times the alternatives on the batch's own arena; -1 / 0 =
+// the launcher's default rule).  An environment override (Tuning) wins over a batch's choice, a batch's choice over the rule.
+struct StepTune {
+    int8_t heads = -1;          // row heads ahead of the state machine (MODE 6 / 7 / 8)
+    int8_t write_through = -1;  // `sc1` stores of the rows
+    int8_t split = -1;          // split rows (big observations)
+    int8_t walk = -1;           // alternating walk of outputs larger than the Infinity Cache
+    uint8_t epw = 0;            // environments per wavefront
+};
+
 enum { KMODE_STEP = 0, KMODE_RESET = 1, KMODE_SET_STATE = 2, KMODE_OBSERVE = 3, KMODE_SOURCES = 4, KMODE_ENV_SOURCES = 5 };
 constexpr uint32_t MIN_ENVS_PER_WAVE = 4;  // step_kernel<16, .>: 4 environments per wavefront
 
@@ -37,7 +64,8 @@ int agent_stride(int A, int L);  // agents per env record in the per-agent buffe
 const char* kernel_variant_name(int variant);
 uint32_t kernel_lds_bytes(const MapHeader& h, uint32_t waves_per_wg, bool pes = false);
 uint32_t kernel_waves_per_wg(const MapHeader& h, bool pes = false);
-bool step_splits_rows(const MapHeader& h, bool pes);                      // step_kernel: rows split over the workgroup's wavefronts
+bool step_splits_rows(const MapHeader& h, bool pes, const StepTune& tune = StepTune());  // step_kernel: rows split over the workgroup's wavefronts
+bool step_can_split_rows(const MapHeader& h, bool pes);                  // ... whether the instantiation carries it at all
 uint32_t split_lds_bytes(const MapHeader& h, uint32_t wpw, uint32_t epw);
 // step_kernel instantiations, one translation unit per MODE (step_mode<N>.hip; step_kernel.hpp)
 hipError_t launch_step_mode0(int G, int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream);
@@ -49,12 +77,13 @@ hipError_t launch_step_mode5(int G, int lm, const BatchPtrs& P, const LaunchArgs
 hipError_t launch_step_mode6(int G, int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream);
 hipError_t launch_step_mode7(int G, int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream);
 hipError_t launch_step_mode8(int G, int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream);
-bool write_through_pays(uint64_t bytes, uint32_t row_pitch);  // store policy of an observation stream (obs_stream.hpp: stream_store)
+bool write_through_pays(uint64_t bytes, uint32_t row_pitch, int chosen = -1);  // store policy of an observation stream (obs_stream.hpp: stream_store)
 hipError_t launch_world_kernel(int mode, const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K, hipStream_t stream);
 // World.step with one lane per agent (the default step path)
-hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K, hipStream_t stream);
+hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K, hipStream_t stream, const StepTune& tune = StepTune());
+bool step_has_row_heads(const MapHeader& h, bool pes);  // whether a single-step launch of this map can take the MODE 6 / 7 / 8 kernels
 int step_group(int A);
-uint32_t step_envs_per_wave(int64_t n, int A);
+uint32_t step_envs_per_wave(int64_t n, int A, const StepTune& tune = StepTune());
 int step_lm(int L);
 
 // observers.hip

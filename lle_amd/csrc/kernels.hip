@@ -17,6 +17,8 @@
 // No MFMA: there is no contraction anywhere on this path.
 #include "kernel_common.hpp"
 
+#include <string.h>
+
 namespace lle {
 
 template <int AM, int LM, int MODE>
@@ -436,6 +438,40 @@ static hipError_t launch_mode(int mode, const BatchPtrs& P, const LaunchArgs& K,
     return hipGetLastError();
 }
 
+// ---- the environment overrides, read once (kernels.h Tuning)
+static Tuning g_tuning;
+static std::atomic<bool> g_tuning_loaded{false};
+static int env_bool(const char* name) {
+    const char* o = getenv(name);
+    return (o && (o[0] == '0' || o[0] == '1') && !o[1]) ? o[0] - '0' : -1;
+}
+static int env_uint(const char* name) {
+    const char* o = getenv(name);
+    const int v = o ? atoi(o) : 0;
+    return v > 0 ? v : 0;
+}
+void tuning_refresh() {
+    Tuning t;
+    t.step_wpw = env_uint("LLE_STEP_WPW");
+    t.step_split = env_bool("LLE_STEP_SPLIT");
+    t.write_through = env_bool("LLE_WRITE_THROUGH");
+    t.row_heads = env_bool("LLE_ROW_HEADS");
+    t.step_epw = env_uint("LLE_STEP_EPW");
+    t.pingpong = env_bool("LLE_PINGPONG");
+    t.partial_project = env_bool("LLE_PARTIAL_PROJECT");
+    if (const char* w = getenv("LLE_PARTIAL_KERNEL")) t.partial_kernel = !strcmp(w, "lanes") ? 1 : (!strcmp(w, "window") ? 2 : (!strcmp(w, "project") ? 3 : 4));
+    t.partial_e = env_uint("LLE_PARTIAL_E");
+    t.partial_batches = env_uint("LLE_PARTIAL_BATCHES");
+    if (const char* o = getenv("LLE_PARTIAL_WT")) t.partial_wt = o[0] == '1' ? 1 : 0;
+    t.partial_epw = env_uint("LLE_PARTIAL_EPW");
+    g_tuning = t;
+    g_tuning_loaded.store(true, std::memory_order_release);
+}
+const Tuning& tuning() {
+    if (!g_tuning_loaded.load(std::memory_order_acquire)) tuning_refresh();
+    return g_tuning;
+}
+
 int kernel_variant(int A, int L) {
     if (A <= 4 && L <= 4) return 0;
     if (A <= 8 && L <= 8) return 1;
@@ -464,8 +500,7 @@ uint32_t kernel_lds_bytes(const MapHeader& h, uint32_t waves_per_wg, bool pes) {
 // workgroups per CU: config 5 (33 KB of tables, 20 KB rows) 4 -> 274 us per step, 2 -> 350, 1 -> 377 (LLE_STEP_WPW)
 constexpr uint32_t LDS_PER_CU = 160 * 1024;
 uint32_t kernel_waves_per_wg(const MapHeader& h, bool pes) {
-    if (const char* o = getenv("LLE_STEP_WPW")) {  // tuning override
-        const uint32_t v = (uint32_t)atoi(o);
+    if (const uint32_t v = (uint32_t)tuning().step_wpw) {  // LLE_STEP_WPW: tuning override
         if ((v == 1 || v == 2 || v == 4) && kernel_lds_bytes(h, v, pes) <= LDS_PER_CU) return v;
     }
     for (uint32_t w = 4; w > 1; w >>= 1)
@@ -477,11 +512,11 @@ uint32_t kernel_waves_per_wg(const MapHeader& h, bool pes) {
 // 5: 33 KB of tables + 4 x 20.5 KB = 135 KB), every wavefront keeps one slice of the row instead and streams that slice
 // of every environment of the workgroup: tables without the pristine row (13 KB) + the row once (20 KB) + records
 // = 36 KB, four workgroups per CU.  LLE_STEP_SPLIT=0 / 1 forces it (tuning aid; 1 only where the kernels carry it).
-bool step_splits_rows(const MapHeader& h, bool pes) {
-    if (pes || step_group((int)h.A) < 8) return false;
-    if (const char* o = getenv("LLE_STEP_SPLIT")) {
-        if ((o[0] == '0' || o[0] == '1') && !o[1]) return o[0] == '1';
-    }
+bool step_can_split_rows(const MapHeader& h, bool pes) { return !pes && step_group((int)h.A) >= 8; }
+bool step_splits_rows(const MapHeader& h, bool pes, const StepTune& tune) {
+    if (!step_can_split_rows(h, pes)) return false;
+    if (tuning().step_split >= 0) return tuning().step_split == 1;
+    if (tune.split >= 0) return tune.split == 1;
     return kernel_lds_bytes(h, 4, false) > LDS_PER_CU / 2;
 }
 uint32_t split_lds_bytes(const MapHeader& h, uint32_t wpw, uint32_t epw) {
@@ -495,9 +530,9 @@ uint32_t split_lds_bytes(const MapHeader& h, uint32_t wpw, uint32_t epw) {
 // and whole: `sc1` then wins at every size (level 6 at 1 920 B: 262 144 envs 99.7 us vs 107.7 plain; 65 536 envs 21.2 vs
 // 23.3).  Packed rows (1 872 B) share lines between neighbours; past the Infinity Cache a shared line written through
 // goes to HBM twice as partial writes (262 144 envs: 163 us vs 98-105 plain), so there the policy follows the size.
-bool write_through_pays(uint64_t bytes, uint32_t row_pitch) {
-    const char* o = getenv("LLE_WRITE_THROUGH");  // read per launch: the parity tests run both policies in one process
-    if (o && (o[0] == '0' || o[0] == '1') && !o[1]) return o[0] == '1';
+bool write_through_pays(uint64_t bytes, uint32_t row_pitch, int chosen) {
+    if (tuning().write_through >= 0) return tuning().write_through == 1;
+    if (chosen >= 0) return chosen == 1;  // (a batch's own choice: lle_batch_autotune)
     return row_pitch % 128u == 0 || bytes <= WRITE_THROUGH_MAX_BYTES;
 }
 
@@ -505,10 +540,10 @@ bool write_through_pays(uint64_t bytes, uint32_t row_pitch) {
 // one or two rounds of workgroups -- every wavefront then runs its state machine at the same time with the memory system
 // idle.  Measured on level 6 with a 3-line head: 32 768 envs (2 048 wavefronts) 13.3 -> 12.4 us, 65 536 21.4 -> 19.8,
 // 131 072 36.7 -> 35.1; a small launch (16 384 envs: 9.4 -> 9.7) or many rounds (262 144: 98.9 -> 100.1) lose a little.
-// LLE_ROW_HEADS=0 / 1 forces it (read per launch: the parity tests run both in one process).
-static bool row_heads_pay(uint32_t n_waves, bool general) {
-    const char* o = getenv("LLE_ROW_HEADS");
-    if (o && (o[0] == '0' || o[0] == '1') && !o[1]) return o[0] == '1';
+// LLE_ROW_HEADS=0 / 1 forces it; a batch's own measurement (lle_batch_autotune: StepTune.heads) comes next; these are the defaults.
+static bool row_heads_pay(uint32_t n_waves, bool general, int chosen) {
+    if (tuning().row_heads >= 0) return tuning().row_heads == 1;
+    if (chosen >= 0) return chosen == 1;
     // The general instantiations (several maps / fused LLE.step outputs: MODE 7 against 4; per-env sources: MODE 8 against 5) win
     // with the heads at every size from 2 048 wavefronts up -- they are also the ones with every load up front and, for MODE 8,
     // without the spills of MODE 5.  Level 6, us per step without / with (round 3, one box): per-env sources 8 192 envs 9.7 / 8.8,
@@ -546,24 +581,26 @@ int step_lm(int L) { return L <= 4 ? 4 : (L <= 8 ? 8 : (L <= 16 ? 16 : 32)); }
 
 // environments per wavefront of the step kernel for a batch of n: as many as fit (64 / G) once that still leaves
 // ~4096 wavefronts (16 per CU), fewer (down to 4) for small batches
-uint32_t step_envs_per_wave(int64_t n, int A) {
+uint32_t step_envs_per_wave(int64_t n, int A, const StepTune& tune) {
     uint32_t e = 64u / (uint32_t)step_group(A);
-    if (const char* o = getenv("LLE_STEP_EPW")) {  // tuning override
-        const uint32_t v = (uint32_t)atoi(o);
+    for (const uint32_t v : {(uint32_t)tuning().step_epw, (uint32_t)tune.epw})  // LLE_STEP_EPW, then the batch's own choice
         if (v >= 1 && v <= e && !(v & (v - 1))) return v;
-    }
     while (e > 4 && n / e < 4096) e >>= 1;  // measured on level 1: 4 beats 1-2 even at n = 4096
     return e;
 }
 
-hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K_in, hipStream_t stream) {
+bool step_has_row_heads(const MapHeader& h, bool pes) {
+    return step_lm((int)h.L) <= 8 && (pes ? h.pes_head_n : h.head_n) != 0;
+}
+
+hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K_in, hipStream_t stream, const StepTune& tune) {
     LaunchArgs K = K_in;
     const int G = step_group((int)h.A), lm = step_lm((int)h.L);
     const bool pes = (K.flags & LAUNCH_PER_ENV_SOURCES) != 0;
     K.n_sources = h.L;
     {   // a ring keeps the rows of min(n_steps, ring_slots) steps; without one every step overwrites the same rows
         const uint64_t slots = K.ring_slots ? (K.n_steps < K.ring_slots ? (K.n_steps ? K.n_steps : 1u) : K.ring_slots) : 1u;
-        if (write_through_pays((uint64_t)(K.env_limit - K.env_base) * h.obs_stride * slots, h.obs_stride)) K.flags |= LAUNCH_WRITE_THROUGH;
+        if (write_through_pays((uint64_t)(K.env_limit - K.env_base) * h.obs_stride * slots, h.obs_stride, tune.write_through)) K.flags |= LAUNCH_WRITE_THROUGH;
     }
     if (pes || K.envs_per_map || K.env_out) K.flags |= LAUNCH_GENERAL;  // (fused LLE.step outputs: MODE 4 / 5 carry the epilogue)
     if (K.env_out && (K.n_steps > 1 || K.ring_slots || K.stamps)) return hipErrorInvalidValue;  // single steps only
@@ -579,7 +616,7 @@ hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const Laun
     const uint32_t epw = K.envs_per_wave;
     const uint32_t n_waves = (uint32_t)((K.env_limit - K.env_base + epw - 1) / epw);
     uint32_t lds = kernel_lds_bytes(h, wpw, pes);
-    if (step_splits_rows(h, pes)) {
+    if (step_splits_rows(h, pes, tune)) {
         const uint32_t cap = 64u / (uint32_t)G, e = epw < cap ? epw : cap;
         wpw = 4;
         if (K.envs_per_map)
@@ -593,13 +630,13 @@ hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const Laun
     if (pes) {
         if (roll) return launch_step_mode3(G, lm, P, K, n_waves, wpw, lds, stream);
         // single steps: the colour-independent head lines ahead of the state machine (MODE 8) under the same conditions as below
-        const bool heads_pes = lm <= 8 && h.pes_head_n != 0 && !(K.flags & (LAUNCH_SPLIT_ROWS | STEP_NO_OBS)) && row_heads_pay(n_waves, true);
+        const bool heads_pes = lm <= 8 && h.pes_head_n != 0 && !(K.flags & (LAUNCH_SPLIT_ROWS | STEP_NO_OBS)) && row_heads_pay(n_waves, true, tune.heads);
         return heads_pes ? launch_step_mode8(G, lm, P, K, n_waves, wpw, lds, stream) : launch_step_mode5(G, lm, P, K, n_waves, wpw, lds, stream);
     }
     // single-step launches with the map's sources: the rows' head lines go out ahead of the state machine (MODE 6 / 7) when
     // the map has a head, the rows are not split and the launch is of the size where it pays
     const bool heads = !roll && lm <= 8 && h.head_n != 0 && !(K.flags & (LAUNCH_SPLIT_ROWS | STEP_NO_OBS)) &&
-                       row_heads_pay(n_waves, (K.flags & LAUNCH_GENERAL) != 0);
+                       row_heads_pay(n_waves, (K.flags & LAUNCH_GENERAL) != 0, tune.heads);
     if (K.flags & LAUNCH_GENERAL) {
         if (roll) return launch_step_mode2(G, lm, P, K, n_waves, wpw, lds, stream);
         return heads ? launch_step_mode7(G, lm, P, K, n_waves, wpw, lds, stream) : launch_step_mode4(G, lm, P, K, n_waves, wpw, lds, stream);

@@ -776,9 +776,7 @@ uint32_t partial_pitch(int A, int k) { return ((uint32_t)(A * (2 * A + 3) * k * 
 // 72 / 200 / 392 cells) 46 / 166, 102 / 170, 168 / 193: about 0.07 us per pair against 0.13-0.3 us per window cell, with
 // the projection's table build on top.  LLE_PARTIAL_PROJECT=0 / 1 forces it (tests, tuning).
 static bool partial_projects(const MapHeader& h, int k, uint32_t n_entities) {
-    if (const char* o = getenv("LLE_PARTIAL_PROJECT")) {
-        if ((o[0] == '0' || o[0] == '1') && !o[1]) return o[0] == '1';
-    }
+    if (tuning().partial_project >= 0) return tuning().partial_project == 1;
     const uint32_t a_pad = h.A <= 1 ? 1u : (h.A <= 2 ? 2u : (h.A <= 4 ? 4u : (h.A <= 8 ? 8u : 16u)));
     const uint64_t pairs = (uint64_t)(n_entities + h.A) * a_pad, cells = (uint64_t)h.A * (uint32_t)(k * k);
     return pairs <= cells * 3u / 2u + 80u;
@@ -790,9 +788,9 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
     const uint32_t pitch_l = partial_pitch((int)h.A, k);
     int force_old = -1;  // LLE_PARTIAL_KERNEL=window / project: one of the two round-1/2 kernels (kept as cross-checks)
     {   // ---- the lane-per-(env, observer) kernel (partial_lanes_kernel): every map and window size
-        const char* which = getenv("LLE_PARTIAL_KERNEL");  // "lanes" (default) | "window" | "project" | "auto" (the round-2 choice)
-        const bool old_forced = getenv("LLE_PARTIAL_PROJECT") != nullptr;
-        if (!old_forced && (!which || !strcmp(which, "lanes"))) {
+        const int which = tuning().partial_kernel;  // LLE_PARTIAL_KERNEL: "lanes" (default) | "window" | "project" | "auto" (the round-2 choice)
+        const bool old_forced = tuning().partial_project >= 0;
+        if (!old_forced && (which == 0 || which == 1)) {
             const uint32_t a_pad = h.A <= 1 ? 1u : (h.A <= 2 ? 2u : (h.A <= 4 ? 4u : (h.A <= 8 ? 8u : 16u)));
             // S = 64 / (E * a_pad) lanes share an observer's rows; a lane's rows must fit its 64-bit set: 8 rows (k <= 8), else 4
             const uint32_t s_min = k <= 8 ? 1u : ((uint32_t)k + 3u) / 4u;
@@ -809,8 +807,7 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
                 const uint32_t S2 = 64u / ((E / 2u) * a_pad), rl = ((uint32_t)k + S2 - 1u) / S2;
                 if (S2 <= (uint32_t)k && 4u * (uint32_t)k >= 3u * S2 * rl) E >>= 1;
             }
-            if (const char* o = getenv("LLE_PARTIAL_E")) {
-                const uint32_t v = (uint32_t)atoi(o);
+            if (const uint32_t v = (uint32_t)tuning().partial_e) {
                 if (v >= 1 && v <= e_max && !(v & (v - 1))) E = v;
             }
             const uint32_t As_l = (uint32_t)agent_stride_of((int)h.A, (int)h.L);
@@ -822,8 +819,7 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
             // be ONE round of workgroups (about four per CU): 65 536 envs -> 16 environments per wavefront, i.e. batches = 16 / E
             uint32_t batches = 1;
             while (batches < 16 && (int64_t)E * batches * 2 * 4096 <= n_envs) batches *= 2;
-            if (const char* o = getenv("LLE_PARTIAL_BATCHES")) {
-                const uint32_t v = (uint32_t)atoi(o);
+            if (const uint32_t v = (uint32_t)tuning().partial_batches) {
                 if (v >= 1 && v <= 64) batches = v;
             }
             uint32_t wpw = 4;
@@ -842,23 +838,22 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
                 // written through (`sc1`): the batch's rows are one contiguous block, so lines are shared only at its two ends;
                 // measured better at every size incl. 489 MB (32x32 7x7: 114 -> 99 us).  LLE_PARTIAL_WT=0 / 1: tuning override
                 int wt = 1;
-                if (const char* o = getenv("LLE_PARTIAL_WT")) wt = o[0] == '1';
+                if (tuning().partial_wt >= 0) wt = tuning().partial_wt;
                 const PartialDims D{(int32_t)h.A, (int32_t)h.L, (int32_t)h.H, (int32_t)h.W, h.off_cell_meta - h.off_cell_lay, h.max_layers};
                 hipLaunchKernelGGL(partial_lanes_kernel, dim3((n_waves + wpw - 1) / wpw), dim3(64 * wpw), lds, stream, P, out, k, pitch_l,
                                    (int64_t)0, n_envs, per_env_sources ? 1 : 0, M, E, batches, tab, wt, D, h.off_cell_lay, walk);
                 return hipGetLastError();
             }
         }
-        if (which && !strcmp(which, "window")) force_old = 0;
-        if (which && !strcmp(which, "project")) force_old = 1;
+        if (which == 2) force_old = 0;
+        if (which == 3) force_old = 1;
     }
 
     const uint32_t pitch = partial_pitch((int)h.A, k);
     const uint32_t As = (uint32_t)agent_stride_of((int)h.A, (int)h.L);
     if (force_old == 1 || (force_old < 0 && partial_projects(h, k, n_entities))) {
         uint32_t epw = 16;  // level 6 7x7: 4 -> 36.8 us, 8 -> 30.2, 16 -> 28.7 (table build and static decode are per wavefront)
-        if (const char* o = getenv("LLE_PARTIAL_EPW")) {
-            const uint32_t v = (uint32_t)atoi(o);
+        if (const uint32_t v = (uint32_t)tuning().partial_epw) {
             if (v >= 1 && v <= OBS_ENVS_PER_WAVE && !(v & (v - 1))) epw = v;
         }
         const uint32_t ent_cap = n_entities;  // an upper bound computed by the host from the map(s)
@@ -880,8 +875,7 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
     // waves in flight; measured at 65 536 envs, level 6 7x7: 16 -> 58 us, 8 -> 46, 4 -> 45, 2 -> 48; 32x32 maps (21 KB of
     // tables per workgroup) 7x7: 166 / 172 / 185 / 209 us, 3x3: 54 / 48 / 52 / 63.  LLE_PARTIAL_EPW: tuning override.
     uint32_t epw = 8;
-    if (const char* o = getenv("LLE_PARTIAL_EPW")) {
-        const uint32_t v = (uint32_t)atoi(o);
+    if (const uint32_t v = (uint32_t)tuning().partial_epw) {
         if (v >= 1 && v <= OBS_ENVS_PER_WAVE && !(v & (v - 1))) epw = v;
     }
     const uint32_t priv = pitch + ((epw * (As / 2 + 1 + h.L) * 4u + 15u) & ~15u) + (((h.HW + 1u) / 2u * 4u + 15u) & ~15u);

@@ -48,6 +48,10 @@ def test_parent_spawns_n_ranks_and_prints_one_line(world):
     assert abs(reg["wall_ms_per_step_without_closing_barrier_max_over_ranks"] - 0.9 * world / 20 * 1e3) < 1e-6
     assert abs(reg["agent_steps_per_s_by_slowest_rank_events"] - 4 * 65536 * world / (0.02e-3 * world)) < 1.0
     assert abs(reg["sustained_kernel_ms_max_over_ranks"] - 0.019 * world) < 1e-9
+    # the shard check's plumbing: one 64-bit hash per rank all-gathered, rank 0 recomputed every window with its env_offset
+    chk = out["shard_check"]
+    assert chk["status"] == "ok" and chk["ranks"] == world and chk["mismatching_ranks"] == []
+    assert len(chk["hashes"]) == world and chk["distinct_windows"] == world
 
 
 def test_scaling_block_and_gpu_count_helpers():
@@ -106,6 +110,7 @@ def test_one_rank_through_the_launcher_and_rccl():
     assert out["rollout_stats"]["env_steps"] == 65536 * steps
     assert out["rollout_stats"]["agent_steps"] == 4 * 65536 * steps
     assert out["roofline"]["bound"] == "infinity-cache-absorbed" and 0.0 < out["roofline"]["frac"] < 1.0
+    assert out["shard_check"]["status"] == "ok" and out["shard_check"]["ranks"] == 1
 
 
 @pytest.mark.gpu
@@ -154,3 +159,8 @@ def test_two_rank_code_path_rehearsed_on_one_gpu():
     assert out["region"]["kernel_ms_max_over_ranks"] >= out["region"]["kernel_ms_min_over_ranks"] > 0
     assert out["sustained"]["steps"] == 40 and out["fused_rollout"]["steps_per_launch"] == 4
     assert "cpu_baseline" not in out and "configs" not in out  # N = 1 only
+    # shard invariance across the two ranks: rank 1's window (env_offset 65 536) hashed by rank 1 and recomputed by rank 0
+    chk = out["shard_check"]
+    assert chk["status"] == "ok" and chk["ranks"] == 2 and chk["distinct_windows"] == 2 and len(set(chk["hashes"])) == 2
+    assert out["tuning"]["autotuned"] == 1 and out["host_issue_us_per_step"] > 0
+    assert out["region"]["wall_ms_per_step_max_over_ranks"] >= out["region"]["wall_ms_per_step_without_closing_barrier_max_over_ranks"] > 0

@@ -57,3 +57,39 @@ def test_two_ranks_reproduce_one_big_batch(tmp_path):
         assert np.array_equal(p["total"], whole.buf("stats"))
         assert float(p["slowest"]) == 2.0
     assert [shard_range(10, r, 3) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
+
+
+def _check_worker(rank, world, port, out_dir, broken_rank):
+    import json
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lle_amd.distributed import shard_check, tensor_hash
+
+    def window_hash(env_offset):
+        # the checksum of a real window: 16 envs of the host build of the device logic stepped from env_offset
+        sb = _rollout(LEVELS[6], 16, env_offset)
+        h = 0
+        for key in ("pos", "bits", "obs"):
+            h = (h * 1099511628211 + tensor_hash(torch.from_numpy(np.ascontiguousarray(sb.buf(key))))) & (2**64 - 1)
+        # a rank whose shard diverged (here: forced) must show up as a mismatch on rank 0, which recomputes every window itself
+        return h ^ 1 if rank == broken_rank and env_offset != 0 else h
+    res = shard_check(window_hash, N_PER_RANK, rank, world, torch.device("cpu"))
+    with open(os.path.join(out_dir, f"check{rank}.json"), "w") as f:
+        json.dump(res, f)
+    dist.destroy_process_group()
+
+
+def test_shard_check_over_the_collective(tmp_path):
+    """bench.py's first-SCALE-run evidence (lle_amd.distributed.shard_check): every rank hashes the window at the head of its
+    shard, the hashes are all-gathered, rank 0 recomputes all windows with the matching env_offset.  Two gloo ranks agree; a rank
+    that diverges is named."""
+    import json
+
+    for broken, want in ((-1, ("ok", [])), (1, ("fail", [1]))):
+        d = tmp_path / f"b{broken}"
+        d.mkdir()
+        mp.spawn(_check_worker, args=(2, _free_port(), str(d), broken), nprocs=2, join=True)
+        r0, r1 = (json.load(open(d / f"check{r}.json")) for r in range(2))
+        assert r1 == {"status": "n/a"}
+        assert (r0["status"], r0["mismatching_ranks"]) == want and r0["ranks"] == 2 and r0["distinct_windows"] == 2

@@ -611,3 +611,34 @@ def test_fused_rollout_with_a_caller_provided_action_ring(oracle_mod, name):
     before = bw.pos.clone()
     bw.rollout(3, auto_reset=False, sample=False)
     assert torch.equal(bw.pos, before) and int(bw.err.max()) == 0
+
+
+@pytest.mark.gpu
+def test_autotune_changes_rules_not_results(oracle_mod):
+    """lle_batch_autotune times the launcher's alternatives on the batch's own arena and keeps the fastest in the handle; the
+    LLE_* overrides are read once per process (lle_tuning_refresh re-reads them).  Whatever it chooses, the results are those of
+    an untuned batch and of the oracle; the batch ends reset with its counters at zero."""
+    from lle_amd import BatchedWorld, mapgen
+
+    for text, n in ((LEVELS[6], 4096 + 37), (mapgen.config5(3), 512)):
+        a, b = BatchedWorld(text, n), BatchedWorld(text, n)
+        before = a.tuning()
+        assert before["autotuned"] == 0 and before["log"] == ""
+        for t in range(3):  # (mid-episode state: autotune must end on the reset state whatever came before)
+            a.step(sample=True, auto_reset=True, seed=9, t=t)
+        tuned = a.autotune(budget_ms=5.0)
+        assert tuned["autotuned"] == 1 and "envs_per_wave:" in tuned["log"] and "write_through:" in tuned["log"]
+        assert tuned["envs_per_wave"] in (1, 2, 4, 8, 16, 32, 64) and a.kernel_info()["envs_per_wave"] == tuned["envs_per_wave"]
+        assert a.stats()["env_steps"] == 0
+        ob = oracle_mod.OracleBatch(text, n)
+        dims = (ob.A, ob.G, ob.Ls, ob.beam_stride, ob.C, ob.H, ob.W)
+        assert_state_equal(unpack_engine(a.host_buffers(), *dims), ob.dump(), "after autotune")
+        for t in range(12):
+            a.step(sample=True, auto_reset=True, seed=4, t=t)
+            b.step(sample=True, auto_reset=True, seed=4, t=t)
+            ostep = ob.step(None, auto_reset=True, seed=4, t=t)
+            ea, eb = unpack_engine(a.host_buffers(), *dims), unpack_engine(b.host_buffers(), *dims)
+            assert_step_equal(ea, ostep, f"tuned t={t}")
+            assert_state_equal(ea, ob.dump(), f"tuned t={t}")
+            assert_step_equal(eb, ostep, f"untuned t={t}")
+        assert a.stats() == b.stats()

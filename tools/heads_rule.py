@@ -20,8 +20,10 @@ for n in (8192, 16384, 32768, 65536, 131072, 196608, 262144, 524288):
             r = []
             for heads in ("0", "1", "0", "1"):
                 os.environ["LLE_ROW_HEADS"] = heads
+                __import__("lle_amd")._capi.refresh_tuning()  # (the library reads its overrides once per process)
                 r.append(timeit(lambda: bw.step(sample=True, auto_reset=True, seed=1, **kw), iters=60 if n > 65536 else 200, warm=10))
             os.environ.pop("LLE_ROW_HEADS")
+            __import__("lle_amd")._capi.refresh_tuning()
             row.append(f"{label}: heads0 {min(r[0], r[2]):6.2f} heads1 {min(r[1], r[3]):6.2f}")
         print(f"n={n:6d} pes={int(pes)}: " + " | ".join(row), flush=True)
         del bw, eo, st, rw, av

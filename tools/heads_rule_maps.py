@@ -23,8 +23,10 @@ for name, m in maps.items():
                 r = []
                 for heads in ("0", "1", "0", "1"):
                     os.environ["LLE_ROW_HEADS"] = heads
+                    __import__("lle_amd")._capi.refresh_tuning()  # (the library reads its overrides once per process)
                     r.append(timeit(lambda: bw.step(sample=True, auto_reset=True, seed=1, **kw), iters=40 if n > 65536 else 150, warm=10))
                 os.environ.pop("LLE_ROW_HEADS")
+                __import__("lle_amd")._capi.refresh_tuning()
                 auto = timeit(lambda: bw.step(sample=True, auto_reset=True, seed=1, **kw), iters=40 if n > 65536 else 150, warm=10)
                 row.append(f"{label}: {min(r[0], r[2]):7.2f} / {min(r[1], r[3]):7.2f} (auto {auto:7.2f})")
             print(f"{name:28s} n={n:6d} pes={int(pes)} head {m.row_head} {bw.kernel_info()['kernel']}: " + " | ".join(row), flush=True)

@@ -127,8 +127,10 @@ def cmd_hbm(args):
             for policy in args.policies.split(","):
                 if policy in ("0", "1"):
                     os.environ["LLE_WRITE_THROUGH"] = policy
+                    __import__("lle_amd")._capi.refresh_tuning()  # (the library reads its overrides once per process)
                 elif policy != "keep":  # "keep": whatever the caller's environment says
                     os.environ.pop("LLE_WRITE_THROUGH", None)
+                    __import__("lle_amd")._capi.refresh_tuning()
                 m = Map(mapgen.config5(0), row_align=align) if args.cfg5 else Map(level=args.level, row_align=align)
                 bw = BatchedWorld(m, n)
                 us = timeit(stepper(bw), iters=args.iters)
@@ -206,7 +208,9 @@ def cmd_partial(args):
             for env in variants:
                 for key in ("LLE_PARTIAL_KERNEL", "LLE_PARTIAL_E", "LLE_PARTIAL_BATCHES", "LLE_PARTIAL_WT"):
                     os.environ.pop(key, None)
+                    __import__("lle_amd")._capi.refresh_tuning()
                 os.environ.update(env)
+                _capi.refresh_tuning()
                 try:
                     us = timeit(lambda: bw.observe_as(_capi.LLE_OBS_PARTIAL, k, out=buf), iters=50, warm=5)
                 except RuntimeError as e:  # (a forced E the launcher cannot use falls back silently; a hard failure is reported)
@@ -383,6 +387,7 @@ def cmd_stamps(args):
 def cmd_heads(args):
     """Row heads (lle_map_set_head_lines): us per launch by head size, over maps and batch sizes (heads forced on)."""
     os.environ["LLE_ROW_HEADS"] = "1"
+    __import__("lle_amd")._capi.refresh_tuning()  # (the library reads its overrides once per process)
     cases = [("level 6", lambda: Map(level=6), [16384, 32768, 65536, 131072, 262144]), ("level 5", lambda: Map(level=5), [65536]),
              ("level 3", lambda: Map(level=3), [65536, 131072]),
              ("generated 16x16, 8 agents", lambda: Map(mapgen.generate(16, 16, 8, 4, 4, seed=1), row_align=128), [16384, 32768]),

@@ -14,6 +14,7 @@ def mk(pes):
     return bw
 for heads in ("1", "0"):
     os.environ["LLE_ROW_HEADS"] = heads
+    __import__("lle_amd")._capi.refresh_tuning()  # (the library reads its overrides once per process)
     for pes in (False, True):
         bw = mk(pes)
         st, rw, av = (torch.empty((n, 16), device="cuda"), torch.empty((n, 1), device="cuda"), torch.empty((n, 4, 5), dtype=torch.uint8, device="cuda"))

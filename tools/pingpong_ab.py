@@ -18,9 +18,11 @@ for label, mk, sizes in (("level 6", lambda: Map(level=6), (65536, 131072, 19660
         row = []
         for pp in ("0", "1", "0", "1"):
             os.environ["LLE_PINGPONG"] = pp
+            __import__("lle_amd")._capi.refresh_tuning()  # (the library reads its overrides once per process)
             row.append(f"{pp}: step {timeit(step, iters=60, warm=6):6.1f} fill {timeit(probe, iters=60, warm=6):6.1f}")
             bw.observe()
         os.environ.pop("LLE_PINGPONG", None)
+        __import__("lle_amd")._capi.refresh_tuning()
         auto = timeit(step, iters=60, warm=6)
         print(f"{label} n={n} ({m.obs_stride * n / 1e6:.0f} MB of rows): " + " | ".join(row)
               + f" | auto: step {auto:6.1f} us = {algo_bytes(m) * n / auto / 1e3:.0f} GB/s", flush=True)

@@ -10,8 +10,10 @@ def run(label, bw):
     row = []
     for pp in ("0", "1", "0", "1"):
         os.environ["LLE_PINGPONG"] = pp
+        __import__("lle_amd")._capi.refresh_tuning()  # (the library reads its overrides once per process)
         row.append(f"{pp}: {timeit(step, iters=40, warm=6):6.1f}")
     os.environ.pop("LLE_PINGPONG")
+    __import__("lle_amd")._capi.refresh_tuning()
     print(f"{label}: " + " | ".join(row) + f"  ({bw.kernel_info()})", flush=True)
 bw = BatchedWorld(Map(level=6), n)
 rng = np.random.default_rng(0)
@@ -25,4 +27,5 @@ env.reset()
 acts = torch.zeros(n, 4, dtype=torch.uint8, device="cuda") + 4
 for pp in ("0", "1", "0", "1"):
     os.environ["LLE_PINGPONG"] = pp
+    __import__("lle_amd")._capi.refresh_tuning()  # (the library reads its overrides once per process)
     print(f"BatchedLLE.step fused, randomize_lasers, 262144 envs, LLE_PINGPONG={pp}: {timeit(lambda: env.step(acts, auto_reset=True, fused=True), iters=40, warm=6):6.1f} us", flush=True)

@@ -18,6 +18,7 @@ for label, m, Es in (("level6", Map(level=6), (2, 4, 8, 16)), ("cfg5", Map(mapge
             row = []
             for E, B in itertools.product(Es, (1, 2, 4, 8)):
                 os.environ.update(LLE_PARTIAL_E=str(E), LLE_PARTIAL_BATCHES=str(B), LLE_PARTIAL_WT=wt)
+                __import__("lle_amd")._capi.refresh_tuning()  # (the library reads its overrides once per process)
                 us = timeit(lambda: bw.observe_as(_capi.LLE_OBS_PARTIAL, k, out=buf), iters=30, warm=3)
                 row.append(f"E{E}B{B}:{us:6.1f}")
             print(label, f"{k}x{k} wt={wt}", " ".join(row), flush=True)
