@@ -324,6 +324,8 @@ class Timer:
             fn()
         self.issue = time.perf_counter() - t0  # the host's own time: K calls issued, nothing waited for
         ev1.record()
+        while not ev1.query():  # spin until the last launch is done: the blocking synchronize below then returns at once
+            pass                # (left to itself it wakes up tens of microseconds late: a tenth of the driver's 20-step region)
         torch.cuda.synchronize(self.dev)
         wall = self.wall_open = time.perf_counter() - t0
         if self.use_dist:
@@ -460,9 +462,11 @@ def measure_consumer_loop(torch, timer, dev, steps):
         big = rows.numel() > INFINITY_CACHE_BYTES
         half = torch.empty(rows.shape, dtype=torch.float16, device=dev)
         step = stepper(bw)
+        read_rows, st = _capi.lib().lle_probe_read_rows, torch.cuda.current_stream(dev).cuda_stream
+        r_ptr, h_ptr, r_bytes = rows.data_ptr(), half.data_ptr(), rows.numel()
 
-        def reader():
-            half.copy_(rows)
+        def reader():  # (torch's own int8 -> fp16 copy_ runs at 0.5 TB/s of reads: a stand-in that slow would hide the step)
+            read_rows(r_ptr, h_ptr, r_bytes, st)
 
         def pair():
             step()
@@ -492,10 +496,14 @@ def measure_consumer_loop(torch, timer, dev, steps):
     half = torch.empty(ring["obs_rows"][0].shape, dtype=torch.float16, device=dev)
     state = {"t": 0}
 
+    read_rows, st = _capi.lib().lle_probe_read_rows, torch.cuda.current_stream(dev).cuda_stream
+    slots = [ring["obs_rows"][k].data_ptr() for k in range(2)]
+    h_ptr, r_bytes = half.data_ptr(), ring["obs_rows"][0].numel()
+
     def ring_pair():
         t = state["t"]
         bw.rollout(1, auto_reset=True, seed=SEED, ring=ring, ring_pos=t)
-        half.copy_(ring["obs_rows"][(t + 1) % 2])  # the slot written by the launch before this one
+        read_rows(slots[(t + 1) % 2], h_ptr, r_bytes, st)  # the slot written by the launch before this one
         state["t"] = t + 1
     for _ in range(8):
         ring_pair()

@@ -472,12 +472,18 @@ typedef struct lle_tuning_info {
     int32_t write_through;    /* 1: `sc1` stores of the observation rows */
     int32_t split_rows;       /* 1: every row split over the wavefronts of a workgroup (big observations) */
     int32_t alternating_walk; /* 1: successive launches walk the environments alternately up and down */
+    int32_t rotate_rows;      /* 1: every wavefront starts its stream at another one of its rows (whole-row streams only) */
     int32_t autotuned;        /* 1: lle_batch_autotune has run on this handle (else: the default rules) */
 } lle_tuning_info;
 int lle_batch_autotune(lle_batch* b, double budget_ms, void* stream);
 /* The rules a plain single step of this batch is launched with, and (log_buf, optional) the trial log of lle_batch_autotune. */
 int lle_batch_tuning(const lle_batch* b, lle_tuning_info* out, char* log_buf, size_t cap);
 void lle_tuning_refresh(void);
+
+/* Profiling aid: a consumer's first touch of an observation buffer -- `bytes` int8 values at rows_dev (any of the observation
+ * outputs, on the current device) converted to fp16 into out_f16_dev (2 x bytes), the way the first layer of a policy reads
+ * `obs` between two steps (python/lle/env/env.py:165-189).  bench.py's `consumer_loop` alternates it with the step. */
+int lle_probe_read_rows(const void* rows_dev, void* out_f16_dev, int64_t bytes, void* stream);
 
 /* Diagnostic knob: step with the one-environment-per-lane kernel at 8, 16, 32 or 64 environments per wavefront
  * instead of the default one-lane-per-agent step kernel (64 / G environments per wavefront). */

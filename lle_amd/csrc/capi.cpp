@@ -1123,7 +1123,16 @@ int lle_batch_probe_row_fill(lle_batch* b, uint32_t value, void* stream) {
     const uint32_t epw = b->lane_per_env_step ? b->envs_per_wave : step_envs_per_wave(b->n_envs, (int)b->hdr.A, b->tune);
     // the same alternation as the step launches it stands in for
     const bool reverse = next_walk_reversed(b, b->ptrs.obs, (uint64_t)b->n_envs * b->hdr.obs_stride);
-    HIP_TRY(launch_row_fill_probe(b->ptrs.obs, b->n_envs, b->hdr.obs_stride, epw, value, reverse, (hipStream_t)stream));
+    HIP_TRY(launch_row_fill_probe(b->ptrs.obs, b->n_envs, b->hdr.obs_stride, epw, value, reverse, rotate_rows_pays(b->tune), (hipStream_t)stream));
+    g_status = LLE_OK;
+    return LLE_OK;
+}
+
+int lle_probe_read_rows(const void* rows_dev, void* out_f16_dev, int64_t bytes, void* stream) {
+    if (!rows_dev || !out_f16_dev) return fail(LLE_ERR_NULL, "NULL argument");
+    if (bytes <= 0 || bytes % 16 != 0 || (reinterpret_cast<uintptr_t>(rows_dev) % 16) != 0 || (reinterpret_cast<uintptr_t>(out_f16_dev) % 16) != 0)
+        return fail(LLE_ERR_ARG, "bytes must be a positive multiple of 16 and both buffers 16-byte aligned");
+    HIP_TRY(launch_cast_rows(static_cast<const int8_t*>(rows_dev), out_f16_dev, bytes, (hipStream_t)stream));
     g_status = LLE_OK;
     return LLE_OK;
 }
@@ -1169,7 +1178,7 @@ int lle_batch_autotune(lle_batch* b, double budget_ms, void* stream) {
     std::vector<uint32_t> epws;
     for (uint32_t e = cap; e >= 1 && epws.size() < 3; e >>= 1) epws.push_back(e);
     const bool can_heads = step_has_row_heads(h, pes), can_split = step_can_split_rows(h, pes), can_walk = row_bytes > (256ull << 20);
-    const int n_trials = (int)epws.size() + (can_heads ? 2 : 0) + 2 + (can_split ? 2 : 0) + (can_walk ? 2 : 0);
+    const int n_trials = (int)epws.size() + (can_heads ? 2 : 0) + 2 + (can_split ? 2 : 0) + (can_walk ? 2 : 0) + 2;
     uint64_t t_idx = 1u << 20;
     StepTune best = b->tune;
     double probe_us = 0.0;
@@ -1204,6 +1213,7 @@ int lle_batch_autotune(lle_batch* b, double budget_ms, void* stream) {
     sweep("write_through", {0, 1}, [](StepTune& t, int v) { t.write_through = (int8_t)v; });
     if (can_split) sweep("split_rows", {0, 1}, [](StepTune& t, int v) { t.split = (int8_t)v; });
     if (can_walk) sweep("alternating_walk", {0, 1}, [](StepTune& t, int v) { t.walk = (int8_t)v; });
+    if (!can_split || !step_splits_rows(h, pes, best)) sweep("rotate_rows", {0, 1}, [](StepTune& t, int v) { t.rotate = (int8_t)v; });
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (rc != LLE_OK) return rc;
@@ -1227,6 +1237,7 @@ int lle_batch_tuning(const lle_batch* b, lle_tuning_info* out, char* log_buf, si
     out->split_rows = step_splits_rows(h, pes, b->tune) ? 1 : 0;
     out->write_through = write_through_pays(row_bytes, h.obs_stride, b->tune.write_through) ? 1 : 0;
     out->alternating_walk = pingpong_pays(b, row_bytes) ? 1 : 0;
+    out->rotate_rows = (!out->split_rows && rotate_rows_pays(b->tune)) ? 1 : 0;
     // (what a plain single step of this batch gets: the same conditions as launch_step_kernel)
     const bool general = pes || b->envs_per_map != 0;
     StepTune t = b->tune;

@@ -42,6 +42,7 @@ struct Tuning {
     int partial_project = -1;  // LLE_PARTIAL_PROJECT = 0 / 1
     int partial_kernel = 0;    // LLE_PARTIAL_KERNEL: 0 unset, 1 "lanes", 2 "window", 3 "project", 4 anything else ("auto")
     int partial_e = 0, partial_batches = 0, partial_wt = -1, partial_epw = 0;  // LLE_PARTIAL_E / _BATCHES / _WT / _EPW
+    int row_rotate = -1;       // LLE_ROW_ROTATE = 0 / 1
 };
 const Tuning& tuning();
 void tuning_refresh();
@@ -53,6 +54,7 @@ struct StepTune {
     int8_t write_through = -1;  // `sc1` stores of the rows
     int8_t split = -1;          // split rows (big observations)
     int8_t walk = -1;           // alternating walk of outputs larger than the Infinity Cache
+    int8_t rotate = -1;         // every wavefront starts its stream at another one of its rows
     uint8_t epw = 0;            // environments per wavefront
 };
 
@@ -99,7 +101,10 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
 hipError_t launch_state_observe(const MapHeader& h, const BatchPtrs& P, float* out, int normalize, int64_t n_envs, hipStream_t stream);
 hipError_t launch_env_outputs(const MapHeader& h, const BatchPtrs& P, const EnvOutputs& O, int64_t n_envs, MapSel M, hipStream_t stream);
 // ceiling probe: n_rows rows of row_bytes (a multiple of 16) filled with the step kernel's store pattern (observers.hip)
-hipError_t launch_row_fill_probe(int8_t* out, int64_t n_rows, uint32_t row_bytes, uint32_t rows_per_wave, uint32_t value, bool reverse, hipStream_t stream);
+hipError_t launch_row_fill_probe(int8_t* out, int64_t n_rows, uint32_t row_bytes, uint32_t rows_per_wave, uint32_t value, bool reverse, bool rotate,
+                                 hipStream_t stream);
+hipError_t launch_cast_rows(const int8_t* rows, void* out_f16, int64_t bytes, hipStream_t stream);  // bench.py's consumer stand-in (observers.hip)
+bool rotate_rows_pays(const StepTune& tune);  // LAUNCH_ROTATE_ROWS for this batch's step launches (obs_stream.hpp row_rotation)
 // out8[k] = sum over the n_blocks per-wavefront slots of stats[slot][k] (one workgroup; lle_batch_stats, lle_batch_stats_allreduce)
 hipError_t launch_stats_sum(const int64_t* stats, int64_t n_blocks, int64_t* out8, hipStream_t stream);
 hipError_t launch_avail(const MapHeader& h, const BatchPtrs& P, uint8_t* out, int walkable_lasers, int64_t n_envs, bool per_env_sources,

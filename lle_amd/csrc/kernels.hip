@@ -464,6 +464,7 @@ void tuning_refresh() {
     t.partial_batches = env_uint("LLE_PARTIAL_BATCHES");
     if (const char* o = getenv("LLE_PARTIAL_WT")) t.partial_wt = o[0] == '1' ? 1 : 0;
     t.partial_epw = env_uint("LLE_PARTIAL_EPW");
+    t.row_rotate = env_bool("LLE_ROW_ROTATE");
     g_tuning = t;
     g_tuning_loaded.store(true, std::memory_order_release);
 }
@@ -589,6 +590,14 @@ uint32_t step_envs_per_wave(int64_t n, int A, const StepTune& tune) {
     return e;
 }
 
+// Row rotation (obs_stream.hpp row_rotation): on by default -- it costs three scalar instructions per wavefront, gains 5 % where
+// the buffer's pages are contiguous and nothing elsewhere.  LLE_ROW_ROTATE=0 / 1 forces it; lle_batch_autotune measures it.
+bool rotate_rows_pays(const StepTune& tune) {
+    if (tuning().row_rotate >= 0) return tuning().row_rotate == 1;
+    if (tune.rotate >= 0) return tune.rotate == 1;
+    return true;
+}
+
 bool step_has_row_heads(const MapHeader& h, bool pes) {
     return step_lm((int)h.L) <= 8 && (pes ? h.pes_head_n : h.head_n) != 0;
 }
@@ -602,6 +611,7 @@ hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const Laun
         const uint64_t slots = K.ring_slots ? (K.n_steps < K.ring_slots ? (K.n_steps ? K.n_steps : 1u) : K.ring_slots) : 1u;
         if (write_through_pays((uint64_t)(K.env_limit - K.env_base) * h.obs_stride * slots, h.obs_stride, tune.write_through)) K.flags |= LAUNCH_WRITE_THROUGH;
     }
+    if (rotate_rows_pays(tune)) K.flags |= LAUNCH_ROTATE_ROWS;
     if (pes || K.envs_per_map || K.env_out) K.flags |= LAUNCH_GENERAL;  // (fused LLE.step outputs: MODE 4 / 5 carry the epilogue)
     if (K.env_out && (K.n_steps > 1 || K.ring_slots || K.stamps)) return hipErrorInvalidValue;  // single steps only
     if (K.n_steps > 1 || K.ring_slots || K.stamps) K.flags |= LAUNCH_ROLLOUT;

@@ -41,6 +41,23 @@ __device__ __forceinline__ uint32_t xcd_block_dir(uint32_t b, uint32_t n_blocks,
     return (flags & LAUNCH_REVERSE) ? n_blocks - 1u - blk : blk;
 }
 
+// ... and in which order a WAVEFRONT walks its own rows (round 4, tools/ceiling/alloc_probe3.hip).  Every wavefront owns E consecutive
+// rows and writes them in turn; with all of them starting at their row 0, the addresses that the thousands of resident wavefronts
+// write at the same moment are a regular lattice with stride E rows (level 6: 16 x 1 920 B = 240 cache lines, a multiple of 16), and
+// on buffers whose physical pages are contiguous -- hipDeviceMallocContiguous, and most of what hipMalloc hands out on some boxes --
+// that lattice loads the memory channels unevenly: 5.75-5.9 TB/s where a memset reaches 6.6.  Starting wavefront w at its row
+// (w mod E) makes the stride E + 1 rows (255 lines: odd): 6.05-6.25 TB/s on the same buffers, nothing lost on the others (a random
+// start row does NOT help; rows per wavefront 4 / 2 / 1 reach 6.05 / 6.15 / 6.45 but cost a state machine per fewer environments).
+// LAUNCH_ROTATE_ROWS; results do not depend on it.
+__device__ __forceinline__ uint32_t row_rotation(uint32_t wave_id, uint32_t rows_per_wave, int64_t n_here, uint32_t flags) {
+    const uint32_t r = wave_id & (rows_per_wave - 1u);  // (rows_per_wave is a power of two)
+    return ((flags & LAUNCH_ROTATE_ROWS) && (int64_t)r < n_here && n_here == (int64_t)rows_per_wave) ? r : 0u;
+}
+__device__ __forceinline__ uint32_t rotated(uint32_t k, uint32_t rot, uint32_t n) {
+    const uint32_t kk = k + rot;
+    return kk >= n ? kk - n : kk;
+}
+
 // ---- static tables -> LDS, once per workgroup (section offsets are those of the blob).  The section is a whole
 // number of 1 KiB rows; every thread requests all of its rows (up to four) before the first LDS write.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -158,10 +175,10 @@ __device__ __forceinline__ void stream_row_tail(uint4* __restrict__ dst, const u
 // touch need not wait for the state machine -- the memory system starts ~2 us earlier (tools/ceiling/head_probe.hip).
 template <bool WT>
 __device__ __forceinline__ void store_heads(int8_t* __restrict__ obs, uint64_t obs_stride, int64_t env0, int64_t n_here, uint32_t head_lo,
-                                            uint32_t head_n, const uint4& v, uint32_t lane) {
+                                            uint32_t head_n, const uint4& v, uint32_t lane, uint32_t rot = 0) {
     if (lane < head_n)
-        for (int64_t k = 0; k < n_here; k++)
-            stream_store<WT>(reinterpret_cast<uint4*>(obs + (uint64_t)(env0 + k) * obs_stride) + head_lo + lane, v);
+        for (uint32_t k = 0; k < (uint32_t)n_here; k++)
+            stream_store<WT>(reinterpret_cast<uint4*>(obs + (uint64_t)(env0 + rotated(k, rot, (uint32_t)n_here)) * obs_stride) + head_lo + lane, v);
 }
 
 // ---- phase 2: layered observation of the wave's environments, one environment at a time.
@@ -172,7 +189,7 @@ template <bool WT, bool HEAD = false>
 __device__ __forceinline__ void write_observations(int A, int L, uint32_t D, uint32_t n_chunks, uint64_t obs_stride,
                                                    const uint64_t* dyn, int8_t* tmpl, const uint32_t* scratch,
                                                    uint32_t scr_stride, int8_t* __restrict__ obs, int64_t env0,
-                                                   int64_t n_here, uint32_t lane, uint32_t head_lo = 0, uint32_t head_n = 0) {
+                                                   int64_t n_here, uint32_t lane, uint32_t head_lo = 0, uint32_t head_n = 0, uint32_t rot = 0) {
     // Each lane serves the same dyn entry for every environment: decode it once.
     // A laser / gem reference becomes (dword of the hand-over record, bit); an absent one points at the record's
     // zero word, so the per-environment evaluation is branch-free.
@@ -188,8 +205,9 @@ __device__ __forceinline__ void write_observations(int A, int L, uint32_t D, uin
     const bool is_agent_lane = (int)lane < A;
     const uint4* srcv = reinterpret_cast<const uint4*>(tmpl);
 
-    for (int64_t k = 0; k < n_here; k++) {
-        const uint32_t* sc = scratch + (uint32_t)k * scr_stride;
+    for (uint32_t k0 = 0; k0 < (uint32_t)n_here; k0++) {
+        const uint32_t k = rotated(k0, rot, (uint32_t)n_here);  // (row_rotation: the wavefront starts at another one of its rows)
+        const uint32_t* sc = scratch + k * scr_stride;
         // (a) bytes that depend on beams / gems
         {
             const uint32_t lit = ((sc[d0_w0] >> d0_s0) | (sc[d0_w1] >> d0_s1) | (sc[d0_wg] >> d0_sg)) & 1u;
@@ -307,7 +325,7 @@ __device__ __forceinline__ void write_observations_env(int A, int L, uint32_t HW
                                                        int8_t* tmpl, const uint32_t* scratch, uint32_t scr_stride,
                                                        int8_t* __restrict__ obs, int64_t env0, int64_t n_here, uint32_t lane,
                                                        const uint8_t* laser_layer = nullptr, uint32_t gem_layer_in = 0xFFFFFFFFu,
-                                                       uint32_t head_lo = 0, uint32_t head_n = 0) {
+                                                       uint32_t head_lo = 0, uint32_t head_n = 0, uint32_t rot = 0) {
     const uint32_t gem_layer = gem_layer_in == 0xFFFFFFFFu ? (uint32_t)(2 * A + 2) : gem_layer_in;
     const bool has_e0 = lane < n_elems;
     const uint32_t e0 = has_e0 ? elems[lane] : 0u;
@@ -324,8 +342,9 @@ __device__ __forceinline__ void write_observations_env(int A, int L, uint32_t HW
     const uint32_t e0_always = (has_e0 && e0_src) ? 1u : 0u, e0_dyn = (has_e0 && !e0_src) ? 1u : 0u;
     const bool is_agent_lane = (int)lane < A;
     const uint4* srcv = reinterpret_cast<const uint4*>(tmpl);
-    for (int64_t k = 0; k < n_here; k++) {
-        const uint32_t* sc = scratch + (uint32_t)k * scr_stride;
+    for (uint32_t k0 = 0; k0 < (uint32_t)n_here; k0++) {
+        const uint32_t k = rotated(k0, rot, (uint32_t)n_here);
+        const uint32_t* sc = scratch + k * scr_stride;
         const uint32_t colour = (sc[e0_colw] >> e0_colsh) & 0xFFu, onw = sc[e0_onw];
         uint32_t idx0 = e0_base + __umul24(colour, e0_mul);
         if (laser_layer && !e0_gem) idx0 = (uint32_t)laser_layer[colour] * HW + e0_cell;   // views: the layer of colour c is a table

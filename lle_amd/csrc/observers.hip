@@ -686,10 +686,36 @@ __global__ void __launch_bounds__(256) row_fill_probe_kernel(int8_t* __restrict_
     const uint32_t lane = threadIdx.x & 63u, wave = blk * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t r0 = (int64_t)wave * rows_per_wave;
     const uint4 v = {value, value, value, value};
-    for (uint32_t r = 0; r < rows_per_wave && r0 + r < n_rows; r++) {
-        uint4* dst = reinterpret_cast<uint4*>(out + (r0 + r) * (int64_t)n_chunks * 16);
+    const int64_t left = n_rows - r0, n_here = left < (int64_t)rows_per_wave ? left : (int64_t)rows_per_wave;
+    const uint32_t rot = row_rotation(wave, rows_per_wave, n_here, flags);  // (the step kernel's own row order)
+    for (uint32_t r = 0; (int64_t)r < n_here; r++) {
+        uint4* dst = reinterpret_cast<uint4*>(out + (r0 + rotated(r, rot, (uint32_t)n_here)) * (int64_t)n_chunks * 16);
         for (uint32_t c = lane; c < n_chunks; c += 64u) stream_store<WT>(dst + c, v);
     }
+}
+
+// A consumer's first touch of the observation (bench.py consumer_loop): every int8 of the rows converted to fp16 into a separate
+// buffer -- what the first layer of a policy does with `obs` before the next step (python/lle/env/env.py:165-189: the caller of
+// LLE.step reads the observation, then steps again).  16 bytes in, 32 bytes out per lane and iteration, grid-stride.
+__global__ void __launch_bounds__(256) cast_rows_kernel(const int8_t* __restrict__ rows, _Float16* __restrict__ out, int64_t n_chunks) {
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += stride) {
+        const uint4 v = reinterpret_cast<const uint4*>(rows)[c];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        half8 lo, hi;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            lo[k] = (_Float16)(int)(int8_t)(w[k >> 2] >> (8 * (k & 3)));
+            hi[k] = (_Float16)(int)(int8_t)(w[2 + (k >> 2)] >> (8 * (k & 3)));
+        }
+        reinterpret_cast<half8*>(out)[2 * c] = lo;
+        reinterpret_cast<half8*>(out)[2 * c + 1] = hi;
+    }
+}
+hipError_t launch_cast_rows(const int8_t* rows, void* out_f16, int64_t bytes, hipStream_t stream) {
+    hipLaunchKernelGGL(cast_rows_kernel, dim3(256 * 8), dim3(256), 0, stream, rows, static_cast<_Float16*>(out_f16), bytes / 16);
+    return hipGetLastError();
 }
 
 // The eight rollout counters: every wavefront of a step launch owns a slot of 8 x i64 (no atomics on the hot path); this sums
@@ -717,8 +743,9 @@ __global__ void __launch_bounds__(1024) stats_sum_kernel(const int64_t* __restri
 }
 
 // ---------------------------------------------------------------------------------------------- launchers
-hipError_t launch_row_fill_probe(int8_t* out, int64_t n_rows, uint32_t row_bytes, uint32_t rows_per_wave, uint32_t value, bool reverse, hipStream_t stream) {
-    const uint32_t flags = reverse ? LAUNCH_REVERSE : 0u;
+hipError_t launch_row_fill_probe(int8_t* out, int64_t n_rows, uint32_t row_bytes, uint32_t rows_per_wave, uint32_t value, bool reverse, bool rotate,
+                                 hipStream_t stream) {
+    const uint32_t flags = (reverse ? LAUNCH_REVERSE : 0u) | (rotate ? LAUNCH_ROTATE_ROWS : 0u);
     const uint32_t n_chunks = row_bytes / 16u, wpw = 4;
     const int64_t n_waves = (n_rows + rows_per_wave - 1) / rows_per_wave;
     const dim3 grid((uint32_t)((n_waves + wpw - 1) / wpw)), block(64 * wpw);

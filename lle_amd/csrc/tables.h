@@ -144,6 +144,7 @@ constexpr uint32_t LAUNCH_ARRAYS_INVALID = 0x40000;   // internal (MODE_ENV_SOUR
 constexpr uint32_t LAUNCH_RESET_FIRST = 0x800000;      // internal (MODE_ENV_SOURCES): World::reset of the env, then the source update
 constexpr uint32_t LAUNCH_SPLIT_ROWS = 0x1000000;      // internal: step_kernel splits every observation row over the wavefronts of a workgroup
 constexpr uint32_t LAUNCH_REVERSE = 0x2000000;         // internal: the workgroups serve the blocks of environments from the last to the first (obs_stream.hpp)
+constexpr uint32_t LAUNCH_ROTATE_ROWS = 0x4000000;     // internal: every wavefront starts its rows at another one of them (obs_stream.hpp row_rotation)
 constexpr uint32_t LAUNCH_WRITE_THROUGH = 0x400000;    // internal: observation rows are stored `sc1` (stream_store, obs_stream.hpp)
 // A launch writes its rows through L2 while all of them fit the Infinity Cache (256 MB, MI355X_MICROARCH.md); beyond
 // that plain write-back stores are faster (measured break-even between 245 MB and 490 MB per launch).

@@ -642,3 +642,28 @@ def test_autotune_changes_rules_not_results(oracle_mod):
             assert_state_equal(ea, ob.dump(), f"tuned t={t}")
             assert_step_equal(eb, ostep, f"untuned t={t}")
         assert a.stats() == b.stats()
+
+
+@pytest.mark.parametrize("name", ["level6", "level1", "nested", "many_agents"])
+def test_row_rotation_changes_nothing(oracle_mod, monkeypatch, name):
+    """Every wavefront starts its observation stream at another one of its rows (obs_stream.hpp row_rotation, LLE_ROW_ROTATE):
+    the order in which a wavefront writes its rows is not observable.  Forced off and on against the oracle, on a batch whose
+    last wavefront is ragged (and therefore not rotated), with and without row heads, single steps and a fused rollout."""
+    from lle_amd import BatchedWorld
+
+    text = MAPS.get(name) or EXTRA_MAPS[name]
+    n = 1000 + 7
+    for rotate in ("0", "1"):
+        for heads in ("0", "1"):
+            monkeypatch.setenv("LLE_ROW_ROTATE", rotate)
+            monkeypatch.setenv("LLE_ROW_HEADS", heads)
+            bw = BatchedWorld(text, n)
+            assert bw.tuning()["rotate_rows"] == int(rotate)
+            ob = oracle_mod.OracleBatch(text, n)
+            for t in range(10):
+                bw.step(sample=True, auto_reset=True, seed=21, t=t)
+                check(bw, ob, ob.step(None, auto_reset=True, seed=21, t=t), f"{name} rotate={rotate} heads={heads} t={t}")
+            bw.rollout(6, auto_reset=True, seed=21, t=10)
+            for t in range(10, 16):
+                ostep = ob.step(None, auto_reset=True, seed=21, t=t)
+            check(bw, ob, ostep, f"{name} rotate={rotate} heads={heads} rollout")
