@@ -1123,7 +1123,8 @@ int lle_batch_probe_row_fill(lle_batch* b, uint32_t value, void* stream) {
     const uint32_t epw = b->lane_per_env_step ? b->envs_per_wave : step_envs_per_wave(b->n_envs, (int)b->hdr.A, b->tune);
     // the same alternation as the step launches it stands in for
     const bool reverse = next_walk_reversed(b, b->ptrs.obs, (uint64_t)b->n_envs * b->hdr.obs_stride);
-    HIP_TRY(launch_row_fill_probe(b->ptrs.obs, b->n_envs, b->hdr.obs_stride, epw, value, reverse, rotate_rows_pays(b->tune), (hipStream_t)stream));
+    HIP_TRY(launch_row_fill_probe(b->ptrs.obs, b->n_envs, b->hdr.obs_stride, epw, value, reverse,
+                                  rotate_rows_pays(b->tune, (uint64_t)b->n_envs * b->hdr.obs_stride, b->hdr.obs_stride), (hipStream_t)stream));
     g_status = LLE_OK;
     return LLE_OK;
 }
@@ -1237,7 +1238,7 @@ int lle_batch_tuning(const lle_batch* b, lle_tuning_info* out, char* log_buf, si
     out->split_rows = step_splits_rows(h, pes, b->tune) ? 1 : 0;
     out->write_through = write_through_pays(row_bytes, h.obs_stride, b->tune.write_through) ? 1 : 0;
     out->alternating_walk = pingpong_pays(b, row_bytes) ? 1 : 0;
-    out->rotate_rows = (!out->split_rows && rotate_rows_pays(b->tune)) ? 1 : 0;
+    out->rotate_rows = (!out->split_rows && rotate_rows_pays(b->tune, row_bytes, h.obs_stride)) ? 1 : 0;
     // (what a plain single step of this batch gets: the same conditions as launch_step_kernel)
     const bool general = pes || b->envs_per_map != 0;
     StepTune t = b->tune;

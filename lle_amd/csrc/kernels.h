@@ -104,7 +104,7 @@ hipError_t launch_env_outputs(const MapHeader& h, const BatchPtrs& P, const EnvO
 hipError_t launch_row_fill_probe(int8_t* out, int64_t n_rows, uint32_t row_bytes, uint32_t rows_per_wave, uint32_t value, bool reverse, bool rotate,
                                  hipStream_t stream);
 hipError_t launch_cast_rows(const int8_t* rows, void* out_f16, int64_t bytes, hipStream_t stream);  // bench.py's consumer stand-in (observers.hip)
-bool rotate_rows_pays(const StepTune& tune);  // LAUNCH_ROTATE_ROWS for this batch's step launches (obs_stream.hpp row_rotation)
+bool rotate_rows_pays(const StepTune& tune, uint64_t row_bytes_per_launch, uint32_t row_pitch);  // LAUNCH_ROTATE_ROWS (obs_stream.hpp row_rotation)
 // out8[k] = sum over the n_blocks per-wavefront slots of stats[slot][k] (one workgroup; lle_batch_stats, lle_batch_stats_allreduce)
 hipError_t launch_stats_sum(const int64_t* stats, int64_t n_blocks, int64_t* out8, hipStream_t stream);
 hipError_t launch_avail(const MapHeader& h, const BatchPtrs& P, uint8_t* out, int walkable_lasers, int64_t n_envs, bool per_env_sources,

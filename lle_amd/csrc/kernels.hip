@@ -590,12 +590,16 @@ uint32_t step_envs_per_wave(int64_t n, int A, const StepTune& tune) {
     return e;
 }
 
-// Row rotation (obs_stream.hpp row_rotation): on by default -- it costs three scalar instructions per wavefront, gains 5 % where
-// the buffer's pages are contiguous and nothing elsewhere.  LLE_ROW_ROTATE=0 / 1 forces it; lle_batch_autotune measures it.
-bool rotate_rows_pays(const StepTune& tune) {
+// Row rotation (obs_stream.hpp row_rotation).  Measured on a box whose buffers are all of the slow kind (tools/rotate_ab.py, level 6,
+// us per step without / with; `fill` = the row-fill probe): every row to DRAM (one-directional walk) 262 144 envs 95.9 / 90.9 (fill
+// 87.4 / 83.9), 524 288 envs 184.2 / 179.5; with the alternating walk 262 144 envs 73.9 / 74.4, 524 288 170.7 / 167.1; inside the
+// Infinity Cache it costs 0.1-0.2 us (65 536 envs 19.8 / 19.9, fill 15.5 / 15.6), and packed rows (level 1: 944-byte pitch) lose with
+// it (108.8 / 113.2).  Hence: rows of whole 128-byte lines, launches that write more than the cache holds.  LLE_ROW_ROTATE=0 / 1
+// forces it; lle_batch_autotune measures it on the batch's own arena.
+bool rotate_rows_pays(const StepTune& tune, uint64_t row_bytes_per_launch, uint32_t row_pitch) {
     if (tuning().row_rotate >= 0) return tuning().row_rotate == 1;
     if (tune.rotate >= 0) return tune.rotate == 1;
-    return true;
+    return row_pitch % 128u == 0 && row_bytes_per_launch > WRITE_THROUGH_MAX_BYTES;
 }
 
 bool step_has_row_heads(const MapHeader& h, bool pes) {
@@ -610,8 +614,8 @@ hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const Laun
     {   // a ring keeps the rows of min(n_steps, ring_slots) steps; without one every step overwrites the same rows
         const uint64_t slots = K.ring_slots ? (K.n_steps < K.ring_slots ? (K.n_steps ? K.n_steps : 1u) : K.ring_slots) : 1u;
         if (write_through_pays((uint64_t)(K.env_limit - K.env_base) * h.obs_stride * slots, h.obs_stride, tune.write_through)) K.flags |= LAUNCH_WRITE_THROUGH;
+        if (rotate_rows_pays(tune, (uint64_t)(K.env_limit - K.env_base) * h.obs_stride * slots, h.obs_stride)) K.flags |= LAUNCH_ROTATE_ROWS;
     }
-    if (rotate_rows_pays(tune)) K.flags |= LAUNCH_ROTATE_ROWS;
     if (pes || K.envs_per_map || K.env_out) K.flags |= LAUNCH_GENERAL;  // (fused LLE.step outputs: MODE 4 / 5 carry the epilogue)
     if (K.env_out && (K.n_steps > 1 || K.ring_slots || K.stamps)) return hipErrorInvalidValue;  // single steps only
     if (K.n_steps > 1 || K.ring_slots || K.stamps) K.flags |= LAUNCH_ROLLOUT;
