@@ -28,13 +28,14 @@
 extern "C" {
 #endif
 
-#define LLE_ABI_VERSION 1
+#define LLE_ABI_VERSION 2  /* 2: beam words (lle_map_info.n_beam_words, lle_laser_tile.word / bit), lle_batch_autotune */
 
 /* static limits of this implementation (maps beyond them are rejected at parse/compile time) */
 #define LLE_MAX_AGENTS 16
 #define LLE_MAX_SOURCES 32
 #define LLE_MAX_GEMS 32
-#define LLE_MAX_BEAM_LEN 32
+#define LLE_MAX_BEAM_LEN 254       /* cells of one beam: any beam a map within LLE_MAX_DIM can hold */
+#define LLE_MAX_BEAM_WORDS 32      /* 32-cell words over all beams of a map (a beam of len cells takes ceil(len / 32), at least 1) */
 #define LLE_MAX_DIM 255
 
 typedef struct lle_map lle_map;     /* a parsed + compiled map (host object; no GPU needed) */
@@ -103,6 +104,11 @@ typedef struct lle_map_info {
     int32_t max_beam_len, max_cell_layers;
     int32_t obs_supported;   /* 0 if a laser colour addresses a layer >= C (IndexError in the reference) */
     int32_t table_bytes;     /* size of the device table blob */
+    /* Beam words: a beam (LaserBeam{Vec<bool>}, src/core/tiles/laser.rs:15-21) is stored as ceil(len / 32) consecutive 32-bit words,
+     * the words of source 0 first, then those of source 1, ... (a map with a beam longer than 32 cells is padded to 5 words).
+     * LLE_BUF_BEAMS / LLE_BUF_SRC_COLOUR hold n_beam_words entries per env; == n_sources when no beam is longer than 32 cells
+     * (every map of the reference's repository).  lle_laser_tile.word / .bit address a tile's bit. */
+    int32_t n_beam_words;
 } lle_map_info;
 int lle_map_get_info(const lle_map* map, lle_map_info* out);
 
@@ -136,7 +142,7 @@ int lle_map_colour_allowed(const lle_map* map, int laser_id, int agent_id);
 /* The beam of source `laser_id` right after World.reset (src/core/world.rs:411-432) when the source is enabled and has
  * colour `agent_id`: bit k = the tile at offset k is on (all on, cut from where that agent's start lies inside the beam:
  * Laser::pre_enter, src/core/tiles/laser.rs:173-182).  What LLE_STEP_RECOLOUR_RESETS stores as the env's reset beams.
- * Negative status on bad arguments. */
+ * Beams longer than 63 cells: LLE_ERR_UNSUPPORTED (the result is one 64-bit mask).  Negative status on bad arguments. */
 int64_t lle_map_reset_beam(const lle_map* map, int laser_id, int agent_id);
 
 /* Pitch of an observation row (lle_map_info.obs_stride, the env stride of LLE_BUF_OBS and of every layered-style
@@ -164,8 +170,9 @@ int lle_map_row_head(const lle_map* map, int32_t* first_byte, int32_t* n_bytes);
 int lle_map_row_head_env_sources(const lle_map* map, int32_t* first_byte, int32_t* n_bytes);
 
 /* static description of World.lasers (src/core/world.rs:159-172): per laser position the outer layer and, if
- * nested, the second one; `offset` indexes the beam mask of `laser_id`. */
-typedef struct lle_laser_tile { int32_t i, j, laser_id, offset, layer; } lle_laser_tile;
+ * nested, the second one; `offset` = the tile's index in the beam of `laser_id`; its on / off bit is bit `bit` of word `word`
+ * of the env's LLE_BUF_BEAMS record (word == laser_id, bit == offset unless a beam of the map is longer than 32 cells). */
+typedef struct lle_laser_tile { int32_t i, j, laser_id, offset, layer, word, bit; } lle_laser_tile;
 int lle_map_laser_tiles(const lle_map* map, lle_laser_tile* out, int cap);
 
 /* World.world_string (pyworld.rs:212-218): v1 text with the current source colours.  Returns needed size. */
@@ -178,7 +185,8 @@ enum {
     LLE_BUF_BITS,      /* u64 [n]         alive bits 0-15 | arrived 16-31 | occupant 32-47 | 48-63: dead by set_state without an
                           AgentDied event (LLE.compute_done counts events: such an agent does not end the episode) */
     LLE_BUF_GEMS,      /* u32 [n]         bit g = gem g collected (parse order; World.gems) */
-    LLE_BUF_BEAMS,     /* u32 [n][L]      bit k = beam of source l is on at offset k (LaserBeam, laser.rs:15-21) */
+    LLE_BUF_BEAMS,     /* u32 [n][Lw]     Lw = lle_map_info.n_beam_words; bit k of word source_first_word + w = the beam is on at offset 32 w + k
+                                          (LaserBeam, laser.rs:15-21; Lw == n_sources and word == laser_id unless a beam is longer than 32 cells) */
     LLE_BUF_AVAIL,     /* u8  [n][A]      bit a = Action a available (World.available_actions) */
     LLE_BUF_ACTIONS,   /* u8  [n][A]      joint action taken by the last step (input, or sampled output) */
     LLE_BUF_ERR,       /* u8  [n]         LLE_ENV_* of the last step / set_state */
@@ -192,7 +200,7 @@ enum {
     LLE_BUF_REQ_ALIVE, /* u16 [n] */
     LLE_BUF_REWARD,    /* u8  [n][4]      per-step (gems collected, exits, deaths, all agents arrived) of the last step:
                           the inputs of the reference's reward strategies (python/lle/env/reward_strategy.py:58-109) */
-    LLE_BUF_SRC_COLOUR,  /* u8  [n][L]     colour (agent_id) of every source of this env; valid after lle_batch_set_sources */
+    LLE_BUF_SRC_COLOUR,  /* u8  [n][Lw]    colour (agent_id) per beam word of this env (the words of a source carry the same one); valid after lle_batch_set_sources */
     LLE_BUF_SRC_ENABLED, /* u32 [n]        bit l = source l of this env enabled;          valid after lle_batch_set_sources */
     LLE_BUF_COUNT
 };

@@ -52,7 +52,7 @@ EXPORTS = [
 class MapInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "height", "width", "n_agents", "n_gems", "n_sources", "n_layers", "n_exits", "n_walls", "n_voids",
-        "n_laser_tiles", "obs_bytes", "obs_stride", "max_beam_len", "max_cell_layers", "obs_supported", "table_bytes")]
+        "n_laser_tiles", "obs_bytes", "obs_stride", "max_beam_len", "max_cell_layers", "obs_supported", "table_bytes", "n_beam_words")]
 
 
 class SourceInfo(C.Structure):
@@ -60,7 +60,7 @@ class SourceInfo(C.Structure):
 
 
 class LaserTile(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("i", "j", "laser_id", "offset", "layer")]
+    _fields_ = [(n, C.c_int32) for n in ("i", "j", "laser_id", "offset", "layer", "word", "bit")]
 
 
 class EnvOutputs(C.Structure):
@@ -317,6 +317,15 @@ class Map:
         arr = (SourceInfo * max(n, 1))()
         lib().lle_map_sources(self.h, arr, n)
         return [arr[k] for k in range(n)]
+
+    def source_first_words(self):
+        """First beam word of every source (lle_map_info.n_beam_words): a beam of `length` cells takes ceil(length / 32) consecutive
+        32-bit words of an env's LLE_BUF_BEAMS / LLE_BUF_SRC_COLOUR record, at least one; == laser_id when no beam exceeds 32 cells."""
+        out, w = [], 0
+        for s in self.sources():
+            out.append(w)
+            w += max(1, -(-int(s.length) // 32))
+        return out
 
     def laser_tiles(self):
         n = lib().lle_map_laser_tiles(self.h, None, 0)

@@ -2,7 +2,8 @@
 
 Pure numpy on host copies; shared by the `World` facade and by the tests.  Layouts:
   pos u8[A,2] (i,j); bits u64: alive 0-15 | arrived 16-31 | occupant 32-47; gems u32 bit g = collected;
-  beams u32[L] bit k = on at offset k; avail u8[A] bit a = Action a; events u8[2A] = type << 4 | agent.
+  beams u32[Lw]: beam WORDS -- the tile at offset k of a beam is bit k % 32 of word (first word of its source) + k // 32
+  (lle_laser_tile.word / .bit; word == laser_id, bit == offset unless a beam is longer than 32 cells); avail u8[A] bit a = Action a; events u8[2A] = type << 4 | agent.
 """
 import numpy as np
 
@@ -37,9 +38,10 @@ def events_list(evcount, events):
     return [(int(ev[k]) >> 4, int(ev[k]) & 15) for k in range(n)]
 
 
-def beam_bits(beams, laser_id, length):
-    m = int(np.asarray(beams).reshape(-1)[laser_id])
-    return [bool((m >> k) & 1) for k in range(length)]
+def beam_bits(beams, first_word, length):
+    """on / off of the `length` tiles of the beam whose words start at `first_word` (== laser_id on maps without long beams)."""
+    bm = np.asarray(beams).reshape(-1)
+    return [bool((int(bm[first_word + k // 32]) >> (k % 32)) & 1) for k in range(length)]
 
 
 def lasers_listing(laser_tiles, sources, beams):
@@ -48,7 +50,7 @@ def lasers_listing(laser_tiles, sources, beams):
     bm = np.asarray(beams).reshape(-1)
     for t in laser_tiles:
         s = sources[t.laser_id]
-        on = (int(bm[t.laser_id]) >> t.offset) & 1
+        on = (int(bm[t.word]) >> t.bit) & 1
         out.append((int(t.i), int(t.j), int(t.laser_id), int(s.agent_id), int(on), int(s.enabled)))
     return out
 

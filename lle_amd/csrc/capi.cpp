@@ -241,6 +241,7 @@ int lle_map_get_info(const lle_map* map, lle_map_info* out) {
     for (auto& s : m.sources) mb = std::max(mb, (int)s.beam.size());
     out->max_beam_len = mb; out->max_cell_layers = (int)m.header.max_layers;
     out->obs_supported = (int)m.header.obs_supported; out->table_bytes = (int)m.header.blob_bytes;
+    out->n_beam_words = m.n_words();
     return LLE_OK;
 }
 
@@ -310,7 +311,7 @@ int lle_map_colour_allowed(const lle_map* map, int laser_id, int agent_id) {
     const Map& m = map->m;
     if (laser_id < 0 || laser_id >= (int)m.sources.size()) return fail(LLE_ERR_ARG, "laser_id out of range");
     if (agent_id < 0 || agent_id >= m.n_agents()) return fail(LLE_ERR_ARG, "Agent ID is greater than the number of agents");
-    return (m.header.colour_ok[laser_id] >> agent_id) & 1;
+    return (m.header.colour_ok[m.source_word[(size_t)laser_id]] >> agent_id) & 1;
 }
 
 int lle_map_set_row_align(lle_map* map, int align) {
@@ -347,9 +348,13 @@ int lle_map_row_head_env_sources(const lle_map* map, int32_t* first_byte, int32_
 int64_t lle_map_reset_beam(const lle_map* map, int laser_id, int agent_id) {
     if (!map) return fail(LLE_ERR_NULL, "NULL map");
     const MapHeader& h = map->m.header;
-    if (laser_id < 0 || laser_id >= (int)h.L || agent_id < 0 || agent_id >= (int)h.A) return fail(LLE_ERR_ARG, "laser_id / agent_id out of range");
+    if (laser_id < 0 || laser_id >= (int)h.n_sources || agent_id < 0 || agent_id >= (int)h.A) return fail(LLE_ERR_ARG, "laser_id / agent_id out of range");
+    if (map->m.sources[(size_t)laser_id].beam.size() > 63) return fail(LLE_ERR_UNSUPPORTED, "lle_map_reset_beam returns one 64-bit mask: beams of at most 63 cells");
     const uint32_t* tab = reinterpret_cast<const uint32_t*>(map->m.blob.data() + h.off_recolour);
-    return (int64_t)tab[(size_t)laser_id * (h.A + 1u) + 1u + (uint32_t)agent_id];
+    int64_t mask = 0;  // the words of the source, low cells first
+    for (int w = h.source_word[laser_id], k = 0; w < (int)h.L && h.word_source[w] == laser_id && ((h.word_mask >> w) & 1u) && k < 2; w++, k++)
+        mask |= (int64_t)tab[(size_t)w * (h.A + 1u) + 1u + (uint32_t)agent_id] << (32 * k);
+    return mask;
 }
 
 int lle_map_laser_tiles(const lle_map* map, lle_laser_tile* out, int cap) {
@@ -359,7 +364,9 @@ int lle_map_laser_tiles(const lle_map* map, lle_laser_tile* out, int cap) {
     for (int c = 0; c < m.H * m.W; c++) {
         const auto& layers = m.cell_layers[c];
         for (int k = 0; k < (int)layers.size() && k < 2; k++) {
-            if (out && n < cap) out[n] = lle_laser_tile{c / m.W, c % m.W, layers[k].laser_id, layers[k].offset, k};
+            if (out && n < cap)
+                out[n] = lle_laser_tile{c / m.W, c % m.W, layers[k].laser_id, layers[k].offset, k, m.word_of(layers[k].laser_id, layers[k].offset),
+                                        Map::bit_of(layers[k].offset)};
             n++;
         }
     }
@@ -517,8 +524,10 @@ static int common_header(const lle_map* const* maps, int n_maps, MapHeader* out,
     uint32_t worst = h.lds_table_bytes + (h.blob_capacity - h.blob_bytes);  // table section with the largest possible dyn table
     for (int m = 1; m < n_maps; m++) {
         const MapHeader& o = maps[m]->m.header;
-        if (o.H != h.H || o.W != h.W || o.A != h.A || o.L != h.L || o.G != h.G)
-            return fail(LLE_ERR_ARG, "the maps of a batch must agree on height, width and the numbers of agents, sources and gems");
+        if (o.H != h.H || o.W != h.W || o.A != h.A || o.L != h.L || o.G != h.G || o.n_sources != h.n_sources)
+            return fail(LLE_ERR_ARG, "the maps of a batch must agree on height, width and the numbers of agents, sources (and beam words) and gems");
+        if (std::memcmp(o.word_source, h.word_source, sizeof h.word_source) != 0 || o.chain_mask != h.chain_mask)
+            return fail(LLE_ERR_ARG, "the maps of a batch must agree on which beams are longer than 32 cells (the layout of their beam words)");
         if (o.obs_stride != h.obs_stride) return fail(LLE_ERR_ARG, "the maps of a batch must agree on the row alignment (lle_map_set_row_align)");
         worst = std::max(worst, o.lds_table_bytes + (o.blob_capacity - o.blob_bytes));
         h.lds_table_bytes = std::max(h.lds_table_bytes, o.lds_table_bytes);

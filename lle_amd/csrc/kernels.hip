@@ -133,6 +133,7 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
     mv.W = (int)hdr->W; mv.A = A; mv.L = L; mv.G = (int)hdr->G;
     mv.enabled = env_enabled; mv.max_layers = hdr->max_layers;
     mv.per_env = pes;
+    mv.chain = hdr->chain_mask;
 #pragma unroll
     for (int q = 0; q < MAX_SOURCES / 4; q++) mv.colw[q] = q < LM / 4 ? colw[q < LM / 4 ? q : 0] : 0u;
     const uint32_t amask = (1u << A) - 1u;
@@ -271,8 +272,20 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
                     reset_first = true;
                     ghost = 0u;
                 }
-                uint32_t new_en = fill ? hdr->enabled_mask : (K.enabled_in ? K.enabled_in[env] : mv.enabled);
-                new_en &= L >= 32 ? 0xFFFFFFFFu : ((1u << L) - 1u);
+                // (the caller speaks of SOURCES -- colours u8 [n][n_sources], bit s of the enabled mask = source s; the kernels of beam
+                // WORDS, tables.h: every word of a source takes its colour and its flag.  word_source is the identity, and
+                // n_sources == L, unless a beam of the map is longer than 32 cells)
+                const int n_src = (int)hdr->n_sources;
+                uint32_t new_en = mv.enabled;
+                if (fill) new_en = hdr->enabled_mask;
+                else if (K.enabled_in) {
+                    const uint32_t in = K.enabled_in[env];
+                    new_en = 0u;
+#pragma unroll
+                    for (int b = 0; b < LM; b++)
+                        if (b < L) new_en |= ((in >> hdr->word_source[b]) & 1u) << b;
+                }
+                new_en &= hdr->word_mask;
                 uint32_t ncol[LM / 4];
 #pragma unroll
                 for (int q = 0; q < LM / 4; q++) ncol[q] = colw[q];
@@ -280,7 +293,7 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
 #pragma unroll
                 for (int b = 0; b < LM; b++) {
                     if (b < L && (fill || K.colours_in)) {
-                        const uint32_t c = fill ? (uint32_t)hdr->beam_colour[b] : (uint32_t)K.colours_in[env * L + b];
+                        const uint32_t c = fill ? (uint32_t)hdr->beam_colour[b] : (uint32_t)K.colours_in[env * n_src + hdr->word_source[b]];
                         bad |= !fill && c >= (uint32_t)A;  // "Agent ID is greater than the number of agents"
                         // "... would cross the start position of agent ..." (pylaser_source.rs:121-139; MapHeader.colour_ok)
                         crosses |= !fill && c < (uint32_t)A && !(((uint32_t)hdr->colour_ok[b] >> c) & 1u);

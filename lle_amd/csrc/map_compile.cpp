@@ -248,12 +248,39 @@ int parse_map(const char* text, size_t len, Map& m) {
         return LLE_PARSE_LIMIT;
     for (auto& s : m.sources)
         if ((int)s.beam.size() > LLE_MAX_BEAM_LEN) return LLE_PARSE_LIMIT;
+    if (!m.layout_words()) return LLE_PARSE_LIMIT;  // more than LLE_MAX_BEAM_WORDS 32-cell words over all beams
     for (auto& l : m.cell_layers)
         if ((int)l.size() > MAX_CELL_LAYERS) return LLE_PARSE_LIMIT;  // impossible: one beam per travel direction
     if ((int64_t)m.n_layers() * HW >= (1 << 20)) return LLE_PARSE_LIMIT;  // 16-bit chunk ids, 20-bit byte indices
 
     m.compile();
     return LLE_PARSE_OK;
+}
+
+bool Map::layout_words() {
+    source_word.clear();
+    word_source.clear();
+    chain_mask = 0;
+    bool chained = false;
+    for (size_t s = 0; s < sources.size(); s++) {
+        const int words = std::max(1, ((int)sources[s].beam.size() + MAX_BEAM_LEN - 1) / MAX_BEAM_LEN);
+        source_word.push_back((int)word_source.size());
+        for (int w = 0; w < words; w++) {
+            if (w > 0 && word_source.size() < 32) chain_mask |= 1u << word_source.size();
+            word_source.push_back((int)s);
+        }
+        chained = chained || words > 1;
+    }
+    // a chained map takes the kernels' LDS-record form of the beam masks (more than four words), the only one that walks chains
+    while (chained && word_source.size() < 5) word_source.push_back(-1);
+    return (int)word_source.size() <= MAX_SOURCES;
+}
+
+int Map::word_len(int b) const {
+    const int s = word_source[(size_t)b];
+    if (s < 0) return 0;
+    const int first = (b - source_word[(size_t)s]) * MAX_BEAM_LEN, len = (int)sources[(size_t)s].beam.size();
+    return std::max(0, std::min(MAX_BEAM_LEN, len - first));
 }
 
 int Map::n_laser_tiles() const {
@@ -289,7 +316,7 @@ bool Map::build_obs_tables(const LayerMap& lm, std::vector<int8_t>& tmpl, std::v
             if (src.agent_id >= lm.n_laser) { supported = false; continue; }
             uint32_t idx = (uint32_t)(lm.laser[src.agent_id] * HW + c);
             Dyn& d = dyn[idx];
-            d.ref[d.n_refs++] = (uint32_t)layers[k].laser_id | ((uint32_t)layers[k].offset << 5);
+            d.ref[d.n_refs++] = (uint32_t)word_of(layers[k].laser_id, layers[k].offset) | ((uint32_t)bit_of(layers[k].offset) << 5);
         }
     }
     for (int g = 0; g < G; g++) dyn[(uint32_t)(lm.gem * HW + gems[g].i * W + gems[g].j)].gem = (uint32_t)g;
@@ -332,7 +359,7 @@ std::vector<uint8_t> Map::compile_view(int kind, int param) const {
     ViewHeader v{};
     v.magic = VIEW_MAGIC;
     v.supported = build_obs_tables(lm, tmpl, dyn_tab) ? 1u : 0u;
-    v.A = (uint32_t)A; v.L = (uint32_t)sources.size(); v.H = (uint32_t)H; v.W = (uint32_t)W; v.HW = (uint32_t)HW;
+    v.A = (uint32_t)A; v.L = (uint32_t)n_words(); v.H = (uint32_t)H; v.W = (uint32_t)W; v.HW = (uint32_t)HW;
     v.C = (uint32_t)lm.C;
     v.obs_bytes = (uint32_t)(lm.C * HW);
     v.obs_stride = row_pitch_of(v.obs_bytes);
@@ -364,8 +391,15 @@ std::vector<uint8_t> Map::compile_view(int kind, int param) const {
 }
 
 void Map::compile() {
-    const int A = n_agents(), G = (int)gems.size(), L = (int)sources.size(), C = n_layers(), HW = H * W;
+    const int A = n_agents(), G = (int)gems.size(), L = n_words(), C = n_layers(), HW = H * W;  // L: beam WORDS (tables.h)
     MapHeader h{};
+    h.n_sources = (uint32_t)sources.size();
+    h.chain_mask = chain_mask;
+    for (int b = 0; b < L; b++) {
+        h.word_source[b] = (uint8_t)std::max(word_source[(size_t)b], 0);
+        if (word_source[(size_t)b] >= 0) h.word_mask |= 1u << b;
+    }
+    for (size_t s = 0; s < sources.size(); s++) h.source_word[s] = (uint8_t)source_word[s];
     h.magic = MAP_MAGIC;
     h.H = H; h.W = W; h.A = A; h.G = G; h.L = L; h.C = C; h.HW = HW;
     h.obs_bytes = (uint32_t)(C * HW);
@@ -377,17 +411,21 @@ void Map::compile() {
         h.gem_cell[g] = (uint16_t)(gems[g].i | (gems[g].j << 8));
         if (cell_layers[gems[g].i * W + gems[g].j].empty()) h.direct_gems |= 1u << g;
     }
-    for (int s = 0; s < L; s++) {
-        const Source& src = sources[s];
-        h.beam_len[s] = (uint8_t)src.beam.size();
-        h.beam_full[s] = src.beam.size() >= 32 ? 0xFFFFFFFFu : ((1u << src.beam.size()) - 1u);
-        h.beam_colour[s] = (uint8_t)std::min(src.agent_id, (int)NO_COLOUR);
-        if (src.enabled) h.enabled_mask |= 1u << s;
+    for (int b = 0; b < L; b++) {  // per word; the words of a chain carry their source's colour and flag
+        if (word_source[(size_t)b] < 0) continue;  // (padding: empty, disabled)
+        const Source& src = sources[(size_t)word_source[(size_t)b]];
+        const int len = word_len(b);
+        h.beam_len[b] = (uint8_t)len;
+        h.beam_full[b] = len >= 32 ? 0xFFFFFFFFu : ((1u << len) - 1u);
+        h.beam_colour[b] = (uint8_t)std::min(src.agent_id, (int)NO_COLOUR);
+        if (src.enabled) h.enabled_mask |= 1u << b;
     }
 
     // which colours a source may take (pylaser_source.rs:121-139): its exposed tiles (outer layer and the one directly
     // below, world.rs:159-172) must not hold a possible start of an agent of another colour
-    for (int s = 0; s < L; s++) {
+    for (int b = 0; b < L; b++) {
+        const int s = word_source[(size_t)b];
+        if (s < 0) continue;
         uint32_t on_beam = 0;  // agents with a start on the exposed tiles of source s
         for (int a = 0; a < A; a++)
             for (const Pos& st : starts[a]) {
@@ -398,7 +436,7 @@ void Map::compile() {
         uint32_t ok = 0;
         for (int c = 0; c < A; c++)
             if ((on_beam & ~(1u << c)) == 0) ok |= 1u << c;
-        h.colour_ok[s] = (uint16_t)ok;
+        h.colour_ok[b] = (uint16_t)ok;
     }
 
     // ---- cell tables
@@ -415,7 +453,7 @@ void Map::compile() {
                 const Source& src = sources[layers[k].laser_id];
                 uint32_t colour = (uint32_t)std::min(src.agent_id, (int)NO_COLOUR);
                 if ((int)colour >= A) colour = NO_COLOUR;
-                lay |= (uint64_t)lay_pack((uint32_t)layers[k].laser_id, (uint32_t)layers[k].offset, colour) << (16 * k);
+                lay |= (uint64_t)lay_pack((uint32_t)word_of(layers[k].laser_id, layers[k].offset), (uint32_t)bit_of(layers[k].offset), colour) << (16 * k);
             }
             cell_lay[c] = lay;
             uint32_t walk = 0;
@@ -426,9 +464,9 @@ void Map::compile() {
                 if (k != K_WALL && k != K_SOURCE) walk |= 1u << d;
             }
             uint32_t gi = gem_index[c] >= 0 ? (uint32_t)gem_index[c] : 31u;
-            if (kind[c] == K_SOURCE)  // the field holds the laser_id of a source cell (read by the partial observer)
+            if (kind[c] == K_SOURCE)  // the field holds the (first) beam word of a source cell (read by the partial observer: its colour)
                 for (const Source& src : sources)
-                    if (src.pos.i == i && src.pos.j == j) gi = (uint32_t)src.laser_id;
+                    if (src.pos.i == i && src.pos.j == j) gi = (uint32_t)source_word[(size_t)src.laser_id];
             cell_meta[c] = kind[c] | (gi << 3) | (walk << 8) | ((uint32_t)layers.size() << 12);
         }
 
@@ -518,11 +556,11 @@ void Map::compile() {
         for (auto& q : exits) bat(2 * A + 3, q) = 1;
     }
     std::vector<uint32_t> elems;
-    for (auto& s : sources) elems.push_back((uint32_t)(s.pos.i * W + s.pos.j) | ((uint32_t)s.laser_id << 16) | (ELEM_SOURCE << 26));
+    for (auto& s : sources) elems.push_back((uint32_t)(s.pos.i * W + s.pos.j) | ((uint32_t)source_word[(size_t)s.laser_id] << 16) | (ELEM_SOURCE << 26));
     for (int c = 0; c < HW; c++)
         for (size_t k = 0; k < cell_layers[c].size() && k < 2; k++)
-            elems.push_back((uint32_t)c | ((uint32_t)cell_layers[c][k].laser_id << 16) | ((uint32_t)cell_layers[c][k].offset << 21) |
-                            (ELEM_TILE << 26));
+            elems.push_back((uint32_t)c | ((uint32_t)word_of(cell_layers[c][k].laser_id, cell_layers[c][k].offset) << 16) |
+                            ((uint32_t)bit_of(cell_layers[c][k].offset) << 21) | (ELEM_TILE << 26));
     for (int g = 0; g < G; g++) elems.push_back((uint32_t)(gems[g].i * W + gems[g].j) | ((uint32_t)g << 16) | (ELEM_GEM << 26));
     h.off_bare = h.blob_capacity;
     h.off_elems = h.off_bare + h.obs_stride;
@@ -530,18 +568,25 @@ void Map::compile() {
     // re-colouring table (tables.h off_recolour): World::reset turns every enabled beam fully on, then the agent standing on
     // its start INSIDE a beam of its own colour cuts that beam from there (pre_enter, laser.rs:173-182)
     std::vector<uint32_t> recolour((size_t)L * (A + 1), 0u);
-    for (int s = 0; s < L; s++) {
-        recolour[(size_t)s * (A + 1)] = h.colour_ok[s];
+    for (int b = 0; b < L; b++) {
+        const int s = word_source[(size_t)b];
+        if (s < 0) continue;
+        recolour[(size_t)b * (A + 1)] = h.colour_ok[b];
         for (int c = 0; c < A; c++) {
-            uint32_t beam = h.beam_full[s];
+            uint32_t beam = h.beam_full[b];
             const Pos st = starts[c][0];
             for (const auto& lay : cell_layers[st.i * W + st.j])
-                if (lay.laser_id == s) beam &= (1u << lay.offset) - 1u;
-            recolour[(size_t)s * (A + 1) + 1 + c] = beam;
+                if (lay.laser_id == s) {  // the cut runs to the end of the beam: this word from the start's bit on, later words whole
+                    const int w = word_of(s, lay.offset);
+                    if (w == b) beam &= (1u << bit_of(lay.offset)) - 1u;
+                    else if (w < b) beam = 0u;
+                }
+            recolour[(size_t)b * (A + 1) + 1 + c] = beam;
         }
     }
     h.off_recolour = h.off_elems + h.n_elems * 4u;
-    h.recolour_exact = h.max_layers <= 2 ? 1u : 0u;
+    // (the step kernel draws one colour per WORD: exact only where a word is a source)
+    h.recolour_exact = (h.max_layers <= 2 && chain_mask == 0) ? 1u : 0u;
     h.ext_bytes = (h.obs_stride + h.n_elems * 4u + (uint32_t)recolour.size() * 4u + 1023u) & ~1023u;
     off = (size_t)h.blob_capacity + h.ext_bytes;
     blob.assign(off, 0);

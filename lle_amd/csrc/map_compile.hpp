@@ -65,6 +65,17 @@ struct Map {
     }
     int head_lines = default_head_lines();
 
+    // Beam words (tables.h): a beam of len cells is ceil(len / 32) consecutive 32-bit words (at least one); chained maps are padded
+    // to five words.  Filled by layout_words() (parse time; the beams never change afterwards).
+    std::vector<int> source_word;   // first word of source s
+    std::vector<int> word_source;   // source of word b (-1: padding)
+    uint32_t chain_mask = 0;        // bit b: word b continues word b - 1
+    int n_words() const { return (int)word_source.size(); }
+    bool layout_words();            // false: more than MAX_SOURCES words
+    int word_of(int laser_id, int offset) const { return source_word[(size_t)laser_id] + offset / 32; }
+    static int bit_of(int offset) { return offset % 32; }
+    int word_len(int b) const;      // cells of word b
+
     int n_agents() const { return (int)starts.size(); }
     int n_layers() const { return 2 * n_agents() + 4; }
     int n_laser_tiles() const;

@@ -116,6 +116,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
 #pragma unroll
     for (int b = 0; b < LR; b++) h_beam_full[b] = (!BM && b < L) ? hdr->beam_full[b] : 0u;
     const uint32_t h_enabled = hdr->enabled_mask;
+    const uint32_t h_chain = BM ? hdr->chain_mask : 0u;  // (beams longer than 32 cells: step_lanes.hpp BM walks the chain of words)
     // (with head stores ahead of them, later header reads would be VECTOR loads -- the scalar cache is not coherent with
     // the kernel's own stores, and the compiler cannot tell the header from the rows -- whose wait covers the stores too)
     const uint32_t h_off_cell_meta = hdr->off_cell_meta, h_off_dyn = hdr->off_dyn, h_off_template = hdr->off_template;
@@ -420,7 +421,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     uint32_t n_ev, meta_step, err;
     bool stepped;
     step_lanes<G, LR, ML1, PES, CWM, true, BM>(cell_lay, cell_meta, A, L, W, max_layers, h_beam_full, a, me, env_ok, enabled, colw, act, pos, avail,
-                                               alive, arrived, occ, gems, beams, err, evw, n_ev, meta_step, stepped, nullptr, bm, beam_tab);
+                                               alive, arrived, occ, gems, beams, err, evw, n_ev, meta_step, stepped, nullptr, bm, beam_tab, h_chain);
     LLE_STAMP(3);
 
     // ---- everything of the step that the observation does not need: availability masks (compute_available_actions,

@@ -142,7 +142,8 @@ LLE_LANE_FN void step_lanes(const uint64_t* cell_lay, const uint32_t* cell_meta,
                        LV<G, uint32_t>& occ, LV<G, uint32_t>& gems, LV<G, uint32_t> (&beams)[LM], LV<G, uint32_t>& err,
                        LV<G, uint64_t> (&evw)[(2 * G + 7) / 8], LV<G, uint32_t>& n_ev, LV<G, uint32_t>& meta_step, LV<G, bool>& stepped,
                        int64_t* passes_executed = nullptr /* test builds: counts the move_agents passes that ran */,
-                       uint32_t* bm = nullptr, const uint32_t* full_tab = nullptr /* BM only */) {
+                       uint32_t* bm = nullptr, const uint32_t* full_tab = nullptr /* BM only */,
+                       uint32_t chain = 0 /* BM only: bit b = word b continues the beam of word b - 1 (tables.h chain_mask) */) {
     constexpr int NW = (2 * G + 7) / 8;
     const uint32_t max_layers = ML1 ? 1u : table_max_layers;
 
@@ -284,7 +285,12 @@ LLE_LANE_FN void step_lanes(const uint64_t* cell_lay, const uint32_t* cell_meta,
                 if (go) {
 #pragma unroll
                     for (int k = 0; k < 4; k++)
-                        if ((uint32_t)rq_m[k]) mem_or(bm + (uint32_t)rq_b[k], (uint32_t)rq_m[k]);
+                        if ((uint32_t)rq_m[k]) {
+                            mem_or(bm + (uint32_t)rq_b[k], (uint32_t)rq_m[k]);
+                            // LaserBeam::turn_on runs to the end of the Vec (laser.rs:50-55): the following words of a chained beam whole
+                            if (chain)
+                                for (uint32_t w = (uint32_t)rq_b[k] + 1u; (chain >> w) & 1u; w++) mem_or(bm + w, full_tab[w]);
+                        }
                 }
             }
         }
@@ -297,7 +303,11 @@ LLE_LANE_FN void step_lanes(const uint64_t* cell_lay, const uint32_t* cell_meta,
                         if ((uint32_t)k < max_layers) {
                             const uint32_t en = (uint32_t)((uint64_t)lay_new >> (16 * k)) & 0xFFFFu;
                             const uint32_t b = (en >> 1) & 31u;
-                            if ((en & LAY_VALID) && (en >> 11) == a && ((enabled >> b) & 1u)) mem_and(bm + b, (1u << ((en >> 6) & 31u)) - 1u);
+                            if ((en & LAY_VALID) && (en >> 11) == a && ((enabled >> b) & 1u)) {
+                                mem_and(bm + b, (1u << ((en >> 6) & 31u)) - 1u);
+                                if (chain)  // LaserBeam::turn_off likewise (laser.rs:57-59)
+                                    for (uint32_t w = b + 1u; (chain >> w) & 1u; w++) mem_and(bm + w, 0u);
+                            }
                         }
                     }
                 }

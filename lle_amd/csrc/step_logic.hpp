@@ -87,6 +87,7 @@ struct MapView {
     // `per_env` is set they replace the colours baked into cell_lay
     bool per_env;
     uint32_t colw[MAX_SOURCES / 4];
+    uint32_t chain = 0;    // bit b: beam word b continues the beam of word b - 1 (tables.h chain_mask)
 };
 
 // colour of beam b from the env's packed colour words (compile-time indexed selects: no private-array indexing)
@@ -175,6 +176,21 @@ LLE_HD void beam_set_if(uint32_t (&b)[LM], uint32_t idx, bool c, uint32_t v) {
     for (int k = 0; k < LM; k++) b[k] = (c && idx == (uint32_t)k) ? v : b[k];
 }
 
+// A re-light / cut of beam word b that runs to the end of the beam (LaserBeam::turn_on / turn_off, laser.rs:50-59) takes the
+// following words of a chained beam whole.  `c`: the operation happens; `fill`: re-light (bits beyond a word's length are trimmed by
+// canonicalise()) or cut.  Maps without a beam longer than 32 cells have chain == 0: a uniform branch.
+template <int LM>
+LLE_HD void chain_rest(uint32_t (&beams)[LM], uint32_t b, bool c, bool fill, uint32_t chain) {
+    if (!chain) return;
+    bool carry = false;
+#pragma unroll
+    for (int k = 0; k < LM; k++) {
+        carry = carry && ((chain >> k) & 1u);
+        beams[k] = carry ? (fill ? 0xFFFFFFFFu : 0u) : beams[k];
+        carry = carry || (c && b == (uint32_t)k);
+    }
+}
+
 // Tile::leave on a laser stack (laser.rs:199-202 -> :157-162 -> :50-55): every layer whose bit is off is
 // re-lit from its offset to the end, unless the source is disabled.  `doit`: the agent is alive (world.rs:483).
 template <int LM>
@@ -185,6 +201,7 @@ LLE_HD void lasers_leave(uint32_t (&beams)[LM], uint64_t lay, bool doit, const M
         const uint32_t m = beam_get<LM>(beams, b);
         const bool c = doit && (e & LAY_VALID) && !((m >> off) & 1u) && ((mv.enabled >> b) & 1u);
         beam_set_if<LM>(beams, b, c, m | (0xFFFFFFFFu << off));  // bits beyond the length are trimmed by canonicalise()
+        chain_rest<LM>(beams, b, c, true, mv.chain);
     }
 }
 
@@ -198,6 +215,7 @@ LLE_HD void lasers_pre_enter(uint32_t (&beams)[LM], uint64_t lay, uint32_t agent
         const bool c = alive && (e & LAY_VALID) && colour == agent && ((mv.enabled >> b) & 1u);
         const uint32_t m = beam_get<LM>(beams, b);
         beam_set_if<LM>(beams, b, c, m & ((1u << off) - 1u));
+        chain_rest<LM>(beams, b, c, false, mv.chain);
     }
 }
 

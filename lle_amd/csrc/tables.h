@@ -3,9 +3,18 @@
 // One map compiles to a flat "blob": a MapHeader followed by 16-byte aligned sections.  The kernel copies the
 // sections into LDS verbatim (same offsets), so the host compiler alone defines the layout.
 //
+// Beam WORDS.  A beam (`LaserBeam{Vec<bool>}`, laser.rs:15-21) is stored as ceil(len / 32) consecutive 32-bit words: word w of
+// source s is index source_word[s] + w, bit k of it = cell 32 w + k of the beam.  Every table below, every kernel and LLE_BUF_BEAMS
+// speak of WORDS ("beam b" = word b): MapHeader.L is their number, MapHeader.n_sources the number of sources.  A map whose
+// beams all fit one word (every map of the reference's repository, every BASELINE configuration) has L == n_sources and
+// word == laser_id -- nothing changes for it.  A longer beam is CHAINED: chain_mask bit b says that word b continues the beam of
+// word b - 1, and a re-light / cut that reaches the end of a word fills / clears every following word of the chain
+// (LaserBeam::turn_on / turn_off run to the end of the Vec, laser.rs:50-59).  Chained maps always carry at least five words (the
+// compiler pads with empty ones), so that they take the kernels' LDS-record form of the beam masks (step_lanes.hpp BM), the only
+// one that walks chains: the register form of maps with at most four sources stays as it was.
 //   cell_lay [HW] u64 : up to 4 laser layers of the cell, OUTERMOST first (a later source wraps an earlier one,
 //                       reference src/core/parsing/world_config.rs:223-247), 16 bits each:
-//                         bit 0 valid | bits 1-5 beam (laser_id) | bits 6-10 offset | bits 11-15 colour
+//                         bit 0 valid | bits 1-5 beam word | bits 6-10 bit within the word | bits 11-15 colour
 //                       colour 31 = "no agent has this colour" (reference colours >= n_agents are legal, Q5)
 //   cell_meta[HW] u32 : bits 0-2 kind | bits 3-7 gem index | bits 8-11 static walk mask (bit = Action N,S,E,W:
 //                       neighbour in bounds and not Wall/LaserSource, reference world.rs:351-356, tile.rs:63-73)
@@ -32,7 +41,7 @@ enum CellKind : uint32_t { K_FLOOR = 0, K_WALL = 1, K_VOID = 2, K_EXIT = 3, K_GE
 constexpr int MAX_AGENTS = 16;
 constexpr int MAX_SOURCES = 32;
 constexpr int MAX_GEMS = 32;
-constexpr int MAX_BEAM_LEN = 32;
+constexpr int MAX_BEAM_LEN = 32;      // bits of one beam WORD (a beam is a chain of words)
 constexpr int MAX_CELL_LAYERS = 4;
 constexpr uint32_t NO_GEM = 63;
 constexpr uint32_t NO_COLOUR = 31;
@@ -79,7 +88,13 @@ struct MapHeader {
     // planes); chunks [pes_head_lo, pes_head_lo + pes_head_n) of the BARE template.  0 when a source of the map itself has
     // a colour >= n_agents (its layer then aliases those planes, quirk Q5).
     uint32_t pes_head_lo, pes_head_n;
-    uint32_t head_pad[6];  // (pads the header to 512 B: the table sections behind it start on a 128-byte line)
+    // beam words (top of this file): L counts words; sources and their chains
+    uint32_t n_sources;                  // laser sources of the map (LaserSource tiles); == L unless a beam is longer than 32 cells
+    uint32_t chain_mask;                 // bit b: word b continues the beam of word b - 1
+    uint32_t word_mask;                  // bit b: word b belongs to a source (0: padding of a chained map)
+    uint8_t word_source[MAX_SOURCES];    // source (laser_id) of word b
+    uint8_t source_word[MAX_SOURCES];    // first word of source s
+    uint32_t head_pad[19];  // (pads the header to 640 B: the table sections behind it start on a 128-byte line)
 };
 static_assert(sizeof(MapHeader) % 128 == 0, "the sections start on a 128-byte line (the LDS copy loads 1 KiB per wave instruction)");
 

@@ -84,7 +84,8 @@ class BatchedLLE:
         self._t = 0
         # auto-resets under randomize_lasers re-colour inside the step kernel (LLE_STEP_RECOLOUR_RESETS) unless a cell
         # of the map carries more than two laser layers (then: a launch of lle_batch_reset_sources per step)
-        self._recolour_in_step = self.randomize_lasers and all(m.max_cell_layers <= 2 for m in self.world.maps)
+        # or a beam is longer than 32 cells (the in-kernel draw is per beam word)
+        self._recolour_in_step = self.randomize_lasers and all(m.max_cell_layers <= 2 and m.n_beam_words == m.n_sources for m in self.world.maps)
         self._fused = None  # output tensors + lle_env_outputs of the one-launch step (step(..., fused=True))
         self._bound = {}    # bound calls over persistent buffers (step(..., persistent=True)): BatchedWorld.bound_*
 

@@ -70,7 +70,7 @@ class GpuWorld:
 
     def beam_bits(self, laser_id):
         from lle_amd import _decode
-        return _decode.beam_bits(self.w._state()["beams"], laser_id, self.w._map.sources()[laser_id].length)
+        return _decode.beam_bits(self.w._state()["beams"], self.w._map.source_first_words()[laser_id], self.w._map.sources()[laser_id].length)
 
     def set_source(self, laser_id, enabled=None, colour=None):
         src = self.w.laser_sources[laser_id]

@@ -76,7 +76,7 @@ class SimBatch:
         self.set_engine(DEFAULT_ENGINE[0])
         self.map = _capi.Map(text)  # static description through the product's host-only map functions
         m = self.map
-        A, Ls = m.n_agents, max(m.n_sources, 1)
+        A, Ls = m.n_agents, max(m.n_beam_words, 1)  # (LLE_BUF_BEAMS holds beam WORDS: == n_sources unless a beam is longer than 32 cells)
         self.shapes = {"pos": (n, A, 2), "bits": (n,), "gems": (n,), "beams": (n, Ls), "avail": (n, A), "actions": (n, A),
                        "err": (n,), "evcount": (n,), "events": (n, 2 * A), "done": (n,), "obs": (n, m.obs_stride),
                        "stats": (8,), "req_pos": (n, A, 2), "req_gems": (n,), "req_alive": (n,)}
@@ -241,7 +241,7 @@ class SimWorld:
         return _decode.lasers_listing(self.b.map.laser_tiles(), self.b.map.sources(), self.b.buf("beams")[0])
 
     def beam_bits(self, laser_id):
-        return _decode.beam_bits(self.b.buf("beams")[0], laser_id, self.b.map.sources()[laser_id].length)
+        return _decode.beam_bits(self.b.buf("beams")[0], self.b.map.source_first_words()[laser_id], self.b.map.sources()[laser_id].length)
 
     def set_source(self, laser_id, enabled=None, colour=None):
         self.b.set_source(laser_id, enabled, colour)

@@ -67,7 +67,7 @@ static uint32_t lanes_step_g(Env<AM, LM>& s, const uint32_t (&act)[AM], uint32_t
     std::vector<uint32_t> bm_exact(bm, bm + (L > 0 ? L : 1)), full_exact(beam_full, beam_full + (L > 0 ? L : 1));
     step_lanes<G, LR, ML1, PES, CWM, SHORTCUT, BM>(mv.cell_lay, mv.cell_meta, A, L, mv.W, mv.max_layers, beam_full_r, a, me, env_ok, enabled, colw,
                                                    actv, pos, av, alive, arrived, occ, gems, beams, err, evw, n_ev, meta_step, stepped, passes,
-                                                   BM ? bm_exact.data() : nullptr, BM ? full_exact.data() : nullptr);
+                                                   BM ? bm_exact.data() : nullptr, BM ? full_exact.data() : nullptr, BM ? mv.chain : 0u);
     const uint32_t e = uniform<G>(err);
     if (!uniform<G>(stepped)) return e;
     avail_lanes<G>(a, me, pos, occ, alive, arrived, meta_step, av);
@@ -115,6 +115,7 @@ static void run(hs_batch* b, int mode, uint32_t flags, uint64_t seed, uint64_t t
     mv.hdr = hdr; mv.W = (int)hdr->W; mv.A = A; mv.L = L; mv.G = (int)hdr->G;
     mv.enabled = hdr->enabled_mask; mv.max_layers = hdr->max_layers;
     mv.per_env = false;
+    mv.chain = hdr->chain_mask;
     const uint64_t* dyn = reinterpret_cast<const uint64_t*>(blob + hdr->off_dyn);
     std::vector<int8_t> tmpl(blob + hdr->off_template, blob + hdr->off_template + hdr->obs_stride);
     const uint32_t amask = (1u << A) - 1u;
@@ -352,24 +353,31 @@ void hs_set_sources(hs_batch* b, const uint8_t* colours, const uint32_t* enabled
         for (int64_t env = 0; env < b->n; env++)
             for (int l = 0; l < L; l++) b->src_colour[env * 32 + l] = h.beam_colour[l];
     }
+    // (the caller speaks of SOURCES -- colours [n][n_sources], bit s of the enabled mask --, the tables of beam WORDS: tables.h)
+    const int S = (int)h.n_sources;
     for (int64_t env = 0; env < b->n; env++) {
         if (mask && !mask[env]) continue;
         bool bad = false, crosses = false;
         if (colours)
             for (int l = 0; l < L; l++) {
-                const int c = colours[env * L + l];
+                if (!((h.word_mask >> l) & 1u)) continue;
+                const int c = colours[env * S + h.word_source[l]];
                 bad |= c >= A;
                 crosses |= c < A && !((h.colour_ok[l] >> c) & 1u);
             }
         b->err[env] = bad ? ENV_INVALID_COLOUR : (crosses ? ENV_COLOUR_CROSSES_START : 0);
         if (bad || crosses) continue;
-        const uint32_t lmask = L >= 32 ? 0xFFFFFFFFu : ((1u << L) - 1u);
-        const uint32_t new_en = enabled ? (enabled[env] & lmask) : b->src_enabled[env];
+        uint32_t new_en = b->src_enabled[env];
+        if (enabled) {
+            new_en = 0u;
+            for (int l = 0; l < L; l++) new_en |= ((enabled[env] >> h.word_source[l]) & 1u) << l;
+            new_en &= h.word_mask;
+        }
         for (int l = 0; l < L; l++) {
             const bool was = (b->src_enabled[env] >> l) & 1u, now = (new_en >> l) & 1u;
             if (was && !now) b->beams[env * L + l] = 0u;                 // LaserBeam::disable (laser.rs:74-77)
             if (!was && now) b->beams[env * L + l] = h.beam_full[l];     // LaserBeam::enable  (laser.rs:69-72)
-            if (colours) b->src_colour[env * 32 + l] = colours[env * L + l];
+            if (colours && ((h.word_mask >> l) & 1u)) b->src_colour[env * 32 + l] = colours[env * S + h.word_source[l]];
         }
         b->src_enabled[env] = new_en;
     }

@@ -2,8 +2,10 @@
 import numpy as np
 
 
-def unpack_engine(bufs, A, G, L, beam_stride, C, H, W):
-    """bufs: dict name -> numpy array in the LLE_BUF_* layout.  Returns the oracle's canonical layout."""
+def unpack_engine(bufs, A, G, L, beam_stride, C, H, W, first_words=None):
+    """bufs: dict name -> numpy array in the LLE_BUF_* layout.  Returns the oracle's canonical layout.
+    first_words: first beam WORD of every source (Map.source_first_words(); None: word == laser_id, i.e. no beam of the map is
+    longer than 32 cells): offset k of source s is bit k % 32 of word first_words[s] + k // 32."""
     n = bufs["bits"].shape[0]
     bits = bufs["bits"].astype(np.uint64)
     ar = np.arange(A, dtype=np.uint64)
@@ -15,7 +17,15 @@ def unpack_engine(bufs, A, G, L, beam_stride, C, H, W):
         "gems": ((bufs["gems"].astype(np.uint64)[:, None] >> np.arange(G, dtype=np.uint64)) & 1).astype(np.uint8),
         "avail": bufs["avail"].reshape(n, A).astype(np.uint8),
     }
-    if L:
+    if L and first_words is not None and beam_stride > 32:
+        bm = bufs["beams"].reshape(n, -1).astype(np.uint64)
+        k = np.arange(beam_stride)
+        words = np.minimum(np.asarray(first_words)[:, None] + k[None, :] // 32, bm.shape[1] - 1)  # [L, beam_stride]
+        out["beams"] = ((bm[:, words] >> (k % 32).astype(np.uint64)[None, None, :]) & 1).astype(np.uint8)
+        # (offsets beyond a shorter beam's words would read another source's word: the oracle reports 0 there)
+        n_words = np.diff(list(first_words) + [bm.shape[1]])
+        out["beams"] *= (k[None, :] < 32 * n_words[:, None]).astype(np.uint8)[None]
+    elif L:
         bm = bufs["beams"].reshape(n, -1)[:, :L].astype(np.uint64)
         out["beams"] = ((bm[:, :, None] >> np.arange(beam_stride, dtype=np.uint64)) & 1).astype(np.uint8)
     else:

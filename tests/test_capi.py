@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in sorted(declared) if not hasattr(L, s)]
     assert not missing, f"liblle_hip.so lacks {missing}"
     assert declared == set(_capi.EXPORTS)
-    assert L.lle_abi_version() == 1
+    assert L.lle_abi_version() == 2
 
 
 def test_no_device_fails_loudly():
@@ -274,15 +274,25 @@ def test_limits_are_refused_loudly(oracle_mod):
     def corridor(n):  # a source followed by n free cells: a beam of n cells (agent 0's own colour, so its start may lie on it)
         return "L0E " + ". " * (n - 2) + "S0 X"
     ok = _capi.Map(corridor(32))
-    assert ok.max_beam_len == 32 and ok.width == 33
+    assert ok.max_beam_len == 32 and ok.width == 33 and ok.n_beam_words == ok.n_sources == 1
     o = oracle_mod.OracleWorld(corridor(32))
     assert [s.length for s in ok.sources()] == [s[5] for s in o.sources()] == [32]
+    # round 4: a beam is a CHAIN of 32-cell words (tables.h): any beam a map of at most 255 x 255 can hold is accepted ...
+    for n in (33, 40, 64, 65, 253):
+        m, o = _capi.Map(corridor(n)), oracle_mod.OracleWorld(corridor(n))
+        assert [s.length for s in m.sources()] == [s[5] for s in o.sources()] == [n] and m.max_beam_len == n
+        assert m.n_sources == 1 and m.n_beam_words == max(5, -(-n // 32)) and m.source_first_words() == [0]  # (padded to the record form's 5 words)
+        tiles = m.laser_tiles()
+        assert [(t.offset, t.word, t.bit) for t in tiles] == [(k, k // 32, k % 32) for k in range(n)]
+    assert World(corridor(40)).n_agents == 1
+    # ... and what is refused is the TOTAL number of words: 32 over all beams of a map
+    rows_of_40 = lambda k: "\n".join("L0E " + ". " * 40 for _ in range(k)) + "\nS0 X" + " ." * 39  # k beams of 40 cells = 2 words each
+    assert _capi.Map(rows_of_40(16)).n_beam_words == 32
     with pytest.raises(_capi.MapParseError) as e:
-        _capi.Map(corridor(33))
+        _capi.Map(rows_of_40(17))
     assert e.value.kind == "Limit"
-    assert oracle_mod.OracleWorld(corridor(33)).sources()[0][5] == 33  # (legal in the reference: laser.rs:15-21 has no bound)
     with pytest.raises(ParsingError, match="static limit"):
-        World(corridor(40))
+        World(rows_of_40(17))
     with pytest.raises(_capi.MapParseError) as e:  # 17 agents
         _capi.Map(" ".join(f"S{k}" for k in range(17)) + "\n" + " ".join("X" for _ in range(17)))
     assert e.value.kind == "Limit"
