@@ -10,7 +10,9 @@ import random
 DELTA = {"N": (-1, 0), "E": (0, 1), "S": (1, 0), "W": (0, -1)}
 
 
-def generate(height=32, width=32, n_agents=8, n_lasers=8, n_gems=8, n_exits=None, wall_fraction=0.10, n_voids=4, seed=0):
+def generate(height=32, width=32, n_agents=8, n_lasers=8, n_gems=8, n_exits=None, wall_fraction=0.10, n_voids=4, seed=0, max_beam=31):
+    """max_beam: longest beam a source may get (31 keeps the maps of earlier rounds, config5 among them, bit for bit; up to 254 for
+    maps with beams of several 32-cell words)."""
     rng = random.Random(seed)
     n_exits = n_agents + 2 if n_exits is None else n_exits
     for _attempt in range(1000):
@@ -34,7 +36,7 @@ def generate(height=32, width=32, n_agents=8, n_lasers=8, n_gems=8, n_exits=None
                 while 0 <= y < height and 0 <= x < width and grid[y][x] == ".":
                     beam.append((y, x))
                     y, x = y + di, x + dj
-                if not (2 <= len(beam) <= 31):
+                if not (2 <= len(beam) <= max_beam):
                     continue
                 grid[i][j] = f"L{colour % n_agents}{d}"
                 for c in beam:

@@ -305,6 +305,17 @@ class OracleBatch:
         self.A, self.G, self.Ls, self.H, self.W = w.n_agents, w.n_gems, w.n_sources, w.height, w.width
         self.C = 2 * self.A + 4
         self.beam_stride = max([s[5] for s in w.sources()] + [1])
+        # where the engines under test keep a beam (include/lle_hip.h lle_map_info.n_beam_words): ceil(len / 32) consecutive 32-bit
+        # words per source, at least one; offset k of source s = bit k % 32 of word first_words[s] + k // 32
+        self.first_words, nw = [], 0
+        for src in w.sources():
+            self.first_words.append(nw)
+            nw += max(1, -(-int(src[5]) // 32))
+
+    @property
+    def dims(self):
+        """The arguments of tests.parity_util.unpack_engine behind `bufs`."""
+        return (self.A, self.G, self.Ls, self.beam_stride, self.C, self.H, self.W, self.first_words)
 
     def __del__(self):
         if getattr(self, "h", None):

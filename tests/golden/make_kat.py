@@ -572,6 +572,76 @@ case("derived_gem_collect_one_of_two", "src/bindings/tiles/pygem.rs:52-66", map=
      script=[reset(), step([E], events=[[GEM, 0]]), collect_gem((0, 2)), expect(gems=[True, True], n_gems_collected=2),
              step([E], n_events=0), step([E], events=[[EXIT, 0]])])
 
+# --------------------------------------------------------------------------- beams longer than 32 cells (derived)
+# `LaserBeam.beam` is a Vec<bool> (src/core/tiles/laser.rs:15-21): no bound on its length; turn_on / turn_off run from an offset to the
+# END of the Vec (:50-59).  No reference test holds a beam of more than 12 cells, so everything here is derived from those lines and
+# from move_agents (src/core/world.rs:477-505); the kernels store such a beam as a chain of 32-cell words (tables.h), and these cases sit
+# on the word boundary (offsets 31 / 32) and behind it.
+def _grid(h, w, cells):
+    rows = [["."] * w for _ in range(h)]
+    for (i, j), t in cells.items():
+        rows[i][j] = t
+    return "\n".join(" ".join(r) for r in rows)
+
+
+# 3 x 40: the beam of L0E at (0, 0) covers (0, 1) ... (0, 38): 38 cells, offset = column - 1; agents walk up into it from row 1
+LONG = _grid(3, 40, {(0, 0): "L0E", (0, 39): "@", (1, 36): "S0", (1, 38): "S1", (2, 0): "X", (2, 1): "X"})
+LONG_FAR = _grid(3, 40, {(0, 0): "L0E", (0, 39): "@", (1, 11): "S0", (1, 38): "S1", (2, 0): "X", (2, 1): "X"})
+ON38 = [True] * 38
+
+case("derived_long_beam_traced_and_lit", "src/core/parsing/world_config.rs:203-250", map=LONG,
+     static={"n_sources": 1, "sources": [[0, 0, 0]]},
+     script=[reset(), expect(beam_len={"0": 38}, beam_bits={"0": ON38}, n_lasers=38, all_lasers="on",
+                             lasers_on=[[0, 1, True], [0, 32, True], [0, 33, True], [0, 38, True]],
+                             obs_cells=[[2, 0, 0, -1], [2, 0, 1, 1], [2, 0, 32, 1], [2, 0, 33, 1], [2, 0, 38, 1], [2, 0, 39, 0]])])
+# the owner walks in at offset 35 (second word): bits 35 .. 37 go off, nothing before them (laser.rs:173-182, :57-59)
+case("derived_long_beam_owner_cuts_at_offset_35", "src/core/tiles/laser.rs:173-182", map=LONG,
+     script=[reset(), step([N, STAY], n_events=0),
+             expect(positions=[[0, 36], [1, 38]], alive=[True, True], beam_bits={"0": [True] * 35 + [False] * 3},
+                    lasers_on=[[0, 35, True], [0, 36, False], [0, 37, False], [0, 38, False]],
+                    obs_cells=[[2, 0, 35, 1], [2, 0, 36, 0], [2, 0, 38, 0]]),
+             step([S, STAY], n_events=0), expect(beam_bits={"0": ON38})])  # it leaves: re-lit from offset 35 on (laser.rs:157-162)
+# another agent walks into the lit tile at offset 37: dies there (laser.rs:184-197) -- and lives when the owner cuts upstream in the same step
+case("derived_long_beam_death_at_offset_37", "src/core/tiles/laser.rs:184-197", map=LONG,
+     script=[reset(), step([STAY, N], events=[[DIED, 1]]), expect(alive=[True, False], beam_bits={"0": ON38}),
+             reset(), step([N, N], n_events=0), expect(alive=[True, True], positions=[[0, 36], [0, 38]], beam_bits={"0": [True] * 35 + [False] * 3})])
+# the owner cuts in the FIRST word (offset 10): every bit behind it goes off, the whole second word included; leaving re-lights them all
+case("derived_long_beam_cut_and_relight_across_the_word_boundary", "src/core/tiles/laser.rs:50-59", map=LONG_FAR,
+     script=[reset(), step([N, STAY], n_events=0), expect(beam_bits={"0": [True] * 10 + [False] * 28}, lasers_on=[[0, 32, False], [0, 33, False], [0, 38, False]]),
+             step([STAY, N], n_events=0), expect(alive=[True, True], positions=[[0, 11], [0, 38]]),   # offset 37 is dark: safe
+             step([E, STAY], n_events=0), expect(beam_bits={"0": [True] * 11 + [False] * 27}),         # re-lit from 10, cut again from 11
+             step([S, STAY], events=[[DIED, 1]]),                                                      # the owner leaves: all on again, agent 1 stands in it
+             expect(alive=[True, False], beam_bits={"0": ON38})])
+# the owner starts ON its beam behind the boundary: World::reset cuts from there (world.rs:411-432 -> laser.rs:173-182)
+case("derived_long_beam_owner_starts_at_offset_33", "src/core/world.rs:411-432",
+     map=_grid(2, 40, {(0, 0): "L0E", (0, 34): "S0", (0, 39): "@", (1, 0): "X"}),
+     script=[reset(), expect(beam_bits={"0": [True] * 33 + [False] * 5}, lasers_on=[[0, 33, True], [0, 34, False], [0, 38, False]]),
+             step([S], n_events=0), expect(beam_bits={"0": ON38}), reset(), expect(beam_bits={"0": [True] * 33 + [False] * 5})])
+# quirk Q1 (stale re-light) ACROSS the boundary.  L1S at (0, 12) lights (1, 12) only (a wall below); L0E at (1, 0) lights (1, 1) ... (1, 38).
+# Step 1: the owner of the long beam (agent 0) walks in at offset 10.  Step 2: it moves on to the crossing at offset 11 -- leave re-lights
+# from 10, pre_enter cuts from 11, enter: the inner beam (colour 1) is lit -> it dies; agent 1 walks into offset 33 (dark: cut) and lives.
+# Pass 2 (somebody died): agent 1 leaves its dark tile -> re-lights 33 .. 37; the dead owner no longer cuts; agent 1 re-enters a lit tile of
+# another colour -> dies (tests/world_integration_tests.rs:279-309 is the same mechanism on 3 cells).  Final beam: on x 11, off x 22, on x 5.
+Q1_LONG = _grid(3, 40, {(0, 12): "L1S", (1, 0): "L0E", (1, 39): "@", (2, 0): "X", (2, 1): "X", (2, 11): "S0", (2, 12): "@", (2, 34): "S1"})
+case("derived_long_beam_stale_relight_across_the_word_boundary", "src/core/world.rs:464-505", map=Q1_LONG,
+     static={"n_sources": 2, "sources": [[0, 12, 1], [1, 0, 0]]},
+     script=[reset(), expect(beam_len={"0": 1, "1": 38}),
+             step([N, STAY], n_events=0), expect(beam_bits={"1": [True] * 10 + [False] * 28}),
+             step([E, N], events=[[DIED, 0], [DIED, 1]]),
+             expect(alive=[False, False], positions=[[1, 12], [1, 34]], beam_bits={"0": [True], "1": [True] * 11 + [False] * 22 + [True] * 5},
+                    lasers_on=[[1, 11, True], [1, 12, False], [1, 32, False], [1, 33, False], [1, 34, True], [1, 38, True]])])
+# LaserSource.disable / enable on a long beam: every cell off / on (laser.rs:69-77); a colour change recolours every cell (laser.rs:79-86)
+case("derived_long_beam_disable_enable_recolour", "src/core/tiles/laser.rs:69-86", map=LONG,
+     script=[reset(), source(0, enabled=False), expect(all_lasers="off", beam_bits={"0": [False] * 38}),
+             step([STAY, N], n_events=0), expect(alive=[True, True]),
+             source(0, enabled=True), expect(all_lasers="on", beam_bits={"0": ON38}),
+             source(0, colour=1), expect(all_laser_colour=1, obs_cells=[[3, 0, 0, -1], [3, 0, 33, 1], [2, 0, 33, 0]])])
+# get_state / set_state with a long beam: the beams are re-derived from positions and alive flags (world.rs:515-597)
+case("derived_long_beam_set_state", "src/core/world.rs:515-597", map=LONG,
+     script=[reset(), set_state([[0, 34], [1, 38]], [], n_events=0), expect(beam_bits={"0": [True] * 33 + [False] * 5}),
+             set_state([[1, 36], [0, 38]], [], alive=[True, False], events=[[DIED, 1]]), expect(alive=[True, False], beam_bits={"0": ON38}),
+             set_state([[1, 36], [0, 38]], [], error="InvalidWorldState")])  # (asked alive, dies on entering: world.rs:588-594)
+
 if __name__ == "__main__":
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kat_world.json")
     with open(out, "w") as f:

@@ -6,6 +6,7 @@
 // maps.txt: maps separated by a line "===".  Per map: rollouts with sampled actions, the first half of the steps without
 // auto-reset (corpses pile up: quirks Q1 / Q2), the second half with.  Exit code 0 = no difference, 1 = a difference
 // (printed), other = a sanitizer report.
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -62,7 +63,7 @@ int main(int argc, char** argv) {
         else maps.back() += line + "\n";
     }
     if (maps.back().empty()) maps.pop_back();
-    int64_t env_steps = 0, deaths = 0, passes = 0, exits_taken = 0, exits_refused = 0;
+    int64_t env_steps = 0, deaths = 0, passes = 0, exits_taken = 0, exits_refused = 0, long_beams = 0;
     for (size_t m = 0; m < maps.size(); m++) {
         const std::string& text = maps[m];
         int perr = 0, oerr = 0;
@@ -75,11 +76,15 @@ int main(int argc, char** argv) {
         hs_set_engine(hb, engine);
         ow_world* w0 = ow_batch_world(ob, 0);
         const int A = ow_n_agents(w0), G = ow_n_gems(w0), L = ow_n_sources(w0), H = ow_height(w0), W = ow_width(w0);
-        const int C = 2 * A + 4, bs = 32, Ls = L ? L : 1;
+        const int C = 2 * A + 4, Ls = L ? L : 1;
         const size_t row = (size_t)C * H * W;
-        lle::Map cm;  // the product's map compiler: row pitch of the host simulator's observation buffer
+        lle::Map cm;  // the product's map compiler: row pitch of the host simulator's observation buffer, layout of the beam words
         if (lle::parse_map(text.c_str(), text.size(), cm) != 0) return fail("parse: the map compiler refused the map", m, 0, 0, text);
         const size_t pitch = (size_t)cm.header.obs_stride;
+        int bs = 32;  // cells per beam in the oracle's dump: the longest beam (beams of more than 32 cells are chains of words, tables.h)
+        for (const auto& src : cm.sources) bs = std::max(bs, (int)src.beam.size());
+        const int Lw = cm.n_words() ? cm.n_words() : 1;
+        long_beams += bs > 32;
         std::vector<uint8_t> o_act(n * A), o_evc(n), o_ev(n * 4 * A), o_pos(n * A * 2), o_alive(n * A), o_arr(n * A), o_occ(n * A),
             o_gems(n * (G ? G : 1)), o_beams(n * Ls * bs), o_avail(n * A);
         std::vector<int32_t> o_err(n);
@@ -140,8 +145,8 @@ int main(int argc, char** argv) {
                 for (int g = 0; g < G; g++)
                     if (((gems[e] >> g) & 1) != o_gems[e * G + g]) return fail("gems", m, t, e, text);
                 for (int s = 0; s < L; s++)
-                    for (int k = 0; k < bs; k++)
-                        if (((beams[e * L + s] >> k) & 1) != o_beams[((size_t)e * L + s) * bs + k]) return fail("beams", m, t, e, text);
+                    for (int k = 0; k < (int)cm.sources[(size_t)s].beam.size(); k++)
+                        if (((beams[e * Lw + cm.word_of(s, k)] >> lle::Map::bit_of(k)) & 1) != o_beams[((size_t)e * L + s) * bs + k]) return fail("beams", m, t, e, text);
                 if (std::memcmp(obs + e * pitch, o_obs.data() + e * row, row) != 0) return fail("obs", m, t, e, text);
             }
             env_steps += n;
@@ -152,8 +157,8 @@ int main(int argc, char** argv) {
         hs_free(hb);
         ow_batch_free(ob);
     }
-    std::printf("OK maps=%zu env_steps=%lld deaths=%lld exits_taken=%lld exits_refused=%lld lane_passes=%lld engine=%d\n", maps.size(), (long long)env_steps, (long long)deaths,
-                (long long)exits_taken, (long long)exits_refused,
+    std::printf("OK maps=%zu env_steps=%lld deaths=%lld exits_taken=%lld exits_refused=%lld long_beam_maps=%lld lane_passes=%lld engine=%d\n", maps.size(), (long long)env_steps, (long long)deaths,
+                (long long)exits_taken, (long long)exits_refused, (long long)long_beams,
                 (long long)passes, engine);
     return 0;
 }

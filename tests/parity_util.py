@@ -120,6 +120,24 @@ def _add_generated():
 _add_generated()
 
 
+def _grid(h, w, cells):
+    rows = [["."] * w for _ in range(h)]
+    for (i, j), t in cells.items():
+        rows[i][j] = t
+    return "\n".join(" ".join(r) for r in rows)
+
+
+# beams longer than 32 cells (a chain of beam words, lle_amd/csrc/tables.h): corridors, a crossing behind the word boundary, several
+# long beams, gems / exits / voids under them, three words
+LONG_MAPS = {
+    "long_corridor": _grid(3, 40, {(0, 0): "L0E", (0, 39): "@", (1, 36): "S0", (1, 38): "S1", (2, 0): "X", (2, 1): "X", (0, 20): "G", (0, 35): "G"}),
+    "long_q1": _grid(3, 40, {(0, 12): "L1S", (1, 0): "L0E", (1, 39): "@", (2, 0): "X", (2, 1): "X", (2, 11): "S0", (2, 12): "@", (2, 34): "S1"}),
+    "long_crossing": _grid(6, 44, {(2, 0): "L0E", (3, 43): "L1W", (0, 36): "L2S", (5, 8): "L1N", (1, 10): "S0", (4, 20): "S1", (1, 30): "S2",
+                                   (5, 0): "X", (5, 1): "X", (5, 2): "X", (2, 40): "G", (3, 3): "G", (2, 36): "V", (3, 35): "X", (4, 36): "G"}),
+    "long_three_words": _grid(2, 72, {(0, 0): "L0E", (1, 5): "S0", (1, 40): "S1", (1, 70): "S2", (1, 0): "X", (1, 1): "X", (1, 2): "X", (0, 66): "G"}),
+}
+
+
 def legal_colours(maps, colours):
     """Random per-env source colours made acceptable to lle_batch_set_sources: a colour that would put another agent's start
     on the source's beam (refused with LLE_ENV_COLOUR_CROSSES_START, like the binding's LaserSource.set_colour,

@@ -5,17 +5,19 @@ import numpy as np
 import pytest
 
 from oracle.levels import LEVELS
-from tests.parity_util import EXTRA_MAPS, assert_state_equal, assert_step_equal, legal_colours, unpack_engine
+from tests.parity_util import EXTRA_MAPS, LONG_MAPS, assert_state_equal, assert_step_equal, legal_colours, unpack_engine
 
 pytestmark = pytest.mark.gpu
 
 MAPS = {"level6": LEVELS[6], "level5": LEVELS[5], "level1_no_lasers": LEVELS[1], "nested": EXTRA_MAPS["nested"], "three_beams": EXTRA_MAPS["three_beams"],
         "four_layers": EXTRA_MAPS["four_layers"], "q1": EXTRA_MAPS["q1"], "many_agents": EXTRA_MAPS["many_agents"],
-        "gen_20_lasers": EXTRA_MAPS["gen_20_lasers"]}
+        "gen_20_lasers": EXTRA_MAPS["gen_20_lasers"],
+        # beams longer than 32 cells (chains of beam words): the caller still speaks of sources, colours [n][n_sources]
+        "long_q1": LONG_MAPS["long_q1"], "long_crossing": LONG_MAPS["long_crossing"]}
 
 
 def dims_of(ob):
-    return (ob.A, ob.G, ob.Ls, ob.beam_stride, ob.C, ob.H, ob.W)
+    return ob.dims
 
 
 def check(bw, ob, ostep, where):
@@ -87,10 +89,13 @@ def test_random_colours_and_flags_per_env(oracle_mod, name):
             check(bw, ob, None, f"{name} after masked reset {episode}")
     got_c = bw.src_colour.cpu().numpy()
     got_e = bw.src_enabled.cpu().numpy()
+    fw = ob.first_words  # (LLE_BUF_SRC_COLOUR / _ENABLED are per beam WORD; every word of a source carries its colour and flag)
+    words_of = [range(fw[l], fw[l + 1] if l + 1 < L else max(fw[l] + 1, -(-ob.world(0).sources()[l][5] // 32) + fw[l])) for l in range(L)]
     for e in range(0, n, 37):
         srcs = ob.world(e).sources()
-        assert [int(c) for c in got_c[e]] == [s[3] for s in srcs]
-        assert [(int(got_e[e]) >> l) & 1 for l in range(L)] == [int(s[4]) for s in srcs]
+        for l in range(L):
+            assert all(int(got_c[e][w]) == srcs[l][3] for w in words_of[l]), (e, l)
+            assert all((int(got_e[e]) >> w) & 1 == int(srcs[l][4]) for w in words_of[l]), (e, l)
 
 
 def test_invalid_colour_is_refused_per_env(oracle_mod):

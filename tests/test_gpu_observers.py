@@ -7,12 +7,13 @@ import pytest
 from oracle.levels import LEVELS
 from tests.kat_observers_runner import _Base, load_cases, run_case
 from tests.observer_checks import compare_all
-from tests.parity_util import EXTRA_MAPS
+from tests.parity_util import EXTRA_MAPS, LONG_MAPS
 
 pytestmark = pytest.mark.gpu
 
 MAPS = {f"level{k}": v for k, v in LEVELS.items()}
 MAPS.update(EXTRA_MAPS)
+MAPS.update(LONG_MAPS)  # beams longer than 32 cells: chains of beam words (tables.h)
 CASES = load_cases()
 
 

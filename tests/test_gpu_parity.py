@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle.levels import LEVELS
-from tests.parity_util import EXTRA_MAPS, assert_state_equal, assert_step_equal, legal_colours, unpack_engine
+from tests.parity_util import EXTRA_MAPS, LONG_MAPS, assert_state_equal, assert_step_equal, legal_colours, unpack_engine
 
 pytestmark = pytest.mark.gpu
 
@@ -667,3 +667,63 @@ def test_row_rotation_changes_nothing(oracle_mod, monkeypatch, name):
             for t in range(10, 16):
                 ostep = ob.step(None, auto_reset=True, seed=21, t=t)
             check(bw, ob, ostep, f"{name} rotate={rotate} heads={heads} rollout")
+
+
+@pytest.mark.parametrize("name", list(LONG_MAPS))
+def test_long_beams(oracle_mod, name):
+    """Beams longer than 32 cells: a chain of 32-cell beam words (lle_amd/csrc/tables.h; the reference's LaserBeam is a Vec<bool>,
+    src/core/tiles/laser.rs:15-21).  The step kernel takes the LDS-record form of the masks and walks the chains; reset / set_state /
+    observe run the lane-per-env engine.  Random rollouts with and without auto-reset, a fused rollout, random set_state requests and
+    a snapshot round trip against the oracle's Vec<bool> beams, on a ragged batch."""
+    import torch
+
+    from lle_amd import BatchedWorld
+
+    text = LONG_MAPS[name]
+    n = 1000 + 11
+    ob = oracle_mod.OracleBatch(text, n)
+    bw = BatchedWorld(text, n)
+    assert bw.map.max_beam_len > 32 and bw.map.n_beam_words >= 5 and bw.map.n_sources == ob.Ls and bw.beams.shape == (n, bw.map.n_beam_words)
+
+    def chk(ostep, where):
+        eng = unpack_engine(bw.host_buffers(), *ob.dims)
+        if ostep is not None:
+            assert_step_equal(eng, ostep, where)
+        assert_state_equal(eng, ob.dump(), where)
+    chk(None, f"{name} after reset")
+    t = 0
+    for auto in (False, True):
+        for _ in range(40):
+            bw.step(sample=True, auto_reset=auto, seed=31, t=t, env_offset=9)
+            chk(ob.step(None, auto_reset=auto, seed=31, t=t, env_offset=9), f"{name} auto_reset={auto} t={t}")
+            t += 1
+    snap = bw.snapshot()
+    bw.rollout(12, auto_reset=True, seed=31, t=t, env_offset=9)
+    for k in range(12):
+        ostep = ob.step(None, auto_reset=True, seed=31, t=t + k, env_offset=9)
+    chk(ostep, f"{name} fused rollout")
+    # World.set_state on random requests (the beams are re-derived: world.rs:515-597)
+    rng = np.random.default_rng(5)
+    A, G = ob.A, ob.G
+    pos = np.stack([rng.integers(0, ob.H, size=(n, A)), rng.integers(0, ob.W, size=(n, A))], axis=-1).astype(np.uint8)
+    gems = rng.random((n, G)) < 0.3
+    alive = rng.random((n, A)) < 0.8
+    bw.set_state(torch.from_numpy(pos), torch.from_numpy(gems), torch.from_numpy(alive))
+    err = bw.err.cpu().numpy()
+    codes = {"InvalidWorldState": 0x40, "OutOfWorldPosition": 0x41, "InvalidAgentPosition": 0x42}
+    for e in range(n):
+        w = ob.world(e)
+        try:
+            w.set_state([tuple(int(v) for v in p) for p in pos[e]], [bool(v) for v in gems[e]], [bool(v) for v in alive[e]])
+            want = 0
+        except oracle_mod.OracleError as ex:
+            want = codes[str(ex)]
+        assert int(err[e]) == want, (name, e, int(err[e]), want)
+    chk(None, f"{name} after set_state")
+    bw.restore(snap)
+    bw.t = t
+    ob2 = oracle_mod.OracleBatch(text, n)  # (replay to the snapshot point)
+    for k in range(t):
+        ob2.step(None, auto_reset=k >= 40, seed=31, t=k, env_offset=9, want_obs=False)
+    eng = unpack_engine(bw.host_buffers(), *ob2.dims)
+    assert_state_equal(eng, ob2.dump(), f"{name} after restore")

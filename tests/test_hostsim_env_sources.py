@@ -5,11 +5,12 @@ import numpy as np
 import pytest
 
 from oracle.levels import LEVELS
-from tests.parity_util import EXTRA_MAPS, assert_state_equal, assert_step_equal, legal_colours, unpack_engine
+from tests.parity_util import EXTRA_MAPS, LONG_MAPS, assert_state_equal, assert_step_equal, legal_colours, unpack_engine
 from tests.test_hostsim_parity import sim_bufs
 
 MAPS = {"level6": LEVELS[6], "nested": EXTRA_MAPS["nested"], "three_beams": EXTRA_MAPS["three_beams"],
-        "four_layers": EXTRA_MAPS["four_layers"], "many_agents": EXTRA_MAPS["many_agents"], "gen_20_lasers": EXTRA_MAPS["gen_20_lasers"]}
+        "four_layers": EXTRA_MAPS["four_layers"], "many_agents": EXTRA_MAPS["many_agents"], "gen_20_lasers": EXTRA_MAPS["gen_20_lasers"],
+        "long_q1": LONG_MAPS["long_q1"], "long_crossing": LONG_MAPS["long_crossing"]}  # (beams of several words: colours stay per SOURCE)
 
 
 @pytest.mark.parametrize("name", list(MAPS))
@@ -21,7 +22,7 @@ def test_random_colours_and_flags_per_env(oracle_mod, name):
     n = 48
     ob = oracle_mod.OracleBatch(text, n)
     sb = hostsim.SimBatch(text, n)
-    dims = (ob.A, ob.G, ob.Ls, ob.beam_stride, ob.C, ob.H, ob.W)
+    dims = ob.dims
     A, L = ob.A, sb.map.n_sources
     is_on = np.array([[bool(s[4]) for s in ob.world(0).sources()]] * n)
     rng = np.random.default_rng(11)

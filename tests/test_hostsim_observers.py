@@ -4,10 +4,11 @@ import pytest
 
 from oracle.levels import LEVELS
 from tests.observer_checks import compare_all
-from tests.parity_util import EXTRA_MAPS
+from tests.parity_util import EXTRA_MAPS, LONG_MAPS
 
 MAPS = {f"level{k}": v for k, v in LEVELS.items()}
 MAPS.update(EXTRA_MAPS)
+MAPS.update(LONG_MAPS)  # beams longer than 32 cells: chains of beam words (tables.h)
 
 
 @pytest.mark.parametrize("name", list(MAPS))

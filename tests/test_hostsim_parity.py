@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from oracle.levels import LEVELS
-from tests.parity_util import EXTRA_MAPS, assert_state_equal, assert_step_equal, unpack_engine
+from tests.parity_util import EXTRA_MAPS, LONG_MAPS, assert_state_equal, assert_step_equal, unpack_engine
 
 MAPS = {f"level{k}": v for k, v in LEVELS.items()}
 MAPS.update(EXTRA_MAPS)
@@ -35,6 +35,33 @@ def test_random_rollout(oracle_mod, name, auto_reset):
         assert_state_equal(eng, ob.dump(), f"{name} t={t}")
     for e in range(0, n, 17):
         assert ob.world(e).panics()[0] == 0
+
+
+@pytest.mark.parametrize("name", list(LONG_MAPS))
+@pytest.mark.parametrize("engine", ["env", "lanes", "lanes_no_shortcut"])
+def test_long_beams_random_rollout(oracle_mod, name, engine):
+    """Beams longer than 32 cells (chains of beam words, tables.h): both host engines -- step_logic.hpp (one lane per environment:
+    reset / set_state / world_kernel) and step_lanes.hpp (one lane per agent, the LDS-record form that walks the chains) -- against the
+    oracle's Vec<bool> beams on random rollouts with and without auto-reset, then random set_state requests."""
+    from lle_amd import _capi
+    from tests import hostsim
+
+    text = LONG_MAPS[name]
+    n, steps = 128, 80
+    ob = oracle_mod.OracleBatch(text, n)
+    sb = hostsim.SimBatch(text, n)
+    sb.set_engine(engine)
+    assert ob.beam_stride > 32 and sb.map.n_beam_words >= 5 and sb.map.n_sources == ob.Ls
+    assert_state_equal(unpack_engine(sim_bufs(sb), *ob.dims), ob.dump(), f"{name} after reset")
+    for auto_reset in (False, True):
+        flags = _capi.LLE_STEP_SAMPLE_ACTIONS | (_capi.LLE_STEP_AUTO_RESET if auto_reset else 0)
+        for t in range(steps):
+            ostep = ob.step(None, auto_reset=auto_reset, seed=77, t=t, env_offset=3)
+            sb.step(None, flags=flags, seed=77, t=t, env_offset=3)
+            eng = unpack_engine(sim_bufs(sb), *ob.dims)
+            assert_step_equal(eng, ostep, f"{name} {engine} auto_reset={auto_reset} t={t}")
+            assert_state_equal(eng, ob.dump(), f"{name} {engine} auto_reset={auto_reset} t={t}")
+    assert (sb.buf("beams")[:, sb.map.n_beam_words:] == 0).all() if sb.buf("beams").shape[1] > sb.map.n_beam_words else True
 
 
 def test_invalid_actions_leave_env_untouched(oracle_mod):

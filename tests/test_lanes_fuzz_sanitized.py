@@ -91,6 +91,34 @@ def test_generated_small_maps(fuzzer, tmp_path, engine):
     assert int(out["exits_taken"]) > 50 and int(out["exits_refused"]) > 50, out
 
 
+def generated_wide_maps(count, seed=0):
+    """2-5 rows x 34-80 columns with few walls: horizontal beams of more than 32 cells (chains of beam words, tables.h)."""
+    from lle_amd import mapgen
+    rng = random.Random(seed)
+    maps = []
+    while len(maps) < count:
+        h, w = rng.randint(2, 5), rng.randint(34, 80)
+        agents = rng.randint(1, 5)
+        kw = dict(height=h, width=w, n_agents=agents, n_lasers=rng.randint(1, 6), n_gems=rng.randint(0, 4), n_exits=agents + rng.randint(0, 2),
+                  wall_fraction=rng.choice([0.0, 0.0, 0.01, 0.03]), n_voids=rng.randint(0, 2), seed=rng.randint(0, 1 << 30), max_beam=254)
+        try:
+            maps.append(mapgen.generate(**kw))
+        except (RuntimeError, ValueError, IndexError):
+            continue
+    return maps
+
+
+@pytest.mark.parametrize("engine", [1, 2], ids=["shortcut", "every_pass"])
+def test_long_beam_maps(fuzzer, tmp_path, engine):
+    """Beams longer than 32 cells under ASan / UBSan: the hand-made maps of tests/parity_util.py LONG_MAPS (long rollouts) and 300
+    generated wide maps, with exits moving every 16 steps; most of the generated maps must actually hold a long beam."""
+    from tests.parity_util import LONG_MAPS
+    out = run(fuzzer, list(LONG_MAPS.values()), tmp_path / "long.txt", envs=48, steps=160, engine=engine)
+    assert int(out["long_beam_maps"]) == len(LONG_MAPS) and int(out["deaths"]) > 1000
+    out = run(fuzzer, generated_wide_maps(300, seed=10 + engine), tmp_path / "wide.txt", envs=12, steps=48, engine=engine)
+    assert int(out["maps"]) == 300 and int(out["long_beam_maps"]) > 120 and int(out["deaths"]) > 3000, out
+
+
 def test_shortcut_saves_passes_and_nothing_else(fuzzer, tmp_path):
     maps = generated_maps(200, seed=7)
     a = run(fuzzer, maps, tmp_path / "a.txt", envs=12, steps=40, engine=1)
