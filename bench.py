@@ -446,6 +446,32 @@ def measure_config(torch, timer, dev, map_or_text, n_envs, algo_bytes, steps, la
     return out
 
 
+def measure_multi_map(torch, timer, dev, steps, single_map_kernel_ms):
+    """SURVEY.md section 8(d), stretch variant of configs[4]: per-env DISTINCT maps -- 1 024 (and 4 096) different `mapgen.config5(seed)`
+    maps in one batch of 65 536 envs, 64 (16) envs per map (lle_batch_create_multi: what a learner on generated maps steps,
+    python/lle/generator/world_builder.py:84-89).  Same launches as the cfg5 block: sampled actions + auto-reset + int8 layered obs."""
+    from lle_amd import BatchedWorld, mapgen
+    out = {"what": "BASELINE configs[4] with a different generated 32x32 map per block of envs; kernel_ms by HIP events", "n_envs": 65536,
+           "single_map_kernel_ms": single_map_kernel_ms}
+    for n_maps in (1024, 4096):
+        per = 65536 // n_maps
+        t0 = time.perf_counter()
+        bw = BatchedWorld([mapgen.config5(seed) for seed in range(n_maps)], 65536, device=dev)
+        create_s = time.perf_counter() - t0
+        fn = stepper(bw)
+        for _ in range(max(10, steps // 10)):
+            fn()
+        wall, ms = timer.run(fn, steps)
+        achieved = ALGO_BYTES_CFG5 * 65536 / (ms * 1e-3) / 1e9
+        out[f"maps{n_maps}_x{per}"] = {"n_maps": n_maps, "envs_per_map": per, "steps": steps, "kernel_ms": ms, "ms_per_step": wall / steps * 1e3,
+                                       "achieved_GBps": achieved, "vs_single_map": ms / single_map_kernel_ms if single_map_kernel_ms else None,
+                                       "create_s": create_s, "table_MB": n_maps * bw.maps[0].table_bytes / 1e6, "kernel": bw.kernel_info(),
+                                       "rollout_stats": bw.stats()}
+        del bw, fn
+        torch.cuda.empty_cache()
+    return out
+
+
 def measure_consumer_loop(torch, timer, dev, steps):
     """step -> reader -> step on the launch stream: what a policy does between two steps is READ the observation (its first layer),
     which changes what the Infinity Cache holds when the next step rewrites the rows.  Reader = an int8 -> fp16 cast of the whole
@@ -737,8 +763,9 @@ def main():
                                                      "cfg5_bytes_per_launch", fill_ceiling=True),
         }
 
-    lle_step = observers = consumer = None
+    lle_step = observers = consumer = multi = None
     if world == 1 and not args.no_configs:
+        multi = measure_multi_map(torch, timer, dev, max(args.config_steps // 2, 50), cfgs["cfg5_32x32_a8_l8_65536"]["kernel_ms"])
         lle_step = measure_lle_step(torch, timer, dev, n, max(args.config_steps, 200))
         observers = measure_observers(torch, timer, dev, n, max(args.config_steps, 200))
         consumer = measure_consumer_loop(torch, timer, dev, max(args.config_steps, 200))
@@ -803,6 +830,8 @@ def main():
             out["observers"] = observers
         if consumer:
             out["consumer_loop"] = consumer
+        if multi:
+            out["cfg5_multi_map"] = multi
         for key, (T, R, launches, fe) in zip(("fused_rollout", "fused_rollout_double_buffer"), fused):
             # per env-step: obs 1872 + actions 4 + reward 4 + err/evcount/done 3 + events 8, state r/w (48 B) once per launch
             fused_bytes = 1891 + 48.0 / T

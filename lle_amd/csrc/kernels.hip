@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
                 bool bad = false, crosses = false;
 #pragma unroll
                 for (int b = 0; b < LM; b++) {
-                    if (b < L && (fill || K.colours_in)) {
+                    if (b < L && ((hdr->word_mask >> b) & 1u) && (fill || K.colours_in)) {  // (not the padding words of a chained map)
                         const uint32_t c = fill ? (uint32_t)hdr->beam_colour[b] : (uint32_t)K.colours_in[env * n_src + hdr->word_source[b]];
                         bad |= !fill && c >= (uint32_t)A;  // "Agent ID is greater than the number of agents"
                         // "... would cross the start position of agent ..." (pylaser_source.rs:121-139; MapHeader.colour_ok)

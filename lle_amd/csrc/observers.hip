@@ -772,7 +772,7 @@ bool view_kernel_fits(const ViewHeader& v, uint32_t n_views, bool pes, uint32_t 
     return view_lds(v, n_views, 1, pes, n_elems) <= OBS_LDS_LIMIT;
 }
 
-// workgroups must not straddle two maps: envs_per_map is a multiple of 64 = 4 waves x OBS_ENVS_PER_WAVE
+// workgroups must not straddle two maps: envs_per_map is a multiple of OBS_ENVS_PER_WAVE (narrower workgroups below 64 envs per map)
 static uint32_t cap_wpw(uint32_t wpw, const MapSel& M) {
     while (wpw > 1 && M.envs_per_map && M.envs_per_map % (int64_t)(wpw * OBS_ENVS_PER_WAVE) != 0) wpw >>= 1;
     return wpw;

@@ -136,7 +136,10 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     for (int b = 0; b < LR; b++) h_init_beams[b] = (!BM && b < L) ? initp->beams[b] : 0u;
     const int64_t n_here = (K.env_limit - env0) < (int64_t)EPW ? (K.env_limit - env0) : (int64_t)EPW;
     const uint32_t amask = (1u << A) - 1u;
-    const uint32_t rot = row_rotation(wave_id, EPW, n_here, K.flags);  // the row this wavefront starts its stream at (obs_stream.hpp)
+    // (the row this wavefront starts its stream at, obs_stream.hpp row_rotation: computed where it is used, from values that are live
+    // there anyway -- carried across the state machine it cost the tightest instantiations a spilled register)
+    // Single-step launches only: a fused rollout's instantiations sit at the register cap already (the extra value cost them 12 B of scratch).
+#define LLE_ROT() (ROLL ? 0u : row_rotation(wave_id, EPW, n_here, K.flags))
     LLE_STAMP(0);
 
     // ---- packed state: own position / availability, and the env-wide words replicated in the group's lanes
@@ -267,8 +270,8 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         // head stores and in the state machine -- where it would wait for the stores as well
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         if (head_n && n_here > 0) {
-            if (K.flags & LAUNCH_WRITE_THROUGH) store_heads<true>(P.obs, h_obs_stride, env0, n_here, head_lo, head_n, head_v, lane, rot);
-            else store_heads<false>(P.obs, h_obs_stride, env0, n_here, head_lo, head_n, head_v, lane, rot);
+            if (K.flags & LAUNCH_WRITE_THROUGH) store_heads<true>(P.obs, h_obs_stride, env0, n_here, head_lo, head_n, head_v, lane, LLE_ROT());
+            else store_heads<false>(P.obs, h_obs_stride, env0, n_here, head_lo, head_n, head_v, lane, LLE_ROT());
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS only: not the head stores' acknowledgements
     } else {
@@ -560,12 +563,12 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         const bool wt = (K.flags & LAUNCH_WRITE_THROUGH) != 0;  // see stream_store (obs_stream.hpp)
         if (PES) {
             if (wt) write_observations_env<true, HEAD>(A, L, h_HW, h_n_elems, h_n_chunks, h_obs_stride, elems, bare, tmpl, scratch, scr_stride,
-                                                       obs_out, env0, n_here, lane, nullptr, 0xFFFFFFFFu, head_lo, head_n, rot);
+                                                       obs_out, env0, n_here, lane, nullptr, 0xFFFFFFFFu, head_lo, head_n, LLE_ROT());
             else write_observations_env<false, HEAD>(A, L, h_HW, h_n_elems, h_n_chunks, h_obs_stride, elems, bare, tmpl, scratch, scr_stride,
-                                                     obs_out, env0, n_here, lane, nullptr, 0xFFFFFFFFu, head_lo, head_n, rot);
+                                                     obs_out, env0, n_here, lane, nullptr, 0xFFFFFFFFu, head_lo, head_n, LLE_ROT());
         } else {
-            if (wt) write_observations<true, HEAD>(A, L, h_D, h_n_chunks, h_obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane, head_lo, head_n, rot);
-            else write_observations<false, HEAD>(A, L, h_D, h_n_chunks, h_obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane, head_lo, head_n, rot);
+            if (wt) write_observations<true, HEAD>(A, L, h_D, h_n_chunks, h_obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane, head_lo, head_n, LLE_ROT());
+            else write_observations<false, HEAD>(A, L, h_D, h_n_chunks, h_obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane, head_lo, head_n, LLE_ROT());
         }
     }
     wave_sync();
@@ -592,6 +595,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         for (int b = (int)a; b < L; b += G) beams_out[b] = bm[b];
 #undef LLE_LATE
 #undef LLE_LOAD_STATE
+#undef LLE_ROT
     }
     flush_stats(P.stats, wave_id, cnt, A, lane, PRE_STATS, stats_old);
     if (ROLL && stamps) {

@@ -159,3 +159,39 @@ def test_env_outputs_on_blocks_of_maps():
                 assert torch.equal(state.view(torch.int32), w.observe_as(_capi.LLE_OBS_NORMALIZED_STATE, 0).view(torch.int32)), (rnd, t)
                 assert torch.equal(reward, w.reward_multi_objective()) and torch.equal(done, w.done), (rnd, t)
                 assert torch.equal(avail.view(torch.bool), w.available_actions(walkable)), (rnd, t, walkable)
+
+
+@pytest.mark.parametrize("n_maps,per", [(1024, 64), (256, 16), (96, 48)])
+def test_one_map_per_block_at_scale(oracle_mod, n_maps, per):
+    """SURVEY.md section 8(d), stretch variant of config 5: per-env distinct maps -- what a learner on generated maps trains on
+    (python/lle/generator/world_builder.py:84-89).  1 024 distinct `mapgen.config5(seed)` maps x 64 envs (the bench's
+    `cfg5_multi_map` block), 256 x 16 (one wavefront's worth per map: envs_per_map may be any multiple of 16) and 96 x 48: every block
+    against its own oracle batch on the global action stream -- state after every step, the full check (events, observation) on a
+    sample of the blocks."""
+    from lle_amd import BatchedWorld, mapgen
+
+    texts = [mapgen.config5(seed) for seed in range(n_maps)]
+    n = n_maps * per
+    bw = BatchedWorld(texts, n)
+    sample = sorted(set([0, 1, n_maps // 2, n_maps - 1] + list(range(0, n_maps, max(1, n_maps // 24)))))
+    obs = {m: oracle_mod.OracleBatch(texts[m], per) for m in sample}
+
+    def check(osteps, where):
+        bufs = bw.host_buffers()
+        for m, ob in obs.items():
+            sl = slice(m * per, (m + 1) * per)
+            eng = unpack_engine({k: v[sl] for k, v in bufs.items()}, *ob.dims)
+            if osteps is not None:
+                assert_step_equal(eng, osteps[m], f"{where} map {m}")
+            assert_state_equal(eng, ob.dump(), f"{where} map {m}")
+    check(None, "after creation")
+    for t in range(12):
+        auto = t >= 4
+        bw.step(sample=True, auto_reset=auto, seed=8, t=t, env_offset=5)
+        check({m: ob.step(None, auto_reset=auto, seed=8, t=t, env_offset=5 + m * per) for m, ob in obs.items()}, f"t={t}")
+    bw.rollout(4, auto_reset=True, seed=8, t=12, env_offset=5)
+    for t in range(12, 16):
+        osteps = {m: ob.step(None, auto_reset=True, seed=8, t=t, env_offset=5 + m * per) for m, ob in obs.items()}
+    check(osteps, "fused rollout")
+    st = bw.stats()
+    assert st["env_steps"] == 16 * n and st["invalid"] == 0
