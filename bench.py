@@ -585,10 +585,12 @@ def measure_observers(torch, timer, dev, n, steps):
         fn = stepper(bw)
         for _ in range(16):
             fn()
-        calls = {f"partial{k}x{k}": bw.bound_observer(_capi.LLE_OBS_PARTIAL, k) for k in (3, 5, 7)}
+        # (outputs larger than the Infinity Cache are placed: k candidate buffers, the one the row stream writes fastest kept)
+        k_place = PLACEMENT_CANDIDATES
+        calls = {f"partial{k}x{k}": bw.bound_observer(_capi.LLE_OBS_PARTIAL, k, placement_candidates=k_place) for k in (3, 5, 7)}
         if label == "level6":  # (config 5's perspective tensor is 10.7 GB: left to tools/lle_prof.py observers)
-            calls["perspective"] = bw.bound_observer(_capi.LLE_OBS_PERSPECTIVE)
-        calls["layered_padded2"] = bw.bound_observer(_capi.LLE_OBS_LAYERED_PADDED, 2)
+            calls["perspective"] = bw.bound_observer(_capi.LLE_OBS_PERSPECTIVE, placement_candidates=k_place)
+        calls["layered_padded2"] = bw.bound_observer(_capi.LLE_OBS_LAYERED_PADDED, 2, placement_candidates=k_place)
         calls["state"] = bw.bound_observer(_capi.LLE_OBS_STATE)
         calls["available_actions"] = bw.bound_available_actions(True)
         calls["available_actions_no_walkable_lasers"] = bw.bound_available_actions(False)
@@ -599,6 +601,8 @@ def measure_observers(torch, timer, dev, n, steps):
             _, ms = timer.run(call, steps)
             nbytes = call.buffer.numel() * call.buffer.element_size()
             blk[name] = {"us": ms * 1e3, "MB": nbytes / 1e6, "GBps": nbytes / (ms * 1e-3) / 1e9}
+            if getattr(call, "placement", None):
+                blk[name]["placement"] = call.placement
         out[label] = blk
         del calls, bw
         torch.cuda.empty_cache()
@@ -729,7 +733,9 @@ def main():
         # (T, R): the ring of args.ring_slots slots is larger than the 256 MB Infinity Cache (true HBM writes); the
         # two-slot ring is a double buffer -- a consumer reads slot t while step t + 1 is written -- and stays in it
         for T, R in ((args.fused_steps, args.ring_slots), (args.fused_steps, 2)):
-            ring = bw.make_ring(R)
+            # (a ring larger than the Infinity Cache is placed like the arenas of the HBM-regime blocks: lle_amd.placement)
+            ring = bw.make_ring(R, placement_candidates=PLACEMENT_CANDIDATES if world == 1 else None)
+            ring_placement = ring.get("placement")
             launches = max(4, max(args.steps, 512) // T)
 
             def roll():
@@ -738,7 +744,7 @@ def main():
                 roll()
             fe, _ = timer.run(roll, launches)
             fe = allreduce_max(fe, cdev) if use_dist else fe
-            fused.append((T, R, launches, fe))
+            fused.append((T, R, launches, fe, ring_placement))
             del ring
 
     A = bw.map.n_agents
@@ -832,7 +838,7 @@ def main():
             out["consumer_loop"] = consumer
         if multi:
             out["cfg5_multi_map"] = multi
-        for key, (T, R, launches, fe) in zip(("fused_rollout", "fused_rollout_double_buffer"), fused):
+        for key, (T, R, launches, fe, ring_placement) in zip(("fused_rollout", "fused_rollout_double_buffer"), fused):
             # per env-step: obs 1872 + actions 4 + reward 4 + err/evcount/done 3 + events 8, state r/w (48 B) once per launch
             fused_bytes = 1891 + 48.0 / T
             ring_mb = R * n * row_stride / 1e6
@@ -845,6 +851,7 @@ def main():
                 "algorithmic_bytes_per_env_step": fused_bytes,
                 "achieved_GBps_per_gpu": fused_bytes * n * launches * T / fe / 1e9,
                 "frac_of_hbm_peak": fused_bytes * n * launches * T / fe / 1e9 / HBM_PEAK_GBS,
+                **({"placement": ring_placement} if ring_placement else {}),
             }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n)

@@ -488,6 +488,12 @@ int lle_batch_autotune(lle_batch* b, double budget_ms, void* stream);
 int lle_batch_tuning(const lle_batch* b, lle_tuning_info* out, char* log_buf, size_t cap);
 void lle_tuning_refresh(void);
 
+/* Placement aid: the step kernel's store pattern (rows_per_wave rows of row_bytes per wavefront, XCD-contiguous blocks) over ANY device
+ * buffer of n_rows x row_bytes bytes, zeros.  Past the Infinity Cache the write rate of a buffer depends on where the allocation landed
+ * (profiles/r04_alloc_probe.md): a host that allocates a trajectory ring or an observer output of that size times this on a few
+ * candidate buffers and keeps the fastest (lle_amd.placement). */
+int lle_probe_fill_rows(void* out_dev, int64_t n_rows, int64_t row_bytes, int rows_per_wave, void* stream);
+
 /* Profiling aid: a consumer's first touch of an observation buffer -- `bytes` int8 values at rows_dev (any of the observation
  * outputs, on the current device) converted to fp16 into out_f16_dev (2 x bytes), the way the first layer of a policy reads
  * `obs` between two steps (python/lle/env/env.py:165-189).  bench.py's `consumer_loop` alternates it with the step. */

@@ -45,7 +45,7 @@ EXPORTS = [
     "lle_comm_unique_id", "lle_comm_create", "lle_comm_create_all", "lle_comm_free", "lle_comm_rank", "lle_batch_stats_allreduce",
     "lle_batch_stats_allreduce_group", "lle_comm_allreduce_i64",
     "lle_batch_stats", "lle_batch_kernel_info", "lle_batch_set_envs_per_wave", "lle_batch_step_stamped", "lle_batch_probe_row_fill",
-    "lle_batch_autotune", "lle_batch_tuning", "lle_tuning_refresh", "lle_probe_read_rows",
+    "lle_batch_autotune", "lle_batch_tuning", "lle_tuning_refresh", "lle_probe_read_rows", "lle_probe_fill_rows",
 ]
 
 
@@ -226,6 +226,8 @@ def lib():
     L.lle_batch_autotune.argtypes = [vp, C.c_double, vp]
     L.lle_batch_tuning.restype = i32
     L.lle_batch_tuning.argtypes = [vp, C.POINTER(TuningInfo), C.c_char_p, C.c_size_t]
+    L.lle_probe_fill_rows.restype = i32
+    L.lle_probe_fill_rows.argtypes = [vp, i64, i64, i32, vp]
     L.lle_probe_read_rows.restype = i32
     L.lle_probe_read_rows.argtypes = [vp, vp, i64, vp]
     L.lle_tuning_refresh.restype = None

@@ -272,13 +272,24 @@ class BatchedWorld:
             self.t = t + 1
         return one_step
 
-    def make_ring(self, slots):
-        """Trajectory rings for `rollout`: obs [R,n,C,H,W] int8, actions [R,n,A] uint8, reward [R,n,4] uint8."""
+    def make_ring(self, slots, placement_candidates=None):
+        """Trajectory rings for `rollout`: obs [R,n,C,H,W] int8, actions [R,n,A] uint8, reward [R,n,4] uint8.
+        placement_candidates: k > 1 samples k allocations of the observation ring and keeps the one the step kernel's store pattern
+        writes fastest (lle_amd.placement; `ring["placement"]` records the timings) -- for rings larger than the 256 MB Infinity Cache."""
+        from . import placement
         m = self.map
         pitch = self._desc["actions"][4][0]
+        shape = (int(slots), self.n_envs, m.obs_stride)
+        k = int(placement_candidates or 1)
+        if k > 1 and shape[0] * shape[1] * shape[2] > placement.INFINITY_CACHE_BYTES:
+            rows, placed = placement.pick_fastest(lambda: torch.zeros(shape, dtype=torch.int8, device=self.device), m.obs_stride, k,
+                                                  rows_per_wave=self.kernel_info()["envs_per_wave"])
+        else:
+            rows, placed = torch.zeros(shape, dtype=torch.int8, device=self.device), None
         ring = {
             "slots": int(slots),
-            "obs_rows": torch.zeros(slots, self.n_envs, m.obs_stride, dtype=torch.int8, device=self.device),
+            "placement": placed,
+            "obs_rows": rows,
             "actions_rows": torch.zeros(slots, self.n_envs, pitch, dtype=torch.uint8, device=self.device),
             "reward": torch.zeros(slots, self.n_envs, 4, dtype=torch.uint8, device=self.device),
         }
@@ -383,15 +394,23 @@ class BatchedWorld:
 
     # ---- bound calls: arguments and output buffer fixed ONCE; per call the C-ABI call on torch's current stream and nothing else.  observe_as() / available_actions() / env_outputs() spend 10-15 us per call in Python (descriptor query,
     # allocation, view construction, argument conversion) around kernels of 4-6 us: a host that steps in a loop uses these.
-    def bound_observer(self, kind, param=0, out=None):
+    def bound_observer(self, kind, param=0, out=None, placement_candidates=None):
         """A zero-argument callable that writes observation `kind` into ONE persistent buffer (`call.out`: the strided view
-        observe_as() returns; overwritten by every call)."""
+        observe_as() returns; overwritten by every call).  placement_candidates: k > 1 samples k allocations of an output larger than
+        the Infinity Cache and keeps the one written fastest (lle_amd.placement; `call.placement`)."""
+        from . import placement
         d = self.obs_desc(kind, param)
         if not d.supported:
             raise IndexError("a laser colour has no layer in this observation (the reference raises IndexError too)")
+        placed = None
         if out is None:
-            out = torch.empty(int(d.bytes) + 256, dtype=torch.uint8, device=self.device)
-            out = out[(-out.data_ptr()) % 256:][: int(d.bytes)]
+            nbytes, k = int(d.bytes), int(placement_candidates or 1)
+            pitch = int(d.stride[0]) * int(d.elem_bytes)  # bytes of one env's record
+            if k > 1 and nbytes > placement.INFINITY_CACHE_BYTES and pitch % 16 == 0 and nbytes % pitch == 0:
+                out, placed = placement.pick_fastest(lambda: torch.empty(nbytes, dtype=torch.uint8, device=self.device), min(pitch, 1 << 24), k)
+            else:
+                out = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+                out = out[(-out.data_ptr()) % 256:][:nbytes]
         assert out.dtype == torch.uint8 and out.is_contiguous() and out.numel() >= d.bytes and out.data_ptr() % 16 == 0
         dt = torch.int8 if d.elem_bytes == 1 else torch.float32
         view = torch.as_strided(out[: int(d.bytes)].view(dt), [int(d.shape[k]) for k in range(d.ndim)], [int(d.stride[k]) for k in range(d.ndim)])
@@ -403,7 +422,7 @@ class BatchedWorld:
             if rc != 0:
                 self._check(rc)
             return view
-        call.out, call.buffer = view, out
+        call.out, call.buffer, call.placement = view, out, placed
         return call
 
     def bound_available_actions(self, walkable_lasers=True, out=None):

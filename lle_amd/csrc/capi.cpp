@@ -1138,6 +1138,18 @@ int lle_batch_probe_row_fill(lle_batch* b, uint32_t value, void* stream) {
     return LLE_OK;
 }
 
+int lle_probe_fill_rows(void* out_dev, int64_t n_rows, int64_t row_bytes, int rows_per_wave, void* stream) {
+    if (!out_dev) return fail(LLE_ERR_NULL, "NULL argument");
+    if (n_rows <= 0 || row_bytes <= 0 || row_bytes % 16 != 0 || row_bytes > (1 << 24) || (reinterpret_cast<uintptr_t>(out_dev) % 16) != 0)
+        return fail(LLE_ERR_ARG, "rows of a positive multiple of 16 bytes, 16-byte aligned");
+    if (rows_per_wave < 1 || rows_per_wave > 64 || (rows_per_wave & (rows_per_wave - 1))) return fail(LLE_ERR_ARG, "rows_per_wave must be a power of two, 1..64");
+    const uint64_t bytes = (uint64_t)n_rows * (uint64_t)row_bytes;
+    HIP_TRY(launch_row_fill_probe(static_cast<int8_t*>(out_dev), n_rows, (uint32_t)row_bytes, (uint32_t)rows_per_wave, 0u, false,
+                                  rotate_rows_pays(StepTune(), bytes, (uint32_t)row_bytes), (hipStream_t)stream));
+    g_status = LLE_OK;
+    return LLE_OK;
+}
+
 int lle_probe_read_rows(const void* rows_dev, void* out_f16_dev, int64_t bytes, void* stream) {
     if (!rows_dev || !out_f16_dev) return fail(LLE_ERR_NULL, "NULL argument");
     if (bytes <= 0 || bytes % 16 != 0 || (reinterpret_cast<uintptr_t>(rows_dev) % 16) != 0 || (reinterpret_cast<uintptr_t>(out_f16_dev) % 16) != 0)

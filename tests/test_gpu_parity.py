@@ -727,3 +727,27 @@ def test_long_beams(oracle_mod, name):
         ob2.step(None, auto_reset=k >= 40, seed=31, t=k, env_offset=9, want_obs=False)
     eng = unpack_engine(bw.host_buffers(), *ob2.dims)
     assert_state_equal(eng, ob2.dump(), f"{name} after restore")
+
+
+def test_placed_rings_and_observer_outputs():
+    """lle_amd.placement: trajectory rings and observer outputs larger than the Infinity Cache may be sampled like the arena
+    (BatchedWorld.make_ring / bound_observer, placement_candidates=k): k candidates timed with the step kernel's store pattern
+    (lle_probe_fill_rows), the fastest kept and zeroed.  Results are those of unplaced buffers; small buffers are not sampled."""
+    import torch
+
+    from lle_amd import BatchedWorld, _capi, placement
+
+    n = 65536
+    a, b = BatchedWorld(LEVELS[6], n), BatchedWorld(LEVELS[6], n)
+    ra, rb = a.make_ring(3, placement_candidates=2), b.make_ring(3)
+    assert ra["placement"]["candidates"] == 2 and len(ra["placement"]["row_fill_us"]) == 2 and all(v > 0 for v in ra["placement"]["row_fill_us"])
+    assert rb["placement"] is None and a.make_ring(1, placement_candidates=4)["placement"] is None  # (126 MB: inside the cache)
+    a.rollout(5, seed=3, ring=ra, ring_pos=0), b.rollout(5, seed=3, ring=rb, ring_pos=0)
+    assert torch.equal(ra["obs_rows"], rb["obs_rows"]) and torch.equal(ra["actions_rows"], rb["actions_rows"]) and torch.equal(ra["reward"], rb["reward"])
+    fa = a.bound_observer(_capi.LLE_OBS_PERSPECTIVE, placement_candidates=2)  # 503 MB
+    fb = b.bound_observer(_capi.LLE_OBS_PERSPECTIVE)
+    assert fa.placement["candidates"] == 2 and fb.placement is None and torch.equal(fa(), fb())
+    small = a.bound_observer(_capi.LLE_OBS_PARTIAL, 3, placement_candidates=4)
+    assert small.placement is None
+    t = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+    assert placement.time_row_fill(t, 1024, rows_per_wave=8) > 0 and int(t.sum()) == 0
