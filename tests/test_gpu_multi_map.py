@@ -128,7 +128,7 @@ def test_mismatched_maps_are_refused():
 
     with pytest.raises(RuntimeError, match="agree"):
         BatchedWorld(["S0 . X", "S0 . . X"], 128)
-    with pytest.raises(RuntimeError, match="multiple of 64"):
+    with pytest.raises(RuntimeError, match="multiple of 16"):
         BatchedWorld(["S0 . X", "S0 X ."], 100)
 
 
