@@ -10,9 +10,11 @@
  *       -Llle_amd -llle_hip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/lle_amd -Wl,-rpath,/opt/rocm/lib
  * Run: examples/c_abi_rollout [n_envs] [steps]      (needs an MI355X; exits non-zero with the library's message otherwise)
  */
+#define _POSIX_C_SOURCE 199309L /* clock_gettime */
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <time.h>
 #include <stdlib.h>
 
 #include "lle_hip.h"
@@ -90,14 +92,18 @@ int main(int argc, char** argv) {
     int64_t zero[8];
     CHECK_LLE(lle_batch_stats(b, zero, 1, stream)); /* reset the counters */
     CHECK_HIP(hipEventRecord(e0, stream));
+    struct timespec h0, h1;
+    clock_gettime(CLOCK_MONOTONIC, &h0);
     for (int t = warmup; t < warmup + steps; t++)
         CHECK_LLE(lle_batch_step(b, NULL, LLE_STEP_SAMPLE_ACTIONS | LLE_STEP_AUTO_RESET, 1234, (uint64_t)t, 0, stream));
+    clock_gettime(CLOCK_MONOTONIC, &h1); /* the calls are issued, nothing has been waited for: the HOST's cost of a step */
     CHECK_HIP(hipEventRecord(e1, stream));
     CHECK_HIP(hipEventSynchronize(e1));
     float ms = 0.f;
     CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
-    printf("%d steps of %lld envs: %.2f us per step, %.2f G agent-steps/s\n", steps, (long long)n, ms * 1e3 / steps,
-           (double)n * A * steps / (ms * 1e-3) / 1e9);
+    printf("%d steps of %lld envs: %.2f us per step, %.2f G agent-steps/s; host: %.2f us per lle_batch_step call to issue\n", steps, (long long)n,
+           ms * 1e3 / steps, (double)n * A * steps / (ms * 1e-3) / 1e9,
+           ((double)(h1.tv_sec - h0.tv_sec) * 1e6 + (double)(h1.tv_nsec - h0.tv_nsec) * 1e-3) / steps);
 
     /* everything LLE.step returns besides the observation, one launch */
     float *state = NULL, *reward = NULL;
