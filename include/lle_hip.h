@@ -399,7 +399,10 @@ typedef struct lle_env_outputs {
     int32_t normalize_state;
     int32_t reward_kind;
     int32_t walkable_lasers;
-    int32_t pad;
+    int32_t partial_k;       /* window size of `partial` (odd, 1..15) */
+    int8_t* partial;         /* lle_batch_step_outputs only: the partial k x k observation (LLE_OBS_PARTIAL, partial_k; layout of
+                              * lle_batch_obs_desc) written by the step launch itself INSTEAD of the layered one -- what
+                              * `LLE(obs_type="partial7x7").step` returns, in one launch.  NULL: not wanted. */
 } lle_env_outputs;
 int lle_batch_env_outputs(lle_batch* b, const lle_env_outputs* out, void* stream);
 
@@ -407,7 +410,10 @@ int lle_batch_env_outputs(lle_batch* b, const lle_env_outputs* out, void* stream
  * by the step kernel itself, from registers (the separate launch costs 4.9 us at 65 536 envs, all of it launch boundary).
  * Same results as the two calls in a row.  `out->available` needs walkable_lasers != 0 (LLE_ERR_UNSUPPORTED otherwise: the
  * mask without moves into foreign beams reads the neighbours' laser stacks -- use lle_batch_env_outputs for it).
- * The struct is mirrored in device memory and re-uploaded only when it changes: keep the output buffers across steps. */
+ * The struct is mirrored in device memory and re-uploaded only when it changes: keep the output buffers across steps.
+ * With `out->partial` set the launch writes the partial observation (python/lle/observations.py:312-369) from the state machine's
+ * own records instead of LLE_BUF_OBS: 38-41 us -> one launch for a step of `LLE(obs_type="partial7x7")` (maps with at most 8 beam
+ * words, the map's own sources; LLE_ERR_UNSUPPORTED otherwise: lle_batch_observe_as behind the step). */
 int lle_batch_step_outputs(lle_batch* b, const uint8_t* actions_dev, uint32_t flags, uint64_t seed, uint64_t t, int64_t env_offset,
                            const lle_env_outputs* out, void* stream);
 

@@ -67,7 +67,7 @@ class EnvOutputs(C.Structure):
     """lle_env_outputs (include/lle_hip.h)."""
     _fields_ = [("state", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p), ("available", C.c_void_p),
                 ("alive", C.c_void_p), ("arrived", C.c_void_p), ("normalize_state", C.c_int32), ("reward_kind", C.c_int32),
-                ("walkable_lasers", C.c_int32), ("pad", C.c_int32)]
+                ("walkable_lasers", C.c_int32), ("partial_k", C.c_int32), ("partial", C.c_void_p)]
 
 
 class TuningInfo(C.Structure):

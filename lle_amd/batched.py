@@ -479,15 +479,31 @@ class BatchedWorld:
         return out.view(torch.bool)
 
     def make_env_outputs(self, state=None, normalize_state=False, reward=None, multi_objective=False, done=None, available=None,
-                         walkable_lasers=True, alive=None, arrived=None):
-        """The lle_env_outputs struct over the given device tensors (None = not wanted); see env_outputs for the shapes."""
+                         walkable_lasers=True, alive=None, arrived=None, partial=None, partial_k=0):
+        """The lle_env_outputs struct over the given device tensors (None = not wanted); see env_outputs for the shapes.
+        partial / partial_k (step(env_out=...) only): a uint8 buffer of obs_desc(LLE_OBS_PARTIAL, k).bytes bytes that the STEP launch fills
+        with the partial k x k observation instead of writing the layered one (lle_batch_step_outputs; `partial_view(buf, k)` shapes it)."""
         o = _capi.EnvOutputs()
+        if partial is not None:
+            assert partial.dtype == torch.uint8 and partial.is_contiguous() and partial.device == self.device and partial.data_ptr() % 16 == 0
+            assert partial.numel() >= int(self.obs_desc(_capi.LLE_OBS_PARTIAL, int(partial_k)).bytes)
+            o.partial, o.partial_k = partial.data_ptr(), int(partial_k)
         for name, t in (("state", state), ("reward", reward), ("done", done), ("available", available), ("alive", alive), ("arrived", arrived)):
             if t is not None:
                 assert t.is_contiguous() and t.device == self.device, name
                 setattr(o, name, t.data_ptr())
         o.normalize_state, o.reward_kind, o.walkable_lasers = int(bool(normalize_state)), int(bool(multi_objective)), int(bool(walkable_lasers))
         return o
+
+    def partial_buffer(self, k):
+        """(buffer, view): a uint8 buffer for make_env_outputs(partial=...) and its int8 view [n, A, 2A + 3, k, k]."""
+        d = self.obs_desc(_capi.LLE_OBS_PARTIAL, int(k))
+        if not d.supported:
+            raise IndexError("a laser colour has no layer in this observation (the reference raises IndexError too)")
+        buf = torch.empty(int(d.bytes) + 256, dtype=torch.uint8, device=self.device)
+        buf = buf[(-buf.data_ptr()) % 256:][: int(d.bytes)]
+        view = torch.as_strided(buf.view(torch.int8), [int(d.shape[q]) for q in range(d.ndim)], [int(d.stride[q]) for q in range(d.ndim)])
+        return buf, view
 
     def env_outputs(self, state=None, normalize_state=False, reward=None, multi_objective=False, done=None, available=None,
                     walkable_lasers=True, alive=None, arrived=None):

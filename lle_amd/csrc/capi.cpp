@@ -706,6 +706,8 @@ int lle_batch_step(lle_batch* b, const uint8_t* actions_dev, uint32_t flags, uin
     return launch(b, KMODE_STEP, K, stream);
 }
 
+static int obs_desc(const lle_batch* b, int kind, int param, lle_obs_desc* d);  // (below)
+
 int lle_batch_step_outputs(lle_batch* b, const uint8_t* actions_dev, uint32_t flags, uint64_t seed, uint64_t t, int64_t env_offset,
                            const lle_env_outputs* out, void* stream) {
     if (!b || !out) return fail(LLE_ERR_NULL, "NULL argument");
@@ -714,8 +716,25 @@ int lle_batch_step_outputs(lle_batch* b, const uint8_t* actions_dev, uint32_t fl
         return fail(LLE_ERR_UNSUPPORTED, "the fused step writes LLE.available_actions with walkable_lasers only: use lle_batch_env_outputs");
     if (b->lane_per_env_step) return fail(LLE_ERR_ARG, "the fused outputs are written by the default step kernel only");
     ON_DEVICE_OF(b);
-    const EnvOutputs O{out->state, out->reward, out->done, out->available, out->alive, out->arrived,
-                       out->normalize_state, out->reward_kind, out->walkable_lasers, b->per_env_sources ? 1 : 0};
+    EnvOutputs O{};
+    O.state = out->state; O.reward = out->reward; O.done = out->done; O.available = out->available; O.alive = out->alive; O.arrived = out->arrived;
+    O.normalize_state = out->normalize_state ? 1 : 0; O.reward_kind = (uint8_t)out->reward_kind; O.walkable_lasers = out->walkable_lasers ? 1 : 0;
+    O.per_env_sources = b->per_env_sources ? 1 : 0;
+    uint32_t partial_E = 0;
+    if (out->partial) {
+        // the partial k x k observation written by the step launch itself (step_kernel MODE 9, partial_stream.hpp)
+        lle_obs_desc d;
+        int rc = obs_desc(b, LLE_OBS_PARTIAL, out->partial_k, &d);
+        if (rc != LLE_OK) return rc;
+        if (!d.supported) return fail(LLE_ERR_UNSUPPORTED, "a laser colour has no layer in this observation (the reference raises IndexError)");
+        if ((reinterpret_cast<uintptr_t>(out->partial) % 16) != 0) return fail(LLE_ERR_ARENA, "the partial observation buffer must be 16-byte aligned");
+        partial_E = step_partial_batch(b->hdr, out->partial_k, b->per_env_sources);
+        if (!partial_E)
+            return fail(LLE_ERR_UNSUPPORTED, "the step launch writes the partial observation for maps with at most 8 beam words and the map's own sources "
+                                             "(not per-environment ones): use lle_batch_observe_as(LLE_OBS_PARTIAL) behind the step");
+        O.partial = out->partial;
+        O.partial_k = (uint32_t)out->partial_k;
+    }
     EnvOutputs* dev = reinterpret_cast<EnvOutputs*>(b->arena + b->layout.off_env_out);
     if (!b->env_out_valid || std::memcmp(&O, &b->env_out_host, sizeof O) != 0) {
         b->env_out_host = O;  // (the source of the copy must outlive it: a member, not the stack)
@@ -724,6 +743,8 @@ int lle_batch_step_outputs(lle_batch* b, const uint8_t* actions_dev, uint32_t fl
     }
     LaunchArgs K{};
     K.flags = flags; K.seed = seed; K.t = t; K.env_offset = env_offset; K.actions_in = actions_dev; K.env_out = dev;
+    K.partial_k = O.partial ? O.partial_k : 0u; K.partial_E = partial_E;
+    if (O.partial && (flags & STEP_RECOLOUR_RESETS)) return fail(LLE_ERR_UNSUPPORTED, "the partial observation of the step launch: the map's own sources only");
     return launch(b, KMODE_STEP, K, stream);
 }
 
@@ -991,8 +1012,11 @@ int lle_batch_env_outputs(lle_batch* b, const lle_env_outputs* out, void* stream
     if (out->reward_kind != 0 && out->reward_kind != 1) return fail(LLE_ERR_ARG, "reward_kind must be 0 (single objective) or 1 (multi objective)");
     ON_DEVICE_OF(b);
     const MapSel M{b->envs_per_map, (uint32_t)b->layout.table_stride, 0u};
-    EnvOutputs O{out->state, out->reward, out->done, out->available, out->alive, out->arrived,
-                 out->normalize_state, out->reward_kind, out->walkable_lasers, b->per_env_sources ? 1 : 0};
+    EnvOutputs O{};
+    O.state = out->state; O.reward = out->reward; O.done = out->done; O.available = out->available; O.alive = out->alive; O.arrived = out->arrived;
+    O.normalize_state = out->normalize_state ? 1 : 0; O.reward_kind = (uint8_t)out->reward_kind; O.walkable_lasers = out->walkable_lasers ? 1 : 0;
+    O.per_env_sources = b->per_env_sources ? 1 : 0;
+    if (out->partial) return fail(LLE_ERR_ARG, "lle_env_outputs.partial is written by lle_batch_step_outputs only (here: lle_batch_observe_as)");
     HIP_TRY(launch_env_outputs(b->hdr, b->ptrs, O, b->n_envs, M, (hipStream_t)stream));
     g_status = LLE_OK;
     return LLE_OK;

@@ -79,6 +79,10 @@ hipError_t launch_step_mode5(int G, int lm, const BatchPtrs& P, const LaunchArgs
 hipError_t launch_step_mode6(int G, int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream);
 hipError_t launch_step_mode7(int G, int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream);
 hipError_t launch_step_mode8(int G, int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream);
+hipError_t launch_step_mode9(int G, int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream);
+// step_kernel MODE 9 (the partial k x k observation written by the step launch): environments per batch of the writer for this map and
+// window, 0 = not served (more than 8 beam words, per-environment sources, or no room in LDS)
+uint32_t step_partial_batch(const MapHeader& h, int k, bool pes);
 bool write_through_pays(uint64_t bytes, uint32_t row_pitch, int chosen = -1);  // store policy of an observation stream (obs_stream.hpp: stream_store)
 hipError_t launch_world_kernel(int mode, const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K, hipStream_t stream);
 // World.step with one lane per agent (the default step path)

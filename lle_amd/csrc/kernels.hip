@@ -16,6 +16,7 @@
 //
 // No MFMA: there is no contraction anywhere on this path.
 #include "kernel_common.hpp"
+#include "partial_stream.hpp"
 
 #include <string.h>
 
@@ -615,9 +616,32 @@ bool rotate_rows_pays(const StepTune& tune, uint64_t row_bytes_per_launch, uint3
     return row_pitch % 128u == 0 && row_bytes_per_launch > WRITE_THROUGH_MAX_BYTES;
 }
 
+// ---- step_kernel MODE 9: LDS of a workgroup and the writer's batch size (partial_stream.hpp; the rule of observers.hip's lane kernel:
+// the largest E whose block of rows stays within 16 KiB per wavefront, halved above 9 KiB while the observer's lanes stay busy)
+static uint32_t partial_step_lds(const MapHeader& h, uint32_t wpw, uint32_t E, int k) {
+    const uint32_t scr_stride = (h.L + h.A + 2) | 1u, pitch = ((h.A * (2 * h.A + 3)) * (uint32_t)(k * k) + 15u) & ~15u;
+    return h.lds_split_table_bytes + (h.L > 4 ? 256u : 0u) + partial_bitmap_bytes(h.H, h.W) + 32u + wpw * (E * pitch + 16u + 64u * scr_stride * 4u) + 64u;
+}
+uint32_t step_partial_batch(const MapHeader& h, int k, bool pes) {
+    if (pes || step_lm((int)h.L) > 8 || k < 1 || k > 15 || !(k & 1)) return 0u;
+    const uint32_t a_pad = (uint32_t)step_group((int)h.A), pitch = ((h.A * (2 * h.A + 3)) * (uint32_t)(k * k) + 15u) & ~15u;
+    const uint32_t s_min = k <= 8 ? 1u : ((uint32_t)k + 3u) / 4u;
+    uint32_t E = 64u / a_pad;
+    while (E > 1 && 64u / (E * a_pad) < s_min) E >>= 1;
+    if (64u / (E * a_pad) < s_min) return 0u;  // (16 agents and a window above 8: an observer's rows do not fit its lanes)
+    while (E > 1 && E * pitch > 16384u) E >>= 1;
+    if (E > 1 && E * pitch > 9216u) {
+        const uint32_t S2 = 64u / ((E / 2u) * a_pad), rl = ((uint32_t)k + S2 - 1u) / S2;
+        if (S2 <= (uint32_t)k && 4u * (uint32_t)k >= 3u * S2 * rl) E >>= 1;
+    }
+    return partial_step_lds(h, 1, E, k) <= LDS_PER_CU ? E : 0u;
+}
+
 bool step_has_row_heads(const MapHeader& h, bool pes) {
     return step_lm((int)h.L) <= 8 && (pes ? h.pes_head_n : h.head_n) != 0;
 }
+
+static bool roll_requested(const LaunchArgs& K) { return K.n_steps > 1 || K.ring_slots || K.stamps; }
 
 hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K_in, hipStream_t stream, const StepTune& tune) {
     LaunchArgs K = K_in;
@@ -650,6 +674,17 @@ hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const Laun
             while (wpw > 1 && K.envs_per_map % (int64_t)(wpw * e) != 0) wpw >>= 1;
         lds = split_lds_bytes(h, wpw, e);
         K.flags |= LAUNCH_SPLIT_ROWS;
+    }
+    if (K.partial_k) {  // the partial observation written by this launch (MODE 9): single steps with the fused outputs, the map's sources
+        if (pes || roll_requested(K) || !K.env_out || !K.partial_E || lm > 8) return hipErrorInvalidValue;
+        wpw = 4;
+        while (wpw > 1 && partial_step_lds(h, wpw, K.partial_E, (int)K.partial_k) > LDS_PER_CU / 2) wpw >>= 1;  // (two workgroups per CU at least)
+        if (K.envs_per_map) {
+            const uint32_t cap = 64u / (uint32_t)G, e = epw < cap ? epw : cap;
+            while (wpw > 1 && K.envs_per_map % (int64_t)(wpw * e) != 0) wpw >>= 1;
+        }
+        K.flags &= ~LAUNCH_SPLIT_ROWS;
+        return launch_step_mode9(G, lm, P, K, n_waves, wpw, partial_step_lds(h, wpw, K.partial_E, (int)K.partial_k), stream);
     }
     // MODE of the instantiation (step_kernel.hpp): per-env sources 3 / 5, several maps 2 / 4, one map 1 / 0 -- the
     // first of each pair with the rollout loop, rings and stamps, the second for single-step launches

@@ -3,6 +3,7 @@
 // in parallel; kernels.hip holds world_kernel and the host-side launch logic.
 #pragma once
 #include "kernel_common.hpp"
+#include "partial_stream.hpp"
 #include "step_lanes.hpp"
 
 namespace lle {
@@ -59,7 +60,10 @@ __device__ __forceinline__ EnvOutputs load_uniform(const EnvOutputs* p) {
 
 template <int G, int LM, int MODE, bool ML1, int LX = -1>
 __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P, LaunchArgs K) {
-    constexpr bool GEN = (MODE >= 2 && MODE <= 5) || MODE == 7 || MODE == 8, ROLL = MODE >= 1 && MODE <= 3;
+    // MODE 9: MODE 4 whose launch writes the PARTIAL k x k observation (python/lle/observations.py:312-369) from the hand-over records
+    // instead of the layered rows (partial_stream.hpp): LLE.step of `obs_type="partial..."` in one launch.  The map's own sources.
+    constexpr bool PARTIAL = MODE == 9;
+    constexpr bool GEN = (MODE >= 2 && MODE <= 5) || MODE == 7 || MODE == 8 || PARTIAL, ROLL = MODE >= 1 && MODE <= 3;
     constexpr bool PES = MODE == 3 || MODE == 5 || MODE == 8;  // (the launcher picks these exactly when LAUNCH_PER_ENV_SOURCES is set)
     // More than 4 sources: the beam masks live in the env's LDS record instead of LM registers of every lane (step_lanes.hpp BM).
     // 4 agents and 8 sources: state machine 11.5 -> 8.9 us, config 5 (8 agents, 8 sources) 41.6 -> 20.1, 20 sources 121 -> 15.
@@ -72,7 +76,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     // the row is split over the wavefronts of the workgroup, see write_observations_split (obs_stream.hpp).  Only the
     // instantiations of maps with more than four agents carry it (rows of 16 KB and more with at most four agents
     // would need maps beyond 36 x 36; those stay on whole-row copies), and not the per-env-sources modes.
-    constexpr bool CAN_SPLIT = G >= 8 && !PES;
+    constexpr bool CAN_SPLIT = G >= 8 && !PES && !PARTIAL;
     constexpr bool HEAD = MODE == 6 || MODE == 7 || MODE == 8;  // MODE 0 / 4 / 5 with the static lines of the rows ahead of the state machine (below)
     const bool split = CAN_SPLIT && (K.flags & LAUNCH_SPLIT_ROWS) != 0;
     // The default instantiation is one step in place and nothing else: the fused rollout (n_steps, trajectory rings)
@@ -107,7 +111,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     const int64_t env = env0 + grp;
     const bool env_ok = grp < EPW && env < K.env_limit;
     const bool me = env_ok && (int)a < A;           // this lane carries a real agent
-    const bool write_obs = hdr->obs_supported && !(K.flags & STEP_NO_OBS);
+    const bool write_obs = !PARTIAL && hdr->obs_supported && !(K.flags & STEP_NO_OBS);
     // Header fields that are needed late (after the first stores) are read HERE, as scalar loads next to the kernel
     // arguments: read where they are used they become vector loads from global memory with a full wait each, three of
     // them in a row between the state machine and the first observation store.
@@ -124,7 +128,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     const uint32_t h_off_recolour = PES ? hdr->off_recolour : 0u, h_off_bare = PES ? hdr->off_bare : 0u;
     const uint32_t h_off_elems = PES ? hdr->off_elems : 0u, h_n_elems = PES ? hdr->n_elems : 0u;
     // (MODE 7: so are the fused LLE.step outputs' descriptor and the header fields of that epilogue)
-    constexpr bool ENV_OUT = MODE == 4 || MODE == 5 || MODE == 7 || MODE == 8;
+    constexpr bool ENV_OUT = MODE == 4 || MODE == 5 || MODE == 7 || MODE == 8 || PARTIAL;
     EnvOutputs O_early = {};
     uint32_t h_G = 0, h_H = 0;
     constexpr bool EARLY_OUT = MODE == 7;  // (MODE 4 / 5 / 8 have no scalar registers to park the descriptor in: they spill vector registers for it;
@@ -253,7 +257,8 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         bt_init = initp->beams[threadIdx.x];
     }
     // (split rows: the pristine static observation stays in global memory, every wavefront copies its slice from there)
-    const uint32_t tab_bytes = split ? hdr->lds_split_table_bytes : hdr->lds_table_bytes, tab_off = hdr->off_cell_lay;
+    // (PARTIAL: no layered row is built, so the pristine template -- the tail of the table section -- stays out of LDS, as with split rows)
+    const uint32_t tab_bytes = (split || PARTIAL) ? hdr->lds_split_table_bytes : hdr->lds_table_bytes, tab_off = hdr->off_cell_lay;
     const uint32_t ext_bytes = PES ? hdr->ext_bytes : 0u;
     if (PES) copy_tables2_to_lds(tables + tab_off, tab_bytes, tables + h_off_bare, ext_bytes, lds, lane, wave_in_wg, waves_per_wg);
     else copy_tables_to_lds(tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
@@ -262,6 +267,14 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     if (BM && (int)threadIdx.x < L) {
         beam_tab[threadIdx.x] = bt_full;
         beam_tab[LM + threadIdx.x] = bt_init;
+    }
+    // PARTIAL: [non-empty bitmap of the map | colour byte of every beam word] behind the tables, one copy per workgroup
+    const uint32_t pm_bytes = PARTIAL ? partial_bitmap_bytes(hdr->H, (uint32_t)W) + 32u : 0u;
+    uint32_t* const part_bm = reinterpret_cast<uint32_t*>(lds + tab_bytes + ext_bytes + bt_bytes);
+    uint8_t* const part_col = lds + tab_bytes + ext_bytes + bt_bytes + (pm_bytes - 32u);
+    if (PARTIAL) {
+        for (uint32_t w = threadIdx.x; w < (pm_bytes - 32u) / 4u; w += blockDim.x) part_bm[w] = 0u;
+        if ((int)threadIdx.x < L) part_col[threadIdx.x] = hdr->beam_colour[threadIdx.x];
     }
     LLE_STAMP(7);
     if (HEAD) {
@@ -283,9 +296,12 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     const uint32_t* cell_meta = reinterpret_cast<const uint32_t*>(lds + (h_off_cell_meta - tab_off));
     const uint64_t* dyn = reinterpret_cast<const uint64_t*>(lds + (h_off_dyn - tab_off));
     const uint32_t scr_stride = (uint32_t)(L + A + 2 + (PES ? CW : 0)) | 1u;
-    const uint32_t priv_bytes = h_obs_stride + 64u * scr_stride * 4u;
-    int8_t* tmpl = reinterpret_cast<int8_t*>(lds + tab_bytes + ext_bytes + bt_bytes + wave_in_wg * priv_bytes);
-    uint32_t* scratch = reinterpret_cast<uint32_t*>(tmpl + h_obs_stride);
+    // a wavefront's private area: [row template | hand-over records]; PARTIAL: [E rows of the partial observation + 16 B | records]
+    const uint32_t part_pitch = PARTIAL ? (((uint32_t)(A * (2 * A + 3)) * K.partial_k * K.partial_k + 15u) & ~15u) : 0u;
+    const uint32_t row_area = PARTIAL ? K.partial_E * part_pitch + 16u : h_obs_stride;
+    const uint32_t priv_bytes = row_area + 64u * scr_stride * 4u;
+    int8_t* tmpl = reinterpret_cast<int8_t*>(lds + tab_bytes + ext_bytes + bt_bytes + pm_bytes + wave_in_wg * priv_bytes);
+    uint32_t* scratch = reinterpret_cast<uint32_t*>(tmpl + row_area);
     const int8_t* bare = reinterpret_cast<const int8_t*>(lds + tab_bytes);
     const uint32_t* elems = reinterpret_cast<const uint32_t*>(lds + tab_bytes + (h_off_elems - h_off_bare));
     // split rows: [tables | one slice per wavefront | the hand-over records of all the workgroup's environments]
@@ -298,6 +314,8 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         const uint4* __restrict__ pristine = reinterpret_cast<const uint4*>(tables + h_off_template) + c_lo;
         uint4* mine = reinterpret_cast<uint4*>(tmpl);
         for (uint32_t c = lane; c < c_hi - c_lo; c += 64) mine[c] = pristine[c];
+    } else if (PARTIAL) {
+        partial_bitmap_fill(part_bm, cell_lay, cell_meta, (int)hdr->H, W);  // (complete behind the barrier in front of the writer, below)
     } else {
         const uint4* pristine = PES ? reinterpret_cast<const uint4*>(bare) : reinterpret_cast<const uint4*>(lds + (h_off_template - tab_off));
         uint4* mine = reinterpret_cast<uint4*>(tmpl);
@@ -533,7 +551,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
                 if (q < CW) sc[L + 2 + A + q] = colw[q];
         }
     }
-    if (me) scratch[grp * scr_stride + L + 2 + a] = a * h_HW + cell_of(pos, W);  // ... | byte index of each agent]
+    if (me) scratch[grp * scr_stride + L + 2 + a] = PARTIAL ? pos : a * h_HW + cell_of(pos, W);  // ... | byte index of each agent (PARTIAL: its packed position)]
     if (split) {
         // the records of the whole workgroup must be in LDS before any wavefront streams its slice.  LDS only: waiting
         // for vmcnt here (what __syncthreads() does) would hold every step of a fused rollout until the previous step's
@@ -545,7 +563,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     LLE_STAMP(4);
     // (deferring it in the single-step launches of MODE 1 / 2 as well measured 1.3-1.5 us SLOWER there: those
     // instantiations already spill, and the deferral lengthens the live ranges)
-    const bool post_first = ROLL || blockIdx.x * 4u >= gridDim.x * 3u;
+    const bool post_first = ROLL || PARTIAL || blockIdx.x * 4u >= gridDim.x * 3u;  // (PARTIAL: the writer wants the state machine's registers)
     if (post_first) post_step();
 
     if (split) {
@@ -559,6 +577,12 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         }
         // fused rollout: the next step's records overwrite these
         if (ROLL && n_steps > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else if (PARTIAL) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the workgroup's bitmap is complete (LDS only: no wait for stores)
+        const EnvOutputs O = load_uniform(K.env_out);
+        if (O.partial && n_here > 0)
+            write_partial<true>(A, L, W, (int)K.partial_k, part_pitch, K.partial_E, h_max_layers, cell_lay, cell_meta, part_bm, part_col, tmpl, scratch,
+                                scr_stride, O.partial, env0, n_here, lane);
     } else if (write_obs && n_here > 0) {
         const bool wt = (K.flags & LAUNCH_WRITE_THROUGH) != 0;  // see stream_store (obs_stream.hpp)
         if (PES) {
@@ -632,7 +656,7 @@ static hipError_t launch_step_mode_gl(const BatchPtrs& P, const LaunchArgs& K, u
 }
 template <int MODE, int G>
 static hipError_t launch_step_mode_g(int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
-    if constexpr (MODE == 6 || MODE == 7 || MODE == 8) {  // (the launcher sends maps with more than 8 sources to MODE 0 / 4 / 5)
+    if constexpr (MODE == 6 || MODE == 7 || MODE == 8 || MODE == 9) {  // (the launcher sends maps with more than 8 sources to MODE 0 / 4 / 5)
         if (lm == 4) return launch_step_mode_gl<MODE, G, 4>(P, K, n_waves, wpw, lds, stream);
         if (lm == 8) return launch_step_mode_gl<MODE, G, 8>(P, K, n_waves, wpw, lds, stream);
         return hipErrorInvalidValue;

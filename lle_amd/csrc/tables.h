@@ -183,7 +183,9 @@ struct EnvOutputs {
     uint8_t* available;
     uint8_t* alive;
     uint8_t* arrived;
-    int32_t normalize_state, reward_kind, walkable_lasers, per_env_sources;
+    int8_t* partial;       // step_kernel MODE 9 only: the partial k x k observation of every env, written by the step launch
+    uint8_t normalize_state, reward_kind, walkable_lasers, per_env_sources;
+    uint32_t partial_k;    // window size of `partial`
 };
 
 // Per-launch arguments.
@@ -197,7 +199,7 @@ struct LaunchArgs {
     const uint8_t* env_mask;   // reset: optional u8[n]
     const uint8_t* actions_in; // step: optional u8[n][A]
     uint32_t old_enabled;      // update_sources: enabled mask before the update
-    uint32_t pad;
+    uint32_t partial_k;        // step_kernel MODE 9: window size of the partial observation this launch writes (0: none)
     // fused rollout (step_kernel only): n_steps consecutive steps per launch; per-step observation / actions / reward
     // counts go to slot (ring_pos + step) % ring_slots of caller-provided trajectory rings (ring_slots = 0: in place)
     uint32_t n_steps, ring_slots;
@@ -214,7 +216,8 @@ struct LaunchArgs {
     // one map.  map_override = m + 1 forces map m (the hidden env that computes a map's reset record).
     int64_t envs_per_map;
     uint32_t table_stride, map_override;
-    uint32_t n_sources, pad3;  // host side only: MapHeader.L, for the launcher's choice of instantiation
+    uint32_t n_sources;        // host side only: MapHeader.L, for the launcher's choice of instantiation
+    uint32_t partial_E;        // step_kernel MODE 9: environments per batch of the partial writer (partial_stream.hpp)
     // step_kernel only: write LLE.step's other outputs in the same launch (lle_batch_step_outputs).  A DEVICE copy of the
     // struct, read with scalar loads where it is used: its six pointers never occupy registers during the state machine.
     const EnvOutputs* env_out;

@@ -87,6 +87,11 @@ class BatchedLLE:
         # or a beam is longer than 32 cells (the in-kernel draw is per beam word)
         self._recolour_in_step = self.randomize_lasers and all(m.max_cell_layers <= 2 and m.n_beam_words == m.n_sources for m in self.world.maps)
         self._fused = None  # output tensors + lle_env_outputs of the one-launch step (step(..., fused=True))
+        # ... which also writes a partial k x k OBSERVATION itself when nobody reads the layered one, the sources are the map's own and
+        # the map has at most 8 beam words (lle_batch_step_outputs: `partial`)
+        self._fused_partial = (self._obs_kind[0] == _capi.LLE_OBS_PARTIAL and not self._needs_layered and not self.randomize_lasers
+                               and all(m.n_beam_words <= 8 for m in self.world.maps)
+                               and self._state_kind[0] in (_capi.LLE_OBS_STATE, _capi.LLE_OBS_NORMALIZED_STATE, _capi.LLE_OBS_PARTIAL))
         self._bound = {}    # bound calls over persistent buffers (step(..., persistent=True)): BatchedWorld.bound_*
 
     @staticmethod
@@ -275,9 +280,14 @@ class BatchedLLE:
             fused_state = self._state_kind[0] in (_capi.LLE_OBS_STATE, _capi.LLE_OBS_NORMALIZED_STATE)
             t = {"state": torch.empty((n, 3 * self.n_agents + w.map.n_gems), dtype=torch.float32, device=dev) if fused_state else None,
                  "reward": torch.empty((n, 4 if self.multi_objective else 1), dtype=torch.float32, device=dev),
-                 "available": torch.empty((n, self.n_agents, 5), dtype=torch.uint8, device=dev)}
+                 "available": torch.empty((n, self.n_agents, 5), dtype=torch.uint8, device=dev), "partial": None, "partial_buf": None}
+            kw = {}
+            if self._fused_partial:
+                # the partial k x k observation written by the step launch itself (lle_batch_step_outputs, step kernel MODE 9)
+                t["partial_buf"], t["partial"] = w.partial_buffer(self._obs_kind[1])
+                kw = dict(partial=t["partial_buf"], partial_k=self._obs_kind[1])
             o = w.make_env_outputs(state=t["state"], normalize_state=self._state_kind[0] == _capi.LLE_OBS_NORMALIZED_STATE, reward=t["reward"],
-                                   multi_objective=self.multi_objective, available=t["available"], walkable_lasers=True)
+                                   multi_objective=self.multi_objective, available=t["available"], walkable_lasers=True, **kw)
             self._fused = (t, o)
         return self._fused
 
@@ -320,7 +330,14 @@ class BatchedLLE:
         self._t += 1
         if fused:
             t = self._fused[0]
-            return {"obs": self.get_observation(), "state": t["state"] if t["state"] is not None else self.get_state(), "reward": t["reward"],
+            if t["partial"] is not None:  # (written by the step launch: no observer launch behind it)
+                obs = t["partial"]
+                state = t["state"] if t["state"] is not None else (obs[:, 0] if self._state_kind == self._obs_kind else self.get_state())
+                if t["state"] is None and self.state_type == "flattened":
+                    state = state.flatten(1)
+            else:
+                obs, state = self.get_observation(), (t["state"] if t["state"] is not None else self.get_state())
+            return {"obs": obs, "state": state, "reward": t["reward"],
                     "done": self.done, "available_actions": t["available"].view(torch.bool), "err": w.err}
         return self._outputs()
 

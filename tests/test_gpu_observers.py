@@ -258,3 +258,82 @@ def test_partial_window_and_projection_kernels_agree_with_the_oracle(oracle_mod,
             for e in range(0, n, 17):
                 want = oo.partial_observe(ob.world(e), k)
                 assert np.array_equal(got[e].astype(np.float32), want), (name, project, t, k, e)
+
+
+@pytest.mark.parametrize("name", ["level6", "level1", "level5", "nested", "three_beams", "four_layers", "colour_alias", "many_agents", "gen_16x16_12agents"])
+def test_partial_written_by_the_step_launch(oracle_mod, name):
+    """lle_batch_step_outputs with `partial` set: the step launch writes the partial k x k observation itself (step kernel MODE 9,
+    partial_stream.hpp) from the state machine's records.  Same bytes as lle_batch_observe_as(LLE_OBS_PARTIAL) behind a plain step and
+    as the oracle's restatement of python/lle/observations.py:312-369, on a ragged batch, every window size the kernel serves, with
+    auto-reset, given actions and refused actions; the other fused outputs unchanged."""
+    import torch
+
+    from lle_amd import BatchedWorld, _capi
+    from oracle import observers as oo
+
+    text = MAPS[name]
+    n = 300 + 5
+    a, b = BatchedWorld(text, n), BatchedWorld(text, n)
+    ob = oracle_mod.OracleBatch(text, n)
+    A = ob.A
+    g = torch.Generator(device="cuda").manual_seed(4)
+    served = 0
+    for k in (3, 5, 7, 9, 15):
+        try:
+            a.obs_desc(_capi.LLE_OBS_PARTIAL, k)
+            buf, view = a.partial_buffer(k)
+        except IndexError:  # (colour_alias: a laser colour without a layer -- the reference raises too)
+            continue
+        state = torch.empty((n, 3 * A + a.map.n_gems), dtype=torch.float32, device="cuda")
+        avail = torch.empty((n, A, 5), dtype=torch.uint8, device="cuda")
+        out = a.make_env_outputs(state=state, available=avail, partial=buf, partial_k=k)
+        try:
+            a.step(sample=True, auto_reset=True, seed=6, t=1000 * k, env_out=out, write_obs=False)
+        except RuntimeError as e:
+            assert "partial observation" in str(e) and (A > 8 and k > 8), (name, k, str(e))  # 16 lanes per env: windows above 8 x 8 do not fit
+            continue
+        served += 1
+        b.restore(a.snapshot()) if False else None
+        a.reset(), b.reset(), ob.reset()
+        for t in range(10):
+            if t % 3 == 2:  # given actions, now and then a refused one
+                acts = torch.multinomial(b.available_actions().reshape(-1, 5).float() + 1e-6, 1, generator=g).reshape(n, A).to(torch.uint8)
+                a.step(acts, auto_reset=t >= 4, env_out=out, write_obs=False)
+                b.step(acts, auto_reset=t >= 4)
+                ob.step(acts.cpu().numpy(), auto_reset=t >= 4, want_obs=False)
+            else:
+                a.step(sample=True, auto_reset=t >= 4, seed=6, t=t, env_out=out, write_obs=False)
+                b.step(sample=True, auto_reset=t >= 4, seed=6, t=t)
+                ob.step(None, auto_reset=t >= 4, seed=6, t=t, want_obs=False)
+            want = b.observe_as(_capi.LLE_OBS_PARTIAL, k)
+            assert torch.equal(view, want), (name, k, t)
+            st = torch.empty_like(state)
+            av = torch.empty_like(avail)
+            b.env_outputs(state=st, available=av)
+            assert torch.equal(state, st) and torch.equal(avail, av), (name, k, t)
+            for e in (0, n // 2, n - 1):
+                assert np.array_equal(view[e].cpu().numpy().astype(np.float32), oo.partial_observe(ob.world(e), k)), (name, k, t, e)
+        assert torch.equal(a.pos, b.pos) and torch.equal(a.bits, b.bits) and torch.equal(a.beams, b.beams)
+    assert served >= 3, name
+
+
+def test_batched_lle_partial_in_one_launch():
+    """BatchedLLE(obs_type="partial7x7").step(fused=True): observation + state + reward + done + available actions from ONE launch;
+    equal to the default (step + observer + outputs launches) along a rollout with auto-reset."""
+    import torch
+
+    from lle_amd import BatchedLLE
+
+    for kw in (dict(obs_type="partial7x7"), dict(obs_type="partial3x3", state_type="normalized-state", multi_objective=True),
+               dict(obs_type="partial5x5", state_type="partial5x5")):
+        n = 640
+        a, b = BatchedLLE(LEVELS[6], n, seed=1, **kw), BatchedLLE(LEVELS[6], n, seed=1, **kw)
+        assert a._fused_partial
+        a.reset(), b.reset()
+        g = torch.Generator(device="cuda").manual_seed(1)
+        for t in range(16):
+            acts = torch.multinomial(b.available_actions().reshape(-1, 5).float(), 1, generator=g).reshape(n, -1).to(torch.uint8)
+            x, y = a.step(acts, auto_reset=True, fused=True), b.step(acts, auto_reset=True)
+            for key in ("obs", "state", "reward", "done", "available_actions", "err"):
+                assert x[key].shape == y[key].shape and torch.equal(x[key], y[key]), (kw, t, key)
+    assert not BatchedLLE(LEVELS[6], 64, obs_type="partial7x7", randomize_lasers=True)._fused_partial  # (per-env sources: two launches)
