@@ -557,7 +557,10 @@ def measure_lle_step(torch, timer, dev, n, steps):
                    "done + available_actions per step; us per step, launch-to-launch", "steps": steps}
     for key, kw, mode in (("two_launches_us", {}, {}), ("two_launches_persistent_us", {}, {"persistent": True}), ("one_launch_us", {}, {"fused": True}),
                           ("randomize_lasers_two_launches_us", {"randomize_lasers": True}, {}),
-                          ("randomize_lasers_one_launch_us", {"randomize_lasers": True}, {"fused": True})):
+                          ("randomize_lasers_one_launch_us", {"randomize_lasers": True}, {"fused": True}),
+                          # obs_type="partial7x7": step + partial observer + outputs (persistent: bound calls), and all of it in the step launch
+                          ("partial7x7_three_launches_persistent_us", {"obs_type": "partial7x7"}, {"persistent": True}),
+                          ("partial7x7_one_launch_us", {"obs_type": "partial7x7"}, {"fused": True})):
         env = BatchedLLE(Map(level=LEVEL), n, device=dev, seed=SEED, **kw)
         env.reset()
         state = {"t": 0}
