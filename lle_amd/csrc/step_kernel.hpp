@@ -258,7 +258,11 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     }
     // (split rows: the pristine static observation stays in global memory, every wavefront copies its slice from there)
     // (PARTIAL: no layered row is built, so the pristine template -- the tail of the table section -- stays out of LDS, as with split rows)
-    const uint32_t tab_bytes = (split || PARTIAL) ? hdr->lds_split_table_bytes : hdr->lds_table_bytes, tab_off = hdr->off_cell_lay;
+    const uint32_t tab_off = hdr->off_cell_lay;
+    // (PARTIAL: the cell tables alone, in whole 1-KiB rows -- no dyn table, no template: four workgroups per CU must fit for a one-round launch)
+    const uint32_t tab_cells = ((hdr->off_dyn - tab_off) + 1023u) & ~1023u;
+    const uint32_t tab_bytes = PARTIAL ? (tab_cells < hdr->lds_table_bytes ? tab_cells : hdr->lds_table_bytes)
+                                       : (split ? hdr->lds_split_table_bytes : hdr->lds_table_bytes);
     const uint32_t ext_bytes = PES ? hdr->ext_bytes : 0u;
     if (PES) copy_tables2_to_lds(tables + tab_off, tab_bytes, tables + h_off_bare, ext_bytes, lds, lane, wave_in_wg, waves_per_wg);
     else copy_tables_to_lds(tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
@@ -299,7 +303,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     // a wavefront's private area: [row template | hand-over records]; PARTIAL: [E rows of the partial observation + 16 B | records]
     const uint32_t part_pitch = PARTIAL ? (((uint32_t)(A * (2 * A + 3)) * K.partial_k * K.partial_k + 15u) & ~15u) : 0u;
     const uint32_t row_area = PARTIAL ? K.partial_E * part_pitch + 16u : h_obs_stride;
-    const uint32_t priv_bytes = row_area + 64u * scr_stride * 4u;
+    const uint32_t priv_bytes = row_area + (PARTIAL ? ((EPW * scr_stride * 4u + 15u) & ~15u) : 64u * scr_stride * 4u);  // (PARTIAL: a record per environment of the wavefront, no spare slots)
     int8_t* tmpl = reinterpret_cast<int8_t*>(lds + tab_bytes + ext_bytes + bt_bytes + pm_bytes + wave_in_wg * priv_bytes);
     uint32_t* scratch = reinterpret_cast<uint32_t*>(tmpl + row_area);
     const int8_t* bare = reinterpret_cast<const int8_t*>(lds + tab_bytes);
