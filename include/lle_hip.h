@@ -249,6 +249,13 @@ enum {
                                     counter-based sampler of DESIGN.md (seed, env, t, agent); writes LLE_BUF_ACTIONS */
     LLE_STEP_AUTO_RESET = 2,     /* reset an env at the start of the step when LLE_BUF_DONE says it is over */
     LLE_STEP_NO_OBS = 4,         /* skip the observation write */
+    LLE_STEP_INCREMENTAL_OBS = 16, /* lle_batch_step / lle_batch_step_outputs (single steps, the map's own sources): write only the 128-byte lines
+                                    of each row of LLE_BUF_OBS that dynamic state can change -- agent layers, lines with a laser tile or a gem.
+                                    The other lines (WALL / VOID / EXIT planes, beam-less parts of the laser planes: a third of level 6's row)
+                                    hold the same bytes after every step and are already in the buffer from the last full write (create, reset,
+                                    observe, any source / exit update, any step without this flag), so the buffer's CONTENT is the same; the
+                                    caller promises not to have written into LLE_BUF_OBS itself.  Ignored (full rows) by fused rollouts into
+                                    rings, with per-environment sources and on rows that are not whole 128-byte lines. */
     LLE_STEP_RECOLOUR_RESETS = 8 /* with LLE_STEP_AUTO_RESET, batches with per-environment sources: an env that is reset also draws a
                                     fresh colour for each of its sources -- LLE.reset with randomize_lasers (python/lle/env/
                                     env.py:189-203: world.reset() under the colours the env had, then the new colours on the live

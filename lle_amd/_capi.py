@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("LLE_HIP_LIB") or os.path.join(_HERE, "liblle_hip.so")
 BUFFER_NAMES = ["pos", "bits", "gems", "beams", "avail", "actions", "err", "evcount", "events", "done", "obs", "stats",
                 "req_pos", "req_gems", "req_alive", "reward", "src_colour", "src_enabled"]
 LLE_POS_START, LLE_POS_EXIT, LLE_POS_WALL, LLE_POS_VOID, LLE_POS_GEM = range(5)
-LLE_STEP_SAMPLE_ACTIONS, LLE_STEP_AUTO_RESET, LLE_STEP_NO_OBS, LLE_STEP_RECOLOUR_RESETS = 1, 2, 4, 8
+LLE_STEP_SAMPLE_ACTIONS, LLE_STEP_AUTO_RESET, LLE_STEP_NO_OBS, LLE_STEP_RECOLOUR_RESETS, LLE_STEP_INCREMENTAL_OBS = 1, 2, 4, 8, 16
 RECOLOUR_SALT = 0xC01055EED  # the colour draws of LLE_STEP_RECOLOUR_RESETS hash (seed ^ RECOLOUR_SALT, env, t, laser_id)
 LLE_ENV_INVALID_WORLD_STATE, LLE_ENV_OUT_OF_WORLD_POSITION, LLE_ENV_INVALID_AGENT_POSITION = 0x40, 0x41, 0x42
 LLE_ENV_INVALID_COLOUR = 0x43

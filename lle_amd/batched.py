@@ -9,8 +9,8 @@ import ctypes as C
 import torch
 
 from . import _capi
-from ._capi import (LLE_BUF_COUNT, BUFFER_NAMES, LLE_STEP_AUTO_RESET, LLE_STEP_NO_OBS, LLE_STEP_RECOLOUR_RESETS, LLE_STEP_SAMPLE_ACTIONS,
-                    BufferDesc, Map)
+from ._capi import (LLE_BUF_COUNT, BUFFER_NAMES, LLE_STEP_AUTO_RESET, LLE_STEP_INCREMENTAL_OBS, LLE_STEP_NO_OBS, LLE_STEP_RECOLOUR_RESETS,
+                    LLE_STEP_SAMPLE_ACTIONS, BufferDesc, Map)
 
 _TORCH_DTYPES = {
     "pos": torch.uint8, "bits": torch.int64, "gems": torch.int32, "beams": torch.int32, "avail": torch.uint8,
@@ -224,7 +224,7 @@ class BatchedWorld:
         self.t = 0
 
     def step(self, actions=None, sample=False, auto_reset=False, seed=0, t=None, env_offset=0, write_obs=True, env_out=None,
-             recolour_resets=False):
+             recolour_resets=False, incremental_obs=False):
         """World.step + Layered.observe for every env.  env_out: an `_capi.EnvOutputs` (make_env_outputs) whose tensors the
         step kernel fills in the same launch (lle_batch_step_outputs: LLE.step's state / reward / done / available / ...).
 
@@ -248,6 +248,8 @@ class BatchedWorld:
             flags |= LLE_STEP_RECOLOUR_RESETS
         if not write_obs:
             flags |= LLE_STEP_NO_OBS
+        if incremental_obs:  # only the lines of a row that dynamic state can change (LLE_STEP_INCREMENTAL_OBS): same content of `obs`
+            flags |= LLE_STEP_INCREMENTAL_OBS
         if t is None:
             t = self.t
         if env_out is not None:
@@ -256,12 +258,13 @@ class BatchedWorld:
             self._check(_capi.lib().lle_batch_step(self.h, ap, flags, int(seed), int(t), int(env_offset), self._stream()))
         self.t = t + 1
 
-    def sampled_stepper(self, auto_reset=True, seed=0, env_offset=0, write_obs=True):
+    def sampled_stepper(self, auto_reset=True, seed=0, env_offset=0, write_obs=True, incremental_obs=False):
         """A zero-argument callable for hot loops: one `step(sample=True, ...)` per call with the arguments and the
         flags bound once, the time index advancing by one per call -- the C-ABI call
         and nothing else per step (`step()` itself spends a few microseconds in Python per launch)."""
         fn, h, dev = _capi.lib().lle_batch_step, self.h, self.device
-        flags = LLE_STEP_SAMPLE_ACTIONS | (LLE_STEP_AUTO_RESET if auto_reset else 0) | (0 if write_obs else LLE_STEP_NO_OBS)
+        flags = (LLE_STEP_SAMPLE_ACTIONS | (LLE_STEP_AUTO_RESET if auto_reset else 0) | (0 if write_obs else LLE_STEP_NO_OBS) |
+                 (LLE_STEP_INCREMENTAL_OBS if incremental_obs else 0))
         seed, env_offset = int(seed), int(env_offset)
 
         def one_step():
@@ -454,11 +457,11 @@ class BatchedWorld:
         call.struct, call.tensors = o, tensors  # (kept alive with the callable)
         return call
 
-    def bound_step(self, auto_reset=False, recolour_resets=False, write_obs=True, seed=0, env_offset=0, env_out=None):
+    def bound_step(self, auto_reset=False, recolour_resets=False, write_obs=True, seed=0, env_offset=0, env_out=None, incremental_obs=False):
         """`fn(actions)` = step(actions, ...) with the flags, the stream and the output struct fixed; `actions` must already be a
         contiguous uint8 [n, A] tensor on this device (no conversion, no checks).  The time index advances by one per call."""
         flags = ((LLE_STEP_AUTO_RESET if auto_reset else 0) | (LLE_STEP_RECOLOUR_RESETS if recolour_resets else 0) |
-                 (0 if write_obs else LLE_STEP_NO_OBS))
+                 (0 if write_obs else LLE_STEP_NO_OBS) | (LLE_STEP_INCREMENTAL_OBS if incremental_obs else 0))
         L, h, dev, seed, env_offset = _capi.lib(), C.c_void_p(self.h), self.device, int(seed), int(env_offset)
         fn = L.lle_batch_step_outputs if env_out is not None else L.lle_batch_step
         tail = (C.byref(env_out),) if env_out is not None else ()

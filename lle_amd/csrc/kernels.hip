@@ -698,7 +698,9 @@ hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const Laun
     }
     // single-step launches with the map's sources: the rows' head lines go out ahead of the state machine (MODE 6 / 7) when
     // the map has a head, the rows are not split and the launch is of the size where it pays
-    const bool heads = !roll && lm <= 8 && h.head_n != 0 && !(K.flags & (LAUNCH_SPLIT_ROWS | STEP_NO_OBS)) &&
+    // (STEP_INCREMENTAL_OBS: the static lines are not written at all, so there is no head to send ahead)
+    const bool incr = (K.flags & STEP_INCREMENTAL_OBS) != 0 && !roll && h.n_dyn_chunks < h.n_chunks;
+    const bool heads = !incr && !roll && lm <= 8 && h.head_n != 0 && !(K.flags & (LAUNCH_SPLIT_ROWS | STEP_NO_OBS)) &&
                        row_heads_pay(n_waves, (K.flags & LAUNCH_GENERAL) != 0, tune.heads);
     if (K.flags & LAUNCH_GENERAL) {
         if (roll) return launch_step_mode2(G, lm, P, K, n_waves, wpw, lds, stream);

@@ -504,6 +504,21 @@ void Map::compile() {
         h.head_n = best_n * 8u;
     }
 
+    // ---- the dynamic chunks of a row (tables.h off_dyn_chunks): every chunk of a line that holds an agent-layer byte or a dyn entry
+    std::vector<uint16_t> dyn_chunks;
+    if (h.obs_stride % 128u == 0 && h.obs_supported && h.n_chunks <= 0xFFFFu) {
+        const uint32_t n_lines = h.obs_stride / 128u;
+        std::vector<uint8_t> dynamic_line(n_lines, 0);
+        for (uint32_t l = 0; l < n_lines && l * 128u < (uint32_t)(A * HW); l++) dynamic_line[l] = 1;
+        for (uint64_t e : dyn_tab) dynamic_line[((uint32_t)e & 0xFFFFFu) / 128u] = 1;
+        for (uint32_t l = 0; l < n_lines; l++)
+            if (dynamic_line[l])
+                for (uint32_t c = 0; c < 8; c++) dyn_chunks.push_back((uint16_t)(l * 8u + c));
+    } else {
+        for (uint32_t c = 0; c < h.n_chunks && c <= 0xFFFFu; c++) dyn_chunks.push_back((uint16_t)c);
+    }
+    h.n_dyn_chunks = h.n_chunks <= 0xFFFFu ? (uint32_t)dyn_chunks.size() : h.n_chunks;
+
     // the same for environments with their own source colours (tables.h pes_head_*): a laser byte may then sit on any of the
     // A laser layers, so the whole of [0, 2A * HW) is dynamic; behind it only the gem bytes are
     if (h.obs_stride % 128u == 0 && h.obs_supported) {
@@ -533,6 +548,7 @@ void Map::compile() {
     h.off_cell_lay = (uint32_t)off; off = align16(off + cell_lay.size() * 8);
     h.off_cell_meta = (uint32_t)off; off = align16(off + cell_meta.size() * 4);
     h.off_dyn = (uint32_t)off; off = align16(off + dyn_tab.size() * 8);
+    h.off_dyn_chunks = (uint32_t)off; off = align16(off + dyn_chunks.size() * 2);  // (ahead of the template: split-row launches keep it in LDS too)
     h.off_template = (uint32_t)off; off = align16(off + tmpl.size());
     // the kernel copies [off_cell_lay, blob_bytes) to LDS in rows of 64 lanes x 16 B: pad to whole rows
     off = h.off_cell_lay + ((off - h.off_cell_lay + 1023) & ~(size_t)1023);
@@ -542,6 +558,7 @@ void Map::compile() {
     {
         size_t cap = h.off_dyn;
         cap = align16(cap + ((size_t)n_laser_tiles() + (size_t)G) * 8);
+        cap = align16(cap + (size_t)h.n_chunks * 2);  // (the dynamic chunks: at most every chunk of the row)
         cap = align16(cap + tmpl.size());
         h.blob_capacity = (uint32_t)(h.off_cell_lay + ((cap - h.off_cell_lay + 1023) & ~(size_t)1023));
     }
@@ -597,6 +614,7 @@ void Map::compile() {
     std::memcpy(blob.data() + h.off_cell_meta, cell_meta.data(), cell_meta.size() * 4);
     if (!dyn_tab.empty()) std::memcpy(blob.data() + h.off_dyn, dyn_tab.data(), dyn_tab.size() * 8);
     std::memcpy(blob.data() + h.off_template, tmpl.data(), tmpl.size());
+    if (!dyn_chunks.empty()) std::memcpy(blob.data() + h.off_dyn_chunks, dyn_chunks.data(), dyn_chunks.size() * 2);
     std::memcpy(blob.data(), &h, sizeof h);
     header = h;
 }

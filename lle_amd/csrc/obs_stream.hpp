@@ -169,6 +169,20 @@ __device__ __forceinline__ void stream_row_tail(uint4* __restrict__ dst, const u
     }
 }
 
+// Only the DYNAMIC chunks of a row (tables.h off_dyn_chunks; STEP_INCREMENTAL_OBS): chunk tab[i] for i = lane, lane + 64, ...  The other
+// lines of the row already hold their bytes.  c0 / c1: this lane's first two chunks (0xFFFF: none), looked up once per wavefront.
+template <bool WT>
+__device__ __forceinline__ void stream_row_dyn(uint4* __restrict__ dst, const uint4* srcv, const uint16_t* tab, uint32_t n_dyn, uint32_t c0, uint32_t c1,
+                                               uint32_t lane) {
+    const uint4 v0 = srcv[c0 != 0xFFFFu ? c0 : 0u], v1 = srcv[c1 != 0xFFFFu ? c1 : 0u];
+    if (c0 != 0xFFFFu) stream_store<WT>(dst + c0, v0);
+    if (c1 != 0xFFFFu) stream_store<WT>(dst + c1, v1);
+    for (uint32_t i = lane + 128u; i < n_dyn; i += 64u) {
+        const uint32_t c = tab[i];
+        stream_store<WT>(dst + c, srcv[c]);
+    }
+}
+
 // The heads of the wave's rows: the same `head_n` (<= 64) chunks, straight from the map's pristine template in global
 // memory (`v`: this lane's chunk), into every row.  Issued BEFORE the state machine: a launch of the step kernel is
 // (ramp) + (state machine, every wavefront at the same time) + (stream), and the lines that no agent, beam or gem can
@@ -185,11 +199,18 @@ __device__ __forceinline__ void store_heads(int8_t* __restrict__ obs, uint64_t o
 // `scratch` holds one hand-over record per environment: [0 | beam masks | ~gem bits | byte index of each agent].
 // `obs_stride` = bytes between the rows of consecutive environments in `obs`.
 // HEAD: the rows' heads are already stored (store_heads); stream the rest.
-template <bool WT, bool HEAD = false>
+// INCR: only the dynamic chunks (dyn_chunks / n_dyn_chunks: stream_row_dyn).
+template <bool WT, bool HEAD = false, bool INCR = false>
 __device__ __forceinline__ void write_observations(int A, int L, uint32_t D, uint32_t n_chunks, uint64_t obs_stride,
                                                    const uint64_t* dyn, int8_t* tmpl, const uint32_t* scratch,
                                                    uint32_t scr_stride, int8_t* __restrict__ obs, int64_t env0,
-                                                   int64_t n_here, uint32_t lane, uint32_t head_lo = 0, uint32_t head_n = 0, uint32_t rot = 0) {
+                                                   int64_t n_here, uint32_t lane, uint32_t head_lo = 0, uint32_t head_n = 0, uint32_t rot = 0,
+                                                   const uint16_t* dyn_chunks = nullptr, uint32_t n_dyn_chunks = 0) {
+    uint32_t dc0 = 0xFFFFu, dc1 = 0xFFFFu;
+    if constexpr (INCR) {
+        dc0 = lane < n_dyn_chunks ? (uint32_t)dyn_chunks[lane] : 0xFFFFu;
+        dc1 = lane + 64u < n_dyn_chunks ? (uint32_t)dyn_chunks[lane + 64u] : 0xFFFFu;
+    }
     // Each lane serves the same dyn entry for every environment: decode it once.
     // A laser / gem reference becomes (dword of the hand-over record, bit); an absent one points at the record's
     // zero word, so the per-environment evaluation is branch-free.
@@ -229,7 +250,8 @@ __device__ __forceinline__ void write_observations(int A, int L, uint32_t D, uin
         wave_sync();
         // (c) stream the patched copy as one contiguous row: 16 B per lane, 1 KiB per wave instruction
         uint4* __restrict__ dst = reinterpret_cast<uint4*>(obs + (uint64_t)(env0 + k) * obs_stride);
-        if constexpr (HEAD) stream_row_tail<WT>(dst, srcv, n_chunks, head_lo, head_n, lane);
+        if constexpr (INCR) stream_row_dyn<WT>(dst, srcv, dyn_chunks, n_dyn_chunks, dc0, dc1, lane);
+        else if constexpr (HEAD) stream_row_tail<WT>(dst, srcv, n_chunks, head_lo, head_n, lane);
         else stream_whole_row<WT>(dst, srcv, n_chunks, lane);
         wave_sync();
         // (d) agents off again (their layers are all-zero in the static copy); LDS is in order, so this lands after
@@ -247,12 +269,21 @@ __device__ __forceinline__ void write_observations(int A, int L, uint32_t D, uin
 // `tmpl` = the wave's slice (pristine bytes of chunks [lo, hi)), `lo`, `hi` in 16-byte chunks, `dyn` the whole (sorted
 // by byte index) table.  Same bytes as write_observations: every dynamic byte and every agent byte belongs to exactly
 // one slice.
-template <bool WT>
+// INCR (STEP_INCREMENTAL_OBS): only the slice's DYNAMIC chunks -- entries [t_lo, t_hi) of the ascending table dyn_chunks.
+template <bool WT, bool INCR = false>
 __device__ __forceinline__ void write_observations_split(int A, int L, uint32_t D, uint32_t lo, uint32_t hi, uint64_t obs_stride,
                                                          const uint64_t* dyn, int8_t* tmpl, const uint32_t* records,
                                                          uint32_t scr_stride, int8_t* __restrict__ obs, int64_t wg_env0,
-                                                         int64_t n_wg_here, uint32_t lane) {
+                                                         int64_t n_wg_here, uint32_t lane, const uint16_t* dyn_chunks = nullptr, uint32_t n_dyn_chunks = 0) {
     const uint32_t b_lo = lo * 16u, b_hi = hi * 16u;
+    uint32_t t_lo = 0, t_hi = 0;
+    if constexpr (INCR) {
+        for (uint32_t i = lane; i < ((n_dyn_chunks + 63u) & ~63u); i += 64) {
+            const uint32_t c = i < n_dyn_chunks ? (uint32_t)dyn_chunks[i] : 0xFFFFFFFFu;
+            t_lo += (uint32_t)__popcll(__ballot(c < lo));
+            t_hi += (uint32_t)__popcll(__ballot(c < hi));
+        }
+    }
     // the dyn table is sorted by byte index: this slice's entries are [d_lo, d_hi)
     uint32_t d_lo = 0, d_hi = 0;
     for (uint32_t d = lane; d < ((D + 63u) & ~63u); d += 64) {
@@ -294,7 +325,14 @@ __device__ __forceinline__ void write_observations_split(int A, int L, uint32_t 
         if (agent_here) tmpl[agent_idx - b_lo] = 1;
         wave_sync();
         uint4* __restrict__ dst = reinterpret_cast<uint4*>(obs + (uint64_t)(wg_env0 + k) * obs_stride) + lo;
-        stream_whole_row<WT>(dst, srcv, n_mine, lane);
+        if constexpr (INCR) {
+            for (uint32_t i = t_lo + lane; i < t_hi; i += 64u) {
+                const uint32_t c = (uint32_t)dyn_chunks[i] - lo;
+                stream_store<WT>(dst + c, srcv[c]);
+            }
+        } else {
+            stream_whole_row<WT>(dst, srcv, n_mine, lane);
+        }
         wave_sync();
         if (agent_here) tmpl[agent_idx - b_lo] = 0;
     }

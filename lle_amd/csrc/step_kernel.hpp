@@ -125,6 +125,10 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     // the kernel's own stores, and the compiler cannot tell the header from the rows -- whose wait covers the stores too)
     const uint32_t h_off_cell_meta = hdr->off_cell_meta, h_off_dyn = hdr->off_dyn, h_off_template = hdr->off_template;
     const uint32_t h_max_layers = ML1 ? 1u : hdr->max_layers;
+    // STEP_INCREMENTAL_OBS (tables.h): single steps in place with the map's own sources write only the lines dynamic state can change
+    constexpr bool CAN_INCR = !ROLL && !PES && !PARTIAL;
+    const uint32_t h_off_dyn_chunks = CAN_INCR ? hdr->off_dyn_chunks : 0u, h_n_dyn_chunks = CAN_INCR ? hdr->n_dyn_chunks : 0u;
+    const bool incr = CAN_INCR && (K.flags & STEP_INCREMENTAL_OBS) != 0 && h_n_dyn_chunks < h_n_chunks;
     const uint32_t h_off_recolour = PES ? hdr->off_recolour : 0u, h_off_bare = PES ? hdr->off_bare : 0u;
     const uint32_t h_off_elems = PES ? hdr->off_elems : 0u, h_n_elems = PES ? hdr->n_elems : 0u;
     // (MODE 7: so are the fused LLE.step outputs' descriptor and the header fields of that epilogue)
@@ -244,7 +248,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     // returned before the first store: the vmcnt counter is in order, so a load waited for AFTER the head stores would
     // wait for their acknowledgements (and the compiler does not see the `sc1` stores, which are inline asm).
     const uint32_t head_lo = HEAD ? (PES ? hdr->pes_head_lo : hdr->head_lo) : 0u;
-    const uint32_t head_n = (HEAD && write_obs && !split) ? (PES ? hdr->pes_head_n : hdr->head_n) : 0u;
+    const uint32_t head_n = (HEAD && write_obs && !split && !incr) ? (PES ? hdr->pes_head_n : hdr->head_n) : 0u;  // (incr: static lines are not written at all)
     uint4 head_v = {0u, 0u, 0u, 0u};
     if (HEAD) {
         if (lane < head_n) head_v = reinterpret_cast<const uint4*>(tables + (PES ? h_off_bare : h_off_template))[head_lo + lane];
@@ -299,6 +303,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     const uint64_t* cell_lay = reinterpret_cast<const uint64_t*>(lds);
     const uint32_t* cell_meta = reinterpret_cast<const uint32_t*>(lds + (h_off_cell_meta - tab_off));
     const uint64_t* dyn = reinterpret_cast<const uint64_t*>(lds + (h_off_dyn - tab_off));
+    const uint16_t* dyn_chunks = reinterpret_cast<const uint16_t*>(lds + (h_off_dyn_chunks - tab_off));
     const uint32_t scr_stride = (uint32_t)(L + A + 2 + (PES ? CW : 0)) | 1u;
     // a wavefront's private area: [row template | hand-over records]; PARTIAL: [E rows of the partial observation + 16 B | records]
     const uint32_t part_pitch = PARTIAL ? (((uint32_t)(A * (2 * A + 3)) * K.partial_k * K.partial_k + 15u) & ~15u) : 0u;
@@ -576,7 +581,11 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
             int64_t n_wg = K.env_limit - wg_env0;
             n_wg = n_wg < 0 ? 0 : (n_wg > (int64_t)(waves_per_wg * EPW) ? (int64_t)(waves_per_wg * EPW) : n_wg);
             const uint32_t* records = reinterpret_cast<const uint32_t*>(lds + tab_bytes + bt_bytes + waves_per_wg * cpw * 16u);
-            if (K.flags & LAUNCH_WRITE_THROUGH) write_observations_split<true>(A, L, h_D, c_lo, c_hi, h_obs_stride, dyn, tmpl, records, scr_stride, obs_out, wg_env0, n_wg, lane);
+            const bool wts = (K.flags & LAUNCH_WRITE_THROUGH) != 0;
+            if (CAN_INCR && incr) {
+                if (wts) write_observations_split<true, true>(A, L, h_D, c_lo, c_hi, h_obs_stride, dyn, tmpl, records, scr_stride, obs_out, wg_env0, n_wg, lane, dyn_chunks, h_n_dyn_chunks);
+                else write_observations_split<false, true>(A, L, h_D, c_lo, c_hi, h_obs_stride, dyn, tmpl, records, scr_stride, obs_out, wg_env0, n_wg, lane, dyn_chunks, h_n_dyn_chunks);
+            } else if (wts) write_observations_split<true>(A, L, h_D, c_lo, c_hi, h_obs_stride, dyn, tmpl, records, scr_stride, obs_out, wg_env0, n_wg, lane);
             else write_observations_split<false>(A, L, h_D, c_lo, c_hi, h_obs_stride, dyn, tmpl, records, scr_stride, obs_out, wg_env0, n_wg, lane);
         }
         // fused rollout: the next step's records overwrite these
@@ -594,6 +603,9 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
                                                        obs_out, env0, n_here, lane, nullptr, 0xFFFFFFFFu, head_lo, head_n, LLE_ROT());
             else write_observations_env<false, HEAD>(A, L, h_HW, h_n_elems, h_n_chunks, h_obs_stride, elems, bare, tmpl, scratch, scr_stride,
                                                      obs_out, env0, n_here, lane, nullptr, 0xFFFFFFFFu, head_lo, head_n, LLE_ROT());
+        } else if (CAN_INCR && incr) {
+            if (wt) write_observations<true, false, true>(A, L, h_D, h_n_chunks, h_obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane, 0u, 0u, LLE_ROT(), dyn_chunks, h_n_dyn_chunks);
+            else write_observations<false, false, true>(A, L, h_D, h_n_chunks, h_obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane, 0u, 0u, LLE_ROT(), dyn_chunks, h_n_dyn_chunks);
         } else {
             if (wt) write_observations<true, HEAD>(A, L, h_D, h_n_chunks, h_obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane, head_lo, head_n, LLE_ROT());
             else write_observations<false, HEAD>(A, L, h_D, h_n_chunks, h_obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane, head_lo, head_n, LLE_ROT());

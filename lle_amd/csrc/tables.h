@@ -94,7 +94,12 @@ struct MapHeader {
     uint32_t word_mask;                  // bit b: word b belongs to a source (0: padding of a chained map)
     uint8_t word_source[MAX_SOURCES];    // source (laser_id) of word b
     uint8_t source_word[MAX_SOURCES];    // first word of source s
-    uint32_t head_pad[19];  // (pads the header to 640 B: the table sections behind it start on a 128-byte line)
+    // The DYNAMIC chunks of a row (u16 chunk indices, ascending, behind the template in the table section): the 16-byte chunks of the
+    // 128-byte lines that an agent, a beam or a gem can change.  Every other line of LLE_BUF_OBS holds the same bytes after every
+    // step (the head lines above are a run of those), so a single step that rewrites the rows IN PLACE may leave them alone
+    // (STEP_INCREMENTAL_OBS): level 6 writes 10 of its 15 lines.  n_dyn_chunks == n_chunks: nothing to skip (or unaligned rows).
+    uint32_t off_dyn_chunks, n_dyn_chunks;
+    uint32_t head_pad[17];  // (pads the header to 640 B: the table sections behind it start on a 128-byte line)
 };
 static_assert(sizeof(MapHeader) % 128 == 0, "the sections start on a 128-byte line (the LDS copy loads 1 KiB per wave instruction)");
 
@@ -150,6 +155,9 @@ constexpr uint8_t ENV_COLOUR_CROSSES_START = 0x44;
 // randomize_lasers, python/lle/env/env.py:189-203); batches with per-env sources only.
 constexpr uint64_t RECOLOUR_SALT = 0xC01055EEDULL;  // seed ^ salt keys the colour draws (a stream of their own)
 constexpr uint32_t STEP_SAMPLE_ACTIONS = 1, STEP_AUTO_RESET = 2, STEP_NO_OBS = 4, STEP_RECOLOUR_RESETS = 8;
+// STEP_INCREMENTAL_OBS: a single step in place writes only the lines of a row that dynamic state can change (MapHeader.n_dyn_chunks);
+// the others already hold their bytes from the last full write (reset, observe, any earlier step).  The buffer's content is the same.
+constexpr uint32_t STEP_INCREMENTAL_OBS = 16;
 constexpr uint32_t LAUNCH_PER_ENV_SOURCES = 0x10000;  // internal: the batch keeps colours / enabled flags per env
 constexpr uint32_t LAUNCH_FILL_DEFAULTS = 0x20000;    // internal (MODE_ENV_SOURCES): take them from the map header
 constexpr uint32_t LAUNCH_GENERAL = 0x80000;          // internal: the general step_kernel instantiation (per-env sources / several maps)

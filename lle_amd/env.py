@@ -50,7 +50,7 @@ class BatchedLLE:
     multi_objective (MultiObjective instead of SingleObjective); death_strategy "end" only, like the reference."""
 
     def __init__(self, maps, n_envs, obs_type="layered", state_type="state", walkable_lasers=True, randomize_lasers=False,
-                 multi_objective=False, death_strategy="end", padding_size=0, device=None, seed=0, name=None):
+                 multi_objective=False, death_strategy="end", padding_size=0, device=None, seed=0, name=None, incremental_obs=False):
         if death_strategy == "respawn":
             raise NotImplementedError("Respawn strategy is not implemented yet")  # env.py:106-107
         if death_strategy != "end":
@@ -78,6 +78,10 @@ class BatchedLLE:
                             raise ValueError(f"randomize_lasers: laser source {s.laser_id} at {(s.i, s.j)} cannot be changed to agent ID "
                                              f"{c} since it would cross the start position of another agent")
         self.multi_objective = bool(multi_objective)
+        # incremental_obs: steps write only the lines of the layered rows that dynamic state can change (LLE_STEP_INCREMENTAL_OBS: the
+        # others keep their bytes from the last full write) -- same observation, a third fewer bytes on level 6; the caller must not write
+        # into `world.obs` itself
+        self._incr = bool(incremental_obs)
         self._gen = torch.Generator(device=self.world.device)
         self._gen.manual_seed(int(seed))
         self._seed_value = int(seed)
@@ -318,15 +322,15 @@ class BatchedLLE:
                 # world.reset() + a fresh colour per source for the envs that are over, inside the step kernel; the draws
                 # are keyed by (seed, env, step counter, source), not by the torch generator that reset() uses
                 w.step(actions, auto_reset=True, recolour_resets=True, seed=self._seed_value, t=self._t, write_obs=self._needs_layered,
-                       env_out=env_out)
+                       env_out=env_out, incremental_obs=self._incr)
             elif self.randomize_lasers:
                 # (the kernel reads an env's mask byte before it rewrites its `done`; the step rewrites the observation)
                 self._reset_world(w.done, write_obs=False)
-                w.step(actions, write_obs=self._needs_layered, env_out=env_out)
+                w.step(actions, write_obs=self._needs_layered, env_out=env_out, incremental_obs=self._incr)
             else:
-                w.step(actions, auto_reset=True, write_obs=self._needs_layered, env_out=env_out)
+                w.step(actions, auto_reset=True, write_obs=self._needs_layered, env_out=env_out, incremental_obs=self._incr)
         else:
-            w.step(actions, write_obs=self._needs_layered, env_out=env_out)
+            w.step(actions, write_obs=self._needs_layered, env_out=env_out, incremental_obs=self._incr)
         self._t += 1
         if fused:
             t = self._fused[0]
@@ -360,7 +364,8 @@ class BatchedLLE:
                     b["obs"] if self._state_kind == self._obs_kind and b["obs"] is not None else w.bound_observer(*self._state_kind))
             recolour = auto_reset and self._recolour_in_step
             in_kernel_reset = auto_reset and (recolour or not self.randomize_lasers)
-            b[key] = w.bound_step(auto_reset=in_kernel_reset, recolour_resets=recolour, write_obs=self._needs_layered, seed=self._seed_value)
+            b[key] = w.bound_step(auto_reset=in_kernel_reset, recolour_resets=recolour, write_obs=self._needs_layered, seed=self._seed_value,
+                                  incremental_obs=self._incr)
         if auto_reset and self.randomize_lasers and not self._recolour_in_step:
             self._reset_world(w.done, write_obs=False)
         w.t = self._t

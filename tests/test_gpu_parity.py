@@ -751,3 +751,58 @@ def test_placed_rings_and_observer_outputs():
     assert small.placement is None
     t = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
     assert placement.time_row_fill(t, 1024, rows_per_wave=8) > 0 and int(t.sum()) == 0
+
+
+@pytest.mark.parametrize("name", ["level6", "level1", "level3", "level5", "nested", "three_beams", "colour_alias", "many_agents", "gen_16x16_12agents"])
+def test_incremental_observation_is_the_full_observation(oracle_mod, name):
+    """LLE_STEP_INCREMENTAL_OBS: a single step in place writes only the lines of a row that dynamic state can change (tables.h
+    off_dyn_chunks); the rest are in the buffer from the last full write.  The CONTENT of LLE_BUF_OBS -- padding included -- equals
+    that of a batch stepped without the flag and the oracle's tensor, every step: sampled and given actions, auto-reset, steps
+    without observation in between, source and exit updates (they rewrite the rows in full), whole-row and split-row kernels."""
+    import torch
+
+    from lle_amd import BatchedWorld
+
+    text = MAPS[name]
+    n = 500 + 3
+    a, b = BatchedWorld(text, n), BatchedWorld(text, n)
+    ob = oracle_mod.OracleBatch(text, n)
+    for t in range(24):
+        if t % 5 == 3:  # a step without observation, then the incremental one must still be complete
+            a.step(sample=True, auto_reset=True, seed=2, t=t, write_obs=False)
+            b.step(sample=True, auto_reset=True, seed=2, t=t, write_obs=False)
+            ob.step(None, auto_reset=True, seed=2, t=t, want_obs=False)
+            continue
+        a.step(sample=True, auto_reset=t >= 8, seed=2, t=t, incremental_obs=True)
+        b.step(sample=True, auto_reset=t >= 8, seed=2, t=t)
+        ostep = ob.step(None, auto_reset=t >= 8, seed=2, t=t)
+        assert torch.equal(a.obs_rows, b.obs_rows), (name, t)
+        check(a, ob, ostep, f"{name} incremental t={t}")
+        if t == 12 and a.map.n_sources:  # LaserSource.disable / set_colour on the map: a full rewrite, then incremental again
+            for bw in (a, b):
+                bw.map.set_source(0, enabled=False)
+                bw.update_sources()
+            for e in range(n):
+                ob.world(e).set_source(0, enabled=False)
+            assert torch.equal(a.obs_rows, b.obs_rows)
+    first, nbytes = a.map.row_head
+    assert a.stats() == b.stats()
+
+
+def test_incremental_observation_on_split_rows_and_several_maps(oracle_mod):
+    from lle_amd import BatchedWorld, mapgen
+    import torch
+
+    texts = [mapgen.config5(s) for s in range(4)]
+    for maps, n in ((texts[0], 256 + 8), (texts, 4 * 64)):
+        a, b = BatchedWorld(maps, n), BatchedWorld(maps, n)
+        for t in range(12):
+            a.step(sample=True, auto_reset=True, seed=3, t=t, incremental_obs=True)
+            b.step(sample=True, auto_reset=True, seed=3, t=t)
+            assert torch.equal(a.obs_rows, b.obs_rows), t
+            assert torch.equal(a.pos, b.pos) and torch.equal(a.beams, b.beams)
+    ob = oracle_mod.OracleBatch(texts[0], 64)
+    c = BatchedWorld(texts[0], 64)
+    for t in range(8):
+        c.step(sample=True, auto_reset=True, seed=5, t=t, incremental_obs=True)
+        check(c, ob, ob.step(None, auto_reset=True, seed=5, t=t), f"cfg5 incremental t={t}")
