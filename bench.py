@@ -472,6 +472,36 @@ def measure_multi_map(torch, timer, dev, steps, single_map_kernel_ms):
     return out
 
 
+def measure_incremental(torch, timer, dev, steps):
+    """LLE_STEP_INCREMENTAL_OBS (opt-in; NOT the headline): single steps that write only the 128-byte lines of each row that dynamic state
+    can change -- the WALL / VOID / EXIT planes and the beam-less parts of the laser planes hold the same bytes after every step and are
+    already in LLE_BUF_OBS from the last full write.  The buffer's content after every step is identical (tests/test_gpu_parity.py
+    test_incremental_observation_is_the_full_observation); the bytes WRITTEN per env-step are `written_bytes_per_env_step`, and the
+    fractions below are computed from those, not from the 1 937 / 20 617 algorithmic bytes of the full rewrite."""
+    from lle_amd import BatchedWorld, Map, mapgen
+    out = {"what": "same workload as the headline / roofline_hbm / cfg5 blocks, rows written incrementally (opt-in flag); us per step by HIP events",
+           "steps": steps}
+    for label, m, n, small in (("level6_65536", Map(level=LEVEL), 65536, 65), ("level6_262144", Map(level=LEVEL), 262144, 65),
+                               ("cfg5_65536", Map(mapgen.config5(0)), 65536, 137)):
+        bw = BatchedWorld(m, n, device=dev)
+        full, incr = bw.sampled_stepper(auto_reset=True, seed=SEED), bw.sampled_stepper(auto_reset=True, seed=SEED, incremental_obs=True)
+        k = steps if n == 65536 and label.startswith("level6") else max(20, steps // 2)
+        for _ in range(10):
+            full()
+        _, f_ms = timer.run(full, k)
+        for _ in range(10):
+            incr()
+        wall, i_ms = timer.run(incr, k)
+        written = m.dyn_row_bytes + small  # rows + state r/w, actions, availability, events (SURVEY section 8(d) without the observation)
+        out[label] = {"full_rewrite_us": f_ms * 1e3, "incremental_us": i_ms * 1e3, "speedup": f_ms / i_ms,
+                      "row_bytes": m.obs_stride, "dyn_row_bytes": m.dyn_row_bytes, "written_bytes_per_env_step": written,
+                      "written_GBps": written * n / (i_ms * 1e-3) / 1e9, "written_frac_of_8TBps": written * n / (i_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "env_steps_per_s": n / (i_ms * 1e-3), "agent_steps_per_s": m.n_agents * n / (i_ms * 1e-3)}
+        del bw, full, incr
+        torch.cuda.empty_cache()
+    return out
+
+
 def measure_consumer_loop(torch, timer, dev, steps):
     """step -> reader -> step on the launch stream: what a policy does between two steps is READ the observation (its first layer),
     which changes what the Infinity Cache holds when the next step rewrites the rows.  Reader = an int8 -> fp16 cast of the whole
@@ -772,8 +802,9 @@ def main():
                                                      "cfg5_bytes_per_launch", fill_ceiling=True),
         }
 
-    lle_step = observers = consumer = multi = None
+    lle_step = observers = consumer = multi = incremental = None
     if world == 1 and not args.no_configs:
+        incremental = measure_incremental(torch, timer, dev, max(args.config_steps, 200))
         multi = measure_multi_map(torch, timer, dev, max(args.config_steps // 2, 50), cfgs["cfg5_32x32_a8_l8_65536"]["kernel_ms"])
         lle_step = measure_lle_step(torch, timer, dev, n, max(args.config_steps, 200))
         observers = measure_observers(torch, timer, dev, n, max(args.config_steps, 200))
@@ -841,6 +872,8 @@ def main():
             out["consumer_loop"] = consumer
         if multi:
             out["cfg5_multi_map"] = multi
+        if incremental:
+            out["incremental_obs"] = incremental
         for key, (T, R, launches, fe, ring_placement) in zip(("fused_rollout", "fused_rollout_double_buffer"), fused):
             # per env-step: obs 1872 + actions 4 + reward 4 + err/evcount/done 3 + events 8, state r/w (48 B) once per launch
             fused_bytes = 1891 + 48.0 / T

@@ -109,6 +109,8 @@ typedef struct lle_map_info {
      * LLE_BUF_BEAMS / LLE_BUF_SRC_COLOUR hold n_beam_words entries per env; == n_sources when no beam is longer than 32 cells
      * (every map of the reference's repository).  lle_laser_tile.word / .bit address a tile's bit. */
     int32_t n_beam_words;
+    int32_t dyn_row_bytes;   /* bytes of a row that dynamic state can change, in whole 128-byte lines: what LLE_STEP_INCREMENTAL_OBS writes per
+                              * env and step (== obs_stride where nothing can be skipped: rows that are not whole lines) */
 } lle_map_info;
 int lle_map_get_info(const lle_map* map, lle_map_info* out);
 

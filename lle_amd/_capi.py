@@ -52,7 +52,7 @@ EXPORTS = [
 class MapInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "height", "width", "n_agents", "n_gems", "n_sources", "n_layers", "n_exits", "n_walls", "n_voids",
-        "n_laser_tiles", "obs_bytes", "obs_stride", "max_beam_len", "max_cell_layers", "obs_supported", "table_bytes", "n_beam_words")]
+        "n_laser_tiles", "obs_bytes", "obs_stride", "max_beam_len", "max_cell_layers", "obs_supported", "table_bytes", "n_beam_words", "dyn_row_bytes")]
 
 
 class SourceInfo(C.Structure):

@@ -242,6 +242,7 @@ int lle_map_get_info(const lle_map* map, lle_map_info* out) {
     out->max_beam_len = mb; out->max_cell_layers = (int)m.header.max_layers;
     out->obs_supported = (int)m.header.obs_supported; out->table_bytes = (int)m.header.blob_bytes;
     out->n_beam_words = m.n_words();
+    out->dyn_row_bytes = (int)(m.header.n_dyn_chunks * 16u);
     return LLE_OK;
 }
 

@@ -1,7 +1,9 @@
 """Soak differential (GPU box): HIP path vs the CPU oracle on long random rollouts, every buffer of every env compared
 bit-for-bit after every step (state, ordered events, availability, error codes, the full int8 observation).
 Beyond the test suite's sizes; prints env-steps compared per map.
-Usage: python tools/soak_parity.py [seconds_per_map] [per-env-sources | full-size | recolour-resets | rollouts | exits]
+Usage: python tools/soak_parity.py [seconds_per_map] [per-env-sources | full-size | recolour-resets | rollouts | exits | incremental]
+With `incremental` every step carries LLE_STEP_INCREMENTAL_OBS (only the lines of a row that dynamic state can change are written):
+the observation compared after every step is the buffer's whole content.
 With `exits` the exits MOVE every 40 steps (World.exit_pos = [...], world.rs:195-234: lle_map_set_exits + lle_batch_update_map on
 the GPU side, set_exit_positions on every oracle world): random legal cells, one of them under a beam where the map has one.
 With `rollouts` the GPU side runs lle_batch_rollout (8 steps per launch into a trajectory ring of 8 slots: the fused
@@ -23,7 +25,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle as om  # noqa: E402  (test infrastructure: this tool is a checker, not product)
 from oracle.levels import LEVELS  # noqa: E402
-from tests.parity_util import EXTRA_MAPS, assert_state_equal, assert_step_equal, legal_colours, unpack_engine  # noqa: E402
+from tests.parity_util import EXTRA_MAPS, LONG_MAPS, assert_state_equal, assert_step_equal, legal_colours, unpack_engine  # noqa: E402
 from lle_amd import BatchedWorld, mapgen  # noqa: E402
 
 import numpy as np  # noqa: E402
@@ -36,6 +38,7 @@ full_size = len(sys.argv) > 2 and sys.argv[2] == "full-size"
 recolour = len(sys.argv) > 2 and sys.argv[2] == "recolour-resets"
 rollouts = len(sys.argv) > 2 and sys.argv[2] == "rollouts"
 exits_mode = len(sys.argv) > 2 and sys.argv[2] == "exits"
+incremental = len(sys.argv) > 2 and sys.argv[2] == "incremental"
 rng = np.random.default_rng(7)
 
 
@@ -68,6 +71,8 @@ def redraw(bw, mirror, A, L, n):
 
 maps = {f"level{k}": (v, 32768) for k, v in LEVELS.items()}
 maps.update({k: (v, 8192) for k, v in EXTRA_MAPS.items()})
+maps.update({k: (v, 8192) for k, v in LONG_MAPS.items()})  # beams longer than 32 cells: chains of beam words (round 4)
+maps["gen_3x60_long_beams"] = (mapgen.generate(3, 60, 3, 3, 2, wall_fraction=0.0, n_voids=1, seed=4, max_beam=254), 8192)
 maps["config5"] = (mapgen.config5(0), 4096)
 # 5-8 sources with few agents: beam masks in the LDS record AND row heads (32 768 envs = 2 048 wavefronts: heads on)
 maps["gen_12x13_4agents_8lasers"] = (mapgen.generate(12, 13, 4, 8, 4, seed=2), 32768)
@@ -84,12 +89,12 @@ for name, (text, n) in maps.items():
     if exits_mode:
         n = min(n, 4096)  # (set_exit_positions on the oracle side is one call per world)
     ob, bw = om.OracleBatch(text, n), BatchedWorld(text, n)
-    dims = (ob.A, ob.G, ob.Ls, ob.beam_stride, ob.C, ob.H, ob.W)
+    dims = ob.dims
     L = bw.map.n_sources
     if (per_env or recolour) and L == 0:
         continue
-    if recolour and bw.map.max_cell_layers > 2:
-        continue
+    if recolour and (bw.map.max_cell_layers > 2 or bw.map.n_beam_words != L):
+        continue  # (the in-kernel draw is per beam word: maps with a beam of several words use lle_batch_reset_sources)
     mirror = Mirror(ob, n, L) if per_env else None
     t, t0 = 0, time.time()
     if recolour:
@@ -136,7 +141,7 @@ for name, (text, n) in maps.items():
         eng["ev_count"] = eng["ev_count"] & 0x7F
         assert_step_equal(eng, ostep, f"{name} t={t}")
         assert_state_equal(eng, ob.dump(), f"{name} t={t}")
-        assert np.array_equal(bw.src_colour.cpu().numpy()[:, :L], colours), f"{name} t={t}: colours"
+        assert np.array_equal(bw.src_colour.cpu().numpy()[:, :L], colours), f"{name} t={t}: colours"  # (words == sources on these maps)
         t += 1
     while not recolour and not rollouts and time.time() - t0 < budget:
         if per_env and t % 48 == 0:
@@ -153,7 +158,7 @@ for name, (text, n) in maps.items():
             assert_state_equal(eng, ob.dump(), f"{name} t={t} after set_exits")
             assert np.array_equal(eng["obs"][:64], np.stack([ob.world(e).obs() for e in range(64)])), f"{name} t={t}: observation after set_exits"
         auto = (t // 64) % 2 == 0  # alternate: auto-reset regime / episodes running into all-dead, all-STAY states (Q1, Q2)
-        bw.step(sample=True, auto_reset=auto, seed=2026, t=t, env_offset=11)
+        bw.step(sample=True, auto_reset=auto, seed=2026, t=t, env_offset=11, incremental_obs=incremental)
         ostep = ob.step(None, auto_reset=auto, seed=2026, t=t, env_offset=11)
         eng = unpack_engine(bw.host_buffers(), *dims)
         assert_step_equal(eng, ostep, f"{name} t={t}")
