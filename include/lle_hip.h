@@ -169,6 +169,9 @@ int lle_map_row_head(const lle_map* map, int32_t* first_byte, int32_t* n_bytes);
 /* The same for batches with per-environment sources (lle_batch_set_sources): the lines that hold no byte an agent, a gem or a
  * laser of ANY colour below n_agents can change (WALL / VOID / EXIT planes).  0 bytes when a source of the map itself has a
  * colour >= n_agents (quirk Q5: its layer aliases those planes). */
+/* Which 128-byte lines of a row dynamic state can change (what LLE_STEP_INCREMENTAL_OBS writes): out_lines[l] = 1 / 0 for line l of the
+ * obs_stride / 128 lines; returns the number of lines (all dynamic where the row is not a whole number of lines).  Host side. */
+int lle_map_row_dynamic_lines(const lle_map* map, uint8_t* out_lines, int cap);
 int lle_map_row_head_env_sources(const lle_map* map, int32_t* first_byte, int32_t* n_bytes);
 
 /* static description of World.lasers (src/core/world.rs:159-172): per laser position the outer layer and, if

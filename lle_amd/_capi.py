@@ -37,7 +37,7 @@ PARSE_ERROR_NAMES = {
 EXPORTS = [
     "lle_abi_version", "lle_last_status", "lle_last_error", "lle_action_hash",
     "lle_map_parse", "lle_map_level", "lle_map_free", "lle_map_get_info", "lle_map_positions", "lle_map_sources",
-    "lle_map_set_source", "lle_map_set_exits", "lle_map_clone", "lle_map_colour_allowed", "lle_map_reset_beam", "lle_map_set_row_align", "lle_map_set_head_lines", "lle_map_row_head", "lle_map_row_head_env_sources", "lle_map_laser_tiles", "lle_map_world_string",
+    "lle_map_set_source", "lle_map_set_exits", "lle_map_clone", "lle_map_colour_allowed", "lle_map_reset_beam", "lle_map_set_row_align", "lle_map_set_head_lines", "lle_map_row_head", "lle_map_row_head_env_sources", "lle_map_row_dynamic_lines", "lle_map_laser_tiles", "lle_map_world_string",
     "lle_batch_arena_bytes", "lle_batch_create", "lle_batch_arena_bytes_multi", "lle_batch_create_multi", "lle_batch_n_maps", "lle_batch_free", "lle_batch_get_buffer", "lle_batch_n_envs",
     "lle_batch_reset", "lle_batch_step", "lle_batch_rollout", "lle_batch_set_state", "lle_batch_update_sources", "lle_batch_update_map", "lle_batch_observe",
     "lle_batch_snapshot_bytes", "lle_batch_snapshot", "lle_batch_restore",
@@ -120,6 +120,8 @@ def lib():
     L.lle_map_level.restype = vp
     L.lle_map_level.argtypes = [i32, C.POINTER(C.c_int)]
     L.lle_map_free.argtypes = [vp]
+    L.lle_map_row_dynamic_lines.restype = i32
+    L.lle_map_row_dynamic_lines.argtypes = [vp, C.POINTER(C.c_uint8), i32]
     L.lle_map_get_info.restype = i32
     L.lle_map_get_info.argtypes = [vp, C.POINTER(MapInfo)]
     L.lle_map_positions.restype = i32
@@ -366,6 +368,14 @@ class Map:
         a, n = C.c_int32(0), C.c_int32(0)
         lib().lle_map_row_head(self.h, C.byref(a), C.byref(n))
         return a.value, n.value
+
+    @property
+    def row_dynamic_lines(self):
+        """One bool per 128-byte line of a row: can dynamic state change it?  (lle_map_row_dynamic_lines; what incremental steps write)"""
+        n = lib().lle_map_row_dynamic_lines(self.h, None, 0)
+        buf = (C.c_uint8 * max(n, 1))()
+        lib().lle_map_row_dynamic_lines(self.h, buf, n)
+        return [bool(buf[k]) for k in range(n)]
 
     @property
     def row_head_env_sources(self):

@@ -339,6 +339,19 @@ int lle_map_row_head(const lle_map* map, int32_t* first_byte, int32_t* n_bytes) 
     return LLE_OK;
 }
 
+int lle_map_row_dynamic_lines(const lle_map* map, uint8_t* out_lines, int cap) {
+    if (!map) return fail(LLE_ERR_NULL, "NULL map");
+    const MapHeader& h = map->m.header;
+    const int n_lines = (int)((h.obs_stride + 127u) / 128u);
+    for (int l = 0; l < n_lines && l < cap && out_lines; l++) out_lines[l] = h.n_dyn_chunks >= h.n_chunks ? 1 : 0;
+    if (h.n_dyn_chunks < h.n_chunks && out_lines) {
+        const uint16_t* tab = reinterpret_cast<const uint16_t*>(map->m.blob.data() + h.off_dyn_chunks);
+        for (uint32_t i = 0; i < h.n_dyn_chunks; i++)
+            if ((int)(tab[i] / 8u) < cap) out_lines[tab[i] / 8u] = 1;
+    }
+    return n_lines;
+}
+
 int lle_map_row_head_env_sources(const lle_map* map, int32_t* first_byte, int32_t* n_bytes) {
     if (!map) return fail(LLE_ERR_NULL, "NULL map");
     if (first_byte) *first_byte = (int32_t)(map->m.header.pes_head_lo * 16u);

@@ -208,6 +208,34 @@ def test_row_head_bytes_never_change(oracle_mod, name):
 
 
 @pytest.mark.parametrize("name", sorted(dict({f"level{k}": v for k, v in LEVELS.items()}, **EXTRA_MAPS)))
+def test_static_lines_of_a_row_never_change(oracle_mod, name):
+    """lle_map_row_dynamic_lines: the 128-byte lines that LLE_STEP_INCREMENTAL_OBS does NOT write hold the same bytes in every
+    environment after every step of an oracle rollout (deaths, collected gems, beams switching, resets) -- the bytes of the
+    reset observation; the row head is a run of them; rows that are not whole lines are all dynamic."""
+    from lle_amd import Map
+
+    text = dict({f"level{k}": v for k, v in LEVELS.items()}, **EXTRA_MAPS)[name]
+    m = Map(text, row_align=128)
+    lines = m.row_dynamic_lines
+    assert len(lines) == m.obs_stride // 128 and sum(lines) * 128 == m.dyn_row_bytes
+    first, nbytes = m.row_head
+    assert not any(lines[first // 128: (first + nbytes) // 128])
+    static = np.zeros(m.obs_stride, bool)
+    for l, dynamic in enumerate(lines):
+        static[l * 128:(l + 1) * 128] = not dynamic
+    static = static[: m.obs_bytes]
+    n = 256
+    ob = oracle_mod.OracleBatch(text, n)
+    ref = np.stack([ob.world(e).obs() for e in range(4)]).reshape(4, -1)[:, static]
+    assert (ref == ref[0]).all()
+    for t in range(60):
+        rows = ob.step(None, auto_reset=(t // 20) % 2 == 0, seed=23, t=t)["obs"].reshape(n, -1)
+        assert (rows[:, static] == ref[0]).all(), (name, t)
+    packed = Map(text, row_align=16)
+    assert packed.obs_stride % 128 == 0 or (all(packed.row_dynamic_lines) and packed.dyn_row_bytes == packed.obs_stride)
+
+
+@pytest.mark.parametrize("name", sorted(dict({f"level{k}": v for k, v in LEVELS.items()}, **EXTRA_MAPS)))
 def test_reset_beam_table_matches_oracle_reset(oracle_mod, name):
     """lle_map_reset_beam(s, c) -- what LLE_STEP_RECOLOUR_RESETS stores as an env's reset beams -- against the oracle:
     colour c on source s, World.reset, read the beam (for every pair the binding's set_colour accepts)."""
