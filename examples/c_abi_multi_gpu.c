@@ -39,6 +39,31 @@
         }                                                                                    \
     } while (0)
 
+/* 64-bit checksum of the 64-env window that starts at global env id `offset`, stepped 8 times on `device`: positions, alive / arrived /
+ * occupant bits, beam words and the int8 layered observation, copied back and hashed on the host (FNV-1a over the bytes, in that order). */
+static int window_hash(const lle_map* map, int device, hipStream_t stream, int64_t offset, uint64_t* out) {
+    enum { ENVS = 64, STEPS = 8 };
+    lle_batch* w = lle_batch_create(map, ENVS, device, NULL, 0, stream);
+    if (!w) { fprintf(stderr, "window batch: %s\n", lle_last_error()); return 1; }
+    for (int t = 0; t < STEPS; t++)
+        CHECK_LLE(lle_batch_step(w, NULL, LLE_STEP_SAMPLE_ACTIONS | LLE_STEP_AUTO_RESET, 1234, (uint64_t)t, offset, stream));
+    CHECK_HIP(hipStreamSynchronize(stream));
+    uint64_t h = 1469598103934665603ull;
+    const int which[4] = {LLE_BUF_POS, LLE_BUF_BITS, LLE_BUF_BEAMS, LLE_BUF_OBS};
+    for (int k = 0; k < 4; k++) {
+        lle_buffer_desc d;
+        CHECK_LLE(lle_batch_get_buffer(w, which[k], &d));
+        const size_t bytes = (size_t)ENVS * (size_t)d.stride[0] * (size_t)d.elem_bytes;
+        uint8_t* host = (uint8_t*)malloc(bytes);
+        CHECK_HIP(hipMemcpy(host, d.ptr, bytes, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < bytes; i++) { h ^= host[i]; h *= 1099511628211ull; }
+        free(host);
+    }
+    lle_batch_free(w);
+    *out = h;
+    return 0;
+}
+
 static double now_s(void) {
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -84,6 +109,34 @@ int main(int argc, char** argv) {
     int current = -1;
     CHECK_HIP(hipGetDevice(&current));
     if (current != n_gpus - 1) { fprintf(stderr, "the library changed the current device (%d)\n", current); return 1; }
+
+    /* Before anything is timed: shard invariance over the run's own collective (bench.py's `shard_check`).  GPU g
+     * hashes the window at the head of ITS shard (env_offset = g * n) into slot g of an int64[n_gpus] array on its device, one RCCL
+     * all-reduce (sum; the other slots are zero) hands every rank every hash, and GPU 0 recomputes all windows with the matching offsets. */
+    {
+        int64_t* slots[MAX_GPUS];
+        for (int g = 0; g < n_gpus; g++) {
+            uint64_t h = 0;
+            if (window_hash(map, g, stream[g], (int64_t)g * n, &h)) return 1;
+            int64_t mine[MAX_GPUS] = {0};
+            mine[g] = (int64_t)(h >> 1);  /* (63 bits: a sum of one value and zeros cannot overflow) */
+            CHECK_HIP(hipSetDevice(g));
+            CHECK_HIP(hipMalloc((void**)&slots[g], sizeof mine));
+            CHECK_HIP(hipMemcpy(slots[g], mine, sizeof mine, hipMemcpyHostToDevice));
+        }
+        CHECK_HIP(hipSetDevice(n_gpus - 1));
+        CHECK_LLE(lle_comm_allreduce_i64_group(comm, slots, streams, n_gpus, n_gpus, LLE_COMM_SUM));
+        int64_t got[MAX_GPUS];
+        CHECK_HIP(hipStreamSynchronize(stream[0]));
+        CHECK_HIP(hipMemcpy(got, slots[0], sizeof(int64_t) * (size_t)n_gpus, hipMemcpyDeviceToHost));
+        for (int g = 0; g < n_gpus; g++) {
+            uint64_t h = 0;
+            if (window_hash(map, 0, stream[0], (int64_t)g * n, &h)) return 1;
+            if ((int64_t)(h >> 1) != got[g]) { fprintf(stderr, "shard check FAILED: GPU %d's window differs from GPU 0's replay of it\n", g); return 1; }
+        }
+        for (int g = 0; g < n_gpus; g++) { CHECK_HIP(hipStreamSynchronize(stream[g])); CHECK_HIP(hipFree(slots[g])); }
+        printf("shard check: ok (%d window(s) of 64 envs x 8 steps hashed on their GPUs, all-reduced over RCCL, replayed on GPU 0)\n", n_gpus);
+    }
 
     const int warmup = 50;
     for (int t = 0; t < warmup; t++)

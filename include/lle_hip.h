@@ -463,6 +463,9 @@ int lle_batch_stats_allreduce_group(lle_batch* const* batches, lle_comm* const* 
 /* In-place all-reduce of `count` int64 values in device memory (op: LLE_COMM_SUM / LLE_COMM_MAX), asynchronous on `stream`:
  * for a host's own end-of-batch numbers (e.g. the slowest rank's elapsed nanoseconds). */
 int lle_comm_allreduce_i64(lle_comm* c, int64_t* buf_dev, int count, int op, void* stream);
+/* The same for ONE process that owns all n ranks: bufs_dev[k] on the device of comms[k]; the n calls are posted inside one group.
+ * Asynchronous on streams[k] (NULL: the default streams). */
+int lle_comm_allreduce_i64_group(lle_comm* const* comms, int64_t* const* bufs_dev, void* const* streams, int n, int count, int op);
 
 /* The sampler used by LLE_STEP_SAMPLE_ACTIONS (host copy, for harnesses): the 16-bit field f of (seed, env, t, agent);
  * the action taken is the k-th available one in enum order with k = (f * popcount(avail)) >> 16.  See DESIGN.md. */

@@ -43,7 +43,7 @@ EXPORTS = [
     "lle_batch_snapshot_bytes", "lle_batch_snapshot", "lle_batch_restore",
     "lle_batch_set_sources", "lle_batch_reset_sources", "lle_batch_obs_desc", "lle_batch_observe_as", "lle_batch_available_actions", "lle_batch_env_outputs", "lle_batch_step_outputs",
     "lle_comm_unique_id", "lle_comm_create", "lle_comm_create_all", "lle_comm_free", "lle_comm_rank", "lle_batch_stats_allreduce",
-    "lle_batch_stats_allreduce_group", "lle_comm_allreduce_i64",
+    "lle_batch_stats_allreduce_group", "lle_comm_allreduce_i64", "lle_comm_allreduce_i64_group",
     "lle_batch_stats", "lle_batch_kernel_info", "lle_batch_set_envs_per_wave", "lle_batch_step_stamped", "lle_batch_probe_row_fill",
     "lle_batch_autotune", "lle_batch_tuning", "lle_tuning_refresh", "lle_probe_read_rows", "lle_probe_fill_rows",
 ]
@@ -214,6 +214,8 @@ def lib():
     L.lle_batch_stats_allreduce.argtypes = [vp, vp, C.POINTER(C.c_int64), i32, vp]
     L.lle_batch_stats_allreduce_group.restype = i32
     L.lle_batch_stats_allreduce_group.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, C.POINTER(C.c_int64), i32]
+    L.lle_comm_allreduce_i64_group.restype = i32
+    L.lle_comm_allreduce_i64_group.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i32, i32]
     L.lle_comm_allreduce_i64.restype = i32
     L.lle_comm_allreduce_i64.argtypes = [vp, vp, i32, i32, vp]
     L.lle_batch_kernel_info.restype = i32

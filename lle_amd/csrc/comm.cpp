@@ -218,6 +218,26 @@ int lle_comm_allreduce_i64(lle_comm* c, int64_t* buf_dev, int count, int op, voi
     return lle::capi_ok();
 }
 
+int lle_comm_allreduce_i64_group(lle_comm* const* comms, int64_t* const* bufs_dev, void* const* streams, int n, int count, int op) {
+    if (!comms || !bufs_dev) return lle::capi_fail(LLE_ERR_NULL, "NULL argument");
+    if (n < 1 || n > 64 || count < 1 || (op != LLE_COMM_SUM && op != LLE_COMM_MAX)) return lle::capi_fail(LLE_ERR_ARG, "n / count / op out of range");
+    Rccl* R = rccl();
+    if (!R) return no_rccl();
+    for (int k = 0; k < n; k++) {
+        if (!comms[k] || !bufs_dev[k]) return lle::capi_fail(LLE_ERR_NULL, "NULL handle");
+        if (comms[k]->n_ranks != n) return lle::capi_fail(LLE_ERR_ARG, "the group must hold every rank of the communicator");
+    }
+    RCCL_TRY(R, R->GroupStart());  // one process drives every rank: all calls inside one group, or the first would block
+    for (int k = 0; k < n; k++) {
+        DeviceScopeC scope(comms[k]->device);
+        ncclResult_t r = R->AllReduce(bufs_dev[k], bufs_dev[k], (size_t)count, NCCL_INT64, op == LLE_COMM_SUM ? NCCL_SUM : NCCL_MAX, comms[k]->comm,
+                                      (hipStream_t)(streams ? streams[k] : nullptr));
+        if (r != 0) { (void)R->GroupEnd(); return lle::capi_fail(LLE_ERR_HIP, std::string("ncclAllReduce: ") + R->GetErrorString(r)); }
+    }
+    RCCL_TRY(R, R->GroupEnd());
+    return lle::capi_ok();
+}
+
 int lle_batch_stats_allreduce(lle_batch* b, lle_comm* c, int64_t out[8], int reset_counters, void* stream) {
     if (!b || !c || !out) return lle::capi_fail(LLE_ERR_NULL, "NULL argument");
     if (lle::capi_batch_device(b) != c->device) return lle::capi_fail(LLE_ERR_ARG, "batch and communicator live on different devices");

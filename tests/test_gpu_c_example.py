@@ -70,6 +70,8 @@ def test_c_host_owning_one_handle_per_gpu_reduces_over_rccl():
     row = next(ln for ln in lines if ln.startswith("env_steps"))
     stats = dict(zip(row.split()[0::2], map(int, row.split()[1::2])))
     assert n_gpus >= 1 and stats["env_steps"] == n_gpus * 8192 * 40 and stats["invalid"] == 0
+    # round 4: before anything is timed, every GPU's first 64 envs hashed, all-reduced over RCCL (lle_comm_allreduce_i64_group), replayed on GPU 0
+    assert any(ln.startswith("shard check: ok") for ln in lines), res.stdout
     # more GPUs than visible: refused, never a smaller run under the same name
     res = subprocess.run([exe, "64", "2", "99"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=60, env=env)
     assert res.returncode == 2 and "refusing" in res.stdout
@@ -110,5 +112,10 @@ def test_comm_api_with_one_rank_matches_the_local_counters():
     assert L.lle_batch_stats_allreduce_group(batches, comms, streams, 1, out, 1) == 0, L.lle_last_error()
     assert list(out) == list(local.values())
     assert bw.stats()["env_steps"] == 0  # reset_counters
+    grp = torch.tensor([11, -3, 2**40], dtype=torch.int64, device=bw.device)
+    bufs = (C.c_void_p * 1)(grp.data_ptr())
+    assert L.lle_comm_allreduce_i64_group(comms, bufs, streams, 1, 3, 0) == 0, L.lle_last_error()
+    torch.cuda.synchronize()
+    assert grp.tolist() == [11, -3, 2**40]
     L.lle_comm_free(comms[0])
     assert L.lle_comm_create(ident, 2, 5, 0) is None and L.lle_last_status() == -2
