@@ -588,6 +588,9 @@ def measure_lle_step(torch, timer, dev, n, steps):
     for key, kw, mode in (("two_launches_us", {}, {}), ("two_launches_persistent_us", {}, {"persistent": True}), ("one_launch_us", {}, {"fused": True}),
                           ("randomize_lasers_two_launches_us", {"randomize_lasers": True}, {}),
                           ("randomize_lasers_one_launch_us", {"randomize_lasers": True}, {"fused": True}),
+                          # opt-in incremental rows (LLE_STEP_INCREMENTAL_OBS): not the default path
+                          ("one_launch_incremental_us", {"incremental_obs": True}, {"fused": True}),
+                          ("randomize_lasers_one_launch_incremental_us", {"randomize_lasers": True, "incremental_obs": True}, {"fused": True}),
                           # obs_type="partial7x7": step + partial observer + outputs (persistent: bound calls), and all of it in the step launch
                           ("partial7x7_three_launches_persistent_us", {"obs_type": "partial7x7"}, {"persistent": True}),
                           ("partial7x7_one_launch_us", {"obs_type": "partial7x7"}, {"fused": True})):

@@ -260,7 +260,7 @@ enum {
                                     hold the same bytes after every step and are already in the buffer from the last full write (create, reset,
                                     observe, any source / exit update, any step without this flag), so the buffer's CONTENT is the same; the
                                     caller promises not to have written into LLE_BUF_OBS itself.  Ignored (full rows) by fused rollouts into
-                                    rings, with per-environment sources and on rows that are not whole 128-byte lines. */
+                                    rings and on rows that are not whole 128-byte lines; with per-environment sources every laser plane is dynamic. */
     LLE_STEP_RECOLOUR_RESETS = 8 /* with LLE_STEP_AUTO_RESET, batches with per-environment sources: an env that is reset also draws a
                                     fresh colour for each of its sources -- LLE.reset with randomize_lasers (python/lle/env/
                                     env.py:189-203: world.reset() under the colours the env had, then the new colours on the live

@@ -693,7 +693,8 @@ hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const Laun
     if (pes) {
         if (roll) return launch_step_mode3(G, lm, P, K, n_waves, wpw, lds, stream);
         // single steps: the colour-independent head lines ahead of the state machine (MODE 8) under the same conditions as below
-        const bool heads_pes = lm <= 8 && h.pes_head_n != 0 && !(K.flags & (LAUNCH_SPLIT_ROWS | STEP_NO_OBS)) && row_heads_pay(n_waves, true, tune.heads);
+        const bool incr_pes = (K.flags & STEP_INCREMENTAL_OBS) != 0 && h.n_pes_dyn_chunks < h.n_chunks;  // (static lines not written: no head to send ahead)
+        const bool heads_pes = !incr_pes && lm <= 8 && h.pes_head_n != 0 && !(K.flags & (LAUNCH_SPLIT_ROWS | STEP_NO_OBS)) && row_heads_pay(n_waves, true, tune.heads);
         return heads_pes ? launch_step_mode8(G, lm, P, K, n_waves, wpw, lds, stream) : launch_step_mode5(G, lm, P, K, n_waves, wpw, lds, stream);
     }
     // single-step launches with the map's sources: the rows' head lines go out ahead of the state machine (MODE 6 / 7) when

@@ -601,15 +601,35 @@ void Map::compile() {
             recolour[(size_t)b * (A + 1) + 1 + c] = beam;
         }
     }
+    // the dynamic chunks of a row under per-environment colours (tables.h off_pes_dyn_chunks)
+    std::vector<uint16_t> pes_dyn_chunks;
+    {
+        bool plain_colours = h.obs_stride % 128u == 0 && h.obs_supported && h.n_chunks <= 0xFFFFu;
+        for (auto& src : sources) plain_colours = plain_colours && src.agent_id < A;
+        const uint32_t n_lines = h.obs_stride / 128u;
+        std::vector<uint8_t> dynamic_line(n_lines ? n_lines : 1, plain_colours ? 0 : 1);
+        for (uint32_t l = 0; plain_colours && l < n_lines && l * 128u < (uint32_t)(2 * A * HW); l++) dynamic_line[l] = 1;
+        for (int g = 0; plain_colours && g < G; g++) dynamic_line[(uint32_t)((2 * A + 2) * HW + gems[g].i * W + gems[g].j) / 128u] = 1;
+        if (plain_colours) {
+            for (uint32_t l = 0; l < n_lines; l++)
+                if (dynamic_line[l])
+                    for (uint32_t c = 0; c < 8; c++) pes_dyn_chunks.push_back((uint16_t)(l * 8u + c));
+        }
+        h.n_pes_dyn_chunks = plain_colours ? (uint32_t)pes_dyn_chunks.size() : h.n_chunks;
+        if (!plain_colours) pes_dyn_chunks.clear();
+    }
     h.off_recolour = h.off_elems + h.n_elems * 4u;
     // (the step kernel draws one colour per WORD: exact only where a word is a source)
     h.recolour_exact = (h.max_layers <= 2 && chain_mask == 0) ? 1u : 0u;
-    h.ext_bytes = (h.obs_stride + h.n_elems * 4u + (uint32_t)recolour.size() * 4u + 1023u) & ~1023u;
+    h.off_pes_dyn_chunks = (h.off_recolour + (uint32_t)recolour.size() * 4u + 15u) & ~15u;
+    // (sized for the largest table -- every chunk of the row --, so that ext_bytes does not depend on the colours)
+    h.ext_bytes = ((h.off_pes_dyn_chunks - h.off_bare) + h.n_chunks * 2u + 1023u) & ~1023u;
     off = (size_t)h.blob_capacity + h.ext_bytes;
     blob.assign(off, 0);
     std::memcpy(blob.data() + h.off_bare, bare.data(), bare.size());
     if (!elems.empty()) std::memcpy(blob.data() + h.off_elems, elems.data(), elems.size() * 4);
     if (!recolour.empty()) std::memcpy(blob.data() + h.off_recolour, recolour.data(), recolour.size() * 4);
+    if (!pes_dyn_chunks.empty()) std::memcpy(blob.data() + h.off_pes_dyn_chunks, pes_dyn_chunks.data(), pes_dyn_chunks.size() * 2);
     std::memcpy(blob.data() + h.off_cell_lay, cell_lay.data(), cell_lay.size() * 8);
     std::memcpy(blob.data() + h.off_cell_meta, cell_meta.data(), cell_meta.size() * 4);
     if (!dyn_tab.empty()) std::memcpy(blob.data() + h.off_dyn, dyn_tab.data(), dyn_tab.size() * 8);

@@ -357,13 +357,19 @@ __device__ __forceinline__ void elem_eval(uint32_t e, const uint32_t* sc, int A,
     val = type == ELEM_SOURCE ? -1 : 1;
     on = type == ELEM_SOURCE ? true : (is_gem ? ((sc[L + 1] >> i5) & 1u) != 0 : ((sc[1 + i5] >> off) & 1u) != 0);
 }
-template <bool WT, bool HEAD = false>
+template <bool WT, bool HEAD = false, bool INCR = false>
 __device__ __forceinline__ void write_observations_env(int A, int L, uint32_t HW, uint32_t n_elems, uint32_t n_chunks,
                                                        uint64_t obs_stride, const uint32_t* elems, const int8_t* bare,
                                                        int8_t* tmpl, const uint32_t* scratch, uint32_t scr_stride,
                                                        int8_t* __restrict__ obs, int64_t env0, int64_t n_here, uint32_t lane,
                                                        const uint8_t* laser_layer = nullptr, uint32_t gem_layer_in = 0xFFFFFFFFu,
-                                                       uint32_t head_lo = 0, uint32_t head_n = 0, uint32_t rot = 0) {
+                                                       uint32_t head_lo = 0, uint32_t head_n = 0, uint32_t rot = 0,
+                                                       const uint16_t* dyn_chunks = nullptr, uint32_t n_dyn_chunks = 0) {
+    uint32_t dc0 = 0xFFFFu, dc1 = 0xFFFFu;  // INCR: this lane's first two dynamic chunks (stream_row_dyn)
+    if constexpr (INCR) {
+        dc0 = lane < n_dyn_chunks ? (uint32_t)dyn_chunks[lane] : 0xFFFFu;
+        dc1 = lane + 64u < n_dyn_chunks ? (uint32_t)dyn_chunks[lane + 64u] : 0xFFFFu;
+    }
     const uint32_t gem_layer = gem_layer_in == 0xFFFFFFFFu ? (uint32_t)(2 * A + 2) : gem_layer_in;
     const bool has_e0 = lane < n_elems;
     const uint32_t e0 = has_e0 ? elems[lane] : 0u;
@@ -397,7 +403,8 @@ __device__ __forceinline__ void write_observations_env(int A, int L, uint32_t HW
         if (is_agent_lane) tmpl[agent_idx] = 1;
         wave_sync();
         uint4* __restrict__ dst = reinterpret_cast<uint4*>(obs + (uint64_t)(env0 + k) * obs_stride);
-        if constexpr (HEAD) stream_row_tail<WT>(dst, srcv, n_chunks, head_lo, head_n, lane);  // (the head is stored already: store_heads)
+        if constexpr (INCR) stream_row_dyn<WT>(dst, srcv, dyn_chunks, n_dyn_chunks, dc0, dc1, lane);
+        else if constexpr (HEAD) stream_row_tail<WT>(dst, srcv, n_chunks, head_lo, head_n, lane);  // (the head is stored already: store_heads)
         else stream_whole_row<WT>(dst, srcv, n_chunks, lane);
         wave_sync();
         // bare bytes back (LDS is in order: after the reads above, before the next environment's writes).  On the agent / laser

@@ -126,8 +126,10 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     const uint32_t h_off_cell_meta = hdr->off_cell_meta, h_off_dyn = hdr->off_dyn, h_off_template = hdr->off_template;
     const uint32_t h_max_layers = ML1 ? 1u : hdr->max_layers;
     // STEP_INCREMENTAL_OBS (tables.h): single steps in place with the map's own sources write only the lines dynamic state can change
-    constexpr bool CAN_INCR = !ROLL && !PES && !PARTIAL;
-    const uint32_t h_off_dyn_chunks = CAN_INCR ? hdr->off_dyn_chunks : 0u, h_n_dyn_chunks = CAN_INCR ? hdr->n_dyn_chunks : 0u;
+    // (per-environment sources: the table of the per-env-sources section -- laser planes all dynamic)
+    constexpr bool CAN_INCR = !ROLL && !PARTIAL;
+    const uint32_t h_off_dyn_chunks = CAN_INCR ? (PES ? hdr->off_pes_dyn_chunks : hdr->off_dyn_chunks) : 0u;
+    const uint32_t h_n_dyn_chunks = CAN_INCR ? (PES ? hdr->n_pes_dyn_chunks : hdr->n_dyn_chunks) : 0u;
     const bool incr = CAN_INCR && (K.flags & STEP_INCREMENTAL_OBS) != 0 && h_n_dyn_chunks < h_n_chunks;
     const uint32_t h_off_recolour = PES ? hdr->off_recolour : 0u, h_off_bare = PES ? hdr->off_bare : 0u;
     const uint32_t h_off_elems = PES ? hdr->off_elems : 0u, h_n_elems = PES ? hdr->n_elems : 0u;
@@ -303,7 +305,8 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     const uint64_t* cell_lay = reinterpret_cast<const uint64_t*>(lds);
     const uint32_t* cell_meta = reinterpret_cast<const uint32_t*>(lds + (h_off_cell_meta - tab_off));
     const uint64_t* dyn = reinterpret_cast<const uint64_t*>(lds + (h_off_dyn - tab_off));
-    const uint16_t* dyn_chunks = reinterpret_cast<const uint16_t*>(lds + (h_off_dyn_chunks - tab_off));
+    const uint16_t* dyn_chunks = PES ? reinterpret_cast<const uint16_t*>(lds + tab_bytes + (h_off_dyn_chunks - h_off_bare))
+                                     : reinterpret_cast<const uint16_t*>(lds + (h_off_dyn_chunks - tab_off));
     const uint32_t scr_stride = (uint32_t)(L + A + 2 + (PES ? CW : 0)) | 1u;
     // a wavefront's private area: [row template | hand-over records]; PARTIAL: [E rows of the partial observation + 16 B | records]
     const uint32_t part_pitch = PARTIAL ? (((uint32_t)(A * (2 * A + 3)) * K.partial_k * K.partial_k + 15u) & ~15u) : 0u;
@@ -598,7 +601,12 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
                                 scr_stride, O.partial, env0, n_here, lane);
     } else if (write_obs && n_here > 0) {
         const bool wt = (K.flags & LAUNCH_WRITE_THROUGH) != 0;  // see stream_store (obs_stream.hpp)
-        if (PES) {
+        if (PES && CAN_INCR && incr) {
+            if (wt) write_observations_env<true, false, true>(A, L, h_HW, h_n_elems, h_n_chunks, h_obs_stride, elems, bare, tmpl, scratch, scr_stride,
+                                                              obs_out, env0, n_here, lane, nullptr, 0xFFFFFFFFu, 0u, 0u, LLE_ROT(), dyn_chunks, h_n_dyn_chunks);
+            else write_observations_env<false, false, true>(A, L, h_HW, h_n_elems, h_n_chunks, h_obs_stride, elems, bare, tmpl, scratch, scr_stride,
+                                                            obs_out, env0, n_here, lane, nullptr, 0xFFFFFFFFu, 0u, 0u, LLE_ROT(), dyn_chunks, h_n_dyn_chunks);
+        } else if (PES) {
             if (wt) write_observations_env<true, HEAD>(A, L, h_HW, h_n_elems, h_n_chunks, h_obs_stride, elems, bare, tmpl, scratch, scr_stride,
                                                        obs_out, env0, n_here, lane, nullptr, 0xFFFFFFFFu, head_lo, head_n, LLE_ROT());
             else write_observations_env<false, HEAD>(A, L, h_HW, h_n_elems, h_n_chunks, h_obs_stride, elems, bare, tmpl, scratch, scr_stride,

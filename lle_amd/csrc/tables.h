@@ -99,7 +99,10 @@ struct MapHeader {
     // step (the head lines above are a run of those), so a single step that rewrites the rows IN PLACE may leave them alone
     // (STEP_INCREMENTAL_OBS): level 6 writes 10 of its 15 lines.  n_dyn_chunks == n_chunks: nothing to skip (or unaligned rows).
     uint32_t off_dyn_chunks, n_dyn_chunks;
-    uint32_t head_pad[17];  // (pads the header to 640 B: the table sections behind it start on a 128-byte line)
+    // the same under per-environment source colours (inside the per-env-sources section, like off_recolour): a laser byte may sit on
+    // any of the A laser planes, so every line below 2A * HW is dynamic, and behind them the lines with a gem byte (pes_head_* is a run of the rest)
+    uint32_t off_pes_dyn_chunks, n_pes_dyn_chunks;
+    uint32_t head_pad[15];  // (pads the header to 640 B: the table sections behind it start on a 128-byte line)
 };
 static_assert(sizeof(MapHeader) % 128 == 0, "the sections start on a 128-byte line (the LDS copy loads 1 KiB per wave instruction)");
 

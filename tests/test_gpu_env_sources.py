@@ -400,3 +400,42 @@ def test_fused_rollout_with_per_env_sources_on_many_source_maps(name):
     for slot, (obs, acts) in obs_of_step.items():
         assert torch.equal(ring["obs"][slot], obs) and torch.equal(ring["actions"][slot], acts), (name, "ring slot", slot)
     assert a.stats()["env_steps"] == b.stats()["env_steps"] == n * T
+
+
+@pytest.mark.parametrize("name", ["level6", "level5", "nested", "three_beams", "many_agents"])
+def test_incremental_rows_with_per_env_sources(oracle_mod, name):
+    """LLE_STEP_INCREMENTAL_OBS on batches with per-environment sources (tables.h off_pes_dyn_chunks: every laser plane is dynamic, the
+    WALL / VOID / EXIT lines are not written): the buffer's content equals that of a twin stepped without the flag and the oracle's,
+    through re-colourings mid-episode, masked subsets, and resets re-coloured inside the step kernel."""
+    import torch
+
+    from lle_amd import BatchedWorld
+
+    text = MAPS[name]
+    n = 300
+    ob = oracle_mod.OracleBatch(text, n)
+    a, b = BatchedWorld(text, n), BatchedWorld(text, n)
+    A, L = ob.A, a.map.n_sources
+    mirror = Mirror(ob, n, L)
+    rng = np.random.default_rng(9)
+    t = 0
+    for episode in range(3):
+        colours = legal_colours(a.map, rng.integers(0, A, size=(n, L), dtype=np.uint8))
+        enabled = rng.integers(0, 1 << L, size=n, dtype=np.int64).astype(np.int32)
+        mask = (rng.random(n) < 0.7).astype(np.uint8) if episode else None
+        for bw in (a, b):
+            bw.set_sources(torch.from_numpy(colours), torch.from_numpy(enabled), None if mask is None else torch.from_numpy(mask))
+        mirror.apply(colours, enabled, mask)
+        for _ in range(8):
+            a.step(sample=True, auto_reset=True, seed=13, t=t, incremental_obs=True)
+            b.step(sample=True, auto_reset=True, seed=13, t=t)
+            ostep = ob.step(None, auto_reset=True, seed=13, t=t)
+            assert torch.equal(a.obs_rows, b.obs_rows), (name, t)
+            check(a, ob, ostep, f"{name} incremental + per-env sources t={t}")
+            t += 1
+    if a.map.max_cell_layers <= 2:  # resets re-coloured inside the step kernel (LLE_STEP_RECOLOUR_RESETS)
+        for _ in range(12):
+            a.step(sample=True, auto_reset=True, recolour_resets=True, seed=13, t=t, incremental_obs=True)
+            b.step(sample=True, auto_reset=True, recolour_resets=True, seed=13, t=t)
+            assert torch.equal(a.obs_rows, b.obs_rows) and torch.equal(a.src_colour, b.src_colour), (name, t)
+            t += 1
