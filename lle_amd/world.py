@@ -37,7 +37,7 @@ class InvalidLevelError(ValueError):
 _PARSE_MESSAGES = {
     "EmptyWorld": "Empty world: no tiles", "NoAgents": "No agents in the world",
     "TomlUnsupported": "TOML (v2) world descriptions are not supported by lle_amd (v1 text maps only)",
-    "Limit": "The map exceeds a static limit of lle_amd (agents<=16, sources<=32, gems<=32, beam length<=32, side<=255)",
+    "Limit": "The map exceeds a static limit of lle_amd (agents<=16, sources<=32, gems<=32, side<=255, 32 beam words of 32 cells over all beams)",
 }
 
 
