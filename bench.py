@@ -659,6 +659,8 @@ def main():
                     help="GPU time lle_batch_autotune may spend per batch choosing its launch rules (0 = the library's default rules)")
     ap.add_argument("--no-fused", action="store_true", help="skip the secondary fused-rollout measurement")
     ap.add_argument("--no-configs", action="store_true", help="skip roofline_hbm and the cfg2 / cfg5 blocks")
+    ap.add_argument("--no-multi-map", action="store_true",
+                    help="skip the cfg5_multi_map block (thousands of tiny launches at batch creation: rocprofv3 --pmc crashes on them)")
     ap.add_argument("--fused-steps", type=int, default=16, help="steps per launch of the fused rollout")
     ap.add_argument("--ring-slots", type=int, default=8, help="trajectory ring slots of the fused rollout")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of a self-spawned N-rank run (0 = pick a free one)")
@@ -808,7 +810,8 @@ def main():
     lle_step = observers = consumer = multi = incremental = None
     if world == 1 and not args.no_configs:
         incremental = measure_incremental(torch, timer, dev, max(args.config_steps, 200))
-        multi = measure_multi_map(torch, timer, dev, max(args.config_steps // 2, 50), cfgs["cfg5_32x32_a8_l8_65536"]["kernel_ms"])
+        if not args.no_multi_map:
+            multi = measure_multi_map(torch, timer, dev, max(args.config_steps // 2, 50), cfgs["cfg5_32x32_a8_l8_65536"]["kernel_ms"])
         lle_step = measure_lle_step(torch, timer, dev, n, max(args.config_steps, 200))
         observers = measure_observers(torch, timer, dev, n, max(args.config_steps, 200))
         consumer = measure_consumer_loop(torch, timer, dev, max(args.config_steps, 200))

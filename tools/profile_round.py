@@ -58,7 +58,7 @@ def main():
     bench_prof = json.loads(res.stdout.strip().splitlines()[-1])
     for kind, counter in (("write", "WRITE_SIZE"), ("fetch", "FETCH_SIZE")):
         run(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(OUT, f"pmc_{kind}"), "--",
-             sys.executable, BENCH] + light + ["--no-fused", "--steps", "50"], f"pmc_{kind}.err")
+             sys.executable, BENCH] + light + ["--no-fused", "--steps", "50", "--no-multi-map"], f"pmc_{kind}.err")  # (see bench.py --no-multi-map)
 
     trace = list(csv.DictReader(open(latest("stats/**/*_kernel_trace.csv"))))
     stats = list(csv.DictReader(open(latest("stats/**/*_kernel_stats.csv"))))
