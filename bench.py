@@ -456,15 +456,23 @@ def measure_multi_map(torch, timer, dev, steps, single_map_kernel_ms):
     for n_maps in (1024, 4096):
         per = 65536 // n_maps
         t0 = time.perf_counter()
-        bw = BatchedWorld([mapgen.config5(seed) for seed in range(n_maps)], 65536, device=dev)
+        # (placed like the single-map block it is compared with: past the Infinity Cache the arena's write rate is a lottery)
+        bw = BatchedWorld([mapgen.config5(seed) for seed in range(n_maps)], 65536, device=dev,
+                          placement_candidates=PLACEMENT_CANDIDATES if n_maps <= 1024 else 2)
         create_s = time.perf_counter() - t0
         fn = stepper(bw)
         for _ in range(max(10, steps // 10)):
             fn()
         wall, ms = timer.run(fn, steps)
+        probe = bw.row_fill_prober()
+        for _ in range(4):
+            probe()
+        _, p_ms = timer.run(probe, max(10, steps // 4))
+        bw.observe()
         achieved = ALGO_BYTES_CFG5 * 65536 / (ms * 1e-3) / 1e9
         out[f"maps{n_maps}_x{per}"] = {"n_maps": n_maps, "envs_per_map": per, "steps": steps, "kernel_ms": ms, "ms_per_step": wall / steps * 1e3,
                                        "achieved_GBps": achieved, "vs_single_map": ms / single_map_kernel_ms if single_map_kernel_ms else None,
+                                       "row_fill_us": p_ms * 1e3, "frac_of_fill": p_ms / ms, "placement": bw.placement,
                                        "create_s": create_s, "table_MB": n_maps * bw.maps[0].table_bytes / 1e6, "kernel": bw.kernel_info(),
                                        "rollout_stats": bw.stats()}
         del bw, fn
