@@ -503,6 +503,7 @@ typedef struct lle_tuning_info {
     int32_t alternating_walk; /* 1: successive launches walk the environments alternately up and down */
     int32_t rotate_rows;      /* 1: every wavefront starts its stream at another one of its rows (whole-row streams only) */
     int32_t autotuned;        /* 1: lle_batch_autotune has run on this handle (else: the default rules) */
+    int32_t head_group;       /* 1 / 2 / 4: wavefronts of a workgroup whose row heads ONE of them stores (row_heads == 1 only; default 1) */
 } lle_tuning_info;
 int lle_batch_autotune(lle_batch* b, double budget_ms, void* stream);
 /* The rules a plain single step of this batch is launched with, and (log_buf, optional) the trial log of lle_batch_autotune. */

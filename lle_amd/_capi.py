@@ -72,7 +72,7 @@ class EnvOutputs(C.Structure):
 
 class TuningInfo(C.Structure):
     """lle_tuning_info (include/lle_hip.h)."""
-    _fields_ = [(n, C.c_int32) for n in ("envs_per_wave", "row_heads", "write_through", "split_rows", "alternating_walk", "rotate_rows", "autotuned")]
+    _fields_ = [(n, C.c_int32) for n in ("envs_per_wave", "row_heads", "write_through", "split_rows", "alternating_walk", "rotate_rows", "autotuned", "head_group")]
 
 
 class RolloutRing(C.Structure):

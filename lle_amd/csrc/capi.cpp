@@ -1238,7 +1238,7 @@ int lle_batch_autotune(lle_batch* b, double budget_ms, void* stream) {
     std::vector<uint32_t> epws;
     for (uint32_t e = cap; e >= 1 && epws.size() < 3; e >>= 1) epws.push_back(e);
     const bool can_heads = step_has_row_heads(h, pes), can_split = step_can_split_rows(h, pes), can_walk = row_bytes > (256ull << 20);
-    const int n_trials = (int)epws.size() + (can_heads ? 2 : 0) + 2 + (can_split ? 2 : 0) + (can_walk ? 2 : 0) + 2;
+    const int n_trials = (int)epws.size() + (can_heads ? 4 : 0) + 2 + (can_split ? 2 : 0) + (can_walk ? 2 : 0) + 2;
     uint64_t t_idx = 1u << 20;
     StepTune best = b->tune;
     double probe_us = 0.0;
@@ -1270,6 +1270,7 @@ int lle_batch_autotune(lle_batch* b, double budget_ms, void* stream) {
     };
     sweep("envs_per_wave", std::vector<int>(epws.begin(), epws.end()), [](StepTune& t, int v) { t.epw = (uint8_t)v; });
     if (can_heads) sweep("row_heads", {0, 1}, [](StepTune& t, int v) { t.heads = (int8_t)v; });
+    if (can_heads && best.heads == 1) sweep("head_group", {1, 2}, [](StepTune& t, int v) { t.head_group = (int8_t)v; });
     sweep("write_through", {0, 1}, [](StepTune& t, int v) { t.write_through = (int8_t)v; });
     if (can_split) sweep("split_rows", {0, 1}, [](StepTune& t, int v) { t.split = (int8_t)v; });
     if (can_walk) sweep("alternating_walk", {0, 1}, [](StepTune& t, int v) { t.walk = (int8_t)v; });
@@ -1307,6 +1308,7 @@ int lle_batch_tuning(const lle_batch* b, lle_tuning_info* out, char* log_buf, si
         heads = forced >= 0 ? forced : ((general ? n_waves >= 2048u : (n_waves >= 2048u && n_waves <= 12288u)) ? 1 : 0);
     }
     out->row_heads = heads;
+    out->head_group = heads ? (tuning().head_group ? tuning().head_group : (t.head_group ? (int)t.head_group : 1)) : 1;
     out->autotuned = b->tune_log.empty() ? 0 : 1;
     if (log_buf && cap) std::snprintf(log_buf, cap, "%s", b->tune_log.c_str());
     g_status = LLE_OK;

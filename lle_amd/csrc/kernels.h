@@ -43,6 +43,7 @@ struct Tuning {
     int partial_kernel = 0;    // LLE_PARTIAL_KERNEL: 0 unset, 1 "lanes", 2 "window", 3 "project", 4 anything else ("auto")
     int partial_e = 0, partial_batches = 0, partial_wt = -1, partial_epw = 0;  // LLE_PARTIAL_E / _BATCHES / _WT / _EPW
     int row_rotate = -1;       // LLE_ROW_ROTATE = 0 / 1
+    int head_group = 0;        // LLE_HEAD_GROUP = 1 / 2 / 4: wavefronts whose row heads ONE wavefront stores (step_kernel.hpp HEAD)
 };
 const Tuning& tuning();
 void tuning_refresh();
@@ -55,6 +56,7 @@ struct StepTune {
     int8_t split = -1;          // split rows (big observations)
     int8_t walk = -1;           // alternating walk of outputs larger than the Infinity Cache
     int8_t rotate = -1;         // every wavefront starts its stream at another one of its rows
+    int8_t head_group = 0;      // 1 / 2 / 4: wavefronts of a workgroup whose row heads one of them stores (0: the default rule)
     uint8_t epw = 0;            // environments per wavefront
 };
 

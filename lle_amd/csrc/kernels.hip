@@ -479,6 +479,7 @@ void tuning_refresh() {
     if (const char* o = getenv("LLE_PARTIAL_WT")) t.partial_wt = o[0] == '1' ? 1 : 0;
     t.partial_epw = env_uint("LLE_PARTIAL_EPW");
     t.row_rotate = env_bool("LLE_ROW_ROTATE");
+    t.head_group = env_uint("LLE_HEAD_GROUP");
     g_tuning = t;
     g_tuning_loaded.store(true, std::memory_order_release);
 }
@@ -708,7 +709,12 @@ hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const Laun
         return heads ? launch_step_mode7(G, lm, P, K, n_waves, wpw, lds, stream) : launch_step_mode4(G, lm, P, K, n_waves, wpw, lds, stream);
     }
     if (roll) return launch_step_mode1(G, lm, P, K, n_waves, wpw, lds, stream);
-    if (heads) return launch_step_mode6(G, lm, P, K, n_waves, wpw, lds, stream);
+    if (heads) {
+        const int hg = tuning().head_group ? tuning().head_group : (tune.head_group ? (int)tune.head_group : 1);
+        if (hg == 2) K.flags |= LAUNCH_HEAD_GROUP2;
+        if (hg == 4) K.flags |= LAUNCH_HEAD_GROUP4;
+        return launch_step_mode6(G, lm, P, K, n_waves, wpw, lds, stream);
+    }
     return launch_step_mode0(G, lm, P, K, n_waves, wpw, lds, stream);
 }
 

@@ -292,11 +292,30 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         // compiler can see, or it puts its own vmcnt(0) where the loaded values are first used -- inside the loop of
         // head stores and in the state machine -- where it would wait for the stores as well
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-        if (head_n && n_here > 0) {
-            if (K.flags & LAUNCH_WRITE_THROUGH) store_heads<true>(P.obs, h_obs_stride, env0, n_here, head_lo, head_n, head_v, lane, LLE_ROT());
-            else store_heads<false>(P.obs, h_obs_stride, env0, n_here, head_lo, head_n, head_v, lane, LLE_ROT());
+        const uint32_t hgroup = (K.flags & LAUNCH_HEAD_GROUP4) ? 4u : ((K.flags & LAUNCH_HEAD_GROUP2) ? 2u : 1u);
+        if (hgroup == 1u) {
+            if (head_n && n_here > 0) {
+                if (K.flags & LAUNCH_WRITE_THROUGH) store_heads<true>(P.obs, h_obs_stride, env0, n_here, head_lo, head_n, head_v, lane, LLE_ROT());
+                else store_heads<false>(P.obs, h_obs_stride, env0, n_here, head_lo, head_n, head_v, lane, LLE_ROT());
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS only: not the head stores' acknowledgements
+        } else {
+            // Phase shift inside the workgroup (round 4): one wavefront of every `hgroup` stores the heads of the whole group's rows (they are
+            // the same bytes for every row), the others go straight to their state machines -- their tails then stream while the head
+            // wavefronts are still in theirs, instead of every wavefront of the CU being in the same phase at the same time.
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (ahead of the head stores here: nobody waits for the storing wavefront)
+            if (head_n && (wave_in_wg & (hgroup - 1u)) == 0u) {
+                for (uint32_t q = 0; q < hgroup && wave_in_wg + q < waves_per_wg; q++) {
+                    const int64_t e0q = env0 + (int64_t)q * EPW;
+                    int64_t nq = K.env_limit - e0q;
+                    nq = nq < 0 ? 0 : (nq > (int64_t)EPW ? (int64_t)EPW : nq);
+                    if (nq > 0) {
+                        if (K.flags & LAUNCH_WRITE_THROUGH) store_heads<true>(P.obs, h_obs_stride, e0q, nq, head_lo, head_n, head_v, lane);
+                        else store_heads<false>(P.obs, h_obs_stride, e0q, nq, head_lo, head_n, head_v, lane);
+                    }
+                }
+            }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS only: not the head stores' acknowledgements
     } else {
         __syncthreads();  // the only workgroup barrier
         LLE_LOAD_STATE();

@@ -149,3 +149,53 @@ def test_source_update_moves_the_head(oracle_mod, heads_forced):
             bw.step(sample=True, auto_reset=True, seed=8, t=t)
             check(bw, ob, ob.step(None, auto_reset=True, seed=8, t=t), f"colour {colour} t={t}")
     assert len(heads) >= 2, heads
+
+
+@pytest.mark.parametrize("group", ["2", "4"])
+@pytest.mark.parametrize("name", ["level6", "level3", "gen_12x13_4agents_8lasers"])
+def test_head_groups_match_oracle(oracle_mod, heads_forced, monkeypatch, name, group):
+    """LLE_HEAD_GROUP (step_kernel.hpp HEAD; lle_batch_autotune's `head_group`): one wavefront of every 2 / 4 of a workgroup stores the
+    row heads of the whole group, the others go straight to their state machines.  A ragged last workgroup included."""
+    from lle_amd import BatchedWorld, Map
+
+    monkeypatch.setenv("LLE_HEAD_GROUP", group)
+    m = Map(MAPS[name], row_align=128)
+    n = 1000 + 8 * int(group)
+    ob = oracle_mod.OracleBatch(MAPS[name], n)
+    bw = BatchedWorld(m, n)
+    assert bw.tuning()["head_group"] == int(group)
+    bw.obs_rows.fill_(55)
+    for t in range(16):
+        auto = t % 8 != 7
+        bw.step(sample=True, auto_reset=auto, seed=7, t=t, env_offset=5)
+        check(bw, ob, ob.step(None, auto_reset=auto, seed=7, t=t, env_offset=5), f"{name} group={group} t={t}")
+
+
+def test_head_groups_in_the_general_kernels(heads_forced, monkeypatch):
+    """The same on several maps per batch (MODE 7) and with per-environment sources (MODE 8): equal buffers whatever the group."""
+    import torch
+
+    from lle_amd import BatchedWorld, mapgen
+    from tests.parity_util import legal_colours
+
+    texts = [mapgen.generate(seed=100 + s, height=9, width=11, n_agents=3, n_lasers=4, n_gems=3, n_voids=2) for s in range(5)]
+    per, want = 208, None
+    for group in ("1", "2", "4"):
+        monkeypatch.setenv("LLE_HEAD_GROUP", group)
+        got = []
+        for pes in (False, True):
+            bw = BatchedWorld(texts, per * len(texts), row_align=128)
+            if pes:
+                g = torch.Generator(device="cuda").manual_seed(1)
+                bw.set_sources(colours=legal_colours(bw.maps, torch.randint(0, 3, (bw.n_envs, bw.map.n_sources), generator=g, device="cuda", dtype=torch.uint8)))
+            bw.obs_rows.fill_(55)
+            for t in range(12):
+                bw.step(sample=True, auto_reset=True, seed=3, t=t)
+            torch.cuda.synchronize()
+            got.append((bw.obs_rows.clone(), bw.pos.clone(), bw.beams.clone()))
+        if want is None:
+            want = got
+        else:
+            for (a, b) in zip(want, got):
+                for x, y in zip(a, b):
+                    assert torch.equal(x, y), group
