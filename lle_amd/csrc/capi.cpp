@@ -436,7 +436,15 @@ static void bind_ptrs(lle_batch* b) {
     p.init_avail = base + l.off_env_init[4];
 }
 
+#ifdef LLE_STAMP_SINGLE
+// diagnostic build only (tools/lle_prof.py stamps --outputs): the next step launches of the process stamp into this buffer
+static uint64_t* g_debug_stamps = nullptr;
+extern "C" void lle_debug_set_stamps(void* stamps_dev) { g_debug_stamps = (uint64_t*)stamps_dev; }
+#endif
 static int launch(lle_batch* b, int mode, LaunchArgs K, void* stream) {
+#ifdef LLE_STAMP_SINGLE
+    if (mode == KMODE_STEP && g_debug_stamps && !K.stamps && !(K.flags & STEP_RECOLOUR_RESETS)) K.stamps = g_debug_stamps;
+#endif
     K.envs_per_wave = b->envs_per_wave;
     K.env_base = 0;
     K.env_limit = b->n_envs;

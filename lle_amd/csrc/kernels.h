@@ -43,6 +43,7 @@ struct Tuning {
     int partial_kernel = 0;    // LLE_PARTIAL_KERNEL: 0 unset, 1 "lanes", 2 "window", 3 "project", 4 anything else ("auto")
     int partial_e = 0, partial_batches = 0, partial_wt = -1, partial_epw = 0;  // LLE_PARTIAL_E / _BATCHES / _WT / _EPW
     int row_rotate = -1;       // LLE_ROW_ROTATE = 0 / 1
+    int post_first = -1;       // LLE_POST_FIRST = 0 / 1: every wavefront's small outputs after / before its observation stream (default: by position in the grid)
     int head_group = 0;        // LLE_HEAD_GROUP = 1 / 2 / 4: wavefronts whose row heads ONE wavefront stores (step_kernel.hpp HEAD)
 };
 const Tuning& tuning();

@@ -480,6 +480,7 @@ void tuning_refresh() {
     t.partial_epw = env_uint("LLE_PARTIAL_EPW");
     t.row_rotate = env_bool("LLE_ROW_ROTATE");
     t.head_group = env_uint("LLE_HEAD_GROUP");
+    t.post_first = env_bool("LLE_POST_FIRST");
     g_tuning = t;
     g_tuning_loaded.store(true, std::memory_order_release);
 }
@@ -644,7 +645,12 @@ bool step_has_row_heads(const MapHeader& h, bool pes) {
     return step_lm((int)h.L) <= 8 && (pes ? h.pes_head_n : h.head_n) != 0;
 }
 
-static bool roll_requested(const LaunchArgs& K) { return K.n_steps > 1 || K.ring_slots || K.stamps; }
+#ifdef LLE_STAMP_SINGLE
+static bool stamps_roll(const LaunchArgs&) { return false; }  // (diagnostic build: a stamped single step stays a single step)
+#else
+static bool stamps_roll(const LaunchArgs& K) { return K.stamps != nullptr; }
+#endif
+static bool roll_requested(const LaunchArgs& K) { return K.n_steps > 1 || K.ring_slots || stamps_roll(K); }
 
 hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K_in, hipStream_t stream, const StepTune& tune) {
     LaunchArgs K = K_in;
@@ -657,8 +663,9 @@ hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const Laun
         if (rotate_rows_pays(tune, (uint64_t)(K.env_limit - K.env_base) * h.obs_stride * slots, h.obs_stride)) K.flags |= LAUNCH_ROTATE_ROWS;
     }
     if (pes || K.envs_per_map || K.env_out) K.flags |= LAUNCH_GENERAL;  // (fused LLE.step outputs: MODE 4 / 5 carry the epilogue)
-    if (K.env_out && (K.n_steps > 1 || K.ring_slots || K.stamps)) return hipErrorInvalidValue;  // single steps only
-    if (K.n_steps > 1 || K.ring_slots || K.stamps) K.flags |= LAUNCH_ROLLOUT;
+    if (K.env_out && roll_requested(K)) return hipErrorInvalidValue;  // single steps only
+    if (tuning().post_first >= 0) K.flags |= tuning().post_first ? LAUNCH_POST_FIRST : LAUNCH_POST_LAST;
+    if (roll_requested(K)) K.flags |= LAUNCH_ROLLOUT;
     if (h.max_layers <= 1) K.flags |= LAUNCH_SINGLE_LAYER;  // several maps: `h` carries the maximum over the maps
     uint32_t wpw = kernel_waves_per_wg(h, pes);
     if (K.envs_per_map) {  // a workgroup's environments must belong to one map

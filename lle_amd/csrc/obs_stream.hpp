@@ -61,49 +61,86 @@ __device__ __forceinline__ uint32_t rotated(uint32_t k, uint32_t rot, uint32_t n
 // ---- static tables -> LDS, once per workgroup (section offsets are those of the blob).  The section is a whole
 // number of 1 KiB rows; every thread requests all of its rows (up to four) before the first LDS write.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// Both copies below request up to EIGHT rows per thread (32 rows per pass of a four-wavefront workgroup) before the first LDS write:
+// a pass is a global round trip in front of every workgroup's first instruction of real work.  With four rows per thread the
+// per-env-sources section of level 6 (12 + 5 rows) took a second pass for ONE row -- 2.3 us on every step with per-environment
+// sources (in-kernel stamps: tables in LDS 3.95 us after entry against 1.61; profiles/r04_pes_tax.md) --, config 5 (33 rows) three.
+// (named scalars, not an array: an indexed private array here ended up in scratch memory)
+#define LLE_COPY_ROWS(SRC)                                                                                              \
+    for (uint32_t r0 = wave_in_wg; r0 < rows; r0 += 8 * waves_per_wg) {                                                \
+        const uint32_t r1 = r0 + waves_per_wg, r2 = r1 + waves_per_wg, r3 = r2 + waves_per_wg, r4 = r3 + waves_per_wg, \
+                       r5 = r4 + waves_per_wg, r6 = r5 + waves_per_wg, r7 = r6 + waves_per_wg;                          \
+        const u32x4 z = {0, 0, 0, 0};                                                                                   \
+        u32x4 v0 = SRC(r0), v1 = z, v2 = z, v3 = z, v4 = z, v5 = z, v6 = z, v7 = z;                                      \
+        if (r1 < rows) v1 = SRC(r1);                                                                                    \
+        if (r2 < rows) v2 = SRC(r2);                                                                                    \
+        if (r3 < rows) v3 = SRC(r3);                                                                                    \
+        if (r4 < rows) {                                                                                                \
+            v4 = SRC(r4);                                                                                               \
+            if (r5 < rows) v5 = SRC(r5);                                                                                \
+            if (r6 < rows) v6 = SRC(r6);                                                                                \
+            if (r7 < rows) v7 = SRC(r7);                                                                                \
+        }                                                                                                               \
+        __builtin_amdgcn_sched_barrier(0); /* keep the loads together, ahead of the LDS writes */                       \
+        dst[r0 * 64] = v0;                                                                                              \
+        if (r1 < rows) dst[r1 * 64] = v1;                                                                               \
+        if (r2 < rows) dst[r2 * 64] = v2;                                                                               \
+        if (r3 < rows) dst[r3 * 64] = v3;                                                                               \
+        if (r4 < rows) {                                                                                                \
+            dst[r4 * 64] = v4;                                                                                          \
+            if (r5 < rows) dst[r5 * 64] = v5;                                                                           \
+            if (r6 < rows) dst[r6 * 64] = v6;                                                                           \
+            if (r7 < rows) dst[r7 * 64] = v7;                                                                           \
+        }                                                                                                               \
+    }
 __device__ __forceinline__ void copy_tables_to_lds(const uint8_t* __restrict__ tables, uint8_t* lds, uint32_t tab_bytes,
                                                    uint32_t lane, uint32_t wave_in_wg, uint32_t waves_per_wg) {
     const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(tables) + lane;
     u32x4* dst = reinterpret_cast<u32x4*>(lds) + lane;
     const uint32_t rows = tab_bytes / 1024;
-    for (uint32_t r0 = wave_in_wg; r0 < rows; r0 += 4 * waves_per_wg) {
-        // rows r0, r0 + W, r0 + 2W, r0 + 3W of this wavefront (named scalars, not an array: an indexed private array
-        // here ended up in scratch memory)
-        const uint32_t r1 = r0 + waves_per_wg, r2 = r1 + waves_per_wg, r3 = r2 + waves_per_wg;
-        u32x4 v0 = src[r0 * 64], v1 = {0, 0, 0, 0}, v2 = {0, 0, 0, 0}, v3 = {0, 0, 0, 0};
-        if (r1 < rows) v1 = src[r1 * 64];
-        if (r2 < rows) v2 = src[r2 * 64];
-        if (r3 < rows) v3 = src[r3 * 64];
-        __builtin_amdgcn_sched_barrier(0);  // keep the loads together, ahead of the LDS writes
-        dst[r0 * 64] = v0;
-        if (r1 < rows) dst[r1 * 64] = v1;
-        if (r2 < rows) dst[r2 * 64] = v2;
-        if (r3 < rows) dst[r3 * 64] = v3;
-    }
+#define LLE_SRC1(r) src[(r) * 64]
+    LLE_COPY_ROWS(LLE_SRC1)
+#undef LLE_SRC1
 }
 
 // Two sections into consecutive LDS ranges (the map tables and, behind them, the per-env-sources section), with the rows of BOTH
 // requested before the first LDS write: called one after the other, the second copy's loads would only be issued once the
-// first copy's have returned -- a second global round trip in front of every workgroup's first instruction of real work.
+// first copy's have returned.
 __device__ __forceinline__ void copy_tables2_to_lds(const uint8_t* __restrict__ t1, uint32_t bytes1, const uint8_t* __restrict__ t2, uint32_t bytes2,
                                                     uint8_t* lds, uint32_t lane, uint32_t wave_in_wg, uint32_t waves_per_wg) {
     const u32x4* __restrict__ s1 = reinterpret_cast<const u32x4*>(t1) + lane;
     const u32x4* __restrict__ s2 = reinterpret_cast<const u32x4*>(t2) + lane;
     u32x4* dst = reinterpret_cast<u32x4*>(lds) + lane;
     const uint32_t rows1 = bytes1 / 1024, rows = rows1 + bytes2 / 1024;
-    auto src = [&](uint32_t r) -> const u32x4* { return r < rows1 ? s1 + r * 64 : s2 + (r - rows1) * 64; };
-    for (uint32_t r0 = wave_in_wg; r0 < rows; r0 += 4 * waves_per_wg) {
-        const uint32_t r1 = r0 + waves_per_wg, r2 = r1 + waves_per_wg, r3 = r2 + waves_per_wg;
-        u32x4 v0 = *src(r0), v1 = {0, 0, 0, 0}, v2 = {0, 0, 0, 0}, v3 = {0, 0, 0, 0};
-        if (r1 < rows) v1 = *src(r1);
-        if (r2 < rows) v2 = *src(r2);
-        if (r3 < rows) v3 = *src(r3);
-        __builtin_amdgcn_sched_barrier(0);  // keep the loads together, ahead of the LDS writes
-        dst[r0 * 64] = v0;
-        if (r1 < rows) dst[r1 * 64] = v1;
-        if (r2 < rows) dst[r2 * 64] = v2;
-        if (r3 < rows) dst[r3 * 64] = v3;
+#define LLE_SRC2(r) (*((r) < rows1 ? s1 + (r) * 64 : s2 + ((r) - rows1) * 64))
+    LLE_COPY_ROWS(LLE_SRC2)
+#undef LLE_SRC2
+}
+#undef LLE_COPY_ROWS
+
+// ---- the small stores of a step (state, events, counters, the fused LLE.step outputs): a few dozen bytes per environment.
+// Plain, they stay dirty in the XCD's L2 until the end of the kernel, whose release then writes them back before the next launch
+// can start; LLE_SMALL_WT (an A/B build: profiles/r04_pes_tax.md) writes them through as they are issued.
+template <typename T>
+__device__ __forceinline__ void small_store(T* p, T v) {
+#ifdef LLE_SMALL_WT
+    if constexpr (sizeof(T) == 1) {
+        asm volatile("global_store_byte %0, %1, off sc1" ::"v"(p), "v"((uint32_t)(uint8_t)v) : "memory");
+    } else if constexpr (sizeof(T) == 2) {
+        asm volatile("global_store_short %0, %1, off sc1" ::"v"(p), "v"((uint32_t)(uint16_t)v) : "memory");
+    } else if constexpr (sizeof(T) == 4) {
+        uint32_t w;
+        __builtin_memcpy(&w, &v, 4);
+        asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
+    } else {
+        static_assert(sizeof(T) == 8, "small_store: 1, 2, 4 or 8 bytes");
+        uint64_t w;
+        __builtin_memcpy(&w, &v, 8);
+        asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
     }
+#else
+    *p = v;
+#endif
 }
 
 // ---- the stores of an observation stream.

@@ -81,11 +81,17 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     const bool split = CAN_SPLIT && (K.flags & LAUNCH_SPLIT_ROWS) != 0;
     // The default instantiation is one step in place and nothing else: the fused rollout (n_steps, trajectory rings)
     // and the timeline stamps run on the general one, so that their arguments do not occupy scalar registers here.
-    uint64_t* const stamps = ROLL ? K.stamps : nullptr;
+    // (-DLLE_STAMP_SINGLE: a diagnostic build whose single-step kernels stamp too -- tools/lle_prof.py stamps --single; never the shipped library)
+#ifdef LLE_STAMP_SINGLE
+    constexpr bool STAMPED = true;
+#else
+    constexpr bool STAMPED = ROLL;
+#endif
+    uint64_t* const stamps = STAMPED ? K.stamps : nullptr;
 #undef LLE_STAMP
 #define LLE_STAMP(i)                                                                              \
     do {                                                                                          \
-        if (ROLL && stamps && lane == 0) stamps[(uint64_t)wave_id * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+        if (STAMPED && stamps && lane == 0) stamps[(uint64_t)wave_id * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
     // environments per wavefront: at most 64 / G; fewer (lanes left idle) when the batch is small, so that there
     // are enough wavefronts to spread phase 2 over the chip
@@ -127,7 +133,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     const uint32_t h_max_layers = ML1 ? 1u : hdr->max_layers;
     // STEP_INCREMENTAL_OBS (tables.h): single steps in place with the map's own sources write only the lines dynamic state can change
     // (per-environment sources: the table of the per-env-sources section -- laser planes all dynamic)
-    constexpr bool CAN_INCR = !ROLL && !PARTIAL;
+    constexpr bool CAN_INCR = !ROLL && !PARTIAL && !HEAD;  // (the launcher sends incremental launches to the kernels without heads: no head to send ahead)
     const uint32_t h_off_dyn_chunks = CAN_INCR ? (PES ? hdr->off_pes_dyn_chunks : hdr->off_dyn_chunks) : 0u;
     const uint32_t h_n_dyn_chunks = CAN_INCR ? (PES ? hdr->n_pes_dyn_chunks : hdr->n_dyn_chunks) : 0u;
     const bool incr = CAN_INCR && (K.flags & STEP_INCREMENTAL_OBS) != 0 && h_n_dyn_chunks < h_n_chunks;
@@ -292,7 +298,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         // compiler can see, or it puts its own vmcnt(0) where the loaded values are first used -- inside the loop of
         // head stores and in the state machine -- where it would wait for the stores as well
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-        const uint32_t hgroup = (K.flags & LAUNCH_HEAD_GROUP4) ? 4u : ((K.flags & LAUNCH_HEAD_GROUP2) ? 2u : 1u);
+        const uint32_t hgroup = MODE != 6 ? 1u : ((K.flags & LAUNCH_HEAD_GROUP4) ? 4u : ((K.flags & LAUNCH_HEAD_GROUP2) ? 2u : 1u));  // (the default kernel only)
         if (hgroup == 1u) {
             if (head_n && n_here > 0) {
                 if (K.flags & LAUNCH_WRITE_THROUGH) store_heads<true>(P.obs, h_obs_stride, env0, n_here, head_lo, head_n, head_v, lane, LLE_ROT());
@@ -452,7 +458,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     if (K.flags & STEP_SAMPLE_ACTIONS) {
         const uint32_t hp = action_hash_pair(action_step_key(K.seed, t_now), (uint64_t)(K.env_offset + env), a >> 1);
         act = sample_action(avail, action_field(hp, a));
-        if (me) actions_out[env * As + a] = (uint8_t)act;
+        if (me) small_store(&actions_out[env * As + a], (uint8_t)act);
     } else if (!ROLL) {
         act = act_given;
         if (me && K.actions_in) P.actions[env * As + a] = (uint8_t)act;
@@ -486,19 +492,19 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
 #pragma unroll
     for (int k = 0; k < NW; k++) evw[k] = grp_or64<G>(evw[k]);
     if (env_ok && a == 0) {
-        *LLE_LATE(err, env_c) = (uint8_t)err;
-        *LLE_LATE(evcount, env_c) = (uint8_t)(n_ev | (was_reset << 7));
+        small_store(LLE_LATE(err, env_c), (uint8_t)err);
+        small_store(LLE_LATE(evcount, env_c), (uint8_t)(n_ev | (was_reset << 7)));
         {
             uint8_t* row = LLE_LATE(events, env_c * 2 * As);  // 2*As bytes per env; this kernel fills the first 2*G
             if (G >= 2) {
                 uint32_t* __restrict__ w = reinterpret_cast<uint32_t*>(row);
 #pragma unroll
-                for (int k = 0; k < G / 2; k++) w[k] = (uint32_t)(evw[k >> 1] >> ((k & 1) * 32));
+                for (int k = 0; k < G / 2; k++) small_store(&w[k], (uint32_t)(evw[k >> 1] >> ((k & 1) * 32)));
             } else {
-                *reinterpret_cast<uint16_t*>(row) = (uint16_t)evw[0];
+                small_store(reinterpret_cast<uint16_t*>(row), (uint16_t)evw[0]);
             }
         }
-        *LLE_LATE(done, env_c) = ((alive | ghost) != amask || arrived == amask) ? 1 : 0;
+        small_store(LLE_LATE(done, env_c), (uint8_t)(((alive | ghost) != amask || arrived == amask) ? 1 : 0));
         uint32_t n_died = 0, n_gem = 0;
 #pragma unroll
         for (int k = 0; k < NW; k++) {
@@ -507,7 +513,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         }
         const uint32_t n_exit = n_ev - n_died - n_gem;
         const uint32_t bonus = (err == 0 && arrived == amask) ? 1u : 0u;
-        reward_out[env] = n_gem | (n_exit << 8) | (n_died << 16) | (bonus << 24);
+        small_store(&reward_out[env], n_gem | (n_exit << 8) | (n_died << 16) | (bonus << 24));
         cnt.steps += 1u; cnt.gems += n_gem; cnt.exits += n_exit; cnt.died += n_died;
         cnt.invalid += err != 0 ? 1u : 0u; cnt.resets += was_reset; cnt.bonus += bonus;
     }
@@ -524,12 +530,12 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         const int n_gems = (int)h_G, len = 3 * A + n_gems;
         if (me) {
             const int64_t ia = env * A + a;
-            if (O.alive) O.alive[ia] = (uint8_t)((alive >> a) & 1u);
-            if (O.arrived) O.arrived[ia] = (uint8_t)((arrived >> a) & 1u);
+            if (O.alive) small_store(&O.alive[ia], (uint8_t)((alive >> a) & 1u));
+            if (O.arrived) small_store(&O.arrived[ia], (uint8_t)((arrived >> a) & 1u));
             if (O.available) {
                 uint8_t* o = O.available + ia * 5;
 #pragma unroll
-                for (int k = 0; k < 5; k++) o[k] = (uint8_t)((avail >> k) & 1u);
+                for (int k = 0; k < 5; k++) small_store(&o[k], (uint8_t)((avail >> k) & 1u));
             }
             if (O.state) {  // WorldState.as_array: [i0, j0, ..., gems..., alive...] (pyworld_state.rs:79-101)
                 float* st = O.state + env * len;
@@ -538,15 +544,15 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
                     fi = (float)((double)(pos & 0xFFu) / (double)h_H);
                     fj = (float)((double)(pos >> 8) / (double)W);
                 }
-                st[2 * a] = fi;
-                st[2 * a + 1] = fj;
-                st[2 * A + n_gems + (int)a] = ((alive >> a) & 1u) ? 1.0f : 0.0f;
+                small_store(&st[2 * a], fi);
+                small_store(&st[2 * a + 1], fj);
+                small_store(&st[2 * A + n_gems + (int)a], ((alive >> a) & 1u) ? 1.0f : 0.0f);
             }
         }
         if (env_ok && O.state)
-            for (int g = (int)a; g < n_gems; g += G) O.state[env * len + 2 * A + g] = ((gems >> g) & 1u) ? 1.0f : 0.0f;
+            for (int g = (int)a; g < n_gems; g += G) small_store(&O.state[env * len + 2 * A + g], ((gems >> g) & 1u) ? 1.0f : 0.0f);
         if (env_ok && a == 0) {
-            if (O.done) O.done[env] = ((alive | ghost) != amask || arrived == amask) ? 1 : 0;
+            if (O.done) small_store(&O.done[env], (uint8_t)(((alive | ghost) != amask || arrived == amask) ? 1 : 0));
             if (O.reward) {
                 uint32_t n_died = 0, n_gem = 0;
 #pragma unroll
@@ -557,11 +563,11 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
                 const float gem = (float)n_gem, died = (float)n_died, ex = (float)(n_ev - n_died - n_gem);
                 const float bonus = (err == 0 && arrived == amask) ? 1.0f : 0.0f;
                 if (O.reward_kind == 0) {
-                    O.reward[env] = gem + ex - died + bonus;  // reward_strategy.py:58-75
+                    small_store(&O.reward[env], gem + ex - died + bonus);  // reward_strategy.py:58-75
                 } else {                                      // reward_strategy.py:90-109: a death zeroes the others
                     const bool dead = n_died > 0;
                     float* o = O.reward + env * 4;
-                    o[0] = dead ? 0.f : gem; o[1] = dead ? 0.f : ex; o[2] = -died; o[3] = dead ? 0.f : bonus;
+                    small_store(&o[0], dead ? 0.f : gem); small_store(&o[1], dead ? 0.f : ex); small_store(&o[2], -died); small_store(&o[3], dead ? 0.f : bonus);
                 }
             }
         }
@@ -594,7 +600,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     LLE_STAMP(4);
     // (deferring it in the single-step launches of MODE 1 / 2 as well measured 1.3-1.5 us SLOWER there: those
     // instantiations already spill, and the deferral lengthens the live ranges)
-    const bool post_first = ROLL || PARTIAL || blockIdx.x * 4u >= gridDim.x * 3u;  // (PARTIAL: the writer wants the state machine's registers)
+    const bool post_first = ROLL || PARTIAL || (K.flags & LAUNCH_POST_FIRST) || (!(K.flags & LAUNCH_POST_LAST) && blockIdx.x * 4u >= gridDim.x * 3u);  // (PARTIAL: the writer wants the state machine's registers)
     if (post_first) post_step();
 
     if (split) {
@@ -646,26 +652,26 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     // ---- final state.  Written unconditionally: an env whose action was refused kept its registers unchanged
     // (world.rs:436-453: errors precede any mutation), so this rewrites the same bytes.
     if (me) {
-        *LLE_LATE(pos, env_c * As + a) = (uint16_t)pos;
-        *LLE_LATE(avail, env_c * As + a) = (uint8_t)avail;
+        small_store(LLE_LATE(pos, env_c * As + a), (uint16_t)pos);
+        small_store(LLE_LATE(avail, env_c * As + a), (uint8_t)avail);
     }
     if (env_ok && a == 0) {
-        *LLE_LATE(bits, env_c) = (uint64_t)alive | ((uint64_t)arrived << 16) | ((uint64_t)occ << 32) | ((uint64_t)ghost << GHOST_SHIFT);
-        *LLE_LATE(gems, env_c) = gems;
+        small_store(LLE_LATE(bits, env_c), (uint64_t)alive | ((uint64_t)arrived << 16) | ((uint64_t)occ << 32) | ((uint64_t)ghost << GHOST_SHIFT));
+        small_store(LLE_LATE(gems, env_c), gems);
         uint32_t* const beams_out = LLE_LATE(beams, env_c * L);
 #pragma unroll
         for (int b = 0; b < LR; b++)
-            if (!BM && b < L) beams_out[b] = beams[b];
+            if (!BM && b < L) small_store(&beams_out[b], beams[b]);
     }
     if (BM && env_ok) {
         uint32_t* const beams_out = LLE_LATE(beams, env_c * L);
-        for (int b = (int)a; b < L; b += G) beams_out[b] = bm[b];
+        for (int b = (int)a; b < L; b += G) small_store(&beams_out[b], bm[b]);
 #undef LLE_LATE
 #undef LLE_LOAD_STATE
 #undef LLE_ROT
     }
     flush_stats(P.stats, wave_id, cnt, A, lane, PRE_STATS, stats_old);
-    if (ROLL && stamps) {
+    if (STAMPED && stamps) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         LLE_STAMP(6);
     }

@@ -172,6 +172,8 @@ constexpr uint32_t LAUNCH_SPLIT_ROWS = 0x1000000;      // internal: step_kernel 
 constexpr uint32_t LAUNCH_REVERSE = 0x2000000;         // internal: the workgroups serve the blocks of environments from the last to the first (obs_stream.hpp)
 constexpr uint32_t LAUNCH_HEAD_GROUP2 = 0x8000000;     // internal (HEAD kernels): every 2nd wavefront of a workgroup stores the row heads of itself and its neighbour,
 constexpr uint32_t LAUNCH_HEAD_GROUP4 = 0x10000000;    //   (4: the first wavefront those of the whole workgroup) -- the others go straight to their state machines
+constexpr uint32_t LAUNCH_POST_FIRST = 0x20000000;     // internal: every wavefront writes its small outputs BEFORE its observation stream (step_kernel.hpp post_first), ...
+constexpr uint32_t LAUNCH_POST_LAST = 0x40000000;      //   ... or every one after it (default: the last quarter of the grid before, the rest after)
 constexpr uint32_t LAUNCH_ROTATE_ROWS = 0x4000000;     // internal: every wavefront starts its rows at another one of them (obs_stream.hpp row_rotation)
 constexpr uint32_t LAUNCH_WRITE_THROUGH = 0x400000;    // internal: observation rows are stored `sc1` (stream_store, obs_stream.hpp)
 // A launch writes its rows through L2 while all of them fit the Infinity Cache (256 MB, MI355X_MICROARCH.md); beyond

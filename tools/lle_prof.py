@@ -353,14 +353,33 @@ def cmd_stamps(args):
     n = ints(args.sizes)[0]
     slots = 16 if args.fine else 8
     for epw in ([0] if args.fine else ints(args.epws)):
-        bw = BatchedWorld(the_map(args), n, envs_per_wave=epw or None)
+        bw = BatchedWorld([the_map(args), the_map(args)] if getattr(args, "general", False) else the_map(args), n, envs_per_wave=epw or None)
         per = bw.kernel_info()["envs_per_wave"]
         nb = (n + per - 1) // per
         stamps = torch.zeros(nb, slots, dtype=torch.int64, device="cuda")
+        if getattr(args, "pes", False):
+            g = torch.Generator(device="cuda").manual_seed(1)
+            bw.set_sources(colours=torch.randint(0, bw.map.n_agents, (n, bw.map.n_sources), generator=g, device="cuda", dtype=torch.uint8))
         for t in range(30):
             bw.step(sample=True, auto_reset=True, seed=1, t=t)
         torch.cuda.synchronize()
-        assert _capi.lib().lle_batch_step_stamped(bw.h, 3, 1, 30, stamps.data_ptr(), bw._stream()) == 0
+        if getattr(args, "outputs", None):
+            import ctypes as C
+            A, G = bw.map.n_agents, bw.map.n_gems
+            every = dict(state=torch.empty((n, 3 * A + G), device="cuda"), reward=torch.empty(n, device="cuda"), done=torch.empty(n, dtype=torch.uint8, device="cuda"),
+                         available=torch.empty((n, A, 5), dtype=torch.uint8, device="cuda"))
+            eo = bw.make_env_outputs(**{k: every[k] for k in args.outputs.split(",") if k != "none"})
+            for t in range(30, 40):
+                bw.step(sample=True, auto_reset=True, seed=1, t=t, env_out=eo)
+            torch.cuda.synchronize()
+            L = C.CDLL(os.environ["LLE_HIP_LIB"])
+            L.lle_debug_set_stamps.argtypes = [C.c_void_p]
+            L.lle_debug_set_stamps(stamps.data_ptr())
+            bw.step(sample=True, auto_reset=True, seed=1, t=40, env_out=eo)
+            torch.cuda.synchronize()
+            L.lle_debug_set_stamps(None)
+        else:
+            assert _capi.lib().lle_batch_step_stamped(bw.h, 3, 1, 30, stamps.data_ptr(), bw._stream()) == 0
         torch.cuda.synchronize()
         s = stamps.cpu().numpy().astype("float64") * 0.01  # us
         t0 = s[:, 0].min()
@@ -465,6 +484,9 @@ def main():
             p.add_argument("--sweep", action="store_true", help="also envs per batch, batches per wavefront and the store policy of the lane kernel")
         if name == "stamps":
             p.add_argument("--fine", action="store_true")
+            p.add_argument("--pes", action="store_true", help="per-environment sources (random colours): the MODE 3 build")
+            p.add_argument("--outputs", default=None, help="comma list of fused LLE.step outputs (state,reward,done,available) or 'none': lle_batch_step_outputs, diagnostic build only")
+            p.add_argument("--general", action="store_true", help="two copies of the map, half of the environments each: the general (several maps) build")
         if name == "target":
             p.add_argument("what", choices=["step", "noobs", "partial", "perspective", "cfg5", "hbm", "pes"])
             p.add_argument("-k", type=int, default=7, help="window of the partial observer")
