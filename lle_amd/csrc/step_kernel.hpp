@@ -537,20 +537,55 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
 #pragma unroll
                 for (int k = 0; k < 5; k++) small_store(&o[k], (uint8_t)((avail >> k) & 1u));
             }
-            if (O.state) {  // WorldState.as_array: [i0, j0, ..., gems..., alive...] (pyworld_state.rs:79-101)
-                float* st = O.state + env * len;
-                float fi = (float)(pos & 0xFFu), fj = (float)(pos >> 8);
-                if (O.normalize_state) {  // divided in float64, rounded to float32 on assignment (observations.py:145-175)
-                    fi = (float)((double)(pos & 0xFFu) / (double)h_H);
-                    fj = (float)((double)(pos >> 8) / (double)W);
+        }
+        // WorldState.as_array: [i0, j0, ..., gems..., alive...] (pyworld_state.rs:79-101); normalised: divided in float64, rounded to
+        // float32 on assignment (observations.py:145-175)
+#define LLE_STATE_IJ()                                               \
+    float fi = (float)(pos & 0xFFu), fj = (float)(pos >> 8);         \
+    if (O.normalize_state) {                                         \
+        fi = (float)((double)(pos & 0xFFu) / (double)h_H);           \
+        fj = (float)((double)(pos >> 8) / (double)W);                \
+    }
+        // `state` (len floats per env) is contiguous over the wavefront's environments: in the kernels with row heads, where a row is a
+        // whole number of 16-byte chunks, it is built in the spare slots of the wavefront's record area (64 slots, EPW in use) and copied
+        // out whole -- one 16-byte store per lane instead of three or four partial ones per row (level 6: `state` cost 0.7 us of a step,
+        // profiles/r04_pes_tax.md).  Those kernels only: full rows follow the state machine there and hide the copy; in a launch without
+        // rows, or with incremental ones, its LDS round trip is exposed (10.9 -> 11.2 us without rows).  Elsewhere, and where the slots do
+        // not hold it, every lane stores its own values.
+        if (HEAD) {
+            const uint32_t st_off = (EPW * scr_stride * 4u + 15u) & ~15u;
+            const bool staged = !split && O.state && (len & 3) == 0 && st_off + EPW * (uint32_t)len * 4u <= 64u * scr_stride * 4u;
+            if (O.state) {
+                float* st = staged ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(scratch) + st_off) + grp * (uint32_t)len : O.state + env * len;
+                if (me) {
+                    LLE_STATE_IJ()
+                    st[2 * a] = fi;
+                    st[2 * a + 1] = fj;
+                    st[2 * A + n_gems + (int)a] = ((alive >> a) & 1u) ? 1.0f : 0.0f;
                 }
+                if (env_ok)
+                    for (int g = (int)a; g < n_gems; g += G) st[2 * A + g] = ((gems >> g) & 1u) ? 1.0f : 0.0f;
+                if (staged) {
+                    wave_sync();  // (LDS operations of a wavefront execute in order)
+                    const float4* src4 = reinterpret_cast<const float4*>(reinterpret_cast<uint8_t*>(scratch) + st_off);
+                    float4* dst4 = reinterpret_cast<float4*>(O.state + env0 * len);  // (len * 4 is a multiple of 16: so is env0 * len * 4)
+                    const uint32_t n4 = n_here > 0 ? (uint32_t)n_here * (uint32_t)len / 4u : 0u;
+                    for (uint32_t c = lane; c < n4; c += 64u) dst4[c] = src4[c];
+                    wave_sync();
+                }
+            }
+        } else {
+            if (me && O.state) {
+                float* st = O.state + env * len;
+                LLE_STATE_IJ()
                 small_store(&st[2 * a], fi);
                 small_store(&st[2 * a + 1], fj);
                 small_store(&st[2 * A + n_gems + (int)a], ((alive >> a) & 1u) ? 1.0f : 0.0f);
             }
+            if (env_ok && O.state)
+                for (int g = (int)a; g < n_gems; g += G) small_store(&O.state[env * len + 2 * A + g], ((gems >> g) & 1u) ? 1.0f : 0.0f);
         }
-        if (env_ok && O.state)
-            for (int g = (int)a; g < n_gems; g += G) small_store(&O.state[env * len + 2 * A + g], ((gems >> g) & 1u) ? 1.0f : 0.0f);
+#undef LLE_STATE_IJ
         if (env_ok && a == 0) {
             if (O.done) small_store(&O.done[env], (uint8_t)(((alive | ghost) != amask || arrived == amask) ? 1 : 0));
             if (O.reward) {
