@@ -173,6 +173,9 @@ int lle_map_row_head(const lle_map* map, int32_t* first_byte, int32_t* n_bytes);
  * obs_stride / 128 lines; returns the number of lines (all dynamic where the row is not a whole number of lines).  Host side. */
 int lle_map_row_dynamic_lines(const lle_map* map, uint8_t* out_lines, int cap);
 int lle_map_row_head_env_sources(const lle_map* map, int32_t* first_byte, int32_t* n_bytes);
+/* ... and the SECOND run of such lines behind the first (level 6: bytes 1280-1535 are the first run, 1792-1919 the second): the two together
+ * are the head lines the map asks for (lle_map_set_head_lines); 0 bytes: none. */
+int lle_map_row_head_env_sources_second(const lle_map* map, int32_t* first_byte, int32_t* n_bytes);
 
 /* static description of World.lasers (src/core/world.rs:159-172): per laser position the outer layer and, if
  * nested, the second one; `offset` = the tile's index in the beam of `laser_id`; its on / off bit is bit `bit` of word `word`

@@ -37,7 +37,7 @@ PARSE_ERROR_NAMES = {
 EXPORTS = [
     "lle_abi_version", "lle_last_status", "lle_last_error", "lle_action_hash",
     "lle_map_parse", "lle_map_level", "lle_map_free", "lle_map_get_info", "lle_map_positions", "lle_map_sources",
-    "lle_map_set_source", "lle_map_set_exits", "lle_map_clone", "lle_map_colour_allowed", "lle_map_reset_beam", "lle_map_set_row_align", "lle_map_set_head_lines", "lle_map_row_head", "lle_map_row_head_env_sources", "lle_map_row_dynamic_lines", "lle_map_laser_tiles", "lle_map_world_string",
+    "lle_map_set_source", "lle_map_set_exits", "lle_map_clone", "lle_map_colour_allowed", "lle_map_reset_beam", "lle_map_set_row_align", "lle_map_set_head_lines", "lle_map_row_head", "lle_map_row_head_env_sources", "lle_map_row_head_env_sources_second", "lle_map_row_dynamic_lines", "lle_map_laser_tiles", "lle_map_world_string",
     "lle_batch_arena_bytes", "lle_batch_create", "lle_batch_arena_bytes_multi", "lle_batch_create_multi", "lle_batch_n_maps", "lle_batch_free", "lle_batch_get_buffer", "lle_batch_n_envs",
     "lle_batch_reset", "lle_batch_step", "lle_batch_rollout", "lle_batch_set_state", "lle_batch_update_sources", "lle_batch_update_map", "lle_batch_observe",
     "lle_batch_snapshot_bytes", "lle_batch_snapshot", "lle_batch_restore",
@@ -146,6 +146,8 @@ def lib():
     L.lle_map_row_head.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.lle_map_row_head_env_sources.restype = i32
     L.lle_map_row_head_env_sources.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    L.lle_map_row_head_env_sources_second.restype = i32
+    L.lle_map_row_head_env_sources_second.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.lle_map_laser_tiles.restype = i32
     L.lle_map_laser_tiles.argtypes = [vp, C.POINTER(LaserTile), i32]
     L.lle_map_world_string.restype = C.c_size_t
@@ -384,6 +386,13 @@ class Map:
         """(first byte, number of bytes) of the row's head under per-environment source colours (lle_map_row_head_env_sources)."""
         a, n = C.c_int32(0), C.c_int32(0)
         lib().lle_map_row_head_env_sources(self.h, C.byref(a), C.byref(n))
+        return a.value, n.value
+
+    @property
+    def row_head_env_sources_second(self):
+        """(first byte, number of bytes) of the second run of head lines under per-environment source colours."""
+        a, n = C.c_int32(0), C.c_int32(0)
+        lib().lle_map_row_head_env_sources_second(self.h, C.byref(a), C.byref(n))
         return a.value, n.value
 
     def set_source(self, laser_id, enabled=None, agent_id=None):

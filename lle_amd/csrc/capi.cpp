@@ -359,6 +359,13 @@ int lle_map_row_head_env_sources(const lle_map* map, int32_t* first_byte, int32_
     return LLE_OK;
 }
 
+int lle_map_row_head_env_sources_second(const lle_map* map, int32_t* first_byte, int32_t* n_bytes) {
+    if (!map) return fail(LLE_ERR_NULL, "NULL map");
+    if (first_byte) *first_byte = (int32_t)(map->m.header.pes_head2_lo * 16u);
+    if (n_bytes) *n_bytes = (int32_t)(map->m.header.pes_head2_n * 16u);
+    return LLE_OK;
+}
+
 int64_t lle_map_reset_beam(const lle_map* map, int laser_id, int agent_id) {
     if (!map) return fail(LLE_ERR_NULL, "NULL map");
     const MapHeader& h = map->m.header;

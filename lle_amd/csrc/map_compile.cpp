@@ -536,10 +536,24 @@ void Map::compile() {
             if (e - l > best_n) { best_lo = l; best_n = e - l; }
             l = e;
         }
-        const uint32_t want = head_lines < 0 ? std::max(1u, (n_lines + 2u) / 5u) : (uint32_t)head_lines;
-        best_n = std::min(best_n, std::min(want, 8u));
+        const uint32_t want = std::min(head_lines < 0 ? std::max(1u, (n_lines + 2u) / 5u) : (uint32_t)head_lines, 8u);
+        const uint32_t run1 = best_n;  // (uncut: the second run lies outside it)
+        best_n = std::min(best_n, want);
+        // what the first run leaves of the wanted lines comes from the next longest run of static lines (one 64-lane store covers both)
+        uint32_t lo2 = 0, n2 = 0;
+        for (uint32_t l = 0; l < n_lines && plain_colours && best_n != 0 && best_n < want;) {
+            if (dynamic_line[l] || (l >= best_lo && l < best_lo + run1)) { l++; continue; }
+            uint32_t e = l;
+            while (e < n_lines && !dynamic_line[e] && !(e >= best_lo && e < best_lo + run1)) e++;
+            if (e - l > n2) { lo2 = l; n2 = e - l; }
+            l = e;
+        }
+        n2 = std::min(n2, want - best_n);
+        if (n2 != 0 && lo2 < best_lo) { std::swap(lo2, best_lo); std::swap(n2, best_n); }  // in row order
         h.pes_head_lo = best_lo * 8u;
         h.pes_head_n = best_n * 8u;
+        h.pes_head2_lo = n2 ? lo2 * 8u : 0u;
+        h.pes_head2_n = n2 * 8u;
     }
 
     // ---- assemble blob

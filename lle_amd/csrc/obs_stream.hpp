@@ -189,19 +189,24 @@ __device__ __forceinline__ void stream_whole_row(uint4* __restrict__ dst, const 
     if (n_chunks > 128u) stream_row<WT>(dst, srcv, 128u, n_chunks, lane);
 }
 
-// The same without the row's HEAD (chunks [head_lo, head_lo + head_n), stored before the state machine, see
-// store_heads): tail chunk i is chunk i + (i >= head_lo ? head_n : 0).
+// The same without the row's HEAD (chunks [head_lo, head_lo + head_n) and, behind them, [head2_lo, head2_lo + head2_n): stored before
+// the state machine, see store_heads): tail chunk i is chunk i + (i >= head_lo ? head_n : 0), + head2_n once that reaches head2_lo.
 template <bool WT>
 __device__ __forceinline__ void stream_row_tail(uint4* __restrict__ dst, const uint4* srcv, uint32_t n_chunks, uint32_t head_lo, uint32_t head_n,
-                                                uint32_t lane) {
-    const uint32_t n_tail = n_chunks - head_n;
+                                                uint32_t lane, uint32_t head2_lo = 0, uint32_t head2_n = 0) {
+    const uint32_t n_tail = n_chunks - head_n - head2_n;
+    auto chunk_of = [&](uint32_t i) {
+        uint32_t c = i + (i >= head_lo ? head_n : 0u);
+        if (head2_n) c += c >= head2_lo ? head2_n : 0u;
+        return c;
+    };
     const uint32_t i0 = lane, i1 = lane + 64u;
-    const uint32_t c0 = i0 + (i0 >= head_lo ? head_n : 0u), c1 = i1 + (i1 >= head_lo ? head_n : 0u);
+    const uint32_t c0 = chunk_of(i0), c1 = chunk_of(i1);
     const uint4 v0 = srcv[i0 < n_tail ? c0 : 0u], v1 = srcv[i1 < n_tail ? c1 : 0u];
     if (i0 < n_tail) stream_store<WT>(dst + c0, v0);
     if (i1 < n_tail) stream_store<WT>(dst + c1, v1);
     for (uint32_t i = lane + 128u; i < n_tail; i += 64u) {
-        const uint32_t c = i + (i >= head_lo ? head_n : 0u);
+        const uint32_t c = chunk_of(i);
         stream_store<WT>(dst + c, srcv[c]);
     }
 }
@@ -226,10 +231,12 @@ __device__ __forceinline__ void stream_row_dyn(uint4* __restrict__ dst, const ui
 // touch need not wait for the state machine -- the memory system starts ~2 us earlier (tools/ceiling/head_probe.hip).
 template <bool WT>
 __device__ __forceinline__ void store_heads(int8_t* __restrict__ obs, uint64_t obs_stride, int64_t env0, int64_t n_here, uint32_t head_lo,
-                                            uint32_t head_n, const uint4& v, uint32_t lane, uint32_t rot = 0) {
-    if (lane < head_n)
+                                            uint32_t head_n, const uint4& v, uint32_t lane, uint32_t rot = 0, uint32_t head2_lo = 0, uint32_t head2_n = 0) {
+    // (two runs: lanes [0, head_n) hold the chunks of the first, lanes [head_n, head_n + head2_n) those of the second)
+    const uint32_t chunk = lane < head_n ? head_lo + lane : head2_lo + (lane - head_n);
+    if (lane < head_n + head2_n)
         for (uint32_t k = 0; k < (uint32_t)n_here; k++)
-            stream_store<WT>(reinterpret_cast<uint4*>(obs + (uint64_t)(env0 + rotated(k, rot, (uint32_t)n_here)) * obs_stride) + head_lo + lane, v);
+            stream_store<WT>(reinterpret_cast<uint4*>(obs + (uint64_t)(env0 + rotated(k, rot, (uint32_t)n_here)) * obs_stride) + chunk, v);
 }
 
 // ---- phase 2: layered observation of the wave's environments, one environment at a time.
@@ -401,7 +408,7 @@ __device__ __forceinline__ void write_observations_env(int A, int L, uint32_t HW
                                                        int8_t* __restrict__ obs, int64_t env0, int64_t n_here, uint32_t lane,
                                                        const uint8_t* laser_layer = nullptr, uint32_t gem_layer_in = 0xFFFFFFFFu,
                                                        uint32_t head_lo = 0, uint32_t head_n = 0, uint32_t rot = 0,
-                                                       const uint16_t* dyn_chunks = nullptr, uint32_t n_dyn_chunks = 0) {
+                                                       const uint16_t* dyn_chunks = nullptr, uint32_t n_dyn_chunks = 0, uint32_t head2_lo = 0, uint32_t head2_n = 0) {
     uint32_t dc0 = 0xFFFFu, dc1 = 0xFFFFu;  // INCR: this lane's first two dynamic chunks (stream_row_dyn)
     if constexpr (INCR) {
         dc0 = lane < n_dyn_chunks ? (uint32_t)dyn_chunks[lane] : 0xFFFFu;
@@ -441,7 +448,7 @@ __device__ __forceinline__ void write_observations_env(int A, int L, uint32_t HW
         wave_sync();
         uint4* __restrict__ dst = reinterpret_cast<uint4*>(obs + (uint64_t)(env0 + k) * obs_stride);
         if constexpr (INCR) stream_row_dyn<WT>(dst, srcv, dyn_chunks, n_dyn_chunks, dc0, dc1, lane);
-        else if constexpr (HEAD) stream_row_tail<WT>(dst, srcv, n_chunks, head_lo, head_n, lane);  // (the head is stored already: store_heads)
+        else if constexpr (HEAD) stream_row_tail<WT>(dst, srcv, n_chunks, head_lo, head_n, lane, head2_lo, head2_n);  // (the head is stored already: store_heads)
         else stream_whole_row<WT>(dst, srcv, n_chunks, lane);
         wave_sync();
         // bare bytes back (LDS is in order: after the reads above, before the next environment's writes).  On the agent / laser

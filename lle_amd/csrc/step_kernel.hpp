@@ -257,9 +257,12 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     // wait for their acknowledgements (and the compiler does not see the `sc1` stores, which are inline asm).
     const uint32_t head_lo = HEAD ? (PES ? hdr->pes_head_lo : hdr->head_lo) : 0u;
     const uint32_t head_n = (HEAD && write_obs && !split && !incr) ? (PES ? hdr->pes_head_n : hdr->head_n) : 0u;  // (incr: static lines are not written at all)
+    // (per-environment sources: a second run of colour-independent lines behind the first, tables.h pes_head2_*)
+    const uint32_t head2_lo = (HEAD && PES) ? hdr->pes_head2_lo : 0u, head2_n = (HEAD && PES && head_n) ? hdr->pes_head2_n : 0u;
     uint4 head_v = {0u, 0u, 0u, 0u};
     if (HEAD) {
-        if (lane < head_n) head_v = reinterpret_cast<const uint4*>(tables + (PES ? h_off_bare : h_off_template))[head_lo + lane];
+        if (lane < head_n + head2_n)
+            head_v = reinterpret_cast<const uint4*>(tables + (PES ? h_off_bare : h_off_template))[lane < head_n ? head_lo + lane : head2_lo + (lane - head_n)];
         LLE_LOAD_STATE();
     }
     // BM: [length masks | beams of the reset state], one copy per workgroup behind the tables; read here, ahead of the table rows
@@ -301,8 +304,8 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         const uint32_t hgroup = MODE != 6 ? 1u : ((K.flags & LAUNCH_HEAD_GROUP4) ? 4u : ((K.flags & LAUNCH_HEAD_GROUP2) ? 2u : 1u));  // (the default kernel only)
         if (hgroup == 1u) {
             if (head_n && n_here > 0) {
-                if (K.flags & LAUNCH_WRITE_THROUGH) store_heads<true>(P.obs, h_obs_stride, env0, n_here, head_lo, head_n, head_v, lane, LLE_ROT());
-                else store_heads<false>(P.obs, h_obs_stride, env0, n_here, head_lo, head_n, head_v, lane, LLE_ROT());
+                if (K.flags & LAUNCH_WRITE_THROUGH) store_heads<true>(P.obs, h_obs_stride, env0, n_here, head_lo, head_n, head_v, lane, LLE_ROT(), head2_lo, head2_n);
+                else store_heads<false>(P.obs, h_obs_stride, env0, n_here, head_lo, head_n, head_v, lane, LLE_ROT(), head2_lo, head2_n);
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS only: not the head stores' acknowledgements
         } else {
@@ -668,9 +671,9 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
                                                             obs_out, env0, n_here, lane, nullptr, 0xFFFFFFFFu, 0u, 0u, LLE_ROT(), dyn_chunks, h_n_dyn_chunks);
         } else if (PES) {
             if (wt) write_observations_env<true, HEAD>(A, L, h_HW, h_n_elems, h_n_chunks, h_obs_stride, elems, bare, tmpl, scratch, scr_stride,
-                                                       obs_out, env0, n_here, lane, nullptr, 0xFFFFFFFFu, head_lo, head_n, LLE_ROT());
+                                                       obs_out, env0, n_here, lane, nullptr, 0xFFFFFFFFu, head_lo, head_n, LLE_ROT(), nullptr, 0u, head2_lo, head2_n);
             else write_observations_env<false, HEAD>(A, L, h_HW, h_n_elems, h_n_chunks, h_obs_stride, elems, bare, tmpl, scratch, scr_stride,
-                                                     obs_out, env0, n_here, lane, nullptr, 0xFFFFFFFFu, head_lo, head_n, LLE_ROT());
+                                                     obs_out, env0, n_here, lane, nullptr, 0xFFFFFFFFu, head_lo, head_n, LLE_ROT(), nullptr, 0u, head2_lo, head2_n);
         } else if (CAN_INCR && incr) {
             if (wt) write_observations<true, false, true>(A, L, h_D, h_n_chunks, h_obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane, 0u, 0u, LLE_ROT(), dyn_chunks, h_n_dyn_chunks);
             else write_observations<false, false, true>(A, L, h_D, h_n_chunks, h_obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane, 0u, 0u, LLE_ROT(), dyn_chunks, h_n_dyn_chunks);

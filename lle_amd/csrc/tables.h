@@ -102,7 +102,10 @@ struct MapHeader {
     // the same under per-environment source colours (inside the per-env-sources section, like off_recolour): a laser byte may sit on
     // any of the A laser planes, so every line below 2A * HW is dynamic, and behind them the lines with a gem byte (pes_head_* is a run of the rest)
     uint32_t off_pes_dyn_chunks, n_pes_dyn_chunks;
-    uint32_t head_pad[15];  // (pads the header to 640 B: the table sections behind it start on a 128-byte line)
+    // a SECOND run of such lines (level 6: lines 10-11 are the first run, line 14 -- the end of the EXIT plane -- the second): together the
+    // `head_lines` the map asks for; chunks, behind the first run (pes_head2_lo > pes_head_lo + pes_head_n), 0: none
+    uint32_t pes_head2_lo, pes_head2_n;
+    uint32_t head_pad[13];  // (pads the header to 640 B: the table sections behind it start on a 128-byte line)
 };
 static_assert(sizeof(MapHeader) % 128 == 0, "the sections start on a 128-byte line (the LDS copy loads 1 KiB per wave instruction)");
 

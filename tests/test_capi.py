@@ -199,12 +199,6 @@ def test_row_head_bytes_never_change(oracle_mod, name):
         rows = ob.step(None, auto_reset=(t // 20) % 2 == 0, seed=21, t=t)["obs"].reshape(n, -1)
         ref = rows[0, lo:hi].copy() if ref is None else ref
         assert (rows[:, lo:hi] == ref).all(), (name, t)
-    # unaligned rows have no head; 0 switches it off; -1 is the automatic size (a fifth of the row, at most 8 lines)
-    assert Map(text, row_align=16).row_head[1] == 0 or Map(text, row_align=16).obs_stride % 128 == 0
-    m.set_head_lines(0)
-    assert m.row_head[1] == 0
-    m.set_head_lines(-1)
-    assert m.row_head[1] <= max(128, min(1024, (m.obs_stride // 128 + 2) // 5 * 128))
 
 
 @pytest.mark.parametrize("name", sorted(dict({f"level{k}": v for k, v in LEVELS.items()}, **EXTRA_MAPS)))
@@ -352,6 +346,11 @@ def test_row_head_under_per_env_colours_never_changes(oracle_mod, name):
     assert first % 128 == 0 and nbytes % 128 == 0 and first + nbytes <= m.obs_stride
     assert nbytes == 0 or first + 127 >= 2 * A * m.height * m.width  # behind the agent and laser layers
     lo, hi = min(first, m.obs_bytes), min(first + nbytes, m.obs_bytes)
+    # the second run of such lines (round 4): behind the first, disjoint from it, together at most the 8 lines asked for
+    first2, nbytes2 = m.row_head_env_sources_second
+    assert first2 % 128 == 0 and nbytes2 % 128 == 0 and first2 + nbytes2 <= m.obs_stride and nbytes + nbytes2 <= 8 * 128
+    assert nbytes2 == 0 or (nbytes != 0 and first2 >= first + nbytes)
+    lo2, hi2 = min(first2, m.obs_bytes), min(first2 + nbytes2, m.obs_bytes)
     n = 96
     ob = oracle_mod.OracleBatch(text, n)
     rng = np.random.default_rng(4)
@@ -364,8 +363,21 @@ def test_row_head_under_per_env_colours_never_changes(oracle_mod, name):
                 for l in range(L):
                     w.set_source(l, colour=int(colours[e, l]), enabled=bool(rng.integers(0, 2)))
         rows = ob.step(None, auto_reset=(t // 15) % 2 == 0, seed=8, t=t)["obs"].reshape(n, -1)
-        ref = rows[0, lo:hi].copy() if ref is None else ref
-        assert (rows[:, lo:hi] == ref).all(), (name, t)
+        both = np.concatenate([rows[:, lo:hi], rows[:, lo2:hi2]], axis=1)
+        ref = both[0].copy() if ref is None else ref
+        assert (both == ref).all(), (name, t)
+
+
+def test_second_head_run_of_level6():
+    """Level 6 under per-environment colours: lines 10-11 (WALL / VOID planes) and line 14 (the end of the EXIT plane)."""
+    from lle_amd import Map
+
+    m = Map(LEVELS[6])
+    assert m.row_head_env_sources == (1280, 256) and m.row_head_env_sources_second == (1792, 128)
+    m.set_head_lines(2)
+    assert m.row_head_env_sources == (1280, 256) and m.row_head_env_sources_second == (0, 0)
+    m.set_head_lines(0)
+    assert m.row_head_env_sources[1] == 0 and m.row_head_env_sources_second[1] == 0
 
 
 def test_laser_tokens():

@@ -199,3 +199,34 @@ def test_head_groups_in_the_general_kernels(heads_forced, monkeypatch):
             for (a, b) in zip(want, got):
                 for x, y in zip(a, b):
                     assert torch.equal(x, y), group
+
+
+@pytest.mark.parametrize("name", ["level6", "level5", "level3", "nested", "gen_12x13_4agents_8lasers"])
+@pytest.mark.parametrize("lines", [-1, 1, 2, 8])
+def test_heads_under_per_env_sources_write_every_byte(oracle_mod, heads_forced, name, lines):
+    """MODE 8 with one or two runs of head lines (lle_map_row_head_env_sources / _second): rows filled with garbage before every step --
+    the launch must write every byte of every row itself, whichever lines went out ahead of the state machine."""
+    import torch
+
+    from lle_amd import BatchedWorld, Map
+    from tests.parity_util import legal_colours
+
+    m = Map(MAPS[name], row_align=128)
+    m.set_head_lines(lines)
+    n = 1000
+    A, L = m.n_agents, m.n_sources
+    ob = oracle_mod.OracleBatch(MAPS[name], n)
+    bw = BatchedWorld(m, n)
+    rng = np.random.default_rng(6)
+    colours = legal_colours(m, rng.integers(0, A, size=(n, L), dtype=np.uint8))
+    bw.set_sources(torch.from_numpy(colours))
+    for e in range(n):
+        for l in range(L):
+            ob.world(e).set_source(l, colour=int(colours[e, l]))
+    for t in range(12):
+        bw.obs_rows.fill_(55)
+        auto = t % 4 != 3
+        bw.step(sample=True, auto_reset=auto, seed=5, t=t, env_offset=2)
+        check(bw, ob, ob.step(None, auto_reset=auto, seed=5, t=t, env_offset=2), f"{name} lines={lines} t={t}")
+        if m.obs_stride > m.obs_bytes:
+            assert int(bw.obs_rows[:, m.obs_bytes:].abs().max()) == 0
