@@ -368,7 +368,13 @@ def cmd_stamps(args):
             A, G = bw.map.n_agents, bw.map.n_gems
             every = dict(state=torch.empty((n, 3 * A + G), device="cuda"), reward=torch.empty(n, device="cuda"), done=torch.empty(n, dtype=torch.uint8, device="cuda"),
                          available=torch.empty((n, A, 5), dtype=torch.uint8, device="cuda"))
-            eo = bw.make_env_outputs(**{k: every[k] for k in args.outputs.split(",") if k != "none"})
+            names = [k for k in args.outputs.split(",") if k != "none"]
+            part = [k for k in names if k.startswith("partial")]
+            extra = {}
+            if part:  # e.g. partial7: the step launch writes the partial 7 x 7 observation (MODE 9)
+                kk = int(part[0][len("partial"):])
+                extra = dict(partial=bw.partial_buffer(kk)[0], partial_k=kk)
+            eo = bw.make_env_outputs(**{k: every[k] for k in names if k not in part}, **extra)
             for t in range(30, 40):
                 bw.step(sample=True, auto_reset=True, seed=1, t=t, env_out=eo)
             torch.cuda.synchronize()
