@@ -324,8 +324,8 @@ class Timer:
             fn()
         self.issue = time.perf_counter() - t0  # the host's own time: K calls issued, nothing waited for
         ev1.record()
-        while not ev1.query():  # spin until the last launch is done: the blocking synchronize below then returns at once
-            pass                # (left to itself it wakes up tens of microseconds late: a tenth of the driver's 20-step region)
+        # (a blocking synchronize, not a spin on ev1.query(): over 40 regions of 20 steps the spin cost 21.5 us per step against 21.0 --
+        # tools/scratch/region_edges.py; the two event records themselves cost the region 0.5 us per step at K = 20, 20.5 without them)
         torch.cuda.synchronize(self.dev)
         wall = self.wall_open = time.perf_counter() - t0
         if self.use_dist:
