@@ -325,7 +325,7 @@ class Timer:
         self.issue = time.perf_counter() - t0  # the host's own time: K calls issued, nothing waited for
         ev1.record()
         # (a blocking synchronize, not a spin on ev1.query(): over 40 regions of 20 steps the spin cost 21.5 us per step against 21.0 --
-        # tools/scratch/region_edges.py; the two event records themselves cost the region 0.5 us per step at K = 20, 20.5 without them)
+        # tools/region_edges.py; the two event records themselves cost the region 0.5 us per step at K = 20, 20.5 without them)
         torch.cuda.synchronize(self.dev)
         wall = self.wall_open = time.perf_counter() - t0
         if self.use_dist:
