@@ -118,6 +118,14 @@ __device__ __forceinline__ void copy_tables2_to_lds(const uint8_t* __restrict__ 
 }
 #undef LLE_COPY_ROWS
 
+// a * b + c with 24-bit a, b in ONE full-rate instruction (v_mad_u32_u24).  __umul24 is a masked 32-bit product to the compiler, which
+// -- in the inner loop of the partial writers -- it turned into v_mul_lo_u32 / v_mad_u64_u32 (quarter rate: three of them per window cell).
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // ---- the small stores of a step (state, events, counters, the fused LLE.step outputs): a few dozen bytes per environment.
 // Plain, they stay dirty in the XCD's L2 until the end of the kernel, whose release then writes them back before the next launch
 // can start; LLE_SMALL_WT (an A/B build: profiles/r04_pes_tax.md) writes them through as they are issued.

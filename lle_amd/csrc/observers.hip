@@ -548,18 +548,39 @@ __global__ void __launch_bounds__(256) partial_lanes_kernel(BatchPtrs P, int8_t*
         const uint32_t* rec32 = reinterpret_cast<const uint32_t*>(rec8);
         const int cell0 = i0 * W + j0;
         const bool two_layers = D.max_layers > 1u;   // (uniform: maps without crossing beams never look at a second layer)
+        // Software-pipelined (round 4, as partial_stream.hpp): the (meta, layers) reads of the NEXT cell are issued ahead of the beam word /
+        // colour reads of the current one -- LDS returns in order, so a pass waits once instead of twice.
+        const uint32_t gems = rec32[As / 2];
 #pragma unroll
         for (int half = 0; half < 2; half++) {
             uint32_t todo = todo2[half];
-            while (todo) {
+            uint32_t wi_n = 0, wj_n = 0, meta_n = 0;
+            uint64_t lay_n = 0;
+            bool have = todo != 0u;
+            if (have) {
                 const uint32_t b = (uint32_t)__builtin_ctz(todo);
                 todo &= todo - 1u;
-                // (24-bit multiplies run at the full vector rate, 32-bit ones at a quarter; every factor here is tiny)
-                const uint32_t r = (b >> SBL) + (half ? RH : 0u), wj = b & ((1u << SBL) - 1u), wi = wi_base + __umul24(r, wi_step);
-                const uint32_t cell = (uint32_t)(cell0 + (int)(__umul24(wi, (uint32_t)W) + wj));
-                const uint32_t meta = cell_meta[cell];
-                const uint64_t lay = cell_lay[cell];
-                const uint32_t gems = rec32[As / 2];
+                const uint32_t r = (b >> SBL) + (half ? RH : 0u);
+                wj_n = b & ((1u << SBL) - 1u);
+                wi_n = mad24(r, wi_step, wi_base);   // (one full-rate v_mad_u32_u24 each: the compiler made quarter-rate 32-bit multiplies of __umul24 here)
+                const uint32_t cell = (uint32_t)cell0 + mad24(wi_n, (uint32_t)W, wj_n);
+                meta_n = cell_meta[cell];
+                lay_n = cell_lay[cell];
+            }
+            while (have) {
+                const uint32_t meta = meta_n, wi = wi_n, wj = wj_n;
+                const uint64_t lay = lay_n;
+                have = todo != 0u;
+                if (have) {   // the next cell's first round trip
+                    const uint32_t b = (uint32_t)__builtin_ctz(todo);
+                    todo &= todo - 1u;
+                    const uint32_t r = (b >> SBL) + (half ? RH : 0u);
+                    wj_n = b & ((1u << SBL) - 1u);
+                    wi_n = mad24(r, wi_step, wi_base);
+                    const uint32_t cell = (uint32_t)cell0 + mad24(wi_n, (uint32_t)W, wj_n);
+                    meta_n = cell_meta[cell];
+                    lay_n = cell_lay[cell];
+                }
                 const uint32_t kind = meta & 7u, idx = (meta >> 3) & 31u;
                 const uint32_t l0 = (uint32_t)lay & 0xFFFFu;   // World.lasers(): the two outer layers of a cell
                 const uint32_t b0 = (l0 >> 1) & 31u, o0 = (l0 >> 6) & 31u;
@@ -569,7 +590,7 @@ __global__ void __launch_bounds__(256) partial_lanes_kernel(BatchPtrs P, int8_t*
                 const uint32_t lt = ((kind < 4u ? lt_lo : lt_hi) >> ((kind & 3u) * 8u)) & 0xFFu;
                 const bool en0 = lt != 0xFFu && !(kind == K_GEM && ((gems >> idx) & 1u));
                 const bool en1 = (l0 & LAY_VALID) && ((m0 >> o0) & 1u);
-                int8_t* cp = mine + __umul24(wi, (uint32_t)k) + wj;
+                int8_t* cp = mine + mad24(wi, (uint32_t)k, wj);
                 if (two_layers) {
                     const uint32_t l1 = (uint32_t)(lay >> 16) & 0xFFFFu, b1 = (l1 >> 1) & 31u, o1 = (l1 >> 6) & 31u;
                     const uint32_t m1 = rec32[As / 2 + 1 + b1], c1 = rec8[colour_at + b1];

@@ -89,16 +89,39 @@ __device__ __forceinline__ void write_partial(int A, int L, int W, int k, uint32
         // (Write order = the reference's, observations.py:347-359; all four commute.)
         const int cell0 = i0 * W + j0;
         const uint32_t not_gems = rec[L + 1];   // ~collected bits
+        // Two dependent LDS round trips per cell -- (meta, layers) of the cell, then the beam word / colour bytes they name -- and nothing
+        // else for the wavefront to do in between: the loop is software-pipelined, the first round trip of the NEXT cell issued ahead of
+        // the second one of the current cell (LDS returns in order: one wait per pass instead of two).
 #pragma unroll
         for (int half = 0; half < 2; half++) {
             uint32_t todo = todo2[half];
-            while (todo) {
+            uint32_t wi_n = 0, wj_n = 0, meta_n = 0;
+            uint64_t lay_n = 0;
+            bool have = todo != 0u;
+            if (have) {
                 const uint32_t b = (uint32_t)__builtin_ctz(todo);
                 todo &= todo - 1u;
-                const uint32_t r = (b >> SBL) + (half ? RH : 0u), wj = b & ((1u << SBL) - 1u), wi = wi_base + __umul24(r, wi_step);
-                const uint32_t cell = (uint32_t)(cell0 + (int)(__umul24(wi, (uint32_t)W) + wj));
-                const uint32_t meta = cell_meta[cell];
-                const uint64_t lay = cell_lay[cell];
+                const uint32_t r = (b >> SBL) + (half ? RH : 0u);
+                wj_n = b & ((1u << SBL) - 1u);
+                wi_n = mad24(r, wi_step, wi_base);
+                const uint32_t cell = (uint32_t)cell0 + mad24(wi_n, (uint32_t)W, wj_n);
+                meta_n = cell_meta[cell];
+                lay_n = cell_lay[cell];
+            }
+            while (have) {
+                const uint32_t meta = meta_n, wi = wi_n, wj = wj_n;
+                const uint64_t lay = lay_n;
+                have = todo != 0u;
+                if (have) {   // the next cell's first round trip
+                    const uint32_t b = (uint32_t)__builtin_ctz(todo);
+                    todo &= todo - 1u;
+                    const uint32_t r = (b >> SBL) + (half ? RH : 0u);
+                    wj_n = b & ((1u << SBL) - 1u);
+                    wi_n = mad24(r, wi_step, wi_base);
+                    const uint32_t cell = (uint32_t)cell0 + mad24(wi_n, (uint32_t)W, wj_n);
+                    meta_n = cell_meta[cell];
+                    lay_n = cell_lay[cell];
+                }
                 const uint32_t kind = meta & 7u, idx = (meta >> 3) & 31u;
                 const uint32_t l0 = (uint32_t)lay & 0xFFFFu;   // World.lasers(): the two outer layers of a cell
                 const uint32_t w0 = (l0 >> 1) & 31u, o0 = (l0 >> 6) & 31u;
@@ -108,7 +131,7 @@ __device__ __forceinline__ void write_partial(int A, int L, int W, int k, uint32
                 const uint32_t lt = ((kind < 4u ? lt_lo : lt_hi) >> ((kind & 3u) * 8u)) & 0xFFu;
                 const bool en0 = lt != 0xFFu && !(kind == K_GEM && !((not_gems >> idx) & 1u));
                 const bool en1 = (l0 & LAY_VALID) && ((m0 >> o0) & 1u);
-                int8_t* cp = mine + __umul24(wi, (uint32_t)k) + wj;
+                int8_t* cp = mine + mad24(wi, (uint32_t)k, wj);
                 if (two_layers) {
                     const uint32_t l1 = (uint32_t)(lay >> 16) & 0xFFFFu, w1 = (l1 >> 1) & 31u, o1 = (l1 >> 6) & 31u;
                     const uint32_t m1 = rec[1u + w1], c1 = colours[w1];
