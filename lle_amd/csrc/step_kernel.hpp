@@ -191,6 +191,11 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     // the env's reset beams, read with the rest of its state in the single-step mode: read where the reset needs them they
     // are a memory round trip between the decision to reset and the state machine, in every wavefront that resets anything
     constexpr bool PRE_BEAMS = PES && !ROLL && LM <= 8;
+    // Round 4: where the reset state depends on an env's colours through its beams ONLY (MapHeader.recolour_exact: no cell with more than
+    // two laser layers, no chained beam words) the single-step kernels do not read the env's own reset record at all -- five loads per
+    // lane ahead of the first store -- but take positions / flags / gems from the map's record and the beams from the table the
+    // re-colouring uses (off_recolour: the mask of beam b after World::reset under colour c), by the env's colour and enabled flag.
+    const bool shared_init = PES && !ROLL && hdr->recolour_exact != 0u;
     uint32_t env_init_beams[LR];
 #pragma unroll
     for (int b = 0; b < LR; b++) env_init_beams[b] = 0u;
@@ -222,8 +227,8 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         if (me) { \
             pos = (uint32_t)*p_pos; \
             avail = (uint32_t)*p_avail; \
-            init_pos_a = PES ? (uint32_t)P.init_pos[env * As + a] : (uint32_t)initp->pos[a]; \
-            init_avail_a = PES ? (uint32_t)P.init_avail[env * As + a] : (uint32_t)initp->avail[a]; \
+            init_pos_a = (PES && !shared_init) ? (uint32_t)P.init_pos[env * As + a] : (uint32_t)initp->pos[a]; \
+            init_avail_a = (PES && !shared_init) ? (uint32_t)P.init_avail[env * As + a] : (uint32_t)initp->avail[a]; \
             if (!ROLL && !(K.flags & STEP_SAMPLE_ACTIONS)) \
                 act_given = K.actions_in ? (uint32_t)K.actions_in[env * A + a] : (uint32_t)P.actions[env * As + a]; \
         } \
@@ -240,7 +245,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         _Pragma("unroll") \
             for (int q = 0; q < CWM; q++) \
                 if (q < CW) colw[q] = reinterpret_cast<const uint32_t*>(P.src_colour)[env * CW + q]; \
-            if (K.flags & STEP_AUTO_RESET) { \
+            if ((K.flags & STEP_AUTO_RESET) && !shared_init) { \
                 init_bits = P.init_bits[env]; \
                 init_gems = P.init_gems[env]; \
         _Pragma("unroll") \
@@ -420,9 +425,27 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         gems = over ? init_gems : gems;
 #pragma unroll
         for (int b = 0; b < LR; b++)
-            if (!BM && b < L) beams[b] = over ? (PES ? (PRE_BEAMS ? env_init_beams[b] : P.init_beams[env_ok ? env * L + b : 0]) : h_init_beams[b]) : beams[b];
-        if (BM && over)  // the group's lanes share the copy of the record
+            if (!BM && b < L && !(PES && shared_init))
+                beams[b] = over ? (PES ? (PRE_BEAMS ? env_init_beams[b] : P.init_beams[env_ok ? env * L + b : 0]) : h_init_beams[b]) : beams[b];
+        if (BM && over && !(PES && shared_init))  // the group's lanes share the copy of the record
             for (int b = (int)a; b < L; b += G) bm[b] = PES ? P.init_beams[env * L + b] : beam_tab[LM + b];
+        if (PES && shared_init && __ballot(over) != 0ull) {  // the env's beams after World::reset, from its colours and enabled flags
+            const uint32_t* rtab0 = reinterpret_cast<const uint32_t*>(lds + tab_bytes + (h_off_recolour - h_off_bare));
+            if (!BM) {
+#pragma unroll
+                for (int b = 0; b < LR; b++)
+                    if (b < L) {
+                        const uint32_t c = (colw[b >> 2] >> ((b & 3) * 8)) & 0xFFu;
+                        const uint32_t m = ((env_enabled >> b) & 1u) ? rtab0[b * (A + 1) + 1 + (int)(c < (uint32_t)A ? c : 0u)] : 0u;
+                        beams[b] = over ? m : beams[b];
+                    }
+            } else if (over) {
+                for (int b = (int)a; b < L; b += G) {
+                    const uint32_t c = (colw[b >> 2] >> ((b & 3) * 8)) & 0xFFu;
+                    bm[b] = ((env_enabled >> b) & 1u) ? rtab0[b * (A + 1) + 1 + (int)(c < (uint32_t)A ? c : 0u)] : 0u;
+                }
+            }
+        }
         was_reset = over ? 1u : 0u;
         // LLE.reset with randomize_lasers (python/lle/env/env.py:189-203): world.reset() -- above, under the colours the env
         // HAD: beams cut at reset stay as they are -- then a fresh colour for every source, uniform over the colours the
