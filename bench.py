@@ -593,8 +593,10 @@ def measure_lle_step(torch, timer, dev, n, steps):
     del ring, rec
     out = {"what": f"lle_amd.BatchedLLE.step(actions, auto_reset=True) on World.level({LEVEL}) x {n} envs: obs (layered) + state + reward + "
                    "done + available_actions per step; us per step, launch-to-launch", "steps": steps}
-    for key, kw, mode in (("two_launches_us", {}, {}), ("two_launches_persistent_us", {}, {"persistent": True}), ("one_launch_us", {}, {"fused": True}),
-                          ("randomize_lasers_two_launches_us", {"randomize_lasers": True}, {}),
+    for key, kw, mode in (("default_us", {}, {}),  # (since round 4 the default step is the one launch, into tensors allocated per step)
+                          ("two_launches_us", {}, {"fused": False}), ("two_launches_persistent_us", {}, {"persistent": True}), ("one_launch_us", {}, {"fused": True}),
+                          ("randomize_lasers_default_us", {"randomize_lasers": True}, {}),
+                          ("randomize_lasers_two_launches_us", {"randomize_lasers": True}, {"fused": False}),
                           ("randomize_lasers_one_launch_us", {"randomize_lasers": True}, {"fused": True}),
                           # opt-in incremental rows (LLE_STEP_INCREMENTAL_OBS): not the default path
                           ("one_launch_incremental_us", {"incremental_obs": True}, {"fused": True}),

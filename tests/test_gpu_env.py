@@ -249,7 +249,7 @@ def test_randomized_lasers_through_auto_reset_steps(map_name):
         over = a.done.clone()
         avail = a.available_actions()
         acts = torch.multinomial(avail.reshape(-1, 5).float(), 1, generator=g).reshape(n, -1).to(torch.uint8)
-        x, y = a.step(acts, auto_reset=True, fused=True), b.step(acts, auto_reset=True)
+        x, y = a.step(acts, auto_reset=True, fused=True), b.step(acts, auto_reset=True, fused=False)
         for k in ("obs", "state", "reward", "done", "available_actions", "err"):
             assert torch.equal(x[k], y[k]), (k, t)
         colours = a.world.src_colour[:, :L].long()
@@ -454,7 +454,7 @@ def test_batched_lle_one_launch_step():
     b.reset()
     for t in range(25):
         acts = a.available_actions().to(torch.uint8).argmax(dim=2).to(torch.uint8)  # first available action of every agent
-        x, y = a.step(acts, auto_reset=True, fused=True), b.step(acts, auto_reset=True)
+        x, y = a.step(acts, auto_reset=True, fused=True), b.step(acts, auto_reset=True, fused=False)
         for k in ("obs", "state", "reward", "done", "available_actions", "err"):
             assert torch.equal(x[k], y[k]), (t, k)
     with pytest.raises(ValueError):
@@ -482,12 +482,12 @@ def test_restore_does_not_bring_back_an_old_output_descriptor():
 
     for _ in range(3):
         acts = acts_of(a)
-        a.step(acts, auto_reset=True, fused=True), b.step(acts, auto_reset=True)
+        a.step(acts, auto_reset=True, fused=True), b.step(acts, auto_reset=True, fused=False)
     snap_a, snap_b = a.world.snapshot(), b.world.snapshot()
     old_fused = a._fused
     a._fused = None  # the next fused step binds fresh output tensors: the device descriptor changes after the snapshot
     acts = acts_of(a)
-    x, y = a.step(acts, auto_reset=True, fused=True), b.step(acts, auto_reset=True)
+    x, y = a.step(acts, auto_reset=True, fused=True), b.step(acts, auto_reset=True, fused=False)
     assert all(torch.equal(x[k], y[k]) for k in ("obs", "state", "reward", "done", "available_actions"))
     del old_fused  # the tensors the snapshot-time descriptor pointed at are gone
     torch.cuda.empty_cache()
@@ -495,7 +495,7 @@ def test_restore_does_not_bring_back_an_old_output_descriptor():
     a._t = b._t = 3
     for t in range(6):
         acts = acts_of(b)
-        x, y = a.step(acts, auto_reset=True, fused=True), b.step(acts, auto_reset=True)
+        x, y = a.step(acts, auto_reset=True, fused=True), b.step(acts, auto_reset=True, fused=False)
         for k in ("obs", "state", "reward", "done", "available_actions", "err"):
             assert torch.equal(x[k], y[k]), (k, t)
 
@@ -519,7 +519,7 @@ def test_persistent_step_equals_the_allocating_step(kw):
     for t in range(20):
         avail = a.available_actions()
         acts = torch.multinomial(avail.reshape(-1, 5).float() + 1e-6, 1, generator=g).reshape(n, -1).to(torch.uint8)  # (now and then a refused one)
-        x, y = a.step(acts, auto_reset=True, persistent=True), b.step(acts, auto_reset=True)
+        x, y = a.step(acts, auto_reset=True, persistent=True), b.step(acts, auto_reset=True, fused=False)
         for k in ("obs", "state", "reward", "done", "available_actions", "err"):
             assert x[k].shape == y[k].shape and torch.equal(x[k], y[k]), (kw, t, k)
     # the bound calls on their own
@@ -553,7 +553,7 @@ def test_seed_after_a_persistent_step_and_another_stream():
         if t == 4:
             a.seed(77), b.seed(77)  # (after the step calls were bound with seed 5)
         acts = acts_of(b)
-        x, y = a.step(acts, auto_reset=True, persistent=True), b.step(acts, auto_reset=True)
+        x, y = a.step(acts, auto_reset=True, persistent=True), b.step(acts, auto_reset=True, fused=False)
         for k in ("obs", "state", "reward", "done", "available_actions", "err"):
             assert torch.equal(x[k], y[k]), (t, k)
         assert torch.equal(a.world.src_colour, b.world.src_colour), t
@@ -564,7 +564,35 @@ def test_seed_after_a_persistent_step_and_another_stream():
     with torch.cuda.stream(side):
         for t in range(6):
             acts = acts_of(b)
-            x, y = a.step(acts, auto_reset=True, persistent=True), b.step(acts, auto_reset=True)
+            x, y = a.step(acts, auto_reset=True, persistent=True), b.step(acts, auto_reset=True, fused=False)
             for k in ("obs", "state", "reward", "done", "err"):
                 assert torch.equal(x[k], y[k]), (t, k)
     side.synchronize()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(randomize_lasers=True), dict(obs_type="partial7x7"), dict(state_type="layered"), dict(multi_objective=True, state_type="normalized-state"),
+                                dict(walkable_lasers=False)])
+def test_default_step_is_one_launch_into_fresh_tensors(kw):
+    """The default BatchedLLE.step (round 4): the step kernel writes state / reward / available_actions itself, into tensors allocated for
+    that step, wherever it can (walkable_lasers) -- same values as the two-launch step (fused=False), and every step's tensors its own."""
+    import torch
+
+    from lle_amd import BatchedLLE
+
+    n = 1500
+    a, b = BatchedLLE(LEVELS[6], n, seed=5, **kw), BatchedLLE(LEVELS[6], n, seed=5, **kw)
+    a.reset(), b.reset()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    earlier = []
+    for t in range(25):
+        probs = a.available_actions().reshape(-1, 5).float()
+        probs[:, 4] += 1e-3  # (without walkable lasers an agent may have NO available action: multinomial asserts on an all-zero row)
+        acts = torch.multinomial(probs, 1, generator=g).reshape(n, -1).to(torch.uint8)
+        x, y = a.step(acts, auto_reset=True), b.step(acts, auto_reset=True, fused=False)
+        for k in ("obs", "state", "reward", "done", "available_actions", "err"):
+            assert torch.equal(x[k], y[k]), (kw, k, t)
+        earlier.append((x["reward"], x["reward"].clone(), x["available_actions"], x["available_actions"].clone()))
+    torch.cuda.synchronize()
+    for r, rc, av, avc in earlier:  # no later step wrote into an earlier step's tensors
+        assert torch.equal(r, rc) and torch.equal(av, avc)
+    assert len({e[0].data_ptr() for e in earlier[-3:]}) == 3

@@ -334,7 +334,7 @@ def test_batched_lle_partial_in_one_launch():
         g = torch.Generator(device="cuda").manual_seed(1)
         for t in range(16):
             acts = torch.multinomial(b.available_actions().reshape(-1, 5).float(), 1, generator=g).reshape(n, -1).to(torch.uint8)
-            x, y = a.step(acts, auto_reset=True, fused=True), b.step(acts, auto_reset=True)
+            x, y = a.step(acts, auto_reset=True, fused=True), b.step(acts, auto_reset=True, fused=False)
             for key in ("obs", "state", "reward", "done", "available_actions", "err"):
                 assert x[key].shape == y[key].shape and torch.equal(x[key], y[key]), (kw, t, key)
     assert not BatchedLLE(LEVELS[6], 64, obs_type="partial7x7", randomize_lasers=True)._fused_partial  # (per-env sources: two launches)
