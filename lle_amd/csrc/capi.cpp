@@ -149,8 +149,6 @@ struct lle_batch {
     struct View { ViewHeader hdr; uint8_t* dev; uint32_t stride; };
     std::map<std::pair<int, int>, View> views;
     // lle_batch_step_outputs: what the device copy of the EnvOutputs holds (re-uploaded only when the caller's struct changes)
-    EnvOutputs env_out_host{};
-    bool env_out_valid = false;
     // outputs larger than the Infinity Cache: the launches that rewrite one walk the environments alternately up and down
     // (obs_stream.hpp xcd_block_dir); per output buffer, the direction of its next launch (the batch's own rows: a member, no lookup)
     std::map<const void*, bool> walk_dir;
@@ -710,7 +708,6 @@ int lle_batch_restore(lle_batch* b, const void* src_dev, void* stream) {
     if (b->per_env_sources)
         HIP_TRY(hipMemcpyAsync(b->arena + b->layout.off[LLE_BUF_SRC_COLOUR], src + 256 + state_bytes(b), (size_t)sources_bytes(b),
                                hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    b->env_out_valid = false;  // (belt and braces: the next lle_batch_step_outputs uploads its descriptor again)
     LaunchArgs K{};
     // bring the observation (and `done`) in line with the restored state.  With per-environment sources also every env's own
     // reset record, from its restored colours / flags under the CURRENT tables: the snapshot may predate an exit change
@@ -764,14 +761,10 @@ int lle_batch_step_outputs(lle_batch* b, const uint8_t* actions_dev, uint32_t fl
         O.partial = out->partial;
         O.partial_k = (uint32_t)out->partial_k;
     }
-    EnvOutputs* dev = reinterpret_cast<EnvOutputs*>(b->arena + b->layout.off_env_out);
-    if (!b->env_out_valid || std::memcmp(&O, &b->env_out_host, sizeof O) != 0) {
-        b->env_out_host = O;  // (the source of the copy must outlive it: a member, not the stack)
-        HIP_TRY(hipMemcpyAsync(dev, &b->env_out_host, sizeof O, hipMemcpyHostToDevice, (hipStream_t)stream));
-        b->env_out_valid = true;
-    }
     LaunchArgs K{};
-    K.flags = flags; K.seed = seed; K.t = t; K.env_offset = env_offset; K.actions_in = actions_dev; K.env_out = dev;
+    // (the struct rides in the kernel arguments: nothing to upload, whatever the caller hands from one step to the next)
+    K.flags = flags; K.seed = seed; K.t = t; K.env_offset = env_offset; K.actions_in = actions_dev;
+    K.out = O; K.env_out = reinterpret_cast<const EnvOutputs*>(b->arena + b->layout.off_env_out);  // (non-NULL: "outputs wanted"; never read)
     K.partial_k = O.partial ? O.partial_k : 0u; K.partial_E = partial_E;
     if (O.partial && (flags & STEP_RECOLOUR_RESETS)) return fail(LLE_ERR_UNSUPPORTED, "the partial observation of the step launch: the map's own sources only");
     return launch(b, KMODE_STEP, K, stream);

@@ -58,6 +58,13 @@ __device__ __forceinline__ EnvOutputs load_uniform(const EnvOutputs* p) {
     return o;
 }
 
+// Where LaunchArgs.out sits in the kernel-argument segment of step_kernel(BatchPtrs, LaunchArgs): explicit arguments start at offset 0,
+// each at its natural alignment.
+constexpr size_t KERNARG_ENV_OUT = ((sizeof(BatchPtrs) + alignof(LaunchArgs) - 1) / alignof(LaunchArgs)) * alignof(LaunchArgs) + offsetof(LaunchArgs, out);
+__device__ __forceinline__ const EnvOutputs* kernarg_env_out() {
+    return reinterpret_cast<const EnvOutputs*>((const char*)__builtin_amdgcn_kernarg_segment_ptr() + KERNARG_ENV_OUT);  // (C cast: out of the constant address space)
+}
+
 template <int G, int LM, int MODE, bool ML1, int LX = -1>
 __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P, LaunchArgs K) {
     // MODE 9: MODE 4 whose launch writes the PARTIAL k x k observation (python/lle/observations.py:312-369) from the hand-over records
@@ -145,7 +152,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     uint32_t h_G = 0, h_H = 0;
     constexpr bool EARLY_OUT = MODE == 7;  // (MODE 4 / 5 / 8 have no scalar registers to park the descriptor in: they spill vector registers for it;
                                            //  they fetch it where it is used through the scalar cache, load_uniform: no vmcnt wait behind the head stores)
-    if (EARLY_OUT && K.env_out) O_early = *K.env_out;
+    if (EARLY_OUT && K.env_out) O_early = K.out;
     if (ENV_OUT) { h_G = hdr->G; h_H = hdr->H; }
     uint32_t h_init_beams[LR];  // the reset state's beams (shared record; the per-env one is read where it is used)
 #pragma unroll
@@ -180,7 +187,15 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     // The general mode is short of VECTOR registers instead (it spilled eight to scratch, and a scratch reload inside
     // the state machine is a memory round trip): there the addresses of the late stores are rebuilt from the scalar
     // bases where they are used, and the per-lane copies above die after the loads.
-#define LLE_LATE(field, offset) (GEN ? P.field + (offset) : p_##field)
+#define LLE_LATE(field, offset) ((GEN || ROLL) ? P.field + (offset) : p_##field)
+    // ... REBUILT, not carried: `env_late` is the env index behind an empty asm, so the compiler cannot fold these addresses with the
+    // prologue's (same expressions) and keep them alive across the state machine after all -- which it did, and then split their live
+    // ranges with a copy placed AHEAD of the exec-restoring s_or_b64 of a divergent join (hipcc 7.2; the copy ran for the lanes of the
+    // region only, the others stored their gems through a stale register: the fault of `step_kernel<4,4,4,false,-1>` on the `nested`
+    // map, found with rocgdb's precise memory mode -- profiles/r04_pes_tax.md, tools/isa_exec_copy_scan.py).
+#define LLE_ENV_LATE(name)                                   \
+    int64_t name = env_c;                                    \
+    if ((GEN || ROLL) && !HEAD) asm volatile("" : "+v"(name))   /* (the kernels with row heads have registers to spare and lose 0.3-0.5 us to the late arithmetic) */
     uint32_t init_pos_a = 0xFFFF0000u + a, init_avail_a = 0;  // this agent's reset position / availability
     uint64_t init_bits = 0;
     uint32_t init_gems = 0;
@@ -514,14 +529,15 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     // the one whose first store ends the idle time of the memory system) does this after its stream, a younger one --
     // which waits for memory anyway and would otherwise add it to the end of the launch -- before.
     auto post_step = [&]() {
+    LLE_ENV_LATE(env_p);
     if (stepped) avail_lanes<G>(a, me, pos, occ, alive, arrived, meta_step, avail);
 #pragma unroll
     for (int k = 0; k < NW; k++) evw[k] = grp_or64<G>(evw[k]);
     if (env_ok && a == 0) {
-        small_store(LLE_LATE(err, env_c), (uint8_t)err);
-        small_store(LLE_LATE(evcount, env_c), (uint8_t)(n_ev | (was_reset << 7)));
+        small_store(LLE_LATE(err, env_p), (uint8_t)err);
+        small_store(LLE_LATE(evcount, env_p), (uint8_t)(n_ev | (was_reset << 7)));
         {
-            uint8_t* row = LLE_LATE(events, env_c * 2 * As);  // 2*As bytes per env; this kernel fills the first 2*G
+            uint8_t* row = LLE_LATE(events, env_p * 2 * As);  // 2*As bytes per env; this kernel fills the first 2*G
             if (G >= 2) {
                 uint32_t* __restrict__ w = reinterpret_cast<uint32_t*>(row);
 #pragma unroll
@@ -530,7 +546,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
                 small_store(reinterpret_cast<uint16_t*>(row), (uint16_t)evw[0]);
             }
         }
-        small_store(LLE_LATE(done, env_c), (uint8_t)(((alive | ghost) != amask || arrived == amask) ? 1 : 0));
+        small_store(LLE_LATE(done, env_p), (uint8_t)(((alive | ghost) != amask || arrived == amask) ? 1 : 0));
         uint32_t n_died = 0, n_gem = 0;
 #pragma unroll
         for (int k = 0; k < NW; k++) {
@@ -552,7 +568,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     if (ENV_OUT && K.env_out) {
         // (read where it is used; through the SCALAR cache by hand: behind the kernel's own stores the compiler would fetch it
         // with vector loads, whose wait also covers every store in flight -- the descriptor is written by the host only)
-        const EnvOutputs O = EARLY_OUT ? O_early : load_uniform(K.env_out);
+        const EnvOutputs O = EARLY_OUT ? O_early : load_uniform(kernarg_env_out());
         const int n_gems = (int)h_G, len = 3 * A + n_gems;
         if (me) {
             const int64_t ia = env * A + a;
@@ -681,7 +697,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         if (ROLL && n_steps > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     } else if (PARTIAL) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the workgroup's bitmap is complete (LDS only: no wait for stores)
-        const EnvOutputs O = load_uniform(K.env_out);
+        const EnvOutputs O = load_uniform(kernarg_env_out());
         if (O.partial && n_here > 0)
             write_partial<true>(A, L, W, (int)K.partial_k, part_pitch, K.partial_E, h_max_layers, cell_lay, cell_meta, part_bm, part_col, tmpl, scratch,
                                 scr_stride, O.partial, env0, n_here, lane);
@@ -712,22 +728,24 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
 
     // ---- final state.  Written unconditionally: an env whose action was refused kept its registers unchanged
     // (world.rs:436-453: errors precede any mutation), so this rewrites the same bytes.
+    LLE_ENV_LATE(env_f);
     if (me) {
-        small_store(LLE_LATE(pos, env_c * As + a), (uint16_t)pos);
-        small_store(LLE_LATE(avail, env_c * As + a), (uint8_t)avail);
+        small_store(LLE_LATE(pos, env_f * As + a), (uint16_t)pos);
+        small_store(LLE_LATE(avail, env_f * As + a), (uint8_t)avail);
     }
     if (env_ok && a == 0) {
-        small_store(LLE_LATE(bits, env_c), (uint64_t)alive | ((uint64_t)arrived << 16) | ((uint64_t)occ << 32) | ((uint64_t)ghost << GHOST_SHIFT));
-        small_store(LLE_LATE(gems, env_c), gems);
-        uint32_t* const beams_out = LLE_LATE(beams, env_c * L);
+        small_store(LLE_LATE(bits, env_f), (uint64_t)alive | ((uint64_t)arrived << 16) | ((uint64_t)occ << 32) | ((uint64_t)ghost << GHOST_SHIFT));
+        small_store(LLE_LATE(gems, env_f), gems);
+        uint32_t* const beams_out = LLE_LATE(beams, env_f * L);
 #pragma unroll
         for (int b = 0; b < LR; b++)
             if (!BM && b < L) small_store(&beams_out[b], beams[b]);
     }
     if (BM && env_ok) {
-        uint32_t* const beams_out = LLE_LATE(beams, env_c * L);
+        uint32_t* const beams_out = LLE_LATE(beams, env_f * L);
         for (int b = (int)a; b < L; b += G) small_store(&beams_out[b], bm[b]);
 #undef LLE_LATE
+#undef LLE_ENV_LATE
 #undef LLE_LOAD_STATE
 #undef LLE_ROT
     }

@@ -236,9 +236,12 @@ struct LaunchArgs {
     uint32_t table_stride, map_override;
     uint32_t n_sources;        // host side only: MapHeader.L, for the launcher's choice of instantiation
     uint32_t partial_E;        // step_kernel MODE 9: environments per batch of the partial writer (partial_stream.hpp)
-    // step_kernel only: write LLE.step's other outputs in the same launch (lle_batch_step_outputs).  A DEVICE copy of the
-    // struct, read with scalar loads where it is used: its six pointers never occupy registers during the state machine.
+    // step_kernel only: write LLE.step's other outputs in the same launch (lle_batch_step_outputs).  `env_out` non-NULL says so; the
+    // struct itself travels in the kernel arguments (`out`, since round 4: a caller that hands other tensors every step pays no
+    // upload for it) and is read from the kernarg segment with scalar loads where it is used (step_kernel.hpp kernarg_env_out):
+    // its pointers never occupy registers during the state machine.
     const EnvOutputs* env_out;
+    EnvOutputs out;
 };
 
 // State of a freshly reset environment (identical for every env of a map: v1 maps have one start per agent).
