@@ -62,7 +62,7 @@ def host_cores():
         return os.cpu_count() or 1
 
 
-def cpu_baseline(n_envs, seconds_target=12.0):
+def cpu_baseline(n_envs, seconds_target=20.0):
     """The CPU oracle (C restatement of the reference algorithm, kind "port") on a bounded sample of the same workload:
     the same n_envs level-6 environments, sampled actions + auto-reset + int8 layered observation.  The thread count is
     SWEPT -- 64, 128 and every core this process may run on (deduplicated, capped at the visible cores), threads pinned to
