@@ -425,7 +425,7 @@ int lle_batch_env_outputs(lle_batch* b, const lle_env_outputs* out, void* stream
  * by the step kernel itself, from registers (the separate launch costs 4.9 us at 65 536 envs, all of it launch boundary).
  * Same results as the two calls in a row.  `out->available` needs walkable_lasers != 0 (LLE_ERR_UNSUPPORTED otherwise: the
  * mask without moves into foreign beams reads the neighbours' laser stacks -- use lle_batch_env_outputs for it).
- * The struct is mirrored in device memory and re-uploaded only when it changes: keep the output buffers across steps.
+ * The struct travels in the launch's kernel arguments (round 4): other buffers every step cost nothing extra.
  * With `out->partial` set the launch writes the partial observation (python/lle/observations.py:312-369) from the state machine's
  * own records instead of LLE_BUF_OBS: 38-41 us -> one launch for a step of `LLE(obs_type="partial7x7")` (maps with at most 8 beam
  * words, the map's own sources; LLE_ERR_UNSUPPORTED otherwise: lle_batch_observe_as behind the step). */

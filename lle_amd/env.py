@@ -277,8 +277,8 @@ class BatchedLLE:
         return reward
 
     def _fresh_outputs(self):
-        """(tensors, struct) for ONE step of the one-launch path: like _fused_outputs, allocated anew (the library mirrors the struct on
-        the device and uploads it when it changes -- 64 bytes on the launch stream; measured: 21.10 us per step against 21.06 persistent)."""
+        """(tensors, struct) for ONE step of the one-launch path: like _fused_outputs, allocated anew (the struct travels in the
+        launch's kernel arguments: 21.04 us per step against 21.02 with persistent tensors)."""
         keep, self._fused = self._fused, None
         try:
             return self._fused_outputs()
@@ -286,8 +286,7 @@ class BatchedLLE:
             self._fused = keep
 
     def _fused_outputs(self):
-        """Persistent output tensors of the one-launch step and the struct over them (lle_batch_step_outputs mirrors the
-        struct on the device and re-uploads it only when it changes)."""
+        """Persistent output tensors of the one-launch step and the struct over them (lle_batch_step_outputs passes the struct in the kernel arguments)."""
         if self._fused is None:
             w, n, dev = self.world, self.n_envs, self.world.device
             fused_state = self._state_kind[0] in (_capi.LLE_OBS_STATE, _capi.LLE_OBS_NORMALIZED_STATE)
