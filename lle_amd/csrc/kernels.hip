@@ -638,6 +638,8 @@ uint32_t step_partial_batch(const MapHeader& h, int k, bool pes) {
         const uint32_t S2 = 64u / ((E / 2u) * a_pad), rl = ((uint32_t)k + S2 - 1u) / S2;
         if (S2 <= (uint32_t)k && 4u * (uint32_t)k >= 3u * S2 * rl) E >>= 1;
     }
+    if (const uint32_t v = (uint32_t)tuning().partial_e)  // LLE_PARTIAL_E: tuning override (a power of two whose lanes still cover a window's rows)
+        if (!(v & (v - 1)) && v * a_pad <= 64u && 64u / (v * a_pad) >= s_min) E = v;
     return partial_step_lds(h, 1, E, k) <= LDS_PER_CU ? E : 0u;
 }
 
