@@ -161,8 +161,9 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     const uint32_t amask = (1u << A) - 1u;
     // (the row this wavefront starts its stream at, obs_stream.hpp row_rotation: computed where it is used, from values that are live
     // there anyway -- carried across the state machine it cost the tightest instantiations a spilled register)
-    // Single-step launches only: a fused rollout's instantiations sit at the register cap already (the extra value cost them 12 B of scratch).
-#define LLE_ROT() (ROLL ? 0u : row_rotation(wave_id, EPW, n_here, K.flags))
+    // Not in the per-env-sources rollout (MODE 3), whose instantiations sit at the register cap; the other rollouts have had room for it since
+    // their late addresses are rebuilt (LLE_ENV_LATE): a 1 GB trajectory ring is written past the Infinity Cache, where the rotation pays.
+#define LLE_ROT() ((ROLL && PES) ? 0u : row_rotation(wave_id, EPW, n_here, K.flags))
     LLE_STAMP(0);
 
     // ---- packed state: own position / availability, and the env-wide words replicated in the group's lanes
