@@ -252,7 +252,7 @@ def scaling_block(rows, steps, sustained_steps, n_envs, agents, n1_reference=Non
                       "host_share_of_wall": 1.0 - k_max * steps * 1e-3 / wall_max if wall_max > 0 else None,
                       "note": "wall = the contract's clock (barrier + synchronize on both sides, max over ranks): what `value` is computed from; "
                               "without_closing_barrier = each rank's clock stopped at its own synchronize, before the closing barrier (the same clock at N = 1); "
-                              "kernel = HIP events on each rank's launch stream around the same launches"}}
+                              "kernel = HIP events on each rank's launch stream INSIDE the same run of launches (behind the first call and ahead of the last: K - 2 launches timed, the records themselves hidden behind running kernels)"}}
     if sustained_steps and all(row[4] > 0 for row in rows):
         s_k = max(row[4] for row in rows)
         out["region"]["sustained_kernel_ms_max_over_ranks"] = s_k
@@ -295,7 +295,7 @@ def n1_reference(n_envs, sustained_steps, write=None):
 class Timer:
     """K launches bracketed the way the contract asks: barrier + synchronize on both sides, every rank's own wall clock
     (the caller takes the MAX over ranks) and HIP events on the launch stream (torch's current stream is the one every
-    launch uses).  Opening: synchronize, barrier, synchronize, clock starts -- the ranks start together.  Closing: synchronize
+    launch uses; since the end of round 4 the two records sit behind the first and ahead of the last call, see run()).  Opening: synchronize, barrier, synchronize, clock starts -- the ranks start together.  Closing: synchronize
     (`wall_open` stops here: this rank's own launches are done), barrier, synchronize, `wall` stops -- the contract's clock, the
     one `value` is computed from.  At N = 1 there is no barrier and the two are the same clock; at N > 1 `wall` carries one
     small all-reduce (tens of microseconds: 5-10 % of the driver's 0.4-ms region of 20 steps), `wall_open` does not but is
@@ -318,21 +318,32 @@ class Timer:
         torch = self.torch
         self.sync()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # The two event records are harness work, not work of the K steps: issued at the region's edges they cost it 0.5 us per step at
+        # K = 20 (tools/region_edges.py: 21.0 us per step with them, 20.5 without).  So they sit INSIDE the run of launches -- ev0 behind
+        # the first call, ev1 ahead of the last one, where the GPU is busy and the host's microseconds are hidden -- and time the K - 2
+        # calls between them; the clock still brackets exactly K calls with a synchronize (and barrier) on both sides.
+        inner = k >= 4
         t0 = time.perf_counter()
-        ev0.record()
-        for _ in range(k):
+        if inner:
             fn()
-        self.issue = time.perf_counter() - t0  # the host's own time: K calls issued, nothing waited for
-        ev1.record()
-        # (a blocking synchronize, not a spin on ev1.query(): over 40 regions of 20 steps the spin cost 21.5 us per step against 21.0 --
-        # tools/region_edges.py; the two event records themselves cost the region 0.5 us per step at K = 20, 20.5 without them)
-        torch.cuda.synchronize(self.dev)
+            ev0.record()
+            for _ in range(k - 2):
+                fn()
+            ev1.record()
+            fn()
+        else:
+            ev0.record()
+            for _ in range(k):
+                fn()
+            ev1.record()
+        self.issue = time.perf_counter() - t0  # the host's own time: K calls (and the two records) issued, nothing waited for
+        torch.cuda.synchronize(self.dev)  # (blocking: a spin on ev1.query() cost 0.5 us per step more)
         wall = self.wall_open = time.perf_counter() - t0
         if self.use_dist:
             self.dist.barrier()
             torch.cuda.synchronize(self.dev)
             wall = time.perf_counter() - t0
-        return wall, ev0.elapsed_time(ev1) / k  # seconds (the contract's clock), ms per launch
+        return wall, ev0.elapsed_time(ev1) / ((k - 2) if inner else k)  # seconds (the contract's clock), ms per launch
 
 
 def stepper(bw, offset=0):
