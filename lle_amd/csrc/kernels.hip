@@ -510,7 +510,7 @@ static bool beams_in_lds(const MapHeader& h) { return h.L > 4; }
 uint32_t kernel_lds_bytes(const MapHeader& h, uint32_t waves_per_wg, bool pes) {
     const uint32_t scr_stride = (h.L + h.A + 2 + (pes ? (uint32_t)src_stride_of((int)h.L) / 4u : 0u)) | 1u;
     // (+ 256 B: step_kernel's beam tables of maps with more than 8 sources, step_kernel.hpp BM)
-    return h.lds_table_bytes + (pes ? h.ext_bytes : 0u) + (beams_in_lds(h) ? 256u : 0u) + waves_per_wg * (h.obs_stride + 64 * scr_stride * 4) + 64;
+    return h.lds_table_bytes + (pes ? h.ext_bytes : 0u) + (beams_in_lds(h) ? 256u : 0u) + waves_per_wg * (h.obs_stride + 64 * scr_stride * 4 + (pes ? PES_WAVE_EXTRA_BYTES : 0u)) + 64;
 }
 
 // wavefronts per workgroup: as many (4, 2, 1) as fit the 160 KiB of a CU.  More wavefronts per table copy beat more

@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     // a wavefront's private area: [row template | hand-over records]; PARTIAL: [E rows of the partial observation + 16 B | records]
     const uint32_t part_pitch = PARTIAL ? (((uint32_t)(A * (2 * A + 3)) * K.partial_k * K.partial_k + 15u) & ~15u) : 0u;
     const uint32_t row_area = PARTIAL ? K.partial_E * part_pitch + 16u : h_obs_stride;
-    const uint32_t priv_bytes = row_area + (PARTIAL ? ((EPW * scr_stride * 4u + 15u) & ~15u) : 64u * scr_stride * 4u);  // (PARTIAL: a record per environment of the wavefront, no spare slots)
+    const uint32_t priv_bytes = row_area + (PARTIAL ? ((EPW * scr_stride * 4u + 15u) & ~15u) : 64u * scr_stride * 4u) + (PES ? PES_WAVE_EXTRA_BYTES : 0u);  // (PARTIAL: a record per environment of the wavefront, no spare slots)
     int8_t* tmpl = reinterpret_cast<int8_t*>(lds + tab_bytes + ext_bytes + bt_bytes + pm_bytes + wave_in_wg * priv_bytes);
     uint32_t* scratch = reinterpret_cast<uint32_t*>(tmpl + row_area);
     const int8_t* bare = reinterpret_cast<const int8_t*>(lds + tab_bytes);
@@ -411,6 +411,15 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     // ---- n_steps consecutive steps of the wave's environments; the state stays in registers in between.
     // (n_steps = 1 is World.step; more is a fused rollout with on-device action sampling, lle_batch_rollout.)
     StepCounts cnt = {0, 0, 0, 0, 0, 0, 0};
+    // Fused rollouts: the seven per-env counters of the launch live in the wavefront's spare record slots (LDS) instead of seven vector
+    // registers carried across the steps -- `ds_add_u32` without a return per step, read back once behind the loop.  The per-env-sources
+    // rollout (MODE 3) sits at the register cap.
+    constexpr bool CNT_LDS = ROLL && PES && G >= 2;   // (tables.h PES_WAVE_EXTRA_BYTES: behind the wavefront's 64 record slots)
+    uint32_t* const cnt_lds = scratch + 64u * scr_stride + grp * 8u;   // (8 words per environment; only lane a == 0 touches them)
+    if (CNT_LDS && env_ok && a == 0) {
+#pragma unroll
+        for (int q = 0; q < 7; q++) cnt_lds[q] = 0u;
+    }
     const uint32_t n_steps = ROLL ? (K.n_steps ? K.n_steps : 1u) : 1u;
     for (uint32_t it = 0; it < n_steps; it++) {
     const uint64_t t_now = K.t + it;
@@ -557,8 +566,14 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         const uint32_t n_exit = n_ev - n_died - n_gem;
         const uint32_t bonus = (err == 0 && arrived == amask) ? 1u : 0u;
         small_store(&reward_out[env], n_gem | (n_exit << 8) | (n_died << 16) | (bonus << 24));
-        cnt.steps += 1u; cnt.gems += n_gem; cnt.exits += n_exit; cnt.died += n_died;
-        cnt.invalid += err != 0 ? 1u : 0u; cnt.resets += was_reset; cnt.bonus += bonus;
+        if (CNT_LDS) {
+            const uint32_t add[7] = {1u, n_gem, n_exit, n_died, err != 0 ? 1u : 0u, was_reset, bonus};
+#pragma unroll
+            for (int q = 0; q < 7; q++) __hip_atomic_fetch_add(&cnt_lds[q], add[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        } else {
+            cnt.steps += 1u; cnt.gems += n_gem; cnt.exits += n_exit; cnt.died += n_died;
+            cnt.invalid += err != 0 ? 1u : 0u; cnt.resets += was_reset; cnt.bonus += bonus;
+        }
     }
     // ---- LLE.step's other outputs (python/lle/env/env.py:165-187), fused: what lle_batch_env_outputs writes in a launch
     // of its own (4.9 us at 65 536 envs, all of it launch boundary), written here from registers.  walkable_lasers only
@@ -749,6 +764,10 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
 #undef LLE_ENV_LATE
 #undef LLE_LOAD_STATE
 #undef LLE_ROT
+    }
+    if (CNT_LDS && env_ok && a == 0) {
+        cnt.steps = cnt_lds[0]; cnt.gems = cnt_lds[1]; cnt.exits = cnt_lds[2]; cnt.died = cnt_lds[3];
+        cnt.invalid = cnt_lds[4]; cnt.resets = cnt_lds[5]; cnt.bonus = cnt_lds[6];
     }
     flush_stats(P.stats, wave_id, cnt, A, lane, PRE_STATS, stats_old);
     if (STAMPED && stamps) {

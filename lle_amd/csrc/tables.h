@@ -206,6 +206,11 @@ struct EnvOutputs {
     uint32_t partial_k;    // window size of `partial`
 };
 
+// Per-env-sources kernels: every wavefront's private LDS area ends with this many bytes for the seven counters of a launch that the fused
+// rollout (MODE 3) would otherwise carry in registers across its steps: 8 words per environment, 64 / 2 environments at most (one-agent
+// maps keep the registers).
+constexpr uint32_t PES_WAVE_EXTRA_BYTES = 32u * 8u * 4u;
+
 // Per-launch arguments.
 struct LaunchArgs {
     uint32_t flags;            // STEP_*

@@ -400,6 +400,7 @@ def test_fused_rollout_with_per_env_sources_on_many_source_maps(name):
     for slot, (obs, acts) in obs_of_step.items():
         assert torch.equal(ring["obs"][slot], obs) and torch.equal(ring["actions"][slot], acts), (name, "ring slot", slot)
     assert a.stats()["env_steps"] == b.stats()["env_steps"] == n * T
+    assert a.stats() == b.stats() == c.stats()  # every counter (the rollout keeps them in LDS across its steps: tables.h PES_WAVE_EXTRA_BYTES)
 
 
 @pytest.mark.parametrize("name", ["level6", "level5", "nested", "three_beams", "many_agents"])
