@@ -469,6 +469,9 @@ static int launch(lle_batch* b, int mode, LaunchArgs K, void* stream) {
     }
     if (mode == KMODE_STEP && !b->lane_per_env_step) {
         K.envs_per_wave = step_envs_per_wave(b->n_envs, (int)b->hdr.A, b->tune);
+        // every wavefront owns one slot of LLE_BUF_STATS (kernel_common.hpp flush_stats): never more wavefronts than slots
+        if ((b->n_envs + K.envs_per_wave - 1) / K.envs_per_wave > b->layout.n_stat_blocks)
+            return fail(LLE_ERR_ARG, "internal: more wavefronts than counter slots (envs_per_wave below " + std::to_string(MIN_ENVS_PER_WAVE) + ")");
         // single steps that rewrite the rows in place (a fused rollout rewrites them inside one launch, a ring never revisits a slot in time)
         if (K.n_steps <= 1 && !K.ring_slots && !K.stamps && !(K.flags & STEP_NO_OBS) &&
             next_walk_reversed(b, b->ptrs.obs, (uint64_t)b->n_envs * b->hdr.obs_stride))
@@ -1244,7 +1247,7 @@ int lle_batch_autotune(lle_batch* b, double budget_ms, void* stream) {
     // heads, store policy, split rows, the alternating walk -- only those that exist for this batch
     const uint32_t cap = 64u / (uint32_t)step_group((int)h.A);
     std::vector<uint32_t> epws;
-    for (uint32_t e = cap; e >= 1 && epws.size() < 3; e >>= 1) epws.push_back(e);
+    for (uint32_t e = cap; e >= MIN_ENVS_PER_WAVE && epws.size() < 3; e >>= 1) epws.push_back(e);  // (one LLE_BUF_STATS slot per wavefront of >= 4 envs)
     const bool can_heads = step_has_row_heads(h, pes), can_split = step_can_split_rows(h, pes), can_walk = row_bytes > (256ull << 20);
     const int n_trials = (int)epws.size() + (can_heads ? 4 : 0) + 2 + (can_split ? 2 : 0) + (can_walk ? 2 : 0) + 2;
     uint64_t t_idx = 1u << 20;

@@ -453,8 +453,10 @@ static hipError_t launch_mode(int mode, const BatchPtrs& P, const LaunchArgs& K,
 }
 
 // ---- the environment overrides, read once (kernels.h Tuning)
-static Tuning g_tuning;
-static std::atomic<bool> g_tuning_loaded{false};
+// The snapshot the launch path reads is published through an atomic pointer: lle_tuning_refresh() may run while other threads launch
+// (distinct handles are independent, lle_hip.h).  A refresh builds a NEW snapshot and swaps the pointer; the old one is never freed (a
+// launch may still be reading it, and refreshes are a handful per process: tests and tuning tools).
+static std::atomic<const Tuning*> g_tuning{nullptr};
 static int env_bool(const char* name) {
     const char* o = getenv(name);
     return (o && (o[0] == '0' || o[0] == '1') && !o[1]) ? o[0] - '0' : -1;
@@ -465,7 +467,8 @@ static int env_uint(const char* name) {
     return v > 0 ? v : 0;
 }
 void tuning_refresh() {
-    Tuning t;
+    Tuning* fresh = new Tuning();
+    Tuning& t = *fresh;
     t.step_wpw = env_uint("LLE_STEP_WPW");
     t.step_split = env_bool("LLE_STEP_SPLIT");
     t.write_through = env_bool("LLE_WRITE_THROUGH");
@@ -481,12 +484,15 @@ void tuning_refresh() {
     t.row_rotate = env_bool("LLE_ROW_ROTATE");
     t.head_group = env_uint("LLE_HEAD_GROUP");
     t.post_first = env_bool("LLE_POST_FIRST");
-    g_tuning = t;
-    g_tuning_loaded.store(true, std::memory_order_release);
+    g_tuning.store(fresh, std::memory_order_release);
 }
 const Tuning& tuning() {
-    if (!g_tuning_loaded.load(std::memory_order_acquire)) tuning_refresh();
-    return g_tuning;
+    const Tuning* t = g_tuning.load(std::memory_order_acquire);
+    if (!t) {
+        tuning_refresh();
+        t = g_tuning.load(std::memory_order_acquire);
+    }
+    return *t;
 }
 
 int kernel_variant(int A, int L) {
@@ -600,8 +606,10 @@ int step_lm(int L) { return L <= 4 ? 4 : (L <= 8 ? 8 : (L <= 16 ? 16 : 32)); }
 // ~4096 wavefronts (16 per CU), fewer (down to 4) for small batches
 uint32_t step_envs_per_wave(int64_t n, int A, const StepTune& tune) {
     uint32_t e = 64u / (uint32_t)step_group(A);
-    for (const uint32_t v : {(uint32_t)tuning().step_epw, (uint32_t)tune.epw})  // LLE_STEP_EPW, then the batch's own choice
-        if (v >= 1 && v <= e && !(v & (v - 1))) return v;
+    // LLE_STEP_EPW, then the batch's own choice.  Never below MIN_ENVS_PER_WAVE: LLE_BUF_STATS holds one slot per wavefront of
+    // AT LEAST that many environments (capi.cpp make_layout), and a wavefront indexes it by its id.
+    for (const uint32_t v : {(uint32_t)tuning().step_epw, (uint32_t)tune.epw})
+        if (v >= MIN_ENVS_PER_WAVE && v <= e && !(v & (v - 1))) return v;
     while (e > 4 && n / e < 4096) e >>= 1;  // measured on level 1: 4 beats 1-2 even at n = 4096
     return e;
 }

@@ -612,7 +612,10 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         // not hold it, every lane stores its own values.
         if (HEAD) {
             const uint32_t st_off = (EPW * scr_stride * 4u + 15u) & ~15u;
-            const bool staged = !split && O.state && (len & 3) == 0 && st_off + EPW * (uint32_t)len * 4u <= 64u * scr_stride * 4u;
+            // (16-byte stores: the caller's `state` pointer must be 16-byte aligned for them -- a torch view at a 4-byte offset is not --,
+            // otherwise every lane stores its own values as in the kernels without heads)
+            const bool staged = !split && O.state && (len & 3) == 0 && (reinterpret_cast<uintptr_t>(O.state) & 15u) == 0u &&
+                                st_off + EPW * (uint32_t)len * 4u <= 64u * scr_stride * 4u;
             if (O.state) {
                 float* st = staged ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(scratch) + st_off) + grp * (uint32_t)len : O.state + env * len;
                 if (me) {

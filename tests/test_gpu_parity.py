@@ -644,6 +644,58 @@ def test_autotune_changes_rules_not_results(oracle_mod):
         assert a.stats() == b.stats()
 
 
+def test_autotune_many_agents_keeps_the_counter_slots(oracle_mod):
+    """lle_batch_autotune swept environments-per-wavefront down to 2 and 1 on maps with more than four agents, where
+    LLE_BUF_STATS (one slot per wavefront of AT LEAST four environments) is too short: the trial launches wrote their counters over
+    REQ_POS / REQ_GEMS / REQ_ALIVE / REWARD / SRC_COLOUR.  Now no launch runs below four environments per wavefront.  A 14-agent map
+    (step_kernel<16, .>, cap 4) and config 5 (8 agents, cap 8) at 65 536 / 32 768 environments: the buffers behind LLE_BUF_STATS keep
+    a sentinel pattern through the sweep, LLE_STEP_EPW=1 / 2 are ignored, and the counters of a rollout add up to the events."""
+    import torch
+
+    from lle_amd import BatchedWorld, _capi, mapgen
+
+    for text, n in ((EXTRA_MAPS["many_agents"], 65536), (mapgen.config5(1), 32768)):
+        bw = BatchedWorld(text, n)
+        assert bw.kernel_info()["envs_per_wave"] >= 4
+        guard = [bw.req_pos, bw.req_gems, bw.req_alive, bw.src_colour, bw.src_enabled]
+        for g in guard:
+            g.fill_(0x5A)
+        tuned = bw.autotune(budget_ms=8.0)
+        assert tuned["envs_per_wave"] >= 4, tuned
+        assert " 2=" not in tuned["log"].split("envs_per_wave:")[1].split("->")[0] and " 1=" not in tuned["log"].split("envs_per_wave:")[1].split("->")[0], tuned["log"]
+        torch.cuda.synchronize()
+        for g in guard:
+            assert bool((g == 0x5A).all() if g.dtype == torch.uint8 else (g.view(torch.uint8) == 0x5A).all()), "a trial launch wrote past LLE_BUF_STATS"
+        assert bw.stats()["env_steps"] == 0
+        ev = torch.zeros(3, dtype=torch.int64, device="cuda")
+        for t in range(6):
+            bw.step(sample=True, auto_reset=True, seed=3, t=t)
+            cnt = (bw.evcount & 0x7F).to(torch.int64)
+            valid = torch.arange(bw.events.shape[1], device="cuda")[None, :] < cnt[:, None]
+            ty = (bw.events >> 4).to(torch.int64)
+            for k in range(3):
+                ev[k] += ((ty == k) & valid).sum()
+        st = bw.stats()
+        assert st["env_steps"] == 6 * n and (st["exits"], st["gems"], st["deaths"]) == tuple(int(v) for v in ev.tolist())
+        for g in guard:
+            assert bool((g.view(torch.uint8) == 0x5A).all())
+        del bw
+    import os
+    os.environ["LLE_STEP_EPW"] = "1"
+    _capi.refresh_tuning()
+    try:
+        bw = BatchedWorld(EXTRA_MAPS["many_agents"], 20000)
+        assert bw.kernel_info()["envs_per_wave"] == 4  # (the override is below the floor: ignored)
+        ob = oracle_mod.OracleBatch(EXTRA_MAPS["many_agents"], 20000)
+        for t in range(3):
+            bw.step(sample=True, auto_reset=True, seed=8, t=t)
+            check(bw, ob, ob.step(None, auto_reset=True, seed=8, t=t), f"LLE_STEP_EPW=1 t={t}")
+        assert bw.stats()["env_steps"] == 3 * 20000
+    finally:
+        del os.environ["LLE_STEP_EPW"]
+        _capi.refresh_tuning()
+
+
 @pytest.mark.parametrize("name", ["level6", "level1", "nested", "many_agents"])
 def test_row_rotation_changes_nothing(oracle_mod, monkeypatch, name):
     """Every wavefront starts its observation stream at another one of its rows (obs_stream.hpp row_rotation, LLE_ROW_ROTATE):
