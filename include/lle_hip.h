@@ -513,6 +513,18 @@ int lle_batch_autotune(lle_batch* b, double budget_ms, void* stream);
 int lle_batch_tuning(const lle_batch* b, lle_tuning_info* out, char* log_buf, size_t cap);
 void lle_tuning_refresh(void);
 
+/* ---- debug registry: which kernel instantiations has this process LAUNCHED, and which can the dispatch REACH?
+ * The library is 570-odd template instantiations of a few kernels (step_kernel<G, LM, MODE, ML1, LX>: lanes per environment, beam
+ * registers, launch mode, single-layer maps, exact source count; world_kernel<AM, LM, MODE>; the observers).  A compiler fault in ONE
+ * of them is only seen by a test that launches that one: tests/test_gpu_instantiations.py drives every reachable instantiation against
+ * the oracle and fails when lle_debug_reachable() names a kernel that lle_debug_launched() does not.
+ * Both write newline-separated names (rocprofv3's spelling without spaces, e.g. "step_kernel<4,4,6,true,3>"), sorted, NUL-terminated,
+ * truncated to `cap`; they return the bytes needed.  `reachable` walks the launchers' own dispatch code with launches suppressed, for
+ * every (agents 1..16, beam words 0..32, crossing beams or not, mode): it cannot drift from the dispatch.  Host side, thread-safe. */
+size_t lle_debug_launched(char* buf, size_t cap);
+size_t lle_debug_reachable(char* buf, size_t cap);
+void lle_debug_reset_launched(void);
+
 /* Placement aid: the step kernel's store pattern (rows_per_wave rows of row_bytes per wavefront, XCD-contiguous blocks) over ANY device
  * buffer of n_rows x row_bytes bytes, zeros.  Past the Infinity Cache the write rate of a buffer depends on where the allocation landed
  * (profiles/r04_alloc_probe.md): a host that allocates a trajectory ring or an observer output of that size times this on a few

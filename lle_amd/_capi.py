@@ -46,6 +46,7 @@ EXPORTS = [
     "lle_batch_stats_allreduce_group", "lle_comm_allreduce_i64", "lle_comm_allreduce_i64_group",
     "lle_batch_stats", "lle_batch_kernel_info", "lle_batch_set_envs_per_wave", "lle_batch_step_stamped", "lle_batch_probe_row_fill",
     "lle_batch_autotune", "lle_batch_tuning", "lle_tuning_refresh", "lle_probe_read_rows", "lle_probe_fill_rows",
+    "lle_debug_launched", "lle_debug_reachable", "lle_debug_reset_launched",
 ]
 
 
@@ -238,8 +239,30 @@ def lib():
     L.lle_probe_read_rows.argtypes = [vp, vp, i64, vp]
     L.lle_tuning_refresh.restype = None
     L.lle_tuning_refresh.argtypes = []
+    for fn in (L.lle_debug_launched, L.lle_debug_reachable):
+        fn.restype = C.c_size_t
+        fn.argtypes = [C.c_char_p, C.c_size_t]
+    L.lle_debug_reset_launched.restype = None
+    L.lle_debug_reset_launched.argtypes = []
     _lib = L
     return L
+
+
+def _debug_names(fn):
+    need = fn(None, 0)
+    buf = C.create_string_buffer(need)
+    fn(buf, need)
+    return [n for n in buf.value.decode().split("\n") if n]
+
+
+def launched_kernels():
+    """Names of the kernel instantiations this process has launched so far (lle_debug_launched)."""
+    return _debug_names(lib().lle_debug_launched)
+
+
+def reachable_kernels():
+    """Names of every kernel instantiation the launchers' dispatch can reach (lle_debug_reachable)."""
+    return _debug_names(lib().lle_debug_reachable)
 
 
 def refresh_tuning():

@@ -1210,6 +1210,10 @@ int lle_probe_read_rows(const void* rows_dev, void* out_f16_dev, int64_t bytes, 
 
 void lle_tuning_refresh(void) { tuning_refresh(); }
 
+size_t lle_debug_launched(char* buf, size_t cap) { return debug_list(false, buf, cap); }
+size_t lle_debug_reachable(char* buf, size_t cap) { return debug_list(true, buf, cap); }
+void lle_debug_reset_launched(void) { debug_reset_launched(); }
+
 // One timed trial of the batch's plain single step (sampled actions + auto-reset) under `t`: us per launch by HIP events.
 static int time_step_trial(lle_batch* b, const StepTune& t, int launches, hipStream_t st, hipEvent_t e0, hipEvent_t e1, uint64_t* t_idx, double* us) {
     const StepTune keep = b->tune;

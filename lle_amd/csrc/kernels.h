@@ -61,6 +61,21 @@ struct StepTune {
     uint8_t epw = 0;            // environments per wavefront
 };
 
+// ---- debug registry: which kernel instantiations this process has LAUNCHED, and which ones the dispatch can reach (lle_debug_launched /
+// lle_debug_reachable, include/lle_hip.h).  A miscompile of ONE instantiation (round 4: a live-range split ahead of an exec restore in
+// step_kernel<4,4,4,false,-1>) is only found by a test that launches that instantiation: the coverage test demands every reachable one.
+// Cost on the launch path: one relaxed atomic load per launch (a static flag per instantiation).
+enum { DBG_STEP = 0, DBG_WORLD = 1, DBG_OBSERVER = 2 };
+enum { OBSK_VIEW = 0, OBSK_PARTIAL_WINDOW, OBSK_PARTIAL_PROJECT, OBSK_PARTIAL_LANES, OBSK_STATE, OBSK_AVAIL, OBSK_ENV_OUTPUTS, OBSK_ROW_FILL_WT,
+       OBSK_ROW_FILL_PLAIN, OBSK_CAST_ROWS, OBSK_STATS_SUM, OBSK_COUNT };
+constexpr uint32_t debug_key(int kind, int g, int lm, int mode, bool ml1, int lx) {
+    return ((uint32_t)kind << 24) | ((uint32_t)g << 16) | ((uint32_t)lm << 8) | ((uint32_t)mode << 4) | ((ml1 ? 1u : 0u) << 3) | (uint32_t)(lx + 1);
+}
+void debug_note(uint32_t key, bool reachable_walk);
+// newline-separated kernel names, sorted; returns the bytes needed (terminator included)
+size_t debug_list(bool reachable, char* buf, size_t cap);
+void debug_reset_launched();
+
 enum { KMODE_STEP = 0, KMODE_RESET = 1, KMODE_SET_STATE = 2, KMODE_OBSERVE = 3, KMODE_SOURCES = 4, KMODE_ENV_SOURCES = 5 };
 constexpr uint32_t MIN_ENVS_PER_WAVE = 4;  // step_kernel<16, .>: 4 environments per wavefront
 

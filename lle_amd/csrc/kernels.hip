@@ -20,6 +20,12 @@
 
 #include <string.h>
 
+#include <algorithm>
+#include <mutex>
+#include <set>
+#include <string>
+#include <vector>
+
 namespace lle {
 
 template <int AM, int LM, int MODE>
@@ -426,6 +432,15 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
 template <int AM, int LM>
 static hipError_t launch_mode(int mode, const BatchPtrs& P, const LaunchArgs& K, const MapHeader& H, uint32_t n_waves,
                               uint32_t waves_per_wg, uint32_t lds_bytes, hipStream_t stream) {
+    if (mode >= 0 && mode < 6) {  // (kernels.h debug registry)
+        static std::atomic<uint32_t> noted{0};
+        const uint32_t bit = 1u << (mode + ((K.flags & LAUNCH_DRY_RUN) ? 8 : 0));
+        if (!(noted.load(std::memory_order_relaxed) & bit)) {
+            noted.fetch_or(bit, std::memory_order_relaxed);
+            debug_note(debug_key(DBG_WORLD, AM, LM, mode, false, -1), (K.flags & LAUNCH_DRY_RUN) != 0);
+        }
+    }
+    if (K.flags & LAUNCH_DRY_RUN) return hipSuccess;
     dim3 grid((n_waves + waves_per_wg - 1) / waves_per_wg), block(64 * waves_per_wg);
     if (lds_bytes > 64 * 1024) {
         static LdsGrant granted[6];  // per mode, per device (kernels.h)
@@ -450,6 +465,90 @@ static hipError_t launch_mode(int mode, const BatchPtrs& P, const LaunchArgs& K,
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+
+// ---- debug registry (kernels.h): the instantiations launched by this process / reachable through the dispatch
+static std::mutex g_dbg_mutex;
+static std::set<uint32_t> g_dbg_launched, g_dbg_reachable;
+void debug_note(uint32_t key, bool reachable_walk) {
+    std::lock_guard<std::mutex> lock(g_dbg_mutex);
+    (reachable_walk ? g_dbg_reachable : g_dbg_launched).insert(key);
+}
+void debug_reset_launched() {
+    // (the per-instantiation `noted` flags stay set: a reset registry only sees instantiations launched for the FIRST time afterwards --
+    // the coverage test runs in a process of its own and never resets; the call exists for symmetry in long-lived tools)
+    std::lock_guard<std::mutex> lock(g_dbg_mutex);
+    g_dbg_launched.clear();
+}
+static const char* const OBS_KERNEL_NAMES[OBSK_COUNT] = {
+    "view_observe_kernel", "partial_observe_kernel", "partial_project_kernel", "partial_lanes_kernel", "state_observe_kernel", "avail_kernel",
+    "env_outputs_kernel", "row_fill_probe_kernel<true>", "row_fill_probe_kernel<false>", "cast_rows_kernel", "stats_sum_kernel"};
+static std::string debug_name(uint32_t key) {
+    const int kind = (int)(key >> 24), g = (int)(key >> 16) & 0xFF, lm = (int)(key >> 8) & 0xFF, mode = (int)(key >> 4) & 0xF, ml1 = (int)(key >> 3) & 1,
+              lx = (int)(key & 7u) - 1;
+    char buf[96];
+    if (kind == DBG_STEP) snprintf(buf, sizeof buf, "step_kernel<%d,%d,%d,%s,%d>", g, lm, mode, ml1 ? "true" : "false", lx);
+    else if (kind == DBG_WORLD) snprintf(buf, sizeof buf, "world_kernel<%d,%d,%d>", g, lm, mode);
+    else snprintf(buf, sizeof buf, "%s", mode * 16 + g < OBSK_COUNT ? OBS_KERNEL_NAMES[mode * 16 + g] : "?");
+    return buf;
+}
+// Every (agents, beam words, crossing or not, MODE) the launcher can be asked for, walked through the SAME dispatch code a launch takes
+// (LAUNCH_DRY_RUN: launch_step_glp / launch_mode note the instantiation and return): the list cannot drift from the dispatch.
+static void debug_walk_reachable() {
+    BatchPtrs P{};
+    for (int A = 1; A <= MAX_AGENTS; A++) {
+        for (int L = 0; L <= MAX_SOURCES; L++) {
+            const int G = step_group(A), lm = step_lm(L);
+            for (int ml1 = 0; ml1 < 2; ml1++) {
+                if (!ml1 && L < 2) continue;  // (a cell with two laser layers needs two sources)
+                LaunchArgs K{};
+                K.flags = LAUNCH_DRY_RUN | (ml1 ? LAUNCH_SINGLE_LAYER : 0u);
+                K.n_sources = (uint32_t)L;
+                (void)launch_step_mode0(G, lm, P, K, 1, 1, 0, nullptr);
+                (void)launch_step_mode1(G, lm, P, K, 1, 1, 0, nullptr);
+                (void)launch_step_mode2(G, lm, P, K, 1, 1, 0, nullptr);
+                (void)launch_step_mode3(G, lm, P, K, 1, 1, 0, nullptr);
+                (void)launch_step_mode4(G, lm, P, K, 1, 1, 0, nullptr);
+                (void)launch_step_mode5(G, lm, P, K, 1, 1, 0, nullptr);
+                if (lm <= 8) {  // (launch_step_kernel: row heads and the partial writer serve maps with at most 8 beam words)
+                    (void)launch_step_mode6(G, lm, P, K, 1, 1, 0, nullptr);
+                    (void)launch_step_mode7(G, lm, P, K, 1, 1, 0, nullptr);
+                    (void)launch_step_mode8(G, lm, P, K, 1, 1, 0, nullptr);
+                    (void)launch_step_mode9(G, lm, P, K, 1, 1, 0, nullptr);
+                }
+            }
+            MapHeader h{};
+            h.A = (uint32_t)A; h.L = (uint32_t)L; h.obs_stride = 16; h.lds_table_bytes = 1024;
+            for (int mode = 0; mode < 6; mode++) {
+                LaunchArgs K{};
+                K.flags = LAUNCH_DRY_RUN;
+                K.envs_per_wave = 4; K.env_limit = 4;
+                (void)launch_world_kernel(mode, h, P, K, nullptr);
+            }
+        }
+    }
+    for (int k = 0; k < OBSK_COUNT; k++) debug_note(debug_key(DBG_OBSERVER, k & 15, 0, k >> 4, false, -1), true);
+}
+size_t debug_list(bool reachable, char* buf, size_t cap) {
+    if (reachable) {
+        bool empty;
+        { std::lock_guard<std::mutex> lock(g_dbg_mutex); empty = g_dbg_reachable.empty(); }
+        if (empty) debug_walk_reachable();
+    }
+    std::vector<std::string> names;
+    {
+        std::lock_guard<std::mutex> lock(g_dbg_mutex);
+        for (uint32_t key : (reachable ? g_dbg_reachable : g_dbg_launched)) names.push_back(debug_name(key));
+    }
+    std::sort(names.begin(), names.end());
+    std::string all;
+    for (const std::string& n : names) { all += n; all += '\n'; }
+    if (buf && cap) {
+        const size_t n = std::min(cap - 1, all.size());
+        memcpy(buf, all.data(), n);
+        buf[n] = 0;
+    }
+    return all.size() + 1;
 }
 
 // ---- the environment overrides, read once (kernels.h Tuning)

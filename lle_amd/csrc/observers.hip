@@ -19,6 +19,16 @@
 #include "observers_logic.hpp"
 #include "tables.h"
 
+// (kernels.h debug registry: one relaxed load per launch)
+#define LLE_NOTE_OBS(ID)                                                                                 \
+    do {                                                                                                 \
+        static std::atomic<bool> noted_{false};                                                          \
+        if (!noted_.load(std::memory_order_relaxed)) {                                                   \
+            noted_.store(true, std::memory_order_relaxed);                                               \
+            lle::debug_note(lle::debug_key(lle::DBG_OBSERVER, (ID) & 15, 0, (ID) >> 4, false, -1), false); \
+        }                                                                                                \
+    } while (0)
+
 namespace lle {
 
 constexpr uint32_t OBS_ENVS_PER_WAVE = 16;
@@ -735,6 +745,7 @@ __global__ void __launch_bounds__(256) cast_rows_kernel(const int8_t* __restrict
     }
 }
 hipError_t launch_cast_rows(const int8_t* rows, void* out_f16, int64_t bytes, hipStream_t stream) {
+    LLE_NOTE_OBS(OBSK_CAST_ROWS);
     hipLaunchKernelGGL(cast_rows_kernel, dim3(256 * 8), dim3(256), 0, stream, rows, static_cast<_Float16*>(out_f16), bytes / 16);
     return hipGetLastError();
 }
@@ -770,14 +781,18 @@ hipError_t launch_row_fill_probe(int8_t* out, int64_t n_rows, uint32_t row_bytes
     const uint32_t n_chunks = row_bytes / 16u, wpw = 4;
     const int64_t n_waves = (n_rows + rows_per_wave - 1) / rows_per_wave;
     const dim3 grid((uint32_t)((n_waves + wpw - 1) / wpw)), block(64 * wpw);
-    if (write_through_pays((uint64_t)n_rows * row_bytes, row_bytes))
+    if (write_through_pays((uint64_t)n_rows * row_bytes, row_bytes)) {
+        LLE_NOTE_OBS(OBSK_ROW_FILL_WT);
         hipLaunchKernelGGL(row_fill_probe_kernel<true>, grid, block, 0, stream, out, n_rows, n_chunks, rows_per_wave, value, flags);
-    else
+    } else {
+        LLE_NOTE_OBS(OBSK_ROW_FILL_PLAIN);
         hipLaunchKernelGGL(row_fill_probe_kernel<false>, grid, block, 0, stream, out, n_rows, n_chunks, rows_per_wave, value, flags);
+    }
     return hipGetLastError();
 }
 
 hipError_t launch_stats_sum(const int64_t* stats, int64_t n_blocks, int64_t* out8, hipStream_t stream) {
+    LLE_NOTE_OBS(OBSK_STATS_SUM);
     hipLaunchKernelGGL(stats_sum_kernel, dim3(1), dim3(1024), 0, stream, stats, n_blocks, out8);
     return hipGetLastError();
 }
@@ -810,6 +825,7 @@ hipError_t launch_view_observe(const ViewHeader& v, const BatchPtrs& P, const ui
     hipError_t e = granted.ensure(reinterpret_cast<const void*>(&view_observe_kernel), lds);
     if (e != hipSuccess) return e;
     const uint32_t n_waves = (uint32_t)((n_envs + OBS_ENVS_PER_WAVE - 1) / OBS_ENVS_PER_WAVE);
+    LLE_NOTE_OBS(OBSK_VIEW);
     hipLaunchKernelGGL(view_observe_kernel, dim3((n_waves + wpw - 1) / wpw), dim3(64 * wpw), lds, stream, P, views_dev, n_views, out,
                        row_pitch, view_pitch, (int64_t)0, n_envs, pes ? 1 : 0, M, views_stride,
                        write_through_pays((uint64_t)n_envs * (uint64_t)(n_views > 1 ? view_pitch * n_views : row_pitch), (uint32_t)v.obs_stride) ? 1 : 0,
@@ -888,6 +904,7 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
                 int wt = 1;
                 if (tuning().partial_wt >= 0) wt = tuning().partial_wt;
                 const PartialDims D{(int32_t)h.A, (int32_t)h.L, (int32_t)h.H, (int32_t)h.W, h.off_cell_meta - h.off_cell_lay, h.max_layers};
+                LLE_NOTE_OBS(OBSK_PARTIAL_LANES);
                 hipLaunchKernelGGL(partial_lanes_kernel, dim3((n_waves + wpw - 1) / wpw), dim3(64 * wpw), lds, stream, P, out, k, pitch_l,
                                    (int64_t)0, n_envs, per_env_sources ? 1 : 0, M, E, batches, tab, wt, D, h.off_cell_lay, walk);
                 return hipGetLastError();
@@ -915,6 +932,7 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
         hipError_t e = granted_p.ensure(reinterpret_cast<const void*>(&partial_project_kernel), lds);
         if (e != hipSuccess) return e;
         const uint32_t n_waves = (uint32_t)((n_envs + epw - 1) / epw);
+        LLE_NOTE_OBS(OBSK_PARTIAL_PROJECT);
         hipLaunchKernelGGL(partial_project_kernel, dim3((n_waves + wpw - 1) / wpw), dim3(64 * wpw), lds, stream, P, out, k, pitch,
                            (int64_t)0, n_envs, per_env_sources ? 1 : 0, M, epw, ent_cap, walk);
         return hipGetLastError();
@@ -936,6 +954,7 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
     hipError_t e = granted.ensure(reinterpret_cast<const void*>(&partial_observe_kernel), lds);
     if (e != hipSuccess) return e;
     const uint32_t n_waves = (uint32_t)((n_envs + epw - 1) / epw);
+    LLE_NOTE_OBS(OBSK_PARTIAL_WINDOW);
     hipLaunchKernelGGL(partial_observe_kernel, dim3((n_waves + wpw - 1) / wpw), dim3(64 * wpw), lds, stream, P, out, k, pitch,
                        (int64_t)0, n_envs, per_env_sources ? 1 : 0, M, epw, walk);
     return hipGetLastError();
@@ -944,6 +963,7 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
 hipError_t launch_state_observe(const MapHeader& h, const BatchPtrs& P, float* out, int normalize, int64_t n_envs, hipStream_t stream) {
     const int64_t total = n_envs * (int64_t)(3 * h.A + h.G);
     if (total == 0) return hipSuccess;
+    LLE_NOTE_OBS(OBSK_STATE);
     hipLaunchKernelGGL(state_observe_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, P, out, normalize, n_envs);
     return hipGetLastError();
 }
@@ -951,6 +971,7 @@ hipError_t launch_state_observe(const MapHeader& h, const BatchPtrs& P, float* o
 hipError_t launch_env_outputs(const MapHeader& h, const BatchPtrs& P, const EnvOutputs& O, int64_t n_envs, MapSel M, hipStream_t stream) {
     const int64_t total = n_envs * (int64_t)h.A;
     if (total == 0) return hipSuccess;
+    LLE_NOTE_OBS(OBSK_ENV_OUTPUTS);
     hipLaunchKernelGGL(env_outputs_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, P, O, n_envs, M);
     return hipGetLastError();
 }
@@ -959,6 +980,7 @@ hipError_t launch_avail(const MapHeader& h, const BatchPtrs& P, uint8_t* out, in
                         MapSel M, hipStream_t stream) {
     const int64_t total = n_envs * (int64_t)h.A;
     if (total == 0) return hipSuccess;
+    LLE_NOTE_OBS(OBSK_AVAIL);
     hipLaunchKernelGGL(avail_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, P, out, walkable_lasers, n_envs,
                        per_env_sources ? 1 : 0, M);
     return hipGetLastError();

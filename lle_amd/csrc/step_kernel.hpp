@@ -783,6 +783,15 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
 // sources and no crossing beams -- the exact source count LX
 template <int G, int LM, int MODE, bool ML1, int LX = -1>
 static hipError_t launch_step_glp(const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
+    // which instantiations this process has launched (kernels.h debug registry: the coverage test of tests/test_gpu_instantiations.py);
+    // LAUNCH_DRY_RUN: the walk of lle_debug_reachable through this very dispatch -- note the instantiation, launch nothing
+    static std::atomic<uint32_t> noted{0};
+    const uint32_t note_bit = (K.flags & LAUNCH_DRY_RUN) ? 2u : 1u;
+    if (!(noted.load(std::memory_order_relaxed) & note_bit)) {
+        noted.fetch_or(note_bit, std::memory_order_relaxed);
+        debug_note(debug_key(DBG_STEP, G, LM, MODE, ML1, LX), (K.flags & LAUNCH_DRY_RUN) != 0);
+    }
+    if (K.flags & LAUNCH_DRY_RUN) return hipSuccess;
     dim3 grid((n_waves + wpw - 1) / wpw), block(64 * wpw);
     if (lds > 64 * 1024) {  // gfx950 has 160 KiB of LDS per CU; more than 64 KiB per workgroup is opt-in, per device (kernels.h)
         static LdsGrant granted;
@@ -796,14 +805,18 @@ template <int MODE, int G, int LM>
 static hipError_t launch_step_mode_gl(const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {
     const bool ml1 = (K.flags & LAUNCH_SINGLE_LAYER) != 0;
     if constexpr (LM == 4) {
+        // (LM == 4 means at most four beam words, so a single-layer map always takes one of the exact-count instantiations: the generic
+        // <G, 4, MODE, true, -1> was compiled until round 4 -- 50 kernels -- and no launch could reach it)
         if (ml1) {
 #define LLE_STEP_LX(X) case X: return launch_step_glp<G, 4, MODE, true, X>(P, K, n_waves, wpw, lds, stream);
-            switch (K.n_sources) { LLE_STEP_LX(0) LLE_STEP_LX(1) LLE_STEP_LX(2) LLE_STEP_LX(3) LLE_STEP_LX(4) default: break; }
+            switch (K.n_sources) { LLE_STEP_LX(0) LLE_STEP_LX(1) LLE_STEP_LX(2) LLE_STEP_LX(3) LLE_STEP_LX(4) default: return hipErrorInvalidValue; }
 #undef LLE_STEP_LX
         }
+        return launch_step_glp<G, 4, MODE, false>(P, K, n_waves, wpw, lds, stream);
+    } else {
+        return ml1 ? launch_step_glp<G, LM, MODE, true>(P, K, n_waves, wpw, lds, stream)
+                   : launch_step_glp<G, LM, MODE, false>(P, K, n_waves, wpw, lds, stream);
     }
-    return ml1 ? launch_step_glp<G, LM, MODE, true>(P, K, n_waves, wpw, lds, stream)
-               : launch_step_glp<G, LM, MODE, false>(P, K, n_waves, wpw, lds, stream);
 }
 template <int MODE, int G>
 static hipError_t launch_step_mode_g(int lm, const BatchPtrs& P, const LaunchArgs& K, uint32_t n_waves, uint32_t wpw, uint32_t lds, hipStream_t stream) {

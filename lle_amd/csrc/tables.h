@@ -178,6 +178,7 @@ constexpr uint32_t LAUNCH_HEAD_GROUP4 = 0x10000000;    //   (4: the first wavefr
 constexpr uint32_t LAUNCH_POST_FIRST = 0x20000000;     // internal: every wavefront writes its small outputs BEFORE its observation stream (step_kernel.hpp post_first), ...
 constexpr uint32_t LAUNCH_POST_LAST = 0x40000000;      //   ... or every one after it (default: the last quarter of the grid before, the rest after)
 constexpr uint32_t LAUNCH_ROTATE_ROWS = 0x4000000;     // internal: every wavefront starts its rows at another one of them (obs_stream.hpp row_rotation)
+constexpr uint32_t LAUNCH_DRY_RUN = 0x80000000u;      // internal, host side only: walk the dispatch, note the instantiation, launch nothing (kernels.h debug registry)
 constexpr uint32_t LAUNCH_WRITE_THROUGH = 0x400000;    // internal: observation rows are stored `sc1` (stream_store, obs_stream.hpp)
 // A launch writes its rows through L2 while all of them fit the Infinity Cache (256 MB, MI355X_MICROARCH.md); beyond
 // that plain write-back stores are faster (measured break-even between 245 MB and 490 MB per launch).

@@ -393,3 +393,25 @@ def test_laser_tokens():
     srcs = m.sources()
     assert [(s.laser_id, s.agent_id, s.direction) for s in srcs] == [(0, 0, 1), (1, 1, 3), (2, 2, 0), (3, 3, 2)]   # N=0 E=1 S=2 W=3
     assert [(s.i, s.j) for s in srcs] == [(0, 0), (1, 3), (3, 1), (4, 0)]
+
+
+def test_every_compiled_kernel_is_reachable_and_every_reachable_one_is_compiled():
+    """lle_debug_reachable walks the launchers' own dispatch (launches suppressed) over every agent count, beam-word count, crossing
+    or not, and mode; tools/compiled_kernels.py reads the kernel descriptors out of the library's gfx950 code objects.  The two lists
+    must be the same: a compiled kernel that no launch can reach is a kernel no test can check (round 4 shipped 50 of them:
+    step_kernel<G,4,MODE,true,-1>), and tests/test_gpu_instantiations.py then launches every one of them against the oracle."""
+    import importlib.util
+
+    from lle_amd import _capi
+    spec = importlib.util.spec_from_file_location("compiled_kernels", os.path.join(ROOT, "tools", "compiled_kernels.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    compiled, reachable = set(mod.compiled_kernels()), set(_capi.reachable_kernels())
+    assert compiled == reachable, (sorted(compiled - reachable)[:8], sorted(reachable - compiled)[:8])
+    assert len(compiled) == 555 and sum(n.startswith("step_kernel<") for n in compiled) == 520
+    assert _capi.launched_kernels() == [] or set(_capi.launched_kernels()) <= reachable  # (nothing launches without a GPU)
+    from tests import instantiation_maps as im
+    # the coverage test's cases name exactly the step-kernel instantiations
+    names = {im.kernel_name(A, L, cross, mode) for (A, _g) in im.AGENT_CLASSES for (L, cross) in im.SOURCE_CLASSES for mode in range(10)
+             if mode < 6 or im.lm_of(L) <= 8}
+    assert names == {n for n in reachable if n.startswith("step_kernel<")}

@@ -43,6 +43,44 @@ def scan(text):
     return hits
 
 
+def kernel_names(hits):
+    """Demangled, in the spelling of lle_debug_launched: 'step_kernel<2,4,1,true,0>'."""
+    dem = subprocess.run(["c++filt"], input="\n".join(h[0] or "?" for h in hits), capture_output=True, text=True).stdout.split("\n")
+    return [re.sub(r"^void ", "", d.split("(")[0]).replace("lle::", "").replace(", ", ",") for d in dem[:len(hits)]]
+
+
+def classify(text, hit):
+    """The SHAPE of a hit, for the allowlist of tests/test_isa_scan.py (tests/golden/isa_exec_copy_allowlist.json):
+      exec_zero_only       the block is entered only by `s_cbranch_scc1` behind `s_cmp_eq_u64 exec, 0` (never by falling through): the copy
+                           runs with no lane active and writes nothing;
+      uniform_under_saved_mask  the block saves its mask (`s_mov_b64 s[a:b], exec`) and every copy broadcasts a SCALAR register: wave-uniform values
+                           handed to the lanes of the region, whose consumer runs under that saved mask again;
+      region_assign_b32    ONE 32-bit VGPR-to-VGPR copy: a source-level assignment inside the divergent region (the argument is per kernel);
+      other                anything else -- the round-4 miscompile was a 64-bit VGPR pair (a pointer) copied this way."""
+    kernel, label, copies, _restore = hit
+    lines = text.split("\n")
+    start = next(i for i, l in enumerate(lines) if l.startswith(kernel + ":"))
+    end = next((i for i in range(start + 1, len(lines)) if re.match(r"^_Z\w+:", lines[i])), len(lines))
+    body = lines[start:end]
+    at = next(i for i, l in enumerate(body) if l.startswith(label + ":"))
+    refs = [i for i, l in enumerate(body) if re.search(r"\s" + re.escape(label) + r"\s*$", l) and not l.startswith(label)]
+    prev = next((body[i].strip() for i in range(at - 1, -1, -1) if body[i].strip() and not body[i].lstrip().startswith(";")), "")
+    falls_through = not prev.startswith(("s_branch", "s_endpgm", "s_setpc"))
+    if refs and not falls_through and all(body[i].strip().startswith("s_cbranch_scc1") and
+                                          any("s_cmp_eq_u64 exec, 0" in body[j] for j in range(max(0, i - 4), i)) for i in refs):
+        return "exec_zero_only"
+    block = []
+    for i in range(at + 1, len(body)):
+        if RESTORE.match(body[i]):
+            break
+        block.append(body[i].strip())
+    if any(re.match(r"s_mov_b64 s\[\d+:\d+\], exec$", b) for b in block) and all(re.search(r",\s*s(\d+|\[\d+:\d+\])$", c) for c in copies):
+        return "uniform_under_saved_mask"
+    if len(copies) == 1 and re.match(r"v_mov_b32_e32 v\d+, v\d+$", copies[0]):
+        return "region_assign_b32"
+    return "other"
+
+
 def main():
     files = sys.argv[1:] or sorted(f for f in os.listdir(SRC) if f.endswith(".hip"))
     bad = 0
