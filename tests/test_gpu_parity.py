@@ -662,7 +662,9 @@ def test_autotune_many_agents_keeps_the_counter_slots(oracle_mod):
             g.fill_(0x5A)
         tuned = bw.autotune(budget_ms=8.0)
         assert tuned["envs_per_wave"] >= 4, tuned
-        assert " 2=" not in tuned["log"].split("envs_per_wave:")[1].split("->")[0] and " 1=" not in tuned["log"].split("envs_per_wave:")[1].split("->")[0], tuned["log"]
+        if "envs_per_wave:" in tuned["log"]:  # (16 lanes per environment: four environments per wavefront is the only choice, nothing is swept)
+            swept = tuned["log"].split("envs_per_wave:")[1].split("->")[0]
+            assert " 2=" not in swept and " 1=" not in swept, tuned["log"]
         torch.cuda.synchronize()
         for g in guard:
             assert bool((g == 0x5A).all() if g.dtype == torch.uint8 else (g.view(torch.uint8) == 0x5A).all()), "a trial launch wrote past LLE_BUF_STATS"
