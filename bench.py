@@ -528,7 +528,8 @@ def measure_consumer_loop(torch, timer, dev, steps):
     Per workload: step alone, reader alone, the pair -- with the alternating walk on and off where the rows exceed the cache.
     The walk's default (capi.cpp pingpong_pays) is read off the `pair_us` columns of this block."""
     from lle_amd import BatchedWorld, Map, _capi, mapgen
-    out = {"what": "us per launch (HIP events): World.step alone, an int8->fp16 cast of the whole observation alone, and step + cast alternating on one stream",
+    out = {"what": "us per launch (HIP events): World.step alone, an int8->fp16 cast of the whole observation alone, step + cast alternating on one stream; "
+                   "step_fp16_us / step_fp32_us: the step of a batch created with obs_dtype = fp16 / fp32 (rows widened at the store: no cast pass)",
            "steps": steps}
     for label, m, n in (("level6_65536", Map(level=LEVEL), 65536), ("level6_262144", Map(level=LEVEL), 262144),
                         ("cfg5_65536", Map(mapgen.config5(0)), 65536)):
@@ -562,8 +563,26 @@ def measure_consumer_loop(torch, timer, dev, steps):
             os.environ.pop("LLE_PINGPONG", None)
             _capi.refresh_tuning()
             blk["walk_that_wins_the_pair"] = "on" if blk["walk_on"]["pair_us"] <= blk["walk_off"]["pair_us"] else "off"
+        # the same step with the rows leaving the kernel in the learner's type (lle_batch_options.obs_dtype: the kernels widen at the store):
+        # what replaces the step + cast pair above.  Bytes = what the launch writes (rows x element size + the small outputs).
+        del half
+        for dt_name, dt in (("fp16", torch.float16), ("fp32", torch.float32)):
+            if rows.numel() * dt.itemsize > 6 << 30:
+                continue
+            wide = BatchedWorld(m, n, device=dev, obs_dtype=dt)
+            wstep = stepper(wide)
+            for _ in range(8):
+                wstep()
+            _, w_ms = timer.run(wstep, k)
+            wbytes = rows.numel() * dt.itemsize + n * (ALGO_BYTES_PER_ENV_STEP - 1872 if label.startswith("level6") else 137)
+            blk[f"step_{dt_name}_us"] = w_ms * 1e3
+            blk[f"step_{dt_name}"] = {"us": w_ms * 1e3, "rows_MB": rows.numel() * dt.itemsize / 1e6, "written_GBps": wbytes / (w_ms * 1e-3) / 1e9,
+                                      "frac_of_hbm_peak": wbytes / (w_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "vs_int8_step_plus_cast_us": blk[("walk_on" if big else "walk_default")]["pair_us"] if dt_name == "fp16" else None}
+            del wide, wstep
+            torch.cuda.empty_cache()
         out[label] = blk
-        del bw, rows, half
+        del bw, rows
         torch.cuda.empty_cache()
     # the fused rollout into a two-slot ring with the reader trailing one slot (a double buffer: slot t is cast while t + 1 is written)
     bw = BatchedWorld(Map(level=LEVEL), 65536, device=dev)

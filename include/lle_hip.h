@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define LLE_ABI_VERSION 2  /* 2: beam words (lle_map_info.n_beam_words, lle_laser_tile.word / bit), lle_batch_autotune */
+#define LLE_ABI_VERSION 3  /* 2: beam words (lle_map_info.n_beam_words, lle_laser_tile.word / bit), lle_batch_autotune
+                            * 3: lle_batch_create_opt (observation rows in fp16 / bf16 / fp32), lle_debug_launched / _reachable */
 
 /* static limits of this implementation (maps beyond them are rejected at parse/compile time) */
 #define LLE_MAX_AGENTS 16
@@ -201,7 +202,8 @@ enum {
     LLE_BUF_EVCOUNT,   /* u8  [n]         number of events of the last step (bit 7: env was auto-reset first) */
     LLE_BUF_EVENTS,    /* u8  [n][2A]     entry = type << 4 | agent, in the reference's order */
     LLE_BUF_DONE,      /* u8  [n]         1 if any agent is dead or all have arrived (LLE.compute_done, env.py:253-254) */
-    LLE_BUF_OBS,       /* i8  [n][obs_stride]  first C*H*W bytes = layered observation (C,H,W) */
+    LLE_BUF_OBS,       /* i8  [n][obs_stride]  first C*H*W elements = layered observation (C,H,W); f16 / bf16 / f32 elements in a batch
+                          created with lle_batch_options.obs_dtype (read elem_bytes from the descriptor) */
     LLE_BUF_STATS,     /* i64 [n_blocks][8] per-block partial counters (see lle_batch_stats) */
     LLE_BUF_REQ_POS,   /* u8  [n][A][2]   set_state request */
     LLE_BUF_REQ_GEMS,  /* u32 [n] */
@@ -291,7 +293,7 @@ typedef struct lle_rollout_ring {
     int32_t ring_slots;   /* R >= 1 */
     int32_t pad;
     uint64_t ring_pos;    /* slot of the first step */
-    int8_t* obs;          /* [R][n_envs][obs_stride] */
+    int8_t* obs;          /* [R][n_envs][obs_stride] elements of the batch's observation type (int8 unless lle_batch_options.obs_dtype says otherwise) */
     uint8_t* actions;     /* [R][n_envs][agent pitch] (pitch: lle_buffer_desc.stride[0] of LLE_BUF_ACTIONS); output with
                              LLE_STEP_SAMPLE_ACTIONS, input without */
     uint32_t* reward;     /* [R][n_envs]  gems | exits << 8 | deaths << 16 | all_arrived << 24 */
@@ -355,6 +357,27 @@ int64_t lle_batch_arena_bytes_multi(const lle_map* const* maps, int n_maps, int6
 lle_batch* lle_batch_create_multi(const lle_map* const* maps, int n_maps, int64_t envs_per_map, int device_id, void* arena,
                                   int64_t arena_bytes, void* stream);
 int lle_batch_n_maps(const lle_batch* b);
+
+/* ---- batch options: the element type of the layered observation.
+ * The reference's Layered.observe returns FLOAT32 (python/lle/observations.py:223: np.zeros(..., dtype=np.float32), values -1 / 0 / 1),
+ * and a learner's first layer usually wants fp16 / bf16.  A caller of an int8 batch pays a second pass over the tensor for the cast (bench.py
+ * consumer_loop: step 19.9 us, int8 -> fp16 cast 85.9 us at level 6 x 65 536).  With obs_dtype set, every kernel that writes LLE_BUF_OBS -- the step
+ * kernel, reset, observe, the source / exit updates -- and the fused rollout's observation ring WIDEN AT THE STORE: the row is built as int8 in
+ * LDS as before and leaves the chip in the caller's type, once.  LLE_BUF_OBS then holds [n][obs_stride] ELEMENTS of that type
+ * (lle_buffer_desc.elem_bytes = 1 / 2 / 2 / 4; stride and shape in elements, unchanged), lle_rollout_ring.obs likewise
+ * [R][n][obs_stride] elements.  Content: exactly the int8 tensor, cast (tests/test_gpu_obs_dtype.py).  The other observation builders
+ * (lle_batch_observe_as, the partial observation of lle_batch_step_outputs) keep the element types of lle_obs_desc.
+ * `opt` == NULL or obs_dtype == LLE_DTYPE_I8: what lle_batch_create / lle_batch_create_multi give.  n_maps == 1: one map (any envs_per_map). */
+enum { LLE_DTYPE_I8 = 0, LLE_DTYPE_F16 = 1, LLE_DTYPE_BF16 = 2, LLE_DTYPE_F32 = 3 };
+typedef struct lle_batch_options {
+    uint32_t struct_bytes;   /* sizeof(lle_batch_options): lets the struct grow */
+    int32_t obs_dtype;       /* LLE_DTYPE_* of LLE_BUF_OBS and of the observation rings */
+    int32_t reserved[6];     /* zero */
+} lle_batch_options;
+int64_t lle_batch_arena_bytes_opt(const lle_map* const* maps, int n_maps, int64_t envs_per_map, const lle_batch_options* opt);
+lle_batch* lle_batch_create_opt(const lle_map* const* maps, int n_maps, int64_t envs_per_map, int device_id, void* arena, int64_t arena_bytes,
+                                const lle_batch_options* opt, void* stream);
+int lle_batch_obs_dtype(const lle_batch* b);  /* LLE_DTYPE_* of the batch */
 
 /* ---- the other observation builders of python/lle/observations.py, from the same device state -------------------
  * kind / param                      reference generator (file:line)                       element, logical shape per env

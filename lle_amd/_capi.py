@@ -47,7 +47,21 @@ EXPORTS = [
     "lle_batch_stats", "lle_batch_kernel_info", "lle_batch_set_envs_per_wave", "lle_batch_step_stamped", "lle_batch_probe_row_fill",
     "lle_batch_autotune", "lle_batch_tuning", "lle_tuning_refresh", "lle_probe_read_rows", "lle_probe_fill_rows",
     "lle_debug_launched", "lle_debug_reachable", "lle_debug_reset_launched",
+    "lle_batch_arena_bytes_opt", "lle_batch_create_opt", "lle_batch_obs_dtype",
 ]
+
+
+LLE_DTYPE_I8, LLE_DTYPE_F16, LLE_DTYPE_BF16, LLE_DTYPE_F32 = 0, 1, 2, 3
+
+
+class BatchOptions(C.Structure):
+    """lle_batch_options (include/lle_hip.h)."""
+    _fields_ = [("struct_bytes", C.c_uint32), ("obs_dtype", C.c_int32), ("reserved", C.c_int32 * 6)]
+
+    def __init__(self, obs_dtype=0):
+        super().__init__()
+        self.struct_bytes = C.sizeof(BatchOptions)
+        self.obs_dtype = int(obs_dtype)
 
 
 class MapInfo(C.Structure):
@@ -163,6 +177,12 @@ def lib():
     L.lle_batch_create_multi.argtypes = [C.POINTER(vp), i32, i64, i32, vp, i64, vp]
     L.lle_batch_n_maps.restype = i32
     L.lle_batch_n_maps.argtypes = [vp]
+    L.lle_batch_arena_bytes_opt.restype = i64
+    L.lle_batch_arena_bytes_opt.argtypes = [C.POINTER(vp), i32, i64, C.POINTER(BatchOptions)]
+    L.lle_batch_create_opt.restype = vp
+    L.lle_batch_create_opt.argtypes = [C.POINTER(vp), i32, i64, i32, vp, i64, C.POINTER(BatchOptions), vp]
+    L.lle_batch_obs_dtype.restype = i32
+    L.lle_batch_obs_dtype.argtypes = [vp]
     L.lle_batch_free.argtypes = [vp]
     L.lle_batch_get_buffer.restype = i32
     L.lle_batch_get_buffer.argtypes = [vp, i32, C.POINTER(BufferDesc)]

@@ -23,6 +23,12 @@ _TORCH_DTYPES = {
 # The raw handle of torch's CURRENT stream on a device: the bound calls below read it on every call (an integer from the C
 # extension, ~0.1 us) instead of freezing the stream that was current when they were bound -- a caller that enters another
 # `torch.cuda.stream(...)` later gets its launches there, ordered with its own tensors.
+# obs_dtype of BatchedWorld -> (LLE_DTYPE_*, torch dtype); strings for hosts that do not hold a torch dtype
+_OBS_DTYPES = {None: (_capi.LLE_DTYPE_I8, torch.int8), torch.int8: (_capi.LLE_DTYPE_I8, torch.int8), torch.float16: (_capi.LLE_DTYPE_F16, torch.float16),
+               torch.bfloat16: (_capi.LLE_DTYPE_BF16, torch.bfloat16), torch.float32: (_capi.LLE_DTYPE_F32, torch.float32)}
+_OBS_DTYPES.update({"int8": _OBS_DTYPES[torch.int8], "float16": _OBS_DTYPES[torch.float16], "bfloat16": _OBS_DTYPES[torch.bfloat16],
+                    "float32": _OBS_DTYPES[torch.float32]})
+
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
@@ -47,7 +53,7 @@ class BatchedWorld:
       err [n] u8 - evcount [n] u8 - events [n,2A] u8 (type<<4|agent) - done [n] u8 - obs [n,C,H,W] i8
     """
 
-    def __init__(self, map_or_text, n_envs, device=None, envs_per_wave=None, row_align=None, placement_candidates=None):
+    def __init__(self, map_or_text, n_envs, device=None, envs_per_wave=None, row_align=None, placement_candidates=None, obs_dtype=None):
         """`map_or_text`: a Map / map text, or a LIST of them for a batch of several maps -- map m then owns the envs
         [m * n_envs / len(maps), (m + 1) * n_envs / len(maps)); the maps must agree on height, width and the numbers of
         agents, sources and gems, and each must own a multiple of 16 envs (64 and more keep full workgroups).
@@ -55,7 +61,10 @@ class BatchedWorld:
         `placement_candidates`: k > 1 allocates k arenas, times the step kernel's store pattern on each
         (lle_batch_probe_row_fill) and keeps the fastest; the others are released (torch.cuda.empty_cache()).  Worth it only
         when the rows of a step exceed the 256 MB Infinity Cache: there the write rate depends on where the allocation landed
-        (profiles/r03_hbm_fronts.md: 5.8 ... 6.8 TB/s over twelve buffers of one process).  `self.placement` records the timings."""
+        (profiles/r03_hbm_fronts.md: 5.8 ... 6.8 TB/s over twelve buffers of one process).  `self.placement` records the timings.
+        `obs_dtype`: element type of `obs` and of the observation rings -- torch.int8 (default), torch.float16, torch.bfloat16 or
+        torch.float32 (the reference's, python/lle/observations.py:223).  The kernels widen at the store (lle_batch_options.obs_dtype):
+        the tensor a learner reads comes out of the step launch in its own type, with the values of the int8 tensor."""
         _require_gpu()
         many = isinstance(map_or_text, (list, tuple))
         self.maps = [m if isinstance(m, Map) else Map(m) for m in (map_or_text if many else [map_or_text])]
@@ -68,26 +77,21 @@ class BatchedWorld:
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = torch.device(device)
         self.n_envs = int(n_envs)
+        self.obs_dtype = _OBS_DTYPES[obs_dtype][1]
+        opt = _capi.BatchOptions(_OBS_DTYPES[obs_dtype][0])
         L = _capi.lib()
-        if many:
-            if self.n_envs % len(self.maps) != 0:
-                raise ValueError("n_envs must be a multiple of the number of maps")
-            self.envs_per_map = self.n_envs // len(self.maps)
-            handles = (C.c_void_p * len(self.maps))(*[m.h for m in self.maps])
-            nbytes = L.lle_batch_arena_bytes_multi(handles, len(self.maps), self.envs_per_map)
-        else:
-            self.envs_per_map = self.n_envs
-            nbytes = L.lle_batch_arena_bytes(self.map.h, self.n_envs)
+        if many and self.n_envs % len(self.maps) != 0:
+            raise ValueError("n_envs must be a multiple of the number of maps")
+        self.envs_per_map = self.n_envs // len(self.maps)
+        handles = (C.c_void_p * len(self.maps))(*[m.h for m in self.maps])
+        nbytes = L.lle_batch_arena_bytes_opt(handles, len(self.maps), self.envs_per_map, C.byref(opt))
         if nbytes <= 0:
             raise RuntimeError(L.lle_last_error().decode())
         def create():
             arena = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
             base = arena[(-arena.data_ptr()) % 256:][:nbytes]
-            if many:
-                h = L.lle_batch_create_multi(handles, len(self.maps), self.envs_per_map, self.device.index or 0, base.data_ptr(), nbytes,
-                                             self._stream())
-            else:
-                h = L.lle_batch_create(self.map.h, self.n_envs, self.device.index or 0, base.data_ptr(), nbytes, self._stream())
+            h = L.lle_batch_create_opt(handles, len(self.maps), self.envs_per_map, self.device.index or 0, base.data_ptr(), nbytes, C.byref(opt),
+                                       self._stream())
             if not h:
                 raise RuntimeError(f"lle_batch_create failed: {L.lle_last_error().decode()}")
             return arena, base, h
@@ -165,7 +169,8 @@ class BatchedWorld:
                                 [int(d.stride[k]) for k in range(d.ndim)])
             raw = self._base[d.arena_offset:d.arena_offset + d.bytes]
             if name == "obs":
-                t = raw.view(torch.int8)[: self.n_envs * m.obs_stride].view(self.n_envs, m.obs_stride)
+                assert int(d.elem_bytes) == self.obs_dtype.itemsize
+                t = raw.view(self.obs_dtype)[: self.n_envs * m.obs_stride].view(self.n_envs, m.obs_stride)
                 self.obs_rows = t
                 t = t[:, : m.obs_bytes].unflatten(1, (m.n_layers, m.height, m.width))
             else:
@@ -284,11 +289,11 @@ class BatchedWorld:
         pitch = self._desc["actions"][4][0]
         shape = (int(slots), self.n_envs, m.obs_stride)
         k = int(placement_candidates or 1)
-        if k > 1 and shape[0] * shape[1] * shape[2] > placement.INFINITY_CACHE_BYTES:
-            rows, placed = placement.pick_fastest(lambda: torch.zeros(shape, dtype=torch.int8, device=self.device), m.obs_stride, k,
+        if k > 1 and shape[0] * shape[1] * shape[2] * self.obs_dtype.itemsize > placement.INFINITY_CACHE_BYTES:
+            rows, placed = placement.pick_fastest(lambda: torch.zeros(shape, dtype=self.obs_dtype, device=self.device), m.obs_stride * self.obs_dtype.itemsize, k,
                                                   rows_per_wave=self.kernel_info()["envs_per_wave"])
         else:
-            rows, placed = torch.zeros(shape, dtype=torch.int8, device=self.device), None
+            rows, placed = torch.zeros(shape, dtype=self.obs_dtype, device=self.device), None
         ring = {
             "slots": int(slots),
             "placement": placed,
@@ -608,6 +613,8 @@ class BatchedWorld:
         out = {}
         for nme in names:
             t = self.obs_rows if nme == "obs" else getattr(self, nme)
+            if t.dtype == torch.bfloat16:  # (numpy has no bfloat16: the values are small integers, exact in float32)
+                t = t.float()
             out[nme] = t.cpu().numpy()
         import numpy as np
         if "bits" in out:

@@ -78,7 +78,7 @@ struct Layout {
 };
 
 // `h`: the common header (dimensions; table sizes = the largest of the batch's maps); n_maps blobs and reset records
-Layout make_layout(const MapHeader& h, int64_t n, int64_t n_maps = 1) {
+Layout make_layout(const MapHeader& h, int64_t n, int64_t n_maps = 1, uint32_t obs_et = OBS_I8) {
     Layout l{};
     const int64_t L = h.L;
     const int64_t A = agent_stride((int)h.A, (int)h.L);  // per-agent buffers are strided by the kernel's agent bound
@@ -95,7 +95,7 @@ Layout make_layout(const MapHeader& h, int64_t n, int64_t n_maps = 1) {
     sz[LLE_BUF_EVCOUNT] = n_pad;
     sz[LLE_BUF_EVENTS] = n_pad * 2 * A;
     sz[LLE_BUF_DONE] = n_pad;
-    sz[LLE_BUF_OBS] = n * (int64_t)h.obs_stride;
+    sz[LLE_BUF_OBS] = (n * (int64_t)h.obs_stride) << obs_elem_shift(obs_et);  // (rows of the batch's element type, lle_batch_options.obs_dtype)
     sz[LLE_BUF_STATS] = l.n_stat_blocks * 8 * 8;
     sz[LLE_BUF_REQ_POS] = n_pad * A * 2;
     sz[LLE_BUF_REQ_GEMS] = n_pad * 4;
@@ -156,6 +156,10 @@ struct lle_batch {
     // what lle_batch_autotune chose for this batch's step launches (kernels.h StepTune) and the log of its trials
     StepTune tune{};
     std::string tune_log;
+    // element type of LLE_BUF_OBS and of the observation rings (tables.h ObsElem; lle_batch_options.obs_dtype): the kernels widen at the store
+    uint32_t obs_et = OBS_I8;
+    uint64_t row_pitch() const { return (uint64_t)hdr.obs_stride << obs_elem_shift(obs_et); }  // bytes between the rows of two environments
+    uint64_t rows_bytes() const { return (uint64_t)n_envs * row_pitch(); }                     // ... of one launch's rows
 };
 
 // Whether alternating the walk can pay: the rows of one launch must exceed what the 256 MB Infinity Cache keeps of them
@@ -456,6 +460,7 @@ static int launch(lle_batch* b, int mode, LaunchArgs K, void* stream) {
     if (b->per_env_sources) K.flags |= LAUNCH_PER_ENV_SOURCES;
     K.envs_per_map = b->envs_per_map;
     K.table_stride = (uint32_t)b->layout.table_stride;
+    K.flags = (K.flags & ~LAUNCH_OBS_ELEM_MASK) | (b->obs_et << LAUNCH_OBS_ELEM_SHIFT);  // every kernel that writes the batch's rows widens alike
     if (mode == KMODE_STEP && (K.flags & STEP_RECOLOUR_RESETS)) {
         if (!(K.flags & STEP_AUTO_RESET)) return fail(LLE_ERR_ARG, "LLE_STEP_RECOLOUR_RESETS re-colours the envs LLE_STEP_AUTO_RESET resets: pass both");
         if (!b->per_env_sources)
@@ -474,12 +479,12 @@ static int launch(lle_batch* b, int mode, LaunchArgs K, void* stream) {
             return fail(LLE_ERR_ARG, "internal: more wavefronts than counter slots (envs_per_wave below " + std::to_string(MIN_ENVS_PER_WAVE) + ")");
         // single steps that rewrite the rows in place (a fused rollout rewrites them inside one launch, a ring never revisits a slot in time)
         if (K.n_steps <= 1 && !K.ring_slots && !K.stamps && !(K.flags & STEP_NO_OBS) &&
-            next_walk_reversed(b, b->ptrs.obs, (uint64_t)b->n_envs * b->hdr.obs_stride))
+            next_walk_reversed(b, b->ptrs.obs, b->rows_bytes()))
             K.flags |= LAUNCH_REVERSE;
         HIP_TRY(launch_step_kernel(b->hdr, b->ptrs, K, (hipStream_t)stream, b->tune));
     }
     else {
-        if (mode != KMODE_SET_STATE && next_walk_reversed(b, b->ptrs.obs, (uint64_t)b->n_envs * b->hdr.obs_stride)) K.flags |= LAUNCH_REVERSE;
+        if (mode != KMODE_SET_STATE && next_walk_reversed(b, b->ptrs.obs, b->rows_bytes())) K.flags |= LAUNCH_REVERSE;
         HIP_TRY(launch_world_kernel(mode, b->hdr, b->ptrs, K, (hipStream_t)stream));
     }
     g_status = LLE_OK;
@@ -521,7 +526,7 @@ static int create_impl(lle_batch* b, void* arena, int64_t arena_bytes, void* str
     worst.lds_table_bytes = b->worst_table_bytes;
     const uint32_t lds = kernel_lds_bytes(worst, 1);
     if (lds > 160 * 1024) return fail(LLE_ERR_UNSUPPORTED, "map tables need " + std::to_string(lds) + " B of LDS per wavefront (> 160 KiB)");
-    b->layout = make_layout(b->hdr, b->n_envs, (int64_t)b->maps.size());
+    b->layout = make_layout(b->hdr, b->n_envs, (int64_t)b->maps.size(), b->obs_et);
     if (arena) {
         if (arena_bytes < b->layout.total || (reinterpret_cast<uintptr_t>(arena) % ALIGN) != 0)
             return fail(LLE_ERR_ARENA, "arena too small or not 256-byte aligned");
@@ -573,10 +578,19 @@ static int common_header(const lle_map* const* maps, int n_maps, MapHeader* out,
     return LLE_OK;
 }
 
+static bool options_ok(const lle_batch_options* opt) {
+    if (!opt) return true;
+    if (opt->struct_bytes < 8u) { fail(LLE_ERR_ARG, "lle_batch_options.struct_bytes must be set to sizeof(lle_batch_options)"); return false; }
+    if (opt->obs_dtype < LLE_DTYPE_I8 || opt->obs_dtype > LLE_DTYPE_F32) { fail(LLE_ERR_ARG, "obs_dtype must be LLE_DTYPE_I8, _F16, _BF16 or _F32"); return false; }
+    return true;
+}
+
 static lle_batch* create_batch(const lle_map* const* maps, int n_maps, int64_t n_envs, int device_id, void* arena, int64_t arena_bytes,
-                               void* stream) {
+                               void* stream, const lle_batch_options* opt = nullptr) {
+    if (!options_ok(opt)) return nullptr;
     lle_batch* b = new (std::nothrow) lle_batch();
     if (!b) return nullptr;
+    if (opt) b->obs_et = (uint32_t)opt->obs_dtype;
     if (common_header(maps, n_maps, &b->hdr, &b->worst_table_bytes) != LLE_OK) { delete b; return nullptr; }
     for (int m = 0; m < n_maps; m++) b->maps.push_back(maps[m]->m);
     b->envs_per_map = n_maps > 1 ? n_envs / n_maps : 0;
@@ -625,6 +639,31 @@ lle_batch* lle_batch_create_multi(const lle_map* const* maps, int n_maps, int64_
     return create_batch(maps, n_maps, envs_per_map * n_maps, device_id, arena, arena_bytes, stream);
 }
 
+int64_t lle_batch_arena_bytes_opt(const lle_map* const* maps, int n_maps, int64_t envs_per_map, const lle_batch_options* opt) {
+    if (!maps || n_maps <= 0 || envs_per_map <= 0) return fail(LLE_ERR_ARG, "bad arguments");
+    for (int m = 0; m < n_maps; m++)
+        if (!maps[m]) return fail(LLE_ERR_NULL, "NULL map");
+    if (!options_ok(opt)) return LLE_ERR_ARG;
+    MapHeader h;
+    int rc = common_header(maps, n_maps, &h, nullptr);
+    if (rc != LLE_OK) return rc;
+    return make_layout(h, envs_per_map * n_maps, n_maps, opt ? (uint32_t)opt->obs_dtype : (uint32_t)OBS_I8).total;
+}
+
+lle_batch* lle_batch_create_opt(const lle_map* const* maps, int n_maps, int64_t envs_per_map, int device_id, void* arena, int64_t arena_bytes,
+                                const lle_batch_options* opt, void* stream) {
+    if (!maps || n_maps <= 0) { fail(LLE_ERR_ARG, "no maps"); return nullptr; }
+    for (int m = 0; m < n_maps; m++)
+        if (!maps[m]) { fail(LLE_ERR_NULL, "NULL map"); return nullptr; }
+    if (envs_per_map <= 0 || (n_maps > 1 && envs_per_map % 16 != 0)) {
+        fail(LLE_ERR_ARG, "envs_per_map must be a positive multiple of 16 (a wavefront serves one map)");
+        return nullptr;
+    }
+    return create_batch(maps, n_maps, envs_per_map * n_maps, device_id, arena, arena_bytes, stream, opt);
+}
+
+int lle_batch_obs_dtype(const lle_batch* b) { return b ? (int)b->obs_et : LLE_ERR_NULL; }
+
 int lle_batch_n_maps(const lle_batch* b) { return b ? (int)b->maps.size() : 0; }
 
 static void drop_views(lle_batch* b) {
@@ -663,7 +702,7 @@ int lle_batch_get_buffer(const lle_batch* b, int which, lle_buffer_desc* out) {
         case LLE_BUF_AVAIL: case LLE_BUF_ACTIONS: set(1, 2, n, A, 1, As, 1, 1); break;
         case LLE_BUF_ERR: case LLE_BUF_EVCOUNT: case LLE_BUF_DONE: set(1, 1, n, 1, 1, 1, 1, 1); break;
         case LLE_BUF_EVENTS: set(1, 2, n, 2 * A, 1, 2 * As, 1, 1); break;
-        case LLE_BUF_OBS: set(1, 2, n, b->hdr.obs_bytes, 1, b->hdr.obs_stride, 1, 1); break;
+        case LLE_BUF_OBS: set(1 << obs_elem_shift(b->obs_et), 2, n, b->hdr.obs_bytes, 1, b->hdr.obs_stride, 1, 1); break;  // (C*H*W ELEMENTS per row, pitch in elements)
         case LLE_BUF_STATS: set(8, 2, b->layout.n_stat_blocks, 8, 1, 8, 1, 1); break;
         case LLE_BUF_REQ_ALIVE: set(2, 1, n, 1, 1, 1, 1, 1); break;
         case LLE_BUF_REWARD: set(1, 2, n, 4, 1, 4, 1, 1); break;
@@ -731,7 +770,7 @@ int lle_batch_step(lle_batch* b, const uint8_t* actions_dev, uint32_t flags, uin
     if (!b) return fail(LLE_ERR_NULL, "NULL batch");
     ON_DEVICE_OF(b);
     LaunchArgs K{};
-    K.flags = flags; K.seed = seed; K.t = t; K.env_offset = env_offset; K.actions_in = actions_dev;
+    K.flags = flags & STEP_PUBLIC_FLAGS; K.seed = seed; K.t = t; K.env_offset = env_offset; K.actions_in = actions_dev;  // (the bits above are the library's own)
     return launch(b, KMODE_STEP, K, stream);
 }
 
@@ -766,7 +805,7 @@ int lle_batch_step_outputs(lle_batch* b, const uint8_t* actions_dev, uint32_t fl
     }
     LaunchArgs K{};
     // (the struct rides in the kernel arguments: nothing to upload, whatever the caller hands from one step to the next)
-    K.flags = flags; K.seed = seed; K.t = t; K.env_offset = env_offset; K.actions_in = actions_dev;
+    K.flags = flags & STEP_PUBLIC_FLAGS; K.seed = seed; K.t = t; K.env_offset = env_offset; K.actions_in = actions_dev;
     K.out = O; K.env_out = reinterpret_cast<const EnvOutputs*>(b->arena + b->layout.off_env_out);  // (non-NULL: "outputs wanted"; never read)
     K.partial_k = O.partial ? O.partial_k : 0u; K.partial_E = partial_E;
     if (O.partial && (flags & STEP_RECOLOUR_RESETS)) return fail(LLE_ERR_UNSUPPORTED, "the partial observation of the step launch: the map's own sources only");
@@ -780,7 +819,7 @@ int lle_batch_rollout(lle_batch* b, uint32_t n_steps, uint32_t flags, uint64_t s
     if (n_steps == 0 || n_steps > 4096) return fail(LLE_ERR_ARG, "n_steps must be 1..4096");
     if (b->lane_per_env_step) return fail(LLE_ERR_ARG, "the fused rollout runs on the default step kernel only");
     LaunchArgs K{};
-    K.flags = flags; K.seed = seed; K.t = t0; K.env_offset = env_offset; K.n_steps = n_steps;
+    K.flags = flags & STEP_PUBLIC_FLAGS; K.seed = seed; K.t = t0; K.env_offset = env_offset; K.n_steps = n_steps;
     if (ring) {
         if (ring->ring_slots < 1 || !ring->obs || !ring->actions || !ring->reward) return fail(LLE_ERR_ARG, "incomplete ring");
         K.ring_slots = (uint32_t)ring->ring_slots; K.ring_pos = ring->ring_pos % (uint64_t)ring->ring_slots; K.ring_env_count = b->n_envs;
@@ -1171,7 +1210,7 @@ int lle_batch_step_stamped(lle_batch* b, uint32_t flags, uint64_t seed, uint64_t
     if (!b || !stamps_dev) return fail(LLE_ERR_NULL, "NULL argument");
     ON_DEVICE_OF(b);
     LaunchArgs K{};
-    K.flags = flags; K.seed = seed; K.t = t; K.stamps = stamps_dev;
+    K.flags = flags & STEP_PUBLIC_FLAGS; K.seed = seed; K.t = t; K.stamps = stamps_dev;
     return launch(b, KMODE_STEP, K, stream);
 }
 
@@ -1180,9 +1219,9 @@ int lle_batch_probe_row_fill(lle_batch* b, uint32_t value, void* stream) {
     ON_DEVICE_OF(b);
     const uint32_t epw = b->lane_per_env_step ? b->envs_per_wave : step_envs_per_wave(b->n_envs, (int)b->hdr.A, b->tune);
     // the same alternation as the step launches it stands in for
-    const bool reverse = next_walk_reversed(b, b->ptrs.obs, (uint64_t)b->n_envs * b->hdr.obs_stride);
-    HIP_TRY(launch_row_fill_probe(b->ptrs.obs, b->n_envs, b->hdr.obs_stride, epw, value, reverse,
-                                  rotate_rows_pays(b->tune, (uint64_t)b->n_envs * b->hdr.obs_stride, b->hdr.obs_stride), (hipStream_t)stream));
+    const bool reverse = next_walk_reversed(b, b->ptrs.obs, b->rows_bytes());
+    HIP_TRY(launch_row_fill_probe(b->ptrs.obs, b->n_envs, (uint32_t)b->row_pitch(), epw, value, reverse,
+                                  rotate_rows_pays(b->tune, b->rows_bytes(), (uint32_t)b->row_pitch()), (hipStream_t)stream));
     g_status = LLE_OK;
     return LLE_OK;
 }
@@ -1246,13 +1285,13 @@ int lle_batch_autotune(lle_batch* b, double budget_ms, void* stream) {
     if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return fail(LLE_ERR_HIP, "hipEventCreate"); }
     const bool pes = b->per_env_sources;
     const MapHeader& h = b->hdr;
-    const uint64_t row_bytes = (uint64_t)b->n_envs * h.obs_stride;
+    const uint64_t row_bytes = b->rows_bytes();
     // the alternatives, one coordinate at a time (each keeps the best of the ones before it): environments per wavefront, row
     // heads, store policy, split rows, the alternating walk -- only those that exist for this batch
     const uint32_t cap = 64u / (uint32_t)step_group((int)h.A);
     std::vector<uint32_t> epws;
     for (uint32_t e = cap; e >= MIN_ENVS_PER_WAVE && epws.size() < 3; e >>= 1) epws.push_back(e);  // (one LLE_BUF_STATS slot per wavefront of >= 4 envs)
-    const bool can_heads = step_has_row_heads(h, pes), can_split = step_can_split_rows(h, pes), can_walk = row_bytes > (256ull << 20);
+    const bool can_heads = step_has_row_heads(h, pes) && b->obs_et == OBS_I8, can_split = step_can_split_rows(h, pes), can_walk = row_bytes > (256ull << 20);
     const int n_trials = (int)epws.size() + (can_heads ? 4 : 0) + 2 + (can_split ? 2 : 0) + (can_walk ? 2 : 0) + 2;
     uint64_t t_idx = 1u << 20;
     StepTune best = b->tune;
@@ -1306,19 +1345,19 @@ int lle_batch_tuning(const lle_batch* b, lle_tuning_info* out, char* log_buf, si
     if (!b || !out) return fail(LLE_ERR_NULL, "NULL argument");
     const bool pes = b->per_env_sources;
     const MapHeader& h = b->hdr;
-    const uint64_t row_bytes = (uint64_t)b->n_envs * h.obs_stride;
+    const uint64_t row_bytes = b->rows_bytes();
     const uint32_t epw = step_envs_per_wave(b->n_envs, (int)h.A, b->tune);
     const uint32_t n_waves = (uint32_t)((b->n_envs + epw - 1) / epw);
     out->envs_per_wave = (int32_t)epw;
     out->split_rows = step_splits_rows(h, pes, b->tune) ? 1 : 0;
-    out->write_through = write_through_pays(row_bytes, h.obs_stride, b->tune.write_through) ? 1 : 0;
+    out->write_through = write_through_pays(row_bytes, (uint32_t)b->row_pitch(), b->tune.write_through) ? 1 : 0;
     out->alternating_walk = pingpong_pays(b, row_bytes) ? 1 : 0;
-    out->rotate_rows = (!out->split_rows && rotate_rows_pays(b->tune, row_bytes, h.obs_stride)) ? 1 : 0;
+    out->rotate_rows = (!out->split_rows && rotate_rows_pays(b->tune, row_bytes, (uint32_t)b->row_pitch())) ? 1 : 0;
     // (what a plain single step of this batch gets: the same conditions as launch_step_kernel)
     const bool general = pes || b->envs_per_map != 0;
     StepTune t = b->tune;
     int heads = 0;
-    if (step_has_row_heads(h, pes) && !out->split_rows) {
+    if (step_has_row_heads(h, pes) && !out->split_rows && b->obs_et == OBS_I8) {
         const int forced = tuning().row_heads >= 0 ? tuning().row_heads : (int)t.heads;
         heads = forced >= 0 ? forced : ((general ? n_waves >= 2048u : (n_waves >= 2048u && n_waves <= 12288u)) ? 1 : 0);
     }

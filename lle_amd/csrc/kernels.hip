@@ -408,16 +408,15 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
     LLE_STAMP(4);
     // ---- phase 2: layered observation, one environment of the wave at a time
     if (write_obs && n_here > 0) {
-        const bool wt = (K.flags & LAUNCH_WRITE_THROUGH) != 0;
-        if (pes) {
-            if (wt) write_observations_env<true>(A, L, hdr->HW, hdr->n_elems, hdr->n_chunks, hdr->obs_stride, elems, bare, tmpl, scratch,
-                                                 scr_stride, P.obs, env0, n_here, lane);
-            else write_observations_env<false>(A, L, hdr->HW, hdr->n_elems, hdr->n_chunks, hdr->obs_stride, elems, bare, tmpl, scratch,
-                                               scr_stride, P.obs, env0, n_here, lane);
-        } else {
-            if (wt) write_observations<true>(A, L, hdr->D, hdr->n_chunks, hdr->obs_stride, dyn, tmpl, scratch, scr_stride, P.obs, env0, n_here, lane);
-            else write_observations<false>(A, L, hdr->D, hdr->n_chunks, hdr->obs_stride, dyn, tmpl, scratch, scr_stride, P.obs, env0, n_here, lane);
-        }
+        const uint32_t et = (K.flags & LAUNCH_OBS_ELEM_MASK) >> LAUNCH_OBS_ELEM_SHIFT;  // (tables.h ObsElem: the rows' element type)
+        const uint64_t row_pitch = (uint64_t)hdr->obs_stride << obs_elem_shift(et);
+        dispatch_stream<true>(K.flags, [&](auto wt_, auto wide_) {
+            constexpr bool WT = decltype(wt_)::value, WIDE = decltype(wide_)::value;
+            if (pes) write_observations_env<WT, false, false, WIDE>(A, L, hdr->HW, hdr->n_elems, hdr->n_chunks, row_pitch, elems, bare, tmpl, scratch, scr_stride, P.obs, env0,
+                                                                    n_here, lane, nullptr, 0xFFFFFFFFu, 0u, 0u, 0u, nullptr, 0u, 0u, 0u, et);
+            else write_observations<WT, false, false, WIDE>(A, L, hdr->D, hdr->n_chunks, row_pitch, dyn, tmpl, scratch, scr_stride, P.obs, env0, n_here, lane, 0u, 0u, 0u,
+                                                            nullptr, 0u, et);
+        });
     }
     LLE_STAMP(5);
     if (MODE == MODE_STEP) flush_stats(P.stats, wave_id, cnt, A, lane);
@@ -679,7 +678,8 @@ static bool row_heads_pay(uint32_t n_waves, bool general, int chosen) {
 
 hipError_t launch_world_kernel(int mode, const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K_in, hipStream_t stream) {
     LaunchArgs K = K_in;
-    if (write_through_pays((uint64_t)(K.env_limit - K.env_base) * h.obs_stride, h.obs_stride)) K.flags |= LAUNCH_WRITE_THROUGH;
+    const uint32_t pitch = h.obs_stride << obs_elem_shift((K.flags & LAUNCH_OBS_ELEM_MASK) >> LAUNCH_OBS_ELEM_SHIFT);  // row pitch in bytes
+    if (write_through_pays((uint64_t)(K.env_limit - K.env_base) * pitch, pitch)) K.flags |= LAUNCH_WRITE_THROUGH;
     const bool pes = (K.flags & LAUNCH_PER_ENV_SOURCES) != 0;
     uint32_t wpw = kernel_waves_per_wg(h, pes);
     if (K.envs_per_map && !K.map_override) {  // a workgroup's environments must belong to one map
@@ -766,10 +766,12 @@ hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const Laun
     const int G = step_group((int)h.A), lm = step_lm((int)h.L);
     const bool pes = (K.flags & LAUNCH_PER_ENV_SOURCES) != 0;
     K.n_sources = h.L;
+    const uint32_t et = (K.flags & LAUNCH_OBS_ELEM_MASK) >> LAUNCH_OBS_ELEM_SHIFT;  // (tables.h ObsElem)
+    const uint32_t pitch = h.obs_stride << obs_elem_shift(et);                      // row pitch in bytes
     {   // a ring keeps the rows of min(n_steps, ring_slots) steps; without one every step overwrites the same rows
         const uint64_t slots = K.ring_slots ? (K.n_steps < K.ring_slots ? (K.n_steps ? K.n_steps : 1u) : K.ring_slots) : 1u;
-        if (write_through_pays((uint64_t)(K.env_limit - K.env_base) * h.obs_stride * slots, h.obs_stride, tune.write_through)) K.flags |= LAUNCH_WRITE_THROUGH;
-        if (rotate_rows_pays(tune, (uint64_t)(K.env_limit - K.env_base) * h.obs_stride * slots, h.obs_stride)) K.flags |= LAUNCH_ROTATE_ROWS;
+        if (write_through_pays((uint64_t)(K.env_limit - K.env_base) * pitch * slots, pitch, tune.write_through)) K.flags |= LAUNCH_WRITE_THROUGH;
+        if (rotate_rows_pays(tune, (uint64_t)(K.env_limit - K.env_base) * pitch * slots, pitch)) K.flags |= LAUNCH_ROTATE_ROWS;
     }
     if (pes || K.envs_per_map || K.env_out) K.flags |= LAUNCH_GENERAL;  // (fused LLE.step outputs: MODE 4 / 5 carry the epilogue)
     if (K.env_out && roll_requested(K)) return hipErrorInvalidValue;  // single steps only
@@ -811,14 +813,15 @@ hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const Laun
         if (roll) return launch_step_mode3(G, lm, P, K, n_waves, wpw, lds, stream);
         // single steps: the colour-independent head lines ahead of the state machine (MODE 8) under the same conditions as below
         const bool incr_pes = (K.flags & STEP_INCREMENTAL_OBS) != 0 && h.n_pes_dyn_chunks < h.n_chunks;  // (static lines not written: no head to send ahead)
-        const bool heads_pes = !incr_pes && lm <= 8 && h.pes_head_n != 0 && !(K.flags & (LAUNCH_SPLIT_ROWS | STEP_NO_OBS)) && row_heads_pay(n_waves, true, tune.heads);
+        // (widened rows -- et != int8 -- go out whole behind the state machine: a head in front of it is a third to a ninth of its int8 size in time)
+        const bool heads_pes = !incr_pes && et == OBS_I8 && lm <= 8 && h.pes_head_n != 0 && !(K.flags & (LAUNCH_SPLIT_ROWS | STEP_NO_OBS)) && row_heads_pay(n_waves, true, tune.heads);
         return heads_pes ? launch_step_mode8(G, lm, P, K, n_waves, wpw, lds, stream) : launch_step_mode5(G, lm, P, K, n_waves, wpw, lds, stream);
     }
     // single-step launches with the map's sources: the rows' head lines go out ahead of the state machine (MODE 6 / 7) when
     // the map has a head, the rows are not split and the launch is of the size where it pays
     // (STEP_INCREMENTAL_OBS: the static lines are not written at all, so there is no head to send ahead)
     const bool incr = (K.flags & STEP_INCREMENTAL_OBS) != 0 && !roll && h.n_dyn_chunks < h.n_chunks;
-    const bool heads = !incr && !roll && lm <= 8 && h.head_n != 0 && !(K.flags & (LAUNCH_SPLIT_ROWS | STEP_NO_OBS)) &&
+    const bool heads = !incr && !roll && et == OBS_I8 && lm <= 8 && h.head_n != 0 && !(K.flags & (LAUNCH_SPLIT_ROWS | STEP_NO_OBS)) &&
                        row_heads_pay(n_waves, (K.flags & LAUNCH_GENERAL) != 0, tune.heads);
     if (K.flags & LAUNCH_GENERAL) {
         if (roll) return launch_step_mode2(G, lm, P, K, n_waves, wpw, lds, stream);

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "tables.h"
 
 namespace lle {
@@ -233,6 +235,77 @@ __device__ __forceinline__ void stream_row_dyn(uint4* __restrict__ dst, const ui
     }
 }
 
+// ---- WIDENED rows (tables.h ObsElem): the LDS row stays int8, every 16-byte chunk of the OUTPUT row is built from the 16 >> shift row bytes
+// it covers -- 8 of them for fp16 / bf16 (one ds_read_b64 per lane), 4 for fp32 (one ds_read_b32) -- so consecutive lanes still read
+// consecutive LDS bytes and write consecutive 16-byte chunks: 1 KiB fully coalesced per wave instruction, as in the int8 stream.
+// One chunk at a time, nothing unrolled: these loops run in the registers the int8 stream leaves them (the kernels sit at their register
+// caps: a four-deep version put 439 of the 555 kernels into scratch), and sixteen wavefronts per CU hide the LDS round trip of each.
+// A row only ever holds -1, 0 and 1 (template, dyn bases, patches): byte b becomes (b & 1 ? ONE : 0) | sign, ONE = 1.0 in the target type.
+__device__ __forceinline__ uint4 widen_chunk16(const int8_t* tmpl, uint32_t q, uint32_t one, uint32_t sel_lo, uint32_t sel_hi) {  // fp16 (one = 0x3C00) / bf16 (0x3F80)
+    const uint2 w = reinterpret_cast<const uint2*>(tmpl)[q];
+    uint32_t o[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t src = k < 2 ? w.x : w.y;
+        // bytes 2(k&1), 2(k&1)+1 of `src` into the low bytes of the two halves (v_perm_b32: selector 0x0c = a zero byte)
+        const uint32_t x = __builtin_amdgcn_perm(src, src, (k & 1) ? sel_hi : sel_lo);
+        o[k] = __umul24(x & 0x00010001u, one) | ((x & 0x00800080u) << 8);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+__device__ __forceinline__ uint4 widen_chunk32(const int8_t* tmpl, uint32_t q) {
+    const uint32_t w = reinterpret_cast<const uint32_t*>(tmpl)[q];
+    uint32_t o[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t b = (w >> (8 * k)) & 0xFFu;
+        o[k] = ((b & 1u) ? 0x3F800000u : 0u) | ((b & 0x80u) << 24);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+// Everything a widening stream needs besides the row itself is REBUILT per row from two opaque values (a scalar zero and the lane id behind
+// empty asm statements): otherwise the compiler hoists the loop-invariant pieces -- the v_perm selectors (a VOP3 operand must sit in a
+// register), `one`, the chunk count, the lane's LDS address -- above the loop over the environments and, in the fused rollouts, above the
+// loop over the STEPS, where they stay live across the whole state machine (58 rollout kernels at their register caps went to scratch).
+struct WideConsts { uint32_t one, sel_lo, sel_hi, sh, lane; };
+__device__ __forceinline__ WideConsts wide_consts(uint32_t et, uint32_t lane) {
+    uint32_t z = 0;
+    asm volatile("" : "+s"(z));
+    asm volatile("" : "+v"(lane));
+    WideConsts c;
+    c.one = (et == OBS_F16 ? 0x3C00u : 0x3F80u) | z;
+    c.sel_lo = 0x0c010c00u | z;
+    c.sel_hi = 0x0c030c02u | z;
+    c.sh = obs_elem_shift(et) + z;
+    c.lane = lane;
+    return c;
+}
+// output chunks [0, n_chunks << shift) of a row (or of a slice of it: `tmpl` and `dst` then both start at the slice)
+template <bool WT>
+__device__ __forceinline__ void stream_wide(uint4* __restrict__ dst, const int8_t* tmpl, uint32_t n_chunks, uint32_t et, uint32_t lane_in) {
+    const WideConsts c = wide_consts(et, lane_in);
+    const uint32_t n_out = n_chunks << c.sh;
+    if (c.sh == 2u) {
+#pragma clang loop unroll(disable)
+        for (uint32_t q = c.lane; q < n_out; q += 64u) stream_store<WT>(dst + q, widen_chunk32(tmpl, q));
+    } else {
+#pragma clang loop unroll(disable)
+        for (uint32_t q = c.lane; q < n_out; q += 64u) stream_store<WT>(dst + q, widen_chunk16(tmpl, q, c.one, c.sel_lo, c.sel_hi));
+    }
+}
+// ... and only the DYNAMIC chunks (STEP_INCREMENTAL_OBS): entries [t_lo, t_hi) of the chunk table, each int8 chunk c = output chunks
+// [c << shift, (c + 1) << shift); `c_base`: first chunk of the slice `tmpl` / `dst` start at (split rows; 0 for whole rows)
+template <bool WT>
+__device__ __forceinline__ void stream_wide_dyn(uint4* __restrict__ dst, const int8_t* tmpl, const uint16_t* tab, uint32_t t_lo, uint32_t t_hi, uint32_t c_base,
+                                                uint32_t et, uint32_t lane_in) {
+    const WideConsts c = wide_consts(et, lane_in);
+#pragma clang loop unroll(disable)
+    for (uint32_t i = (t_lo << c.sh) + c.lane; i < (t_hi << c.sh); i += 64u) {
+        const uint32_t q = (((uint32_t)tab[i >> c.sh] - c_base) << c.sh) + (i & ((1u << c.sh) - 1u));
+        stream_store<WT>(dst + q, c.sh == 2u ? widen_chunk32(tmpl, q) : widen_chunk16(tmpl, q, c.one, c.sel_lo, c.sel_hi));
+    }
+}
+
 // The heads of the wave's rows: the same `head_n` (<= 64) chunks, straight from the map's pristine template in global
 // memory (`v`: this lane's chunk), into every row.  Issued BEFORE the state machine: a launch of the step kernel is
 // (ramp) + (state machine, every wavefront at the same time) + (stream), and the lines that no agent, beam or gem can
@@ -247,17 +320,38 @@ __device__ __forceinline__ void store_heads(int8_t* __restrict__ obs, uint64_t o
             stream_store<WT>(reinterpret_cast<uint4*>(obs + (uint64_t)(env0 + rotated(k, rot, (uint32_t)n_here)) * obs_stride) + chunk, v);
 }
 
+// Store policy x element width of a launch as compile-time tags: f(std::bool_constant<WT>, std::bool_constant<WIDE>) is called for the one
+// combination the launch flags name (CAN_WIDE = false: kernels that never widen -- the ones with row heads -- instantiate two, not four).
+template <bool CAN_WIDE, typename F>
+__device__ __forceinline__ void dispatch_stream(uint32_t lflags, F&& f) {
+    const bool wt = (lflags & LAUNCH_WRITE_THROUGH) != 0;
+    if constexpr (CAN_WIDE) {
+        if (lflags & LAUNCH_OBS_ELEM_MASK) {
+            if (wt) f(std::true_type{}, std::true_type{});
+            else f(std::false_type{}, std::true_type{});
+            return;
+        }
+    }
+    if (wt) f(std::true_type{}, std::false_type{});
+    else f(std::false_type{}, std::false_type{});
+}
+
 // ---- phase 2: layered observation of the wave's environments, one environment at a time.
 // `scratch` holds one hand-over record per environment: [0 | beam masks | ~gem bits | byte index of each agent].
 // `obs_stride` = bytes between the rows of consecutive environments in `obs`.
 // HEAD: the rows' heads are already stored (store_heads); stream the rest.
 // INCR: only the dynamic chunks (dyn_chunks / n_dyn_chunks: stream_row_dyn).
-template <bool WT, bool HEAD = false, bool INCR = false>
+// WIDE: the row leaves as fp16 / bf16 / fp32 (tables.h ObsElem, `et`), stream_wide.  A template parameter, chosen by the caller OUTSIDE the loop
+// over the environments: with the choice inside it, the loop-invariant addresses of both streams were hoisted above the loop together and
+// 105 kernels at their register caps went to scratch.
+template <bool WT, bool HEAD = false, bool INCR = false, bool WIDE = false>
 __device__ __forceinline__ void write_observations(int A, int L, uint32_t D, uint32_t n_chunks, uint64_t obs_stride,
                                                    const uint64_t* dyn, int8_t* tmpl, const uint32_t* scratch,
                                                    uint32_t scr_stride, int8_t* __restrict__ obs, int64_t env0,
                                                    int64_t n_here, uint32_t lane, uint32_t head_lo = 0, uint32_t head_n = 0, uint32_t rot = 0,
-                                                   const uint16_t* dyn_chunks = nullptr, uint32_t n_dyn_chunks = 0) {
+                                                   const uint16_t* dyn_chunks = nullptr, uint32_t n_dyn_chunks = 0, uint32_t et = OBS_I8) {
+    // (`obs_stride` is the row pitch in BYTES: the map's pitch in elements times the element size)
+    static_assert(!(WIDE && HEAD), "the kernels with row heads carry no widening code: the launcher never sends them a widened launch");
     uint32_t dc0 = 0xFFFFu, dc1 = 0xFFFFu;
     if constexpr (INCR) {
         dc0 = lane < n_dyn_chunks ? (uint32_t)dyn_chunks[lane] : 0xFFFFu;
@@ -302,7 +396,10 @@ __device__ __forceinline__ void write_observations(int A, int L, uint32_t D, uin
         wave_sync();
         // (c) stream the patched copy as one contiguous row: 16 B per lane, 1 KiB per wave instruction
         uint4* __restrict__ dst = reinterpret_cast<uint4*>(obs + (uint64_t)(env0 + k) * obs_stride);
-        if constexpr (INCR) stream_row_dyn<WT>(dst, srcv, dyn_chunks, n_dyn_chunks, dc0, dc1, lane);
+        if constexpr (WIDE) {
+            if constexpr (INCR) stream_wide_dyn<WT>(dst, tmpl, dyn_chunks, 0u, n_dyn_chunks, 0u, et, lane);
+            else stream_wide<WT>(dst, tmpl, n_chunks, et, lane);
+        } else if constexpr (INCR) stream_row_dyn<WT>(dst, srcv, dyn_chunks, n_dyn_chunks, dc0, dc1, lane);
         else if constexpr (HEAD) stream_row_tail<WT>(dst, srcv, n_chunks, head_lo, head_n, lane);
         else stream_whole_row<WT>(dst, srcv, n_chunks, lane);
         wave_sync();
@@ -322,11 +419,12 @@ __device__ __forceinline__ void write_observations(int A, int L, uint32_t D, uin
 // by byte index) table.  Same bytes as write_observations: every dynamic byte and every agent byte belongs to exactly
 // one slice.
 // INCR (STEP_INCREMENTAL_OBS): only the slice's DYNAMIC chunks -- entries [t_lo, t_hi) of the ascending table dyn_chunks.
-template <bool WT, bool INCR = false>
+template <bool WT, bool INCR = false, bool WIDE = false>
 __device__ __forceinline__ void write_observations_split(int A, int L, uint32_t D, uint32_t lo, uint32_t hi, uint64_t obs_stride,
                                                          const uint64_t* dyn, int8_t* tmpl, const uint32_t* records,
                                                          uint32_t scr_stride, int8_t* __restrict__ obs, int64_t wg_env0,
-                                                         int64_t n_wg_here, uint32_t lane, const uint16_t* dyn_chunks = nullptr, uint32_t n_dyn_chunks = 0) {
+                                                         int64_t n_wg_here, uint32_t lane, const uint16_t* dyn_chunks = nullptr, uint32_t n_dyn_chunks = 0,
+                                                         uint32_t et = OBS_I8) {
     const uint32_t b_lo = lo * 16u, b_hi = hi * 16u;
     uint32_t t_lo = 0, t_hi = 0;
     if constexpr (INCR) {
@@ -376,8 +474,11 @@ __device__ __forceinline__ void write_observations_split(int A, int L, uint32_t 
         const bool agent_here = agent_idx >= b_lo && agent_idx < b_hi;  // (idle lanes: 0xFFFFFFFF is in no slice)
         if (agent_here) tmpl[agent_idx - b_lo] = 1;
         wave_sync();
-        uint4* __restrict__ dst = reinterpret_cast<uint4*>(obs + (uint64_t)(wg_env0 + k) * obs_stride) + lo;
-        if constexpr (INCR) {
+        uint4* __restrict__ dst = reinterpret_cast<uint4*>(obs + (uint64_t)(wg_env0 + k) * obs_stride) + ((uint64_t)lo << (WIDE ? obs_elem_shift(et) : 0u));
+        if constexpr (WIDE) {
+            if constexpr (INCR) stream_wide_dyn<WT>(dst, tmpl, dyn_chunks, t_lo, t_hi, lo, et, lane);
+            else stream_wide<WT>(dst, tmpl, n_mine, et, lane);
+        } else if constexpr (INCR) {
             for (uint32_t i = t_lo + lane; i < t_hi; i += 64u) {
                 const uint32_t c = (uint32_t)dyn_chunks[i] - lo;
                 stream_store<WT>(dst + c, srcv[c]);
@@ -409,14 +510,16 @@ __device__ __forceinline__ void elem_eval(uint32_t e, const uint32_t* sc, int A,
     val = type == ELEM_SOURCE ? -1 : 1;
     on = type == ELEM_SOURCE ? true : (is_gem ? ((sc[L + 1] >> i5) & 1u) != 0 : ((sc[1 + i5] >> off) & 1u) != 0);
 }
-template <bool WT, bool HEAD = false, bool INCR = false>
+template <bool WT, bool HEAD = false, bool INCR = false, bool WIDE = false>
 __device__ __forceinline__ void write_observations_env(int A, int L, uint32_t HW, uint32_t n_elems, uint32_t n_chunks,
                                                        uint64_t obs_stride, const uint32_t* elems, const int8_t* bare,
                                                        int8_t* tmpl, const uint32_t* scratch, uint32_t scr_stride,
                                                        int8_t* __restrict__ obs, int64_t env0, int64_t n_here, uint32_t lane,
                                                        const uint8_t* laser_layer = nullptr, uint32_t gem_layer_in = 0xFFFFFFFFu,
                                                        uint32_t head_lo = 0, uint32_t head_n = 0, uint32_t rot = 0,
-                                                       const uint16_t* dyn_chunks = nullptr, uint32_t n_dyn_chunks = 0, uint32_t head2_lo = 0, uint32_t head2_n = 0) {
+                                                       const uint16_t* dyn_chunks = nullptr, uint32_t n_dyn_chunks = 0, uint32_t head2_lo = 0, uint32_t head2_n = 0,
+                                                       uint32_t et = OBS_I8) {
+    static_assert(!(WIDE && HEAD), "no widening in the kernels with row heads");
     uint32_t dc0 = 0xFFFFu, dc1 = 0xFFFFu;  // INCR: this lane's first two dynamic chunks (stream_row_dyn)
     if constexpr (INCR) {
         dc0 = lane < n_dyn_chunks ? (uint32_t)dyn_chunks[lane] : 0xFFFFu;
@@ -455,7 +558,10 @@ __device__ __forceinline__ void write_observations_env(int A, int L, uint32_t HW
         if (is_agent_lane) tmpl[agent_idx] = 1;
         wave_sync();
         uint4* __restrict__ dst = reinterpret_cast<uint4*>(obs + (uint64_t)(env0 + k) * obs_stride);
-        if constexpr (INCR) stream_row_dyn<WT>(dst, srcv, dyn_chunks, n_dyn_chunks, dc0, dc1, lane);
+        if constexpr (WIDE) {
+            if constexpr (INCR) stream_wide_dyn<WT>(dst, tmpl, dyn_chunks, 0u, n_dyn_chunks, 0u, et, lane);
+            else stream_wide<WT>(dst, tmpl, n_chunks, et, lane);
+        } else if constexpr (INCR) stream_row_dyn<WT>(dst, srcv, dyn_chunks, n_dyn_chunks, dc0, dc1, lane);
         else if constexpr (HEAD) stream_row_tail<WT>(dst, srcv, n_chunks, head_lo, head_n, lane, head2_lo, head2_n);  // (the head is stored already: store_heads)
         else stream_whole_row<WT>(dst, srcv, n_chunks, lane);
         wave_sync();

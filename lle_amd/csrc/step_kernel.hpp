@@ -129,6 +129,11 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     // arguments: read where they are used they become vector loads from global memory with a full wait each, three of
     // them in a row between the state machine and the first observation store.
     const uint32_t h_HW = hdr->HW, h_obs_stride = hdr->obs_stride, h_n_chunks = hdr->n_chunks, h_D = hdr->D;
+    // element type of the rows this launch writes (tables.h ObsElem: int8, or widened at the store) and their pitch in BYTES: recomputed from
+    // the launch flags where they are used (macros, not variables: nothing new is live across the state machine); the kernels with row heads
+    // are never launched widened (kernels.hip launch_step_kernel) and carry none of it
+#define LLE_ET() (HEAD ? (uint32_t)OBS_I8 : (K.flags & LAUNCH_OBS_ELEM_MASK) >> LAUNCH_OBS_ELEM_SHIFT)
+#define LLE_PITCH() ((uint64_t)h_obs_stride << obs_elem_shift(LLE_ET()))
     uint32_t h_beam_full[LR];
 #pragma unroll
     for (int b = 0; b < LR; b++) h_beam_full[b] = (!BM && b < L) ? hdr->beam_full[b] : 0u;
@@ -434,7 +439,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         while (slot >= K.ring_slots) slot -= K.ring_slots;
         actions_out = K.ring_actions + (int64_t)slot * K.ring_env_count * As;
         reward_out = K.ring_reward + (int64_t)slot * K.ring_env_count;
-        obs_out = K.ring_obs + (int64_t)slot * K.ring_env_count * (int64_t)h_obs_stride;
+        obs_out = K.ring_obs + (int64_t)slot * K.ring_env_count * (int64_t)LLE_PITCH();
     }
 
     // ---- auto-reset: a finished env restarts from the reset state (identical for every env, see InitRecord)
@@ -699,18 +704,19 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     const bool post_first = ROLL || PARTIAL || (K.flags & LAUNCH_POST_FIRST) || (!(K.flags & LAUNCH_POST_LAST) && blockIdx.x * 4u >= gridDim.x * 3u);  // (PARTIAL: the writer wants the state machine's registers)
     if (post_first) post_step();
 
+    // (the store policy and the element width of the launch become template arguments here, outside the loops over the environments)
+    const uint32_t et = LLE_ET();
     if (split) {
         if (write_obs) {
             const int64_t wg_env0 = K.env_base + (int64_t)(blk * waves_per_wg) * EPW;
             int64_t n_wg = K.env_limit - wg_env0;
             n_wg = n_wg < 0 ? 0 : (n_wg > (int64_t)(waves_per_wg * EPW) ? (int64_t)(waves_per_wg * EPW) : n_wg);
             const uint32_t* records = reinterpret_cast<const uint32_t*>(lds + tab_bytes + bt_bytes + waves_per_wg * cpw * 16u);
-            const bool wts = (K.flags & LAUNCH_WRITE_THROUGH) != 0;
-            if (CAN_INCR && incr) {
-                if (wts) write_observations_split<true, true>(A, L, h_D, c_lo, c_hi, h_obs_stride, dyn, tmpl, records, scr_stride, obs_out, wg_env0, n_wg, lane, dyn_chunks, h_n_dyn_chunks);
-                else write_observations_split<false, true>(A, L, h_D, c_lo, c_hi, h_obs_stride, dyn, tmpl, records, scr_stride, obs_out, wg_env0, n_wg, lane, dyn_chunks, h_n_dyn_chunks);
-            } else if (wts) write_observations_split<true>(A, L, h_D, c_lo, c_hi, h_obs_stride, dyn, tmpl, records, scr_stride, obs_out, wg_env0, n_wg, lane);
-            else write_observations_split<false>(A, L, h_D, c_lo, c_hi, h_obs_stride, dyn, tmpl, records, scr_stride, obs_out, wg_env0, n_wg, lane);
+            dispatch_stream<!HEAD>(K.flags, [&](auto wt_, auto wide_) {
+                constexpr bool WT = decltype(wt_)::value, WIDE = decltype(wide_)::value;
+                if (CAN_INCR && incr) write_observations_split<WT, true, WIDE>(A, L, h_D, c_lo, c_hi, LLE_PITCH(), dyn, tmpl, records, scr_stride, obs_out, wg_env0, n_wg, lane, dyn_chunks, h_n_dyn_chunks, et);
+                else write_observations_split<WT, false, WIDE>(A, L, h_D, c_lo, c_hi, LLE_PITCH(), dyn, tmpl, records, scr_stride, obs_out, wg_env0, n_wg, lane, nullptr, 0u, et);
+            });
         }
         // fused rollout: the next step's records overwrite these
         if (ROLL && n_steps > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -721,24 +727,21 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
             write_partial<true>(A, L, W, (int)K.partial_k, part_pitch, K.partial_E, h_max_layers, cell_lay, cell_meta, part_bm, part_col, tmpl, scratch,
                                 scr_stride, O.partial, env0, n_here, lane);
     } else if (write_obs && n_here > 0) {
-        const bool wt = (K.flags & LAUNCH_WRITE_THROUGH) != 0;  // see stream_store (obs_stream.hpp)
-        if (PES && CAN_INCR && incr) {
-            if (wt) write_observations_env<true, false, true>(A, L, h_HW, h_n_elems, h_n_chunks, h_obs_stride, elems, bare, tmpl, scratch, scr_stride,
-                                                              obs_out, env0, n_here, lane, nullptr, 0xFFFFFFFFu, 0u, 0u, LLE_ROT(), dyn_chunks, h_n_dyn_chunks);
-            else write_observations_env<false, false, true>(A, L, h_HW, h_n_elems, h_n_chunks, h_obs_stride, elems, bare, tmpl, scratch, scr_stride,
-                                                            obs_out, env0, n_here, lane, nullptr, 0xFFFFFFFFu, 0u, 0u, LLE_ROT(), dyn_chunks, h_n_dyn_chunks);
-        } else if (PES) {
-            if (wt) write_observations_env<true, HEAD>(A, L, h_HW, h_n_elems, h_n_chunks, h_obs_stride, elems, bare, tmpl, scratch, scr_stride,
-                                                       obs_out, env0, n_here, lane, nullptr, 0xFFFFFFFFu, head_lo, head_n, LLE_ROT(), nullptr, 0u, head2_lo, head2_n);
-            else write_observations_env<false, HEAD>(A, L, h_HW, h_n_elems, h_n_chunks, h_obs_stride, elems, bare, tmpl, scratch, scr_stride,
-                                                     obs_out, env0, n_here, lane, nullptr, 0xFFFFFFFFu, head_lo, head_n, LLE_ROT(), nullptr, 0u, head2_lo, head2_n);
-        } else if (CAN_INCR && incr) {
-            if (wt) write_observations<true, false, true>(A, L, h_D, h_n_chunks, h_obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane, 0u, 0u, LLE_ROT(), dyn_chunks, h_n_dyn_chunks);
-            else write_observations<false, false, true>(A, L, h_D, h_n_chunks, h_obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane, 0u, 0u, LLE_ROT(), dyn_chunks, h_n_dyn_chunks);
-        } else {
-            if (wt) write_observations<true, HEAD>(A, L, h_D, h_n_chunks, h_obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane, head_lo, head_n, LLE_ROT());
-            else write_observations<false, HEAD>(A, L, h_D, h_n_chunks, h_obs_stride, dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane, head_lo, head_n, LLE_ROT());
-        }
+        dispatch_stream<!HEAD>(K.flags, [&](auto wt_, auto wide_) {  // see stream_store (obs_stream.hpp)
+            constexpr bool WT = decltype(wt_)::value, WIDE = decltype(wide_)::value;
+            if (PES && CAN_INCR && incr)
+                write_observations_env<WT, false, true, WIDE>(A, L, h_HW, h_n_elems, h_n_chunks, LLE_PITCH(), elems, bare, tmpl, scratch, scr_stride, obs_out, env0, n_here,
+                                                              lane, nullptr, 0xFFFFFFFFu, 0u, 0u, LLE_ROT(), dyn_chunks, h_n_dyn_chunks, 0u, 0u, et);
+            else if (PES)
+                write_observations_env<WT, HEAD, false, WIDE>(A, L, h_HW, h_n_elems, h_n_chunks, LLE_PITCH(), elems, bare, tmpl, scratch, scr_stride, obs_out, env0, n_here,
+                                                              lane, nullptr, 0xFFFFFFFFu, head_lo, head_n, LLE_ROT(), nullptr, 0u, head2_lo, head2_n, et);
+            else if (CAN_INCR && incr)
+                write_observations<WT, false, true, WIDE>(A, L, h_D, h_n_chunks, LLE_PITCH(), dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane, 0u, 0u, LLE_ROT(),
+                                                          dyn_chunks, h_n_dyn_chunks, et);
+            else
+                write_observations<WT, HEAD, false, WIDE>(A, L, h_D, h_n_chunks, LLE_PITCH(), dyn, tmpl, scratch, scr_stride, obs_out, env0, n_here, lane, head_lo, head_n,
+                                                          LLE_ROT(), nullptr, 0u, et);
+        });
     }
     wave_sync();
     if (!post_first) post_step();
@@ -767,6 +770,8 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
 #undef LLE_ENV_LATE
 #undef LLE_LOAD_STATE
 #undef LLE_ROT
+#undef LLE_ET
+#undef LLE_PITCH
     }
     if (CNT_LDS && env_ok && a == 0) {
         cnt.steps = cnt_lds[0]; cnt.gems = cnt_lds[1]; cnt.exits = cnt_lds[2]; cnt.died = cnt_lds[3];

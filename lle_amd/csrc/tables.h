@@ -178,6 +178,16 @@ constexpr uint32_t LAUNCH_HEAD_GROUP4 = 0x10000000;    //   (4: the first wavefr
 constexpr uint32_t LAUNCH_POST_FIRST = 0x20000000;     // internal: every wavefront writes its small outputs BEFORE its observation stream (step_kernel.hpp post_first), ...
 constexpr uint32_t LAUNCH_POST_LAST = 0x40000000;      //   ... or every one after it (default: the last quarter of the grid before, the rest after)
 constexpr uint32_t LAUNCH_ROTATE_ROWS = 0x4000000;     // internal: every wavefront starts its rows at another one of them (obs_stream.hpp row_rotation)
+// The element type of the batch's own layered rows (LLE_BUF_OBS and the observation rings; lle_batch_options.obs_dtype): the kernels keep the row
+// as int8 in LDS and WIDEN AT THE STORE (obs_stream.hpp stream_wide) -- what the reference returns is float32 (python/lle/observations.py:223),
+// what a learner's first layer reads is usually fp16 / bf16; the values are -1, 0, 1 in every type.  Two bits of the launch flags.
+enum ObsElem : uint32_t { OBS_I8 = 0, OBS_F16 = 1, OBS_BF16 = 2, OBS_F32 = 3 };
+constexpr uint32_t LAUNCH_OBS_ELEM_SHIFT = 13, LAUNCH_OBS_ELEM_MASK = 3u << LAUNCH_OBS_ELEM_SHIFT;  // internal
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline constexpr uint32_t obs_elem_shift(uint32_t et) { return et == OBS_I8 ? 0u : (et == OBS_F32 ? 2u : 1u); }  // log2(bytes per element)
+constexpr uint32_t STEP_PUBLIC_FLAGS = 0x1Fu;        // the LLE_STEP_* bits a caller may pass; everything above is the library's own
 constexpr uint32_t LAUNCH_DRY_RUN = 0x80000000u;      // internal, host side only: walk the dispatch, note the instantiation, launch nothing (kernels.h debug registry)
 constexpr uint32_t LAUNCH_WRITE_THROUGH = 0x400000;    // internal: observation rows are stored `sc1` (stream_store, obs_stream.hpp)
 // A launch writes its rows through L2 while all of them fit the Infinity Cache (256 MB, MI355X_MICROARCH.md); beyond

@@ -88,7 +88,9 @@ class ObservationGenerator:
         return self._world.observation(self._kind, self._param)
 
     def observe(self):
-        single = self._device_tensor().astype(np.float32)
+        # float32 like the reference.  The layered tensor arrives in that type from the kernels (World.layered_observation: no cast
+        # here, `copy=False` hands it through); the observers' int8 outputs (padded / perspective / partial) are cast once
+        single = self._device_tensor().astype(np.float32, copy=False)
         if not self._tile:
             return single
         reps = getattr(self, "n_agents", self._world.n_agents)

@@ -18,9 +18,10 @@ INFINITY_CACHE_BYTES = 256 << 20
 
 def time_row_fill(t, row_bytes, rows_per_wave=16, launches=10):
     """us per launch of the row-fill probe over the uint8 / int8 tensor `t` (contiguous, a whole number of rows)."""
-    assert t.is_contiguous() and t.element_size() == 1 and t.numel() % row_bytes == 0 and t.data_ptr() % 16 == 0
+    nbytes = t.numel() * t.element_size()  # (rings of a batch with a wider observation type: row_bytes is the pitch in BYTES)
+    assert t.is_contiguous() and nbytes % row_bytes == 0 and t.data_ptr() % 16 == 0
     L, st = _capi.lib(), C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
-    n_rows = t.numel() // row_bytes
+    n_rows = nbytes // row_bytes
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for k in range(3 + launches):
         if k == 3:

@@ -473,7 +473,10 @@ class World:
     def _batch(self):
         if self._batch_obj is None:
             from .batched import BatchedWorld
-            self._batch_obj = BatchedWorld(self._map, 1, device=self._device)  # creation resets (World::new, world.rs:82)
+            # creation resets (World::new, world.rs:82).  The layered observation of the facade's one environment leaves the kernels as
+            # float32, the reference's dtype (python/lle/observations.py:223): lle_batch_options.obs_dtype -- no cast on the host
+            import torch
+            self._batch_obj = BatchedWorld(self._map, 1, device=self._device, obs_dtype=torch.float32)
             self._map = self._batch_obj.map  # (the batch may hold a copy: mutators go through the object it pushes from)
         return self._batch_obj
 
@@ -669,7 +672,8 @@ class World:
         raise NotImplementedError("rendering is outside the scope of lle_amd (SURVEY.md section 2, row 11)")
 
     def layered_observation(self):
-        """(C, H, W) int8 layered observation of the current state (python/lle/observations.py:254-266), from the GPU."""
+        """(C, H, W) float32 layered observation of the current state (python/lle/observations.py:254-266), from the GPU: the
+        kernels store it in that type (a batch of one environment created with obs_dtype = float32)."""
         b = self._batch
         if not self._map.obs_supported:
             raise IndexError("a laser colour addresses a layer beyond 2*n_agents+4")

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in sorted(declared) if not hasattr(L, s)]
     assert not missing, f"liblle_hip.so lacks {missing}"
     assert declared == set(_capi.EXPORTS)
-    assert L.lle_abi_version() == 2
+    assert L.lle_abi_version() == 3
 
 
 def test_no_device_fails_loudly():
