@@ -644,6 +644,9 @@ def test_autotune_changes_rules_not_results(oracle_mod):
         assert a.stats() == b.stats()
 
 
+PATTERN = {1: 0x5A, 2: 0x5A5A, 4: 0x5A5A5A5A}  # a sentinel byte pattern per element size
+
+
 def test_autotune_many_agents_keeps_the_counter_slots(oracle_mod):
     """lle_batch_autotune swept environments-per-wavefront down to 2 and 1 on maps with more than four agents, where
     LLE_BUF_STATS (one slot per wavefront of AT LEAST four environments) is too short: the trial launches wrote their counters over
@@ -659,7 +662,7 @@ def test_autotune_many_agents_keeps_the_counter_slots(oracle_mod):
         assert bw.kernel_info()["envs_per_wave"] >= 4
         guard = [bw.req_pos, bw.req_gems, bw.req_alive, bw.src_colour, bw.src_enabled]
         for g in guard:
-            g.fill_(0x5A)
+            g.fill_(PATTERN[g.element_size()])
         tuned = bw.autotune(budget_ms=8.0)
         assert tuned["envs_per_wave"] >= 4, tuned
         if "envs_per_wave:" in tuned["log"]:  # (16 lanes per environment: four environments per wavefront is the only choice, nothing is swept)
@@ -667,7 +670,7 @@ def test_autotune_many_agents_keeps_the_counter_slots(oracle_mod):
             assert " 2=" not in swept and " 1=" not in swept, tuned["log"]
         torch.cuda.synchronize()
         for g in guard:
-            assert bool((g == 0x5A).all() if g.dtype == torch.uint8 else (g.view(torch.uint8) == 0x5A).all()), "a trial launch wrote past LLE_BUF_STATS"
+            assert bool((g == PATTERN[g.element_size()]).all()), "a trial launch wrote past LLE_BUF_STATS"
         assert bw.stats()["env_steps"] == 0
         ev = torch.zeros(3, dtype=torch.int64, device="cuda")
         for t in range(6):
@@ -680,7 +683,7 @@ def test_autotune_many_agents_keeps_the_counter_slots(oracle_mod):
         st = bw.stats()
         assert st["env_steps"] == 6 * n and (st["exits"], st["gems"], st["deaths"]) == tuple(int(v) for v in ev.tolist())
         for g in guard:
-            assert bool((g.view(torch.uint8) == 0x5A).all())
+            assert bool((g == PATTERN[g.element_size()]).all())
         del bw
     import os
     os.environ["LLE_STEP_EPW"] = "1"
