@@ -695,8 +695,9 @@ def main():
     ap.add_argument("--sustained-steps", type=int, default=2000, help="launches of the `sustained` block (0 = skip)")
     ap.add_argument("--config-steps", type=int, default=200, help="launches per secondary configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--autotune-ms", type=float, default=30.0,
-                    help="GPU time lle_batch_autotune may spend per batch choosing its launch rules (0 = the library's default rules)")
+    ap.add_argument("--autotune-ms", type=float, default=None,
+                    help="GPU time lle_batch_autotune may spend on the headline batch choosing its launch rules (default: what a plain "
+                         "BatchedWorld(map, n) spends at construction -- BatchedWorld.AUTOTUNE_MS; 0 = the library's default rules)")
     ap.add_argument("--no-fused", action="store_true", help="skip the secondary fused-rollout measurement")
     ap.add_argument("--no-configs", action="store_true", help="skip roofline_hbm and the cfg2 / cfg5 blocks")
     ap.add_argument("--no-multi-map", action="store_true",
@@ -772,9 +773,10 @@ def main():
     if rank == 0 and check["status"] != "ok":
         print(f"bench.py: shard check FAILED: {check}", file=sys.stderr)
 
-    bw = BatchedWorld(Map(level=LEVEL), n, device=dev, envs_per_wave=args.envs_per_wave or None)
+    # the headline batch is what a user gets from the constructor: since round 5 BatchedWorld autotunes at construction (10 ms by default)
+    bw = BatchedWorld(Map(level=LEVEL), n, device=dev, envs_per_wave=args.envs_per_wave or None, autotune_ms=args.autotune_ms)
     offset = shard_offset(n, rank)
-    tuning = bw.autotune(args.autotune_ms) if args.autotune_ms > 0 and not args.envs_per_wave else bw.tuning()
+    tuning = dict(bw.tuning(), constructor_default=args.autotune_ms is None)
     step = stepper(bw, offset)
 
     bw.stats_blocks.zero_()  # (the first torch fill of the process loads a code object: not right in front of the timed region)

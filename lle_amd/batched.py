@@ -5,6 +5,7 @@ of include/lle_hip.h; torch only provides the device arena, the stream and (for 
 Every tensor below is a zero-copy view into the batch's arena and is overwritten by the next call.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -53,7 +54,13 @@ class BatchedWorld:
       err [n] u8 - evcount [n] u8 - events [n,2A] u8 (type<<4|agent) - done [n] u8 - obs [n,C,H,W] i8
     """
 
-    def __init__(self, map_or_text, n_envs, device=None, envs_per_wave=None, row_align=None, placement_candidates=None, obs_dtype=None):
+    # Batches from this size on run lle_batch_autotune at construction (AUTOTUNE_MS of GPU time): below it a launch is a few
+    # microseconds of latency whatever the rules say.  LLE_AUTOTUNE_MS in the environment overrides the budget (0: never).
+    AUTOTUNE_MIN_ENVS = 2048
+    AUTOTUNE_MS = 10.0
+
+    def __init__(self, map_or_text, n_envs, device=None, envs_per_wave=None, row_align=None, placement_candidates=None, obs_dtype=None,
+                 autotune_ms=None, incremental_obs=False):
         """`map_or_text`: a Map / map text, or a LIST of them for a batch of several maps -- map m then owns the envs
         [m * n_envs / len(maps), (m + 1) * n_envs / len(maps)); the maps must agree on height, width and the numbers of
         agents, sources and gems, and each must own a multiple of 16 envs (64 and more keep full workgroups).
@@ -64,7 +71,14 @@ class BatchedWorld:
         (profiles/r03_hbm_fronts.md: 5.8 ... 6.8 TB/s over twelve buffers of one process).  `self.placement` records the timings.
         `obs_dtype`: element type of `obs` and of the observation rings -- torch.int8 (default), torch.float16, torch.bfloat16 or
         torch.float32 (the reference's, python/lle/observations.py:223).  The kernels widen at the store (lle_batch_options.obs_dtype):
-        the tensor a learner reads comes out of the step launch in its own type, with the values of the int8 tensor."""
+        the tensor a learner reads comes out of the step launch in its own type, with the values of the int8 tensor.
+        `autotune_ms`: GPU time lle_batch_autotune may spend, right here, timing the step launcher's alternatives on this batch's own
+        arena (environments per wavefront, row heads, store policy, split rows, walk, rotation) -- None: AUTOTUNE_MS for batches of
+        AUTOTUNE_MIN_ENVS environments and more (the default since round 5: the product a caller gets is the product bench.py
+        measures), 0: the library's default rules.  Results never depend on it; `tuning()` says what was chosen.
+        `incremental_obs`: every in-place single step of this batch writes only the lines of a row that dynamic state can change
+        (LLE_STEP_INCREMENTAL_OBS; INTEGRATION.md section 5d says why this is an opt-in: the caller promises not to write into `obs`).
+        `check_obs()` verifies the buffer against the state at any time; LLE_DEBUG_CHECK_OBS=1 does so after every step."""
         _require_gpu()
         many = isinstance(map_or_text, (list, tuple))
         self.maps = [m if isinstance(m, Map) else Map(m) for m in (map_or_text if many else [map_or_text])]
@@ -107,6 +121,13 @@ class BatchedWorld:
             self.set_envs_per_wave(envs_per_wave)
         self._bind()
         self.t = 0
+        self.incremental_obs = bool(incremental_obs)
+        self._debug_check_obs = os.environ.get("LLE_DEBUG_CHECK_OBS", "0") == "1"
+        if autotune_ms is None:
+            env_ms = os.environ.get("LLE_AUTOTUNE_MS")
+            autotune_ms = float(env_ms) if env_ms not in (None, "") else (self.AUTOTUNE_MS if self.n_envs >= self.AUTOTUNE_MIN_ENVS else 0.0)
+        if autotune_ms and autotune_ms > 0 and envs_per_wave is None:  # (envs_per_wave selects the diagnostic lane-per-env kernel: nothing to tune)
+            self.autotune(autotune_ms)
 
     def _place(self, create, k):
         """k candidate arenas side by side (all alive until every one is timed: distinct physical memory), the row-fill
@@ -253,7 +274,7 @@ class BatchedWorld:
             flags |= LLE_STEP_RECOLOUR_RESETS
         if not write_obs:
             flags |= LLE_STEP_NO_OBS
-        if incremental_obs:  # only the lines of a row that dynamic state can change (LLE_STEP_INCREMENTAL_OBS): same content of `obs`
+        if incremental_obs or self.incremental_obs:  # only the lines of a row that dynamic state can change (LLE_STEP_INCREMENTAL_OBS): same content of `obs`
             flags |= LLE_STEP_INCREMENTAL_OBS
         if t is None:
             t = self.t
@@ -262,6 +283,11 @@ class BatchedWorld:
         else:
             self._check(_capi.lib().lle_batch_step(self.h, ap, flags, int(seed), int(t), int(env_offset), self._stream()))
         self.t = t + 1
+        if self._debug_check_obs and write_obs and not (env_out is not None and env_out.partial):
+            bad = self.check_obs()
+            if bad:
+                raise AssertionError(f"LLE_DEBUG_CHECK_OBS: the rows of {bad} environments differ from their state after step t={t} "
+                                     "(an incremental step over a buffer somebody else wrote into?)")
 
     def sampled_stepper(self, auto_reset=True, seed=0, env_offset=0, write_obs=True, incremental_obs=False):
         """A zero-argument callable for hot loops: one `step(sample=True, ...)` per call with the arguments and the
@@ -269,7 +295,7 @@ class BatchedWorld:
         and nothing else per step (`step()` itself spends a few microseconds in Python per launch)."""
         fn, h, dev = _capi.lib().lle_batch_step, self.h, self.device
         flags = (LLE_STEP_SAMPLE_ACTIONS | (LLE_STEP_AUTO_RESET if auto_reset else 0) | (0 if write_obs else LLE_STEP_NO_OBS) |
-                 (LLE_STEP_INCREMENTAL_OBS if incremental_obs else 0))
+                 (LLE_STEP_INCREMENTAL_OBS if (incremental_obs or self.incremental_obs) else 0))
         seed, env_offset = int(seed), int(env_offset)
 
         def one_step():
@@ -377,6 +403,20 @@ class BatchedWorld:
         self._check(_capi.lib().lle_batch_observe(self.h, self._stream()))
         return self.obs
 
+    def check_obs(self):
+        """Debug aid: the number of environments whose row of `obs` (the padding must be zero) differs from the layered observation of their
+        CURRENT state, rebuilt in full by another kernel into a scratch buffer (lle_batch_observe_as(LLE_OBS_LAYERED)).  0 after any step /
+        reset / observe / source update -- unless somebody wrote into `obs` between two incremental steps (LLE_STEP_INCREMENTAL_OBS
+        leaves the static lines alone) or an observation-less step (write_obs=False) came last.  Costs a pass over the rows: not for hot loops."""
+        d = self.obs_desc(_capi.LLE_OBS_LAYERED, 0)
+        if not d.supported:
+            return 0
+        want = self.observe_as(_capi.LLE_OBS_LAYERED, 0)  # int8 [n, C, H, W] over rows of the same pitch
+        nb = self.map.obs_bytes
+        rows = torch.as_strided(want, (self.n_envs, nb), (int(d.stride[0]), 1))
+        pad = self.obs_rows[:, nb:]
+        return int(((self.obs_rows[:, :nb] != rows.to(self.obs_dtype)).any(dim=1) | (pad != 0).any(dim=1)).sum())
+
     # ---- the other observation builders (SURVEY section 8(f) rank 3; python/lle/observations.py)
     def obs_desc(self, kind, param=0):
         d = _capi.ObsDesc()
@@ -466,7 +506,7 @@ class BatchedWorld:
         """`fn(actions)` = step(actions, ...) with the flags, the stream and the output struct fixed; `actions` must already be a
         contiguous uint8 [n, A] tensor on this device (no conversion, no checks).  The time index advances by one per call."""
         flags = ((LLE_STEP_AUTO_RESET if auto_reset else 0) | (LLE_STEP_RECOLOUR_RESETS if recolour_resets else 0) |
-                 (0 if write_obs else LLE_STEP_NO_OBS) | (LLE_STEP_INCREMENTAL_OBS if incremental_obs else 0))
+                 (0 if write_obs else LLE_STEP_NO_OBS) | (LLE_STEP_INCREMENTAL_OBS if (incremental_obs or self.incremental_obs) else 0))
         L, h, dev, seed, env_offset = _capi.lib(), C.c_void_p(self.h), self.device, int(seed), int(env_offset)
         fn = L.lle_batch_step_outputs if env_out is not None else L.lle_batch_step
         tail = (C.byref(env_out),) if env_out is not None else ()

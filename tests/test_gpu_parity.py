@@ -621,9 +621,10 @@ def test_autotune_changes_rules_not_results(oracle_mod):
     from lle_amd import BatchedWorld, mapgen
 
     for text, n in ((LEVELS[6], 4096 + 37), (mapgen.config5(3), 512)):
-        a, b = BatchedWorld(text, n), BatchedWorld(text, n)
+        a, b = BatchedWorld(text, n, autotune_ms=0), BatchedWorld(text, n, autotune_ms=0)
         before = a.tuning()
         assert before["autotuned"] == 0 and before["log"] == ""
+        assert BatchedWorld(text, 2048).tuning()["autotuned"] == 1 and BatchedWorld(text, 2047).tuning()["autotuned"] == 0  # (the constructor's default)
         for t in range(3):  # (mid-episode state: autotune must end on the reset state whatever came before)
             a.step(sample=True, auto_reset=True, seed=9, t=t)
         tuned = a.autotune(budget_ms=5.0)
@@ -658,7 +659,7 @@ def test_autotune_many_agents_keeps_the_counter_slots(oracle_mod):
     from lle_amd import BatchedWorld, _capi, mapgen
 
     for text, n in ((EXTRA_MAPS["many_agents"], 65536), (mapgen.config5(1), 32768)):
-        bw = BatchedWorld(text, n)
+        bw = BatchedWorld(text, n, autotune_ms=0)
         assert bw.kernel_info()["envs_per_wave"] >= 4
         guard = [bw.req_pos, bw.req_gems, bw.req_alive, bw.src_colour, bw.src_enabled]
         for g in guard:
@@ -863,3 +864,38 @@ def test_incremental_observation_on_split_rows_and_several_maps(oracle_mod):
     for t in range(8):
         c.step(sample=True, auto_reset=True, seed=5, t=t, incremental_obs=True)
         check(c, ob, ob.step(None, auto_reset=True, seed=5, t=t), f"cfg5 incremental t={t}")
+
+
+def test_check_obs_finds_a_tampered_row_and_incremental_is_a_batch_option(oracle_mod, monkeypatch):
+    """incremental rows are an opt-in because the caller promises not to write into `obs`.  The opt-in can be
+    given once, at construction; `check_obs()` is the debug check of that promise (the rows rebuilt in full from the state by another
+    kernel and compared), LLE_DEBUG_CHECK_OBS=1 runs it after every step."""
+    import torch
+
+    from lle_amd import BatchedWorld
+
+    n = 300
+    for dt in (None, torch.float16):
+        a, b = BatchedWorld(LEVELS[6], n, incremental_obs=True, obs_dtype=dt), BatchedWorld(LEVELS[6], n, obs_dtype=dt)
+        ob = oracle_mod.OracleBatch(LEVELS[6], n)
+        for t in range(10):
+            a.step(sample=True, auto_reset=True, seed=4, t=t)   # (incremental: the batch's own default)
+            b.step(sample=True, auto_reset=True, seed=4, t=t)
+            assert torch.equal(a.obs_rows, b.obs_rows) and a.check_obs() == 0 and b.check_obs() == 0
+            ostep = ob.step(None, auto_reset=True, seed=4, t=t)
+            if dt is None:
+                check(a, ob, ostep, f"incremental batch t={t}")
+        first, nbytes = a.map.row_head   # static lines of the row (never rewritten by an incremental step)
+        assert nbytes > 0
+        a.obs_rows[7, first] = 1         # the caller breaks the promise ...
+        a.obs_rows[11, first + 5] = -1
+        a.step(sample=True, auto_reset=True, seed=4, t=10)
+        assert a.check_obs() == 2        # ... and the check says so (an incremental step does not repair static lines)
+        a.observe()                      # a full rewrite does
+        assert a.check_obs() == 0
+    monkeypatch.setenv("LLE_DEBUG_CHECK_OBS", "1")
+    c = BatchedWorld(LEVELS[6], n, incremental_obs=True)
+    c.step(sample=True, seed=1, t=0)
+    c.obs_rows[3, c.map.row_head[0]] = 1
+    with pytest.raises(AssertionError, match="LLE_DEBUG_CHECK_OBS"):
+        c.step(sample=True, seed=1, t=1)
