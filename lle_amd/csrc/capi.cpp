@@ -156,6 +156,12 @@ struct lle_batch {
     // what lle_batch_autotune chose for this batch's step launches (kernels.h StepTune) and the log of its trials
     StepTune tune{};
     std::string tune_log;
+    // the window sets of the partial k x k observation (tables.h), k = 3, 5, 7: one table per map, uploaded when the batch first writes that
+    // window; dropped with the views when a map changes (exits)
+    uint8_t* win_sets[3] = {nullptr, nullptr, nullptr};
+    // lle_batch_observe_as(LLE_OBS_PARTIAL, k): the variant of the lane kernel measured fastest on this batch (window sets or bitmap, environments
+    // per batch), chosen at the first call for that k; 0 = not decided
+    struct PartialChoice { uint8_t decided = 0, use_sets = 0, E = 0; } partial_choice[16];
     // element type of LLE_BUF_OBS and of the observation rings (tables.h ObsElem; lle_batch_options.obs_dtype): the kernels widen at the store
     uint32_t obs_et = OBS_I8;
     uint64_t row_pitch() const { return (uint64_t)hdr.obs_stride << obs_elem_shift(obs_et); }  // bytes between the rows of two environments
@@ -670,6 +676,36 @@ static void drop_views(lle_batch* b) {
     for (auto& kv : b->views)
         if (kv.second.dev) (void)hipFree(kv.second.dev);
     b->views.clear();
+    for (auto& w : b->win_sets) {
+        if (w) (void)hipFree(w);
+        w = nullptr;
+    }
+}
+
+// Device copy of the window sets of window size k (tables.h): one table of win_set_bytes(HW) per map; NULL for the other sizes.
+static int get_win_sets(lle_batch* b, int k, hipStream_t st, const uint8_t** out) {
+    *out = nullptr;
+    if (!win_sets_serve(k) || getenv("LLE_PARTIAL_NO_SETS")) return LLE_OK;  // (LLE_PARTIAL_NO_SETS: the bitmap path for every size -- A/B and cross-check)
+    uint8_t*& dev = b->win_sets[(k - 3) / 2];
+    if (!dev) {
+        const size_t each = win_set_bytes(b->hdr.HW);
+        std::vector<uint8_t> all(each * b->maps.size());
+        for (size_t m = 0; m < b->maps.size(); m++) {
+            const std::vector<uint8_t> one = b->maps[m].window_sets(k);
+            std::memcpy(all.data() + m * each, one.data(), each);
+        }
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, all.size()));
+        hipError_t e = hipMemcpyAsync(p, all.data(), all.size(), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);  // (a host temporary)
+        if (e != hipSuccess) {
+            (void)hipFree(p);
+            return fail(LLE_ERR_HIP, std::string("window sets upload: ") + hipGetErrorString(e));
+        }
+        dev = static_cast<uint8_t*>(p);
+    }
+    *out = dev;
+    return LLE_OK;
 }
 
 void lle_batch_free(lle_batch* b) {
@@ -808,6 +844,10 @@ int lle_batch_step_outputs(lle_batch* b, const uint8_t* actions_dev, uint32_t fl
     K.flags = flags & STEP_PUBLIC_FLAGS; K.seed = seed; K.t = t; K.env_offset = env_offset; K.actions_in = actions_dev;
     K.out = O; K.env_out = reinterpret_cast<const EnvOutputs*>(b->arena + b->layout.off_env_out);  // (non-NULL: "outputs wanted"; never read)
     K.partial_k = O.partial ? O.partial_k : 0u; K.partial_E = partial_E;
+    if (O.partial) {  // (the launcher uses the window sets where they do not cost the launch a workgroup per CU: kernels.hip launch_step_kernel)
+        int rc = get_win_sets(b, (int)O.partial_k, (hipStream_t)stream, &K.win_sets);
+        if (rc != LLE_OK) return rc;
+    }
     if (O.partial && (flags & STEP_RECOLOUR_RESETS)) return fail(LLE_ERR_UNSUPPORTED, "the partial observation of the step launch: the map's own sources only");
     return launch(b, KMODE_STEP, K, stream);
 }
@@ -1051,7 +1091,48 @@ int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64
             for (const Map& mp : b->maps)
                 n_entities = std::max<uint32_t>(n_entities, (uint32_t)(mp.walls.size() + mp.exits.size() + mp.gems.size() + mp.n_laser_tiles() +
                                                                     mp.sources.size()));
-            HIP_TRY(launch_partial_observe(h, b->ptrs, static_cast<int8_t*>(out_dev), param, b->n_envs, b->per_env_sources, M, n_entities, reverse, st));
+            const uint8_t* win = nullptr;
+            rc = get_win_sets(b, param, st, &win);
+            if (rc != LLE_OK) return rc;
+            // Window sets cut a third of the lane kernel's vector instructions (2 464 -> 1 876 per wavefront at 7 x 7 on level 6) but cost LDS --
+            // 24 B per cell against a bitmap of a few hundred bytes -- and whether that drops a workgroup per CU depends on the map, the
+            // window and the environments per batch together (profiles/r05_partial.md).  So the first call for a window size times the four
+            // neighbours of the rule on THIS batch (sets or bitmap x the rule's E or half of it; identical bytes, a few hundred microseconds
+            // once, one synchronisation of `stream`) and later calls launch the winner.  The LLE_PARTIAL_* overrides switch the trial off.
+            lle_batch::PartialChoice& ch = b->partial_choice[param & 15];
+            const Tuning& tn = tuning();
+            const bool overridden = tn.partial_e || tn.partial_kernel || tn.partial_project >= 0 || tn.partial_batches || getenv("LLE_PARTIAL_NO_SETS") || getenv("LLE_PARTIAL_NO_TRIAL");
+            if (!ch.decided && win && !overridden && b->n_envs >= 4096) {
+                uint32_t rule = 0;
+                HIP_TRY(launch_partial_observe(h, b->ptrs, static_cast<int8_t*>(out_dev), param, b->n_envs, b->per_env_sources, M, n_entities, reverse, st, nullptr, 0, &rule));
+                hipEvent_t e0, e1;
+                HIP_TRY(hipEventCreate(&e0));
+                if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return fail(LLE_ERR_HIP, "hipEventCreate"); }
+                float best = 0.f;
+                hipError_t err = hipSuccess;
+                for (int v = 0; v < 4 && rule && err == hipSuccess; v++) {
+                    const bool sets = (v & 1) != 0;
+                    const uint32_t E = (v & 2) ? rule / 2u : rule;
+                    if (!E) continue;
+                    for (int i = 0; i < 6 && err == hipSuccess; i++) {  // two warm-ups, four timed
+                        if (i == 2) err = hipEventRecord(e0, st);
+                        if (err == hipSuccess)
+                            err = launch_partial_observe(h, b->ptrs, static_cast<int8_t*>(out_dev), param, b->n_envs, b->per_env_sources, M, n_entities, reverse, st, sets ? win : nullptr, E);
+                    }
+                    float ms = 0.f;
+                    if (err == hipSuccess) err = hipEventRecord(e1, st);
+                    if (err == hipSuccess) err = hipEventSynchronize(e1);
+                    if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+                    if (err == hipSuccess && (!ch.decided || ms < best)) { best = ms; ch.decided = 1; ch.use_sets = sets ? 1 : 0; ch.E = (uint8_t)E; }
+                }
+                (void)hipEventDestroy(e0);
+                (void)hipEventDestroy(e1);
+                if (err != hipSuccess) return fail(LLE_ERR_HIP, std::string("partial observer trial: ") + hipGetErrorString(err));
+            }
+            const bool use = ch.decided ? ch.use_sets != 0 : false;  // (undecided -- small batches, overrides: the bitmap form and the rule's E, as before round 5; LLE_PARTIAL_SETS=1 forces the sets)
+            const bool force_sets = getenv("LLE_PARTIAL_SETS") != nullptr;
+            HIP_TRY(launch_partial_observe(h, b->ptrs, static_cast<int8_t*>(out_dev), param, b->n_envs, b->per_env_sources, M, n_entities, reverse, st,
+                                           (use || force_sets) ? win : nullptr, ch.decided ? ch.E : 0u));
             break;
         }
         default:
@@ -1138,6 +1219,7 @@ static int push_map(lle_batch* b, int map_index, const lle_map* map, bool broadc
     b->hdr = new_common;
     b->worst_table_bytes = new_worst;
     drop_views(b);  // their tables depend on the colours and the exits (the stream is idle: synchronised above)
+    for (auto& c : b->partial_choice) c = lle_batch::PartialChoice();
     int rc = refresh_init_record(b, stream);
     if (rc != LLE_OK) return rc;
     if (b->per_env_sources) {

@@ -727,11 +727,13 @@ bool rotate_rows_pays(const StepTune& tune, uint64_t row_bytes_per_launch, uint3
 
 // ---- step_kernel MODE 9: LDS of a workgroup and the writer's batch size (partial_stream.hpp; the rule of observers.hip's lane kernel:
 // the largest E whose block of rows stays within 16 KiB per wavefront, halved above 9 KiB while the observer's lanes stay busy)
-static uint32_t partial_step_lds(const MapHeader& h, uint32_t wpw, uint32_t E, int k, uint32_t epw = 64u) {
+// (`sets`: the launch carries the window sets of k -- tables.h -- instead of building the map's non-empty bitmap)
+static uint32_t partial_step_lds(const MapHeader& h, uint32_t wpw, uint32_t E, int k, uint32_t epw = 64u, bool sets = false) {
     const uint32_t scr_stride = (h.L + h.A + 2) | 1u, pitch = ((h.A * (2 * h.A + 3)) * (uint32_t)(k * k) + 15u) & ~15u;
     uint32_t tab = ((h.off_dyn - h.off_cell_lay) + 1023u) & ~1023u;
     if (tab > h.lds_table_bytes) tab = h.lds_table_bytes;
-    return tab + (h.L > 4 ? 256u : 0u) + partial_bitmap_bytes(h.H, h.W) + 32u + wpw * (E * pitch + 16u + ((epw * scr_stride * 4u + 15u) & ~15u)) + 64u;
+    const uint32_t window = sets ? win_set_bytes(h.HW) : partial_bitmap_bytes(h.H, h.W);
+    return tab + (h.L > 4 ? 256u : 0u) + window + 32u + wpw * (E * pitch + 16u + ((epw * scr_stride * 4u + 15u) & ~15u)) + 64u;
 }
 uint32_t step_partial_batch(const MapHeader& h, int k, bool pes) {
     if (pes || step_lm((int)h.L) > 8 || k < 1 || k > 15 || !(k & 1)) return 0u;
@@ -747,7 +749,7 @@ uint32_t step_partial_batch(const MapHeader& h, int k, bool pes) {
     }
     if (const uint32_t v = (uint32_t)tuning().partial_e)  // LLE_PARTIAL_E: tuning override (a power of two whose lanes still cover a window's rows)
         if (!(v & (v - 1)) && v * a_pad <= 64u && 64u / (v * a_pad) >= s_min) E = v;
-    return partial_step_lds(h, 1, E, k) <= LDS_PER_CU ? E : 0u;
+    return partial_step_lds(h, 1, E, k, 64u, win_sets_serve(k)) <= LDS_PER_CU ? E : 0u;
 }
 
 bool step_has_row_heads(const MapHeader& h, bool pes) {
@@ -799,12 +801,20 @@ hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const Laun
     if (K.partial_k) {  // the partial observation written by this launch (MODE 9): single steps with the fused outputs, the map's sources
         if (pes || roll_requested(K) || !K.env_out || !K.partial_E || lm > 8) return hipErrorInvalidValue;
         const uint32_t cap = 64u / (uint32_t)G, e = epw < cap ? epw : cap;  // environments (= records) per wavefront
+        // the window sets (tables.h; a third fewer vector instructions in the writer) where they do not cost the launch a workgroup per CU:
+        // a launch of this kernel is ONE round of workgroups, and 24 B per cell of sets against a bitmap of a few hundred bytes can be the
+        // difference between four per CU and three (level 6, 7 x 7: 39.2 -> 42.1 KB; profiles/r05_partial.md).  LLE_PARTIAL_SETS=1 forces them.
+        bool sets = K.win_sets != nullptr && win_sets_serve((int)K.partial_k);
+        if (sets && !getenv("LLE_PARTIAL_SETS") &&
+            LDS_PER_CU / partial_step_lds(h, 4, K.partial_E, (int)K.partial_k, e, true) < LDS_PER_CU / partial_step_lds(h, 4, K.partial_E, (int)K.partial_k, e, false))
+            sets = false;
+        if (!sets) K.win_sets = nullptr;
         wpw = 4;
-        while (wpw > 1 && partial_step_lds(h, wpw, K.partial_E, (int)K.partial_k, e) > LDS_PER_CU / 2) wpw >>= 1;  // (two workgroups per CU at least)
+        while (wpw > 1 && partial_step_lds(h, wpw, K.partial_E, (int)K.partial_k, e, sets) > LDS_PER_CU / 2) wpw >>= 1;  // (two workgroups per CU at least)
         if (K.envs_per_map)
             while (wpw > 1 && K.envs_per_map % (int64_t)(wpw * e) != 0) wpw >>= 1;
         K.flags &= ~LAUNCH_SPLIT_ROWS;
-        return launch_step_mode9(G, lm, P, K, n_waves, wpw, partial_step_lds(h, wpw, K.partial_E, (int)K.partial_k, e), stream);
+        return launch_step_mode9(G, lm, P, K, n_waves, wpw, partial_step_lds(h, wpw, K.partial_E, (int)K.partial_k, e, sets), stream);
     }
     // MODE of the instantiation (step_kernel.hpp): per-env sources 3 / 5, several maps 2 / 4, one map 1 / 0 -- the
     // first of each pair with the rollout loop, rings and stamps, the second for single-step launches

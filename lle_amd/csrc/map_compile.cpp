@@ -653,6 +653,27 @@ void Map::compile() {
     header = h;
 }
 
+// The window sets of the partial k x k observation (tables.h): [HW][3] u64, padded to whole 1-KiB rows.
+std::vector<uint8_t> Map::window_sets(int k) const {
+    const int HW = H * W, centre = k / 2;
+    std::vector<uint8_t> out(win_set_bytes((uint32_t)HW), 0);
+    uint64_t* sets = reinterpret_cast<uint64_t*>(out.data());
+    for (int pi = 0; pi < H; pi++)
+        for (int pj = 0; pj < W; pj++)
+            for (int wi = 0; wi < k; wi++)
+                for (int wj = 0; wj < k; wj++) {
+                    const int i = pi - centre + wi, j = pj - centre + wj;
+                    if (i < 0 || j < 0 || i >= H || j >= W) continue;  // (outside the map: nothing, observations.py:331-340)
+                    const int c = i * W + j;
+                    const uint64_t bit = 1ull << (wi * k + wj);
+                    uint64_t* e = sets + (size_t)(pi * W + pj) * 3;
+                    if (kind[c] == K_WALL || kind[c] == K_SOURCE) e[0] |= bit;   // wall_pos holds the sources too (parser_v1.rs:22-25)
+                    if (kind[c] == K_EXIT) e[1] |= bit;
+                    if (kind[c] == K_GEM || kind[c] == K_SOURCE || !cell_layers[c].empty()) e[2] |= bit;
+                }
+    return out;
+}
+
 // World::set_exit_positions, src/core/world.rs:195-234.  The reference swaps tile objects: `Exit{agent}` -> `Floor{agent}`
 // for every current exit, then `Floor{agent}` -> `Exit{agent}` for every new one; under a beam `Laser::set_tile`
 // (laser.rs:109-115) replaces the INNERMOST tile whatever it is.  Here the innermost tile is `kind[cell]` and the

@@ -17,6 +17,7 @@
 #include "kernels.h"
 #include "obs_stream.hpp"
 #include "observers_logic.hpp"
+#include "partial_stream.hpp"
 #include "tables.h"
 
 // (kernels.h debug registry: one relaxed load per launch)
@@ -426,7 +427,8 @@ __global__ void __launch_bounds__(256) partial_project_kernel(BatchPtrs P, int8_
 struct PartialDims { int32_t A, L, H, W; uint32_t off_cell_meta, max_layers; };  // common to the maps of a batch; off_cell_meta relative to off_cell_lay
 __global__ void __launch_bounds__(256) partial_lanes_kernel(BatchPtrs P, int8_t* __restrict__ out, int k, uint32_t pitch, int64_t env_base,
                                                             int64_t env_limit, int per_env_sources, MapSel M, uint32_t E, uint32_t batches,
-                                                            uint32_t tab_bytes, int wt, PartialDims D, uint32_t tab_off, uint32_t walk) {
+                                                            uint32_t tab_bytes, int wt, PartialDims D, uint32_t tab_off, uint32_t walk,
+                                                            const uint8_t* __restrict__ win_sets, uint32_t win_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t lane = threadIdx.x & 63u, wave_in_wg = threadIdx.x >> 6, waves_per_wg = blockDim.x >> 6;
     const uint32_t blk = xcd_block_dir(blockIdx.x, gridDim.x, walk);
@@ -465,27 +467,29 @@ __global__ void __launch_bounds__(256) partial_lanes_kernel(BatchPtrs P, int8_t*
     uint32_t rv[RV], rat[RV];
 #pragma unroll
     for (int q = 0; q < RV; q++) rv[q] = rec_word(lane + 64u * (uint32_t)q, rat[q]);
-    copy_tables_to_lds(tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
-    // ---- the non-empty bitmap: (H + 16) rows of RW words, cell (i, j) at row i + 8, bit j + 8
-    const uint32_t RW = ((uint32_t)W + 16u + 31u) / 32u + 1u, bm_words = (uint32_t)(H + 16) * RW, bm_bytes = (bm_words * 4u + 15u) & ~15u;
-    uint32_t* bm = reinterpret_cast<uint32_t*>(lds + tab_bytes);
-    for (uint32_t w = threadIdx.x; w < bm_words; w += blockDim.x) bm[w] = 0u;
-    __syncthreads();  // (also: the table copy has landed)
+    // behind the cell tables: the window sets of this window size (tables.h; k = 3, 5, 7: copied with the tables, `win_sets` = this launch's
+    // tables, win_bytes apart per map) -- or, for the other sizes, the non-empty bitmap of the map, built here from the cell tables
     const uint64_t* cell_lay = reinterpret_cast<const uint64_t*>(lds);
     const uint32_t* cell_meta = reinterpret_cast<const uint32_t*>(lds + D.off_cell_meta);
-    for (uint32_t c = threadIdx.x; c < (uint32_t)(H * W); c += blockDim.x) {
-        if ((cell_meta[c] & 7u) != K_FLOOR || cell_lay[c] != 0ull) {
-            const uint32_t i = c / (uint32_t)W, j = c - i * (uint32_t)W;
-            atomicOr(&bm[(i + 8u) * RW + ((j + 8u) >> 5)], 1u << ((j + 8u) & 31u));
-        }
+    const uint32_t RW = partial_bitmap_row_words((uint32_t)W), bm_words = (uint32_t)(H + 16) * RW;
+    const uint32_t bm_bytes = win_sets ? win_bytes : (bm_words * 4u + 15u) & ~15u;
+    uint32_t* bm = reinterpret_cast<uint32_t*>(lds + tab_bytes);
+    if (win_sets) {
+        const uint64_t map_idx = M.envs_per_map ? (uint64_t)(env_base + (int64_t)(blk * waves_per_wg) * epw) / (uint64_t)M.envs_per_map : 0ull;
+        copy_tables2_to_lds(tables + tab_off, tab_bytes, win_sets + map_idx * win_bytes, win_bytes, lds, lane, wave_in_wg, waves_per_wg);
+        __syncthreads();
+    } else {
+        copy_tables_to_lds(tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
+        for (uint32_t w = threadIdx.x; w < bm_words; w += blockDim.x) bm[w] = 0u;
+        __syncthreads();  // (also: the table copy has landed)
+        partial_bitmap_fill(bm, cell_lay, cell_meta, H, W);
+        __syncthreads();
     }
-    __syncthreads();
+    const uint64_t* sets = win_sets ? reinterpret_cast<const uint64_t*>(bm) : nullptr;
     // ---- who this lane is: environment slot e of the batch, observer a, share s of S of the window rows
     const uint32_t logA = A <= 1 ? 0u : (A <= 2 ? 1u : (A <= 4 ? 2u : (A <= 8 ? 3u : 4u)));
     const uint32_t S = 64u / (E << logA);                 // lanes per (env, observer); the launcher keeps E << logA <= 64
     const uint32_t e_slot = lane / (S << logA), a = (lane / S) & ((1u << logA) - 1u), s = lane % S;
-    const uint32_t SBL = k <= 8 ? 3u : 4u;                // a window row takes 8 (k <= 8) or 16 bits of the lane's 64-bit set
-    const int centre = k / 2;
     const uint32_t kk = (uint32_t)(k * k), layers = (uint32_t)(2 * A + 3), n_chunks = pitch / 16u;
     const uint32_t rec_bytes = (epw * rec_dwords * 4u + 15u) & ~15u;
     const uint32_t priv_bytes = E * pitch + rec_bytes + 16u;
@@ -493,7 +497,6 @@ __global__ void __launch_bounds__(256) partial_lanes_kernel(BatchPtrs P, int8_t*
     uint32_t* recs_all = reinterpret_cast<uint32_t*>(rows + E * pitch);
     uint4* rows16 = reinterpret_cast<uint4*>(rows);
     const uint32_t colour_at = (uint32_t)(As / 2 + 1 + L) * 4u;  // byte offset of the colour bytes in a record
-    const int WALL = A, LASER_0 = A + 1, GEM = 2 * A + 1, EXIT = 2 * A + 2;   // observations.py:318-323
 #pragma unroll
     for (int q = 0; q < RV; q++)
         if (rat[q] != 0xFFFFFFFFu) recs_all[rat[q]] = rv[q];
@@ -502,9 +505,9 @@ __global__ void __launch_bounds__(256) partial_lanes_kernel(BatchPtrs P, int8_t*
         const uint32_t v = rec_word(idx, at);
         if (at != 0xFFFFFFFFu) recs_all[at] = v;
     }
-    // layer of the one static byte of a cell, by kind (0xFF: none): FLOOR, WALL, VOID, EXIT | GEM, SOURCE (wall_pos holds the sources too)
-    const uint32_t lt_lo = 0xFFu | ((uint32_t)WALL << 8) | (0xFFu << 16) | ((uint32_t)EXIT << 24), lt_hi = (uint32_t)GEM | ((uint32_t)WALL << 8) | 0xFFFF0000u;
     int8_t* dummy = rows + E * pitch + rec_bytes;   // 16 bytes nobody reads: where the writes of a cell that do not apply go
+    const PartialGeo G{A, W, k, kk, S, RW, D.max_layers > 1u};   // (two_layers, uniform: maps without crossing beams never look at a second layer)
+    const uint64_t share = sets ? partial_share_mask((uint32_t)k, S, s) : 0ull;
 
     for (uint32_t batch = 0; batch < batches; batch++) {
         const int64_t env0 = env_base + (int64_t)wave_id * epw + (int64_t)batch * E;
@@ -515,103 +518,10 @@ __global__ void __launch_bounds__(256) partial_lanes_kernel(BatchPtrs P, int8_t*
         for (uint32_t c = lane; c < (uint32_t)n_here * n_chunks; c += 64) rows16[c] = make_uint4(0u, 0u, 0u, 0u);
         wave_sync();  // LDS operations of a wavefront execute in order: everything below lands after the clears
         const bool live = e_slot < (uint32_t)n_here && a < (uint32_t)A;
-        const uint8_t* rec8 = reinterpret_cast<const uint8_t*>(recs + (live ? e_slot : 0u) * rec_dwords);
-        const uint16_t* pos = reinterpret_cast<const uint16_t*>(rec8);
-        const uint32_t pa = pos[live ? a : 0u];
-        const int i0 = (int)(pa & 0xFFu) - centre, j0 = (int)(pa >> 8) - centre;   // the window's origin on the map
+        const PartialRecPacked R{reinterpret_cast<const uint8_t*>(recs + (live ? e_slot : 0u) * rec_dwords), (uint32_t)(As / 2), colour_at};
         int8_t* mine = rows + __umul24(live ? e_slot : 0u, pitch) + __umul24(a, layers * kk);   // observer a's block of this env's row
-        // ---- other agents (dead ones included: agents_positions): lane s takes agents s, s + S, ...
-        if (live)
-            for (uint32_t a2 = s; a2 < (uint32_t)A; a2 += S) {
-                const uint32_t p2 = pos[a2];
-                const uint32_t dy = (uint32_t)((int)(p2 & 0xFFu) - i0), dx = (uint32_t)((int)(p2 >> 8) - j0);
-                if (dy < (uint32_t)k && dx < (uint32_t)k) mine[__umul24(a2, kk) + __umul24(dy, (uint32_t)k) + dx] = 1;
-            }
-        // ---- this lane's share of the window's non-empty cells: bit (r << SBL) + wj of `todo` = cell (wi_base + r * wi_step, wj).
-        // Windows up to 8 x 8 fit one 64-bit set whole, and the S lanes of an observer split it DIAGONALLY -- lane s takes the
-        // cells with (wi + wj) mod S == s -- so that a row of walls or a beam, the runs maps are made of, is spread over all of
-        // them (split by rows, the lane that holds the wall row decides the trip count of the whole wavefront: level 6 7x7
-        // 27.7 -> 25.x us).  Larger windows are split by rows (a lane's rows must fit its set: at most four of 16 bits).
-        // The set is kept as two dwords (rows [0, RH) and [RH, 2 RH) of the lane's rows, RH = 32 >> SBL): 32-bit find-first-set,
-        // shifts and clears instead of 64-bit ones, which cost two to four instructions each.
-        uint32_t todo2[2] = {0u, 0u};
-        const bool diag = k <= 8;
-        const uint32_t wi_base = diag ? 0u : s, wi_step = diag ? 1u : S, RH = 32u >> SBL;
-        if (live) {
-            const uint32_t off = (uint32_t)(j0 + 8);   // >= 1: bit of the window's first column in a bitmap row
-            const uint32_t rep = S >= 8 ? 0x01u : (S == 4 ? 0x11u : (S == 2 ? 0x55u : 0xFFu));   // every S-th bit of a row
-            const uint32_t kmask = (1u << k) - 1u;
-            uint32_t r = 0;
-            for (uint32_t wi = wi_base; wi < (uint32_t)k; wi += wi_step, r++) {
-                const uint32_t* rowp = bm + __umul24((uint32_t)(i0 + (int)wi + 8), RW) + (off >> 5);
-                uint32_t bits = __funnelshift_r(rowp[0], rowp[1], off & 31u) & kmask;   // v_alignbit_b32
-                if (diag) bits &= rep << ((s - wi) & (S - 1u));
-                const uint32_t sh = (r & (RH - 1u)) << SBL;
-                if (r < RH) todo2[0] |= bits << sh;
-                else todo2[1] |= bits << sh;
-            }
-        }
-        // One non-empty cell per pass, no branch inside: a cell has at most four bytes to give -- its static one (wall / exit /
-        // uncollected gem), the two laser layers World.lasers() exposes when lit, the -1 of a source -- and each is a store
-        // whose address is the byte, or `dummy` when it does not apply.  Every LDS read of a pass is issued before the first
-        // is needed.  (Write order = the reference's, observations.py:347-359; all four commute, see the kernel's header.)
-        const uint32_t* rec32 = reinterpret_cast<const uint32_t*>(rec8);
-        const int cell0 = i0 * W + j0;
-        const bool two_layers = D.max_layers > 1u;   // (uniform: maps without crossing beams never look at a second layer)
-        // Software-pipelined (round 4, as partial_stream.hpp): the (meta, layers) reads of the NEXT cell are issued ahead of the beam word /
-        // colour reads of the current one -- LDS returns in order, so a pass waits once instead of twice.
-        const uint32_t gems = rec32[As / 2];
-#pragma unroll
-        for (int half = 0; half < 2; half++) {
-            uint32_t todo = todo2[half];
-            uint32_t wi_n = 0, wj_n = 0, meta_n = 0;
-            uint64_t lay_n = 0;
-            bool have = todo != 0u;
-            if (have) {
-                const uint32_t b = (uint32_t)__builtin_ctz(todo);
-                todo &= todo - 1u;
-                const uint32_t r = (b >> SBL) + (half ? RH : 0u);
-                wj_n = b & ((1u << SBL) - 1u);
-                wi_n = mad24(r, wi_step, wi_base);   // (one full-rate v_mad_u32_u24 each: the compiler made quarter-rate 32-bit multiplies of __umul24 here)
-                const uint32_t cell = (uint32_t)cell0 + mad24(wi_n, (uint32_t)W, wj_n);
-                meta_n = cell_meta[cell];
-                lay_n = cell_lay[cell];
-            }
-            while (have) {
-                const uint32_t meta = meta_n, wi = wi_n, wj = wj_n;
-                const uint64_t lay = lay_n;
-                have = todo != 0u;
-                if (have) {   // the next cell's first round trip
-                    const uint32_t b = (uint32_t)__builtin_ctz(todo);
-                    todo &= todo - 1u;
-                    const uint32_t r = (b >> SBL) + (half ? RH : 0u);
-                    wj_n = b & ((1u << SBL) - 1u);
-                    wi_n = mad24(r, wi_step, wi_base);
-                    const uint32_t cell = (uint32_t)cell0 + mad24(wi_n, (uint32_t)W, wj_n);
-                    meta_n = cell_meta[cell];
-                    lay_n = cell_lay[cell];
-                }
-                const uint32_t kind = meta & 7u, idx = (meta >> 3) & 31u;
-                const uint32_t l0 = (uint32_t)lay & 0xFFFFu;   // World.lasers(): the two outer layers of a cell
-                const uint32_t b0 = (l0 >> 1) & 31u, o0 = (l0 >> 6) & 31u;
-                const uint32_t src = kind == K_SOURCE ? idx : 0u;   // idx = laser id of a source cell (gem index otherwise)
-                const uint32_t m0 = rec32[As / 2 + 1 + b0];
-                const uint32_t c0 = rec8[colour_at + b0], cs = rec8[colour_at + src];
-                const uint32_t lt = ((kind < 4u ? lt_lo : lt_hi) >> ((kind & 3u) * 8u)) & 0xFFu;
-                const bool en0 = lt != 0xFFu && !(kind == K_GEM && ((gems >> idx) & 1u));
-                const bool en1 = (l0 & LAY_VALID) && ((m0 >> o0) & 1u);
-                int8_t* cp = mine + mad24(wi, (uint32_t)k, wj);
-                if (two_layers) {
-                    const uint32_t l1 = (uint32_t)(lay >> 16) & 0xFFFFu, b1 = (l1 >> 1) & 31u, o1 = (l1 >> 6) & 31u;
-                    const uint32_t m1 = rec32[As / 2 + 1 + b1], c1 = rec8[colour_at + b1];
-                    const bool en2 = (l1 & LAY_VALID) && ((m1 >> o1) & 1u);
-                    *(en2 ? cp + __umul24((uint32_t)LASER_0 + c1, kk) : dummy) = 1;
-                }
-                *(en0 ? cp + __umul24(lt, kk) : dummy) = 1;
-                *(en1 ? cp + __umul24((uint32_t)LASER_0 + c0, kk) : dummy) = 1;
-                *(kind == K_SOURCE ? cp + __umul24((uint32_t)LASER_0 + cs, kk) : dummy) = -1;
-            }
-        }
+        // the lane's agents and its share of the window's non-empty cells (partial_stream.hpp: shared with the step kernel's writer)
+        partial_window(G, R, live, a, s, mine, dummy, cell_lay, cell_meta, bm, sets, share);
         wave_sync();
         uint4* __restrict__ dst = reinterpret_cast<uint4*>(out + (uint64_t)env0 * pitch);
         if (wt) stream_row<true>(dst, rows16, 0u, (uint32_t)n_here * n_chunks, lane);
@@ -847,7 +757,8 @@ static bool partial_projects(const MapHeader& h, int k, uint32_t n_entities) {
 }
 
 hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t* out, int k, int64_t n_envs, bool per_env_sources,
-                                  MapSel M, uint32_t n_entities, bool reverse, hipStream_t stream) {
+                                  MapSel M, uint32_t n_entities, bool reverse, hipStream_t stream, const uint8_t* win_sets, uint32_t force_E,
+                                  uint32_t* rule_E) {
     const uint32_t walk = reverse ? LAUNCH_REVERSE : 0u;
     const uint32_t pitch_l = partial_pitch((int)h.A, k);
     int force_old = -1;  // LLE_PARTIAL_KERNEL=window / project: one of the two round-1/2 kernels (kept as cross-checks)
@@ -871,6 +782,8 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
                 const uint32_t S2 = 64u / ((E / 2u) * a_pad), rl = ((uint32_t)k + S2 - 1u) / S2;
                 if (S2 <= (uint32_t)k && 4u * (uint32_t)k >= 3u * S2 * rl) E >>= 1;
             }
+            if (rule_E) *rule_E = E;  // (what the rule says: lle_batch_observe_as times its neighbours once per batch and window size)
+            if (force_E >= 1 && force_E <= e_max && !(force_E & (force_E - 1))) E = force_E;
             if (const uint32_t v = (uint32_t)tuning().partial_e) {
                 if (v >= 1 && v <= e_max && !(v & (v - 1))) E = v;
             }
@@ -878,7 +791,9 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
             const uint32_t rec_dwords = As_l / 2 + 1 + h.L + (uint32_t)src_stride_of((int)h.L) / 4u;
             uint32_t tab = (h.off_dyn - h.off_cell_lay + 1023u) & ~1023u;
             if (tab > h.lds_table_bytes) tab = h.lds_table_bytes;
-            const uint32_t RW = (h.W + 16u + 31u) / 32u + 1u, bm_bytes = ((h.H + 16u) * RW * 4u + 15u) & ~15u;
+            // (behind the cell tables: the window sets of this size, or the map's non-empty bitmap)
+            const uint32_t win_bytes = win_sets ? win_set_bytes(h.HW) : 0u;
+            const uint32_t bm_bytes = win_sets ? win_bytes : partial_bitmap_bytes(h.H, h.W);
             // batches per wavefront: a workgroup copies the tables and builds the bitmap before its first row, so a launch should
             // be ONE round of workgroups (about four per CU): 65 536 envs -> 16 environments per wavefront, i.e. batches = 16 / E
             uint32_t batches = 1;
@@ -906,7 +821,7 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
                 const PartialDims D{(int32_t)h.A, (int32_t)h.L, (int32_t)h.H, (int32_t)h.W, h.off_cell_meta - h.off_cell_lay, h.max_layers};
                 LLE_NOTE_OBS(OBSK_PARTIAL_LANES);
                 hipLaunchKernelGGL(partial_lanes_kernel, dim3((n_waves + wpw - 1) / wpw), dim3(64 * wpw), lds, stream, P, out, k, pitch_l,
-                                   (int64_t)0, n_envs, per_env_sources ? 1 : 0, M, E, batches, tab, wt, D, h.off_cell_lay, walk);
+                                   (int64_t)0, n_envs, per_env_sources ? 1 : 0, M, E, batches, tab, wt, D, h.off_cell_lay, walk, win_sets, win_bytes);
                 return hipGetLastError();
             }
         }

@@ -110,9 +110,10 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     const uint32_t wave_id = blk * waves_per_wg + wave_in_wg;
     const uint8_t* __restrict__ tables = P.tables;
     const InitRecord* __restrict__ initp = P.init;
+    uint32_t map_idx = 0u;
     if (GEN) {  // this workgroup's map (its envs never straddle two maps: the launcher sizes workgroups accordingly)
         const uint32_t EPW0 = K.envs_per_wave < (uint32_t)(64 / G) ? K.envs_per_wave : (uint32_t)(64 / G);
-        const uint32_t map_idx = map_index_of(K, K.env_base + (int64_t)(blk * waves_per_wg) * EPW0);
+        map_idx = map_index_of(K, K.env_base + (int64_t)(blk * waves_per_wg) * EPW0);
         tables += (uint64_t)map_idx * K.table_stride;
         initp += map_idx;
     }
@@ -304,8 +305,11 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     const uint32_t tab_cells = ((hdr->off_dyn - tab_off) + 1023u) & ~1023u;
     const uint32_t tab_bytes = PARTIAL ? (tab_cells < hdr->lds_table_bytes ? tab_cells : hdr->lds_table_bytes)
                                        : (split ? hdr->lds_split_table_bytes : hdr->lds_table_bytes);
-    const uint32_t ext_bytes = PES ? hdr->ext_bytes : 0u;
+    // (PARTIAL, windows of 3 / 5 / 7: the window sets of the launch's window size come in with the tables, right behind them -- tables.h)
+    const bool use_sets = PARTIAL && K.win_sets != nullptr;
+    const uint32_t ext_bytes = PES ? hdr->ext_bytes : (use_sets ? win_set_bytes(hdr->HW) : 0u);
     if (PES) copy_tables2_to_lds(tables + tab_off, tab_bytes, tables + h_off_bare, ext_bytes, lds, lane, wave_in_wg, waves_per_wg);
+    else if (use_sets) copy_tables2_to_lds(tables + tab_off, tab_bytes, K.win_sets + (uint64_t)map_idx * ext_bytes, ext_bytes, lds, lane, wave_in_wg, waves_per_wg);
     else copy_tables_to_lds(tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
     constexpr uint32_t bt_bytes = BM ? 2u * LM * 4u : 0u;
     uint32_t* beam_tab = reinterpret_cast<uint32_t*>(lds + tab_bytes + ext_bytes);
@@ -314,7 +318,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         beam_tab[LM + threadIdx.x] = bt_init;
     }
     // PARTIAL: [non-empty bitmap of the map | colour byte of every beam word] behind the tables, one copy per workgroup
-    const uint32_t pm_bytes = PARTIAL ? partial_bitmap_bytes(hdr->H, (uint32_t)W) + 32u : 0u;
+    const uint32_t pm_bytes = PARTIAL ? (use_sets ? 0u : partial_bitmap_bytes(hdr->H, (uint32_t)W)) + 32u : 0u;
     uint32_t* const part_bm = reinterpret_cast<uint32_t*>(lds + tab_bytes + ext_bytes + bt_bytes);
     uint8_t* const part_col = lds + tab_bytes + ext_bytes + bt_bytes + (pm_bytes - 32u);
     if (PARTIAL) {
@@ -381,7 +385,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         uint4* mine = reinterpret_cast<uint4*>(tmpl);
         for (uint32_t c = lane; c < c_hi - c_lo; c += 64) mine[c] = pristine[c];
     } else if (PARTIAL) {
-        partial_bitmap_fill(part_bm, cell_lay, cell_meta, (int)hdr->H, W);  // (complete behind the barrier in front of the writer, below)
+        if (!use_sets) partial_bitmap_fill(part_bm, cell_lay, cell_meta, (int)hdr->H, W);  // (complete behind the barrier in front of the writer, below)
     } else {
         const uint4* pristine = PES ? reinterpret_cast<const uint4*>(bare) : reinterpret_cast<const uint4*>(lds + (h_off_template - tab_off));
         uint4* mine = reinterpret_cast<uint4*>(tmpl);
@@ -725,7 +729,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         const EnvOutputs O = load_uniform(kernarg_env_out());
         if (O.partial && n_here > 0)
             write_partial<true>(A, L, W, (int)K.partial_k, part_pitch, K.partial_E, h_max_layers, cell_lay, cell_meta, part_bm, part_col, tmpl, scratch,
-                                scr_stride, O.partial, env0, n_here, lane);
+                                scr_stride, O.partial, env0, n_here, lane, use_sets ? reinterpret_cast<const uint64_t*>(lds + tab_bytes) : nullptr);
     } else if (write_obs && n_here > 0) {
         dispatch_stream<!HEAD>(K.flags, [&](auto wt_, auto wide_) {  // see stream_store (obs_stream.hpp)
             constexpr bool WT = decltype(wt_)::value, WIDE = decltype(wide_)::value;

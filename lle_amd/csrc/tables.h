@@ -44,6 +44,20 @@ constexpr int MAX_GEMS = 32;
 constexpr int MAX_BEAM_LEN = 32;      // bits of one beam WORD (a beam is a chain of words)
 constexpr int MAX_CELL_LAYERS = 4;
 constexpr uint32_t NO_GEM = 63;
+// Window sets of the partial k x k observation (python/lle/observations.py:312-369) for k = 3, 5, 7: per observer cell p three 64-bit sets over
+// the k x k window centred at p, bit wi * k + wj = window cell (wi, wj) -- [0] a wall or a source there (the WALL layer's byte), [1] an exit
+// (EXIT layer), [2] a gem, a laser tile or a source (the cells whose bytes depend on dynamic state or on colours).  A bit's index is the byte's
+// offset inside a layer of the window: the writers turn set bits into bytes with find-first-set and a store, instead of cutting the sets
+// out of a bitmap of the map per environment and evaluating EVERY non-empty cell against the cell tables (partial_stream.hpp).  Built on
+// the host (map_compile.cpp Map::window_sets), one table of win_set_bytes(HW) per map, uploaded when a batch first writes that window.
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline constexpr bool win_sets_serve(int k) { return k == 3 || k == 5 || k == 7; }
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline constexpr uint32_t win_set_bytes(uint32_t HW) { return (HW * 24u + 1023u) & ~1023u; }  // whole 1-KiB rows (the LDS copy's unit)
 constexpr uint32_t NO_COLOUR = 31;
 
 struct MapHeader {
@@ -252,6 +266,7 @@ struct LaunchArgs {
     uint32_t table_stride, map_override;
     uint32_t n_sources;        // host side only: MapHeader.L, for the launcher's choice of instantiation
     uint32_t partial_E;        // step_kernel MODE 9: environments per batch of the partial writer (partial_stream.hpp)
+    const uint8_t* win_sets;   // step_kernel MODE 9: the window sets of partial_k (one table of win_set_bytes(HW) per map), or NULL (other window sizes)
     // step_kernel only: write LLE.step's other outputs in the same launch (lle_batch_step_outputs).  `env_out` non-NULL says so; the
     // struct itself travels in the kernel arguments (`out`, since round 4: a caller that hands other tensors every step pays no
     // upload for it) and is read from the kernarg segment with scalar loads where it is used (step_kernel.hpp kernarg_env_out):
