@@ -15,7 +15,7 @@ All inputs are resident in HBM before the timed region.  Envs shard over GPUs wi
 (weak scaling); the only collective is one RCCL all-reduce of the rollout counters after the timed region.
 
 Prints ONE JSON line (rank 0).  value = agent-steps/s over the whole job (agents x envs x steps / s);
-env-steps/s is reported next to it.  Objects of the line:
+env-steps/s is reported next to it.  Objects of the line (NOTEBOOK.md section 7):
   roofline       the dominant kernel of the --steps region (HIP events on the launch stream).  Each step rewrites the
                  same 122.7 MB of rows, which the 256 MB Infinity Cache absorbs: bound = "infinity-cache-absorbed".
   roofline_hbm   the same kernel on a batch whose rows (503 MB per launch) do not fit the Infinity Cache.  Since round 3 such launches
@@ -418,7 +418,7 @@ def measure_config(torch, timer, dev, map_or_text, n_envs, algo_bytes, steps, la
     if fill_ceiling:
         # what THIS box gives a writer of the same shape: (a) the step kernel's own store pattern without a state machine
         # (lle_batch_probe_row_fill), (b) a memset-class fill of the same bytes (a narrow write front); ~10 ms each.  Boxes
-        # differ by up to 15 % past the Infinity Cache (DESIGN.md section 4 "Two kinds of box"): read `frac_of_fill`.
+        # differ by up to 15 % past the Infinity Cache (NOTEBOOK.md section 4 "Two kinds of box"): read `frac_of_fill`.
         probe = bw.row_fill_prober()
         launches = max(20, min(400, int(10e-3 / (ms * 1e-3))))
         for _ in range(5):

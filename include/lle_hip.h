@@ -514,12 +514,12 @@ int lle_batch_probe_row_fill(lle_batch* b, uint32_t value, void* stream);
 /* ---- launch rules measured on the batch itself (no reference counterpart: the reference has no launch to tune).
  * The step launcher's rules -- environments per wavefront, row heads ahead of the state machine, `sc1` or plain stores,
  * split rows, the alternating walk of outputs larger than the Infinity Cache -- have defaults fitted on the builder's
- * boxes.  lle_batch_autotune times the alternatives that exist for THIS batch on ITS OWN arena
+ * boxes (NOTEBOOK.md section 4).  lle_batch_autotune times the alternatives that exist for THIS batch on ITS OWN arena
  * (its plain single step with sampled actions and auto-reset, HIP events on `stream`, about budget_ms of GPU time in total;
  * <= 0: 20 ms) and keeps the fastest of each in the handle; later launches of the batch follow them.  The trials are real
  * steps: the call ends with World.reset of every environment and the counters at zero -- call it right after
  * lle_batch_create (or lle_batch_set_sources), not in the middle of an episode.  Results never depend on these choices.
- * The LLE_* environment overrides still win; they are read ONCE per process, never on the launch
+ * The LLE_* environment overrides (NOTEBOOK.md section 7) still win; they are read ONCE per process, never on the launch
  * path -- lle_tuning_refresh() reads them again (tests and tuning tools change them mid-process). */
 typedef struct lle_tuning_info {
     int32_t envs_per_wave;    /* environments per wavefront of the step kernel */

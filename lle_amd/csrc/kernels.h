@@ -29,7 +29,7 @@ struct LdsGrant {
     }
 };
 
-// ---- tuning overrides.  The LLE_* environment variables of DESIGN.md section 7 are read ONCE per process into this snapshot
+// ---- tuning overrides.  The LLE_* environment variables of NOTEBOOK.md section 7 are read ONCE per process into this snapshot
 // (first use) -- never on the launch path; lle_tuning_refresh() reads them again (the parity tests and the tuning tools change
 // them mid-process).  -1 / 0 = not set.
 struct Tuning {

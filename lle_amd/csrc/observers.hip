@@ -619,7 +619,7 @@ __global__ void __launch_bounds__(256) env_outputs_kernel(BatchPtrs P, EnvOutput
 // ---- ceiling probe (lle_probe_row_fill; bench.py `fill_ceiling`): the write pattern of the step kernel's observation stream
 // and nothing else -- wavefront w owns rows [w * rows_per_wave, (w + 1) * rows_per_wave), 16 B per lane and instruction, the
 // same stores (stream_store) and the same workgroup -> block mapping (xcd_block).  What this reaches on a box is what a
-// row-owning writer can reach there; the step kernel is read against it (DESIGN.md section 4 "Two kinds of box").
+// row-owning writer can reach there; the step kernel is read against it (NOTEBOOK.md section 4 "Two kinds of box").
 template <bool WT>
 __global__ void __launch_bounds__(256) row_fill_probe_kernel(int8_t* __restrict__ out, int64_t n_rows, uint32_t n_chunks, uint32_t rows_per_wave,
                                                              uint32_t value, uint32_t flags) {

@@ -190,7 +190,7 @@ def test_config1_single_env_10k_steps(oracle_mod):
 
 
 def test_sampler_is_uniform_and_decorrelated(oracle_mod):
-    """The 16-bit fields of the counter-based sampler: flat histogram, no visible dependence
+    """The 16-bit fields of the counter-based sampler (NOTEBOOK.md section 6): flat histogram, no visible dependence
     between neighbouring envs / steps / agents (chi-square bounds loose enough to be deterministic)."""
     f = np.array([[[oracle_mod.action_hash(1234, e, t, a) for a in range(4)] for t in range(16)] for e in range(512)], dtype=np.int64)
     assert f.min() >= 0 and f.max() < 65536

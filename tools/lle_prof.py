@@ -348,7 +348,7 @@ def cmd_placement(args):
 
 def cmd_stamps(args):
     """In-kernel timeline: per-wave s_memrealtime stamps (10 ns ticks) of lle_batch_step_stamped (MODE 1 build of the step
-    kernel).  --fine expects the one-off diagnostic build that stamps in MODE 0 with 16 slots per wave."""
+    kernel).  --fine expects the one-off diagnostic build that stamps in MODE 0 with 16 slots per wave (NOTEBOOK.md section 4)."""
     import numpy as np
     n = ints(args.sizes)[0]
     slots = 16 if args.fine else 8
