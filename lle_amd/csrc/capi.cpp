@@ -83,7 +83,7 @@ Layout make_layout(const MapHeader& h, int64_t n, int64_t n_maps = 1, uint32_t o
     const int64_t L = h.L;
     const int64_t A = agent_stride((int)h.A, (int)h.L);  // per-agent buffers are strided by the kernel's agent bound
     const int64_t n_pad = (n + 1 + 63) / 64 * 64;  // + one hidden env (slot n) used to compute the reset state on the device
-    l.n_stat_blocks = std::max<int64_t>(8192, (n + MIN_ENVS_PER_WAVE - 1) / MIN_ENVS_PER_WAVE);  // one slot per wavefront
+    l.n_stat_blocks = std::max<int64_t>(MIN_STAT_SLOTS, (n + MIN_ENVS_PER_WAVE - 1) / MIN_ENVS_PER_WAVE);  // one slot per wavefront
     int64_t sz[LLE_BUF_COUNT];
     sz[LLE_BUF_POS] = n_pad * A * 2;
     sz[LLE_BUF_BITS] = n_pad * 8;
@@ -1371,8 +1371,15 @@ int lle_batch_autotune(lle_batch* b, double budget_ms, void* stream) {
     // the alternatives, one coordinate at a time (each keeps the best of the ones before it): environments per wavefront, row
     // heads, store policy, split rows, the alternating walk -- only those that exist for this batch
     const uint32_t cap = 64u / (uint32_t)step_group((int)h.A);
+    // environments per wavefront: the default rule's choice and its two neighbours (the rule already shrinks the wavefronts of small batches:
+    // sweeping {cap, cap / 2, cap / 4} kept a one-agent map's 4 096-env batch at 16 environments per wavefront -- 64 workgroups for 256 CUs --
+    // where the rule says 4; round 5).  Below MIN_ENVS_PER_WAVE only while the wavefronts still fit LLE_BUF_STATS' slots (step_envs_per_wave).
     std::vector<uint32_t> epws;
-    for (uint32_t e = cap; e >= MIN_ENVS_PER_WAVE && epws.size() < 3; e >>= 1) epws.push_back(e);  // (one LLE_BUF_STATS slot per wavefront of >= 4 envs)
+    {
+        const uint32_t rule = step_envs_per_wave(b->n_envs, (int)h.A, StepTune());
+        for (uint32_t e : {rule * 2u, rule, rule / 2u})
+            if (e >= 1 && e <= cap && (e >= MIN_ENVS_PER_WAVE || (b->n_envs + e - 1) / e <= (int64_t)MIN_STAT_SLOTS)) epws.push_back(e);
+    }
     const bool can_heads = step_has_row_heads(h, pes) && b->obs_et == OBS_I8, can_split = step_can_split_rows(h, pes), can_walk = row_bytes > (256ull << 20);
     const int n_trials = (int)epws.size() + (can_heads ? 4 : 0) + 2 + (can_split ? 2 : 0) + (can_walk ? 2 : 0) + 2;
     uint64_t t_idx = 1u << 20;

@@ -78,6 +78,7 @@ void debug_reset_launched();
 
 enum { KMODE_STEP = 0, KMODE_RESET = 1, KMODE_SET_STATE = 2, KMODE_OBSERVE = 3, KMODE_SOURCES = 4, KMODE_ENV_SOURCES = 5 };
 constexpr uint32_t MIN_ENVS_PER_WAVE = 4;  // step_kernel<16, .>: 4 environments per wavefront
+constexpr uint32_t MIN_STAT_SLOTS = 8192;  // LLE_BUF_STATS never has fewer per-wavefront slots than this (capi.cpp make_layout)
 
 int kernel_variant(int A, int L);
 int agent_stride(int A, int L);  // agents per env record in the per-agent buffers (= the variant's agent bound)

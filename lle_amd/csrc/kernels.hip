@@ -705,11 +705,16 @@ int step_lm(int L) { return L <= 4 ? 4 : (L <= 8 ? 8 : (L <= 16 ? 16 : 32)); }
 // ~4096 wavefronts (16 per CU), fewer (down to 4) for small batches
 uint32_t step_envs_per_wave(int64_t n, int A, const StepTune& tune) {
     uint32_t e = 64u / (uint32_t)step_group(A);
-    // LLE_STEP_EPW, then the batch's own choice.  Never below MIN_ENVS_PER_WAVE: LLE_BUF_STATS holds one slot per wavefront of
-    // AT LEAST that many environments (capi.cpp make_layout), and a wavefront indexes it by its id.
+    // LLE_STEP_EPW, then the batch's own choice.  LLE_BUF_STATS holds max(MIN_STAT_SLOTS, n / MIN_ENVS_PER_WAVE) slots, one per wavefront
+    // (capi.cpp make_layout), and a wavefront indexes it by its id: fewer than MIN_ENVS_PER_WAVE environments per wavefront only while
+    // the batch is small enough for its wavefronts to fit the slots that always exist.
     for (const uint32_t v : {(uint32_t)tuning().step_epw, (uint32_t)tune.epw})
-        if (v >= MIN_ENVS_PER_WAVE && v <= e && !(v & (v - 1))) return v;
-    while (e > 4 && n / e < 4096) e >>= 1;  // measured on level 1: 4 beats 1-2 even at n = 4096
+        if (v >= 1 && v <= e && !(v & (v - 1)) && (v >= MIN_ENVS_PER_WAVE || (n + v - 1) / v <= (int64_t)MIN_STAT_SLOTS)) return v;
+    while (e > 4 && n / e < 4096) e >>= 1;
+    // ... and below four for batches that would otherwise leave most of the chip without a wavefront: a wavefront streams its rows one
+    // after the other (0.45 us each on level 1), so at 4 096 envs two per wavefront beat four (5.67 -> 5.41 us), at 1 024 one beats four
+    // (5.72 -> 4.73 us); one per wavefront at 4 096 loses again (6.27: four times the table copies).  tools/small_batch_epw.py, round 5.
+    while (e > 1 && n / e < 2048) e >>= 1;
     return e;
 }
 
