@@ -462,7 +462,7 @@ def cmd_target(args):
             bw.step(sample=True, auto_reset=True, seed=1, t=t, recolour_resets=True)
     else:  # step | noobs | cfg5 | hbm
         m = Map(mapgen.config5(0), row_align=args.row_align) if what == "cfg5" else the_map(args)
-        bw = BatchedWorld(m, 262144 if what == "hbm" and n == 65536 else n)
+        bw = BatchedWorld(m, 262144 if what == "hbm" and n == 65536 else n, obs_dtype=getattr(args, "obs_dtype", None))
         for t in range(args.iters):
             bw.step(sample=True, auto_reset=True, seed=1, t=t, write_obs=what != "noobs")
     torch.cuda.synchronize()
@@ -496,6 +496,7 @@ def main():
         if name == "target":
             p.add_argument("what", choices=["step", "noobs", "partial", "perspective", "cfg5", "hbm", "pes"])
             p.add_argument("-k", type=int, default=7, help="window of the partial observer")
+            p.add_argument("--obs-dtype", default=None, help="element type of the rows (step / hbm / cfg5): int8 (default), float16, bfloat16, float32")
     args = ap.parse_args()
     assert torch.cuda.is_available(), "lle_prof.py needs an MI355X"
     cmds[args.cmd](args)

@@ -24,14 +24,20 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 ENV = dict(os.environ, TMPDIR="/tmp")
 BENCH = os.path.join(ROOT, "bench.py")
 # (label, kernel-name fragment, grid size in work-items = waves x 64): the single-step launches of the bench line
+# (label, kernel-name fragment, environments, algorithmic bytes): the single-step launches of the bench line.  The grid is environments /
+# (environments per wavefront) x 64 work-items; since round 5 the batches autotune their environments per wavefront at construction, so the
+# grid is whichever of those sizes the kernel was launched with most often.
 WORKLOADS = [
-    ("cfg3 level 6 x 65 536 (headline)", "step_kernel<4, 4, 6, true, 3>", 65536 // 16 * 64, 1937 * 65536),  # MODE 6: row heads first
-    ("level 6 x 262 144 (rows > Infinity Cache)", "step_kernel<4, 4, 0, true, 3>", 262144 // 16 * 64, 1937 * 262144),
-    ("cfg2 level 1 x 4 096", "step_kernel<1, 4, 0, true, 0>", 4096 // 4 * 64, 953 * 4096),
-    ("cfg5 32x32 8 agents x 65 536", "step_kernel<8, 8, 0, false, -1>", 65536 // 8 * 64, 20617 * 65536),
+    ("cfg3 level 6 x 65 536 (headline)", "step_kernel<4, 4, 6, true, 3>", 65536, 1937 * 65536),  # MODE 6: row heads first
+    ("level 6 x 262 144 (rows > Infinity Cache)", "step_kernel<4, 4, 0, true, 3>", 262144, 1937 * 262144),
+    ("cfg2 level 1 x 4 096", "step_kernel<1, 4, 0, true, 0>", 4096, 953 * 4096),
+    ("cfg5 32x32 8 agents x 65 536", "step_kernel<8, 8, 0, false, -1>", 65536, 20617 * 65536),
     # BatchedLLE.step with randomize_lasers (bench `lle_step`): per-env sources, row heads first (MODE 8), the fused outputs on top
-    ("LLE.step + randomize_lasers, level 6 x 65 536 (MODE 8)", "step_kernel<4, 4, 8, true, 3>", 65536 // 16 * 64, (1937 + 16 * 4 + 4 + 20 + 1) * 65536),
+    ("LLE.step + randomize_lasers, level 6 x 65 536 (MODE 8)", "step_kernel<4, 4, 8, true, 3>", 65536, (1937 + 16 * 4 + 4 + 20 + 1) * 65536),
 ]
+# the step with the rows widened at the store (round 5): profiled in passes of their own (`tools/lle_prof.py target step --obs-dtype ...`: the kernel's
+# name is MODE 0's, which the bench line also launches with int8 rows)
+WIDE = [("level 6 x 65 536, fp16 rows", "float16", 2), ("level 6 x 65 536, bf16 rows", "bfloat16", 2), ("level 6 x 65 536, fp32 rows", "float32", 4)]
 
 
 def run(cmd, log):
@@ -76,7 +82,10 @@ def main():
              "|---|---|---|---|---|---|---|---|---|---|---|"]
     traffic = {}
     csv_rows = [["workload", "kernel", "grid", "launches", "avg_ns", "median_ns", "min_ns", "max_ns", "write_bytes", "fetch_bytes_corrected"]]
-    for label, frag, grid, algo in WORKLOADS:
+    import collections
+    for label, frag, n_envs, algo in WORKLOADS:
+        grids = collections.Counter(int(r["Grid_Size_X"]) for r in trace if frag in r["Kernel_Name"] and int(r["Grid_Size_X"]) in {n_envs // e * 64 for e in (1, 2, 4, 8, 16, 32, 64)})
+        grid = grids.most_common(1)[0][0] if grids else 0
         d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in trace if frag in r["Kernel_Name"] and int(r["Grid_Size_X"]) == grid]
         if not d:
             lines.append(f"| {label} | `{frag}` | 0 | - | - | - | - | - | - | - | - |")
@@ -91,6 +100,28 @@ def main():
                      f"{(wb or 0)/1e6:.1f} | {(fb or 0)/1e6:.1f} | {(tr/algo if tr else float('nan')):.3f} |")
         csv_rows.append([label, frag, grid, len(d), round(avg), statistics.median(d), min(d), max(d), wb, fb])
         traffic[label] = tr
+    # ---- the widened steps, each in three passes of its own (kernel trace, WRITE_SIZE, FETCH_SIZE)
+    lines += ["", "## The step with the rows widened at the store (`lle_batch_options.obs_dtype`; level 6 x 65 536, `tools/lle_prof.py target step --obs-dtype`)", "",
+              "| rows | launches | avg us | min us | bytes the launch writes (rows x element size + small outputs) MB | GB/s at avg | of 8 TB/s | WRITE_SIZE MB | 2 x FETCH_SIZE MB |", "|---|---|---|---|---|---|---|---|---|"]
+    LP = os.path.join(ROOT, "tools", "lle_prof.py")
+    for label, dt, es in WIDE:
+        vals = {}
+        for kind, extra in (("trace", ["--kernel-trace", "--stats"]), ("write", ["--pmc", "WRITE_SIZE", "--kernel-trace"]), ("fetch", ["--pmc", "FETCH_SIZE", "--kernel-trace"])):
+            sub = os.path.join(OUT, f"wide_{dt}_{kind}")
+            subprocess.run(["rm", "-rf", sub])
+            run(["rocprofv3"] + extra + ["--output-format", "csv", "-d", sub, "--", sys.executable, LP, "target", "step", "--obs-dtype", dt, "--iters", "300"], f"wide_{dt}_{kind}.err")
+            if kind == "trace":
+                tr_rows = list(csv.DictReader(open(latest(f"wide_{dt}_trace/**/*_kernel_trace.csv"))))
+                dd = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tr_rows if "step_kernel<4, 4, 0, true, 3>" in r["Kernel_Name"]][20:]
+                vals["d"] = dd
+            else:
+                rows_ = [float(r["Counter_Value"]) for r in csv.DictReader(open(latest(f"wide_{dt}_{kind}/**/*_counter_collection.csv"))) if "step_kernel<4, 4, 0, true, 3>" in r["Kernel_Name"]]
+                vals[kind] = statistics.median(rows_) * 1024 if rows_ else None
+        dd = vals["d"]
+        wbytes = 65536 * (1920 * es + (1937 - 1872))
+        avg = statistics.mean(dd)
+        lines.append(f"| {label} | {len(dd)} | {avg/1e3:.2f} | {min(dd)/1e3:.2f} | {wbytes/1e6:.1f} | {wbytes/avg:.0f} | {wbytes/avg/8000:.3f} | {(vals['write'] or 0)/1e6:.1f} | {2*(vals['fetch'] or 0)/1e6:.1f} |")
+        csv_rows.append([label, "step_kernel<4, 4, 0, true, 3>", 0, len(dd), round(avg), statistics.median(dd), min(dd), max(dd), vals["write"], 2 * (vals["fetch"] or 0)])
     lines += ["", "## Kernel stats of the profiled run (`--stats`; a kernel name covers every grid it ran with)", "",
               "| kernel | calls | avg ns | min ns | max ns | % |", "|---|---|---|---|---|---|"]
     for r in stats:
