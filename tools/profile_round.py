@@ -84,8 +84,10 @@ def main():
     csv_rows = [["workload", "kernel", "grid", "launches", "avg_ns", "median_ns", "min_ns", "max_ns", "write_bytes", "fetch_bytes_corrected"]]
     import collections
     for label, frag, n_envs, algo in WORKLOADS:
-        grids = collections.Counter(int(r["Grid_Size_X"]) for r in trace if frag in r["Kernel_Name"] and int(r["Grid_Size_X"]) in {n_envs // e * 64 for e in (1, 2, 4, 8, 16, 32, 64)})
-        grid = grids.most_common(1)[0][0] if grids else 0
+        # (the largest number of environments per wavefront the kernel's lane group allows first: the default; a grid counts from 20 launches on)
+        lanes = int(frag.split("<")[1].split(",")[0])
+        grids = collections.Counter(int(r["Grid_Size_X"]) for r in trace if frag in r["Kernel_Name"])
+        grid = next((n_envs // e * 64 for e in (64, 32, 16, 8, 4, 2, 1) if e <= 64 // lanes and grids.get(n_envs // e * 64, 0) >= 20), 0)
         d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in trace if frag in r["Kernel_Name"] and int(r["Grid_Size_X"]) == grid]
         if not d:
             lines.append(f"| {label} | `{frag}` | 0 | - | - | - | - | - | - | - | - |")
