@@ -29,7 +29,9 @@ BENCH = os.path.join(ROOT, "bench.py")
 # grid is whichever of those sizes the kernel was launched with most often.
 WORKLOADS = [
     ("cfg3 level 6 x 65 536 (headline)", "step_kernel<4, 4, 6, true, 3>", 65536, 1937 * 65536),  # MODE 6: row heads first
-    ("level 6 x 262 144 (rows > Infinity Cache)", "step_kernel<4, 4, 0, true, 3>", 262144, 1937 * 262144),
+    # (the same kernel also serves 65 536-env batches of other bench blocks -- incremental rows, widened rows -- at 16 / 8 per wavefront: this row's
+    #  launches are told apart by grids those cannot produce)
+    ("level 6 x 262 144 (rows > Infinity Cache)", "step_kernel<4, 4, 0, true, 3>", 262144, 1937 * 262144, (16, 8)),
     ("cfg2 level 1 x 4 096", "step_kernel<1, 4, 0, true, 0>", 4096, 953 * 4096),
     ("cfg5 32x32 8 agents x 65 536", "step_kernel<8, 8, 0, false, -1>", 65536, 20617 * 65536),
     # BatchedLLE.step with randomize_lasers (bench `lle_step`): per-env sources, row heads first (MODE 8), the fused outputs on top
@@ -78,16 +80,20 @@ def main():
              "Collected by `tools/profile_round.py` (one gpurun call): bench.py un-profiled; `rocprofv3 --kernel-trace --stats -- python3 bench.py "
              + " ".join(light) + "`; `--pmc WRITE_SIZE` and `--pmc FETCH_SIZE` in passes of their own.", "",
              "## Launches of the bench line, by (kernel, grid)", "",
+             "(A (kernel, grid) pair is launched by several blocks of the bench line -- the cfg5 kernel also by its incremental-rows and consumer-loop blocks, the 262 144-env "
+             "kernel with the alternating and the one-directional walk -- so for every row but the headline the MEDIAN is the figure of the block that names it; the headline "
+             "kernel's launches are all the same workload.)", "",
              "| workload | kernel | launches | avg us | median us | min us | algorithmic MB | algorithmic GB/s at avg | WRITE_SIZE MB | 2 x FETCH_SIZE MB | traffic / algorithmic |",
              "|---|---|---|---|---|---|---|---|---|---|---|"]
     traffic = {}
     csv_rows = [["workload", "kernel", "grid", "launches", "avg_ns", "median_ns", "min_ns", "max_ns", "write_bytes", "fetch_bytes_corrected"]]
     import collections
-    for label, frag, n_envs, algo in WORKLOADS:
-        # (the largest number of environments per wavefront the kernel's lane group allows first: the default; a grid counts from 20 launches on)
+    for label, frag, n_envs, algo, *only in WORKLOADS:
+        # the grid this batch's launches used most (the autotune's trials at neighbouring sizes are a few dozen launches each)
         lanes = int(frag.split("<")[1].split(",")[0])
         grids = collections.Counter(int(r["Grid_Size_X"]) for r in trace if frag in r["Kernel_Name"])
-        grid = next((n_envs // e * 64 for e in (64, 32, 16, 8, 4, 2, 1) if e <= 64 // lanes and grids.get(n_envs // e * 64, 0) >= 20), 0)
+        cands = [n_envs // e * 64 for e in (only[0] if only else (64, 32, 16, 8, 4, 2, 1)) if e <= 64 // lanes]
+        grid = max(cands, key=lambda g: grids.get(g, 0)) if cands else 0
         d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in trace if frag in r["Kernel_Name"] and int(r["Grid_Size_X"]) == grid]
         if not d:
             lines.append(f"| {label} | `{frag}` | 0 | - | - | - | - | - | - | - | - |")
