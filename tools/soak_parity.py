@@ -1,7 +1,9 @@
 """Soak differential (GPU box): HIP path vs the CPU oracle on long random rollouts, every buffer of every env compared
 bit-for-bit after every step (state, ordered events, availability, error codes, the full int8 observation).
 Beyond the test suite's sizes; prints env-steps compared per map.
-Usage: python tools/soak_parity.py [seconds_per_map] [per-env-sources | full-size | recolour-resets | rollouts | exits | incremental]
+Usage: python tools/soak_parity.py [seconds_per_map] [per-env-sources | full-size | recolour-resets | rollouts | exits | incremental | dtype]
+With `dtype` the batch's rows are fp16 / bf16 / fp32 in turn (lle_batch_options.obs_dtype: widened at the store, round 5) -- single steps, and every 16th
+step a fused rollout of 4 steps in place; the values must be the oracle's int8 tensor exactly.
 With `incremental` every step carries LLE_STEP_INCREMENTAL_OBS (only the lines of a row that dynamic state can change are written):
 the observation compared after every step is the buffer's whole content.
 With `exits` the exits MOVE every 40 steps (World.exit_pos = [...], world.rs:195-234: lle_map_set_exits + lle_batch_update_map on
@@ -39,6 +41,8 @@ recolour = len(sys.argv) > 2 and sys.argv[2] == "recolour-resets"
 rollouts = len(sys.argv) > 2 and sys.argv[2] == "rollouts"
 exits_mode = len(sys.argv) > 2 and sys.argv[2] == "exits"
 incremental = len(sys.argv) > 2 and sys.argv[2] == "incremental"
+dtype_mode = len(sys.argv) > 2 and sys.argv[2] == "dtype"
+DTYPES = [torch.float16, torch.bfloat16, torch.float32]
 rng = np.random.default_rng(7)
 
 
@@ -88,7 +92,7 @@ for name, (text, n) in maps.items():
         n = min(n, 8192)
     if exits_mode:
         n = min(n, 4096)  # (set_exit_positions on the oracle side is one call per world)
-    ob, bw = om.OracleBatch(text, n), BatchedWorld(text, n)
+    ob, bw = om.OracleBatch(text, n), BatchedWorld(text, n, obs_dtype=DTYPES[len(name) % 3] if dtype_mode else None)
     dims = ob.dims
     L = bw.map.n_sources
     if (per_env or recolour) and L == 0:
@@ -158,7 +162,16 @@ for name, (text, n) in maps.items():
             assert_state_equal(eng, ob.dump(), f"{name} t={t} after set_exits")
             assert np.array_equal(eng["obs"][:64], np.stack([ob.world(e).obs() for e in range(64)])), f"{name} t={t}: observation after set_exits"
         auto = (t // 64) % 2 == 0  # alternate: auto-reset regime / episodes running into all-dead, all-STAY states (Q1, Q2)
-        bw.step(sample=True, auto_reset=auto, seed=2026, t=t, env_offset=11, incremental_obs=incremental)
+        if dtype_mode and t % 16 == 15:  # a fused rollout in place: the last step's rows are in `obs`
+            bw.rollout(4, auto_reset=True, seed=2026, t=t, env_offset=11)
+            for j in range(4):
+                ostep = ob.step(None, auto_reset=True, seed=2026, t=t + j, env_offset=11)
+            eng = unpack_engine(bw.host_buffers(), *dims)
+            assert np.array_equal(eng["obs"], ostep["obs"]), f"{name} t={t}: rows after the fused rollout"
+            assert_state_equal(eng, ob.dump(), f"{name} t={t} (rollout)")
+            t += 4
+            continue
+        bw.step(sample=True, auto_reset=auto, seed=2026, t=t, env_offset=11, incremental_obs=incremental or (dtype_mode and t % 5 == 2))
         ostep = ob.step(None, auto_reset=auto, seed=2026, t=t, env_offset=11)
         eng = unpack_engine(bw.host_buffers(), *dims)
         assert_step_equal(eng, ostep, f"{name} t={t}")
