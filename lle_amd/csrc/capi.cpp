@@ -682,16 +682,16 @@ static void drop_views(lle_batch* b) {
     }
 }
 
-// Device copy of the window sets of window size k (tables.h): one table of win_set_bytes(HW) per map; NULL for the other sizes.
+// Device copy of the window tables of window size k (tables.h): win_table_bytes(HW) per map; NULL for the other sizes.
 static int get_win_sets(lle_batch* b, int k, hipStream_t st, const uint8_t** out) {
     *out = nullptr;
     if (!win_sets_serve(k) || getenv("LLE_PARTIAL_NO_SETS")) return LLE_OK;  // (LLE_PARTIAL_NO_SETS: the bitmap path for every size -- A/B and cross-check)
     uint8_t*& dev = b->win_sets[(k - 3) / 2];
     if (!dev) {
-        const size_t each = win_set_bytes(b->hdr.HW);
-        std::vector<uint8_t> all(each * b->maps.size());
+        const size_t each = win_table_bytes(b->hdr.HW);
+        std::vector<uint8_t> all(each * b->maps.size() + 1024);  // (+ a row: a kernel's whole-row copy of a part of the last table may read past it)
         for (size_t m = 0; m < b->maps.size(); m++) {
-            const std::vector<uint8_t> one = b->maps[m].window_sets(k);
+            const std::vector<uint8_t> one = b->maps[m].window_table(k);
             std::memcpy(all.data() + m * each, one.data(), each);
         }
         void* p = nullptr;

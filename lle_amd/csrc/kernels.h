@@ -119,7 +119,7 @@ hipError_t launch_view_observe(const ViewHeader& v, const BatchPtrs& P, const ui
 bool view_kernel_fits(const ViewHeader& v, uint32_t n_views, bool pes, uint32_t n_elems);
 uint32_t partial_pitch(int A, int k);
 // n_entities: walls (sources included) + exits + gems + exposed laser tiles + sources of the map (the largest of a multi-map batch)
-// win_sets: the window sets of k (tables.h; one table of win_set_bytes(HW) per map, device memory) or NULL (window sizes other than 3, 5, 7)
+// win_sets: the window tables of k (tables.h; win_table_bytes(HW) apart per map, device memory) or NULL (window sizes other than 3, 5, 7)
 hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t* out, int k, int64_t n_envs, bool per_env_sources,
                                   MapSel M, uint32_t n_entities, bool reverse, hipStream_t stream, const uint8_t* win_sets = nullptr,
                                   uint32_t force_E = 0 /* environments per batch of the lane kernel; 0: the rule */, uint32_t* rule_E = nullptr);

@@ -737,7 +737,7 @@ static uint32_t partial_step_lds(const MapHeader& h, uint32_t wpw, uint32_t E, i
     const uint32_t scr_stride = (h.L + h.A + 2) | 1u, pitch = ((h.A * (2 * h.A + 3)) * (uint32_t)(k * k) + 15u) & ~15u;
     uint32_t tab = ((h.off_dyn - h.off_cell_lay) + 1023u) & ~1023u;
     if (tab > h.lds_table_bytes) tab = h.lds_table_bytes;
-    const uint32_t window = sets ? win_set_bytes(h.HW) : partial_bitmap_bytes(h.H, h.W);
+    const uint32_t window = sets ? win_sets_bytes(h.HW) : partial_bitmap_bytes(h.H, h.W);
     return tab + (h.L > 4 ? 256u : 0u) + window + 32u + wpw * (E * pitch + 16u + ((epw * scr_stride * 4u + 15u) & ~15u)) + 64u;
 }
 uint32_t step_partial_batch(const MapHeader& h, int k, bool pes) {

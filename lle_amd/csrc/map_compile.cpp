@@ -653,10 +653,10 @@ void Map::compile() {
     header = h;
 }
 
-// The window sets of the partial k x k observation (tables.h): [HW][3] u64, padded to whole 1-KiB rows.
-std::vector<uint8_t> Map::window_sets(int k) const {
+// The window table of the partial k x k observation (tables.h): [sets u64[HW][2] | cell_lay u64[HW] | cell_meta u32[HW]], whole 1-KiB rows.
+std::vector<uint8_t> Map::window_table(int k) const {
     const int HW = H * W, centre = k / 2;
-    std::vector<uint8_t> out(win_set_bytes((uint32_t)HW), 0);
+    std::vector<uint8_t> out(win_table_bytes((uint32_t)HW), 0);
     uint64_t* sets = reinterpret_cast<uint64_t*>(out.data());
     for (int pi = 0; pi < H; pi++)
         for (int pj = 0; pj < W; pj++)
@@ -666,11 +666,12 @@ std::vector<uint8_t> Map::window_sets(int k) const {
                     if (i < 0 || j < 0 || i >= H || j >= W) continue;  // (outside the map: nothing, observations.py:331-340)
                     const int c = i * W + j;
                     const uint64_t bit = 1ull << (wi * k + wj);
-                    uint64_t* e = sets + (size_t)(pi * W + pj) * 3;
+                    uint64_t* e = sets + (size_t)(pi * W + pj) * 2;
                     if (kind[c] == K_WALL || kind[c] == K_SOURCE) e[0] |= bit;   // wall_pos holds the sources too (parser_v1.rs:22-25)
-                    if (kind[c] == K_EXIT) e[1] |= bit;
-                    if (kind[c] == K_GEM || kind[c] == K_SOURCE || !cell_layers[c].empty()) e[2] |= bit;
+                    if (kind[c] == K_GEM || kind[c] == K_EXIT || kind[c] == K_SOURCE || !cell_layers[c].empty()) e[1] |= bit;
                 }
+    std::memcpy(out.data() + (size_t)HW * 16, blob.data() + header.off_cell_lay, (size_t)HW * 8);
+    std::memcpy(out.data() + (size_t)HW * 24, blob.data() + header.off_cell_meta, (size_t)HW * 4);
     return out;
 }
 

@@ -90,7 +90,7 @@ struct Map {
     };
     bool build_obs_tables(const LayerMap& lm, std::vector<int8_t>& tmpl, std::vector<uint64_t>& dyn_tab) const;
     std::vector<uint8_t> compile_view(int kind, int param) const;  // ViewHeader + dyn + template (tables.h)
-    std::vector<uint8_t> window_sets(int k) const;                 // the window sets of the partial k x k observation (tables.h), k = 3, 5, 7
+    std::vector<uint8_t> window_table(int k) const;                // the window table of the partial k x k observation (tables.h), k = 3, 5, 7
 
     // compiled form
     MapHeader header{};

@@ -467,16 +467,20 @@ __global__ void __launch_bounds__(256) partial_lanes_kernel(BatchPtrs P, int8_t*
     uint32_t rv[RV], rat[RV];
 #pragma unroll
     for (int q = 0; q < RV; q++) rv[q] = rec_word(lane + 64u * (uint32_t)q, rat[q]);
-    // behind the cell tables: the window sets of this window size (tables.h; k = 3, 5, 7: copied with the tables, `win_sets` = this launch's
-    // tables, win_bytes apart per map) -- or, for the other sizes, the non-empty bitmap of the map, built here from the cell tables
-    const uint64_t* cell_lay = reinterpret_cast<const uint64_t*>(lds);
-    const uint32_t* cell_meta = reinterpret_cast<const uint32_t*>(lds + D.off_cell_meta);
+    // Two LDS layouts ahead of the wavefronts' private areas:
+    //   win_sets != NULL (k = 3, 5, 7): ONE window table of this window size and map -- [sets | cell_lay | cell_meta], tables.h --, copied in whole
+    //     1-KiB rows (`win_bytes` = the table's stride per map); `tab_bytes` = what of it is kept, and the tail of the copy's last row lands in
+    //     the first wavefront's row block, which that wavefront clears before use (behind the barrier below);
+    //   else: the map's cell tables (tab_bytes, whole rows) and the non-empty bitmap of the map, built here from them.
+    const uint32_t HWc = (uint32_t)(H * W);
+    const uint64_t* cell_lay = reinterpret_cast<const uint64_t*>(lds + (win_sets ? HWc * 16u : 0u));
+    const uint32_t* cell_meta = reinterpret_cast<const uint32_t*>(lds + (win_sets ? HWc * 24u : D.off_cell_meta));
     const uint32_t RW = partial_bitmap_row_words((uint32_t)W), bm_words = (uint32_t)(H + 16) * RW;
-    const uint32_t bm_bytes = win_sets ? win_bytes : (bm_words * 4u + 15u) & ~15u;
+    const uint32_t bm_bytes = win_sets ? 0u : (bm_words * 4u + 15u) & ~15u;
     uint32_t* bm = reinterpret_cast<uint32_t*>(lds + tab_bytes);
     if (win_sets) {
         const uint64_t map_idx = M.envs_per_map ? (uint64_t)(env_base + (int64_t)(blk * waves_per_wg) * epw) / (uint64_t)M.envs_per_map : 0ull;
-        copy_tables2_to_lds(tables + tab_off, tab_bytes, win_sets + map_idx * win_bytes, win_bytes, lds, lane, wave_in_wg, waves_per_wg);
+        copy_tables_to_lds(win_sets + map_idx * win_bytes, lds, win_bytes, lane, wave_in_wg, waves_per_wg);
         __syncthreads();
     } else {
         copy_tables_to_lds(tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
@@ -485,7 +489,7 @@ __global__ void __launch_bounds__(256) partial_lanes_kernel(BatchPtrs P, int8_t*
         partial_bitmap_fill(bm, cell_lay, cell_meta, H, W);
         __syncthreads();
     }
-    const uint64_t* sets = win_sets ? reinterpret_cast<const uint64_t*>(bm) : nullptr;
+    const uint64_t* sets = win_sets ? reinterpret_cast<const uint64_t*>(lds) : nullptr;
     // ---- who this lane is: environment slot e of the batch, observer a, share s of S of the window rows
     const uint32_t logA = A <= 1 ? 0u : (A <= 2 ? 1u : (A <= 4 ? 2u : (A <= 8 ? 3u : 4u)));
     const uint32_t S = 64u / (E << logA);                 // lanes per (env, observer); the launcher keeps E << logA <= 64
@@ -791,9 +795,11 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
             const uint32_t rec_dwords = As_l / 2 + 1 + h.L + (uint32_t)src_stride_of((int)h.L) / 4u;
             uint32_t tab = (h.off_dyn - h.off_cell_lay + 1023u) & ~1023u;
             if (tab > h.lds_table_bytes) tab = h.lds_table_bytes;
-            // (behind the cell tables: the window sets of this size, or the map's non-empty bitmap)
-            const uint32_t win_bytes = win_sets ? win_set_bytes(h.HW) : 0u;
-            const uint32_t bm_bytes = win_sets ? win_bytes : partial_bitmap_bytes(h.H, h.W);
+            // (ahead of the wavefronts' areas: the window table of this size -- sets and cell tables in one, tables.h --, or the cell tables and the
+            // map's non-empty bitmap)
+            const uint32_t win_bytes = win_sets ? win_table_bytes(h.HW) : 0u;
+            if (win_sets) tab = win_table_used(h.HW);
+            const uint32_t bm_bytes = win_sets ? 0u : partial_bitmap_bytes(h.H, h.W);
             // batches per wavefront: a workgroup copies the tables and builds the bitmap before its first row, so a launch should
             // be ONE round of workgroups (about four per CU): 65 536 envs -> 16 environments per wavefront, i.e. batches = 16 / E
             uint32_t batches = 1;
@@ -806,7 +812,8 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
             while (batches > 1 && M.envs_per_map && M.envs_per_map % (int64_t)(wpw * E * batches) != 0) batches >>= 1;
             uint32_t priv = E * pitch_l + ((E * batches * rec_dwords * 4u + 15u) & ~15u) + 16u;
             while (wpw > 1 && tab + bm_bytes + wpw * priv > OBS_LDS_LIMIT) wpw >>= 1;
-            const uint32_t lds = tab + bm_bytes + wpw * priv;
+            uint32_t lds = tab + bm_bytes + wpw * priv;
+            if (lds < win_bytes) lds = win_bytes;  // (the table is copied in whole rows: the allocation holds the last one)
             const bool fits = lds <= OBS_LDS_LIMIT && (!M.envs_per_map || M.envs_per_map % (int64_t)(wpw * E * batches) == 0);
             if (fits) {
                 static LdsGrant granted_l;

@@ -96,8 +96,8 @@ __device__ __forceinline__ uint64_t partial_share_mask(uint32_t k, uint32_t S, u
 }
 
 // One lane = share s of observer a of one environment: its agents, then its share of the window's non-empty cells.
-//   sets != NULL (k = 3, 5, 7): the window sets of the observer's cell (tables.h), cut to the lane's share -- walls and exits are bits turned
-//     into bytes, only gems / laser tiles / sources go through the cell tables;
+//   sets != NULL (k = 3, 5, 7): the two window sets of the observer's cell (tables.h), cut to the lane's share -- walls are bits turned into
+//     bytes, only gems / exits / laser tiles / sources go through the cell tables;
 //   sets == NULL: every non-empty cell of the window, found in the map's non-empty bitmap `bm` row by row, goes through the cell tables
 //     (windows up to 8 x 8 split diagonally, larger ones by rows: a lane's rows must fit its 64-bit set, at most four of 16 bits).
 template <class Rec>
@@ -122,13 +122,12 @@ __device__ __forceinline__ void partial_window(const PartialGeo& G, const Rec& R
     const bool diag = k <= 8;
     const uint32_t wi_base = diag ? 0u : s, wi_step = diag ? 1u : S, RH = 32u >> SBL;
     if (sets) {
-        uint64_t walls = 0, exits = 0, dyn = 0;
+        uint64_t walls = 0, dyn = 0;
         if (live) {
-            const uint64_t* e = sets + __umul24((pa & 0xFFu) * (uint32_t)W + ((pa >> 8) & 0xFFu), 3u);
-            walls = e[0] & share; exits = e[1] & share; dyn = e[2] & share;
+            const uint64_t* e = sets + 2u * ((pa & 0xFFu) * (uint32_t)W + ((pa >> 8) & 0xFFu));
+            walls = e[0] & share; dyn = e[1] & share;
         }
-        partial_bits_to_bytes(mine + __umul24((uint32_t)G.A, kk), walls);            // WALL layer
-        partial_bits_to_bytes(mine + __umul24(2u * (uint32_t)G.A + 2u, kk), exits);  // EXIT layer
+        partial_bits_to_bytes(mine + __umul24((uint32_t)G.A, kk), walls);   // WALL layer
         todo2[0] = (uint32_t)dyn; todo2[1] = (uint32_t)(dyn >> 32);
     } else if (live) {
         const uint32_t off = (uint32_t)(j0 + 8);   // >= 1: bit of the window's first column in a bitmap row

@@ -307,9 +307,9 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
                                        : (split ? hdr->lds_split_table_bytes : hdr->lds_table_bytes);
     // (PARTIAL, windows of 3 / 5 / 7: the window sets of the launch's window size come in with the tables, right behind them -- tables.h)
     const bool use_sets = PARTIAL && K.win_sets != nullptr;
-    const uint32_t ext_bytes = PES ? hdr->ext_bytes : (use_sets ? win_set_bytes(hdr->HW) : 0u);
+    const uint32_t ext_bytes = PES ? hdr->ext_bytes : (use_sets ? win_sets_bytes(hdr->HW) : 0u);
     if (PES) copy_tables2_to_lds(tables + tab_off, tab_bytes, tables + h_off_bare, ext_bytes, lds, lane, wave_in_wg, waves_per_wg);
-    else if (use_sets) copy_tables2_to_lds(tables + tab_off, tab_bytes, K.win_sets + (uint64_t)map_idx * ext_bytes, ext_bytes, lds, lane, wave_in_wg, waves_per_wg);
+    else if (use_sets) copy_tables2_to_lds(tables + tab_off, tab_bytes, K.win_sets + (uint64_t)map_idx * win_table_bytes(hdr->HW), ext_bytes, lds, lane, wave_in_wg, waves_per_wg);
     else copy_tables_to_lds(tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
     constexpr uint32_t bt_bytes = BM ? 2u * LM * 4u : 0u;
     uint32_t* beam_tab = reinterpret_cast<uint32_t*>(lds + tab_bytes + ext_bytes);

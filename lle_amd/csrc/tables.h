@@ -44,12 +44,17 @@ constexpr int MAX_GEMS = 32;
 constexpr int MAX_BEAM_LEN = 32;      // bits of one beam WORD (a beam is a chain of words)
 constexpr int MAX_CELL_LAYERS = 4;
 constexpr uint32_t NO_GEM = 63;
-// Window sets of the partial k x k observation (python/lle/observations.py:312-369) for k = 3, 5, 7: per observer cell p three 64-bit sets over
-// the k x k window centred at p, bit wi * k + wj = window cell (wi, wj) -- [0] a wall or a source there (the WALL layer's byte), [1] an exit
-// (EXIT layer), [2] a gem, a laser tile or a source (the cells whose bytes depend on dynamic state or on colours).  A bit's index is the byte's
-// offset inside a layer of the window: the writers turn set bits into bytes with find-first-set and a store, instead of cutting the sets
-// out of a bitmap of the map per environment and evaluating EVERY non-empty cell against the cell tables (partial_stream.hpp).  Built on
-// the host (map_compile.cpp Map::window_sets), one table of win_set_bytes(HW) per map, uploaded when a batch first writes that window.
+// Window tables of the partial k x k observation (python/lle/observations.py:312-369) for k = 3, 5, 7, built on the host per map and window size
+// (map_compile.cpp Map::window_table) and uploaded when a batch first writes that window:
+//   sets [HW][2] u64 : per observer cell p two 64-bit sets over the k x k window centred at p, bit wi * k + wj = window cell (wi, wj) --
+//                      [0] a wall or a source there (the WALL layer's byte), [1] the cells whose bytes go through the cell tables (a gem, an exit,
+//                      a laser tile, a source).  A bit's index is the byte's offset inside a layer of the window: the writers turn wall bits into
+//                      bytes with find-first-set and a store, instead of cutting the sets out of a bitmap of the map per environment and
+//                      evaluating EVERY non-empty cell against the cell tables (partial_stream.hpp);
+//   cell_lay [HW] u64, cell_meta [HW] u32 : copies of the map's cell tables, so that the observer kernel takes ONE table into LDS -- 28 B per
+//                      cell in all: with a separate (KiB-padded) copy of the cell tables next to the sets a workgroup of level 6's 7 x 7
+//                      writer is 42.6 KB, three per CU; with this table 40.8 KB, four (profiles/r05_partial.md).
+// Padded to whole 1-KiB rows (the LDS copy's unit); the step kernel's writer (MODE 9) has the cell tables already and takes the sets only.
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
@@ -57,7 +62,15 @@ inline constexpr bool win_sets_serve(int k) { return k == 3 || k == 5 || k == 7;
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-inline constexpr uint32_t win_set_bytes(uint32_t HW) { return (HW * 24u + 1023u) & ~1023u; }  // whole 1-KiB rows (the LDS copy's unit)
+inline constexpr uint32_t win_table_bytes(uint32_t HW) { return (HW * 28u + 1023u) & ~1023u; }  // the whole table, as uploaded (stride per map)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline constexpr uint32_t win_table_used(uint32_t HW) { return (HW * 28u + 15u) & ~15u; }       // ... what of it a kernel keeps in LDS
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline constexpr uint32_t win_sets_bytes(uint32_t HW) { return (HW * 16u + 1023u) & ~1023u; }   // the sets alone, in whole rows (MODE 9)
 constexpr uint32_t NO_COLOUR = 31;
 
 struct MapHeader {
@@ -266,7 +279,7 @@ struct LaunchArgs {
     uint32_t table_stride, map_override;
     uint32_t n_sources;        // host side only: MapHeader.L, for the launcher's choice of instantiation
     uint32_t partial_E;        // step_kernel MODE 9: environments per batch of the partial writer (partial_stream.hpp)
-    const uint8_t* win_sets;   // step_kernel MODE 9: the window sets of partial_k (one table of win_set_bytes(HW) per map), or NULL (other window sizes)
+    const uint8_t* win_sets;   // step_kernel MODE 9: the window tables of partial_k (win_table_bytes(HW) apart per map; the sets lead each), or NULL
     // step_kernel only: write LLE.step's other outputs in the same launch (lle_batch_step_outputs).  `env_out` non-NULL says so; the
     // struct itself travels in the kernel arguments (`out`, since round 4: a caller that hands other tensors every step pays no
     // upload for it) and is read from the kernarg segment with scalar loads where it is used (step_kernel.hpp kernarg_env_out):
