@@ -464,7 +464,7 @@ def measure_multi_map(torch, timer, dev, steps, single_map_kernel_ms):
     from lle_amd import BatchedWorld, mapgen
     out = {"what": "BASELINE configs[4] with a different generated 32x32 map per block of envs; kernel_ms by HIP events", "n_envs": 65536,
            "single_map_kernel_ms": single_map_kernel_ms}
-    for n_maps in (1024, 4096):
+    for n_maps in (1024, 4096, 8192):  # (8 192 x 8: one wavefront per map, supported since round 5)
         per = 65536 // n_maps
         t0 = time.perf_counter()
         # (placed like the single-map block it is compared with: past the Infinity Cache the arena's write rate is a lottery)

@@ -351,7 +351,8 @@ int lle_batch_observe(lle_batch* b, void* stream);
 /* ---- batches of SEVERAL maps (e.g. one generated map per block of environments; SURVEY.md section 8(d), config 5 variant)
  * Map m owns the envs [m * envs_per_map, (m + 1) * envs_per_map); n_envs = n_maps * envs_per_map.  The maps must agree on
  * height, width and the numbers of agents, sources and gems (one tensor shape, one kernel instantiation); walls, exits,
- * starts, beams and colours are free.  envs_per_map must be a multiple of 16: a wavefront serves one map (from 64 on, whole workgroups do).  Every entry
+ * starts, beams and colours are free.  envs_per_map must be a multiple of 8 (16 until round 5): a wavefront serves one map (from 64 on, whole workgroups
+ * do; below that the workgroups -- and, on maps with up to four agents, the wavefronts -- are narrowed, which costs throughput: bench.py cfg5_multi_map).  Every entry
  * point works on such a batch except lle_batch_update_sources (use lle_batch_set_sources). */
 int64_t lle_batch_arena_bytes_multi(const lle_map* const* maps, int n_maps, int64_t envs_per_map);
 lle_batch* lle_batch_create_multi(const lle_map* const* maps, int n_maps, int64_t envs_per_map, int device_id, void* arena,

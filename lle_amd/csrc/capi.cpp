@@ -638,8 +638,8 @@ lle_batch* lle_batch_create_multi(const lle_map* const* maps, int n_maps, int64_
     if (!maps || n_maps <= 0) { fail(LLE_ERR_ARG, "no maps"); return nullptr; }
     for (int m = 0; m < n_maps; m++)
         if (!maps[m]) { fail(LLE_ERR_NULL, "NULL map"); return nullptr; }
-    if (envs_per_map <= 0 || (n_maps > 1 && envs_per_map % 16 != 0)) {
-        fail(LLE_ERR_ARG, "envs_per_map must be a positive multiple of 16 (a wavefront serves one map)");
+    if (envs_per_map <= 0 || (n_maps > 1 && envs_per_map % 8 != 0)) {
+        fail(LLE_ERR_ARG, "envs_per_map must be a positive multiple of 8 (a wavefront serves one map)");
         return nullptr;
     }
     return create_batch(maps, n_maps, envs_per_map * n_maps, device_id, arena, arena_bytes, stream);
@@ -661,8 +661,8 @@ lle_batch* lle_batch_create_opt(const lle_map* const* maps, int n_maps, int64_t 
     if (!maps || n_maps <= 0) { fail(LLE_ERR_ARG, "no maps"); return nullptr; }
     for (int m = 0; m < n_maps; m++)
         if (!maps[m]) { fail(LLE_ERR_NULL, "NULL map"); return nullptr; }
-    if (envs_per_map <= 0 || (n_maps > 1 && envs_per_map % 16 != 0)) {
-        fail(LLE_ERR_ARG, "envs_per_map must be a positive multiple of 16 (a wavefront serves one map)");
+    if (envs_per_map <= 0 || (n_maps > 1 && envs_per_map % 8 != 0)) {
+        fail(LLE_ERR_ARG, "envs_per_map must be a positive multiple of 8 (a wavefront serves one map)");
         return nullptr;
     }
     return create_batch(maps, n_maps, envs_per_map * n_maps, device_id, arena, arena_bytes, stream, opt);

@@ -49,12 +49,13 @@ constexpr uint32_t OBS_LDS_LIMIT = 160 * 1024;
 // every env writes its laser / gem bytes through the view's colour -> layer table (write_observations_env).
 __global__ void __launch_bounds__(256) view_observe_kernel(BatchPtrs P, const uint8_t* __restrict__ views, uint32_t n_views,
                                                            int8_t* __restrict__ out, int64_t row_pitch, int64_t view_pitch,
-                                                           int64_t env_base, int64_t env_limit, int pes, MapSel M, uint32_t views_stride, int wt, uint32_t walk) {
+                                                           int64_t env_base, int64_t env_limit, int pes, MapSel M, uint32_t views_stride, int wt, uint32_t walk,
+                                                           uint32_t epw /* environments per wavefront: OBS_ENVS_PER_WAVE, or fewer when a map owns fewer */) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t lane = threadIdx.x & 63u, wave_in_wg = threadIdx.x >> 6, waves_per_wg = blockDim.x >> 6;
     const uint32_t blk = xcd_block_dir(blockIdx.x, gridDim.x, walk);  // the block of environments this workgroup serves, and the launch's direction (obs_stream.hpp)
     const uint32_t wave_id = blk * waves_per_wg + wave_in_wg;
-    const int64_t wg_env0 = env_base + (int64_t)(blk * waves_per_wg) * OBS_ENVS_PER_WAVE;
+    const int64_t wg_env0 = env_base + (int64_t)(blk * waves_per_wg) * epw;
     const uint8_t* __restrict__ map_tables = tables_of(P, M, wg_env0);   // this workgroup's map and its views
     views += (M.envs_per_map ? (uint64_t)wg_env0 / (uint64_t)M.envs_per_map : 0ull) * views_stride;
     const ViewHeader* __restrict__ gh = reinterpret_cast<const ViewHeader*>(views);
@@ -79,9 +80,9 @@ __global__ void __launch_bounds__(256) view_observe_kernel(BatchPtrs P, const ui
     const uint32_t rec_bytes = OBS_ENVS_PER_WAVE * scr_stride * 4u;
     uint8_t* priv = lds + blob_bytes * n_views + elem_bytes + wave_in_wg * (obs_stride + n_views * rec_bytes);
     int8_t* tmpl = reinterpret_cast<int8_t*>(priv);
-    const int64_t env0 = env_base + (int64_t)wave_id * OBS_ENVS_PER_WAVE;
+    const int64_t env0 = env_base + (int64_t)wave_id * epw;
     int64_t n_here = env_limit - env0;
-    n_here = n_here < 0 ? 0 : (n_here > (int64_t)OBS_ENVS_PER_WAVE ? (int64_t)OBS_ENVS_PER_WAVE : n_here);
+    n_here = n_here < 0 ? 0 : (n_here > (int64_t)epw ? (int64_t)epw : n_here);
     // hand-over records [0 | beam masks | ~gem bits | byte index of each agent | colour words], all loads in flight together
     const uint32_t per_env = (uint32_t)(L + A + 2 + CW);
     for (uint32_t idx = lane; idx < (uint32_t)n_here * per_env; idx += 64) {
@@ -723,27 +724,34 @@ bool view_kernel_fits(const ViewHeader& v, uint32_t n_views, bool pes, uint32_t 
 }
 
 // workgroups must not straddle two maps: envs_per_map is a multiple of OBS_ENVS_PER_WAVE (narrower workgroups below 64 envs per map)
-static uint32_t cap_wpw(uint32_t wpw, const MapSel& M) {
-    while (wpw > 1 && M.envs_per_map && M.envs_per_map % (int64_t)(wpw * OBS_ENVS_PER_WAVE) != 0) wpw >>= 1;
+// (a map may own as few as 8 environments since round 5: the wavefronts then take fewer environments each)
+static uint32_t obs_envs_per_wave(const MapSel& M) {
+    uint32_t epw = OBS_ENVS_PER_WAVE;
+    while (epw > 1 && M.envs_per_map && M.envs_per_map % (int64_t)epw != 0) epw >>= 1;
+    return epw;
+}
+static uint32_t cap_wpw(uint32_t wpw, const MapSel& M, uint32_t epw = OBS_ENVS_PER_WAVE) {
+    while (wpw > 1 && M.envs_per_map && M.envs_per_map % (int64_t)(wpw * epw) != 0) wpw >>= 1;
     return wpw;
 }
 
 hipError_t launch_view_observe(const ViewHeader& v, const BatchPtrs& P, const uint8_t* views_dev, uint32_t n_views, int8_t* out,
                                int64_t row_pitch, int64_t view_pitch, int64_t n_envs, bool pes, uint32_t n_elems, MapSel M,
                                uint32_t views_stride, bool reverse, hipStream_t stream) {
-    uint32_t wpw = cap_wpw(4, M);
+    const uint32_t epw = obs_envs_per_wave(M);
+    uint32_t wpw = cap_wpw(4, M, epw);
     while (wpw > 1 && view_lds(v, n_views, wpw, pes, n_elems) > OBS_LDS_LIMIT) wpw >>= 1;
     const uint32_t lds = view_lds(v, n_views, wpw, pes, n_elems);
     if (lds > OBS_LDS_LIMIT) return hipErrorInvalidValue;
     static LdsGrant granted;  // per device (kernels.h)
     hipError_t e = granted.ensure(reinterpret_cast<const void*>(&view_observe_kernel), lds);
     if (e != hipSuccess) return e;
-    const uint32_t n_waves = (uint32_t)((n_envs + OBS_ENVS_PER_WAVE - 1) / OBS_ENVS_PER_WAVE);
+    const uint32_t n_waves = (uint32_t)((n_envs + epw - 1) / epw);
     LLE_NOTE_OBS(OBSK_VIEW);
     hipLaunchKernelGGL(view_observe_kernel, dim3((n_waves + wpw - 1) / wpw), dim3(64 * wpw), lds, stream, P, views_dev, n_views, out,
                        row_pitch, view_pitch, (int64_t)0, n_envs, pes ? 1 : 0, M, views_stride,
                        write_through_pays((uint64_t)n_envs * (uint64_t)(n_views > 1 ? view_pitch * n_views : row_pitch), (uint32_t)v.obs_stride) ? 1 : 0,
-                       reverse ? LAUNCH_REVERSE : 0u);
+                       reverse ? LAUNCH_REVERSE : 0u, epw);
     return hipGetLastError();
 }
 
@@ -786,6 +794,7 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
                 const uint32_t S2 = 64u / ((E / 2u) * a_pad), rl = ((uint32_t)k + S2 - 1u) / S2;
                 if (S2 <= (uint32_t)k && 4u * (uint32_t)k >= 3u * S2 * rl) E >>= 1;
             }
+            while (E > 1 && M.envs_per_map && M.envs_per_map % (int64_t)E != 0) E >>= 1;  // (a batch of E environments belongs to one map)
             if (rule_E) *rule_E = E;  // (what the rule says: lle_batch_observe_as times its neighbours once per batch and window size)
             if (force_E >= 1 && force_E <= e_max && !(force_E & (force_E - 1))) E = force_E;
             if (const uint32_t v = (uint32_t)tuning().partial_e) {
@@ -843,10 +852,11 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
         if (const uint32_t v = (uint32_t)tuning().partial_epw) {
             if (v >= 1 && v <= OBS_ENVS_PER_WAVE && !(v & (v - 1))) epw = v;
         }
+        while (epw > 1 && M.envs_per_map && M.envs_per_map % (int64_t)epw != 0) epw >>= 1;
         const uint32_t ent_cap = n_entities;  // an upper bound computed by the host from the map(s)
         const uint32_t rec_dwords = As / 2 + 1 + h.L + (uint32_t)src_stride_of((int)h.L) / 4u;
         const uint32_t shared = (16u + ent_cap * 4u + 15u) & ~15u, priv = pitch + ((epw * rec_dwords * 4u + 15u) & ~15u);
-        uint32_t wpw = cap_wpw(4, M);
+        uint32_t wpw = cap_wpw(4, M, epw);
         while (wpw > 1 && shared + wpw * priv > OBS_LDS_LIMIT) wpw >>= 1;
         const uint32_t lds = shared + wpw * priv;
         if (lds > OBS_LDS_LIMIT) return hipErrorInvalidValue;
@@ -866,9 +876,10 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
     if (const uint32_t v = (uint32_t)tuning().partial_epw) {
         if (v >= 1 && v <= OBS_ENVS_PER_WAVE && !(v & (v - 1))) epw = v;
     }
+    while (epw > 1 && M.envs_per_map && M.envs_per_map % (int64_t)epw != 0) epw >>= 1;
     const uint32_t priv = pitch + ((epw * (As / 2 + 1 + h.L) * 4u + 15u) & ~15u) + (((h.HW + 1u) / 2u * 4u + 15u) & ~15u);
     const uint32_t shared = h.lds_table_bytes + (((uint32_t)(h.A * k * k) * 4u + 15u) & ~15u);
-    uint32_t wpw = cap_wpw(4, M);
+    uint32_t wpw = cap_wpw(4, M, epw);
     while (wpw > 1 && shared + wpw * priv > OBS_LDS_LIMIT) wpw >>= 1;
     const uint32_t lds = shared + wpw * priv;
     if (lds > OBS_LDS_LIMIT) return hipErrorInvalidValue;

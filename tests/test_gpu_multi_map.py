@@ -128,7 +128,7 @@ def test_mismatched_maps_are_refused():
 
     with pytest.raises(RuntimeError, match="agree"):
         BatchedWorld(["S0 . X", "S0 . . X"], 128)
-    with pytest.raises(RuntimeError, match="multiple of 16"):
+    with pytest.raises(RuntimeError, match="multiple of 8"):
         BatchedWorld(["S0 . X", "S0 X ."], 100)
 
 
@@ -161,11 +161,11 @@ def test_env_outputs_on_blocks_of_maps():
                 assert torch.equal(avail.view(torch.bool), w.available_actions(walkable)), (rnd, t, walkable)
 
 
-@pytest.mark.parametrize("n_maps,per", [(1024, 64), (256, 16), (96, 48)])
+@pytest.mark.parametrize("n_maps,per", [(1024, 64), (256, 16), (96, 48), (512, 8), (33, 24)])
 def test_one_map_per_block_at_scale(oracle_mod, n_maps, per):
     """SURVEY.md section 8(d), stretch variant of config 5: per-env distinct maps -- what a learner on generated maps trains on
     (python/lle/generator/world_builder.py:84-89).  1 024 distinct `mapgen.config5(seed)` maps x 64 envs (the bench's
-    `cfg5_multi_map` block), 256 x 16 (one wavefront's worth per map: envs_per_map may be any multiple of 16) and 96 x 48: every block
+    `cfg5_multi_map` block), 256 x 16, 96 x 48, and -- since round 5 -- 512 x 8 (ONE wavefront per map) and 33 x 24: envs_per_map may be any multiple of 8: every block
     against its own oracle batch on the global action stream -- state after every step, the full check (events, observation) on a
     sample of the blocks."""
     from lle_amd import BatchedWorld, mapgen
@@ -195,3 +195,74 @@ def test_one_map_per_block_at_scale(oracle_mod, n_maps, per):
     check(osteps, "fused rollout")
     st = bw.stats()
     assert st["env_steps"] == 16 * n and st["invalid"] == 0
+
+
+@pytest.mark.parametrize("shape", [dict(height=9, width=11, n_agents=3, n_lasers=4, n_gems=3, n_voids=2),
+                                   dict(height=6, width=7, n_agents=1, n_lasers=2, n_gems=2, n_voids=1),
+                                   dict(height=12, width=12, n_agents=12, n_lasers=6, n_gems=4, n_voids=2)])
+def test_eight_envs_per_map(oracle_mod, shape):
+    """Round 5: a map may own as few as EIGHT environments (the reference hands every env its own map, python/lle/generator/
+    world_builder.py:84-89; 16 was the floor until now).  Lane groups of 1, 4 and 16 -- the wavefronts of the small groups are narrowed to
+    8 environments, the 16-lane group takes two wavefronts per map --: single steps, a fused rollout, masked reset, every observation builder
+    and per-environment sources, each block against its own oracle batch."""
+    import torch
+
+    from lle_amd import BatchedWorld
+
+    texts = _maps(9, **shape)
+    per = 8
+    n = per * len(texts)
+    bw = BatchedWorld(texts, n)
+    obs = [oracle_mod.OracleBatch(t, per) for t in texts]
+    check_blocks(bw, obs, None, per, "after creation")
+    for t in range(24):
+        auto = t >= 8
+        bw.step(sample=True, auto_reset=auto, seed=8, t=t, env_offset=100)
+        osteps = [ob.step(None, auto_reset=auto, seed=8, t=t, env_offset=100 + m * per) for m, ob in enumerate(obs)]
+        check_blocks(bw, obs, osteps, per, f"t={t}")
+    bw.rollout(5, auto_reset=True, seed=8, t=24, env_offset=100)
+    for t in range(24, 29):
+        osteps = [ob.step(None, auto_reset=True, seed=8, t=t, env_offset=100 + m * per) for m, ob in enumerate(obs)]
+    check_blocks(bw, obs, osteps, per, "fused rollout")
+    rng = np.random.default_rng(1)
+    mask = (rng.random(n) < 0.5).astype(np.uint8)
+    bw.reset(torch.from_numpy(mask))
+    for m, ob in enumerate(obs):
+        for e in np.nonzero(mask[m * per:(m + 1) * per])[0]:
+            ob.world(int(e)).reset()
+    check_blocks(bw, obs, None, per, "after masked reset")
+    for t in range(4):
+        bw.step(sample=True, seed=9, t=t)
+        for m, ob in enumerate(obs):
+            ob.step(None, seed=9, t=t, env_offset=m * per, want_obs=False)
+
+    def engine(m):
+        def observe(kind, param):
+            try:
+                out = bw.observe_as(kind, param)
+            except IndexError:
+                return None
+            torch.cuda.synchronize()
+            return out[m * per:(m + 1) * per].cpu().numpy()
+
+        def avail(walkable):
+            out = bw.available_actions(walkable)
+            torch.cuda.synchronize()
+            return out[m * per:(m + 1) * per].cpu().numpy()
+        return observe, avail
+    for m, ob in enumerate(obs):
+        compare_all(*engine(m), ob, range(per), f"map {m}")
+    A, L = obs[0].A, bw.map.n_sources
+    colours = legal_colours(bw.maps, rng.integers(0, A, size=(n, L), dtype=np.uint8))
+    bw.set_sources(torch.from_numpy(colours))
+    for m, ob in enumerate(obs):
+        for e in range(per):
+            for l in range(L):
+                ob.world(e).set_source(l, colour=int(colours[m * per + e, l]))
+    check_blocks(bw, obs, None, per, "after set_sources")
+    for t in range(8):
+        bw.step(sample=True, auto_reset=True, seed=4, t=t)
+        osteps = [ob.step(None, auto_reset=True, seed=4, t=t, env_offset=m * per) for m, ob in enumerate(obs)]
+        check_blocks(bw, obs, osteps, per, f"per-env sources t={t}")
+    for m, ob in enumerate(obs):
+        compare_all(*engine(m), ob, range(per), f"per-env sources map {m}")
