@@ -31,3 +31,5 @@ for n_maps in (1024, 4096):
     same = [Map(one) for _ in range(n_maps)]
     run(f"{n_maps} copies of ONE map x {n // n_maps}", same)
     del maps, same
+maps = [Map(mapgen.config5(s)) for s in range(8192)]
+run("8192 maps x 8", maps)
