@@ -411,7 +411,10 @@ typedef struct lle_obs_desc {
 /* Shape, strides and size of the buffer lle_batch_observe_as writes for (kind, param). */
 int lle_batch_obs_desc(lle_batch* b, int kind, int param, lle_obs_desc* out);
 
-/* Write the observation of every env to `out_dev` (device memory, 256-byte aligned, >= desc.bytes). */
+/* Write the observation of every env to `out_dev` (device memory, 256-byte aligned, >= desc.bytes).
+ * LLE_OBS_PARTIAL with k = 3, 5, 7 on a batch of 4 096 environments and more: the FIRST call for a window size times four variants of the writer on this
+ * batch (window tables or bitmap x two batch sizes; identical bytes; about 24 launches and ONE synchronisation of `stream`, so not inside a stream
+ * capture) and later calls launch the fastest; LLE_PARTIAL_NO_TRIAL=1 in the environment skips the trial (profiles/r05_partial.md). */
 int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64_t out_bytes, void* stream);
 
 /* LLE.available_actions (python/lle/env/env.py:146-163): u8 bools [n_envs][A][5] in Action value order N,S,E,W,STAY.
