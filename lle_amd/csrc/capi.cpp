@@ -168,6 +168,13 @@ struct lle_batch {
     uint64_t rows_bytes() const { return (uint64_t)n_envs * row_pitch(); }                     // ... of one launch's rows
 };
 
+// environments per wavefront of the batch's step launches (kernels.hip step_envs_per_wave; small blocks of a multi-map batch with split rows
+// take fewer so that a map's block fills a workgroup)
+static uint32_t batch_step_epw(const lle_batch* b, const StepTune& tune) {
+    const bool split_block = b->envs_per_map != 0 && step_splits_rows(b->hdr, b->per_env_sources, tune);
+    return step_envs_per_wave(b->n_envs, (int)b->hdr.A, tune, split_block ? b->envs_per_map : 0);
+}
+
 // Whether alternating the walk can pay: the rows of one launch must exceed what the 256 MB Infinity Cache keeps of them
 // (LLE_PINGPONG=0 / 1 forces it either way; read per launch, the parity tests run both in one process).
 static bool pingpong_pays(const lle_batch* b, uint64_t row_bytes_per_launch) {
@@ -479,7 +486,7 @@ static int launch(lle_batch* b, int mode, LaunchArgs K, void* stream) {
                                                  "(use lle_batch_reset_sources, which resets such an env in full)");
     }
     if (mode == KMODE_STEP && !b->lane_per_env_step) {
-        K.envs_per_wave = step_envs_per_wave(b->n_envs, (int)b->hdr.A, b->tune);
+        K.envs_per_wave = batch_step_epw(b, b->tune);
         // every wavefront owns one slot of LLE_BUF_STATS (kernel_common.hpp flush_stats): never more wavefronts than slots
         if ((b->n_envs + K.envs_per_wave - 1) / K.envs_per_wave > b->layout.n_stat_blocks)
             return fail(LLE_ERR_ARG, "internal: more wavefronts than counter slots (envs_per_wave below " + std::to_string(MIN_ENVS_PER_WAVE) + ")");
@@ -1276,13 +1283,13 @@ int lle_batch_kernel_info(const lle_batch* b, char* name_buf, size_t cap, int32_
     if (lds_bytes) {
         const bool pes = b->per_env_sources;
         if (!b->lane_per_env_step && step_splits_rows(b->hdr, pes, b->tune)) {
-            const uint32_t cap = 64u / (uint32_t)step_group((int)b->hdr.A), e = step_envs_per_wave(b->n_envs, (int)b->hdr.A, b->tune);
+            const uint32_t cap = 64u / (uint32_t)step_group((int)b->hdr.A), e = batch_step_epw(b, b->tune);
             *lds_bytes = (int32_t)split_lds_bytes(b->hdr, 4, e < cap ? e : cap);
         } else {
             *lds_bytes = (int32_t)kernel_lds_bytes(b->hdr, kernel_waves_per_wg(b->hdr, pes), pes);
         }
     }
-    if (envs_per_wave) *envs_per_wave = b->lane_per_env_step ? (int32_t)b->envs_per_wave : (int32_t)step_envs_per_wave(b->n_envs, (int)b->hdr.A, b->tune);
+    if (envs_per_wave) *envs_per_wave = b->lane_per_env_step ? (int32_t)b->envs_per_wave : (int32_t)batch_step_epw(b, b->tune);
     return LLE_OK;
 }
 
@@ -1299,7 +1306,7 @@ int lle_batch_step_stamped(lle_batch* b, uint32_t flags, uint64_t seed, uint64_t
 int lle_batch_probe_row_fill(lle_batch* b, uint32_t value, void* stream) {
     if (!b) return fail(LLE_ERR_NULL, "NULL batch");
     ON_DEVICE_OF(b);
-    const uint32_t epw = b->lane_per_env_step ? b->envs_per_wave : step_envs_per_wave(b->n_envs, (int)b->hdr.A, b->tune);
+    const uint32_t epw = b->lane_per_env_step ? b->envs_per_wave : batch_step_epw(b, b->tune);
     // the same alternation as the step launches it stands in for
     const bool reverse = next_walk_reversed(b, b->ptrs.obs, b->rows_bytes());
     HIP_TRY(launch_row_fill_probe(b->ptrs.obs, b->n_envs, (uint32_t)b->row_pitch(), epw, value, reverse,
@@ -1376,7 +1383,7 @@ int lle_batch_autotune(lle_batch* b, double budget_ms, void* stream) {
     // where the rule says 4; round 5).  Below MIN_ENVS_PER_WAVE only while the wavefronts still fit LLE_BUF_STATS' slots (step_envs_per_wave).
     std::vector<uint32_t> epws;
     {
-        const uint32_t rule = step_envs_per_wave(b->n_envs, (int)h.A, StepTune());
+        const uint32_t rule = batch_step_epw(b, StepTune());
         for (uint32_t e : {rule * 2u, rule, rule / 2u})
             if (e >= 1 && e <= cap && (e >= MIN_ENVS_PER_WAVE || (b->n_envs + e - 1) / e <= (int64_t)MIN_STAT_SLOTS)) epws.push_back(e);
     }
@@ -1456,7 +1463,7 @@ int lle_batch_tuning(const lle_batch* b, lle_tuning_info* out, char* log_buf, si
     const bool pes = b->per_env_sources;
     const MapHeader& h = b->hdr;
     const uint64_t row_bytes = b->rows_bytes();
-    const uint32_t epw = step_envs_per_wave(b->n_envs, (int)h.A, b->tune);
+    const uint32_t epw = batch_step_epw(b, b->tune);
     const uint32_t n_waves = (uint32_t)((b->n_envs + epw - 1) / epw);
     out->envs_per_wave = (int32_t)epw;
     out->split_rows = step_splits_rows(h, pes, b->tune) ? 1 : 0;

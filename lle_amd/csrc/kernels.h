@@ -108,7 +108,7 @@ hipError_t launch_world_kernel(int mode, const MapHeader& h, const BatchPtrs& P,
 hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const LaunchArgs& K, hipStream_t stream, const StepTune& tune = StepTune());
 bool step_has_row_heads(const MapHeader& h, bool pes);  // whether a single-step launch of this map can take the MODE 6 / 7 / 8 kernels
 int step_group(int A);
-uint32_t step_envs_per_wave(int64_t n, int A, const StepTune& tune = StepTune());
+uint32_t step_envs_per_wave(int64_t n, int A, const StepTune& tune = StepTune(), int64_t split_block = 0);
 int step_lm(int L);
 
 // observers.hip

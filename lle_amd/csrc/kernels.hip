@@ -703,7 +703,7 @@ int step_lm(int L) { return L <= 4 ? 4 : (L <= 8 ? 8 : (L <= 16 ? 16 : 32)); }
 
 // environments per wavefront of the step kernel for a batch of n: as many as fit (64 / G) once that still leaves
 // ~4096 wavefronts (16 per CU), fewer (down to 4) for small batches
-uint32_t step_envs_per_wave(int64_t n, int A, const StepTune& tune) {
+uint32_t step_envs_per_wave(int64_t n, int A, const StepTune& tune, int64_t split_block) {
     uint32_t e = 64u / (uint32_t)step_group(A);
     // LLE_STEP_EPW, then the batch's own choice.  LLE_BUF_STATS holds max(MIN_STAT_SLOTS, n / MIN_ENVS_PER_WAVE) slots, one per wavefront
     // (capi.cpp make_layout), and a wavefront indexes it by its id: fewer than MIN_ENVS_PER_WAVE environments per wavefront only while
@@ -715,6 +715,13 @@ uint32_t step_envs_per_wave(int64_t n, int A, const StepTune& tune) {
     // after the other (0.45 us each on level 1), so at 4 096 envs two per wavefront beat four (5.67 -> 5.41 us), at 1 024 one beats four
     // (5.72 -> 4.73 us); one per wavefront at 4 096 loses again (6.27: four times the table copies).  tools/small_batch_epw.py, round 5.
     while (e > 1 && n / e < 2048) e >>= 1;
+    // Small blocks of a multi-map batch whose rows are split (`split_block` = environments per map): a workgroup serves one map, and what it
+    // pays per map -- the table copy, the one shared row in LDS -- buys the stores of as many wavefronts as the block fills.  Fewer environments
+    // per wavefront until the block fills four: config 5's shape, 4 096 maps x 16: 8 per wavefront (two wavefronts per workgroup) 246 us, 4 per
+    // wavefront (four) 238; 8 192 maps x 8: 314 -> 282 (one map: 211; tools/multimap_epw.py, round 5).  Whole-row launches (small maps) lose
+    // with it: their wavefronts each keep a row of their own, and fewer environments per wavefront only idle the state machine's lanes.
+    if (split_block > 0)
+        while (e > MIN_ENVS_PER_WAVE && split_block % (int64_t)(4u * e) != 0) e >>= 1;
     return e;
 }
 

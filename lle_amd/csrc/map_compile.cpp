@@ -559,6 +559,22 @@ void Map::compile() {
     // ---- assemble blob
     auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     size_t off = sizeof(MapHeader);
+    // the static observation as bits (tables.h off_tmpl_bits), right behind the header: at the same offset in every map of these dimensions
+    std::vector<uint16_t> tmpl_bits(h.n_chunks, 0);
+    std::vector<uint32_t> tmpl_neg;
+    {
+        bool bits_ok = true;
+        for (size_t i = 0; i < tmpl.size(); i++) {
+            if (tmpl[i] == 1) tmpl_bits[i / 16] |= (uint16_t)(1u << (i % 16));
+            else if (tmpl[i] == -1) tmpl_neg.push_back((uint32_t)i);
+            else if (tmpl[i] != 0) bits_ok = false;
+        }
+        bits_ok = bits_ok && tmpl_neg.size() <= TMPL_NEG_MAX;
+        h.off_tmpl_bits = bits_ok ? (uint32_t)off : 0u;
+        h.tmpl_neg_n = bits_ok ? (uint32_t)tmpl_neg.size() : 0u;
+        h.bits_bytes = tmpl_section_bytes(h.n_chunks);
+        off += h.bits_bytes;
+    }
     h.off_cell_lay = (uint32_t)off; off = align16(off + cell_lay.size() * 8);
     h.off_cell_meta = (uint32_t)off; off = align16(off + cell_meta.size() * 4);
     h.off_dyn = (uint32_t)off; off = align16(off + dyn_tab.size() * 8);
@@ -640,6 +656,10 @@ void Map::compile() {
     h.ext_bytes = ((h.off_pes_dyn_chunks - h.off_bare) + h.n_chunks * 2u + 1023u) & ~1023u;
     off = (size_t)h.blob_capacity + h.ext_bytes;
     blob.assign(off, 0);
+    if (h.off_tmpl_bits) {
+        std::memcpy(blob.data() + h.off_tmpl_bits, tmpl_bits.data(), tmpl_bits.size() * 2);
+        if (!tmpl_neg.empty()) std::memcpy(blob.data() + h.off_tmpl_bits + tmpl_bits_bytes(h.n_chunks), tmpl_neg.data(), tmpl_neg.size() * 4);
+    }
     std::memcpy(blob.data() + h.off_bare, bare.data(), bare.size());
     if (!elems.empty()) std::memcpy(blob.data() + h.off_elems, elems.data(), elems.size() * 4);
     if (!recolour.empty()) std::memcpy(blob.data() + h.off_recolour, recolour.data(), recolour.size() * 4);

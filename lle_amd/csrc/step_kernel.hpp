@@ -308,6 +308,26 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     // (PARTIAL, windows of 3 / 5 / 7: the window sets of the launch's window size come in with the tables, right behind them -- tables.h)
     const bool use_sets = PARTIAL && K.win_sets != nullptr;
     const uint32_t ext_bytes = PES ? hdr->ext_bytes : (use_sets ? win_sets_bytes(hdr->HW) : 0u);
+    // split rows: this wavefront's slice of the row, chunks [c_lo, c_hi), is built from the static observation's BITS (tables.h off_tmpl_bits: 2 B
+    // per chunk at a fixed offset behind the header) -- requested HERE, ahead of the table rows, with the wavefront's state: the split-row
+    // launch is the one whose workgroups each read their own map's tables from memory when a batch has thousands of maps, and every dependent
+    // round trip of its prologue then costs a few microseconds in which the workgroup stores nothing (profiles/r05_multi_map.md).
+    constexpr int PB = CAN_SPLIT ? 8 : 1;  // chunks per lane that come in early (slices up to 8 KiB; longer ones: the rest after the barrier)
+    const uint32_t cpw = (h_n_chunks + waves_per_wg - 1u) / waves_per_wg;  // chunks per slice
+    const uint32_t c_lo = wave_in_wg * cpw < h_n_chunks ? wave_in_wg * cpw : h_n_chunks;
+    const uint32_t c_hi = c_lo + cpw < h_n_chunks ? c_lo + cpw : h_n_chunks;
+    uint32_t pre_bits[PB];
+    uint32_t pre_neg = 0xFFFFFFFFu;
+#pragma unroll
+    for (int q = 0; q < PB; q++) pre_bits[q] = 0u;
+    if (CAN_SPLIT && split) {
+        const uint16_t* __restrict__ bits = reinterpret_cast<const uint16_t*>(tables + sizeof(MapHeader)) + c_lo;
+#pragma unroll
+        for (int q = 0; q < PB; q++)
+            if (lane + 64u * q < c_hi - c_lo) pre_bits[q] = bits[lane + 64u * q];
+        if (lane < TMPL_NEG_MAX) pre_neg = reinterpret_cast<const uint32_t*>(tables + sizeof(MapHeader) + tmpl_bits_bytes(h_n_chunks))[lane];
+        if (!HEAD) LLE_LOAD_STATE();
+    }
     if (PES) copy_tables2_to_lds(tables + tab_off, tab_bytes, tables + h_off_bare, ext_bytes, lds, lane, wave_in_wg, waves_per_wg);
     else if (use_sets) copy_tables2_to_lds(tables + tab_off, tab_bytes, K.win_sets + (uint64_t)map_idx * win_table_bytes(hdr->HW), ext_bytes, lds, lane, wave_in_wg, waves_per_wg);
     else copy_tables_to_lds(tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
@@ -357,7 +377,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         }
     } else {
         __syncthreads();  // the only workgroup barrier
-        LLE_LOAD_STATE();
+        if (!(CAN_SPLIT && split)) LLE_LOAD_STATE();  // (split rows: requested ahead of the table rows, above)
     }
 
     const uint64_t* cell_lay = reinterpret_cast<const uint64_t*>(lds);
@@ -375,15 +395,28 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     const int8_t* bare = reinterpret_cast<const int8_t*>(lds + tab_bytes);
     const uint32_t* elems = reinterpret_cast<const uint32_t*>(lds + tab_bytes + (h_off_elems - h_off_bare));
     // split rows: [tables | one slice per wavefront | the hand-over records of all the workgroup's environments]
-    const uint32_t cpw = (h_n_chunks + waves_per_wg - 1u) / waves_per_wg;  // chunks per slice
-    const uint32_t c_lo = wave_in_wg * cpw < h_n_chunks ? wave_in_wg * cpw : h_n_chunks;
-    const uint32_t c_hi = c_lo + cpw < h_n_chunks ? c_lo + cpw : h_n_chunks;
     if (split) {
         tmpl = reinterpret_cast<int8_t*>(lds + tab_bytes + bt_bytes + wave_in_wg * cpw * 16u);
         scratch = reinterpret_cast<uint32_t*>(lds + tab_bytes + bt_bytes + waves_per_wg * cpw * 16u) + wave_in_wg * EPW * scr_stride;
-        const uint4* __restrict__ pristine = reinterpret_cast<const uint4*>(tables + h_off_template) + c_lo;
         uint4* mine = reinterpret_cast<uint4*>(tmpl);
-        for (uint32_t c = lane; c < c_hi - c_lo; c += 64) mine[c] = pristine[c];
+        if (hdr->off_tmpl_bits) {
+            // Four bits to four bytes: b_i lands on bit 8 i of nibble * (1 + 2^7 + 2^14 + 2^21) (the sixteen partial products fall on distinct
+            // bits: no carries).
+            auto expand = [](uint32_t b) {
+                return uint4{((b & 15u) * 0x00204081u) & 0x01010101u, (((b >> 4) & 15u) * 0x00204081u) & 0x01010101u,
+                             (((b >> 8) & 15u) * 0x00204081u) & 0x01010101u, ((b >> 12) * 0x00204081u) & 0x01010101u};
+            };
+#pragma unroll
+            for (int q = 0; q < PB; q++)
+                if (lane + 64u * q < c_hi - c_lo) mine[lane + 64u * q] = expand(pre_bits[q]);
+            const uint16_t* __restrict__ bits = reinterpret_cast<const uint16_t*>(tables + sizeof(MapHeader)) + c_lo;
+            for (uint32_t c = lane + 64u * PB; c < c_hi - c_lo; c += 64) mine[c] = expand(bits[c]);  // (slices of more than 8 KiB)
+            // ... and the -1 marks of the sources (LDS serves a wavefront's instructions in order: these bytes land on the chunks written above)
+            if (lane < hdr->tmpl_neg_n && pre_neg >= c_lo * 16u && pre_neg < c_hi * 16u) tmpl[pre_neg - c_lo * 16u] = (int8_t)-1;
+        } else {
+            const uint4* __restrict__ pristine = reinterpret_cast<const uint4*>(tables + h_off_template) + c_lo;
+            for (uint32_t c = lane; c < c_hi - c_lo; c += 64) mine[c] = pristine[c];
+        }
     } else if (PARTIAL) {
         if (!use_sets) partial_bitmap_fill(part_bm, cell_lay, cell_meta, (int)hdr->H, W);  // (complete behind the barrier in front of the writer, below)
     } else {

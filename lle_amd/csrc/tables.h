@@ -72,6 +72,15 @@ __host__ __device__
 #endif
 inline constexpr uint32_t win_sets_bytes(uint32_t HW) { return (HW * 16u + 1023u) & ~1023u; }   // the sets alone, in whole rows (MODE 9)
 constexpr uint32_t NO_COLOUR = 31;
+constexpr uint32_t TMPL_NEG_MAX = 64;  // -1 bytes of a static observation that the bit form lists (MapHeader.off_tmpl_bits)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline constexpr uint32_t tmpl_bits_bytes(uint32_t n_chunks) { return (n_chunks * 2u + 15u) & ~15u; }  // the u16s, ahead of the list
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline constexpr uint32_t tmpl_section_bytes(uint32_t n_chunks) { return (tmpl_bits_bytes(n_chunks) + TMPL_NEG_MAX * 4u + 127u) & ~127u; }
 
 struct MapHeader {
     uint32_t magic;          // 'LLE1'
@@ -132,7 +141,14 @@ struct MapHeader {
     // a SECOND run of such lines (level 6: lines 10-11 are the first run, line 14 -- the end of the EXIT plane -- the second): together the
     // `head_lines` the map asks for; chunks, behind the first run (pes_head2_lo > pes_head_lo + pes_head_n), 0: none
     uint32_t pes_head2_lo, pes_head2_n;
-    uint32_t head_pad[13];  // (pads the header to 640 B: the table sections behind it start on a 128-byte line)
+    // The static observation once more, as BITS, between the header and the cell tables (outside every LDS copy; at the same offset in every map of
+    // these dimensions): [u16 per 16-byte chunk of the row: bit i = byte i of the chunk is 1 | u32 byte index of every -1 (the sources' marks), tmpl_neg_n
+    // of them], bits_bytes in all (whole 128-byte lines).  The split-row launch's wavefronts build their slices of the row from it instead of copying
+    // them from `template`: an eighth of the bytes, at an address that does not wait for the header -- what a workgroup reads per map, and in how many
+    // dependent round trips, is what a batch of many maps with few environments each pays on top of one map (profiles/r05_multi_map.md).
+    // off_tmpl_bits == 0: the template holds another value than -1 / 0 / 1 or more than TMPL_NEG_MAX marks; the wavefronts copy it.
+    uint32_t off_tmpl_bits, tmpl_neg_n, bits_bytes;
+    uint32_t head_pad[10];  // (pads the header to 640 B: the table sections behind it start on a 128-byte line)
 };
 static_assert(sizeof(MapHeader) % 128 == 0, "the sections start on a 128-byte line (the LDS copy loads 1 KiB per wave instruction)");
 

@@ -46,6 +46,8 @@ def lib():
         L.hs_observe_as.restype = C.c_int
         L.hs_observe_as.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.hs_available_actions.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.hs_template_from_bits.restype = C.c_int64
+        L.hs_template_from_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.hs_buffer.restype = C.c_void_p
         L.hs_buffer.argtypes = [C.c_void_p, C.c_int]
         _lib = L
@@ -102,6 +104,13 @@ class SimBatch:
         ptr = self.L.hs_buffer(self.h, which)
         arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(_DT[name]))), shape=(count,))
         return arr.reshape(shape)
+
+    def template_from_bits(self):
+        """(rebuilt from the blob's bit form with the kernel's arithmetic, the template itself), or (None, template) when the map has no bit form."""
+        a, b = np.zeros(self.map.obs_stride, np.int8), np.zeros(self.map.obs_stride, np.int8)
+        r = int(self.L.hs_template_from_bits(self.h, a.ctypes.data, b.ctypes.data))
+        assert r >= 0, "malformed bit section"
+        return (a if r else None), b
 
     def reset(self):
         self.L.hs_reset(self.h, None)

@@ -472,6 +472,26 @@ void hs_available_actions(hs_batch* b, int walkable_lasers, uint8_t* out) {
         }
 }
 
+// The static observation rebuilt from its bit form (tables.h off_tmpl_bits) with the arithmetic of the split-row prologue (step_kernel.hpp), next
+// to the template itself: returns obs_stride, or 0 when the map carries no bit form.
+int64_t hs_template_from_bits(hs_batch* b, int8_t* from_bits, int8_t* pristine) {
+    const MapHeader& h = b->map.header;
+    const uint8_t* blob = b->map.blob.data();
+    std::memcpy(pristine, blob + h.off_template, h.obs_stride);
+    if (!h.off_tmpl_bits) return 0;
+    if (h.off_tmpl_bits != sizeof(MapHeader) || h.off_tmpl_bits + h.bits_bytes != h.off_cell_lay || h.tmpl_neg_n > TMPL_NEG_MAX) return -1;
+    const uint16_t* bits = reinterpret_cast<const uint16_t*>(blob + h.off_tmpl_bits);
+    for (uint32_t c = 0; c < h.n_chunks; c++) {
+        const uint32_t v = bits[c];
+        const uint32_t d[4] = {((v & 15u) * 0x00204081u) & 0x01010101u, (((v >> 4) & 15u) * 0x00204081u) & 0x01010101u,
+                               (((v >> 8) & 15u) * 0x00204081u) & 0x01010101u, ((v >> 12) * 0x00204081u) & 0x01010101u};
+        std::memcpy(from_bits + (size_t)c * 16, d, 16);
+    }
+    const uint32_t* neg = reinterpret_cast<const uint32_t*>(blob + h.off_tmpl_bits + tmpl_bits_bytes(h.n_chunks));
+    for (uint32_t i = 0; i < h.tmpl_neg_n; i++) from_bits[neg[i]] = (int8_t)-1;
+    return (int64_t)h.obs_stride;
+}
+
 void* hs_buffer(hs_batch* b, int which) {
     switch (which) {
         case LLE_BUF_POS: return b->pos.data();

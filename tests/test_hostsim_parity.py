@@ -205,3 +205,37 @@ def test_sampler_is_uniform_and_decorrelated(oracle_mod):
         joint = np.bincount(a0 * 5 + a1, minlength=25).astype(float)
         exp = joint.sum() / 25
         assert float(((joint - exp) ** 2 / exp).sum()) < 60, axis  # 24 dof
+
+
+def test_template_bit_form_rebuilds_the_template(oracle_mod):
+    """MapHeader.off_tmpl_bits (tables.h): the static observation as one bit per byte plus the list of -1 marks, which the split-row launch's
+    wavefronts expand instead of copying the template -- the expansion (the kernel's arithmetic, restated in tests/hostsim) gives the template
+    byte for byte, on every level, every extra map, the fuzz maps, config 5's shape, and after a source is re-coloured / disabled (the table
+    is recompiled), and the template is the oracle's observation of a world without agents' and dynamic bytes where both are static."""
+    from lle_amd import mapgen
+    from tests import hostsim
+
+    texts = dict(MAPS)
+    texts.update(dict(_fuzz_maps()[:40]))
+    texts.update({f"config5_{s}": mapgen.config5(s) for s in range(3)})
+    seen = recoloured = 0
+    for name, text in texts.items():
+        sb = hostsim.SimBatch(text, 1)
+        got, tmpl = sb.template_from_bits()
+        assert got is not None, name  # (every value of a static observation is -1 / 0 / 1, at most one mark per source)
+        assert np.array_equal(got, tmpl), name
+        seen += int((tmpl == -1).sum() > 0)
+        if sb.map.n_sources:
+            cur = int(sb.map.sources()[0].agent_id)
+            for c in range(sb.map.n_agents):
+                if c == cur:
+                    continue
+                try:
+                    sb.set_source(0, colour=c, enabled=False)
+                except Exception:
+                    continue  # (a colour whose beam would cross another agent's start is refused)
+                got, tmpl2 = sb.template_from_bits()
+                assert got is not None and np.array_equal(got, tmpl2), (name, "after set_source")
+                recoloured += int(not np.array_equal(tmpl, tmpl2))
+                break
+    assert seen > 10 and recoloured > 5
