@@ -105,7 +105,7 @@ Layout make_layout(const MapHeader& h, int64_t n, int64_t n_maps = 1, uint32_t o
     sz[LLE_BUF_SRC_ENABLED] = n_pad * 4;
     int64_t off = 0;
     l.off_tables = off;
-    l.table_stride = align_up((int64_t)h.blob_capacity + h.ext_bytes);
+    l.table_stride = align_up((int64_t)h.blob_capacity + h.ext_bytes + h.packed_cap);
     off = align_up(off + n_maps * l.table_stride);
     l.off_init = off;
     off = align_up(off + n_maps * (int64_t)sizeof(InitRecord));
@@ -581,6 +581,8 @@ static int common_header(const lle_map* const* maps, int n_maps, MapHeader* out,
         h.lds_table_bytes = std::max(h.lds_table_bytes, o.lds_table_bytes);
         h.blob_capacity = std::max(h.blob_capacity, o.blob_capacity);
         h.ext_bytes = std::max(h.ext_bytes, o.ext_bytes);
+        h.packed_cap = std::max(h.packed_cap, o.packed_cap);
+        if (!o.off_packed) h.off_packed = 0;  // (the common header: non-zero only when every map carries the packed image)
         h.lds_split_table_bytes = std::max(h.lds_split_table_bytes, o.lds_split_table_bytes);
         h.n_elems = std::max(h.n_elems, o.n_elems);
         h.obs_supported = h.obs_supported && o.obs_supported;

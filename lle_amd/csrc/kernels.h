@@ -45,6 +45,7 @@ struct Tuning {
     int row_rotate = -1;       // LLE_ROW_ROTATE = 0 / 1
     int post_first = -1;       // LLE_POST_FIRST = 0 / 1: every wavefront's small outputs after / before its observation stream (default: by position in the grid)
     int head_group = 0;        // LLE_HEAD_GROUP = 1 / 2 / 4: wavefronts whose row heads ONE wavefront stores (step_kernel.hpp HEAD)
+    int packed_tables = -1;    // LLE_PACKED_TABLES = 0 / 1: split-row launches of multi-map batches expand the packed table image (tables.h off_packed)
 };
 const Tuning& tuning();
 void tuning_refresh();

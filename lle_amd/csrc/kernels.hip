@@ -582,6 +582,7 @@ void tuning_refresh() {
     t.row_rotate = env_bool("LLE_ROW_ROTATE");
     t.head_group = env_uint("LLE_HEAD_GROUP");
     t.post_first = env_bool("LLE_POST_FIRST");
+    t.packed_tables = env_bool("LLE_PACKED_TABLES");
     g_tuning.store(fresh, std::memory_order_release);
 }
 const Tuning& tuning() {
@@ -809,6 +810,13 @@ hipError_t launch_step_kernel(const MapHeader& h, const BatchPtrs& P, const Laun
             while (wpw > 1 && K.envs_per_map % (int64_t)(wpw * e) != 0) wpw >>= 1;
         lds = split_lds_bytes(h, wpw, e);
         K.flags |= LAUNCH_SPLIT_ROWS;
+        // A map that serves at most four workgroups is read from memory by each of them, cold, ahead of its first store: those launches take the packed
+        // image of the table section (tables.h off_packed; the common header carries the offset only when every map has one).
+        // LLE_PACKED_TABLES=0 / 1 forces it.
+        // Four-wavefront workgroups only: with two (8 environments per map) the expansion's share per thread doubles and eats the gain
+        // (config 5's shape, us per step verbatim / packed on one arena: 1 024 x 64 250.9 / 245.9, 4 096 x 16 259.1 / 251.2, 8 192 x 8 271.6 / 275.5).
+        if (K.envs_per_map && h.off_packed && (tuning().packed_tables >= 0 ? tuning().packed_tables == 1 : (wpw == 4 && (uint64_t)K.envs_per_map <= 4ull * wpw * e)))
+            K.flags |= LAUNCH_PACKED_TABLES;
     }
     if (K.partial_k) {  // the partial observation written by this launch (MODE 9): single steps with the fused outputs, the map's sources
         if (pes || roll_requested(K) || !K.env_out || !K.partial_E || lm > 8) return hipErrorInvalidValue;

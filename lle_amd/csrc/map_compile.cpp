@@ -655,7 +655,36 @@ void Map::compile() {
     // (sized for the largest table -- every chunk of the row --, so that ext_bytes does not depend on the colours)
     h.ext_bytes = ((h.off_pes_dyn_chunks - h.off_bare) + h.n_chunks * 2u + 1023u) & ~1023u;
     off = (size_t)h.blob_capacity + h.ext_bytes;
+    // ---- the packed image of the table section (tables.h off_packed), sized for the largest dyn table like blob_capacity
+    std::vector<uint16_t> pk_meta(HW), pk_idx;
+    std::vector<uint64_t> pk_lay;
+    bool pk_ok = HW <= 0xFFFF;
+    for (int c = 0; c < HW; c++) {
+        pk_ok = pk_ok && cell_meta[c] <= 0xFFFFu;
+        pk_meta[c] = (uint16_t)cell_meta[c];
+        if (cell_lay[c]) { pk_idx.push_back((uint16_t)c); pk_lay.push_back(cell_lay[c]); }
+    }
+    const uint32_t pk_tail = h.off_template - h.off_dyn;  // (dyn + dynamic chunks, verbatim)
+    h.packed_n_lay = pk_ok ? (uint32_t)pk_idx.size() : 0u;
+    h.packed_bytes = pk_ok ? packed_meta_bytes((uint32_t)HW) + packed_idx_bytes(h.packed_n_lay) + ((h.packed_n_lay * 8u + 15u) & ~15u) + pk_tail : 0u;
+    h.off_packed = pk_ok ? (uint32_t)off : 0u;
+    {   // capacity: every cell with a layer, the largest dyn table, every chunk dynamic -- the same for any colouring of the sources
+        const size_t cap_tail = (((size_t)n_laser_tiles() + (size_t)G) * 8 + 15) / 16 * 16 + ((size_t)h.n_chunks * 2 + 15) / 16 * 16;
+        size_t n_lay_cells = 0;
+        for (auto& l : cell_layers) n_lay_cells += l.empty() ? 0 : 1;
+        h.packed_cap = (uint32_t)((packed_meta_bytes((uint32_t)HW) + packed_idx_bytes((uint32_t)n_lay_cells) + ((n_lay_cells * 8 + 15) & ~(size_t)15) + cap_tail + 127) & ~(size_t)127);
+        off += h.packed_cap;
+    }
     blob.assign(off, 0);
+    if (h.off_packed) {
+        uint8_t* q = blob.data() + h.off_packed;
+        std::memcpy(q, pk_meta.data(), pk_meta.size() * 2); q += packed_meta_bytes((uint32_t)HW);
+        if (!pk_idx.empty()) std::memcpy(q, pk_idx.data(), pk_idx.size() * 2);
+        q += packed_idx_bytes(h.packed_n_lay);
+        if (!pk_lay.empty()) std::memcpy(q, pk_lay.data(), pk_lay.size() * 8);
+        q += (h.packed_n_lay * 8u + 15u) & ~15u;
+        // (the tail is copied below, once the sections it repeats are in place)
+    }
     if (h.off_tmpl_bits) {
         std::memcpy(blob.data() + h.off_tmpl_bits, tmpl_bits.data(), tmpl_bits.size() * 2);
         if (!tmpl_neg.empty()) std::memcpy(blob.data() + h.off_tmpl_bits + tmpl_bits_bytes(h.n_chunks), tmpl_neg.data(), tmpl_neg.size() * 4);
@@ -669,6 +698,7 @@ void Map::compile() {
     if (!dyn_tab.empty()) std::memcpy(blob.data() + h.off_dyn, dyn_tab.data(), dyn_tab.size() * 8);
     std::memcpy(blob.data() + h.off_template, tmpl.data(), tmpl.size());
     if (!dyn_chunks.empty()) std::memcpy(blob.data() + h.off_dyn_chunks, dyn_chunks.data(), dyn_chunks.size() * 2);
+    if (h.off_packed) std::memcpy(blob.data() + h.off_packed + h.packed_bytes - pk_tail, blob.data() + h.off_dyn, pk_tail);
     std::memcpy(blob.data(), &h, sizeof h);
     header = h;
 }

@@ -120,6 +120,37 @@ __device__ __forceinline__ void copy_tables2_to_lds(const uint8_t* __restrict__ 
 }
 #undef LLE_COPY_ROWS
 
+// The same LDS image from the PACKED form of the table section (tables.h off_packed), for launches whose workgroups each read their own map's tables
+// from memory (batches of thousands of maps): 16-bit cell words widened, the layer words of the few cells under a beam scattered over zeros, dyn table
+// and dynamic chunks as they are.  All `T` threads of the workgroup; the first round of every part is requested before the first LDS write.  Contains
+// ONE workgroup barrier (the zeros are in place before the scatter): every wavefront of the workgroup calls it.
+__device__ __forceinline__ void expand_packed_tables(const uint8_t* __restrict__ pk, uint8_t* lds, uint32_t HW, uint32_t n_lay, uint32_t lds_meta, uint32_t lds_dyn,
+                                                     uint32_t tail_bytes, uint32_t tid, uint32_t T) {
+    const uint64_t* __restrict__ m4 = reinterpret_cast<const uint64_t*>(pk);  // four cell words each
+    const uint16_t* __restrict__ idx = reinterpret_cast<const uint16_t*>(pk + packed_meta_bytes(HW));
+    const uint64_t* __restrict__ lay = reinterpret_cast<const uint64_t*>(pk + packed_meta_bytes(HW) + packed_idx_bytes(n_lay));
+    const uint4* __restrict__ tail = reinterpret_cast<const uint4*>(pk + packed_meta_bytes(HW) + packed_idx_bytes(n_lay) + ((n_lay * 8u + 15u) & ~15u));
+    const uint32_t n4 = (HW + 3u) / 4u, nt = tail_bytes / 16u;
+    const uint64_t w0 = tid < n4 ? m4[tid] : 0ull;
+    const uint32_t i0 = tid < n_lay ? (uint32_t)idx[tid] : 0u;
+    const uint64_t l0 = tid < n_lay ? lay[tid] : 0ull;
+    uint4 t0 = {0u, 0u, 0u, 0u};
+    if (tid < nt) t0 = tail[tid];
+    auto widen = [](uint64_t w) { return uint4{(uint32_t)w & 0xFFFFu, (uint32_t)(w >> 16) & 0xFFFFu, (uint32_t)(w >> 32) & 0xFFFFu, (uint32_t)(w >> 48)}; };
+    uint4* z = reinterpret_cast<uint4*>(lds);
+    for (uint32_t i = tid; i < lds_meta / 16u; i += T) z[i] = uint4{0u, 0u, 0u, 0u};
+    uint4* md = reinterpret_cast<uint4*>(lds + lds_meta);
+    if (tid < n4) md[tid] = widen(w0);
+    for (uint32_t i = tid + T; i < n4; i += T) md[i] = widen(m4[i]);
+    uint4* td = reinterpret_cast<uint4*>(lds + lds_dyn);
+    if (tid < nt) td[tid] = t0;
+    for (uint32_t i = tid + T; i < nt; i += T) td[i] = tail[i];
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    uint64_t* ld = reinterpret_cast<uint64_t*>(lds);
+    if (tid < n_lay) ld[i0] = l0;
+    for (uint32_t i = tid + T; i < n_lay; i += T) ld[idx[i]] = lay[i];
+}
+
 // a * b + c with 24-bit a, b in ONE full-rate instruction (v_mad_u32_u24).  __umul24 is a masked 32-bit product to the compiler, which
 // -- in the inner loop of the partial writers -- it turned into v_mul_lo_u32 / v_mad_u64_u32 (quarter rate: three of them per window cell).
 __device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {

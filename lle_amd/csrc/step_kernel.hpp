@@ -330,6 +330,9 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
     }
     if (PES) copy_tables2_to_lds(tables + tab_off, tab_bytes, tables + h_off_bare, ext_bytes, lds, lane, wave_in_wg, waves_per_wg);
     else if (use_sets) copy_tables2_to_lds(tables + tab_off, tab_bytes, K.win_sets + (uint64_t)map_idx * win_table_bytes(hdr->HW), ext_bytes, lds, lane, wave_in_wg, waves_per_wg);
+    else if (CAN_SPLIT && GEN && split && (K.flags & LAUNCH_PACKED_TABLES))  // (many maps, few environments each: obs_stream.hpp expand_packed_tables)
+        expand_packed_tables(tables + hdr->off_packed, lds, h_HW, hdr->packed_n_lay, h_off_cell_meta - tab_off, h_off_dyn - tab_off, h_off_template - h_off_dyn,
+                             threadIdx.x, blockDim.x);
     else copy_tables_to_lds(tables + tab_off, lds, tab_bytes, lane, wave_in_wg, waves_per_wg);
     constexpr uint32_t bt_bytes = BM ? 2u * LM * 4u : 0u;
     uint32_t* beam_tab = reinterpret_cast<uint32_t*>(lds + tab_bytes + ext_bytes);

@@ -80,6 +80,14 @@ inline constexpr uint32_t tmpl_bits_bytes(uint32_t n_chunks) { return (n_chunks 
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
+inline constexpr uint32_t packed_meta_bytes(uint32_t HW) { return (HW * 2u + 15u) & ~15u; }   // packed image: the u16 cell words
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline constexpr uint32_t packed_idx_bytes(uint32_t n_lay) { return (n_lay * 2u + 15u) & ~15u; }  // ... the cells of the layer words
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
 inline constexpr uint32_t tmpl_section_bytes(uint32_t n_chunks) { return (tmpl_bits_bytes(n_chunks) + TMPL_NEG_MAX * 4u + 127u) & ~127u; }
 
 struct MapHeader {
@@ -148,7 +156,15 @@ struct MapHeader {
     // dependent round trips, is what a batch of many maps with few environments each pays on top of one map (profiles/r05_multi_map.md).
     // off_tmpl_bits == 0: the template holds another value than -1 / 0 / 1 or more than TMPL_NEG_MAX marks; the wavefronts copy it.
     uint32_t off_tmpl_bits, tmpl_neg_n, bits_bytes;
-    uint32_t head_pad[10];  // (pads the header to 640 B: the table sections behind it start on a 128-byte line)
+    // The table section [off_cell_lay, off_template) once more, PACKED (behind the per-env-sources section; never copied verbatim):
+    //   [cell_meta as u16[HW] (its 15 bits) | cells u16[packed_n_lay]: the cells with a laser layer | cell_lay u64[packed_n_lay] of those cells |
+    //    the bytes [off_dyn, off_template) as they are (dyn, dynamic chunks)], each part padded to 16 B; packed_bytes in all.
+    // In a batch of thousands of maps with a few environments each, every workgroup reads its map's tables from memory, once, ahead of its first store --
+    // and pays for the bytes (profiles/r05_multi_map.md): the step kernels of such a launch (LAUNCH_PACKED_TABLES) read this image and expand it into the
+    // same LDS layout the verbatim copy gives.  Config 5's shape: 13.3 KB -> 4.1 KB.  off_packed == 0: none (a cell_meta word beyond 16 bits).
+    uint32_t off_packed, packed_bytes, packed_n_lay;
+    uint32_t packed_cap;   // bytes reserved for the image behind off_bare + ext_bytes: its size under any colouring of the sources (capi.cpp table_stride)
+    uint32_t head_pad[6];  // (pads the header to 640 B: the table sections behind it start on a 128-byte line)
 };
 static_assert(sizeof(MapHeader) % 128 == 0, "the sections start on a 128-byte line (the LDS copy loads 1 KiB per wave instruction)");
 
@@ -225,6 +241,7 @@ constexpr uint32_t LAUNCH_ROTATE_ROWS = 0x4000000;     // internal: every wavefr
 // as int8 in LDS and WIDEN AT THE STORE (obs_stream.hpp stream_wide) -- what the reference returns is float32 (python/lle/observations.py:223),
 // what a learner's first layer reads is usually fp16 / bf16; the values are -1, 0, 1 in every type.  Two bits of the launch flags.
 enum ObsElem : uint32_t { OBS_I8 = 0, OBS_F16 = 1, OBS_BF16 = 2, OBS_F32 = 3 };
+constexpr uint32_t LAUNCH_PACKED_TABLES = 0x8000;     // internal (step_kernel, several maps): the workgroups expand MapHeader.off_packed instead of copying the table section
 constexpr uint32_t LAUNCH_OBS_ELEM_SHIFT = 13, LAUNCH_OBS_ELEM_MASK = 3u << LAUNCH_OBS_ELEM_SHIFT;  // internal
 #if defined(__HIPCC__)
 __host__ __device__

@@ -48,6 +48,8 @@ def lib():
         L.hs_available_actions.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.hs_template_from_bits.restype = C.c_int64
         L.hs_template_from_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hs_tables_from_packed.restype = C.c_int64
+        L.hs_tables_from_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int)]
         L.hs_buffer.restype = C.c_void_p
         L.hs_buffer.argtypes = [C.c_void_p, C.c_int]
         _lib = L
@@ -111,6 +113,14 @@ class SimBatch:
         r = int(self.L.hs_template_from_bits(self.h, a.ctypes.data, b.ctypes.data))
         assert r >= 0, "malformed bit section"
         return (a if r else None), b
+
+    def tables_from_packed(self):
+        """(the table section rebuilt from the blob's packed image the way the kernel fills LDS -- None when the map has no image --, the section itself)."""
+        cap = 1 << 22
+        a, b, has = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8), C.c_int(0)
+        n = int(self.L.hs_tables_from_packed(self.h, a.ctypes.data, b.ctypes.data, cap, C.byref(has)))
+        assert n >= 0, "malformed packed image"
+        return (a[:n] if has.value else None), b[:n]
 
     def reset(self):
         self.L.hs_reset(self.h, None)

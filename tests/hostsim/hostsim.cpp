@@ -492,6 +492,33 @@ int64_t hs_template_from_bits(hs_batch* b, int8_t* from_bits, int8_t* pristine) 
     return (int64_t)h.obs_stride;
 }
 
+// The table section [off_cell_lay, off_template) rebuilt from its packed image (tables.h off_packed) the way obs_stream.hpp expand_packed_tables fills
+// LDS, next to the section itself: returns its size, 0 when the map carries no image, -1 when the image is malformed.
+int64_t hs_tables_from_packed(hs_batch* b, uint8_t* from_packed, uint8_t* verbatim, int64_t cap, int* has_image) {
+    const MapHeader& h = b->map.header;
+    const uint8_t* blob = b->map.blob.data();
+    const uint32_t bytes = h.off_template - h.off_cell_lay, HW = h.HW, n_lay = h.packed_n_lay;
+    if ((int64_t)bytes > cap) return -1;
+    std::memcpy(verbatim, blob + h.off_cell_lay, bytes);
+    *has_image = h.off_packed != 0;
+    if (!h.off_packed) return (int64_t)bytes;
+    if (h.off_packed != h.off_bare + h.ext_bytes || (size_t)h.off_packed + h.packed_cap != b->map.blob.size() || h.packed_bytes > h.packed_cap) return -1;
+    const uint8_t* pk = blob + h.off_packed;
+    const uint16_t* m = reinterpret_cast<const uint16_t*>(pk);
+    const uint16_t* idx = reinterpret_cast<const uint16_t*>(pk + packed_meta_bytes(HW));
+    const uint64_t* lay = reinterpret_cast<const uint64_t*>(pk + packed_meta_bytes(HW) + packed_idx_bytes(n_lay));
+    const uint8_t* tail = pk + packed_meta_bytes(HW) + packed_idx_bytes(n_lay) + ((n_lay * 8u + 15u) & ~15u);
+    const uint32_t tail_bytes = h.off_template - h.off_dyn;
+    if (packed_meta_bytes(HW) + packed_idx_bytes(n_lay) + ((n_lay * 8u + 15u) & ~15u) + tail_bytes != h.packed_bytes) return -1;
+    std::memset(from_packed, 0, bytes);
+    uint32_t* md = reinterpret_cast<uint32_t*>(from_packed + (h.off_cell_meta - h.off_cell_lay));
+    for (uint32_t c = 0; c < HW; c++) md[c] = m[c];
+    std::memcpy(from_packed + (h.off_dyn - h.off_cell_lay), tail, tail_bytes);
+    uint64_t* ld = reinterpret_cast<uint64_t*>(from_packed);
+    for (uint32_t i = 0; i < n_lay; i++) ld[idx[i]] = lay[i];
+    return (int64_t)bytes;
+}
+
 void* hs_buffer(hs_batch* b, int which) {
     switch (which) {
         case LLE_BUF_POS: return b->pos.data();

@@ -197,6 +197,42 @@ def test_one_map_per_block_at_scale(oracle_mod, n_maps, per):
     assert st["env_steps"] == 16 * n and st["invalid"] == 0
 
 
+@pytest.mark.parametrize("per", [8, 16, 64])
+@pytest.mark.parametrize("packed", ["0", "1"])
+def test_packed_table_image_either_way(oracle_mod, monkeypatch, per, packed):
+    """tables.h off_packed: the split-row launches of a multi-map batch expand the packed image of the table section (16-bit cell words, the layer words
+    of the cells under a beam scattered over zeros) instead of copying it -- by default where a map's block fills a four-wavefront workgroup.  Both
+    ways forced (LLE_PACKED_TABLES) on blocks of 8 (two wavefronts per workgroup), 16 and 64: single steps, the fused outputs, a rollout; every
+    block against its own oracle batch, observation included."""
+    import torch
+
+    from lle_amd import BatchedWorld, _capi, mapgen
+
+    monkeypatch.setenv("LLE_PACKED_TABLES", packed)
+    _capi.refresh_tuning()
+    try:
+        n_maps = 40
+        texts = [mapgen.config5(100 + s) for s in range(n_maps)]
+        n = n_maps * per
+        bw = BatchedWorld(texts, n)
+        obs = [oracle_mod.OracleBatch(t, per) for t in texts]
+        check_blocks(bw, obs, None, per, "after creation")
+        done = torch.empty(n, dtype=torch.uint8, device="cuda")
+        eo = bw.make_env_outputs(done=done)
+        for t in range(10):
+            auto = t >= 3
+            bw.step(sample=True, auto_reset=auto, seed=4, t=t, env_offset=7, env_out=eo if t % 3 == 2 else None)
+            osteps = [ob.step(None, auto_reset=auto, seed=4, t=t, env_offset=7 + m * per) for m, ob in enumerate(obs)]
+            check_blocks(bw, obs, osteps, per, f"packed={packed} t={t}")
+        bw.rollout(4, auto_reset=True, seed=4, t=10, env_offset=7)
+        for t in range(10, 14):
+            osteps = [ob.step(None, auto_reset=True, seed=4, t=t, env_offset=7 + m * per) for m, ob in enumerate(obs)]
+        check_blocks(bw, obs, osteps, per, f"packed={packed} fused rollout")
+    finally:
+        monkeypatch.delenv("LLE_PACKED_TABLES")
+        _capi.refresh_tuning()
+
+
 @pytest.mark.parametrize("shape", [dict(height=9, width=11, n_agents=3, n_lasers=4, n_gems=3, n_voids=2),
                                    dict(height=6, width=7, n_agents=1, n_lasers=2, n_gems=2, n_voids=1),
                                    dict(height=12, width=12, n_agents=12, n_lasers=6, n_gems=4, n_voids=2)])

@@ -207,8 +207,9 @@ def test_sampler_is_uniform_and_decorrelated(oracle_mod):
         assert float(((joint - exp) ** 2 / exp).sum()) < 60, axis  # 24 dof
 
 
-def test_template_bit_form_rebuilds_the_template(oracle_mod):
-    """MapHeader.off_tmpl_bits (tables.h): the static observation as one bit per byte plus the list of -1 marks, which the split-row launch's
+def test_template_bit_form_and_packed_tables_rebuild_the_sections(oracle_mod):
+    """MapHeader.off_packed (tables.h): the table section as 16-bit cell words + the layer words of the cells under a beam + dyn table and dynamic chunks,
+    expanded (tests/hostsim: the kernel's arithmetic) gives the verbatim section byte for byte.  MapHeader.off_tmpl_bits (tables.h): the static observation as one bit per byte plus the list of -1 marks, which the split-row launch's
     wavefronts expand instead of copying the template -- the expansion (the kernel's arithmetic, restated in tests/hostsim) gives the template
     byte for byte, on every level, every extra map, the fuzz maps, config 5's shape, and after a source is re-coloured / disabled (the table
     is recompiled), and the template is the oracle's observation of a world without agents' and dynamic bytes where both are static."""
@@ -224,6 +225,8 @@ def test_template_bit_form_rebuilds_the_template(oracle_mod):
         got, tmpl = sb.template_from_bits()
         assert got is not None, name  # (every value of a static observation is -1 / 0 / 1, at most one mark per source)
         assert np.array_equal(got, tmpl), name
+        packed, section = sb.tables_from_packed()  # (tables.h off_packed: the table section as the multi-map split-row launches read it)
+        assert packed is not None and np.array_equal(packed, section), name
         seen += int((tmpl == -1).sum() > 0)
         if sb.map.n_sources:
             cur = int(sb.map.sources()[0].agent_id)
@@ -236,6 +239,8 @@ def test_template_bit_form_rebuilds_the_template(oracle_mod):
                     continue  # (a colour whose beam would cross another agent's start is refused)
                 got, tmpl2 = sb.template_from_bits()
                 assert got is not None and np.array_equal(got, tmpl2), (name, "after set_source")
+                packed, section = sb.tables_from_packed()
+                assert packed is not None and np.array_equal(packed, section), (name, "after set_source")
                 recoloured += int(not np.array_equal(tmpl, tmpl2))
                 break
     assert seen > 10 and recoloured > 5
