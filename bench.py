@@ -457,13 +457,16 @@ def measure_config(torch, timer, dev, map_or_text, n_envs, algo_bytes, steps, la
     return out
 
 
-def measure_multi_map(torch, timer, dev, steps, single_map_kernel_ms):
+def measure_multi_map(torch, timer, dev, steps, single_map_kernel_ms, single_map_frac_of_fill=None):
     """SURVEY.md section 8(d), stretch variant of configs[4]: per-env DISTINCT maps -- 1 024 (and 4 096) different `mapgen.config5(seed)`
     maps in one batch of 65 536 envs, 64 (16) envs per map (lle_batch_create_multi: what a learner on generated maps steps,
     python/lle/generator/world_builder.py:84-89).  Same launches as the cfg5 block: sampled actions + auto-reset + int8 layered obs."""
     from lle_amd import BatchedWorld, mapgen
     out = {"what": "BASELINE configs[4] with a different generated 32x32 map per block of envs; kernel_ms by HIP events", "n_envs": 65536,
-           "single_map_kernel_ms": single_map_kernel_ms}
+           "single_map_kernel_ms": single_map_kernel_ms, "single_map_frac_of_fill": single_map_frac_of_fill,
+           "note": "every batch sits on its own arena, and past the Infinity Cache an arena's write rate is a lottery (row_fill_us: the same stores with no state "
+                   "machine, 175-230 us by arena): vs_single_map compares raw times across arenas, vs_single_map_at_equal_fill each launch against its OWN arena's "
+                   "fill (profiles/r05_multi_map.md)"}
     for n_maps in (1024, 4096, 8192):  # (8 192 x 8: one wavefront per map, supported since round 5)
         per = 65536 // n_maps
         t0 = time.perf_counter()
@@ -483,7 +486,9 @@ def measure_multi_map(torch, timer, dev, steps, single_map_kernel_ms):
         achieved = ALGO_BYTES_CFG5 * 65536 / (ms * 1e-3) / 1e9
         out[f"maps{n_maps}_x{per}"] = {"n_maps": n_maps, "envs_per_map": per, "steps": steps, "kernel_ms": ms, "ms_per_step": wall / steps * 1e3,
                                        "achieved_GBps": achieved, "vs_single_map": ms / single_map_kernel_ms if single_map_kernel_ms else None,
-                                       "row_fill_us": p_ms * 1e3, "frac_of_fill": p_ms / ms, "placement": bw.placement,
+                                       "row_fill_us": p_ms * 1e3, "frac_of_fill": p_ms / ms,
+                                       "vs_single_map_at_equal_fill": (single_map_frac_of_fill / (p_ms / ms)) if single_map_frac_of_fill else None,
+                                       "placement": bw.placement,
                                        "create_s": create_s, "table_MB": n_maps * bw.maps[0].table_bytes / 1e6, "kernel": bw.kernel_info(),
                                        "rollout_stats": bw.stats()}
         del bw, fn
@@ -853,7 +858,8 @@ def main():
     if world == 1 and not args.no_configs:
         incremental = measure_incremental(torch, timer, dev, max(args.config_steps, 200))
         if not args.no_multi_map:
-            multi = measure_multi_map(torch, timer, dev, max(args.config_steps // 2, 50), cfgs["cfg5_32x32_a8_l8_65536"]["kernel_ms"])
+            multi = measure_multi_map(torch, timer, dev, max(args.config_steps // 2, 50), cfgs["cfg5_32x32_a8_l8_65536"]["kernel_ms"],
+                                          (cfgs["cfg5_32x32_a8_l8_65536"].get("fill_ceiling") or {}).get("frac_of_fill"))
         lle_step = measure_lle_step(torch, timer, dev, n, max(args.config_steps, 200))
         observers = measure_observers(torch, timer, dev, n, max(args.config_steps, 200))
         consumer = measure_consumer_loop(torch, timer, dev, max(args.config_steps, 200))

@@ -596,3 +596,33 @@ def test_default_step_is_one_launch_into_fresh_tensors(kw):
     for r, rc, av, avc in earlier:  # no later step wrote into an earlier step's tensors
         assert torch.equal(r, rc) and torch.equal(av, avc)
     assert len({e[0].data_ptr() for e in earlier[-3:]}) == 3
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(obs_type="flattened"), dict(randomize_lasers=True), dict(state_type="layered", obs_type="partial3x3")])
+def test_batched_lle_in_the_learner_dtype(kw):
+    """BatchedLLE(obs_dtype=...): the layered observation (obs_type / state_type "layered", "flattened") arrives from the step kernel as float32 --
+    the reference's element type, python/lle/observations.py:223 --, float16 or bfloat16; every step path (default one-launch, two launches, fused,
+    persistent), reset included: the values of the int8 environment stepped alongside, cast."""
+    import torch
+
+    from lle_amd import BatchedLLE
+
+    n = 700
+    for dt in (torch.float32, torch.float16, torch.bfloat16):
+        a, b = BatchedLLE(LEVELS[6], n, seed=5, obs_dtype=dt, **kw), BatchedLLE(LEVELS[6], n, seed=5, **kw)
+        (oa, sa), (ob, sb) = a.reset(), b.reset()
+        layered_obs = kw.get("obs_type", "layered") in ("layered", "flattened")
+        assert oa.dtype == (dt if layered_obs else torch.int8) and torch.equal(oa, ob.to(oa.dtype))
+        assert torch.equal(sa, sb.to(sa.dtype))
+        g = torch.Generator(device="cuda").manual_seed(3)
+        for t, how in enumerate([dict(), dict(fused=False), dict(fused=True), dict(persistent=True)] * 4):
+            acts = torch.multinomial(a.available_actions().reshape(-1, 5).float(), 1, generator=g).reshape(n, -1).to(torch.uint8)
+            x, y = a.step(acts, auto_reset=True, **how), b.step(acts, auto_reset=True, **how)
+            if layered_obs:
+                assert x["obs"].dtype == dt and x["obs"].shape == y["obs"].shape
+            if kw.get("state_type") == "layered":
+                assert x["state"].dtype == dt
+            for k in ("obs", "state", "reward", "done", "available_actions", "err"):
+                assert torch.equal(x[k], y[k].to(x[k].dtype)), (kw, dt, how, k, t)
+    with pytest.raises(ValueError):
+        BatchedLLE(LEVELS[6], 64, obs_type="partial3x3", obs_dtype=torch.float32)
