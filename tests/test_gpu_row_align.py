@@ -20,9 +20,9 @@ def padded_rows(monkeypatch):
 
     orig = BatchedWorld.__init__
 
-    def init(self, map_or_text, n_envs, device=None, envs_per_wave=None, row_align=None):
+    def init(self, map_or_text, n_envs, device=None, envs_per_wave=None, row_align=None, **kw):
         align = ALIGN if row_align is None else row_align
-        orig(self, map_or_text, n_envs, device=device, envs_per_wave=envs_per_wave, row_align=align)
+        orig(self, map_or_text, n_envs, device=device, envs_per_wave=envs_per_wave, row_align=align, **kw)
         assert self.map.obs_stride % align == 0 and self.obs_rows.shape[1] == self.map.obs_stride
 
     monkeypatch.setattr(BatchedWorld, "__init__", init)

@@ -14,8 +14,8 @@ def heads_forced_on_aligned_rows(monkeypatch):
     monkeypatch.setenv("LLE_ROW_HEADS", "1")
     orig = BatchedWorld.__init__
 
-    def init(self, map_or_text, n_envs, device=None, envs_per_wave=None, row_align=None):
-        orig(self, map_or_text, n_envs, device=device, envs_per_wave=envs_per_wave, row_align=128 if row_align is None else row_align)
+    def init(self, map_or_text, n_envs, device=None, envs_per_wave=None, row_align=None, **kw):
+        orig(self, map_or_text, n_envs, device=device, envs_per_wave=envs_per_wave, row_align=128 if row_align is None else row_align, **kw)
 
     monkeypatch.setattr(BatchedWorld, "__init__", init)
 
