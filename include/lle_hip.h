@@ -351,9 +351,10 @@ int lle_batch_observe(lle_batch* b, void* stream);
 /* ---- batches of SEVERAL maps (e.g. one generated map per block of environments; SURVEY.md section 8(d), config 5 variant)
  * Map m owns the envs [m * envs_per_map, (m + 1) * envs_per_map); n_envs = n_maps * envs_per_map.  The maps must agree on
  * height, width and the numbers of agents, sources and gems (one tensor shape, one kernel instantiation); walls, exits,
- * starts, beams and colours are free.  envs_per_map must be a multiple of 8 (16 until round 5): a wavefront serves one map (from 64 on, whole workgroups
- * do; below that the workgroups -- and, on maps with up to four agents, the wavefronts -- are narrowed, which costs throughput: bench.py cfg5_multi_map).  Every entry
- * point works on such a batch except lle_batch_update_sources (use lle_batch_set_sources). */
+ * starts, beams and colours are free.  envs_per_map: any positive number, down to ONE map per environment (the reference's WorldBuilder hands every env
+ * its own map; a multiple of 8 was required until the end of round 5, of 16 before).  A wavefront serves one map: from 64 envs per map on the launches keep
+ * their full shape; below that the workgroups -- and, below a wavefront's worth, the wavefronts -- are narrowed, which costs throughput (INTEGRATION.md
+ * section 6; bench.py cfg5_multi_map).  Every entry point works on such a batch except lle_batch_update_sources (use lle_batch_set_sources). */
 int64_t lle_batch_arena_bytes_multi(const lle_map* const* maps, int n_maps, int64_t envs_per_map);
 lle_batch* lle_batch_create_multi(const lle_map* const* maps, int n_maps, int64_t envs_per_map, int device_id, void* arena,
                                   int64_t arena_bytes, void* stream);

@@ -63,7 +63,8 @@ class BatchedWorld:
                  autotune_ms=None, incremental_obs=False):
         """`map_or_text`: a Map / map text, or a LIST of them for a batch of several maps -- map m then owns the envs
         [m * n_envs / len(maps), (m + 1) * n_envs / len(maps)); the maps must agree on height, width and the numbers of
-        agents, sources and gems, and each must own a multiple of 8 envs (64 and more keep full workgroups).
+        agents, sources and gems; any number of envs per map, down to one map per env (round 5; a wavefront serves one map, so blocks of 64 and
+        more keep the kernels' full shape, smaller ones cost throughput: INTEGRATION.md section 6).
         `row_align`: pitch of the observation rows in bytes (Map.set_row_align: applied to the maps given).
         `placement_candidates`: k > 1 allocates k arenas, times the step kernel's store pattern on each
         (lle_batch_probe_row_fill) and keeps the fastest; the others are released (torch.cuda.empty_cache()).  Worth it only

@@ -83,7 +83,12 @@ Layout make_layout(const MapHeader& h, int64_t n, int64_t n_maps = 1, uint32_t o
     const int64_t L = h.L;
     const int64_t A = agent_stride((int)h.A, (int)h.L);  // per-agent buffers are strided by the kernel's agent bound
     const int64_t n_pad = (n + 1 + 63) / 64 * 64;  // + one hidden env (slot n) used to compute the reset state on the device
-    l.n_stat_blocks = std::max<int64_t>(MIN_STAT_SLOTS, (n + MIN_ENVS_PER_WAVE - 1) / MIN_ENVS_PER_WAVE);  // one slot per wavefront
+    // one slot of LLE_BUF_STATS per wavefront.  A wavefront serves ONE map, so in a batch of several maps it takes at most the largest power of two that
+    // divides envs_per_map (1 when every env has its own map: a slot per environment)
+    int64_t min_epw = MIN_ENVS_PER_WAVE;
+    if (n_maps > 1)
+        while (min_epw > 1 && (n / n_maps) % min_epw != 0) min_epw >>= 1;
+    l.n_stat_blocks = std::max<int64_t>(MIN_STAT_SLOTS, (n + min_epw - 1) / min_epw);
     int64_t sz[LLE_BUF_COUNT];
     sz[LLE_BUF_POS] = n_pad * A * 2;
     sz[LLE_BUF_BITS] = n_pad * 8;
@@ -172,7 +177,14 @@ struct lle_batch {
 // take fewer so that a map's block fills a workgroup)
 static uint32_t batch_step_epw(const lle_batch* b, const StepTune& tune) {
     const bool split_block = b->envs_per_map != 0 && step_splits_rows(b->hdr, b->per_env_sources, tune);
-    return step_envs_per_wave(b->n_envs, (int)b->hdr.A, tune, split_block ? b->envs_per_map : 0);
+    uint32_t e = step_envs_per_wave(b->n_envs, (int)b->hdr.A, tune, split_block ? b->envs_per_map : 0);
+    // a wavefront serves one map (the launcher narrows it the same way; done HERE so that the check against the counter slots sees the final number)
+    if (b->envs_per_map) {
+        const uint32_t cap = 64u / (uint32_t)step_group((int)b->hdr.A);
+        e = e < cap ? e : cap;
+        while (e > 1 && b->envs_per_map % (int64_t)e != 0) e >>= 1;
+    }
+    return e;
 }
 
 // Whether alternating the walk can pay: the rows of one launch must exceed what the 256 MB Infinity Cache keeps of them
@@ -497,6 +509,10 @@ static int launch(lle_batch* b, int mode, LaunchArgs K, void* stream) {
         HIP_TRY(launch_step_kernel(b->hdr, b->ptrs, K, (hipStream_t)stream, b->tune));
     }
     else {
+        if (b->envs_per_map)  // (narrowed like the launcher will: the lane-per-env STEP flushes its counters per wavefront too)
+            while (K.envs_per_wave > 1 && b->envs_per_map % (int64_t)K.envs_per_wave != 0) K.envs_per_wave >>= 1;
+        if (mode == KMODE_STEP && (b->n_envs + K.envs_per_wave - 1) / K.envs_per_wave > b->layout.n_stat_blocks)
+            return fail(LLE_ERR_ARG, "internal: more wavefronts than counter slots");
         if (mode != KMODE_SET_STATE && next_walk_reversed(b, b->ptrs.obs, b->rows_bytes())) K.flags |= LAUNCH_REVERSE;
         HIP_TRY(launch_world_kernel(mode, b->hdr, b->ptrs, K, (hipStream_t)stream));
     }
@@ -647,8 +663,8 @@ lle_batch* lle_batch_create_multi(const lle_map* const* maps, int n_maps, int64_
     if (!maps || n_maps <= 0) { fail(LLE_ERR_ARG, "no maps"); return nullptr; }
     for (int m = 0; m < n_maps; m++)
         if (!maps[m]) { fail(LLE_ERR_NULL, "NULL map"); return nullptr; }
-    if (envs_per_map <= 0 || (n_maps > 1 && envs_per_map % 8 != 0)) {
-        fail(LLE_ERR_ARG, "envs_per_map must be a positive multiple of 8 (a wavefront serves one map)");
+    if (envs_per_map <= 0) {
+        fail(LLE_ERR_ARG, "envs_per_map must be positive");
         return nullptr;
     }
     return create_batch(maps, n_maps, envs_per_map * n_maps, device_id, arena, arena_bytes, stream);
@@ -670,8 +686,8 @@ lle_batch* lle_batch_create_opt(const lle_map* const* maps, int n_maps, int64_t 
     if (!maps || n_maps <= 0) { fail(LLE_ERR_ARG, "no maps"); return nullptr; }
     for (int m = 0; m < n_maps; m++)
         if (!maps[m]) { fail(LLE_ERR_NULL, "NULL map"); return nullptr; }
-    if (envs_per_map <= 0 || (n_maps > 1 && envs_per_map % 8 != 0)) {
-        fail(LLE_ERR_ARG, "envs_per_map must be a positive multiple of 8 (a wavefront serves one map)");
+    if (envs_per_map <= 0) {
+        fail(LLE_ERR_ARG, "envs_per_map must be positive");
         return nullptr;
     }
     return create_batch(maps, n_maps, envs_per_map * n_maps, device_id, arena, arena_bytes, stream, opt);
