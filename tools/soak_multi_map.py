@@ -1,4 +1,4 @@
-"""Soak differential for batches of MANY maps (lle_batch_create_multi): every round builds a batch of distinct generated maps with 8 / 16 / 24 / 64
+"""Soak differential for batches of MANY maps (lle_batch_create_multi): every round builds a batch of distinct generated maps with 8 / 16 / 24 / 64 / 1 / 3 / 5 / 2
 environments each -- config 5's shape (split rows: the bit-form template, and the packed table image where a map's block fills four wavefronts) and a
 small shape (whole rows) --, steps it with sampled actions and auto-reset, and compares every buffer of every env with that map's own oracle batch after
 every step (state, ordered events, availability, error codes, the full observation), a fused rollout of 4 steps every 8th step.
@@ -21,7 +21,7 @@ t_end = time.time() + budget
 total, rnd, seed0 = 0, 0, 5000
 while time.time() < t_end:
     for shape, gen in shapes.items():
-        per = (8, 16, 24, 64)[rnd % 4]
+        per = (8, 16, 24, 64, 1, 3, 5, 2)[rnd % 8]
         n_maps = 96 if shape == "config5" else 160
         texts = []
         while len(texts) < n_maps:
