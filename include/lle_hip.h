@@ -367,8 +367,10 @@ int lle_batch_n_maps(const lle_batch* b);
  * kernel, reset, observe, the source / exit updates -- and the fused rollout's observation ring WIDEN AT THE STORE: the row is built as int8 in
  * LDS as before and leaves the chip in the caller's type, once.  LLE_BUF_OBS then holds [n][obs_stride] ELEMENTS of that type
  * (lle_buffer_desc.elem_bytes = 1 / 2 / 2 / 4; stride and shape in elements, unchanged), lle_rollout_ring.obs likewise
- * [R][n][obs_stride] elements.  Content: exactly the int8 tensor, cast (tests/test_gpu_obs_dtype.py).  The other observation builders
- * (lle_batch_observe_as, the partial observation of lle_batch_step_outputs) keep the element types of lle_obs_desc.
+ * [R][n][obs_stride] elements.  Content: exactly the int8 tensor, cast (tests/test_gpu_obs_dtype.py).  The other layered-style observations
+ * (lle_batch_observe_as of LLE_OBS_LAYERED / _LAYERED_PADDED / _PERSPECTIVE / _PARTIAL, the partial observation of lle_batch_step_outputs) come in the
+ * same type since the end of round 5 -- lle_obs_desc.elem_bytes says so, its strides stay in elements, `bytes` is the buffer to hand --; the state
+ * vector (LLE_OBS_STATE / _NORMALIZED_STATE) is float32 whatever the batch.
  * `opt` == NULL or obs_dtype == LLE_DTYPE_I8: what lle_batch_create / lle_batch_create_multi give.  n_maps == 1: one map (any envs_per_map). */
 enum { LLE_DTYPE_I8 = 0, LLE_DTYPE_F16 = 1, LLE_DTYPE_BF16 = 2, LLE_DTYPE_F32 = 3 };
 typedef struct lle_batch_options {
@@ -400,7 +402,7 @@ enum lle_obs_kind {
 
 typedef struct lle_obs_desc {
     int32_t kind, param;
-    int32_t elem_bytes;  /* 1 (int8) or 4 (float32) */
+    int32_t elem_bytes;  /* the layered-style kinds: element size of the batch's observation type (1 = int8 unless lle_batch_options.obs_dtype); state kinds: 4 (float32) */
     int32_t ndim;        /* dimensions incl. the env axis: shape[0] = n_envs */
     int64_t shape[6];
     int64_t stride[6];   /* in elements */

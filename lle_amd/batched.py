@@ -424,11 +424,19 @@ class BatchedWorld:
         self._check(_capi.lib().lle_batch_obs_desc(self.h, int(kind), int(param), C.byref(d)))
         return d
 
+    def _desc_dtype(self, kind, d):
+        """torch dtype of an observation's elements: float32 for the state kinds; the batch's element type (obs_dtype; int8 by default) for the
+        layered-style ones -- every kernel that writes those widens at the store."""
+        if int(kind) in (_capi.LLE_OBS_STATE, _capi.LLE_OBS_NORMALIZED_STATE):
+            return torch.float32
+        assert int(d.elem_bytes) == self.obs_dtype.itemsize
+        return self.obs_dtype
+
     def observe_as(self, kind, param=0, out=None):
         """Observation `kind` (lle_amd._capi.LLE_OBS_*) of every env, written by the kernels of observers.hip into `out`
         (a uint8 device tensor of obs_desc(kind, param).bytes bytes; allocated when None).  Returns a strided view of
-        that buffer with the reference's per-env shape behind the env axis: int8 for the layered kinds, float32 for
-        the state kinds.  Raises IndexError where the reference does (a laser colour without a layer)."""
+        that buffer with the reference's per-env shape behind the env axis: the batch's element type (int8 unless obs_dtype was given)
+        for the layered kinds, float32 for the state kinds.  Raises IndexError where the reference does (a laser colour without a layer)."""
         d = self.obs_desc(kind, param)
         if not d.supported:
             raise IndexError("a laser colour has no layer in this observation (the reference raises IndexError too)")
@@ -437,7 +445,7 @@ class BatchedWorld:
             out = out[(-out.data_ptr()) % 256:][: int(d.bytes)]
         assert out.dtype == torch.uint8 and out.is_contiguous() and out.numel() >= d.bytes and out.data_ptr() % 16 == 0
         self._check(_capi.lib().lle_batch_observe_as(self.h, int(kind), int(param), out.data_ptr(), out.numel(), self._stream()))
-        dt = torch.int8 if d.elem_bytes == 1 else torch.float32
+        dt = self._desc_dtype(kind, d)
         flat = out[: int(d.bytes)].view(dt)
         return torch.as_strided(flat, [int(d.shape[k]) for k in range(d.ndim)], [int(d.stride[k]) for k in range(d.ndim)])
 
@@ -461,7 +469,7 @@ class BatchedWorld:
                 out = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
                 out = out[(-out.data_ptr()) % 256:][:nbytes]
         assert out.dtype == torch.uint8 and out.is_contiguous() and out.numel() >= d.bytes and out.data_ptr() % 16 == 0
-        dt = torch.int8 if d.elem_bytes == 1 else torch.float32
+        dt = self._desc_dtype(kind, d)
         view = torch.as_strided(out[: int(d.bytes)].view(dt), [int(d.shape[k]) for k in range(d.ndim)], [int(d.stride[k]) for k in range(d.ndim)])
         fn = _capi.lib().lle_batch_observe_as
         args, dev = (C.c_void_p(self.h), C.c_int(int(kind)), C.c_int(int(param)), C.c_void_p(out.data_ptr()), C.c_int64(out.numel())), self.device
@@ -545,13 +553,13 @@ class BatchedWorld:
         return o
 
     def partial_buffer(self, k):
-        """(buffer, view): a uint8 buffer for make_env_outputs(partial=...) and its int8 view [n, A, 2A + 3, k, k]."""
+        """(buffer, view): a uint8 buffer for make_env_outputs(partial=...) and its view [n, A, 2A + 3, k, k] in the batch's element type."""
         d = self.obs_desc(_capi.LLE_OBS_PARTIAL, int(k))
         if not d.supported:
             raise IndexError("a laser colour has no layer in this observation (the reference raises IndexError too)")
         buf = torch.empty(int(d.bytes) + 256, dtype=torch.uint8, device=self.device)
         buf = buf[(-buf.data_ptr()) % 256:][: int(d.bytes)]
-        view = torch.as_strided(buf.view(torch.int8), [int(d.shape[q]) for q in range(d.ndim)], [int(d.stride[q]) for q in range(d.ndim)])
+        view = torch.as_strided(buf.view(self.obs_dtype), [int(d.shape[q]) for q in range(d.ndim)], [int(d.stride[q]) for q in range(d.ndim)])
         return buf, view
 
     def env_outputs(self, state=None, normalize_state=False, reward=None, multi_objective=False, done=None, available=None,

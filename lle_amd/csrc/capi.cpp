@@ -956,17 +956,20 @@ static int obs_desc(const lle_batch* b, int kind, int param, lle_obs_desc* d) {
         d->stride[0] = env_pitch_elems;
         d->bytes = n * env_pitch_elems * elem;
     };
+    // the layered-style observations (-1 / 0 / 1) come in the batch's element type (lle_batch_options.obs_dtype): every kernel that writes them widens
+    // at the store; the state vector is float32 whatever the batch
+    const int el = 1 << obs_elem_shift(b->obs_et);
     switch (kind) {
         case LLE_OBS_LAYERED:
             if (param != 0) return fail(LLE_ERR_ARG, "LLE_OBS_LAYERED takes no parameter");
-            set(1, {n, (int64_t)h.C, H, W}, h.obs_stride);
+            set(el, {n, (int64_t)h.C, H, W}, h.obs_stride);
             d->supported = (int32_t)h.obs_supported;
             return LLE_OK;
         case LLE_OBS_LAYERED_PADDED: {
             if (param < 0 || A + param > 32) return fail(LLE_ERR_ARG, "padding out of range (n_agents + padding <= 32)");
             const int64_t C = 2 * (A + param) + 4;
             if (C * H * W >= (1 << 20)) return fail(LLE_ERR_UNSUPPORTED, "padded observation too large");
-            set(1, {n, C, H, W}, (int64_t)b->maps[0].row_pitch_of((uint32_t)(C * H * W)));
+            set(el, {n, C, H, W}, (int64_t)b->maps[0].row_pitch_of((uint32_t)(C * H * W)));
             for (const Map& mp : b->maps)
                 for (const Source& s : mp.sources)
                     if (s.agent_id >= C - (A + param)) d->supported = 0;
@@ -974,14 +977,14 @@ static int obs_desc(const lle_batch* b, int kind, int param, lle_obs_desc* d) {
         }
         case LLE_OBS_PERSPECTIVE: {
             if (param != 0) return fail(LLE_ERR_ARG, "LLE_OBS_PERSPECTIVE takes no parameter");
-            set(1, {n, A, (int64_t)h.C, H, W}, A * (int64_t)h.obs_stride);
+            set(el, {n, A, (int64_t)h.C, H, W}, A * (int64_t)h.obs_stride);
             d->stride[1] = h.obs_stride;  // one padded layered row per observer
             d->supported = (int32_t)h.obs_supported;
             return LLE_OK;
         }
         case LLE_OBS_PARTIAL: {
             if (param < 1 || param > 15 || param % 2 == 0) return fail(LLE_ERR_ARG, "square size must be odd, 1..15");
-            set(1, {n, A, 2 * A + 3, (int64_t)param, (int64_t)param}, partial_pitch((int)A, param));
+            set(el, {n, A, 2 * A + 3, (int64_t)param, (int64_t)param}, partial_pitch((int)A, param));
             for (const Map& mp : b->maps)
                 for (const Source& s : mp.sources)
                     if (s.agent_id > (int)A + 1) d->supported = 0;  // LASER_0 + colour must be a layer (< 2A+3)
@@ -1063,7 +1066,7 @@ int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64
         LaunchArgs K{};
         K.envs_per_wave = b->envs_per_wave;
         K.env_limit = b->n_envs;
-        K.flags = LAUNCH_PER_ENV_SOURCES;
+        K.flags = LAUNCH_PER_ENV_SOURCES | (b->obs_et << LAUNCH_OBS_ELEM_SHIFT);
         if (next_walk_reversed(b, out_dev, (uint64_t)d.bytes)) K.flags |= LAUNCH_REVERSE;
         K.envs_per_map = b->envs_per_map;
         K.table_stride = (uint32_t)b->layout.table_stride;
@@ -1079,6 +1082,7 @@ int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64
     const bool pes = b->per_env_sources;
     const MapSel M{b->envs_per_map, (uint32_t)b->layout.table_stride, 0u};
     const bool reverse = next_walk_reversed(b, out_dev, (uint64_t)d.bytes);  // (every launch of this call in the same direction)
+    const uint32_t sh = obs_elem_shift(b->obs_et);  // (log2 of the element size of the layered-style outputs)
     switch (kind) {
         case LLE_OBS_LAYERED:
         case LLE_OBS_PERSPECTIVE: {
@@ -1092,14 +1096,14 @@ int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64
                 rc = get_view(b, LLE_OBS_PERSPECTIVE, -1, st, &v);
                 if (rc != LLE_OK) return rc;
                 HIP_TRY(launch_view_observe(v->hdr, b->ptrs, v->dev, (uint32_t)n_views, static_cast<int8_t*>(out_dev),
-                                            (int64_t)n_views * h.obs_stride, (int64_t)h.obs_stride, b->n_envs, pes, h.n_elems, M, v->stride, reverse, st));
+                                            ((int64_t)n_views * h.obs_stride) << sh, (int64_t)h.obs_stride << sh, b->n_envs, pes, h.n_elems, M, v->stride, reverse, st, b->obs_et));
                 break;
             }
             for (int k = 0; k < n_views; k++) {  // big rows: one launch per observer, rows strided by A * obs_stride
                 rc = get_view(b, LLE_OBS_PERSPECTIVE, k, st, &v);
                 if (rc != LLE_OK) return rc;
-                HIP_TRY(launch_view_observe(v->hdr, b->ptrs, v->dev, 1u, static_cast<int8_t*>(out_dev) + (int64_t)k * h.obs_stride,
-                                            (int64_t)n_views * h.obs_stride, 0, b->n_envs, pes, h.n_elems, M, v->stride, reverse, st));
+                HIP_TRY(launch_view_observe(v->hdr, b->ptrs, v->dev, 1u, static_cast<int8_t*>(out_dev) + (((int64_t)k * h.obs_stride) << sh),
+                                            ((int64_t)n_views * h.obs_stride) << sh, 0, b->n_envs, pes, h.n_elems, M, v->stride, reverse, st, b->obs_et));
             }
             break;
         }
@@ -1107,8 +1111,8 @@ int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64
             const lle_batch::View* v;
             rc = get_view(b, kind, param, st, &v);
             if (rc != LLE_OK) return rc;
-            HIP_TRY(launch_view_observe(v->hdr, b->ptrs, v->dev, 1u, static_cast<int8_t*>(out_dev), (int64_t)v->hdr.obs_stride, 0,
-                                        b->n_envs, pes, h.n_elems, M, v->stride, reverse, st));
+            HIP_TRY(launch_view_observe(v->hdr, b->ptrs, v->dev, 1u, static_cast<int8_t*>(out_dev), (int64_t)v->hdr.obs_stride << sh, 0,
+                                        b->n_envs, pes, h.n_elems, M, v->stride, reverse, st, b->obs_et));
             break;
         }
         case LLE_OBS_PARTIAL: {
@@ -1129,7 +1133,7 @@ int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64
             const bool overridden = tn.partial_e || tn.partial_kernel || tn.partial_project >= 0 || tn.partial_batches || getenv("LLE_PARTIAL_NO_SETS") || getenv("LLE_PARTIAL_NO_TRIAL");
             if (!ch.decided && win && !overridden && b->n_envs >= 4096) {
                 uint32_t rule = 0;
-                HIP_TRY(launch_partial_observe(h, b->ptrs, static_cast<int8_t*>(out_dev), param, b->n_envs, b->per_env_sources, M, n_entities, reverse, st, nullptr, 0, &rule));
+                HIP_TRY(launch_partial_observe(h, b->ptrs, static_cast<int8_t*>(out_dev), param, b->n_envs, b->per_env_sources, M, n_entities, reverse, st, nullptr, 0, &rule, b->obs_et));
                 hipEvent_t e0, e1;
                 HIP_TRY(hipEventCreate(&e0));
                 if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return fail(LLE_ERR_HIP, "hipEventCreate"); }
@@ -1142,7 +1146,7 @@ int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64
                     for (int i = 0; i < 6 && err == hipSuccess; i++) {  // two warm-ups, four timed
                         if (i == 2) err = hipEventRecord(e0, st);
                         if (err == hipSuccess)
-                            err = launch_partial_observe(h, b->ptrs, static_cast<int8_t*>(out_dev), param, b->n_envs, b->per_env_sources, M, n_entities, reverse, st, sets ? win : nullptr, E);
+                            err = launch_partial_observe(h, b->ptrs, static_cast<int8_t*>(out_dev), param, b->n_envs, b->per_env_sources, M, n_entities, reverse, st, sets ? win : nullptr, E, nullptr, b->obs_et);
                     }
                     float ms = 0.f;
                     if (err == hipSuccess) err = hipEventRecord(e1, st);
@@ -1157,7 +1161,7 @@ int lle_batch_observe_as(lle_batch* b, int kind, int param, void* out_dev, int64
             const bool use = ch.decided ? ch.use_sets != 0 : false;  // (undecided -- small batches, overrides: the bitmap form and the rule's E, as before round 5; LLE_PARTIAL_SETS=1 forces the sets)
             const bool force_sets = getenv("LLE_PARTIAL_SETS") != nullptr;
             HIP_TRY(launch_partial_observe(h, b->ptrs, static_cast<int8_t*>(out_dev), param, b->n_envs, b->per_env_sources, M, n_entities, reverse, st,
-                                           (use || force_sets) ? win : nullptr, ch.decided ? ch.E : 0u));
+                                           (use || force_sets) ? win : nullptr, ch.decided ? ch.E : 0u, nullptr, b->obs_et));
             break;
         }
         default:

@@ -115,7 +115,7 @@ int step_lm(int L);
 // observers.hip
 hipError_t launch_view_observe(const ViewHeader& v, const BatchPtrs& P, const uint8_t* views_dev, uint32_t n_views, int8_t* out,
                                int64_t row_pitch, int64_t view_pitch, int64_t n_envs, bool pes, uint32_t n_elems, MapSel M,
-                               uint32_t views_stride, bool reverse, hipStream_t stream);
+                               uint32_t views_stride, bool reverse, hipStream_t stream, uint32_t et = OBS_I8 /* element type of the rows: the pitches are in BYTES */);
 // do n_views views fit the LDS of one workgroup together?
 bool view_kernel_fits(const ViewHeader& v, uint32_t n_views, bool pes, uint32_t n_elems);
 uint32_t partial_pitch(int A, int k);
@@ -123,7 +123,8 @@ uint32_t partial_pitch(int A, int k);
 // win_sets: the window tables of k (tables.h; win_table_bytes(HW) apart per map, device memory) or NULL (window sizes other than 3, 5, 7)
 hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t* out, int k, int64_t n_envs, bool per_env_sources,
                                   MapSel M, uint32_t n_entities, bool reverse, hipStream_t stream, const uint8_t* win_sets = nullptr,
-                                  uint32_t force_E = 0 /* environments per batch of the lane kernel; 0: the rule */, uint32_t* rule_E = nullptr);
+                                  uint32_t force_E = 0 /* environments per batch of the lane kernel; 0: the rule */, uint32_t* rule_E = nullptr,
+                                  uint32_t et = OBS_I8 /* element type of the rows (the pitch stays in elements) */);
 hipError_t launch_state_observe(const MapHeader& h, const BatchPtrs& P, float* out, int normalize, int64_t n_envs, hipStream_t stream);
 hipError_t launch_env_outputs(const MapHeader& h, const BatchPtrs& P, const EnvOutputs& O, int64_t n_envs, MapSel M, hipStream_t stream);
 // ceiling probe: n_rows rows of row_bytes (a multiple of 16) filled with the step kernel's store pattern (observers.hip)

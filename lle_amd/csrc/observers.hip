@@ -50,7 +50,8 @@ constexpr uint32_t OBS_LDS_LIMIT = 160 * 1024;
 __global__ void __launch_bounds__(256) view_observe_kernel(BatchPtrs P, const uint8_t* __restrict__ views, uint32_t n_views,
                                                            int8_t* __restrict__ out, int64_t row_pitch, int64_t view_pitch,
                                                            int64_t env_base, int64_t env_limit, int pes, MapSel M, uint32_t views_stride, int wt, uint32_t walk,
-                                                           uint32_t epw /* environments per wavefront: OBS_ENVS_PER_WAVE, or fewer when a map owns fewer */) {
+                                                           uint32_t epw /* environments per wavefront: OBS_ENVS_PER_WAVE, or fewer when a map owns fewer */,
+                                                           uint32_t et /* element type of the rows (tables.h ObsElem): row_pitch / view_pitch are in BYTES */) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t lane = threadIdx.x & 63u, wave_in_wg = threadIdx.x >> 6, waves_per_wg = blockDim.x >> 6;
     const uint32_t blk = xcd_block_dir(blockIdx.x, gridDim.x, walk);  // the block of environments this workgroup serves, and the launch's direction (obs_stream.hpp)
@@ -114,18 +115,23 @@ __global__ void __launch_bounds__(256) view_observe_kernel(BatchPtrs P, const ui
                 for (uint32_t c = lane; c < n_chunks; c += 64) mine[c] = pristine[c];
                 wave_sync();
             }
+            // (the store policy and the element width become template arguments here, outside the loops over the environments: obs_stream.hpp dispatch_stream)
+            const uint32_t sflags = (wt ? LAUNCH_WRITE_THROUGH : 0u) | (et << LAUNCH_OBS_ELEM_SHIFT);
             if (pes) {
                 const int8_t* bare = reinterpret_cast<const int8_t*>(lds + q * blob_bytes + vh->off_bare);
-                if (wt) write_observations_env<true>(A, L, vh->HW, n_elems, n_chunks, (uint64_t)row_pitch, elems, bare, tmpl, scratch, scr_stride,
-                                                     out + (int64_t)q * view_pitch, env0, n_here, lane, vh->laser_layer, vh->gem_layer);
-                else write_observations_env<false>(A, L, vh->HW, n_elems, n_chunks, (uint64_t)row_pitch, elems, bare, tmpl, scratch, scr_stride,
-                                                   out + (int64_t)q * view_pitch, env0, n_here, lane, vh->laser_layer, vh->gem_layer);
+                dispatch_stream<true>(sflags, [&](auto wt_, auto wide_) {
+                    constexpr bool WT = decltype(wt_)::value, WIDE = decltype(wide_)::value;
+                    write_observations_env<WT, false, false, WIDE>(A, L, vh->HW, n_elems, n_chunks, (uint64_t)row_pitch, elems, bare, tmpl, scratch, scr_stride,
+                                                                   out + (int64_t)q * view_pitch, env0, n_here, lane, vh->laser_layer, vh->gem_layer, 0u, 0u, 0u,
+                                                                   nullptr, 0u, 0u, 0u, et);
+                });
             } else {
                 const uint64_t* dyn = reinterpret_cast<const uint64_t*>(lds + q * blob_bytes + vh->off_dyn);
-                if (wt) write_observations<true>(A, L, vh->D, n_chunks, (uint64_t)row_pitch, dyn, tmpl, scratch, scr_stride,
-                                                 out + (int64_t)q * view_pitch, env0, n_here, lane);
-                else write_observations<false>(A, L, vh->D, n_chunks, (uint64_t)row_pitch, dyn, tmpl, scratch, scr_stride,
-                                               out + (int64_t)q * view_pitch, env0, n_here, lane);
+                dispatch_stream<true>(sflags, [&](auto wt_, auto wide_) {
+                    constexpr bool WT = decltype(wt_)::value, WIDE = decltype(wide_)::value;
+                    write_observations<WT, false, false, WIDE>(A, L, vh->D, n_chunks, (uint64_t)row_pitch, dyn, tmpl, scratch, scr_stride,
+                                                               out + (int64_t)q * view_pitch, env0, n_here, lane, 0u, 0u, 0u, nullptr, 0u, et);
+                });
             }
         }
 }
@@ -137,7 +143,7 @@ __global__ void __launch_bounds__(256) view_observe_kernel(BatchPtrs P, const ui
 // non-zero bytes are written), and the row is streamed as 16 B per lane.
 __global__ void __launch_bounds__(256) partial_observe_kernel(BatchPtrs P, int8_t* __restrict__ out, int k, uint32_t pitch,
                                                               int64_t env_base, int64_t env_limit, int per_env_sources, MapSel M,
-                                                              uint32_t epw, uint32_t walk) {
+                                                              uint32_t epw, uint32_t walk, uint32_t et) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t lane = threadIdx.x & 63u, wave_in_wg = threadIdx.x >> 6, waves_per_wg = blockDim.x >> 6;
     const uint32_t blk = xcd_block_dir(blockIdx.x, gridDim.x, walk);
@@ -231,9 +237,10 @@ __global__ void __launch_bounds__(256) partial_observe_kernel(BatchPtrs P, int8_
             if (kind == K_SOURCE) cp[(LASER_0 + (int)T.beam_colour[idx]) * (int)kk] = -1;
         }
         wave_sync();
-        uint4* __restrict__ dst = reinterpret_cast<uint4*>(out + (uint64_t)(env0 + e) * pitch);
+        uint4* __restrict__ dst = reinterpret_cast<uint4*>(out + (((uint64_t)(env0 + e) * pitch) << obs_elem_shift(et)));
         // plain stores: written through (stream_store<true>) this kernel measured 5-10 % slower at every size
-        stream_whole_row<false>(dst, row16, n_chunks, lane);
+        if (et == OBS_I8) stream_whole_row<false>(dst, row16, n_chunks, lane);
+        else stream_wide<false>(dst, reinterpret_cast<const int8_t*>(row16), n_chunks, et, lane);  // (the batch's element type: widened at the store, obs_stream.hpp)
         wave_sync();
     }
 }
@@ -256,7 +263,7 @@ __global__ void __launch_bounds__(256) partial_observe_kernel(BatchPtrs P, int8_
 enum : uint32_t { PE_WALL = 0, PE_EXIT = 1, PE_GEM = 2, PE_TILE = 3, PE_SOURCE = 4, PE_AGENT = 5 };
 __global__ void __launch_bounds__(256) partial_project_kernel(BatchPtrs P, int8_t* __restrict__ out, int k, uint32_t pitch,
                                                               int64_t env_base, int64_t env_limit, int per_env_sources, MapSel M,
-                                                              uint32_t epw, uint32_t ent_cap, uint32_t walk) {
+                                                              uint32_t epw, uint32_t ent_cap, uint32_t walk, uint32_t et) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t lane = threadIdx.x & 63u, wave_in_wg = threadIdx.x >> 6, waves_per_wg = blockDim.x >> 6;
     const uint32_t blk = xcd_block_dir(blockIdx.x, gridDim.x, walk);
@@ -404,8 +411,9 @@ __global__ void __launch_bounds__(256) partial_project_kernel(BatchPtrs P, int8_
             if (in) row[(a * layers + layer) * kk + (uint32_t)(dy * k + dx)] = type == PE_SOURCE ? (int8_t)-1 : (int8_t)1;
         }
         wave_sync();
-        uint4* __restrict__ dst = reinterpret_cast<uint4*>(out + (uint64_t)(env0 + e) * pitch);
-        stream_whole_row<false>(dst, row16, n_chunks, lane);
+        uint4* __restrict__ dst = reinterpret_cast<uint4*>(out + (((uint64_t)(env0 + e) * pitch) << obs_elem_shift(et)));
+        if (et == OBS_I8) stream_whole_row<false>(dst, row16, n_chunks, lane);
+        else stream_wide<false>(dst, reinterpret_cast<const int8_t*>(row16), n_chunks, et, lane);
         wave_sync();
     }
 }
@@ -429,7 +437,7 @@ struct PartialDims { int32_t A, L, H, W; uint32_t off_cell_meta, max_layers; }; 
 __global__ void __launch_bounds__(256) partial_lanes_kernel(BatchPtrs P, int8_t* __restrict__ out, int k, uint32_t pitch, int64_t env_base,
                                                             int64_t env_limit, int per_env_sources, MapSel M, uint32_t E, uint32_t batches,
                                                             uint32_t tab_bytes, int wt, PartialDims D, uint32_t tab_off, uint32_t walk,
-                                                            const uint8_t* __restrict__ win_sets, uint32_t win_bytes) {
+                                                            const uint8_t* __restrict__ win_sets, uint32_t win_bytes, uint32_t et) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t lane = threadIdx.x & 63u, wave_in_wg = threadIdx.x >> 6, waves_per_wg = blockDim.x >> 6;
     const uint32_t blk = xcd_block_dir(blockIdx.x, gridDim.x, walk);
@@ -528,8 +536,11 @@ __global__ void __launch_bounds__(256) partial_lanes_kernel(BatchPtrs P, int8_t*
         // the lane's agents and its share of the window's non-empty cells (partial_stream.hpp: shared with the step kernel's writer)
         partial_window(G, R, live, a, s, mine, dummy, cell_lay, cell_meta, bm, sets, share);
         wave_sync();
-        uint4* __restrict__ dst = reinterpret_cast<uint4*>(out + (uint64_t)env0 * pitch);
-        if (wt) stream_row<true>(dst, rows16, 0u, (uint32_t)n_here * n_chunks, lane);
+        uint4* __restrict__ dst = reinterpret_cast<uint4*>(out + (((uint64_t)env0 * pitch) << obs_elem_shift(et)));
+        if (et != OBS_I8) {  // (the batch's element type: the block of rows widened at the store, obs_stream.hpp stream_wide)
+            if (wt) stream_wide<true>(dst, rows, (uint32_t)n_here * n_chunks, et, lane);
+            else stream_wide<false>(dst, rows, (uint32_t)n_here * n_chunks, et, lane);
+        } else if (wt) stream_row<true>(dst, rows16, 0u, (uint32_t)n_here * n_chunks, lane);
         else stream_row<false>(dst, rows16, 0u, (uint32_t)n_here * n_chunks, lane);
         wave_sync();  // the next batch clears the rows: after these reads (in order, same wavefront)
     }
@@ -737,7 +748,7 @@ static uint32_t cap_wpw(uint32_t wpw, const MapSel& M, uint32_t epw = OBS_ENVS_P
 
 hipError_t launch_view_observe(const ViewHeader& v, const BatchPtrs& P, const uint8_t* views_dev, uint32_t n_views, int8_t* out,
                                int64_t row_pitch, int64_t view_pitch, int64_t n_envs, bool pes, uint32_t n_elems, MapSel M,
-                               uint32_t views_stride, bool reverse, hipStream_t stream) {
+                               uint32_t views_stride, bool reverse, hipStream_t stream, uint32_t et) {
     const uint32_t epw = obs_envs_per_wave(M);
     uint32_t wpw = cap_wpw(4, M, epw);
     while (wpw > 1 && view_lds(v, n_views, wpw, pes, n_elems) > OBS_LDS_LIMIT) wpw >>= 1;
@@ -750,8 +761,8 @@ hipError_t launch_view_observe(const ViewHeader& v, const BatchPtrs& P, const ui
     LLE_NOTE_OBS(OBSK_VIEW);
     hipLaunchKernelGGL(view_observe_kernel, dim3((n_waves + wpw - 1) / wpw), dim3(64 * wpw), lds, stream, P, views_dev, n_views, out,
                        row_pitch, view_pitch, (int64_t)0, n_envs, pes ? 1 : 0, M, views_stride,
-                       write_through_pays((uint64_t)n_envs * (uint64_t)(n_views > 1 ? view_pitch * n_views : row_pitch), (uint32_t)v.obs_stride) ? 1 : 0,
-                       reverse ? LAUNCH_REVERSE : 0u, epw);
+                       write_through_pays((uint64_t)n_envs * (uint64_t)(n_views > 1 ? view_pitch * n_views : row_pitch), (uint32_t)v.obs_stride << obs_elem_shift(et)) ? 1 : 0,
+                       reverse ? LAUNCH_REVERSE : 0u, epw, et);
     return hipGetLastError();
 }
 
@@ -770,7 +781,7 @@ static bool partial_projects(const MapHeader& h, int k, uint32_t n_entities) {
 
 hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t* out, int k, int64_t n_envs, bool per_env_sources,
                                   MapSel M, uint32_t n_entities, bool reverse, hipStream_t stream, const uint8_t* win_sets, uint32_t force_E,
-                                  uint32_t* rule_E) {
+                                  uint32_t* rule_E, uint32_t et) {
     const uint32_t walk = reverse ? LAUNCH_REVERSE : 0u;
     const uint32_t pitch_l = partial_pitch((int)h.A, k);
     int force_old = -1;  // LLE_PARTIAL_KERNEL=window / project: one of the two round-1/2 kernels (kept as cross-checks)
@@ -837,7 +848,7 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
                 const PartialDims D{(int32_t)h.A, (int32_t)h.L, (int32_t)h.H, (int32_t)h.W, h.off_cell_meta - h.off_cell_lay, h.max_layers};
                 LLE_NOTE_OBS(OBSK_PARTIAL_LANES);
                 hipLaunchKernelGGL(partial_lanes_kernel, dim3((n_waves + wpw - 1) / wpw), dim3(64 * wpw), lds, stream, P, out, k, pitch_l,
-                                   (int64_t)0, n_envs, per_env_sources ? 1 : 0, M, E, batches, tab, wt, D, h.off_cell_lay, walk, win_sets, win_bytes);
+                                   (int64_t)0, n_envs, per_env_sources ? 1 : 0, M, E, batches, tab, wt, D, h.off_cell_lay, walk, win_sets, win_bytes, et);
                 return hipGetLastError();
             }
         }
@@ -866,7 +877,7 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
         const uint32_t n_waves = (uint32_t)((n_envs + epw - 1) / epw);
         LLE_NOTE_OBS(OBSK_PARTIAL_PROJECT);
         hipLaunchKernelGGL(partial_project_kernel, dim3((n_waves + wpw - 1) / wpw), dim3(64 * wpw), lds, stream, P, out, k, pitch,
-                           (int64_t)0, n_envs, per_env_sources ? 1 : 0, M, epw, ent_cap, walk);
+                           (int64_t)0, n_envs, per_env_sources ? 1 : 0, M, epw, ent_cap, walk, et);
         return hipGetLastError();
     }
     // envs per wavefront: the chain of one env (clear, agents, cells, stream) is latency, so fewer envs per wave = more
@@ -889,7 +900,7 @@ hipError_t launch_partial_observe(const MapHeader& h, const BatchPtrs& P, int8_t
     const uint32_t n_waves = (uint32_t)((n_envs + epw - 1) / epw);
     LLE_NOTE_OBS(OBSK_PARTIAL_WINDOW);
     hipLaunchKernelGGL(partial_observe_kernel, dim3((n_waves + wpw - 1) / wpw), dim3(64 * wpw), lds, stream, P, out, k, pitch,
-                       (int64_t)0, n_envs, per_env_sources ? 1 : 0, M, epw, walk);
+                       (int64_t)0, n_envs, per_env_sources ? 1 : 0, M, epw, walk, et);
     return hipGetLastError();
 }
 

@@ -200,7 +200,7 @@ template <bool WT>
 __device__ __forceinline__ void write_partial(int A, int L, int W, int k, uint32_t pitch, uint32_t E, uint32_t max_layers, const uint64_t* cell_lay,
                                               const uint32_t* cell_meta, const uint32_t* bm, const uint8_t* colours, int8_t* rows,
                                               const uint32_t* records, uint32_t scr_stride, int8_t* __restrict__ out, int64_t env0,
-                                              int64_t n_here_all, uint32_t lane, const uint64_t* sets = nullptr) {
+                                              int64_t n_here_all, uint32_t lane, const uint64_t* sets = nullptr, uint32_t et = OBS_I8) {
     const uint32_t logA = A <= 1 ? 0u : (A <= 2 ? 1u : (A <= 4 ? 2u : (A <= 8 ? 3u : 4u)));
     const uint32_t S = 64u / (E << logA);                 // lanes per (env, observer); the launcher keeps E << logA <= 64
     const uint32_t e_slot = lane / (S << logA), a = (lane / S) & ((1u << logA) - 1u), s = lane % S;
@@ -220,8 +220,9 @@ __device__ __forceinline__ void write_partial(int A, int L, int W, int k, uint32
         int8_t* mine = rows + __umul24(live ? e_slot : 0u, pitch) + __umul24(a, layers * kk);   // observer a's block of this env's row
         partial_window(G, R, live, a, s, mine, dummy, cell_lay, cell_meta, bm, sets, share);
         wave_sync();
-        uint4* __restrict__ dst = reinterpret_cast<uint4*>(out + (uint64_t)(env0 + b0) * pitch);
-        stream_row<WT>(dst, rows16, 0u, n_here * n_chunks, lane);
+        uint4* __restrict__ dst = reinterpret_cast<uint4*>(out + (((uint64_t)(env0 + b0) * pitch) << obs_elem_shift(et)));
+        if (et != OBS_I8) stream_wide<WT>(dst, rows, n_here * n_chunks, et, lane);  // (the batch's element type: widened at the store, obs_stream.hpp)
+        else stream_row<WT>(dst, rows16, 0u, n_here * n_chunks, lane);
         wave_sync();  // the next batch clears the rows: after these reads (in order, same wavefront)
     }
 }

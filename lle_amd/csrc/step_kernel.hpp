@@ -765,7 +765,7 @@ __global__ void __launch_bounds__(256, (G >= 8 ? 3 : 4)) step_kernel(BatchPtrs P
         const EnvOutputs O = load_uniform(kernarg_env_out());
         if (O.partial && n_here > 0)
             write_partial<true>(A, L, W, (int)K.partial_k, part_pitch, K.partial_E, h_max_layers, cell_lay, cell_meta, part_bm, part_col, tmpl, scratch,
-                                scr_stride, O.partial, env0, n_here, lane, use_sets ? reinterpret_cast<const uint64_t*>(lds + tab_bytes) : nullptr);
+                                scr_stride, O.partial, env0, n_here, lane, use_sets ? reinterpret_cast<const uint64_t*>(lds + tab_bytes) : nullptr, et);
     } else if (write_obs && n_here > 0) {
         dispatch_stream<!HEAD>(K.flags, [&](auto wt_, auto wide_) {  // see stream_store (obs_stream.hpp)
             constexpr bool WT = decltype(wt_)::value, WIDE = decltype(wide_)::value;

@@ -46,8 +46,8 @@ _OBS_KINDS = {
 class BatchedLLE:
     """Arguments follow `LLE.__init__` / `Builder` (python/lle/env/env.py:72-114, builder.py:30-116):
     obs_type / state_type: ObservationType values ("layered", "flattened", "partial3x3", ..., "state", "normalized-state",
-    "perspective", "layered-padded[-k]"; padding_size for plain "layered-padded"); obs_dtype (the layered observation in float32 -- the reference's --,
-    float16 or bfloat16 instead of int8, straight from the step kernel); walkable_lasers; randomize_lasers;
+    "perspective", "layered-padded[-k]"; padding_size for plain "layered-padded"); obs_dtype (the layered-style observations in float32 -- the reference's --,
+    float16 or bfloat16 instead of int8, straight from the kernels); walkable_lasers; randomize_lasers;
     multi_objective (MultiObjective instead of SingleObjective); death_strategy "end" only, like the reference."""
 
     def __init__(self, maps, n_envs, obs_type="layered", state_type="state", walkable_lasers=True, randomize_lasers=False,
@@ -62,11 +62,11 @@ class BatchedLLE:
         self.obs_type, self.state_type = str(obs_type), str(state_type)
         self._obs_kind = self._kind(self.obs_type, padding_size)
         self._state_kind = self._kind(self.state_type, padding_size)
-        # obs_dtype: element type of the LAYERED observation ("layered" / "flattened": the rows the step kernel writes) -- torch.float32 is the
-        # reference's (python/lle/observations.py:223), float16 / bfloat16 what a learner's first layer usually reads; the kernels widen at the
-        # store (BatchedWorld(obs_dtype=...)).  The other observation builders write int8.
-        if obs_dtype is not None and _capi.LLE_OBS_LAYERED not in (self._obs_kind[0], self._state_kind[0]):
-            raise ValueError("obs_dtype is the element type of the layered observation: neither obs_type nor state_type is layered")
+        # obs_dtype: element type of the layered-style observations (layered, flattened, padded, perspective, partial: values -1 / 0 / 1) --
+        # torch.float32 is the reference's (python/lle/observations.py:223), float16 / bfloat16 what a learner's first layer usually reads; every
+        # kernel that writes them widens at the store (BatchedWorld(obs_dtype=...)).  The state vector is float32 whatever the type.
+        if obs_dtype is not None and all(k[0] in (_capi.LLE_OBS_STATE, _capi.LLE_OBS_NORMALIZED_STATE) for k in (self._obs_kind, self._state_kind)):
+            raise ValueError("obs_dtype is the element type of the layered-style observations: obs_type and state_type are both state vectors")
         self.world = BatchedWorld(maps, n_envs, device=device, obs_dtype=obs_dtype)
         self.n_envs, self.n_agents, self.n_actions = self.world.n_envs, self.world.map.n_agents, 5
         # the step kernel's own (layered) observation is only written when somebody reads it

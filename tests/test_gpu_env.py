@@ -598,11 +598,12 @@ def test_default_step_is_one_launch_into_fresh_tensors(kw):
     assert len({e[0].data_ptr() for e in earlier[-3:]}) == 3
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(obs_type="flattened"), dict(randomize_lasers=True), dict(state_type="layered", obs_type="partial3x3")])
+@pytest.mark.parametrize("kw", [dict(), dict(obs_type="flattened"), dict(randomize_lasers=True), dict(state_type="layered", obs_type="partial3x3"),
+                                dict(obs_type="partial7x7"), dict(obs_type="perspective", state_type="layered-padded-2"), dict(obs_type="partial5x5", randomize_lasers=True)])
 def test_batched_lle_in_the_learner_dtype(kw):
-    """BatchedLLE(obs_dtype=...): the layered observation (obs_type / state_type "layered", "flattened") arrives from the step kernel as float32 --
-    the reference's element type, python/lle/observations.py:223 --, float16 or bfloat16; every step path (default one-launch, two launches, fused,
-    persistent), reset included: the values of the int8 environment stepped alongside, cast."""
+    """BatchedLLE(obs_dtype=...): the layered-style observations (layered, flattened, padded, perspective, partial -- the step launch's own partial
+    writer included) arrive from the kernels as float32 -- the reference's element type, python/lle/observations.py:223 --, float16 or bfloat16;
+    every step path (default one-launch, two launches, fused, persistent), reset included: the values of the int8 environment stepped alongside, cast."""
     import torch
 
     from lle_amd import BatchedLLE
@@ -611,8 +612,8 @@ def test_batched_lle_in_the_learner_dtype(kw):
     for dt in (torch.float32, torch.float16, torch.bfloat16):
         a, b = BatchedLLE(LEVELS[6], n, seed=5, obs_dtype=dt, **kw), BatchedLLE(LEVELS[6], n, seed=5, **kw)
         (oa, sa), (ob, sb) = a.reset(), b.reset()
-        layered_obs = kw.get("obs_type", "layered") in ("layered", "flattened")
-        assert oa.dtype == (dt if layered_obs else torch.int8) and torch.equal(oa, ob.to(oa.dtype))
+        layered_obs = True  # (every observation type of these cases is a layered-style one)
+        assert oa.dtype == dt and torch.equal(oa, ob.to(oa.dtype))
         assert torch.equal(sa, sb.to(sa.dtype))
         g = torch.Generator(device="cuda").manual_seed(3)
         for t, how in enumerate([dict(), dict(fused=False), dict(fused=True), dict(persistent=True)] * 4):
@@ -620,9 +621,9 @@ def test_batched_lle_in_the_learner_dtype(kw):
             x, y = a.step(acts, auto_reset=True, **how), b.step(acts, auto_reset=True, **how)
             if layered_obs:
                 assert x["obs"].dtype == dt and x["obs"].shape == y["obs"].shape
-            if kw.get("state_type") == "layered":
+            if kw.get("state_type", "state") != "state":
                 assert x["state"].dtype == dt
             for k in ("obs", "state", "reward", "done", "available_actions", "err"):
                 assert torch.equal(x[k], y[k].to(x[k].dtype)), (kw, dt, how, k, t)
     with pytest.raises(ValueError):
-        BatchedLLE(LEVELS[6], 64, obs_type="partial3x3", obs_dtype=torch.float32)
+        BatchedLLE(LEVELS[6], 64, obs_type="state", obs_dtype=torch.float32)

@@ -10,7 +10,7 @@ from tests.parity_util import EXTRA_MAPS, legal_colours
 
 pytestmark = pytest.mark.gpu
 
-MAPS = {"level6": LEVELS[6], "level1": LEVELS[1], "nested": EXTRA_MAPS["nested"], "colour_alias": EXTRA_MAPS["colour_alias"],
+MAPS = {"level6": LEVELS[6], "level3": LEVELS[3], "level1": LEVELS[1], "nested": EXTRA_MAPS["nested"], "colour_alias": EXTRA_MAPS["colour_alias"],
         "many_agents": EXTRA_MAPS["many_agents"], "gen_20_lasers": EXTRA_MAPS["gen_20_lasers"], "config5_32x32": EXTRA_MAPS["config5_32x32"]}
 
 
@@ -194,3 +194,81 @@ def test_options_are_validated():
     d = _capi.BufferDesc()
     assert L.lle_batch_get_buffer(h, _capi.BUFFER_NAMES.index("obs"), C.byref(d)) == 0 and d.elem_bytes == 2 and d.bytes == 2 * 64 * m.obs_stride
     L.lle_batch_free(h)
+
+
+@pytest.mark.parametrize("name", ["level6", "level3", "nested", "many_agents", "config5_32x32"])
+def test_every_observation_builder_in_the_batch_dtype(name, monkeypatch):
+    """lle_batch_observe_as on a batch created with obs_dtype: layered, layered-padded, perspective (one launch and one launch per observer) and
+    partial 3x3 / 5x5 / 7x7 / 9x9 -- the lane kernel in its window-table and bitmap forms, the window and projection kernels -- come in the
+    batch's element type, the values of the int8 batch's outputs; per-environment sources; the partial observation written by the STEP launch
+    (lle_env_outputs.partial, step kernel MODE 9); the state vector stays float32."""
+    import torch
+
+    from lle_amd import BatchedWorld, _capi
+
+    text = MAPS[name]
+    n = 333
+    kinds = [(_capi.LLE_OBS_LAYERED, 0), (_capi.LLE_OBS_LAYERED_PADDED, 2), (_capi.LLE_OBS_PERSPECTIVE, 0)] + [(_capi.LLE_OBS_PARTIAL, k) for k in (3, 5, 7, 9)]
+    for dt in _dtypes():
+        a, b = BatchedWorld(text, n, obs_dtype=dt), BatchedWorld(text, n)
+        for t in range(9):
+            for w in (a, b):
+                w.step(sample=True, auto_reset=t >= 2, seed=3, t=t)
+
+        def compare(where):
+            for kind, param in kinds:
+                da, db = a.obs_desc(kind, param), b.obs_desc(kind, param)
+                assert da.supported == db.supported and int(da.elem_bytes) == dt.itemsize and int(db.elem_bytes) == 1 and int(da.bytes) == int(db.bytes) * dt.itemsize
+                assert [int(da.stride[q]) for q in range(da.ndim)] == [int(db.stride[q]) for q in range(db.ndim)]  # (strides are in elements)
+                if not da.supported:
+                    continue
+                xa, xb = a.observe_as(kind, param), b.observe_as(kind, param)
+                assert xa.dtype == dt and xb.dtype == torch.int8 and torch.equal(xa, xb.to(dt)), (name, dt, kind, param, where)
+            sa, sb = a.observe_as(_capi.LLE_OBS_STATE), b.observe_as(_capi.LLE_OBS_STATE)
+            assert sa.dtype == torch.float32 and torch.equal(sa, sb)
+        compare("rule")
+        for env in (dict(LLE_PARTIAL_KERNEL="window"), dict(LLE_PARTIAL_KERNEL="project"), dict(LLE_PARTIAL_NO_SETS="1"), dict(LLE_PARTIAL_SETS="1", LLE_PARTIAL_E="2")):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            _capi.refresh_tuning()
+            try:
+                compare(str(env))
+            finally:
+                for k in env:
+                    monkeypatch.delenv(k)
+                _capi.refresh_tuning()
+        if a.map.n_beam_words <= 8:  # the step launch writes the partial observation itself (MODE 9)
+            for k in (3, 7):
+                (ba, va), (bb, vb) = a.partial_buffer(k), b.partial_buffer(k)
+                done = torch.empty(n, dtype=torch.uint8, device="cuda")
+                ea, eb = a.make_env_outputs(done=done, partial=ba, partial_k=k), b.make_env_outputs(done=done, partial=bb, partial_k=k)
+                for t in range(9, 13):
+                    a.step(sample=True, auto_reset=True, seed=3, t=t, env_out=ea)
+                    b.step(sample=True, auto_reset=True, seed=3, t=t, env_out=eb)
+                    assert va.dtype == dt and torch.equal(va, vb.to(dt)), (name, dt, k, t)
+                    assert torch.equal(va, a.observe_as(_capi.LLE_OBS_PARTIAL, k))
+        if a.map.n_sources:
+            rng = np.random.default_rng(5)
+            colours = legal_colours(a.map, torch.from_numpy(rng.integers(0, a.map.n_agents, size=(n, a.map.n_sources), dtype=np.uint8)))
+            for w in (a, b):
+                w.set_sources(colours=colours)
+                w.step(sample=True, auto_reset=True, seed=4, t=0)
+            compare("per-env sources")
+
+
+def test_observation_builders_widened_on_blocks_of_maps():
+    import torch
+
+    from lle_amd import BatchedWorld, _capi, mapgen
+
+    texts = [mapgen.generate(9, 11, 3, 4, 3, n_voids=2, seed=40 + s) for s in range(6)]
+    n = 6 * 24
+    for dt in (torch.float16, torch.float32):
+        a, b = BatchedWorld(texts, n, obs_dtype=dt), BatchedWorld(texts, n)
+        for t in range(6):
+            for w in (a, b):
+                w.step(sample=True, auto_reset=True, seed=6, t=t)
+        for kind, param in ((_capi.LLE_OBS_LAYERED, 0), (_capi.LLE_OBS_LAYERED_PADDED, 1), (_capi.LLE_OBS_PERSPECTIVE, 0), (_capi.LLE_OBS_PARTIAL, 3), (_capi.LLE_OBS_PARTIAL, 5)):
+            if not a.obs_desc(kind, param).supported:
+                continue
+            assert torch.equal(a.observe_as(kind, param), b.observe_as(kind, param).to(dt)), (dt, kind, param)
