@@ -687,6 +687,22 @@ def measure_observers(torch, timer, dev, n, steps):
         out[label] = blk
         del calls, bw
         torch.cuda.empty_cache()
+    # the same builders on a batch whose element type is fp16 (lle_batch_options.obs_dtype: every layered-style builder widens at the store)
+    bw = BatchedWorld(Map(level=LEVEL), n, device=dev, obs_dtype=torch.float16)
+    fn = stepper(bw)
+    for _ in range(16):
+        fn()
+    blk = {}
+    for name, kind, param in (("partial7x7", _capi.LLE_OBS_PARTIAL, 7), ("layered_padded2", _capi.LLE_OBS_LAYERED_PADDED, 2), ("perspective", _capi.LLE_OBS_PERSPECTIVE, 0)):
+        call = bw.bound_observer(kind, param)
+        for _ in range(10):
+            call()
+        _, ms = timer.run(call, steps)
+        nbytes = call.buffer.numel() * call.buffer.element_size()
+        blk[name] = {"us": ms * 1e3, "MB": nbytes / 1e6, "GBps": nbytes / (ms * 1e-3) / 1e9}
+    out["level6_fp16"] = blk
+    del bw, fn
+    torch.cuda.empty_cache()
     return out
 
 
