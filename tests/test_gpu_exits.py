@@ -139,12 +139,19 @@ def test_exits_with_per_env_sources(oracle_mod, name):
                 bw.update_map()
 
 
-def test_exits_of_one_map_of_several(oracle_mod):
+@pytest.mark.parametrize("case", ["small_x128", "config5_x16", "config5_x8"])
+def test_exits_of_one_map_of_several(oracle_mod, case):
+    """(config 5's shape in blocks of 16 and 8: the split-row kernels, whose workgroups build their rows from the bit form of the static observation and --
+    at 16 per map -- their tables from the packed image: both are recompiled with the exits and travel with the blob.)"""
     from lle_amd import BatchedWorld, mapgen
 
-    shape = dict(height=9, width=11, n_agents=3, n_lasers=4, n_gems=3, n_voids=2)
-    texts = [mapgen.generate(seed=200 + s, **shape) for s in range(3)]
-    per = 128
+    if case == "small_x128":
+        shape = dict(height=9, width=11, n_agents=3, n_lasers=4, n_gems=3, n_voids=2)
+        texts = [mapgen.generate(seed=200 + s, **shape) for s in range(3)]
+        per = 128
+    else:
+        texts = [mapgen.config5(300 + s) for s in range(3)]
+        per = 16 if case == "config5_x16" else 8
     bw = BatchedWorld(texts, per * len(texts))
     obs = [oracle_mod.OracleBatch(t, per) for t in texts]
     rng = np.random.default_rng(5)
@@ -156,7 +163,7 @@ def test_exits_of_one_map_of_several(oracle_mod):
             if osteps is not None:
                 assert_step_equal(eng, osteps[m], f"{where} map {m}")
             else:
-                assert np.array_equal(eng["obs"][:32], oracle_obs(ob, 32)), f"{where} map {m}: observation"
+                assert np.array_equal(eng["obs"][:min(32, per)], oracle_obs(ob, min(32, per))), f"{where} map {m}: observation"
             assert_state_equal(eng, ob.dump(), f"{where} map {m}")
 
     t = 0
@@ -165,7 +172,7 @@ def test_exits_of_one_map_of_several(oracle_mod):
             bw.step(sample=True, auto_reset=True, seed=2, t=t, env_offset=64)
             check_blocks([ob.step(None, auto_reset=True, seed=2, t=t, env_offset=64 + m * per) for m, ob in enumerate(obs)], f"t={t}")
             t += 1
-        exits = legal_exits(bw.maps[which], rng, 4)
+        exits = legal_exits(bw.maps[which], rng, bw.map.n_agents + 1)
         bw.set_exits(exits, map_index=which)
         for e in range(per):
             obs[which].world(e).set_exits(exits)
