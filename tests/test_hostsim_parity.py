@@ -244,3 +244,21 @@ def test_template_bit_form_and_packed_tables_rebuild_the_sections(oracle_mod):
                 recoloured += int(not np.array_equal(tmpl, tmpl2))
                 break
     assert seen > 10 and recoloured > 5
+    # ... and on a few hundred generated maps of every shape class (1 - 14 agents, 0 - 20 sources, beams up to the map's width, voids, many gems)
+    rng = np.random.default_rng(11)
+    checked = 0
+    for k in range(400):
+        h, w = int(rng.integers(3, 20)), int(rng.integers(3, 20))
+        agents = int(rng.integers(1, min(14, max(1, h * w // 6)) + 1))
+        try:
+            text = mapgen.generate(h, w, agents, int(rng.integers(0, 21)), n_gems=int(rng.integers(0, 12)), wall_fraction=float(rng.uniform(0.0, 0.2)),
+                                   n_voids=int(rng.integers(0, 4)), seed=7000 + k, max_beam=int(rng.integers(3, 40)))
+            sb = hostsim.SimBatch(text, 1)
+        except (RuntimeError, hostsim.SimError):
+            continue  # (no placement for these sizes, or beyond the static limits)
+        got, tmpl = sb.template_from_bits()
+        packed, section = sb.tables_from_packed()
+        assert got is not None and np.array_equal(got, tmpl), text
+        assert packed is not None and np.array_equal(packed, section), text
+        checked += 1
+    assert checked > 200, checked
