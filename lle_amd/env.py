@@ -479,10 +479,11 @@ class Builder:
             return self
         raise NotImplementedError("extras generators are outside the scope of lle_amd (SURVEY.md section 2, row 9)")
 
-    def build(self, n_envs=1, device=None, seed=0):
+    def build(self, n_envs=1, device=None, seed=0, obs_dtype=None):
+        """(n_envs, device, seed, obs_dtype: what a batch needs beyond the reference's builder -- BatchedLLE's arguments of the same names)"""
         return BatchedLLE(self._map, n_envs, obs_type=self._obs_type, state_type=self._state_type, walkable_lasers=self._walkable_lasers,
                           randomize_lasers=self._randomize_lasers, multi_objective=self._multi_objective, death_strategy=self._death_strategy,
-                          padding_size=self._padding_size, device=device, seed=seed, name=self._env_name)
+                          padding_size=self._padding_size, device=device, seed=seed, name=self._env_name, obs_dtype=obs_dtype)
 
 
 def level(level):
