@@ -28,6 +28,13 @@ def run(label, maps):
     del bw
     torch.cuda.empty_cache()
 
-run("one map", mapgen.config5(0))
-for n_maps in (1024, 4096):
-    run(f"{n_maps} maps x {n // n_maps}", [Map(mapgen.config5(s)) for s in range(n_maps)])
+if len(sys.argv) > 1 and sys.argv[1] == "small":  # 12 x 13 maps with 4 agents, down to a map per environment
+    gen = lambda s: mapgen.generate(12, 13, 4, 4, 4, seed=s, n_voids=2)
+    n = 16384
+    run("one map", gen(0))
+    for per in (8, 1):
+        run(f"{n // per} maps x {per}", [Map(gen(s)) for s in range(n // per)])
+else:
+    run("one map", mapgen.config5(0))
+    for n_maps in (1024, 4096):
+        run(f"{n_maps} maps x {n // n_maps}", [Map(mapgen.config5(s)) for s in range(n_maps)])
