@@ -1,5 +1,6 @@
-"""Small maps (12 x 13, 4 agents, 4 lasers), 65 536 envs: one map, 4 096 x 16, 8 192 x 8; with LLE_DEBUG_SAME_TABLES=1 every workgroup reads map 0's tables
-(timing experiment: what the reads of the maps' own tables cost)."""
+"""Small maps (12 x 13, 4 agents, 4 lasers), 65 536 envs: one map, 4 096 x 16, 8 192 x 8; (the comparison of profiles/r05_multi_map.md section 1 ran this script a second time on a
+DIAGNOSTIC build in which every workgroup reads map 0's tables -- one line in capi.cpp's launch(): K.table_stride = 0 under LLE_DEBUG_SAME_TABLES; results wrong,
+timing only; the shipped library has no such switch)."""
 import os, sys
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
 import torch
