@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(256) world_kernel(BatchPtrs P, LaunchArgs K) {
                     // `avail` is the cached list of the reference (world.rs:444-453).  It can only disagree with the
                     // static walk mask after a failed set_state left it stale (world.rs:588-594 returns before
                     // recomputing it); the reference would then index out of the grid and panic, we refuse the action.
-                    const uint32_t walk = ((cur.meta[a] >> 8) & 15u) | 16u;
+                    const uint32_t walk = meta_walk(cur.meta[a]) | 16u;
                     const bool bad = act[a] > 4u || !(((avail[a] & walk) >> (act[a] & 7u)) & 1u);
                     err = bad ? (uint32_t)a + 1u : err;
                 }

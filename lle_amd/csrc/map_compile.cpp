@@ -316,15 +316,14 @@ bool Map::build_obs_tables(const LayerMap& lm, std::vector<int8_t>& tmpl, std::v
             if (src.agent_id >= lm.n_laser) { supported = false; continue; }
             uint32_t idx = (uint32_t)(lm.laser[src.agent_id] * HW + c);
             Dyn& d = dyn[idx];
-            d.ref[d.n_refs++] = (uint32_t)word_of(layers[k].laser_id, layers[k].offset) | ((uint32_t)bit_of(layers[k].offset) << 5);
+            d.ref[d.n_refs++] = ref_pack((uint32_t)word_of(layers[k].laser_id, layers[k].offset), (uint32_t)bit_of(layers[k].offset));
         }
     }
     for (int g = 0; g < G; g++) dyn[(uint32_t)(lm.gem * HW + gems[g].i * W + gems[g].j)].gem = (uint32_t)g;
     dyn_tab.clear();
     for (auto& kv : dyn) {
         const Dyn& d = kv.second;
-        uint64_t e = kv.first | ((uint64_t)(uint8_t)tmpl[kv.first] << 20) | ((uint64_t)d.n_refs << 28) |
-                     ((uint64_t)d.ref[0] << 30) | ((uint64_t)d.ref[1] << 40) | ((uint64_t)d.gem << 50);
+        uint64_t e = dyn_pack(kv.first, (uint8_t)tmpl[kv.first], d.n_refs, d.ref[0], d.ref[1], d.gem);
         dyn_tab.push_back(e);
     }
     return supported;
@@ -467,7 +466,7 @@ void Map::compile() {
             if (kind[c] == K_SOURCE)  // the field holds the (first) beam word of a source cell (read by the partial observer: its colour)
                 for (const Source& src : sources)
                     if (src.pos.i == i && src.pos.j == j) gi = (uint32_t)source_word[(size_t)src.laser_id];
-            cell_meta[c] = kind[c] | (gi << 3) | (walk << 8) | ((uint32_t)layers.size() << 12);
+            cell_meta[c] = meta_pack(kind[c], gi, walk, (uint32_t)layers.size());
         }
 
     // ---- layered observation tables (static template + dynamic bytes) with the Layered channel order
@@ -603,12 +602,12 @@ void Map::compile() {
         for (auto& q : exits) bat(2 * A + 3, q) = 1;
     }
     std::vector<uint32_t> elems;
-    for (auto& s : sources) elems.push_back((uint32_t)(s.pos.i * W + s.pos.j) | ((uint32_t)source_word[(size_t)s.laser_id] << 16) | (ELEM_SOURCE << 26));
+    for (auto& s : sources) elems.push_back(elem_pack((uint32_t)(s.pos.i * W + s.pos.j), (uint32_t)source_word[(size_t)s.laser_id], 0u, ELEM_SOURCE));
     for (int c = 0; c < HW; c++)
         for (size_t k = 0; k < cell_layers[c].size() && k < 2; k++)
-            elems.push_back((uint32_t)c | ((uint32_t)word_of(cell_layers[c][k].laser_id, cell_layers[c][k].offset) << 16) |
-                            ((uint32_t)bit_of(cell_layers[c][k].offset) << 21) | (ELEM_TILE << 26));
-    for (int g = 0; g < G; g++) elems.push_back((uint32_t)(gems[g].i * W + gems[g].j) | ((uint32_t)g << 16) | (ELEM_GEM << 26));
+            elems.push_back(elem_pack((uint32_t)c, (uint32_t)word_of(cell_layers[c][k].laser_id, cell_layers[c][k].offset),
+                                      (uint32_t)bit_of(cell_layers[c][k].offset), ELEM_TILE));
+    for (int g = 0; g < G; g++) elems.push_back(elem_pack((uint32_t)(gems[g].i * W + gems[g].j), (uint32_t)g, 0u, ELEM_GEM));
     h.off_bare = h.blob_capacity;
     h.off_elems = h.off_bare + h.obs_stride;
     h.n_elems = (uint32_t)elems.size();

@@ -393,13 +393,13 @@ __device__ __forceinline__ void write_observations(int A, int L, uint32_t D, uin
     // zero word, so the per-environment evaluation is branch-free.
     const bool has_d0 = lane < D;
     const uint64_t e0 = has_d0 ? dyn[lane] : 0ull;
-    const uint32_t d0_idx = (uint32_t)e0 & 0xFFFFFu;
-    const int32_t d0_base = (int8_t)(uint8_t)(e0 >> 20);
-    const uint32_t d0_refs = (uint32_t)(e0 >> 28) & 3u, d0_gem = (uint32_t)(e0 >> 50) & 63u;
-    const uint32_t d0_r0 = (uint32_t)(e0 >> 30) & 0x3FFu, d0_r1 = (uint32_t)(e0 >> 40) & 0x3FFu;
-    const uint32_t d0_w0 = d0_refs >= 1 ? 1u + (d0_r0 & 31u) : 0u, d0_s0 = d0_refs >= 1 ? d0_r0 >> 5 : 0u;
-    const uint32_t d0_w1 = d0_refs >= 2 ? 1u + (d0_r1 & 31u) : 0u, d0_s1 = d0_refs >= 2 ? d0_r1 >> 5 : 0u;
-    const uint32_t d0_wg = d0_gem != NO_GEM ? (uint32_t)L + 1u : 0u, d0_sg = d0_gem != NO_GEM ? (d0_gem & 31u) : 0u;
+    const uint32_t d0_idx = dyn_index(e0);
+    const int32_t d0_base = dyn_base(e0);
+    const uint32_t d0_refs = dyn_refs(e0), d0_gem = dyn_gem(e0);
+    const uint32_t d0_r0 = dyn_ref0(e0), d0_r1 = dyn_ref1(e0);
+    const uint32_t d0_w0 = d0_refs >= 1 ? 1u + ref_word(d0_r0) : 0u, d0_s0 = d0_refs >= 1 ? ref_bit(d0_r0) : 0u;
+    const uint32_t d0_w1 = d0_refs >= 2 ? 1u + ref_word(d0_r1) : 0u, d0_s1 = d0_refs >= 2 ? ref_bit(d0_r1) : 0u;
+    const uint32_t d0_wg = d0_gem != NO_GEM ? (uint32_t)L + 1u : 0u, d0_sg = d0_gem != NO_GEM ? gem_bit(d0_gem) : 0u;
     const bool is_agent_lane = (int)lane < A;
     const uint4* srcv = reinterpret_cast<const uint4*>(tmpl);
 
@@ -413,13 +413,13 @@ __device__ __forceinline__ void write_observations(int A, int L, uint32_t D, uin
         }
         for (uint32_t d = lane + 64u; d < D; d += 64) {  // maps with more than 64 dynamic bytes
             const uint64_t e = dyn[d];
-            const uint32_t refs = (uint32_t)(e >> 28) & 3u, gem = (uint32_t)(e >> 50) & 63u;
-            const uint32_t r0 = (uint32_t)(e >> 30) & 0x3FFu, r1 = (uint32_t)(e >> 40) & 0x3FFu;
-            const uint32_t w0 = refs >= 1 ? 1u + (r0 & 31u) : 0u, w1 = refs >= 2 ? 1u + (r1 & 31u) : 0u;
+            const uint32_t refs = dyn_refs(e), gem = dyn_gem(e);
+            const uint32_t r0 = dyn_ref0(e), r1 = dyn_ref1(e);
+            const uint32_t w0 = refs >= 1 ? 1u + ref_word(r0) : 0u, w1 = refs >= 2 ? 1u + ref_word(r1) : 0u;
             const uint32_t wg = gem != NO_GEM ? (uint32_t)L + 1u : 0u;
-            const uint32_t lit = ((sc[w0] >> (refs >= 1 ? r0 >> 5 : 0u)) | (sc[w1] >> (refs >= 2 ? r1 >> 5 : 0u)) |
-                                  (sc[wg] >> (gem != NO_GEM ? (gem & 31u) : 0u))) & 1u;
-            tmpl[(uint32_t)e & 0xFFFFFu] = (int8_t)(lit ? 1 : (int32_t)(int8_t)(uint8_t)(e >> 20));
+            const uint32_t lit = ((sc[w0] >> (refs >= 1 ? ref_bit(r0) : 0u)) | (sc[w1] >> (refs >= 2 ? ref_bit(r1) : 0u)) |
+                                  (sc[wg] >> (gem != NO_GEM ? gem_bit(gem) : 0u))) & 1u;
+            tmpl[dyn_index(e)] = (int8_t)(lit ? 1 : dyn_base(e));
         }
         // (b) agents (dead ones included, observations.py:264-265)
         const uint32_t agent_idx = is_agent_lane ? sc[L + 2 + lane] : 0u;
@@ -468,19 +468,19 @@ __device__ __forceinline__ void write_observations_split(int A, int L, uint32_t 
     // the dyn table is sorted by byte index: this slice's entries are [d_lo, d_hi)
     uint32_t d_lo = 0, d_hi = 0;
     for (uint32_t d = lane; d < ((D + 63u) & ~63u); d += 64) {
-        const uint32_t idx = d < D ? (uint32_t)dyn[d] & 0xFFFFFu : 0xFFFFFFFFu;
+        const uint32_t idx = d < D ? dyn_index(dyn[d]) : 0xFFFFFFFFu;
         d_lo += (uint32_t)__popcll(__ballot(idx < b_lo));
         d_hi += (uint32_t)__popcll(__ballot(idx < b_hi));
     }
     const bool has_d0 = d_lo + lane < d_hi;
     const uint64_t e0 = has_d0 ? dyn[d_lo + lane] : 0ull;
-    const uint32_t d0_idx = has_d0 ? ((uint32_t)e0 & 0xFFFFFu) - b_lo : 0u;
-    const int32_t d0_base = (int8_t)(uint8_t)(e0 >> 20);
-    const uint32_t d0_refs = (uint32_t)(e0 >> 28) & 3u, d0_gem = (uint32_t)(e0 >> 50) & 63u;
-    const uint32_t d0_r0 = (uint32_t)(e0 >> 30) & 0x3FFu, d0_r1 = (uint32_t)(e0 >> 40) & 0x3FFu;
-    const uint32_t d0_w0 = d0_refs >= 1 ? 1u + (d0_r0 & 31u) : 0u, d0_s0 = d0_refs >= 1 ? d0_r0 >> 5 : 0u;
-    const uint32_t d0_w1 = d0_refs >= 2 ? 1u + (d0_r1 & 31u) : 0u, d0_s1 = d0_refs >= 2 ? d0_r1 >> 5 : 0u;
-    const uint32_t d0_wg = d0_gem != NO_GEM ? (uint32_t)L + 1u : 0u, d0_sg = d0_gem != NO_GEM ? (d0_gem & 31u) : 0u;
+    const uint32_t d0_idx = has_d0 ? dyn_index(e0) - b_lo : 0u;
+    const int32_t d0_base = dyn_base(e0);
+    const uint32_t d0_refs = dyn_refs(e0), d0_gem = dyn_gem(e0);
+    const uint32_t d0_r0 = dyn_ref0(e0), d0_r1 = dyn_ref1(e0);
+    const uint32_t d0_w0 = d0_refs >= 1 ? 1u + ref_word(d0_r0) : 0u, d0_s0 = d0_refs >= 1 ? ref_bit(d0_r0) : 0u;
+    const uint32_t d0_w1 = d0_refs >= 2 ? 1u + ref_word(d0_r1) : 0u, d0_s1 = d0_refs >= 2 ? ref_bit(d0_r1) : 0u;
+    const uint32_t d0_wg = d0_gem != NO_GEM ? (uint32_t)L + 1u : 0u, d0_sg = d0_gem != NO_GEM ? gem_bit(d0_gem) : 0u;
     const bool is_agent_lane = (int)lane < A;
     const uint4* srcv = reinterpret_cast<const uint4*>(tmpl);
     const uint32_t n_mine = hi - lo;
@@ -493,13 +493,13 @@ __device__ __forceinline__ void write_observations_split(int A, int L, uint32_t 
         }
         for (uint32_t d = d_lo + lane + 64u; d < d_hi; d += 64) {  // slices with more than 64 dynamic bytes
             const uint64_t e = dyn[d];
-            const uint32_t refs = (uint32_t)(e >> 28) & 3u, gem = (uint32_t)(e >> 50) & 63u;
-            const uint32_t r0 = (uint32_t)(e >> 30) & 0x3FFu, r1 = (uint32_t)(e >> 40) & 0x3FFu;
-            const uint32_t w0 = refs >= 1 ? 1u + (r0 & 31u) : 0u, w1 = refs >= 2 ? 1u + (r1 & 31u) : 0u;
+            const uint32_t refs = dyn_refs(e), gem = dyn_gem(e);
+            const uint32_t r0 = dyn_ref0(e), r1 = dyn_ref1(e);
+            const uint32_t w0 = refs >= 1 ? 1u + ref_word(r0) : 0u, w1 = refs >= 2 ? 1u + ref_word(r1) : 0u;
             const uint32_t wg = gem != NO_GEM ? (uint32_t)L + 1u : 0u;
-            const uint32_t lit = ((sc[w0] >> (refs >= 1 ? r0 >> 5 : 0u)) | (sc[w1] >> (refs >= 2 ? r1 >> 5 : 0u)) |
-                                  (sc[wg] >> (gem != NO_GEM ? (gem & 31u) : 0u))) & 1u;
-            tmpl[((uint32_t)e & 0xFFFFFu) - b_lo] = (int8_t)(lit ? 1 : (int32_t)(int8_t)(uint8_t)(e >> 20));
+            const uint32_t lit = ((sc[w0] >> (refs >= 1 ? ref_bit(r0) : 0u)) | (sc[w1] >> (refs >= 2 ? ref_bit(r1) : 0u)) |
+                                  (sc[wg] >> (gem != NO_GEM ? gem_bit(gem) : 0u))) & 1u;
+            tmpl[dyn_index(e) - b_lo] = (int8_t)(lit ? 1 : dyn_base(e));
         }
         const uint32_t agent_idx = is_agent_lane ? sc[L + 2 + lane] : 0xFFFFFFFFu;
         const bool agent_here = agent_idx >= b_lo && agent_idx < b_hi;  // (idle lanes: 0xFFFFFFFF is in no slice)
@@ -533,7 +533,7 @@ __device__ __forceinline__ void write_observations_split(int A, int L, uint32_t 
 // `laser_layer` (views: layer of colour c) or NULL (Layered: LASER_0 + c); `gem_layer` = the GEM channel.
 __device__ __forceinline__ void elem_eval(uint32_t e, const uint32_t* sc, int A, int L, uint32_t HW, const uint8_t* laser_layer,
                                           uint32_t gem_layer, uint32_t& idx, int32_t& val, bool& on) {
-    const uint32_t cell = e & 0xFFFFu, i5 = (e >> 16) & 31u, off = (e >> 21) & 31u, type = (e >> 26) & 3u;
+    const uint32_t cell = elem_cell(e), i5 = elem_index(e), off = elem_bit(e), type = elem_type(e);
     const uint32_t colour = (sc[L + 2 + A + (i5 >> 2)] >> ((i5 & 3u) * 8u)) & 0xFFu;
     const bool is_gem = type == ELEM_GEM;
     const uint32_t llayer = laser_layer ? (uint32_t)laser_layer[colour] : (uint32_t)A + colour;
@@ -561,7 +561,7 @@ __device__ __forceinline__ void write_observations_env(int A, int L, uint32_t HW
     const uint32_t e0 = has_e0 ? elems[lane] : 0u;
     // the lane serves the same element for every environment: what does not depend on the environment is decoded once --
     // the cell, the record word and shift that hold its colour, the record word and bit that say whether it shows
-    const uint32_t e0_cell = e0 & 0xFFFFu, e0_i5 = (e0 >> 16) & 31u, e0_off = (e0 >> 21) & 31u, e0_type = (e0 >> 26) & 3u;
+    const uint32_t e0_cell = elem_cell(e0), e0_i5 = elem_index(e0), e0_off = elem_bit(e0), e0_type = elem_type(e0);
     const bool e0_gem = e0_type == ELEM_GEM, e0_src = e0_type == ELEM_SOURCE;
     const uint32_t e0_colw = (uint32_t)(L + 2 + A) + (e0_i5 >> 2), e0_colsh = (e0_i5 & 3u) * 8u;
     const uint32_t e0_onw = e0_gem ? (uint32_t)L + 1u : (e0_src ? 0u : 1u + e0_i5);   // gem: ~collected bits; tile: the beam mask; source: always

@@ -221,17 +221,17 @@ __global__ void __launch_bounds__(256) partial_observe_kernel(BatchPtrs P, int8_
                 here &= here - 1u;
                 cp[a2 * (int)kk] = 1;
             }
-            if ((meta & 7u) == K_FLOOR && lay == 0ull) continue;  // nothing else can be on the cell
+            if (meta_kind(meta) == K_FLOOR && lay == 0ull) continue;  // nothing else can be on the cell
             // gems, exits, walls, lasers that are on, -1 at sources: the reference's order (partial_cell, observers_logic.hpp)
-            const uint32_t kind = meta & 7u, idx = (meta >> 3) & 31u;
+            const uint32_t kind = meta_kind(meta), idx = meta_index(meta);
             const int WALL = A, LASER_0 = A + 1, GEM = 2 * A + 1, EXIT = 2 * A + 2;
             if (kind == K_GEM && !((gems >> idx) & 1u)) cp[GEM * (int)kk] = 1;
             if (kind == K_EXIT) cp[EXIT * (int)kk] = 1;
             if (kind == K_WALL || kind == K_SOURCE) cp[WALL * (int)kk] = 1;
             for (int q = 0; q < 2; q++) {
-                const uint32_t e2 = (uint32_t)(lay >> (16 * q)) & 0xFFFFu;
+                const uint32_t e2 = lay_entry(lay, (int)q);
                 if (!(e2 & LAY_VALID)) break;
-                const uint32_t beam = (e2 >> 1) & 31u, off = (e2 >> 6) & 31u;
+                const uint32_t beam = lay_word(e2), off = lay_bit(e2);
                 if ((beams[beam] >> off) & 1u) cp[(LASER_0 + (int)T.beam_colour[beam]) * (int)kk] = 1;
             }
             if (kind == K_SOURCE) cp[(LASER_0 + (int)T.beam_colour[idx]) * (int)kk] = -1;
@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(256) partial_project_kernel(BatchPtrs P, int8_
         const uint64_t* __restrict__ glay = reinterpret_cast<const uint64_t*>(tables + hdr->off_cell_lay);
         const uint32_t* __restrict__ gmeta = reinterpret_cast<const uint32_t*>(tables + hdr->off_cell_meta);
         for (uint32_t c = threadIdx.x; c < hdr->HW; c += blockDim.x) {
-            const uint32_t meta = gmeta[c], kind = meta & 7u, idx = (meta >> 3) & 31u;
+            const uint32_t meta = gmeta[c], kind = meta_kind(meta), idx = meta_index(meta);
             const uint64_t lay = glay[c];
             const uint32_t i = c / (uint32_t)W, ij = i | ((c - i * (uint32_t)W) << 8);
             uint32_t e[4], n = 0;
@@ -289,9 +289,9 @@ __global__ void __launch_bounds__(256) partial_project_kernel(BatchPtrs P, int8_
             if (kind == K_EXIT) e[n++] = ij | (PE_EXIT << 16);
             if (kind == K_GEM) e[n++] = ij | (PE_GEM << 16) | (idx << 19);
             for (int q = 0; q < 2; q++) {                                            // World.lasers(): two layers per cell
-                const uint32_t e2 = (uint32_t)(lay >> (16 * q)) & 0xFFFFu;
+                const uint32_t e2 = lay_entry(lay, (int)q);
                 if (!(e2 & LAY_VALID)) break;
-                e[n++] = ij | (PE_TILE << 16) | (((e2 >> 1) & 31u) << 19) | (((e2 >> 6) & 31u) << 24);
+                e[n++] = ij | (PE_TILE << 16) | (lay_word(e2) << 19) | (lay_bit(e2) << 24);
             }
             if (n) {
                 const uint32_t at = atomicAdd(ent_count, n);

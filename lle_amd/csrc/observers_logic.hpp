@@ -41,15 +41,15 @@ LLE_HD void partial_cell(const ObsTables& T, const uint16_t* pos, uint32_t gems,
     for (int a2 = 0; a2 < A; a2++)
         if (pos[a2] == here) cellp[a2 * kk] = 1;                 // dead agents included (agents_positions)
     const int c = i * T.W + j;
-    const uint32_t meta = T.cell_meta[c], kind = meta & 7u, idx = (meta >> 3) & 31u;
+    const uint32_t meta = T.cell_meta[c], kind = meta_kind(meta), idx = meta_index(meta);
     if (kind == K_GEM && !((gems >> idx) & 1u)) cellp[GEM * kk] = 1;
     if (kind == K_EXIT) cellp[EXIT * kk] = 1;
     if (kind == K_WALL || kind == K_SOURCE) cellp[WALL * kk] = 1;  // wall_pos holds the sources too (parser_v1.rs:22-25)
     const uint64_t lay = T.cell_lay[c];
     for (int q = 0; q < 2; q++) {                                 // World.lasers(): two layers per cell (world.rs:159-172)
-        const uint32_t e = (uint32_t)(lay >> (16 * q)) & 0xFFFFu;
+        const uint32_t e = lay_entry(lay, (int)q);
         if (!(e & LAY_VALID)) break;
-        const uint32_t beam = (e >> 1) & 31u, off = (e >> 6) & 31u;
+        const uint32_t beam = lay_word(e), off = lay_bit(e);
         if ((beams[beam] >> off) & 1u) cellp[(LASER_0 + (int)T.beam_colour[beam]) * kk] = 1;
     }
     if (kind == K_SOURCE) cellp[(LASER_0 + (int)T.beam_colour[idx]) * kk] = -1;   // idx = laser_id of a source cell
@@ -83,9 +83,9 @@ LLE_HD uint32_t avail_bools(const ObsTables& T, const uint16_t* pos, const uint3
         if (i >= 0 && j >= 0 && i < T.H && j < T.W) {
             const uint64_t lay = T.cell_lay[i * T.W + j];
             for (int q = 0; q < 2; q++) {
-                const uint32_t e = (uint32_t)(lay >> (16 * q)) & 0xFFFFu;
+                const uint32_t e = lay_entry(lay, (int)q);
                 if (!(e & LAY_VALID)) break;
-                const uint32_t beam = (e >> 1) & 31u, off = (e >> 6) & 31u;
+                const uint32_t beam = lay_word(e), off = lay_bit(e);
                 if (((beams[beam] >> off) & 1u) && (int)T.beam_colour[beam] != a) blocked = true;
             }
         }

@@ -20,7 +20,7 @@ __host__ __device__ inline uint32_t partial_bitmap_bytes(uint32_t H, uint32_t W)
 __device__ __forceinline__ void partial_bitmap_fill(uint32_t* bm, const uint64_t* cell_lay, const uint32_t* cell_meta, int H, int W) {
     const uint32_t RW = partial_bitmap_row_words((uint32_t)W);
     for (uint32_t c = threadIdx.x; c < (uint32_t)(H * W); c += blockDim.x) {
-        if ((cell_meta[c] & 7u) != K_FLOOR || cell_lay[c] != 0ull) {
+        if (meta_kind(cell_meta[c]) != K_FLOOR || cell_lay[c] != 0ull) {
             const uint32_t i = c / (uint32_t)W, j = c - i * (uint32_t)W;
             atomicOr(&bm[(i + 8u) * RW + ((j + 8u) >> 5)], 1u << ((j + 8u) & 31u));
         }
@@ -59,9 +59,9 @@ __device__ __forceinline__ void partial_eval_cell(const PartialGeo& G, const Rec
     const uint32_t WALL = (uint32_t)G.A, LASER_0 = (uint32_t)G.A + 1u, GEM = 2u * (uint32_t)G.A + 1u, EXIT = 2u * (uint32_t)G.A + 2u;   // observations.py:318-323
     // layer of the one static byte of a cell, by kind (0xFF: none): FLOOR, WALL, VOID, EXIT | GEM, SOURCE (wall_pos holds the sources too)
     const uint32_t lt_lo = 0xFFu | (WALL << 8) | (0xFFu << 16) | (EXIT << 24), lt_hi = GEM | (WALL << 8) | 0xFFFF0000u;
-    const uint32_t kind = meta & 7u, idx = (meta >> 3) & 31u;
-    const uint32_t l0 = (uint32_t)lay & 0xFFFFu;   // World.lasers(): the two outer layers of a cell
-    const uint32_t w0 = (l0 >> 1) & 31u, o0 = (l0 >> 6) & 31u;
+    const uint32_t kind = meta_kind(meta), idx = meta_index(meta);
+    const uint32_t l0 = lay_entry(lay, 0);   // World.lasers(): the two outer layers of a cell
+    const uint32_t w0 = lay_word(l0), o0 = lay_bit(l0);
     const uint32_t src = kind == K_SOURCE ? idx : 0u;   // idx = first beam word of a source cell (gem index otherwise)
     const uint32_t m0 = R.beam(w0);
     const uint32_t c0 = R.colour(w0), cs = R.colour(src);
@@ -69,7 +69,7 @@ __device__ __forceinline__ void partial_eval_cell(const PartialGeo& G, const Rec
     const bool en0 = lt != 0xFFu && !(kind == K_GEM && !((gems_left >> idx) & 1u));
     const bool en1 = (l0 & LAY_VALID) && ((m0 >> o0) & 1u);
     if (G.two_layers) {
-        const uint32_t l1 = (uint32_t)(lay >> 16) & 0xFFFFu, w1 = (l1 >> 1) & 31u, o1 = (l1 >> 6) & 31u;
+        const uint32_t l1 = lay_entry(lay, 1), w1 = lay_word(l1), o1 = lay_bit(l1);
         const uint32_t m1 = R.beam(w1), c1 = R.colour(w1);
         const bool en2 = (l1 & LAY_VALID) && ((m1 >> o1) & 1u);
         *(en2 ? cp + __umul24(LASER_0 + c1, G.kk) : dummy) = 1;

@@ -162,7 +162,7 @@ LLE_LANE_FN void step_lanes(const uint64_t* cell_lay, const uint32_t* cell_meta,
             lc = recolour_lay<(CWM > 0 ? CWM : 1), (ML1 ? 1 : MAX_CELL_LAYERS)>(lc, cw);
         }
         lay_cur = lc;
-        const uint32_t walk_cur = ((cell_meta[cur_cell] >> 8) & 15u) | 16u;
+        const uint32_t walk_cur = meta_walk(cell_meta[cur_cell]) | 16u;
         const bool bad = me && (act > 4u || !(((avail & walk_cur) >> (act & 7u)) & 1u));
         badbit = bad ? (uint32_t)bit : 0u;
     }
@@ -212,8 +212,8 @@ LLE_LANE_FN void step_lanes(const uint64_t* cell_lay, const uint32_t* cell_meta,
         lay_new = ln;
         const uint32_t mn = cell_meta[new_cell];
         meta_new = mn;
-        kind = mn & 7u;
-        gbit = 1u << ((mn >> 3) & 31u);
+        kind = meta_kind(mn);
+        gbit = 1u << meta_index(mn);
         lay_from = (uint64_t)lay_cur;  // pass 1 leaves the old cells, later passes the new ones
     }
 
@@ -233,8 +233,8 @@ LLE_LANE_FN void step_lanes(const uint64_t* cell_lay, const uint32_t* cell_meta,
                 for (int k = 0; k < 4; k++) {
                     uint32_t rb = 0, rm = 0;
                     if ((uint32_t)k < max_layers) {
-                        const uint32_t eo = (uint32_t)((uint64_t)lay_from >> (16 * k)) & 0xFFFFu;
-                        const uint32_t b = (eo >> 1) & 31u, off = (eo >> 6) & 31u;
+                        const uint32_t eo = lay_entry((uint64_t)lay_from, k);
+                        const uint32_t b = lay_word(eo), off = lay_bit(eo);
                         const bool valid = (eo & LAY_VALID) != 0;  // (an empty layer slot names no beam: nothing is read for it)
                         const uint32_t cur = valid ? bm[b] : 0xFFFFFFFFu, full = valid ? full_tab[b] : 0u;
                         const bool lo = me_alive && valid && ((enabled >> b) & 1u) && !((cur >> off) & 1u);
@@ -252,10 +252,10 @@ LLE_LANE_FN void step_lanes(const uint64_t* cell_lay, const uint32_t* cell_meta,
                     uint32_t lt = 0;
                     if (b < L) {
                         for (uint32_t k = 0; k < max_layers; k++) {
-                            const uint32_t eo = (uint32_t)((uint64_t)lay_from >> (16 * k)) & 0xFFFFu;
-                            const bool lo = me_alive && (eo & LAY_VALID) && ((eo >> 1) & 31u) == (uint32_t)b &&
-                                            !(((uint32_t)beams[b] >> ((eo >> 6) & 31u)) & 1u);
-                            lt |= lo ? (0xFFFFFFFFu << ((eo >> 6) & 31u)) : 0u;
+                            const uint32_t eo = lay_entry((uint64_t)lay_from, k);
+                            const bool lo = me_alive && (eo & LAY_VALID) && lay_word(eo) == (uint32_t)b &&
+                                            !(((uint32_t)beams[b] >> lay_bit(eo)) & 1u);
+                            lt |= lo ? (0xFFFFFFFFu << lay_bit(eo)) : 0u;
                         }
                         lt = ((enabled >> b) & 1u) ? lt : 0u;
                     }
@@ -301,10 +301,10 @@ LLE_LANE_FN void step_lanes(const uint64_t* cell_lay, const uint32_t* cell_meta,
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         if ((uint32_t)k < max_layers) {
-                            const uint32_t en = (uint32_t)((uint64_t)lay_new >> (16 * k)) & 0xFFFFu;
-                            const uint32_t b = (en >> 1) & 31u;
-                            if ((en & LAY_VALID) && (en >> 11) == a && ((enabled >> b) & 1u)) {
-                                mem_and(bm + b, (1u << ((en >> 6) & 31u)) - 1u);
+                            const uint32_t en = lay_entry((uint64_t)lay_new, k);
+                            const uint32_t b = lay_word(en);
+                            if ((en & LAY_VALID) && lay_colour(en) == a && ((enabled >> b) & 1u)) {
+                                mem_and(bm + b, (1u << lay_bit(en)) - 1u);
                                 if (chain)  // LaserBeam::turn_off likewise (laser.rs:57-59)
                                     for (uint32_t w = b + 1u; (chain >> w) & 1u; w++) mem_and(bm + w, 0u);
                             }
@@ -317,9 +317,9 @@ LLE_LANE_FN void step_lanes(const uint64_t* cell_lay, const uint32_t* cell_meta,
                     uint32_t keep = 0xFFFFFFFFu;
                     if (b < L) {
                         for (uint32_t k = 0; k < max_layers; k++) {
-                            const uint32_t en = (uint32_t)((uint64_t)lay_new >> (16 * k)) & 0xFFFFu;
-                            const bool pe = go && me_alive && (en & LAY_VALID) && ((en >> 1) & 31u) == (uint32_t)b && (en >> 11) == a;
-                            keep &= pe ? ((1u << ((en >> 6) & 31u)) - 1u) : 0xFFFFFFFFu;
+                            const uint32_t en = lay_entry((uint64_t)lay_new, k);
+                            const bool pe = go && me_alive && (en & LAY_VALID) && lay_word(en) == (uint32_t)b && lay_colour(en) == a;
+                            keep &= pe ? ((1u << lay_bit(en)) - 1u) : 0xFFFFFFFFu;
                         }
                     }
                     cutv[b] = ((b < L) && ((enabled >> b) & 1u)) ? ~keep : 0u;
@@ -341,11 +341,11 @@ LLE_LANE_FN void step_lanes(const uint64_t* cell_lay, const uint32_t* cell_meta,
         LLE_LANES(G) {
             bool blocked = false;
             for (uint32_t k = 0; k < max_layers; k++) {
-                const uint32_t en = (uint32_t)((uint64_t)lay_new >> (16 * k)) & 0xFFFFu;
+                const uint32_t en = lay_entry((uint64_t)lay_new, k);
                 uint32_t m;
-                if constexpr (BM) m = (en & LAY_VALID) ? bm[(en >> 1) & 31u] : 0u;
-                else m = beam_get_lv<LM>(beams, (en >> 1) & 31u);
-                blocked |= (en & LAY_VALID) && ((m >> ((en >> 6) & 31u)) & 1u) && ((en >> 11) != a);
+                if constexpr (BM) m = (en & LAY_VALID) ? bm[lay_word(en)] : 0u;
+                else m = beam_get_lv<LM>(beams, lay_word(en));
+                blocked |= (en & LAY_VALID) && ((m >> lay_bit(en)) & 1u) && (lay_colour(en) != a);
             }
             const bool is_alive = (alive & bit) != 0;
             inner = go && me && !blocked;
@@ -412,7 +412,7 @@ LLE_LANE_FN void avail_lanes(const LV<G, uint32_t>& a, const LV<G, bool>& me, co
             hit |= (d == -256) ? 8u : 0u;
             blocked_dirs |= ((oc >> (aa ^ (uint32_t)j)) & 1u) ? hit : 0u;
         });
-        avail = 16u | (can_move ? (((meta_step >> 8) & 15u) & ~blocked_dirs) : 0u);
+        avail = 16u | (can_move ? (meta_walk(meta_step) & ~blocked_dirs) : 0u);
     }
 }
 

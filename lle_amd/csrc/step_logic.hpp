@@ -105,8 +105,8 @@ LLE_HD uint64_t recolour_lay(uint64_t lay, const uint32_t (&colw)[NWORDS]) {
     uint64_t out = NL < MAX_CELL_LAYERS ? (lay & ~((1ull << (16 * NL)) - 1ull)) : 0ull;
 #pragma unroll
     for (int q = 0; q < NL; q++) {
-        uint32_t e = (uint32_t)(lay >> (16 * q)) & 0xFFFFu;
-        const uint32_t c = colour_get<NWORDS>(colw, (e >> 1) & 31u);
+        uint32_t e = lay_entry(lay, (int)q);
+        const uint32_t c = colour_get<NWORDS>(colw, lay_word(e));
         e = (e & LAY_VALID) ? ((e & 0x7FFu) | (c << 11)) : e;
         out |= (uint64_t)e << (16 * q);
     }
@@ -196,8 +196,8 @@ LLE_HD void chain_rest(uint32_t (&beams)[LM], uint32_t b, bool c, bool fill, uin
 template <int LM>
 LLE_HD void lasers_leave(uint32_t (&beams)[LM], uint64_t lay, bool doit, const MapView& mv) {
     for (uint32_t k = 0; k < mv.max_layers; k++) {  // uniform trip count; absent layers are predicated off
-        const uint32_t e = (uint32_t)(lay >> (16 * k)) & 0xFFFFu;
-        const uint32_t b = (e >> 1) & 31u, off = (e >> 6) & 31u;
+        const uint32_t e = lay_entry(lay, (int)k);
+        const uint32_t b = lay_word(e), off = lay_bit(e);
         const uint32_t m = beam_get<LM>(beams, b);
         const bool c = doit && (e & LAY_VALID) && !((m >> off) & 1u) && ((mv.enabled >> b) & 1u);
         beam_set_if<LM>(beams, b, c, m | (0xFFFFFFFFu << off));  // bits beyond the length are trimmed by canonicalise()
@@ -210,8 +210,8 @@ LLE_HD void lasers_leave(uint32_t (&beams)[LM], uint64_t lay, bool doit, const M
 template <int LM>
 LLE_HD void lasers_pre_enter(uint32_t (&beams)[LM], uint64_t lay, uint32_t agent, bool alive, const MapView& mv) {
     for (uint32_t k = 0; k < mv.max_layers; k++) {
-        const uint32_t e = (uint32_t)(lay >> (16 * k)) & 0xFFFFu;
-        const uint32_t b = (e >> 1) & 31u, off = (e >> 6) & 31u, colour = e >> 11;
+        const uint32_t e = lay_entry(lay, (int)k);
+        const uint32_t b = lay_word(e), off = lay_bit(e), colour = lay_colour(e);
         const bool c = alive && (e & LAY_VALID) && colour == agent && ((mv.enabled >> b) & 1u);
         const uint32_t m = beam_get<LM>(beams, b);
         beam_set_if<LM>(beams, b, c, m & ((1u << off) - 1u));
@@ -225,8 +225,8 @@ template <int LM>
 LLE_HD bool lasers_block(const uint32_t (&beams)[LM], uint64_t lay, uint32_t agent, const MapView& mv) {
     bool blocked = false;
     for (uint32_t k = 0; k < mv.max_layers; k++) {
-        const uint32_t e = (uint32_t)(lay >> (16 * k)) & 0xFFFFu;
-        const uint32_t b = (e >> 1) & 31u, off = (e >> 6) & 31u, colour = e >> 11;
+        const uint32_t e = lay_entry(lay, (int)k);
+        const uint32_t b = lay_word(e), off = lay_bit(e), colour = lay_colour(e);
         const uint32_t m = beam_get<LM>(beams, b);
         blocked |= (e & LAY_VALID) && ((m >> off) & 1u) && (colour != agent);
     }
@@ -242,8 +242,8 @@ LLE_HD bool enter_agent(Env<AM, LM>& s, uint32_t a, uint64_t lay, uint32_t meta,
     const uint32_t bit = 1u << a;
     const bool is_alive = (s.alive & bit) != 0;
     const bool blocked = lasers_block<LM>(s.beams, lay, a, mv);
-    const uint32_t kind = meta & 7u;
-    const uint32_t gbit = 1u << ((meta >> 3) & 31u);
+    const uint32_t kind = meta_kind(meta);
+    const uint32_t gbit = 1u << meta_index(meta);
     const bool inner = !blocked;
     const bool ev_exit = inner && kind == K_EXIT && !(s.arrived & bit);
     const bool ev_gem = inner && kind == K_GEM && !(s.gems & gbit);
@@ -290,7 +290,7 @@ LLE_HD void compute_avail(const Env<AM, LM>& s, const MapView& mv, const Cells<A
     for (int a = 0; a < AM; a++) {
         if (a >= mv.A) { avail[a] = 0; continue; }
         const bool can_move = ((s.alive >> a) & 1u) && !((s.arrived >> a) & 1u);
-        const uint32_t walk = (at.meta[a] >> 8) & 15u;  // `at`: table entries of the agents' current cells
+        const uint32_t walk = meta_walk(at.meta[a]);  // `at`: table entries of the agents' current cells
         uint32_t blocked = 0;
 #pragma unroll
         for (int o = 0; o < AM; o++) {
@@ -427,7 +427,7 @@ LLE_HD uint8_t set_state_env(Env<AM, LM>& s, const uint32_t (&req_pos)[AM], uint
 #pragma unroll
     for (int a = 0; a < AM; a++) {
         if (a >= mv.A) continue;
-        const uint32_t kind = mv.cell_meta[cell_of(req_pos[a], mv.W)] & 7u;
+        const uint32_t kind = meta_kind(mv.cell_meta[cell_of(req_pos[a], mv.W)]);
         if (kind == K_WALL || kind == K_SOURCE) unwalkable = true;
     }
     if (unwalkable) {

@@ -201,11 +201,44 @@ __host__ __device__
 #endif
 inline int agent_stride_of(int A, int L) { return (A <= 4 && L <= 4) ? 4 : ((A <= 8 && L <= 8) ? 8 : 16); }
 
-// ---- cell_lay entry helpers
+// ---- cell_lay / cell_meta field accessors: EVERY reader of the two cell tables goes through these (and the compiler packs through lay_pack /
+// meta_pack), so the widths of the beam-word, bit, colour and gem-index fields are written down once -- the limits of MAX_SOURCES / MAX_GEMS live here
 constexpr uint32_t LAY_VALID = 1u;
-inline constexpr uint32_t lay_pack(uint32_t beam, uint32_t off, uint32_t colour) {
-    return LAY_VALID | (beam << 1) | (off << 6) | (colour << 11);
+#if defined(__HIPCC__)
+#define LLE_TAB_FN __host__ __device__ inline constexpr
+#else
+#define LLE_TAB_FN inline constexpr
+#endif
+LLE_TAB_FN uint32_t lay_pack(uint32_t beam, uint32_t off, uint32_t colour) { return LAY_VALID | (beam << 1) | (off << 6) | (colour << 11); }
+LLE_TAB_FN uint32_t lay_entry(uint64_t lay, int k) { return (uint32_t)(lay >> (16 * k)) & 0xFFFFu; }  // layer k of a cell's u64 (0 = outermost)
+LLE_TAB_FN uint32_t lay_word(uint32_t e) { return (e >> 1) & 31u; }    // beam word of a 16-bit layer entry
+LLE_TAB_FN uint32_t lay_bit(uint32_t e) { return (e >> 6) & 31u; }     // bit of the cell within that word
+LLE_TAB_FN uint32_t lay_colour(uint32_t e) { return e >> 11; }         // colour (the entry's top five bits; NO_COLOUR: nobody's)
+LLE_TAB_FN uint32_t meta_pack(uint32_t kind, uint32_t index, uint32_t walk, uint32_t layers) { return kind | (index << 3) | (walk << 8) | (layers << 12); }
+LLE_TAB_FN uint32_t meta_kind(uint32_t m) { return m & 7u; }           // CellKind
+LLE_TAB_FN uint32_t meta_index(uint32_t m) { return (m >> 3) & 31u; }  // gem index of a gem cell / first beam word of a source cell
+LLE_TAB_FN uint32_t meta_walk(uint32_t m) { return (m >> 8) & 15u; }   // static walk mask (bit = Action N, S, E, W)
+LLE_TAB_FN uint32_t meta_layers(uint32_t m) { return (m >> 12) & 7u; } // number of laser layers of the cell
+// ---- dyn entries (u64; layout at the top of this file) and their laser references (10 bits: beam word | bit << 5)
+LLE_TAB_FN uint64_t dyn_pack(uint32_t byte_index, uint8_t base, uint32_t n_refs, uint32_t ref0, uint32_t ref1, uint32_t gem) {
+    return (uint64_t)byte_index | ((uint64_t)base << 20) | ((uint64_t)n_refs << 28) | ((uint64_t)ref0 << 30) | ((uint64_t)ref1 << 40) | ((uint64_t)gem << 50);
 }
+LLE_TAB_FN uint32_t dyn_index(uint64_t e) { return (uint32_t)e & 0xFFFFFu; }        // byte index in the (C, H, W) observation
+LLE_TAB_FN int32_t dyn_base(uint64_t e) { return (int32_t)(int8_t)(uint8_t)(e >> 20); }  // value when nothing is lit
+LLE_TAB_FN uint32_t dyn_refs(uint64_t e) { return (uint32_t)(e >> 28) & 3u; }        // number of laser references (0-2)
+LLE_TAB_FN uint32_t dyn_ref0(uint64_t e) { return (uint32_t)(e >> 30) & 0x3FFu; }
+LLE_TAB_FN uint32_t dyn_ref1(uint64_t e) { return (uint32_t)(e >> 40) & 0x3FFu; }
+LLE_TAB_FN uint32_t dyn_gem(uint64_t e) { return (uint32_t)(e >> 50) & 63u; }        // gem index, NO_GEM: none
+LLE_TAB_FN uint32_t ref_pack(uint32_t word, uint32_t bit) { return word | (bit << 5); }
+LLE_TAB_FN uint32_t ref_word(uint32_t r) { return r & 31u; }
+LLE_TAB_FN uint32_t ref_bit(uint32_t r) { return r >> 5; }
+LLE_TAB_FN uint32_t gem_bit(uint32_t gem) { return gem & 31u; }                      // bit of a gem in the record's ~gems word
+// ---- elems (per-environment sources; u32: cell | beam word or gem index << 16 | bit << 21 | type << 26)
+LLE_TAB_FN uint32_t elem_pack(uint32_t cell, uint32_t index, uint32_t bit, uint32_t type) { return cell | (index << 16) | (bit << 21) | (type << 26); }
+LLE_TAB_FN uint32_t elem_cell(uint32_t e) { return e & 0xFFFFu; }
+LLE_TAB_FN uint32_t elem_index(uint32_t e) { return (e >> 16) & 31u; }
+LLE_TAB_FN uint32_t elem_bit(uint32_t e) { return (e >> 21) & 31u; }
+LLE_TAB_FN uint32_t elem_type(uint32_t e) { return (e >> 26) & 3u; }
 
 // ---- per-env error codes (mirror include/lle_hip.h)
 constexpr uint8_t ENV_OK = 0;

@@ -172,7 +172,7 @@ static void run(hs_batch* b, int mode, uint32_t flags, uint64_t seed, uint64_t t
                     // `avail` is the cached list of the reference (world.rs:444-453).  It can only disagree with the
                     // static walk mask after a failed set_state left it stale (world.rs:588-594 returns before
                     // recomputing it); the reference would then index out of the grid and panic, we refuse the action.
-                    const uint32_t walk = ((cur.meta[a] >> 8) & 15u) | 16u;
+                    const uint32_t walk = meta_walk(cur.meta[a]) | 16u;
                     if (act[a] > 4u || !((avail[a] >> act[a]) & 1u) || !((walk >> act[a]) & 1u)) err = (uint32_t)a + 1u;
                 }
             }
