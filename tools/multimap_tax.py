@@ -1,5 +1,7 @@
 """Where the multi-map tax of small blocks comes from (config 5's shape, 65 536 envs): one map at four and at two wavefronts per workgroup, against
-1 024 x 64, 4 096 x 16 distinct maps.  us per step (HIP events)."""
+1 024 x 64, 4 096 x 16 distinct maps.  us per step (HIP events).
+(Its "copies of ONE map" rows are distinct memory like distinct maps, so they do NOT separate the table reads from the launch shape -- the comparison that does
+is in profiles/r05_multi_map.md section 1: a build in which every workgroup reads map 0's tables.)"""
 import os, sys
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
 import torch
