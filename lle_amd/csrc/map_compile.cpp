@@ -462,7 +462,7 @@ void Map::compile() {
                 uint8_t k = kind[ni * W + nj];
                 if (k != K_WALL && k != K_SOURCE) walk |= 1u << d;
             }
-            uint32_t gi = gem_index[c] >= 0 ? (uint32_t)gem_index[c] : 31u;
+            uint32_t gi = gem_index[c] >= 0 ? (uint32_t)gem_index[c] : NO_INDEX;
             if (kind[c] == K_SOURCE)  // the field holds the (first) beam word of a source cell (read by the partial observer: its colour)
                 for (const Source& src : sources)
                     if (src.pos.i == i && src.pos.j == j) gi = (uint32_t)source_word[(size_t)src.laser_id];

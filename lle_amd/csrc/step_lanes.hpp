@@ -213,7 +213,7 @@ LLE_LANE_FN void step_lanes(const uint64_t* cell_lay, const uint32_t* cell_meta,
         const uint32_t mn = cell_meta[new_cell];
         meta_new = mn;
         kind = meta_kind(mn);
-        gbit = 1u << meta_index(mn);
+        gbit = 1u << gem_bit(meta_index(mn));  // (cells without a gem carry NO_INDEX: the shift stays defined, the bit unused)
         lay_from = (uint64_t)lay_cur;  // pass 1 leaves the old cells, later passes the new ones
     }
 

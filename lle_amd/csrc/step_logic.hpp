@@ -243,7 +243,7 @@ LLE_HD bool enter_agent(Env<AM, LM>& s, uint32_t a, uint64_t lay, uint32_t meta,
     const bool is_alive = (s.alive & bit) != 0;
     const bool blocked = lasers_block<LM>(s.beams, lay, a, mv);
     const uint32_t kind = meta_kind(meta);
-    const uint32_t gbit = 1u << meta_index(meta);
+    const uint32_t gbit = 1u << gem_bit(meta_index(meta));  // (cells without a gem carry NO_INDEX: the shift stays defined, the bit unused)
     const bool inner = !blocked;
     const bool ev_exit = inner && kind == K_EXIT && !(s.arrived & bit);
     const bool ev_gem = inner && kind == K_GEM && !(s.gems & gbit);

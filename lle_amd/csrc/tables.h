@@ -16,20 +16,22 @@
 //                       reference src/core/parsing/world_config.rs:223-247), 16 bits each:
 //                         bit 0 valid | bits 1-5 beam word | bits 6-10 bit within the word | bits 11-15 colour
 //                       colour 31 = "no agent has this colour" (reference colours >= n_agents are legal, Q5)
-//   cell_meta[HW] u32 : bits 0-2 kind | bits 3-7 gem index | bits 8-11 static walk mask (bit = Action N,S,E,W:
+//   cell_meta[HW] u32 : bits 0-2 kind | bits 3-8 gem index (source cells: first beam word) | bits 9-12 static walk mask (bit = Action N,S,E,W:
 //                       neighbour in bounds and not Wall/LaserSource, reference world.rs:351-356, tile.rs:63-73)
-//                       | bits 12-14 number of layers
+//                       | bits 13-15 number of layers   (accessors: meta_*.  Since the end of round 5 the gem-index fields and the laser references of
+//                       cell_meta, dyn and elems are wide enough for 64 gems / beam words; the layer entries of cell_lay above still carry 5-bit
+//                       words, and the state's masks are u32: NOTEBOOK.md section 10 has the rest of the work list)
 //   dyn      [D]  u64 : the observation bytes that depend on dynamic state other than agent positions:
 //                         bits 0-19 byte index in the (C,H,W) int8 observation | bits 20-27 base value (int8)
-//                         bits 28-29 number of laser refs (0-2) | bits 30-39 ref0 (beam:5, offset:5)
-//                         bits 40-49 ref1 | bits 50-55 gem index (63 = none)
+//                         bits 28-29 number of laser refs (0-2) | bits 30-40 ref0 (beam word:6, offset:5)
+//                         bits 41-51 ref1 | bits 52-58 gem index (127 = none)
 //                       value = base; any ref on -> 1; gem present and not collected -> 1
 //                       (write order of reference python/lle/observations.py:216-266)
 //   template [obs_stride] i8 : static observation (walls, voids, exits, -1 at sources), dyn bytes at their base
 // Second section, used when every environment has its own source colours / enabled flags (lle_batch_set_sources):
 //   bare     [obs_stride] i8 : walls, voids, exits only
-//   elems    [E]  u32 : what depends on colours or dynamic state: bits 0-15 cell | 16-20 beam or gem index |
-//                       21-25 offset | 26-27 type (0 source: -1 on layer LASER_0 + colour; 1 laser tile exposed by
+//   elems    [E]  u32 : what depends on colours or dynamic state: bits 0-15 cell | 16-21 beam word or gem index |
+//                       22-26 offset | 27-28 type (0 source: -1 on layer LASER_0 + colour; 1 laser tile exposed by
 //                       World.lasers(): 1 on that layer when the beam bit is on; 2 gem: 1 on GEM when not collected)
 #pragma once
 #include <stdint.h>
@@ -43,7 +45,8 @@ constexpr int MAX_SOURCES = 32;
 constexpr int MAX_GEMS = 32;
 constexpr int MAX_BEAM_LEN = 32;      // bits of one beam WORD (a beam is a chain of words)
 constexpr int MAX_CELL_LAYERS = 4;
-constexpr uint32_t NO_GEM = 63;
+constexpr uint32_t NO_GEM = 127;       // dyn entries: no gem on this byte (7-bit field)
+constexpr uint32_t NO_INDEX = 63;      // cell_meta index field of a cell that is neither a gem nor a source
 // Window tables of the partial k x k observation (python/lle/observations.py:312-369) for k = 3, 5, 7, built on the host per map and window size
 // (map_compile.cpp Map::window_table) and uploaded when a batch first writes that window:
 //   sets [HW][2] u64 : per observer cell p two 64-bit sets over the k x k window centred at p, bit wi * k + wj = window cell (wi, wj) --
@@ -214,31 +217,31 @@ LLE_TAB_FN uint32_t lay_entry(uint64_t lay, int k) { return (uint32_t)(lay >> (1
 LLE_TAB_FN uint32_t lay_word(uint32_t e) { return (e >> 1) & 31u; }    // beam word of a 16-bit layer entry
 LLE_TAB_FN uint32_t lay_bit(uint32_t e) { return (e >> 6) & 31u; }     // bit of the cell within that word
 LLE_TAB_FN uint32_t lay_colour(uint32_t e) { return e >> 11; }         // colour (the entry's top five bits; NO_COLOUR: nobody's)
-LLE_TAB_FN uint32_t meta_pack(uint32_t kind, uint32_t index, uint32_t walk, uint32_t layers) { return kind | (index << 3) | (walk << 8) | (layers << 12); }
+LLE_TAB_FN uint32_t meta_pack(uint32_t kind, uint32_t index, uint32_t walk, uint32_t layers) { return kind | (index << 3) | (walk << 9) | (layers << 13); }  // 16 bits: the packed image keeps u16
 LLE_TAB_FN uint32_t meta_kind(uint32_t m) { return m & 7u; }           // CellKind
-LLE_TAB_FN uint32_t meta_index(uint32_t m) { return (m >> 3) & 31u; }  // gem index of a gem cell / first beam word of a source cell
-LLE_TAB_FN uint32_t meta_walk(uint32_t m) { return (m >> 8) & 15u; }   // static walk mask (bit = Action N, S, E, W)
-LLE_TAB_FN uint32_t meta_layers(uint32_t m) { return (m >> 12) & 7u; } // number of laser layers of the cell
-// ---- dyn entries (u64; layout at the top of this file) and their laser references (10 bits: beam word | bit << 5)
+LLE_TAB_FN uint32_t meta_index(uint32_t m) { return (m >> 3) & 63u; }  // gem index of a gem cell / first beam word of a source cell (6 bits: room for 64 of either)
+LLE_TAB_FN uint32_t meta_walk(uint32_t m) { return (m >> 9) & 15u; }   // static walk mask (bit = Action N, S, E, W)
+LLE_TAB_FN uint32_t meta_layers(uint32_t m) { return (m >> 13) & 7u; } // number of laser layers of the cell
+// ---- dyn entries (u64; layout at the top of this file) and their laser references (11 bits: beam word | bit << 6)
 LLE_TAB_FN uint64_t dyn_pack(uint32_t byte_index, uint8_t base, uint32_t n_refs, uint32_t ref0, uint32_t ref1, uint32_t gem) {
-    return (uint64_t)byte_index | ((uint64_t)base << 20) | ((uint64_t)n_refs << 28) | ((uint64_t)ref0 << 30) | ((uint64_t)ref1 << 40) | ((uint64_t)gem << 50);
+    return (uint64_t)byte_index | ((uint64_t)base << 20) | ((uint64_t)n_refs << 28) | ((uint64_t)ref0 << 30) | ((uint64_t)ref1 << 41) | ((uint64_t)gem << 52);
 }
 LLE_TAB_FN uint32_t dyn_index(uint64_t e) { return (uint32_t)e & 0xFFFFFu; }        // byte index in the (C, H, W) observation
 LLE_TAB_FN int32_t dyn_base(uint64_t e) { return (int32_t)(int8_t)(uint8_t)(e >> 20); }  // value when nothing is lit
 LLE_TAB_FN uint32_t dyn_refs(uint64_t e) { return (uint32_t)(e >> 28) & 3u; }        // number of laser references (0-2)
-LLE_TAB_FN uint32_t dyn_ref0(uint64_t e) { return (uint32_t)(e >> 30) & 0x3FFu; }
-LLE_TAB_FN uint32_t dyn_ref1(uint64_t e) { return (uint32_t)(e >> 40) & 0x3FFu; }
-LLE_TAB_FN uint32_t dyn_gem(uint64_t e) { return (uint32_t)(e >> 50) & 63u; }        // gem index, NO_GEM: none
-LLE_TAB_FN uint32_t ref_pack(uint32_t word, uint32_t bit) { return word | (bit << 5); }
-LLE_TAB_FN uint32_t ref_word(uint32_t r) { return r & 31u; }
-LLE_TAB_FN uint32_t ref_bit(uint32_t r) { return r >> 5; }
+LLE_TAB_FN uint32_t dyn_ref0(uint64_t e) { return (uint32_t)(e >> 30) & 0x7FFu; }
+LLE_TAB_FN uint32_t dyn_ref1(uint64_t e) { return (uint32_t)(e >> 41) & 0x7FFu; }
+LLE_TAB_FN uint32_t dyn_gem(uint64_t e) { return (uint32_t)(e >> 52) & 127u; }       // gem index, NO_GEM: none
+LLE_TAB_FN uint32_t ref_pack(uint32_t word, uint32_t bit) { return word | (bit << 6); }   // 11 bits: beam word 6 | bit 5
+LLE_TAB_FN uint32_t ref_word(uint32_t r) { return r & 63u; }
+LLE_TAB_FN uint32_t ref_bit(uint32_t r) { return r >> 6; }
 LLE_TAB_FN uint32_t gem_bit(uint32_t gem) { return gem & 31u; }                      // bit of a gem in the record's ~gems word
-// ---- elems (per-environment sources; u32: cell | beam word or gem index << 16 | bit << 21 | type << 26)
-LLE_TAB_FN uint32_t elem_pack(uint32_t cell, uint32_t index, uint32_t bit, uint32_t type) { return cell | (index << 16) | (bit << 21) | (type << 26); }
+// ---- elems (per-environment sources; u32: cell | beam word or gem index << 16 | bit << 22 | type << 27)
+LLE_TAB_FN uint32_t elem_pack(uint32_t cell, uint32_t index, uint32_t bit, uint32_t type) { return cell | (index << 16) | (bit << 22) | (type << 27); }
 LLE_TAB_FN uint32_t elem_cell(uint32_t e) { return e & 0xFFFFu; }
-LLE_TAB_FN uint32_t elem_index(uint32_t e) { return (e >> 16) & 31u; }
-LLE_TAB_FN uint32_t elem_bit(uint32_t e) { return (e >> 21) & 31u; }
-LLE_TAB_FN uint32_t elem_type(uint32_t e) { return (e >> 26) & 3u; }
+LLE_TAB_FN uint32_t elem_index(uint32_t e) { return (e >> 16) & 63u; }
+LLE_TAB_FN uint32_t elem_bit(uint32_t e) { return (e >> 22) & 31u; }
+LLE_TAB_FN uint32_t elem_type(uint32_t e) { return (e >> 27) & 3u; }
 
 // ---- per-env error codes (mirror include/lle_hip.h)
 constexpr uint8_t ENV_OK = 0;

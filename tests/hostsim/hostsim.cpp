@@ -258,7 +258,7 @@ static void run(hs_batch* b, int mode, uint32_t flags, uint64_t seed, uint64_t t
         if (b->per_env) {  // same element evaluation as write_observations_env (obs_stream.hpp)
             std::vector<int8_t> row(bare, bare + hdr->obs_stride);
             for (uint32_t d = 0; d < hdr->n_elems; d++) {
-                const uint32_t e = elems[d], cell = e & 0xFFFFu, i5 = (e >> 16) & 31u, off = (e >> 21) & 31u, type = (e >> 26) & 3u;
+                const uint32_t e = elems[d], cell = elem_cell(e), i5 = elem_index(e), off = elem_bit(e), type = elem_type(e);
                 const uint32_t colour = b->src_colour[env * 32 + i5];
                 if (type == ELEM_SOURCE) row[((uint32_t)A + colour) * hdr->HW + cell] = -1;
                 else if (type == ELEM_TILE) { if ((s.beams[i5] >> off) & 1u) row[((uint32_t)A + colour) * hdr->HW + cell] = 1; }
@@ -270,13 +270,13 @@ static void run(hs_batch* b, int mode, uint32_t flags, uint64_t seed, uint64_t t
         }
         for (uint32_t d = 0; d < hdr->D; d++) {
             const uint64_t e = dyn[d];
-            const uint32_t idx = (uint32_t)e & 0xFFFFFu;
-            int32_t v = (int8_t)(uint8_t)(e >> 20);
-            const uint32_t n_refs = (uint32_t)(e >> 28) & 3u;
-            const uint32_t r0 = (uint32_t)(e >> 30) & 0x3FFu, r1 = (uint32_t)(e >> 40) & 0x3FFu;
-            const uint32_t gem = (uint32_t)(e >> 50) & 63u;
-            if (n_refs >= 1 && ((s.beams[r0 & 31u] >> (r0 >> 5)) & 1u)) v = 1;
-            if (n_refs >= 2 && ((s.beams[r1 & 31u] >> (r1 >> 5)) & 1u)) v = 1;
+            const uint32_t idx = dyn_index(e);
+            int32_t v = dyn_base(e);
+            const uint32_t n_refs = dyn_refs(e);
+            const uint32_t r0 = dyn_ref0(e), r1 = dyn_ref1(e);
+            const uint32_t gem = dyn_gem(e);
+            if (n_refs >= 1 && ((s.beams[ref_word(r0)] >> ref_bit(r0)) & 1u)) v = 1;
+            if (n_refs >= 2 && ((s.beams[ref_word(r1)] >> ref_bit(r1)) & 1u)) v = 1;
             if (gem != NO_GEM && !((s.gems >> gem) & 1u)) v = 1;
             tmpl[idx] = (int8_t)v;
         }
@@ -397,13 +397,13 @@ static void view_rows(hs_batch* b, int kind, int param, int8_t* out, int64_t env
         std::vector<int8_t> row(blob.data() + v.off_template, blob.data() + v.off_template + v.obs_bytes);
         for (uint32_t d = 0; d < v.D; d++) {  // same evaluation as write_observations (obs_stream.hpp)
             const uint64_t e = dyn[d];
-            const uint32_t refs = (uint32_t)(e >> 28) & 3u, gem = (uint32_t)(e >> 50) & 63u;
-            const uint32_t r0 = (uint32_t)(e >> 30) & 0x3FFu, r1 = (uint32_t)(e >> 40) & 0x3FFu;
+            const uint32_t refs = dyn_refs(e), gem = dyn_gem(e);
+            const uint32_t r0 = dyn_ref0(e), r1 = dyn_ref1(e);
             uint32_t lit = 0;
-            if (refs >= 1) lit |= (b->beams[env * (L ? L : 1) + (r0 & 31u)] >> (r0 >> 5)) & 1u;
-            if (refs >= 2) lit |= (b->beams[env * (L ? L : 1) + (r1 & 31u)] >> (r1 >> 5)) & 1u;
+            if (refs >= 1) lit |= (b->beams[env * (L ? L : 1) + ref_word(r0)] >> ref_bit(r0)) & 1u;
+            if (refs >= 2) lit |= (b->beams[env * (L ? L : 1) + ref_word(r1)] >> ref_bit(r1)) & 1u;
             if (gem != NO_GEM) lit |= (~b->gems[env] >> gem) & 1u;
-            row[(uint32_t)e & 0xFFFFFu] = (int8_t)(lit ? 1 : (int32_t)(int8_t)(uint8_t)(e >> 20));
+            row[dyn_index(e)] = (int8_t)(lit ? 1 : dyn_base(e));
         }
         for (int a = 0; a < A; a++) row[(uint32_t)v.agent_layer[a] * v.HW + cell_of(b->pos[env * A + a], (int)v.W)] = 1;
         std::memcpy(out + env * env_pitch, row.data(), v.obs_bytes);
